@@ -1,0 +1,137 @@
+/*
+ * lepton_mi355x.h -- C ABI of liblepton_mi355x.so, the MI355X-native drop-in for Lepton's
+ * arithmetic-coding hot path (the code behind BaseEncoder::encode_chunk / BaseDecoder::decode_chunk,
+ * src/lepton/base_coders.hh:26-65 of dropbox/lepton).  Plain pointers and sizes only.
+ *
+ * Layers, bottom up:
+ *   1. lep_gpu_*        the hot path itself: batches of (image x thread-segment) work items coded by
+ *                        HIP kernels on gfx950.  Replaces VP8ComponentEncoder::vp8_full_encoder's
+ *                        per-segment loop (src/lepton/vp8_encoder.cc:239-445, 460-519) and
+ *                        VP8ComponentDecoder::decode_chunk / LeptonCodec::decode_row
+ *                        (src/lepton/vp8_decoder.cc:387-490, src/lepton/lepton_codec.cc:7-47,119-309).
+ *   2. lep_jpeg_* / lep_file_*   host-side callers either side of the hot path (JPEG <-> coefficient
+ *                        frames, .lep container); what src/lepton/jpgcoder.cc + recoder.cc do.
+ *   3. lep_compress / lep_decompress   whole-file convenience = `lepton in.jpg out.lep` and back.
+ *
+ * Return values are the reference's process exit codes (src/vp8/util/memory.hh:13-40); 0 = SUCCESS.
+ * There is NO CPU fallback: every lep_gpu_* entry point fails with LEP_GPU_ERROR when no gfx950
+ * device or kernel image is available.
+ */
+#ifndef LEPTON_MI355X_H
+#define LEPTON_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    LEP_SUCCESS = 0, LEP_ASSERTION_FAILURE = 1, LEP_CODING_ERROR = 2, LEP_SHORT_READ = 3,
+    LEP_UNSUPPORTED_4_COLORS = 4, LEP_COEFFICIENT_OUT_OF_RANGE = 6, LEP_STREAM_INCONSISTENT = 7,
+    LEP_PROGRESSIVE_UNSUPPORTED = 8, LEP_SAMPLING_BEYOND_TWO_UNSUPPORTED = 10,
+    LEP_THREADING_PARTIAL_MCU = 12, LEP_VERSION_UNSUPPORTED = 13, LEP_OS_ERROR = 33,
+    LEP_UNSUPPORTED_JPEG = 38, LEP_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 39,
+    LEP_BUFFER_TOO_SMALL = 100, LEP_GPU_ERROR = 120
+};
+
+#define LEP_MAX_COMPONENTS 3   /* default reference build: ColorChannel::NumBlockTypes == 3 */
+#define LEP_MAX_SEGMENTS 16    /* MuxReader::MAX_STREAM_ID, src/io/MuxReader.hh:201 */
+
+/* One image's coefficient frame: what UncompressedComponents exposes to encode_chunk
+ * (src/lepton/uncompressed_components.hh:24-302; consumed at src/lepton/vp8_encoder.cc:521-548). */
+typedef struct lep_image_desc {
+    int32_t ncomp;                                   /* get_num_components() */
+    int32_t mcu_rows;                                /* get_mcu_count_vertical() */
+    int32_t width_blocks[LEP_MAX_COMPONENTS];        /* block_width(c) */
+    int32_t height_blocks[LEP_MAX_COMPONENTS];       /* full_component_nosync(c).original_height() */
+    int32_t coded_blocks[LEP_MAX_COMPONENTS];        /* component_size_in_blocks(c) (truncated files) */
+    int32_t coded_height[LEP_MAX_COMPONENTS];        /* get_max_coded_heights()[c] */
+    uint16_t qtable_zigzag[LEP_MAX_COMPONENTS][64];  /* get_quantization_tables(c), zig-zag order */
+    /* per component: width*height AlignedBlocks = 64 x int16 in "aligned" order
+     * (src/vp8/util/aligned_block.hh:32-44).  HOST pointers for lep_gpu_*_host, DEVICE pointers
+     * for lep_gpu_*_device. */
+    int16_t *blocks[LEP_MAX_COMPONENTS];
+} lep_image_desc;
+
+/* One thread segment of one image = one independent arithmetic-coded stream = one wavefront.
+ * luma_y_start/end come from ThreadHandoff (src/lepton/thread_handoff.hh:8-39). */
+typedef struct lep_segment {
+    int32_t image;          /* index into the images[] array of the call */
+    int32_t luma_y_start;
+    int32_t luma_y_end;
+    int32_t is_last;        /* last segment of its image runs to the end (vp8_encoder.cc:280) */
+} lep_segment;
+
+typedef struct lep_bytes { uint8_t *data; size_t len; size_t cap; } lep_bytes;
+
+/* ---- layer 1: the GPU hot path ------------------------------------------------------------- */
+typedef struct lep_gpu lep_gpu;   /* owns a HIP stream, per-segment models and staging buffers */
+
+int lep_gpu_create(int device, lep_gpu **out);
+void lep_gpu_destroy(lep_gpu *g);
+const char *lep_gpu_last_error(lep_gpu *g);
+
+/* Encode nseg segments of nimg images.  Host variant: blocks[] are host pointers, copied to HBM,
+ * coded, streams copied back into out[i] (out[i].data with capacity out[i].cap; len is set).
+ * status[i] receives the per-segment exit code. */
+int lep_gpu_encode_host(lep_gpu *g, const lep_image_desc *images, int nimg, const lep_segment *segs, int nseg,
+                        lep_bytes *out, int32_t *status);
+/* Decode: in[i] are the de-multiplexed streams; coefficient rows of each segment are written into
+ * images[].blocks (host). */
+int lep_gpu_decode_host(lep_gpu *g, const lep_image_desc *images, int nimg, const lep_segment *segs, int nseg,
+                        const lep_bytes *in, int32_t *status);
+
+/* Device-resident variants (inputs already in HBM; nothing crosses PCIe inside the call):
+ * images[].blocks are device pointers; streams live in one device arena: segment i uses
+ * [stream_offsets[i], stream_offsets[i+1]) of d_streams; d_stream_len[i] (device, uint32) is
+ * written by encode and read by decode.  hip_stream may be NULL (library stream).
+ * The calls enqueue work and return; lep_gpu_sync waits.  kernel_ms (may be NULL) receives the
+ * HIP-event time of the kernel(s) when sync'd via lep_gpu_last_kernel_ms. */
+int lep_gpu_encode_device(lep_gpu *g, const lep_image_desc *images, int nimg, const lep_segment *segs, int nseg,
+                          uint8_t *d_streams, const uint64_t *stream_offsets, uint32_t *d_stream_len,
+                          int32_t *d_status, void *hip_stream);
+int lep_gpu_decode_device(lep_gpu *g, const lep_image_desc *images, int nimg, const lep_segment *segs, int nseg,
+                          const uint8_t *d_streams, const uint64_t *stream_offsets, const uint32_t *d_stream_len,
+                          int32_t *d_status, void *hip_stream);
+int lep_gpu_sync(lep_gpu *g);
+double lep_gpu_last_kernel_ms(lep_gpu *g);   /* HIP-event duration of the most recent encode/decode kernel */
+/* plain device memory helpers so non-torch callers need no HIP binding */
+int lep_gpu_malloc(lep_gpu *g, size_t bytes, void **dptr);
+int lep_gpu_free(lep_gpu *g, void *dptr);
+int lep_gpu_memcpy_h2d(lep_gpu *g, void *dst, const void *src, size_t bytes);
+int lep_gpu_memcpy_d2h(lep_gpu *g, void *dst, const void *src, size_t bytes);
+int lep_gpu_memset(lep_gpu *g, void *dst, int value, size_t bytes);
+
+/* ---- layer 2: host-side callers of the hot path --------------------------------------------- */
+typedef struct lep_jpeg lep_jpeg;   /* a parsed JPEG: header bytes, coefficient frame, row hand-offs */
+typedef struct lep_file lep_file;   /* a parsed .lep: header sections, hand-offs, de-muxed streams */
+
+/* JPEG -> coefficient frame (read_jpeg + decode_jpeg, src/lepton/jpgcoder.cc:2269-2466, 2799-3302) */
+int lep_jpeg_open(const uint8_t *jpg, size_t len, int allow_progressive, lep_jpeg **out);
+void lep_jpeg_close(lep_jpeg *j);
+int lep_jpeg_describe(const lep_jpeg *j, lep_image_desc *desc);          /* host pointers into j */
+/* segment choice of write_ujpg (src/lepton/jpgcoder.cc:3856-3934); returns count, fills segs */
+int lep_jpeg_plan(const lep_jpeg *j, int max_threads, lep_segment *segs, int image_index);
+/* whole .lep file from the per-segment streams (header + mux + trailer) */
+int lep_jpeg_write_lep(const lep_jpeg *j, int max_threads, const lep_bytes *streams, int nstreams, lep_bytes *out);
+
+/* .lep -> streams + frame geometry (read_ujpg, src/lepton/jpgcoder.cc:4117-4362) */
+int lep_file_open(const uint8_t *lepdata, size_t len, lep_file **out);
+void lep_file_close(lep_file *f);
+int lep_file_describe(lep_file *f, lep_image_desc *desc);                /* allocates zeroed host frame */
+int lep_file_segments(const lep_file *f, lep_segment *segs, lep_bytes *streams, int image_index);
+uint32_t lep_file_jpeg_size(const lep_file *f);
+/* coefficient frame -> original JPEG bytes (recode_baseline_jpeg, src/lepton/recoder.cc:694-889) */
+int lep_file_recode(lep_file *f, lep_bytes *out);
+
+/* ---- layer 3: whole files ------------------------------------------------------------------- */
+int lep_compress(lep_gpu *g, const uint8_t *jpg, size_t len, lep_bytes *out);
+int lep_decompress(lep_gpu *g, const uint8_t *lepdata, size_t len, lep_bytes *out);
+
+void lep_free(void *p);   /* frees lep_bytes.data returned by this library */
+const char *lep_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,110 @@
+"""ctypes binding of include/lepton_mi355x.h (the C ABI of liblepton_mi355x.so).
+
+This is the reference-side binding a maintainer would write for a Python caller; the C++ adapter that
+plugs the same ABI behind BaseEncoder/BaseDecoder (src/lepton/base_coders.hh:26-65) is shown in
+INTEGRATION.md.  Nothing here computes: every function forwards to the shared library, and loading
+fails loudly if the library has not been built (``python -c 'import __graft_entry__ as g; g.build()'``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblepton_mi355x.so")
+
+MAX_COMPONENTS = 3
+MAX_SEGMENTS = 16
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [
+        ("ncomp", C.c_int32),
+        ("mcu_rows", C.c_int32),
+        ("width_blocks", C.c_int32 * MAX_COMPONENTS),
+        ("height_blocks", C.c_int32 * MAX_COMPONENTS),
+        ("coded_blocks", C.c_int32 * MAX_COMPONENTS),
+        ("coded_height", C.c_int32 * MAX_COMPONENTS),
+        ("qtable_zigzag", (C.c_uint16 * 64) * MAX_COMPONENTS),
+        ("blocks", C.c_void_p * MAX_COMPONENTS),
+    ]
+
+    def nblocks(self, c):
+        return self.width_blocks[c] * self.height_blocks[c]
+
+    def total_blocks(self):
+        return sum(self.nblocks(c) for c in range(self.ncomp))
+
+
+class Segment(C.Structure):
+    _fields_ = [("image", C.c_int32), ("luma_y_start", C.c_int32), ("luma_y_end", C.c_int32), ("is_last", C.c_int32)]
+
+
+class Bytes(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("cap", C.c_size_t)]
+
+    def tobytes(self):
+        return C.string_at(self.data, self.len) if self.len else b""
+
+
+_lib = None
+
+
+def lib():
+    """Load liblepton_mi355x.so (built in-tree by __graft_entry__.build()); no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "liblepton_mi355x.so is not built (%s). Run `python -c \"import __graft_entry__ as g; g.build()\"`."
+                % LIB_PATH
+            )
+        L = C.CDLL(LIB_PATH)
+        P = C.POINTER
+        vp = C.c_void_p
+        L.lep_version.restype = C.c_char_p
+        L.lep_free.argtypes = [vp]
+        L.lep_free.restype = None
+        L.lep_jpeg_open.argtypes = [vp, C.c_size_t, C.c_int, P(vp)]
+        L.lep_jpeg_close.argtypes = [vp]
+        L.lep_jpeg_close.restype = None
+        L.lep_jpeg_describe.argtypes = [vp, P(ImageDesc)]
+        L.lep_jpeg_plan.argtypes = [vp, C.c_int, P(Segment), C.c_int]
+        L.lep_jpeg_write_lep.argtypes = [vp, C.c_int, P(Bytes), C.c_int, P(Bytes)]
+        L.lep_file_open.argtypes = [vp, C.c_size_t, P(vp)]
+        L.lep_file_close.argtypes = [vp]
+        L.lep_file_close.restype = None
+        L.lep_file_describe.argtypes = [vp, P(ImageDesc)]
+        L.lep_file_segments.argtypes = [vp, P(Segment), P(Bytes), C.c_int]
+        L.lep_file_jpeg_size.argtypes = [vp]
+        L.lep_file_jpeg_size.restype = C.c_uint32
+        L.lep_file_recode.argtypes = [vp, P(Bytes)]
+        L.lep_gpu_create.argtypes = [C.c_int, P(vp)]
+        L.lep_gpu_destroy.argtypes = [vp]
+        L.lep_gpu_destroy.restype = None
+        L.lep_gpu_last_error.argtypes = [vp]
+        L.lep_gpu_last_error.restype = C.c_char_p
+        L.lep_gpu_encode_host.argtypes = [vp, P(ImageDesc), C.c_int, P(Segment), C.c_int, P(Bytes), P(C.c_int32)]
+        L.lep_gpu_decode_host.argtypes = [vp, P(ImageDesc), C.c_int, P(Segment), C.c_int, P(Bytes), P(C.c_int32)]
+        L.lep_gpu_encode_device.argtypes = [vp, P(ImageDesc), C.c_int, P(Segment), C.c_int, vp, P(C.c_uint64), vp, vp, vp]
+        L.lep_gpu_decode_device.argtypes = [vp, P(ImageDesc), C.c_int, P(Segment), C.c_int, vp, P(C.c_uint64), vp, vp, vp]
+        L.lep_gpu_sync.argtypes = [vp]
+        L.lep_gpu_last_kernel_ms.argtypes = [vp]
+        L.lep_gpu_last_kernel_ms.restype = C.c_double
+        L.lep_gpu_malloc.argtypes = [vp, C.c_size_t, P(vp)]
+        L.lep_gpu_free.argtypes = [vp, vp]
+        L.lep_gpu_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+        L.lep_gpu_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        L.lep_gpu_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
+        L.lep_compress.argtypes = [vp, vp, C.c_size_t, P(Bytes)]
+        L.lep_decompress.argtypes = [vp, vp, C.c_size_t, P(Bytes)]
+        _lib = L
+    return _lib
+
+
+EXPORTS = [
+    "lep_gpu_create", "lep_gpu_destroy", "lep_gpu_last_error", "lep_gpu_encode_host", "lep_gpu_decode_host",
+    "lep_gpu_encode_device", "lep_gpu_decode_device", "lep_gpu_sync", "lep_gpu_last_kernel_ms", "lep_gpu_malloc",
+    "lep_gpu_free", "lep_gpu_memcpy_h2d", "lep_gpu_memcpy_d2h", "lep_gpu_memset", "lep_jpeg_open", "lep_jpeg_close",
+    "lep_jpeg_describe", "lep_jpeg_plan", "lep_jpeg_write_lep", "lep_file_open", "lep_file_close", "lep_file_describe",
+    "lep_file_segments", "lep_file_jpeg_size", "lep_file_recode", "lep_compress", "lep_decompress", "lep_free",
+    "lep_version",
+]

@@ -1,0 +1,112 @@
+// jpeg_bits.h -- MSB-first bit reader / writer over un-stuffed JPEG scan bytes, with the exact
+// end-of-data and position semantics of the reference's abitreader / abitwriter
+// (src/lepton/bitops.hh:66-362), because hand-off records (byte position, overhang bits) and the
+// handling of truncated files depend on them.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "jpeg_model.h"
+
+namespace lep {
+
+struct BitReader {
+    const uint8_t* data;
+    int size;
+    int next_byte = 0;     // first byte not yet loaded into `window`
+    int avail = 0;         // unread bits in `window` (right-aligned)
+    uint64_t window = 0;
+    bool eof = false;
+
+    BitReader(const uint8_t* d, int n) : data(d), size(n) {}
+
+    static inline uint64_t low_bits(uint64_t v, int n) { return n == 0 ? 0 : (v & (~0ULL >> (64 - n))); }
+
+    unsigned read(int nbits) {
+        if (eof || !nbits) return 0;
+        unsigned out;
+        if (nbits >= avail) {
+            int took = avail;
+            out = (unsigned)((low_bits(window, avail) << (nbits - took)) & ((1u << nbits) - 1));
+            int want = nbits - took;
+            window = took >= 64 ? 0 : window >> took;
+            avail = 0;
+            if (next_byte == size) { eof = true; return out; }
+            int nb = size - next_byte < 8 ? size - next_byte : 8;
+            uint64_t w = 0;
+            for (int i = 0; i < nb; ++i) w = (w << 8) | data[next_byte + i];
+            window = w;
+            next_byte += nb;
+            avail = nb * 8;
+            if (want) {
+                if (want <= avail) { out |= (unsigned)(low_bits(window, avail) >> (avail - want)); avail -= want; }
+                else { out |= (unsigned)window; window = 0; avail = 0; }
+            }
+        } else {
+            out = (unsigned)(low_bits(window, avail) >> (avail - nbits));
+            avail -= nbits;
+        }
+        return out;
+    }
+    // pad-bit pattern of the current partial byte (consumes it)
+    uint8_t unpad(uint8_t fillbit) {
+        if ((avail & 7) == 0 || eof) return fillbit;
+        int last = (int)read(1);
+        fillbit = (uint8_t)last;
+        int off = 1;
+        while (avail & 7) { last = (int)read(1); fillbit |= (uint8_t)(last << off); ++off; }
+        while (off < 7) { fillbit |= (uint8_t)(last << off); ++off; }
+        return fillbit;
+    }
+    // 1 + index of the byte holding the next unread bit
+    int getpos() const { return next_byte - 7 + ((64 - avail) >> 3); }
+    // bits already consumed from the current byte, and those bits (left-aligned)
+    void overhang(uint8_t* nbits, uint8_t* byte) const {
+        int rem = (64 - avail) & 7;
+        uint8_t cur = 0;
+        if (rem) {
+            // byte containing the next unread bit: it is the one whose low (8-rem) bits are still in window
+            int bit_index_from_low = avail - (8 - rem);   // shift that brings that byte to the bottom
+            cur = (uint8_t)(window >> bit_index_from_low);
+        }
+        *nbits = (uint8_t)rem;
+        *byte = (uint8_t)(cur & (uint8_t)(((1 << rem) - 1) << (8 - rem)));
+    }
+};
+
+inline int next_huffcode(BitReader& br, const HuffTable& t) {
+    int node = 0;
+    while (node < 256) {
+        node = br.read(1) == 1 ? t.r[node] : t.l[node];
+        if (node == 0) break;
+    }
+    return node - 256;
+}
+
+// MSB-first writer producing un-stuffed bytes; optional hard bound on produced bytes.
+struct BitWriter {
+    std::vector<uint8_t> bytes;
+    uint64_t acc = 0;   // pending bits, left-aligned
+    int nacc = 0;       // number of pending bits (< 8 after drain)
+    uint8_t fillbit = 1;
+
+    void put(unsigned val, int nbits) {
+        while (nbits > 0) {
+            int take = nbits > 32 ? 32 : nbits;
+            uint64_t v = (val >> (nbits - take)) & (take == 32 ? 0xffffffffull : ((1ull << take) - 1));
+            acc |= v << (64 - nacc - take);
+            nacc += take;
+            nbits -= take;
+            while (nacc >= 8) { bytes.push_back((uint8_t)(acc >> 56)); acc <<= 8; nacc -= 8; }
+        }
+    }
+    void pad(uint8_t pattern) {
+        int off = 1;
+        while (nacc & 7) { put((pattern & off) ? 1 : 0, 1); off <<= 1; }
+    }
+    void seed(uint8_t overhang_byte, int nbits) { bytes.clear(); acc = (uint64_t)overhang_byte << 56; nacc = nbits; }
+    uint8_t overhang_byte() const { return (uint8_t)(acc >> 56); }
+    int overhang_bits() const { return nacc; }
+};
+
+}  // namespace lep

@@ -1,0 +1,102 @@
+// jpeg_model.h -- host-side data model for one JPEG file split the way the reference splits it
+// (src/lepton/jpgcoder.cc:2269-2466 read_jpeg, :2799-3302 decode_jpeg): marker segments, the
+// un-stuffed entropy-coded bytes, trailing garbage, and the quantised DCT coefficients in the
+// reference's "aligned" block order (src/vp8/util/aligned_block.hh:32-44).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace lep {
+
+// exit codes = src/vp8/util/memory.hh:13-40 (the process exit status is the reference's error API)
+enum ExitCode : int {
+    EX_SUCCESS = 0, EX_ASSERTION_FAILURE = 1, EX_CODING_ERROR = 2, EX_SHORT_READ = 3,
+    EX_UNSUPPORTED_4_COLORS = 4, EX_THREAD_PROTOCOL_ERROR = 5, EX_COEFFICIENT_OUT_OF_RANGE = 6,
+    EX_STREAM_INCONSISTENT = 7, EX_PROGRESSIVE_UNSUPPORTED = 8, EX_FILE_NOT_FOUND = 9,
+    EX_SAMPLING_BEYOND_TWO_UNSUPPORTED = 10, EX_SAMPLING_BEYOND_FOUR_UNSUPPORTED = 11,
+    EX_THREADING_PARTIAL_MCU = 12, EX_VERSION_UNSUPPORTED = 13, EX_ONLY_GARBAGE_NO_JPEG = 14,
+    EX_OS_ERROR = 33, EX_HEADER_TOO_LARGE = 34, EX_BLOCK_OFFSET_OOM = 37,
+    EX_UNSUPPORTED_JPEG = 38, EX_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 39,
+    EX_INVALID_RESET_MARKER_FOUND = 40, EX_UNSUPPORTED_4_COLORS_B = 4,
+    EX_GPU_ERROR = 120,   // ours: HIP runtime failure (no reference equivalent)
+};
+
+// aligned index -> raster / zig-zag maps (aligned_block.hh:32-76)
+extern const uint8_t kAlignedToRaster[64];
+extern const uint8_t kZigzagToAligned[64];
+extern const uint8_t kZigzagToRaster[64];
+
+struct Component {
+    int jid = 0;      // component id from SOF
+    int hs = 0;       // horizontal sampling factor (reference name: sfv)
+    int vs = 0;       // vertical sampling factor   (reference name: sfh)
+    int qidx = 0;     // quantisation table index
+    int dc_tbl = 0, ac_tbl = 0;
+    int bch = 0, bcv = 0, bc = 0;   // blocks per row / column / total (MCU padded)
+    int nch = 0, ncv = 0;           // non-interleaved dimensions
+    int mbs = 0;                    // blocks per MCU
+};
+
+// src/lepton/thread_handoff.hh:8-39
+struct Handoff {
+    uint16_t luma_y_start = 0, luma_y_end = 0;
+    uint32_t segment_size = 0;
+    uint8_t overhang_byte = 0, num_overhang_bits = 0;
+    int16_t last_dc[4] = {0, 0, 0, 0};
+};
+
+struct HuffTable {
+    bool set = false;
+    uint16_t clen[256];
+    uint16_t cval[256];
+    uint16_t l[256], r[256];   // decoding tree, leaf = 256 + symbol
+    int max_eobrun = 0;
+};
+
+struct JpegFile {
+    // --- container split
+    std::vector<uint8_t> hdr;       // every marker segment after SOI (hdrdata)
+    std::vector<uint8_t> scan;      // entropy-coded bytes, FF00 un-stuffed, RSTn removed (huffdata)
+    std::vector<uint8_t> garbage;   // bytes from EOI on, empty if exactly FF D9 (grbgdata)
+    std::vector<std::pair<uint32_t, uint32_t>> scan_to_file;   // huff_input_offsets
+    std::vector<uint32_t> rst_cnt;  // RST markers seen per scan
+    std::vector<uint8_t> rst_err;   // wrongly placed RST markers at scan end, per scan
+    bool early_eof = false;
+    int padbit = -1;
+    uint32_t file_size = 0;
+    // --- frame
+    int width = 0, height = 0, ncomp = 0;
+    int jpegtype = 0;               // 1 sequential, 2 progressive
+    Component comp[4];
+    uint16_t qtables[4][64];        // zig-zag order, as stored
+    int hmax = 0, vmax = 0;
+    int mcuh = 0, mcuv = 0, mcuc = 0;   // MCUs per row / per column / total
+    int rsti = 0;
+    HuffTable htab[2][4];
+    bool progressive_needed = false;    // not a single interleaved sequential scan
+    // --- scan state (current SOS)
+    int cs_cmpc = 0, cs_cmp[4] = {0, 0, 0, 0}, cs_from = 0, cs_to = 0, cs_sah = 0, cs_sal = 0;
+    int scan_count = 0;
+    // --- coefficients
+    std::vector<int16_t> coef[4];       // bc * 64, aligned order
+    std::vector<Handoff> rows;          // one per MCU row + final
+    // truncation
+    int max_cmp = 0, max_bpos = 0, max_sah = 0, max_dpos[4] = {0, 0, 0, 0};
+    int trunc_bcv[4] = {0, 0, 0, 0}, trunc_bc[4] = {0, 0, 0, 0};
+    int warn = 0;                       // reference errorlevel 1
+    std::string error;
+};
+
+// Parses `data` (a whole JPEG file). Returns an ExitCode (0 = ok). allow_progressive mirrors
+// -allowprogressive (jpgcoder.cc:1090) -- without it, non-baseline files return
+// EX_PROGRESSIVE_UNSUPPORTED like the reference does.
+int parse_jpeg(const uint8_t* data, size_t size, bool allow_progressive, JpegFile* out);
+
+bool build_huff_table(const uint8_t* clen, size_t clen_avail, const uint8_t* cval, size_t cval_avail,
+                      HuffTable* t, bool strict);
+bool parse_segment(JpegFile* jf, uint8_t type, unsigned len, unsigned avail, const uint8_t* seg, bool strict);
+bool setup_frame(JpegFile* jf);
+
+}  // namespace lep

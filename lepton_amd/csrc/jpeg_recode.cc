@@ -1,0 +1,189 @@
+// jpeg_recode.cc -- coefficient frame -> the original JPEG bytes (sequential JPEGs): the host-side
+// consumer of the decode hot path.  Behaviour follows
+//   recode_baseline_jpeg   src/lepton/recoder.cc:694-889
+//   recode_physical_thread src/lepton/recoder.cc:560-652  (per-segment byte bounds)
+//   recode_row_range       src/lepton/recoder.cc:471-545
+//   recode_one_mcu_row     src/lepton/recoder.cc:316-412
+//   encode_block_seq       src/lepton/recoder.cc:245-314
+//   handle_initial_segments src/lepton/recoder.cc:414-460
+#include <algorithm>
+#include <cstring>
+
+#include "jpeg_bits.h"
+#include "lep_container.h"
+
+namespace lep {
+
+int next_mcupos(const JpegFile& jf, int* mcu, int* cmp, int* csc, int* sub, int* dpos, int* rstw, int cs_cmpc);
+int next_mcuposn(const JpegFile& jf, int cmp, int* dpos, int* rstw);
+
+namespace {
+
+struct BoundedOut {   // bounded_iostream / BoundedMemWriter: bytes past the bound are dropped but counted
+    std::vector<uint8_t> buf;
+    size_t bound = 0, attempted = 0;
+    void put(uint8_t b) { ++attempted; if (!bound || buf.size() < bound) buf.push_back(b); }
+    void write(const uint8_t* d, size_t n) { for (size_t i = 0; i < n; ++i) put(d[i]); }
+    bool exceeded() const { return bound && attempted > bound; }
+    bool reached() const { return bound && buf.size() >= bound; }
+};
+
+static inline int blen16(unsigned v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+static inline unsigned envli(int s, int v) { return (unsigned)((v > 0) ? v : (v - 1) + (1 << s)) & ((1u << s) - 1); }
+
+void encode_block(BitWriter& w, const HuffTable& dc, const HuffTable& ac, const int16_t* blk) {
+    int t = blk[0];
+    int s = blen16((unsigned)(t > 0 ? t : -t) & 0xffff);
+    w.put(dc.cval[s], dc.clen[s]);
+    w.put(envli(s, t), s);
+    int end = 63;
+    while (end && !blk[end]) --end;
+    int z = 0;
+    for (int b = 1; b <= end; ++b) {
+        t = blk[b];
+        if (!t) { ++z; continue; }
+        s = blen16((unsigned)(t > 0 ? t : -t) & 0xffff);
+        while (z & 0xf0) { w.put(ac.cval[0xF0], ac.clen[0xF0]); z -= 16; }
+        int hc = ((z & 0xf) << 4) + s;
+        w.put(ac.cval[hc & 255], ac.clen[hc & 255]);
+        w.put(envli(s, t), s);
+        z = 0;
+    }
+    if (end != 63) w.put(ac.cval[0], ac.clen[0]);
+}
+
+// move whole bytes from the bit writer to the output, stuffing 00 after FF
+void drain(BitWriter& w, BoundedOut& out) {
+    for (uint8_t b : w.bytes) { out.put(b); if (b == 0xFF) out.put(0); }
+    w.bytes.clear();
+}
+
+struct RowCoder {
+    LepFile& lf;
+    JpegFile& jf;
+    int ncomp;
+    RowCoder(LepFile& l) : lf(l), jf(l.jpeg), ncomp(l.jpeg.ncomp) {}
+
+    // Huffman-code one MCU row starting at MCU index `mcu`; false on error
+    void mcu_row(BitWriter& w, int mcu, BoundedOut& out, int16_t lastdc[4]) {
+        int cmp = jf.cs_cmp[0], csc = 0, sub = 0;
+        const int mcumul = jf.comp[cmp].hs * jf.comp[cmp].vs;
+        int dpos = mcu * mcumul;
+        int rstw = jf.rsti ? jf.rsti - mcu % jf.rsti : 0;
+        unsigned cum_rst = rstw ? (unsigned)(mcu / jf.rsti) : 0;
+        bool end_of_row = false;
+        int16_t blk[64];
+        while (!end_of_row) {
+            int sta = 0;
+            while (sta == 0) {
+                const int16_t* src = jf.coef[cmp].data() + (size_t)dpos * 64;
+                for (int b = 0; b < 64; ++b) blk[b] = src[kZigzagToAligned[b]];
+                int16_t dc = blk[0];
+                blk[0] = (int16_t)(blk[0] - lastdc[cmp]);
+                lastdc[cmp] = dc;
+                const Component& k = jf.comp[cmp];
+                encode_block(w, jf.htab[0][k.dc_tbl], jf.htab[1][k.ac_tbl], blk);
+                int old_mcu = mcu;
+                if (ncomp == 1) { sta = next_mcuposn(jf, cmp, &dpos, &rstw); mcu = dpos / mcumul; }
+                else sta = next_mcupos(jf, &mcu, &cmp, &csc, &sub, &dpos, &rstw, ncomp);
+                drain(w, out);
+                if (out.exceeded()) sta = 2;
+                if (old_mcu != mcu && mcu % jf.mcuh == 0) {
+                    end_of_row = true;
+                    if (sta == 0) return;
+                }
+            }
+            w.pad((uint8_t)jf.padbit);
+            drain(w, out);
+            if (sta == 2) break;
+            if (sta == 1 && jf.rsti > 0) {
+                if (jf.rst_cnt.empty() || !lf.rst_cnt_set || cum_rst < jf.rst_cnt[0]) {
+                    out.put(0xFF);
+                    out.put((uint8_t)(0xD0 + (cum_rst & 7)));
+                    ++cum_rst;
+                }
+                rstw = jf.rsti;
+                lastdc[0] = lastdc[1] = lastdc[2] = lastdc[3] = 0;
+            }
+        }
+    }
+};
+
+}  // namespace
+
+int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
+    JpegFile& jf = lf->jpeg;
+    if (lf->flag != 'Z') return EX_PROGRESSIVE_UNSUPPORTED;   // progressive re-coding: jpeg_progressive.cc
+    const size_t max_file_size = lf->jpeg_size;
+    if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
+    BoundedOut out;
+    out.bound = max_file_size - jf.garbage.size();
+
+    // 1. header segments up to and including the first SOS (parsing DHT / DRI / SOS on the way)
+    size_t pos = 0;
+    const uint8_t* h = jf.hdr.data();
+    const size_t hdrs = jf.hdr.size();
+    for (;;) {
+        if (pos + 3 >= hdrs) return EX_CODING_ERROR;
+        if (h[pos] != 0xff) return EX_CODING_ERROR;
+        uint8_t type = h[pos + 1];
+        unsigned len = 2 + ((unsigned)h[pos + 2] << 8) + h[pos + 3];
+        if (type == 0xC4 || type == 0xDD || type == 0xDA)
+            if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - pos), h + pos, false)) return EX_CODING_ERROR;
+        pos += len;
+        if (type == 0xDA) break;
+    }
+    if (lf->has_prefix) out.write(lf->prefix_garbage.data(), lf->prefix_garbage.size());
+    if (lf->embedded || !lf->has_prefix) {
+        out.put(0xFF); out.put(0xD8);
+        out.write(h, std::min(pos, hdrs));
+    }
+
+    // 2. the scan, segment by segment
+    RowCoder rc(*lf);
+    const int luma_mul = jf.comp[0].bcv / jf.mcuv;
+    Handoff carry;
+    for (size_t s = 0; s < lf->segs.size(); ++s) {
+        Handoff th = lf->segs[s];
+        bool legacy = th.num_overhang_bits == 0xff;
+        if (legacy) {
+            if (s == 0) carry.num_overhang_bits = 0;
+            th.overhang_byte = carry.overhang_byte;
+            th.num_overhang_bits = carry.num_overhang_bits;
+            memcpy(th.last_dc, carry.last_dc, sizeof th.last_dc);
+        }
+        BoundedOut seg;
+        BoundedOut* o = &out;
+        if (s > 0 && !legacy) { seg.bound = th.segment_size ? th.segment_size : max_file_size; o = &seg; }
+        BitWriter w;
+        w.fillbit = (uint8_t)jf.padbit;
+        w.seed(th.overhang_byte, th.num_overhang_bits);
+        int16_t lastdc[4];
+        memcpy(lastdc, th.last_dc, sizeof lastdc);
+        for (int mcu_row = 0; mcu_row < jf.mcuv; ++mcu_row) {
+            int y0 = mcu_row * luma_mul, y1 = y0 + luma_mul;
+            if (y0 >= jf.trunc_bcv[0]) break;                 // rows past the coded height are skipped
+            if (y0 < th.luma_y_start) continue;
+            if (y1 > th.luma_y_end) break;
+            rc.mcu_row(w, mcu_row * jf.mcuh, *o, lastdc);
+            drain(w, *o);
+        }
+        carry.overhang_byte = w.overhang_byte();
+        carry.num_overhang_bits = (uint8_t)w.overhang_bits();
+        memcpy(carry.last_dc, lastdc, sizeof lastdc);
+        if (o == &seg) out.write(seg.buf.data(), seg.buf.size());
+    }
+
+    // 3. wrongly placed RST markers at the end of the scan, then the rest of the header, then garbage
+    if (!jf.rst_err.empty()) {
+        unsigned cum = jf.rsti ? (unsigned)((jf.mcuh * jf.mcuv - 1) / jf.rsti) : 0;
+        for (unsigned i = 0; i < jf.rst_err[0]; ++i) { out.put(0xFF); out.put((uint8_t)(0xD0 + ((cum + i) & 7))); }
+    }
+    if (!out.reached() && pos < hdrs) out.write(h + pos, hdrs - pos);
+    out.bound = max_file_size;
+    out.write(jf.garbage.data(), jf.garbage.size());
+    result->swap(out.buf);
+    return 0;
+}
+
+}  // namespace lep

@@ -1,0 +1,524 @@
+// jpeg_scan.cc -- JPEG file -> (header bytes, un-stuffed scan bytes, garbage, DCT coefficients,
+// one Huffman hand-off record per MCU row).  Host-side caller of the hot path; behaviour follows
+//   read_jpeg          src/lepton/jpgcoder.cc:2269-2466
+//   setup_imginfo_jpg  src/lepton/jpgcoder.cc:4450-4539
+//   parse_jfif_jpg     src/lepton/jpgcoder.cc:4545-4843
+//   decode_jpeg        src/lepton/jpgcoder.cc:2799-3302   (sequential scans; progressive: jpeg_progressive.cc)
+//   decode_block_seq   src/lepton/jpgcoder.cc:4893-4966
+//   build_huffcodes    src/lepton/jpgcoder.cc:5507-5606
+//   abitreader         src/lepton/bitops.hh:229-362
+// so that the .lep container written from it is byte-identical to the reference's.
+#include "jpeg_model.h"
+#include "jpeg_bits.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace lep {
+
+const uint8_t kAlignedToRaster[64] = {
+    9, 10, 17, 25, 18, 11, 12, 19, 26, 33, 41, 34, 27, 20, 13, 14, 21, 28, 35, 42, 49, 57, 50, 43, 36,
+    29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 16, 24, 32, 40, 48, 56};
+const uint8_t kZigzagToRaster[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34,
+    27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+    58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const uint8_t kZigzagToAligned[64] = {
+    49, 50, 57, 58, 0, 51, 52, 1, 2, 59, 60, 3, 4, 5, 53, 54, 6, 7, 8, 9, 61, 62, 10, 11,
+    12, 13, 14, 55, 56, 15, 16, 17, 18, 19, 20, 63, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32,
+    33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48};
+
+static inline unsigned be16(unsigned a, unsigned b) { return (a << 8) + b; }
+
+// ------------------------------------------------------------------------------------------------
+// Huffman tables: code assignment in DHT order, then a binary tree of <=256 inner nodes.
+bool build_huff_table(const uint8_t* clen, size_t clen_avail, const uint8_t* cval, size_t cval_avail,
+                      HuffTable* t, bool strict) {
+    memset(t->clen, 0, sizeof t->clen);
+    memset(t->cval, 0, sizeof t->cval);
+    memset(t->l, 0, sizeof t->l);
+    memset(t->r, 0, sizeof t->r);
+    unsigned k = 0, code = 0;
+    for (unsigned bits = 0; bits < 16; ++bits) {
+        unsigned n = bits < clen_avail ? clen[bits] : 0;
+        for (unsigned j = 0; j < n; ++j, ++k, ++code) {
+            unsigned idx = k & 0xff;
+            uint8_t sym = idx < cval_avail ? cval[idx] : 0;
+            t->clen[sym] = (uint16_t)(bits + 1);
+            t->cval[sym] = (uint16_t)code;
+        }
+        code <<= 1;
+    }
+    t->max_eobrun = 0;
+    for (int i = 14; i >= 0; --i)
+        if (t->clen[(i << 4) & 255] > 0) { t->max_eobrun = (2 << i) - 1; break; }
+    unsigned next_free = 1;
+    for (unsigned sym = 0; sym < 256; ++sym) {
+        unsigned node = 0;
+        for (int j = (int)t->clen[sym] - 1; j > 0; --j) {
+            if (node > 0xff) { if (strict) return false; continue; }
+            uint16_t* side = ((t->cval[sym] >> j) & 1) ? t->r : t->l;
+            if (side[node] == 0) side[node] = (uint16_t)next_free++;
+            node = side[node];
+        }
+        if (node > 0xff) { if (strict) return false; continue; }
+        if (t->clen[sym] > 0) ((t->cval[sym] & 1) ? t->r : t->l)[node] = (uint16_t)(sym + 256);
+    }
+    t->set = true;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+bool parse_segment(JpegFile* jf, uint8_t type, unsigned len, unsigned avail, const uint8_t* seg, bool strict) {
+    auto at = [&](unsigned i) -> unsigned { return i < avail ? seg[i] : 0u; };
+    unsigned hpos = 4;
+    switch (type) {
+    case 0xC4: {  // DHT
+        while (hpos < len) {
+            unsigned cls = at(hpos) >> 4, id = at(hpos) & 15;
+            if (cls >= 2 || id >= 4) break;
+            ++hpos;
+            if (!build_huff_table(seg + hpos, avail > hpos ? avail - hpos : 0, seg + hpos + 16,
+                                  avail > hpos + 16 ? avail - hpos - 16 : 0, &jf->htab[cls][id], strict)) {
+                jf->error = "huffman table out of space";
+                return false;
+            }
+            unsigned skip = 16;
+            for (unsigned i = 0; i < 16; ++i) skip += at(hpos + i);
+            hpos += skip;
+        }
+        if (hpos != len) { jf->error = "size mismatch in dht marker"; return false; }
+        return true;
+    }
+    case 0xDB: {  // DQT
+        while (hpos < len) {
+            unsigned prec = at(hpos) >> 4, id = at(hpos) & 15;
+            if (prec >= 2 || id >= 4) break;
+            ++hpos;
+            if (prec == 0) {
+                for (unsigned i = 0; i < 64; ++i) {
+                    jf->qtables[id][i] = (uint16_t)at(hpos + i);
+                    if (jf->qtables[id][i] == 0) break;
+                }
+                hpos += 64;
+            } else {
+                for (unsigned i = 0; i < 64; ++i) {
+                    jf->qtables[id][i] = (uint16_t)be16(at(hpos + 2 * i), at(hpos + 2 * i + 1));
+                    if (jf->qtables[id][i] == 0) break;
+                }
+                hpos += 128;
+            }
+        }
+        if (hpos != len) { jf->error = "size mismatch in dqt marker"; return false; }
+        return true;
+    }
+    case 0xDD: jf->rsti = (int)be16(at(hpos), at(hpos + 1)); return true;
+    case 0xDA: {  // SOS
+        jf->cs_cmpc = (int)at(hpos);
+        if (jf->cs_cmpc > jf->ncomp) { jf->error = "too many components in scan"; return false; }
+        ++hpos;
+        for (int i = 0; i < jf->cs_cmpc; ++i) {
+            int c = 0;
+            while (c < jf->ncomp && (int)at(hpos) != jf->comp[c].jid) ++c;
+            if (c == jf->ncomp) { jf->error = "component id mismatch in start-of-scan"; return false; }
+            jf->cs_cmp[i] = c;
+            jf->comp[c].dc_tbl = (int)(at(hpos + 1) >> 4);
+            jf->comp[c].ac_tbl = (int)(at(hpos + 1) & 15);
+            if (jf->comp[c].dc_tbl >= 4 || jf->comp[c].ac_tbl >= 4) { jf->error = "huffman table number mismatch"; return false; }
+            hpos += 2;
+        }
+        jf->cs_from = (int)at(hpos);
+        jf->cs_to = (int)at(hpos + 1);
+        jf->cs_sah = (int)(at(hpos + 2) >> 4);
+        jf->cs_sal = (int)(at(hpos + 2) & 15);
+        if (jf->cs_from > jf->cs_to || jf->cs_from > 63 || jf->cs_to > 63) { jf->error = "spectral selection out of range"; return false; }
+        if (jf->cs_sah >= 12 || jf->cs_sal >= 12) { jf->error = "successive approximation out of range"; return false; }
+        return true;
+    }
+    case 0xC0: case 0xC1: case 0xC2: {
+        jf->jpegtype = type == 0xC2 ? 2 : 1;
+        if (at(hpos) != 8) { jf->error = "only 8 bit precision supported"; return false; }
+        jf->height = (int)be16(at(hpos + 1), at(hpos + 2));
+        jf->width = (int)be16(at(hpos + 3), at(hpos + 4));
+        jf->ncomp = (int)at(hpos + 5);
+        if (jf->ncomp > 4) { jf->ncomp = 4; jf->error = "max 4 components"; return false; }
+        hpos += 6;
+        for (int c = 0; c < jf->ncomp; ++c) {
+            jf->comp[c].jid = (int)at(hpos);
+            jf->comp[c].hs = (int)(at(hpos + 1) >> 4);
+            jf->comp[c].vs = (int)(at(hpos + 1) & 15);
+            if (jf->comp[c].hs > 4 || jf->comp[c].vs > 4) { jf->error = "sampling"; jf->warn = -EX_SAMPLING_BEYOND_FOUR_UNSUPPORTED; return false; }
+            if (jf->comp[c].hs > 2 || jf->comp[c].vs > 2) { jf->error = "sampling"; jf->warn = -EX_SAMPLING_BEYOND_TWO_UNSUPPORTED; return false; }
+            unsigned q = at(hpos + 2);
+            if (q >= 4) { jf->error = "quantisation table index"; return false; }
+            jf->comp[c].qidx = (int)q;
+            hpos += 3;
+        }
+        return true;
+    }
+    case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+        jf->error = "unsupported SOF type (lossless / differential / arithmetic)";
+        return false;
+    case 0xD0: case 0xD1: case 0xD2: case 0xD3: case 0xD4: case 0xD5: case 0xD6: case 0xD7:
+        jf->error = "rst marker found out of place"; return false;
+    case 0xD8: jf->error = "soi marker found out of place"; return false;
+    case 0xD9: jf->error = "eoi marker found out of place"; return false;
+    default:
+        if ((type >= 0xE0 && type <= 0xEF) || type == 0xFE) return true;
+        jf->warn = std::max(jf->warn, 1);  // unknown marker: warning only
+        return true;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+bool setup_frame(JpegFile* jf) {
+    size_t hpos = 0, hdrs = jf->hdr.size();
+    const uint8_t* h = jf->hdr.data();
+    while (hpos < hdrs) {
+        uint8_t type = hpos + 1 < hdrs ? h[hpos + 1] : 0;
+        unsigned len = 2 + be16(hpos + 2 < hdrs ? h[hpos + 2] : 0, hpos + 3 < hdrs ? h[hpos + 3] : 0);
+        if (type != 0xDA && type != 0xC4 && type != 0xDD)
+            if (!parse_segment(jf, type, len, (unsigned)(hdrs - hpos), h + hpos, true)) return false;
+        hpos += len;
+    }
+    if (jf->ncomp == 0) { jf->error = "header contains incomplete information"; return false; }
+    for (int c = 0; c < jf->ncomp; ++c)
+        if (jf->comp[c].hs == 0 || jf->comp[c].vs == 0 || jf->qtables[jf->comp[c].qidx][0] == 0 || jf->jpegtype == 0) {
+            jf->error = "header information is incomplete";
+            return false;
+        }
+    jf->hmax = jf->vmax = 0;
+    for (int c = 0; c < jf->ncomp; ++c) {
+        jf->hmax = std::max(jf->hmax, jf->comp[c].hs);
+        jf->vmax = std::max(jf->vmax, jf->comp[c].vs);
+    }
+    jf->mcuv = (int)ceilf((float)jf->height / (float)(8 * jf->vmax));
+    jf->mcuh = (int)ceilf((float)jf->width / (float)(8 * jf->hmax));
+    jf->mcuc = jf->mcuv * jf->mcuh;
+    for (int c = 0; c < jf->ncomp; ++c) {
+        Component& k = jf->comp[c];
+        k.mbs = k.hs * k.vs;
+        k.bcv = jf->mcuv * k.vs;
+        k.bch = jf->mcuh * k.hs;
+        k.bc = k.bcv * k.bch;
+        k.ncv = (int)ceilf((float)jf->height * ((float)k.vs / (8.0f * jf->vmax)));
+        k.nch = (int)ceilf((float)jf->width * ((float)k.hs / (8.0f * jf->hmax)));
+        if (k.bch == 0 || k.bcv == 0) { jf->error = "zero sized component"; return false; }
+        jf->trunc_bcv[c] = k.bcv;
+        jf->trunc_bc[c] = k.bc;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Step 1: split the file into header segments / scan bytes / garbage.
+static int split_file(const uint8_t* d, size_t n, JpegFile* jf) {
+    size_t pos = 2;  // past SOI
+    uint8_t last2[2] = {0, 0};
+    auto rd1 = [&](uint8_t* o) -> bool {
+        if (pos >= n) return false;
+        *o = d[pos++]; last2[0] = last2[1]; last2[1] = *o;
+        return true;
+    };
+    auto rdn = [&](uint8_t* o, unsigned cnt) -> unsigned {
+        if (cnt == 1) return rd1(o) ? 1 : 0;
+        unsigned got = (unsigned)std::min<size_t>(cnt, n - pos);
+        memcpy(o, d + pos, got);
+        pos += got;
+        if (got >= 2) { last2[0] = o[got - 2]; last2[1] = o[got - 1]; }   // (reference indexes by the requested size;
+        else if (got) { last2[0] = last2[1]; last2[1] = o[0]; }          //  identical whenever the read is complete)
+        return got;
+    };
+    std::vector<uint8_t> seg(1024);
+    uint8_t type = 0, tmp = 0;
+    int scnc = 0;
+    bool have_hdr = false;
+    for (;;) {
+        if (type == 0xDA) {
+            unsigned cpos = 0, crst = 0;
+            for (;;) {
+                jf->scan_to_file.emplace_back((uint32_t)jf->scan.size(), (uint32_t)pos);
+                if (!rd1(&tmp)) { jf->early_eof = true; have_hdr = true; break; }
+                bool dead = false;
+                if (tmp != 0xFF) {
+                    crst = 0;
+                    while (tmp != 0xFF) {
+                        jf->scan.push_back(tmp);
+                        if (!rd1(&tmp)) { jf->early_eof = true; have_hdr = true; dead = true; break; }
+                    }
+                }
+                if (dead || tmp != 0xFF) break;
+                if (!rd1(&tmp)) { jf->early_eof = true; have_hdr = true; break; }
+                if (tmp == 0x00) { crst = 0; jf->scan.push_back(0xFF); }
+                else if (tmp == 0xD0 + (cpos & 7)) {
+                    ++cpos; ++crst;
+                    if (jf->rst_cnt.size() <= (size_t)scnc) jf->rst_cnt.resize(scnc + 1, 0);
+                    ++jf->rst_cnt[scnc];
+                } else {
+                    if ((int)jf->rst_err.size() < scnc) jf->rst_err.resize(scnc, 0);
+                    jf->rst_err.push_back((uint8_t)crst);
+                    ++scnc;
+                    seg[0] = 0xFF; seg[1] = tmp;
+                    break;
+                }
+            }
+            if (jf->early_eof) { /* fall through to the stale-segment path below, as the reference does */ }
+        } else {
+            if (rdn(seg.data(), 2) != 2) break;
+            if (seg[0] != 0xFF) {
+                bool recovered = false;
+                if (type == 0xFE) {
+                    if (rdn(seg.data(), 1) != 1) break;
+                    if (seg[0] == 0xFF) { recovered = true; jf->warn = std::max(jf->warn, 1); }
+                }
+                if (!recovered) { jf->error = "size mismatch in marker segment"; return EX_UNSUPPORTED_JPEG; }
+            }
+        }
+        type = seg[1];
+        if (type == 0xD9) { have_hdr = true; break; }
+        if (rdn(seg.data() + 2, 2) != 2) break;
+        unsigned len = 2 + be16(seg[2], seg[3]);
+        if (len < 4) break;
+        if (seg.size() < len) seg.resize(len);
+        if (rdn(seg.data() + 4, len - 4) != (uint16_t)(len - 4)) break;
+        jf->hdr.insert(jf->hdr.end(), seg.begin(), seg.begin() + len);
+    }
+    if (!have_hdr || jf->hdr.empty()) { jf->error = "unexpected end of data encountered in header"; return EX_UNSUPPORTED_JPEG; }
+    if (jf->scan.empty()) { jf->error = "unexpected end of data encountered in huffman"; return EX_UNSUPPORTED_JPEG; }
+    jf->garbage.push_back(last2[0]);
+    jf->garbage.push_back(last2[1]);
+    jf->garbage.insert(jf->garbage.end(), d + pos, d + n);
+    pos = n;
+    if (jf->garbage.size() == 2 && jf->garbage[0] == 0xFF && jf->garbage[1] == 0xD9) jf->garbage.clear();
+    jf->file_size = (uint32_t)n;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static Handoff make_handoff(BitReader& br, const JpegFile& jf, int mcu_y, const int lastdc[4], int luma_mul) {
+    const auto& offs = jf.scan_to_file;
+    uint32_t p = (uint32_t)br.getpos();
+    auto it = std::lower_bound(offs.begin(), offs.end(), std::pair<uint32_t, uint32_t>(p, p));
+    if (it != offs.begin()) --it;
+    uint32_t mapped = 0;
+    if (it != offs.end()) mapped = it->second + (p - it->first);
+    Handoff h;
+    h.segment_size = mapped;
+    for (int i = 0; i < 4; ++i) h.last_dc[i] = (int16_t)lastdc[i];
+    h.luma_y_start = (uint16_t)(luma_mul * mcu_y);
+    h.luma_y_end = (uint16_t)(luma_mul * (mcu_y + 1));
+    br.overhang(&h.num_overhang_bits, &h.overhang_byte);
+    return h;
+}
+
+static inline int devli(int s, int n) { return s == 0 ? n : (n >= (1 << (s - 1)) ? n : n + 1 - (1 << s)); }
+
+// returns eob (1..64) or -1
+static int decode_block_seq(BitReader& br, const HuffTable& dc, const HuffTable& ac, int16_t* blk) {
+    int hc = next_huffcode(br, dc);
+    if (hc < 0) return -1;
+    int s = hc & 0xff;
+    int n = (int)br.read(s);
+    blk[0] = (int16_t)devli(s, n);
+    int eob = 64, bpos;
+    bool fixup = false;
+    for (bpos = 1; bpos < 64;) {
+        hc = next_huffcode(br, ac);
+        if (hc > 0) {
+            int z = (hc >> 4) & 15;
+            s = hc & 15;
+            n = (int)br.read(s);
+            if (z + bpos >= 64) { fixup = true; break; }
+            while (z > 0) { blk[bpos++] = 0; --z; }
+            blk[bpos++] = (int16_t)devli(s, n);
+        } else if (hc == 0) { eob = bpos; break; }
+        else return -1;
+    }
+    if (fixup) {
+        if (!br.eof) return -2;  // "If 0run is longer than the block must be truncated" (assertion in the reference)
+        for (; bpos < eob; ++bpos) blk[bpos] = 0;
+        if (eob) blk[eob - 1] = 1;
+    }
+    return eob;
+}
+
+// next block position, interleaved scan (recoder.cc:186-241)
+int next_mcupos(const JpegFile& jf, int* mcu, int* cmp, int* csc, int* sub, int* dpos, int* rstw, int cs_cmpc) {
+    int sta = 0;
+    if (++(*sub) >= jf.comp[*cmp].mbs) {
+        *sub = 0;
+        if (++(*csc) >= cs_cmpc) {
+            *csc = 0;
+            *cmp = jf.cs_cmp[0];
+            ++(*mcu);
+            if (*mcu >= jf.mcuc) sta = 2;
+            else if (jf.rsti > 0 && --(*rstw) == 0) sta = 1;
+        } else *cmp = jf.cs_cmp[*csc];
+    }
+    const Component& k = jf.comp[*cmp];
+    unsigned m = (unsigned)*mcu, sb = (unsigned)*sub, mh = (unsigned)jf.mcuh;
+    if (k.vs > 1) *dpos = (int)(((m / mh) * k.vs + sb / k.hs) * k.bch + (m % mh) * k.hs + sb % k.hs);
+    else if (k.hs > 1) *dpos = (int)(m * k.mbs + sb);
+    else *dpos = *mcu;
+    return sta;
+}
+
+// next block position, non-interleaved scan (jpgcoder.cc:5432-5456)
+int next_mcuposn(const JpegFile& jf, int cmp, int* dpos, int* rstw) {
+    const Component& k = jf.comp[cmp];
+    ++(*dpos);
+    if (k.bch != k.nch && (*dpos) % k.bch == k.nch) *dpos += k.bch - k.nch;
+    if (k.bcv != k.ncv && (*dpos) / k.bch == k.ncv) *dpos = k.bc;
+    if (*dpos >= k.bc) return 2;
+    if (jf.rsti > 0 && --(*rstw) == 0) return 1;
+    return 0;
+}
+
+static int min_vertical_multiple(const JpegFile& jf, int c) {   // uncompressed_components.cc:26-35
+    return jf.comp[c].bcv / jf.mcuv;
+}
+
+int decode_progressive_scan(JpegFile* jf, BitReader& br, int* lastdc, int* sta_io, int* cmp_io, int* dpos_io,
+                            int* mcu_io, int* csc_io, int* sub_io, int* rstw_io, unsigned* eobrun_io, int* peobrun_io,
+                            bool* do_handoff);
+
+// Step 2: Huffman-decode every scan into the coefficient planes.
+static int decode_scans(JpegFile* jf, bool allow_progressive) {
+    BitReader br(jf->scan.data(), (int)jf->scan.size());
+    const uint8_t* h = jf->hdr.data();
+    size_t hdrs = jf->hdr.size(), hpos = 0;
+    int lastdc[4] = {0, 0, 0, 0};
+    int mcu = 0;
+    for (int c = 0; c < jf->ncomp; ++c) jf->coef[c].assign((size_t)jf->comp[c].bc * 64, 0);
+    jf->scan_count = 0;
+    const int luma_mul = jf->comp[0].bcv / jf->mcuv;
+    int16_t blk[64];
+    for (;;) {
+        uint8_t type = 0;
+        while (type != 0xDA) {
+            if (3 + (uint64_t)hpos >= hdrs) break;
+            type = h[hpos + 1];
+            unsigned len = 2 + be16(h[hpos + 2], h[hpos + 3]);
+            if (type == 0xC4 || type == 0xDA || type == 0xDD) {
+                std::vector<uint8_t> over;
+                const uint8_t* sp = h + hpos;
+                if ((uint64_t)hpos + len > hdrs) { over.assign(h + hpos, h + hdrs); over.resize(len, 0); sp = over.data(); }
+                if (!parse_segment(jf, type, len, len, sp, true)) return EX_UNSUPPORTED_JPEG;
+            }
+            hpos += len;
+        }
+        if (type != 0xDA) break;
+        for (int i = 0; i < jf->cs_cmpc; ++i) {
+            const Component& k = jf->comp[jf->cs_cmp[i]];
+            bool need_dc = jf->jpegtype == 1 || ((jf->cs_cmpc > 1 || jf->cs_to == 0) && jf->cs_sah == 0);
+            if ((need_dc && !jf->htab[0][k.dc_tbl].set) || (jf->jpegtype == 1 && !jf->htab[1][k.dc_tbl].set) ||
+                (jf->cs_cmpc == 1 && jf->cs_to > 0 && jf->cs_sah == 0 && !jf->htab[1][k.ac_tbl].set)) {
+                jf->error = "huffman table missing in scan";
+                return EX_UNSUPPORTED_JPEG;
+            }
+        }
+        int cmp = jf->cs_cmp[0], csc = 0, sub = 0, dpos = 0;
+        mcu = 0;
+        if (!br.eof) {
+            jf->max_bpos = std::max(jf->max_bpos, jf->cs_to);
+            jf->max_sah = std::max(jf->max_sah, std::max(jf->cs_sal, jf->cs_sah));
+            for (int i = 0; i < jf->cs_cmpc; ++i) jf->max_cmp = std::max(jf->max_cmp, jf->cs_cmp[i]);
+        }
+        bool do_handoff = true;
+        for (;;) {  // one restart interval per iteration
+            lastdc[0] = lastdc[1] = lastdc[2] = lastdc[3] = 0;
+            int sta = 0, rstw = jf->rsti;
+            unsigned eobrun = 0;
+            int peobrun = 0;
+            if (jf->cs_cmpc != jf->ncomp || jf->jpegtype != 1) {
+                if (!allow_progressive) return EX_PROGRESSIVE_UNSUPPORTED;
+                jf->progressive_needed = true;
+            }
+            if (jf->jpegtype == 1 && jf->cs_cmpc > 1) {
+                while (sta == 0) {
+                    if (do_handoff) { jf->rows.push_back(make_handoff(br, *jf, mcu / jf->mcuh, lastdc, luma_mul)); do_handoff = false; }
+                    if (!br.eof) jf->max_dpos[cmp] = std::max(dpos, jf->max_dpos[cmp]);
+                    const Component& k = jf->comp[cmp];
+                    int eob = decode_block_seq(br, jf->htab[0][k.dc_tbl], jf->htab[1][k.ac_tbl], blk);
+                    if (eob == -2) return EX_ASSERTION_FAILURE;
+                    if (eob > 1 && !blk[eob - 1]) jf->warn = std::max(jf->warn, 1);
+                    blk[0] = (int16_t)(blk[0] + lastdc[cmp]);
+                    lastdc[cmp] = blk[0];
+                    int16_t* dst = jf->coef[cmp].data() + (size_t)dpos * 64;
+                    for (int b = 0; b < eob; ++b) dst[kZigzagToAligned[b]] = blk[b];
+                    int old_mcu = mcu;
+                    if (eob < 0) sta = -1;
+                    else sta = next_mcupos(*jf, &mcu, &cmp, &csc, &sub, &dpos, &rstw, jf->cs_cmpc);
+                    if (mcu % jf->mcuh == 0 && old_mcu != mcu) do_handoff = true;
+                    if (br.eof) { sta = 2; break; }
+                }
+            } else if (jf->jpegtype == 1) {
+                const int vmul = jf->comp[0].bcv / jf->mcuv, hmul = jf->comp[0].bch / jf->mcuh;
+                while (sta == 0) {
+                    if (do_handoff) { jf->rows.push_back(make_handoff(br, *jf, (dpos / (hmul * vmul)) / jf->mcuh, lastdc, luma_mul)); do_handoff = false; }
+                    if (!br.eof) jf->max_dpos[cmp] = std::max(dpos, jf->max_dpos[cmp]);
+                    const Component& k = jf->comp[cmp];
+                    int eob = decode_block_seq(br, jf->htab[0][k.dc_tbl], jf->htab[1][k.ac_tbl], blk);
+                    if (eob == -2) return EX_ASSERTION_FAILURE;
+                    if (eob > 1 && !blk[eob - 1]) jf->warn = std::max(jf->warn, 1);
+                    blk[0] = (int16_t)(blk[0] + lastdc[cmp]);
+                    lastdc[cmp] = blk[0];
+                    int16_t* dst = jf->coef[cmp].data() + (size_t)dpos * 64;
+                    for (int b = 0; b < eob; ++b) dst[kZigzagToAligned[b]] = blk[b];
+                    if (eob < 0) sta = -1;
+                    else sta = next_mcuposn(*jf, cmp, &dpos, &rstw);
+                    mcu = dpos / (hmul * vmul);
+                    if (cmp == 0 && (mcu % jf->mcuh == 0) && (dpos % (hmul * vmul) == 0)) do_handoff = true;
+                    if (br.eof) { sta = 2; break; }
+                }
+            } else {
+                int rc = decode_progressive_scan(jf, br, lastdc, &sta, &cmp, &dpos, &mcu, &csc, &sub, &rstw, &eobrun,
+                                                 &peobrun, &do_handoff);
+                if (rc) return rc;
+            }
+            if (jf->padbit != -1) {
+                if (jf->padbit != (int)br.unpad((uint8_t)jf->padbit)) { jf->padbit = 1; jf->warn = std::max(jf->warn, 1); }
+            } else {
+                jf->padbit = (int8_t)br.unpad((uint8_t)jf->padbit);
+            }
+            if (sta == -1) { jf->error = "decode error in scan"; return EX_UNSUPPORTED_JPEG; }
+            if (sta == 2) { ++jf->scan_count; break; }
+        }
+    }
+    if (jf->early_eof) {   // uncompressed_components.hh:166-185
+        for (int c = 0; c < jf->ncomp; ++c) {
+            const Component& k = jf->comp[c];
+            int tbc = jf->max_dpos[c] + 1;
+            int lines = std::min(tbc / k.bch + (tbc % k.bch ? 1 : 0), k.bcv);
+            int ratio = std::max(min_vertical_multiple(*jf, c), 1);
+            while (lines % ratio != 0 && lines + 1 <= k.bcv) ++lines;
+            jf->trunc_bcv[c] = lines;
+            jf->trunc_bc[c] = tbc;
+        }
+    }
+    jf->rows.push_back(make_handoff(br, *jf, (uint16_t)(mcu / jf->mcuh), lastdc, luma_mul));
+    for (size_t i = 1; i < jf->rows.size(); ++i)
+        if (jf->rows[i].luma_y_start < jf->rows[i - 1].luma_y_end) jf->rows[i].luma_y_start = jf->rows[i - 1].luma_y_end;
+    if (!br.eof) jf->warn = std::max(jf->warn, 1);  // "unneeded data found after coded image data"
+    return 0;
+}
+
+#ifndef LEP_HAVE_PROGRESSIVE
+int decode_progressive_scan(JpegFile*, BitReader&, int*, int*, int*, int*, int*, int*, int*, int*, unsigned*, int*, bool*) {
+    return EX_PROGRESSIVE_UNSUPPORTED;
+}
+#endif
+
+int parse_jpeg(const uint8_t* data, size_t size, bool allow_progressive, JpegFile* jf) {
+    if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) { jf->error = "not a jpeg"; return EX_UNSUPPORTED_JPEG; }
+    memset(jf->qtables, 0, sizeof jf->qtables);
+    int rc = split_file(data, size, jf);
+    if (rc) return rc;
+    if (!setup_frame(jf)) return jf->warn < 0 ? -jf->warn : EX_UNSUPPORTED_JPEG;
+    if (jf->ncomp > 3) return EX_UNSUPPORTED_4_COLORS;
+    return decode_scans(jf, allow_progressive);
+}
+
+}  // namespace lep

@@ -1,0 +1,150 @@
+// lep_api.cc -- C ABI, layers 2 and 3 (host-side callers of the GPU hot path).  See include/lepton_mi355x.h.
+#include "../../include/lepton_mi355x.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "jpeg_model.h"
+#include "lep_container.h"
+
+struct lep_jpeg {
+    lep::JpegFile jf;
+    lep::EncodeOptions opt;
+};
+struct lep_file {
+    lep::LepFile lf;
+    bool frame_ready = false;
+};
+
+static void fill_desc(const lep::JpegFile& jf, lep_image_desc* d, int16_t* const* planes) {
+    memset(d, 0, sizeof *d);
+    d->ncomp = jf.ncomp;
+    d->mcu_rows = jf.mcuv;
+    for (int c = 0; c < jf.ncomp && c < LEP_MAX_COMPONENTS; ++c) {
+        d->width_blocks[c] = jf.comp[c].bch;
+        d->height_blocks[c] = jf.comp[c].bcv;
+        d->coded_blocks[c] = jf.trunc_bc[c];
+        d->coded_height[c] = jf.trunc_bcv[c];
+        memcpy(d->qtable_zigzag[c], jf.qtables[jf.comp[c].qidx], 128);
+        d->blocks[c] = planes[c];
+    }
+}
+
+static int to_bytes(const std::vector<uint8_t>& v, lep_bytes* out) {
+    out->data = (uint8_t*)malloc(v.size() ? v.size() : 1);
+    if (!out->data) return LEP_OS_ERROR;
+    memcpy(out->data, v.data(), v.size());
+    out->len = out->cap = v.size();
+    return 0;
+}
+
+extern "C" {
+
+const char* lep_version(void) { return "lepton-mi355x 0.1 (format v1, gfx950)"; }
+void lep_free(void* p) { free(p); }
+
+int lep_jpeg_open(const uint8_t* jpg, size_t len, int allow_progressive, lep_jpeg** out) {
+    std::unique_ptr<lep_jpeg> j(new lep_jpeg);
+    j->opt.allow_progressive = allow_progressive != 0;
+    int rc = lep::parse_jpeg(jpg, len, allow_progressive != 0, &j->jf);
+    if (rc) return rc;
+    *out = j.release();
+    return 0;
+}
+void lep_jpeg_close(lep_jpeg* j) { delete j; }
+
+int lep_jpeg_describe(const lep_jpeg* j, lep_image_desc* d) {
+    int16_t* planes[4];
+    for (int c = 0; c < 4; ++c) planes[c] = const_cast<int16_t*>(j->jf.coef[c].data());
+    fill_desc(j->jf, d, planes);
+    return 0;
+}
+
+int lep_jpeg_plan(const lep_jpeg* j, int max_threads, lep_segment* segs, int image_index) {
+    lep::EncodeOptions o = j->opt;
+    if (max_threads > 0) o.max_threads = (unsigned)max_threads;
+    std::vector<lep::Handoff> s = lep::plan_segments(j->jf, o);
+    for (size_t i = 0; i < s.size(); ++i) {
+        segs[i].image = image_index;
+        segs[i].luma_y_start = s[i].luma_y_start;
+        segs[i].luma_y_end = s[i].luma_y_end;
+        segs[i].is_last = i + 1 == s.size();
+    }
+    return (int)s.size();
+}
+
+int lep_jpeg_write_lep(const lep_jpeg* j, int max_threads, const lep_bytes* streams, int nstreams, lep_bytes* out) {
+    lep::EncodeOptions o = j->opt;
+    if (max_threads > 0) o.max_threads = (unsigned)max_threads;
+    std::vector<lep::Handoff> s = lep::plan_segments(j->jf, o);
+    if ((int)s.size() != nstreams) return LEP_ASSERTION_FAILURE;
+    std::vector<std::vector<uint8_t>> st(nstreams);
+    for (int i = 0; i < nstreams; ++i) st[i].assign(streams[i].data, streams[i].data + streams[i].len);
+    std::vector<uint8_t> file;
+    int rc = lep::write_lep(j->jf, s, st, &file);
+    if (rc) return rc;
+    return to_bytes(file, out);
+}
+
+int lep_file_open(const uint8_t* d, size_t len, lep_file** out) {
+    std::unique_ptr<lep_file> f(new lep_file);
+    int rc = lep::parse_lep(d, len, &f->lf);
+    if (rc) return rc;
+    lep::JpegFile& jf = f->lf.jpeg;
+    memset(jf.qtables, 0, sizeof jf.qtables);
+    if (!lep::setup_frame(&jf)) return LEP_UNSUPPORTED_JPEG;
+    if (jf.ncomp > 3) return LEP_UNSUPPORTED_4_COLORS;
+    if (jf.early_eof) {
+        for (int c = 0; c < jf.ncomp; ++c) {
+            const lep::Component& k = jf.comp[c];
+            int tbc = jf.max_dpos[c] + 1;
+            int lines = std::min(tbc / k.bch + (tbc % k.bch ? 1 : 0), k.bcv);
+            int ratio = std::max(k.bcv / jf.mcuv, 1);
+            while (lines % ratio != 0 && lines + 1 <= k.bcv) ++lines;
+            jf.trunc_bcv[c] = lines;
+            jf.trunc_bc[c] = tbc;
+        }
+    }
+    if (!f->lf.segs.empty()) f->lf.segs.back().luma_y_end = (uint16_t)jf.trunc_bcv[0];   // vp8_decoder.cc:366-368
+    *out = f.release();
+    return 0;
+}
+void lep_file_close(lep_file* f) { delete f; }
+uint32_t lep_file_jpeg_size(const lep_file* f) { return f->lf.jpeg_size; }
+
+int lep_file_describe(lep_file* f, lep_image_desc* d) {
+    lep::JpegFile& jf = f->lf.jpeg;
+    if (!f->frame_ready) {
+        for (int c = 0; c < jf.ncomp; ++c) jf.coef[c].assign((size_t)jf.comp[c].bc * 64, 0);
+        f->frame_ready = true;
+    }
+    int16_t* planes[4];
+    for (int c = 0; c < 4; ++c) planes[c] = jf.coef[c].data();
+    fill_desc(jf, d, planes);
+    return 0;
+}
+
+int lep_file_segments(const lep_file* f, lep_segment* segs, lep_bytes* streams, int image_index) {
+    const auto& s = f->lf.segs;
+    for (size_t i = 0; i < s.size(); ++i) {
+        segs[i].image = image_index;
+        segs[i].luma_y_start = s[i].luma_y_start;
+        segs[i].luma_y_end = s[i].luma_y_end;
+        segs[i].is_last = i + 1 == s.size();
+        streams[i].data = const_cast<uint8_t*>(f->lf.streams[i].data());
+        streams[i].len = streams[i].cap = f->lf.streams[i].size();
+    }
+    return (int)s.size();
+}
+
+int lep_file_recode(lep_file* f, lep_bytes* out) {
+    std::vector<uint8_t> jpg;
+    int rc = lep::recode_jpeg(&f->lf, &jpg);
+    if (rc) return rc;
+    return to_bytes(jpg, out);
+}
+
+}  // extern "C"

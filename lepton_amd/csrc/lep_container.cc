@@ -1,0 +1,375 @@
+// lep_container.cc -- the .lep container around the arithmetic-coded streams (host side).
+//   segment choice        src/lepton/jpgcoder.cc:3856-3934 (write_ujpg)
+//   header sections       src/lepton/jpgcoder.cc:3953-4027 (write), :4117-4362 (read_ujpg)
+//   fixed 28-byte prefix  src/lepton/jpgcoder.cc:4045-4069, :2140-2176 (read_fixed_ujpg_header)
+//   hand-off records      src/lepton/thread_handoff.cc:4-76
+//   stream multiplexing   src/io/MuxReader.hh:336-522 (MuxWriter), :38-334 (MuxReader);
+//                         slice order src/lepton/vp8_encoder.cc:575-594; size trailer :602-614
+#include "lep_container.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstring>
+
+namespace lep {
+
+// ------------------------------------------------------------------------------------------------
+std::vector<Handoff> plan_segments(const JpegFile& jf, const EncodeOptions& opt) {
+    const std::vector<Handoff>& rows = jf.rows;
+    unsigned n = std::min(8u, opt.max_threads);
+    const uint32_t scan_bytes = rows.back().segment_size - rows.front().segment_size;
+    const uint32_t nrows = (uint32_t)rows.size();
+    if (nrows / 2 < n) {
+        unsigned want = std::max(nrows / 2, opt.min_threads);
+        n = std::min(std::max(want, 1u), n);
+    }
+    if (scan_bytes < 125000) n = std::min(std::max(opt.min_threads, 1u), n);
+    else if (scan_bytes < 250000) n = std::min(std::max(opt.min_threads, 2u), n);
+    else if (scan_bytes < 500000) n = std::min(std::max(opt.min_threads, 4u), n);
+
+    std::vector<int> cut(n, 0);
+    if (!opt.even_split) {
+        for (uint32_t i = 0; i + 1 < n; ++i) {
+            uint32_t target = rows.back().segment_size - rows.front().segment_size;
+            target = (uint32_t)((uint64_t)target * (i + 1)) ;   // 32-bit wrap matches the reference's uint32 math
+            target /= n;
+            target += rows.front().segment_size;
+            auto it = std::lower_bound(rows.begin() + 1, rows.end(), target,
+                                       [](const Handoff& a, uint32_t v) { return a.segment_size < v; });
+            if (it != rows.begin() + 1) --it;
+            cut[i] = (int)(it - rows.begin());
+        }
+    } else {
+        for (uint32_t i = 0; i + 1 < n; ++i) cut[i] = (int)(rows.size() * (i + 1) / n);
+    }
+    for (uint32_t i = 0; i + 1 < n; ++i)
+        if (cut[i] == cut[i + 1]) {
+            for (uint32_t j = 0; j + 1 < n; ++j) cut[j] = (int)((j + 1) * rows.size() / n);
+            break;
+        }
+    cut[n - 1] = (int)rows.size() - 1;
+    std::vector<Handoff> segs(n);
+    size_t begin = 0;
+    for (size_t i = 0; i < n; ++i) {
+        size_t end = (size_t)cut[i];
+        Handoff s = rows[begin];                 // start-of-range state ...
+        s.luma_y_end = rows[end].luma_y_start;   // ... up to where the end record starts
+        s.segment_size = rows[end].segment_size - rows[begin].segment_size;
+        if (i + 1 == n && rows[end].num_overhang_bits) ++s.segment_size;
+        segs[i] = s;
+        begin = end;
+    }
+    return segs;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void put_le32(std::vector<uint8_t>& v, uint32_t x) {
+    for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i)));
+}
+static uint32_t get_le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+std::vector<uint8_t> serialize_handoffs(const std::vector<Handoff>& segs) {
+    std::vector<uint8_t> out;
+    out.push_back('H');
+    out.push_back((uint8_t)segs.size());
+    for (const Handoff& h : segs) {
+        out.push_back(h.luma_y_start & 255);
+        out.push_back(h.luma_y_start >> 8);
+        put_le32(out, h.segment_size);
+        out.push_back(h.overhang_byte);
+        out.push_back(h.num_overhang_bits);
+        for (int i = 0; i < 3; ++i) { uint16_t dc = (uint16_t)h.last_dc[i]; out.push_back(dc & 255); out.push_back(dc >> 8); }
+        out.push_back(0); out.push_back(0);   // 4th channel slot (3 colour channels in the default build)
+    }
+    return out;
+}
+
+bool deserialize_handoffs(const uint8_t* d, size_t n, std::vector<Handoff>* out) {
+    if (n < 2 || d[0] != 'H') return false;
+    int cnt = d[1];
+    if ((size_t)cnt * 16 + 2 > n) return false;
+    d += 2;
+    for (int i = 0; i < cnt; ++i, d += 16) {
+        Handoff h;
+        h.luma_y_start = (uint16_t)(d[0] | (d[1] << 8));
+        h.segment_size = get_le32(d + 2);
+        h.overhang_byte = d[6];
+        h.num_overhang_bits = d[7];
+        for (int k = 0; k < 4; ++k) h.last_dc[k] = (int16_t)(d[8 + 2 * k] | (d[9 + 2 * k] << 8));
+        h.last_dc[3] = 0;
+        out->push_back(h);
+    }
+    for (size_t i = 1; i < out->size(); ++i) (*out)[i - 1].luma_y_end = (*out)[i].luma_y_start;
+    return true;
+}
+
+static std::vector<uint8_t> build_header_payload(const JpegFile& jf, const std::vector<Handoff>& segs) {
+    std::vector<uint8_t> p;
+    p.insert(p.end(), {'H', 'D', 'R'});
+    put_le32(p, (uint32_t)jf.hdr.size());
+    p.insert(p.end(), jf.hdr.begin(), jf.hdr.end());
+    p.insert(p.end(), {'P', '0', 'D'});
+    p.push_back((uint8_t)(int8_t)jf.padbit);
+    p.push_back('H');
+    std::vector<uint8_t> hs = serialize_handoffs(segs);
+    p.insert(p.end(), hs.begin(), hs.end());
+    if (!jf.rst_cnt.empty()) {
+        p.insert(p.end(), {'C', 'R', 'S'});
+        put_le32(p, (uint32_t)jf.rst_cnt.size());
+        for (uint32_t c : jf.rst_cnt) put_le32(p, c);
+    }
+    if (!jf.rst_err.empty()) {
+        p.insert(p.end(), {'F', 'R', 'S'});
+        put_le32(p, (uint32_t)jf.rst_err.size());
+        p.insert(p.end(), jf.rst_err.begin(), jf.rst_err.end());
+    }
+    if (jf.early_eof) {
+        p.insert(p.end(), {'E', 'E', 'E'});
+        put_le32(p, (uint32_t)jf.max_cmp);
+        put_le32(p, (uint32_t)jf.max_bpos);
+        put_le32(p, (uint32_t)jf.max_sah);
+        for (int i = 0; i < 4; ++i) put_le32(p, (uint32_t)jf.max_dpos[i]);
+    }
+    if (!jf.garbage.empty()) {
+        p.insert(p.end(), {'G', 'R', 'B'});
+        put_le32(p, (uint32_t)jf.garbage.size());
+        p.insert(p.end(), jf.garbage.begin(), jf.garbage.end());
+    }
+    return p;
+}
+
+// zlib level 9, one deflate(Z_NO_FLUSH) then Z_FINISH (src/io/ZlibCompression.cc:44-75)
+static bool zlib9(const std::vector<uint8_t>& in, std::vector<uint8_t>* out) {
+    z_stream s;
+    memset(&s, 0, sizeof s);
+    if (deflateInit(&s, 9) != Z_OK) return false;
+    out->resize(compressBound((uLong)in.size()));
+    s.next_in = (Bytef*)in.data(); s.avail_in = (uInt)in.size();
+    s.next_out = out->data(); s.avail_out = (uInt)out->size();
+    int r = deflate(&s, Z_NO_FLUSH);
+    while (r != Z_STREAM_END) {
+        r = deflate(&s, Z_FINISH);
+        if (r != Z_OK && r != Z_STREAM_END && r != Z_BUF_ERROR) { deflateEnd(&s); return false; }
+    }
+    out->resize(out->size() - s.avail_out);
+    deflateEnd(&s);
+    return true;
+}
+
+static bool unzlib(const uint8_t* d, size_t n, std::vector<uint8_t>* out) {
+    z_stream s;
+    memset(&s, 0, sizeof s);
+    if (inflateInit(&s) != Z_OK) return false;
+    s.next_in = (Bytef*)d; s.avail_in = (uInt)n;
+    out->clear();
+    uint8_t buf[65536];
+    int r;
+    do {
+        s.next_out = buf; s.avail_out = sizeof buf;
+        r = inflate(&s, Z_NO_FLUSH);
+        if (r != Z_OK && r != Z_STREAM_END) { inflateEnd(&s); return false; }
+        out->insert(out->end(), buf, buf + (sizeof buf - s.avail_out));
+    } while (r != Z_STREAM_END);
+    inflateEnd(&s);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multiplexer: same packetisation policy as MuxWriter, expressed over per-stream pending queues.
+namespace {
+struct Mux {
+    std::vector<uint8_t>& out;
+    std::vector<uint8_t> pend[16];     // bytes accepted but not yet emitted
+    uint32_t flushed[16] = {0};
+    uint32_t low_water[16] = {0};
+    uint32_t total = 0;
+    explicit Mux(std::vector<uint8_t>& o) : out(o) {}
+
+    static uint32_t high_water(uint32_t flushed) { return (flushed & 0xffffc000u) ? 65536 : (flushed & 0xfffff000u) ? 16384 : 4096; }
+
+    void emit_all(int id) {   // variable-length packets, <= 65536 each ("flushFull")
+        std::vector<uint8_t>& q = pend[id];
+        size_t off = 0;
+        while (off < q.size()) {
+            uint32_t len = (uint32_t)std::min<size_t>(q.size() - off, 65536);
+            out.push_back((uint8_t)id);
+            out.push_back((uint8_t)((len - 1) & 0xff));
+            out.push_back((uint8_t)((len - 1) >> 8));
+            out.insert(out.end(), q.begin() + off, q.begin() + off + len);
+            off += len; total += len; flushed[id] += len;
+        }
+        if (!q.empty()) { q.clear(); low_water[id] = total; }
+    }
+    void emit_fixed(int id) {   // power-of-four sized packets with a 1-byte header ("flushPartial")
+        std::vector<uint8_t>& q = pend[id];
+        uint32_t have = (uint32_t)q.size(), len, code;
+        if (have < 4096) { emit_all(id); return; }
+        if (have < 16384) { if (have > 8192) { emit_all(id); return; } len = 4096; code = 1; }
+        else if (have < 65536) { if (have > 32768) { emit_all(id); return; } len = 16384; code = 2; }
+        else { if (have > 131072) { emit_all(id); return; } len = 65536; code = 3; }
+        uint32_t off = 0;
+        for (; off + len <= have; off += len) {
+            out.push_back((uint8_t)(id | (code << 4)));
+            out.insert(out.end(), q.begin() + off, q.begin() + off + len);
+            total += len; flushed[id] += len;
+        }
+        q.erase(q.begin(), q.begin() + off);
+        uint32_t behind = (uint32_t)q.size();
+        low_water[id] = behind > total ? 0 : total - behind;
+    }
+    void flush_for(int id) {
+        for (int i = 0; i < 16; ++i) {
+            uint32_t have = (uint32_t)pend[i].size();
+            if (i == id || !have) continue;
+            bool urgent = total - low_water[i] > 65537;
+            if (have < 4096) { if (urgent) emit_all(i); }
+            else if (urgent && have < 16384) emit_all(i);
+            else emit_fixed(i);
+        }
+        emit_fixed(id);
+    }
+    void write(int id, const uint8_t* d, size_t n) {
+        pend[id].insert(pend[id].end(), d, d + n);
+        if (pend[id].size() >= high_water(flushed[id])) flush_for(id);
+    }
+    void close(int version) {
+        for (int i = 0; i < 16; ++i) emit_all(i);
+        if (version > 1) out.insert(out.end(), {0xFF, 0xFE, 0xFF});
+    }
+};
+}  // namespace
+
+void mux_streams(const std::vector<std::vector<uint8_t>>& streams, int version, std::vector<uint8_t>* out) {
+    Mux m(*out);
+    std::vector<size_t> off(streams.size(), 0);
+    bool any = true;
+    while (any) {
+        any = false;
+        for (size_t i = 0; i < streams.size() && i < 16; ++i) {
+            if (streams[i].size() <= off[i]) continue;
+            any = true;
+            size_t slice = off[i] == 0 ? 256 : off[i] == 256 ? 4096 : 65536;
+            size_t n = std::min(slice, streams[i].size() - off[i]);
+            m.write((int)i, streams[i].data() + off[i], n);
+            off[i] += n;
+        }
+    }
+    m.close(version);
+}
+
+// ------------------------------------------------------------------------------------------------
+int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::vector<std::vector<uint8_t>>& streams,
+              std::vector<uint8_t>* out) {
+    std::vector<uint8_t> payload = build_header_payload(jf, segs), z;
+    if (!zlib9(payload, &z)) return EX_OS_ERROR;
+    out->clear();
+    out->reserve(z.size() + 64);
+    out->push_back(0xCF); out->push_back(0x84);
+    out->push_back(1);                                     // format version
+    out->push_back(jf.progressive_needed ? 'X' : 'Z');
+    out->push_back((uint8_t)segs.size());
+    out->insert(out->end(), 3, 0);
+    out->insert(out->end(), 12, 0);                        // git revision: zeros, as an out-of-git reference build writes
+    put_le32(*out, jf.file_size);
+    put_le32(*out, (uint32_t)z.size());
+    out->insert(out->end(), z.begin(), z.end());
+    out->insert(out->end(), {'C', 'M', 'P'});
+    mux_streams(streams, 1, out);
+    put_le32(*out, (uint32_t)out->size() + 4);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
+    if (n < 28 || d[0] != 0xCF || d[1] != 0x84) return EX_VERSION_UNSUPPORTED;
+    lf->version = d[2];
+    lf->flag = d[3];
+    lf->nthreads = d[4];
+    if (lf->version != 1) return EX_VERSION_UNSUPPORTED;   // v2+ (brotli header) is not produced by the default encoder
+    lf->jpeg_size = get_le32(d + 20);
+    uint32_t zsize = get_le32(d + 24);
+    if (28 + (uint64_t)zsize + 3 > n) return EX_SHORT_READ;
+    std::vector<uint8_t> p;
+    if (!unzlib(d + 28, zsize, &p)) return EX_STREAM_INCONSISTENT;
+    size_t pos = 0;
+    auto need = [&](size_t k) { return pos + k <= p.size(); };
+    JpegFile& jf = lf->jpeg;
+    if (!need(7) || memcmp(&p[pos], "HDR", 3)) return EX_STREAM_INCONSISTENT;
+    uint32_t hdrs = get_le32(&p[pos + 3]); pos += 7;
+    if (!need(hdrs)) return EX_STREAM_INCONSISTENT;
+    jf.hdr.assign(p.begin() + pos, p.begin() + pos + hdrs); pos += hdrs;
+    if (!need(4)) return EX_STREAM_INCONSISTENT;
+    if (!memcmp(&p[pos], "P0D", 3)) jf.padbit = (int8_t)p[pos + 3];
+    else if (!memcmp(&p[pos], "PAD", 3)) {
+        int8_t pb = (int8_t)p[pos + 3];
+        if (!(pb == 0 || pb == 1 || pb == -1)) return EX_STREAM_INCONSISTENT;
+        jf.padbit = pb == 1 ? 0x7f : pb;
+    } else return EX_STREAM_INCONSISTENT;
+    pos += 4;
+    lf->garbage_default_eoi = true;
+    while (need(3)) {
+        const uint8_t* m = &p[pos];
+        if (!memcmp(m, "CRS", 3)) {
+            if (!need(7)) return EX_STREAM_INCONSISTENT;
+            uint32_t c = get_le32(m + 3); pos += 7;
+            if (!need((size_t)c * 4)) return EX_STREAM_INCONSISTENT;
+            lf->rst_cnt_set = true;
+            jf.rst_cnt.resize(c);
+            for (uint32_t i = 0; i < c; ++i, pos += 4) jf.rst_cnt[i] = get_le32(&p[pos]);
+        } else if (m[0] == 'H' && m[1] == 'H') {
+            size_t bytes = (size_t)m[2] * 16 + 2;
+            if (!need(1 + bytes)) return EX_STREAM_INCONSISTENT;
+            if (!deserialize_handoffs(m + 1, bytes, &lf->segs)) return EX_VERSION_UNSUPPORTED;
+            pos += 1 + bytes;
+        } else if (!memcmp(m, "FRS", 3)) {
+            if (!need(7)) return EX_STREAM_INCONSISTENT;
+            uint32_t c = get_le32(m + 3); pos += 7;
+            if (!need(c)) return EX_STREAM_INCONSISTENT;
+            jf.rst_err.assign(p.begin() + pos, p.begin() + pos + c); pos += c;
+        } else if (!memcmp(m, "GRB", 3)) {
+            if (!need(7)) return EX_STREAM_INCONSISTENT;
+            uint32_t c = get_le32(m + 3); pos += 7;
+            if (!need(c)) return EX_STREAM_INCONSISTENT;
+            jf.garbage.assign(p.begin() + pos, p.begin() + pos + c); pos += c;
+            lf->garbage_default_eoi = false;
+        } else if (!memcmp(m, "PGR", 3) || !memcmp(m, "PGE", 3)) {
+            if (!need(7)) return EX_STREAM_INCONSISTENT;
+            uint32_t c = get_le32(m + 3); pos += 7;
+            if (!need(c)) return EX_STREAM_INCONSISTENT;
+            lf->embedded = m[2] == 'E';
+            lf->has_prefix = true;
+            lf->prefix_garbage.assign(p.begin() + pos, p.begin() + pos + c); pos += c;
+        } else if (!memcmp(m, "SIZ", 3)) {
+            if (!need(7)) return EX_STREAM_INCONSISTENT;
+            lf->jpeg_size = get_le32(m + 3); pos += 7;
+        } else if (!memcmp(m, "EEE", 3)) {
+            if (!need(31)) return EX_STREAM_INCONSISTENT;
+            jf.max_cmp = (int)get_le32(m + 3); jf.max_bpos = (int)get_le32(m + 7); jf.max_sah = (int)get_le32(m + 11);
+            for (int i = 0; i < 4; ++i) jf.max_dpos[i] = (int)get_le32(m + 15 + 4 * i);
+            jf.early_eof = true;
+            pos += 31;
+        } else break;
+    }
+    if (lf->garbage_default_eoi) jf.garbage = {0xFF, 0xD9};
+    const uint8_t* q = d + 28 + zsize;
+    if (memcmp(q, "CMP", 3)) return EX_STREAM_INCONSISTENT;
+    // de-multiplex until the bytes run out (v1 has no end marker; the 4-byte size trailer never parses
+    // as a complete packet -- MuxReader::nextDataPacket, MuxReader.hh:230-283)
+    size_t at = 28 + (size_t)zsize + 3;
+    lf->streams.assign(16, {});
+    while (at + 3 <= n) {
+        uint8_t h = d[at];
+        if (d[at] == 0xFF && d[at + 1] == 0xFE && d[at + 2] == 0xFF) break;
+        int id = h & 15, fl = (h >> 4) & 3;
+        size_t len, hl;
+        if (fl == 0) { len = (size_t)d[at + 1] + ((size_t)d[at + 2] << 8) + 1; hl = 3; }
+        else { len = (size_t)1024 << (2 * fl); hl = 1; }
+        if (at + hl + len + 3 > n) break;   // the reader needs the next 3 header bytes too
+        lf->streams[id].insert(lf->streams[id].end(), d + at + hl, d + at + hl + len);
+        at += hl + len;
+    }
+    return 0;
+}
+
+}  // namespace lep
