@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X (contract: see the build prompt / DESIGN.md).
+
+A "step" = one encode pass + one decode pass of the arithmetic-coding hot path over one batch of
+synthetic 4K 4:2:0 baseline JPEGs whose coefficient frames (encode input) and streams (decode input)
+are already resident in HBM.  value = JPEG file bytes coded per second of wall clock over the K timed
+steps, aggregated over all ranks (weak scaling: every rank codes its own `--images` images)."""
+import argparse
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(jpgs, budget_s=24.0):
+    """Reference binary (oracle/_ref/lepton, built from the real reference) timed on this host, one core:
+    `lepton -singlethread -unjailed -skipverify` encode then decode per file; also the arithmetic-coding
+    interval alone (TS_ARITH_STARTED..FINISHED from its stderr) for a like-for-like hot-path number."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "lepton")
+    if not os.path.exists(ref):
+        return None
+    tmp = tempfile.mkdtemp(prefix="lepbench")
+    enc_s = dec_s = arith_enc = arith_dec = 0.0
+    nbytes = n = 0
+    t_start = time.perf_counter()
+
+    def arith(err):
+        st = [float(x) for x in re.findall(r"TS_ARITH_STARTED\s+\(\d+\)\s+([0-9.]+)", err)]
+        fi = [float(x) for x in re.findall(r"TS_ARITH_FINISHED\s+\(\d+\)\s+([0-9.]+)", err)]
+        return sum(f - s for s, f in zip(st, fi) if f > s)
+
+    for i, j in enumerate(jpgs):
+        jp, lp, bp = (os.path.join(tmp, "%d.%s" % (i, e)) for e in ("jpg", "lep", "back.jpg"))
+        open(jp, "wb").write(j)
+        t0 = time.perf_counter()
+        r = subprocess.run([ref, "-singlethread", "-unjailed", "-skipverify", jp, lp], capture_output=True, text=True)
+        t1 = time.perf_counter()
+        if r.returncode:
+            continue
+        r2 = subprocess.run([ref, "-singlethread", "-unjailed", lp, bp], capture_output=True, text=True)
+        t2 = time.perf_counter()
+        if r2.returncode or open(bp, "rb").read() != j:
+            continue
+        enc_s += t1 - t0; dec_s += t2 - t1
+        arith_enc += arith(r.stderr); arith_dec += arith(r2.stderr)
+        nbytes += len(j); n += 1
+        if time.perf_counter() - t_start > budget_s:
+            break
+    if not n:
+        return None
+    mb = nbytes / 1e6
+    return {
+        "value": round(mb / (enc_s + dec_s), 3), "unit": "MB/s", "cores": 1, "kind": "reference",
+        "sample": "%d of the bench's 4K JPEGs (%.1f MB), reference `lepton -singlethread -unjailed -skipverify`, encode then decode, whole process wall clock" % (n, mb),
+        "encode_MBps": round(mb / enc_s, 3), "decode_MBps": round(mb / dec_s, 3),
+        "hot_path_only_encode_MBps": round(mb / arith_enc, 3) if arith_enc else None,
+        "hot_path_only_decode_MBps": round(mb / arith_dec, 3) if arith_dec else None,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images", type=int, default=32, help="4K images per GPU per step")
+    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic images per GPU (replicated up to --images)")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import __graft_entry__ as ge
+    from lepton_amd import abi, corpus, shard
+    from lepton_amd.codec import GpuCodec, JpegImage
+
+    rank, local_rank, world = shard.dist_env()
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        ge.build()
+    if dist:
+        dist.barrier()
+    L = abi.lib()
+    codec = GpuCodec(local_rank)
+    g = codec.handle
+
+    # ---- corpus: weak scaling, every rank has its own distinct images
+    t0 = time.perf_counter()
+    nuniq = max(1, min(args.unique, args.images))
+    seeds = shard.weak_seeds(nuniq, rank, 20001)
+    uniq = corpus.make_corpus(nuniq, args.width, args.height, seeds[0])
+    log("[rank %d] corpus: %d unique %dx%d JPEGs in %.1fs" % (rank, nuniq, args.width, args.height, time.perf_counter() - t0))
+    imgs = [JpegImage(j) for j in uniq]
+    plans = [im.plan() for im in imgs]
+    order = [i % nuniq for i in range(args.images)]
+    jpeg_bytes = sum(len(uniq[i]) for i in order)
+    nimg = len(order)
+
+    # ---- make everything resident in HBM
+    def dmalloc(n):
+        p = C.c_void_p()
+        rc = L.lep_gpu_malloc(g, n, C.byref(p))
+        assert rc == 0, codec.last_error()
+        return p.value
+
+    descs = (abi.ImageDesc * nimg)()
+    dec_descs = (abi.ImageDesc * nimg)()
+    flat = []
+    nblocks = 0
+    for k, u in enumerate(order):
+        d = imgs[u].desc
+        C.memmove(C.byref(descs[k]), C.byref(d), C.sizeof(abi.ImageDesc))
+        C.memmove(C.byref(dec_descs[k]), C.byref(d), C.sizeof(abi.ImageDesc))
+        for c in range(d.ncomp):
+            n = d.nblocks(c) * 128
+            p = dmalloc(n)
+            assert L.lep_gpu_memcpy_h2d(g, p, d.blocks[c], n) == 0
+            descs[k].blocks[c] = p
+            q = dmalloc(n)
+            assert L.lep_gpu_memset(g, q, 0, n) == 0
+            dec_descs[k].blocks[c] = q
+        nblocks += d.total_blocks()
+        for s in plans[u]:
+            flat.append(abi.Segment(k, s.luma_y_start, s.luma_y_end, s.is_last))
+    nseg = len(flat)
+    segs = (abi.Segment * nseg)(*flat)
+    offs = (C.c_uint64 * (nseg + 1))()
+    for i, s in enumerate(flat):
+        d = descs[s.image]
+        per = len(plans[order[s.image]])
+        offs[i + 1] = offs[i] + ((d.total_blocks() * 40 // per + 65536 + 255) & ~255)
+    d_streams = dmalloc(offs[nseg])
+    d_len = dmalloc(4 * nseg)
+    d_status = dmalloc(4 * nseg)
+
+    def step():
+        rc = L.lep_gpu_encode_device(g, descs, nimg, segs, nseg, d_streams, offs, d_len, d_status, None)
+        assert rc == 0, (rc, codec.last_error())
+        rc = L.lep_gpu_sync(g)
+        assert rc == 0, codec.last_error()
+        e_ms = L.lep_gpu_last_kernel_ms(g)
+        rc = L.lep_gpu_decode_device(g, dec_descs, nimg, segs, nseg, d_streams, offs, d_len, d_status, None)
+        assert rc == 0, (rc, codec.last_error())
+        rc = L.lep_gpu_sync(g)
+        assert rc == 0, codec.last_error()
+        return e_ms, L.lep_gpu_last_kernel_ms(g)
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        L.lep_gpu_sync(g)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    enc_ms = dec_ms = 0.0
+    for _ in range(args.steps):
+        e, d = step()
+        enc_ms += e; dec_ms += d
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # ---- validity (outside the timed region): statuses, stream parity with the oracle, exact round trip
+    status = (C.c_int32 * nseg)()
+    lens = (C.c_uint32 * nseg)()
+    L.lep_gpu_memcpy_d2h(g, status, d_status, 4 * nseg)
+    L.lep_gpu_memcpy_d2h(g, lens, d_len, 4 * nseg)
+    assert not any(status), "segment exit codes: %s" % sorted(set(status))
+    stream_bytes = sum(lens)
+    import hashlib
+    for k in range(min(nimg, nuniq)):
+        d = imgs[order[k]].desc
+        for c in range(d.ncomp):
+            n = d.nblocks(c) * 128
+            buf = C.create_string_buffer(n)
+            L.lep_gpu_memcpy_d2h(g, buf, dec_descs[k].blocks[c], n)
+            assert hashlib.md5(buf.raw).digest() == hashlib.md5(C.string_at(d.blocks[c], n)).digest(), "decode(encode(x)) != x"
+    parity = "roundtrip-only"
+    try:
+        import oracle_binding as ob
+        want, bins = ob.oracle_encode(imgs[0].desc, plans[0])
+        base = 0
+        for i, w in enumerate(want):
+            buf = C.create_string_buffer(lens[base + i])
+            L.lep_gpu_memcpy_d2h(g, buf, d_streams + offs[base + i], lens[base + i])
+            assert buf.raw == w, "GPU stream %d differs from the oracle" % i
+        parity = "streams==oracle(image 0) + exact round trip(all unique images)"
+        bins_per_image = bins
+    except ImportError:
+        bins_per_image = None
+
+    agg = shard.aggregate({"jpeg_bytes": jpeg_bytes, "images": nimg, "segments": nseg, "blocks": nblocks,
+                           "stream_bytes": stream_bytes, "elapsed_max": elapsed, "enc_ms_max": enc_ms, "dec_ms_max": dec_ms},
+                          backend_device=("cuda:%d" % local_rank) if dist else None)
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+    K = args.steps
+    t = agg["elapsed_max"]
+    mb = agg["jpeg_bytes"] / 1e6
+    value = mb * K / t
+    b_alg = 128.0 * agg["blocks"] / world + agg["stream_bytes"] / world      # per launch, one GPU
+    enc_kernel_s = agg["enc_ms_max"] / K / 1e3
+    dec_kernel_s = agg["dec_ms_max"] / K / 1e3
+    dominant = "decode" if dec_kernel_s >= enc_kernel_s else "encode"
+    dom_s = max(enc_kernel_s, dec_kernel_s)
+    achieved = b_alg / dom_s / 1e9
+    out = {
+        "metric": "encode+decode MB/s (JPEG bytes/sec), bit-exact round trip", "value": round(value, 3), "unit": "MB/s",
+        "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(t / K * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16/u8 (integer coder, no floating point)",
+        "data": "synthetic (seeded PIL baseline JPEGs, q90 4:2:0; %d distinct per GPU replicated to %d)" % (nuniq, args.images),
+        "config": {"workload": "%d x %dx%d 4:2:0 baseline JPEG corpus per GPU, %d thread segments, coefficient frames and streams resident in HBM"
+                   % (args.images, args.width, args.height, int(agg["segments"] / world)),
+                   "images_per_gpu": args.images, "segments_per_gpu": int(agg["segments"] / world), "jpeg_MB_per_step": round(mb, 3),
+                   "parallelism": "image-sharded x%d, one wavefront per thread segment" % world, "parity": parity},
+        "encode_MBps": round(mb / (agg["enc_ms_max"] / K / 1e3), 3), "decode_MBps": round(mb / (agg["dec_ms_max"] / K / 1e3), 3),
+        "roofline": {"bound": "hbm", "kernel": "lep_segment_kernel<%s>" % dominant, "achieved": round(achieved, 4), "peak": 8000.0,
+                     "unit": "GB/s", "frac": round(achieved / 8000.0, 7), "traffic": None,
+                     "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms": round(dom_s * 1e3, 3),
+                     "encode_kernel_ms": round(enc_kernel_s * 1e3, 3), "decode_kernel_ms": round(dec_kernel_s * 1e3, 3),
+                     "note": "dependency-latency bound integer coder; see bins_per_s"},
+    }
+    if bins_per_image:
+        bins_launch = bins_per_image * args.images
+        out["bins_per_s"] = {"encode": round(bins_launch / enc_kernel_s / 1e6, 1), "decode": round(bins_launch / dec_kernel_s / 1e6, 1), "unit": "Mbins/s (per GPU, image 0's bin count x images)"}
+    if world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline(uniq)
+        if cb:
+            out["cpu_baseline"] = cb
+    print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,22 @@ uint32_t lep_file_jpeg_size(const lep_file *f);
 /* coefficient frame -> original JPEG bytes (recode_baseline_jpeg, src/lepton/recoder.cc:694-889) */
 int lep_file_recode(lep_file *f, lep_bytes *out);
 
+
+/* .lep framing pieces, exposed for callers that assemble containers themselves */
+typedef struct lep_handoff {           /* ThreadHandoff, src/lepton/thread_handoff.hh:8-39 */
+    uint16_t luma_y_start, luma_y_end;
+    uint32_t segment_size;
+    uint8_t overhang_byte, num_overhang_bits;
+    int16_t last_dc[4];
+} lep_handoff;
+/* 'H', n, then n 16-byte records (ThreadHandoff::serialize / deserialize, thread_handoff.cc:4-76) */
+int lep_handoffs_serialize(const lep_handoff *h, int n, uint8_t *out, size_t out_cap);
+int lep_handoffs_parse(const uint8_t *data, size_t len, lep_handoff *out, int out_cap);
+/* MuxWriter policy (src/io/MuxReader.hh:336-522) fed in the encoder's slice order (vp8_encoder.cc:575-594) */
+int lep_mux(const lep_bytes *streams, int nstreams, int version, lep_bytes *out);
+/* MuxReader (src/io/MuxReader.hh:230-283): packets until the data runs out; streams[16] are malloc'd */
+int lep_demux(const uint8_t *data, size_t len, lep_bytes *streams16);
+
 /* ---- layer 3: whole files ------------------------------------------------------------------- */
 int lep_compress(lep_gpu *g, const uint8_t *jpg, size_t len, lep_bytes *out);
 int lep_decompress(lep_gpu *g, const uint8_t *lepdata, size_t len, lep_bytes *out);

@@ -38,6 +38,11 @@ class Segment(C.Structure):
     _fields_ = [("image", C.c_int32), ("luma_y_start", C.c_int32), ("luma_y_end", C.c_int32), ("is_last", C.c_int32)]
 
 
+class Handoff(C.Structure):
+    _fields_ = [("luma_y_start", C.c_uint16), ("luma_y_end", C.c_uint16), ("segment_size", C.c_uint32),
+                ("overhang_byte", C.c_uint8), ("num_overhang_bits", C.c_uint8), ("last_dc", C.c_int16 * 4)]
+
+
 class Bytes(C.Structure):
     _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("cap", C.c_size_t)]
 
@@ -96,6 +101,10 @@ def lib():
         L.lep_gpu_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
         L.lep_compress.argtypes = [vp, vp, C.c_size_t, P(Bytes)]
         L.lep_decompress.argtypes = [vp, vp, C.c_size_t, P(Bytes)]
+        L.lep_handoffs_serialize.argtypes = [P(Handoff), C.c_int, vp, C.c_size_t]
+        L.lep_handoffs_parse.argtypes = [vp, C.c_size_t, P(Handoff), C.c_int]
+        L.lep_mux.argtypes = [P(Bytes), C.c_int, C.c_int, P(Bytes)]
+        L.lep_demux.argtypes = [vp, C.c_size_t, P(Bytes)]
         _lib = L
     return _lib
 
@@ -106,5 +115,5 @@ EXPORTS = [
     "lep_gpu_free", "lep_gpu_memcpy_h2d", "lep_gpu_memcpy_d2h", "lep_gpu_memset", "lep_jpeg_open", "lep_jpeg_close",
     "lep_jpeg_describe", "lep_jpeg_plan", "lep_jpeg_write_lep", "lep_file_open", "lep_file_close", "lep_file_describe",
     "lep_file_segments", "lep_file_jpeg_size", "lep_file_recode", "lep_compress", "lep_decompress", "lep_free",
-    "lep_version",
+    "lep_version", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
 ]

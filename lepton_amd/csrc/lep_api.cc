@@ -148,3 +148,96 @@ int lep_file_recode(lep_file* f, lep_bytes* out) {
 }
 
 }  // extern "C"
+
+// ---- layer 3: whole files (JPEG -> .lep -> JPEG) through the GPU hot path ---------------------------
+extern "C" {
+
+int lep_compress(lep_gpu* g, const uint8_t* jpg, size_t len, lep_bytes* out) {
+    if (!g) return LEP_GPU_ERROR;
+    lep_jpeg* j = nullptr;
+    int rc = lep_jpeg_open(jpg, len, 1, &j);
+    if (rc) return rc;
+    std::unique_ptr<lep_jpeg> hold(j);
+    if (j->jf.progressive_needed) return LEP_PROGRESSIVE_UNSUPPORTED;   // hot path is identical; host re-coder is sequential-only so far
+    lep_image_desc d;
+    lep_jpeg_describe(j, &d);
+    lep_segment segs[LEP_MAX_SEGMENTS];
+    int n = lep_jpeg_plan(j, 0, segs, 0);
+    size_t blocks = 0;
+    for (int c = 0; c < d.ncomp; ++c) blocks += (size_t)d.width_blocks[c] * d.height_blocks[c];
+    std::vector<std::vector<uint8_t>> bufs(n);
+    lep_bytes streams[LEP_MAX_SEGMENTS];
+    int32_t status[LEP_MAX_SEGMENTS];
+    for (int i = 0; i < n; ++i) {
+        bufs[i].resize(blocks * 160 / n + blocks * 16 + 65536);   // worst case is far below 2 bytes per coefficient
+        streams[i].data = bufs[i].data(); streams[i].cap = bufs[i].size(); streams[i].len = 0;
+    }
+    rc = lep_gpu_encode_host(g, &d, 1, segs, n, streams, status);
+    if (rc) return rc;
+    return lep_jpeg_write_lep(j, 0, streams, n, out);
+}
+
+int lep_decompress(lep_gpu* g, const uint8_t* lepdata, size_t len, lep_bytes* out) {
+    if (!g) return LEP_GPU_ERROR;
+    lep_file* f = nullptr;
+    int rc = lep_file_open(lepdata, len, &f);
+    if (rc) return rc;
+    std::unique_ptr<lep_file> hold(f);
+    lep_image_desc d;
+    lep_file_describe(f, &d);
+    lep_segment segs[LEP_MAX_SEGMENTS];
+    lep_bytes streams[LEP_MAX_SEGMENTS];
+    int32_t status[LEP_MAX_SEGMENTS];
+    int n = lep_file_segments(f, segs, streams, 0);
+    rc = lep_gpu_decode_host(g, &d, 1, segs, n, streams, status);
+    if (rc) return rc;
+    return lep_file_recode(f, out);
+}
+
+}  // extern "C"
+
+// ---- framing pieces -----------------------------------------------------------------------------
+extern "C" {
+
+int lep_handoffs_serialize(const lep_handoff* h, int n, uint8_t* out, size_t out_cap) {
+    if (n < 0 || n > 255 || out_cap < (size_t)n * 16 + 2) return LEP_BUFFER_TOO_SMALL;
+    std::vector<lep::Handoff> v(n);
+    for (int i = 0; i < n; ++i) {
+        v[i].luma_y_start = h[i].luma_y_start; v[i].luma_y_end = h[i].luma_y_end; v[i].segment_size = h[i].segment_size;
+        v[i].overhang_byte = h[i].overhang_byte; v[i].num_overhang_bits = h[i].num_overhang_bits;
+        memcpy(v[i].last_dc, h[i].last_dc, sizeof v[i].last_dc);
+    }
+    std::vector<uint8_t> b = lep::serialize_handoffs(v);
+    memcpy(out, b.data(), b.size());
+    return (int)b.size();
+}
+
+int lep_handoffs_parse(const uint8_t* data, size_t len, lep_handoff* out, int out_cap) {
+    std::vector<lep::Handoff> v;
+    if (!lep::deserialize_handoffs(data, len, &v)) return -LEP_VERSION_UNSUPPORTED;
+    if ((int)v.size() > out_cap) return -LEP_BUFFER_TOO_SMALL;
+    for (size_t i = 0; i < v.size(); ++i) {
+        out[i].luma_y_start = v[i].luma_y_start; out[i].luma_y_end = v[i].luma_y_end; out[i].segment_size = v[i].segment_size;
+        out[i].overhang_byte = v[i].overhang_byte; out[i].num_overhang_bits = v[i].num_overhang_bits;
+        memcpy(out[i].last_dc, v[i].last_dc, sizeof v[i].last_dc);
+    }
+    return (int)v.size();
+}
+
+int lep_mux(const lep_bytes* streams, int nstreams, int version, lep_bytes* out) {
+    std::vector<std::vector<uint8_t>> st(nstreams);
+    for (int i = 0; i < nstreams; ++i) st[i].assign(streams[i].data, streams[i].data + streams[i].len);
+    std::vector<uint8_t> o;
+    lep::mux_streams(st, version, &o);
+    return to_bytes(o, out);
+}
+
+int lep_demux(const uint8_t* data, size_t len, lep_bytes* streams16) {
+    std::vector<std::vector<uint8_t>> st;
+    lep::demux_packets(data, len, 0, &st);
+    for (int i = 0; i < 16; ++i)
+        if (int rc = to_bytes(st[i], &streams16[i])) return rc;
+    return 0;
+}
+
+}  // extern "C"

@@ -281,6 +281,21 @@ int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::v
 }
 
 // ------------------------------------------------------------------------------------------------
+void demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vector<uint8_t>>* streams) {
+    streams->assign(16, {});
+    while (at + 3 <= n) {
+        uint8_t h = d[at];
+        if (d[at] == 0xFF && d[at + 1] == 0xFE && d[at + 2] == 0xFF) break;
+        int id = h & 15, fl = (h >> 4) & 3;
+        size_t len, hl;
+        if (fl == 0) { len = (size_t)d[at + 1] + ((size_t)d[at + 2] << 8) + 1; hl = 3; }
+        else { len = (size_t)1024 << (2 * fl); hl = 1; }
+        if (at + hl + len + 3 > n) break;   // the reader needs the next 3 header bytes too
+        (*streams)[id].insert((*streams)[id].end(), d + at + hl, d + at + hl + len);
+        at += hl + len;
+    }
+}
+
 int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
     if (n < 28 || d[0] != 0xCF || d[1] != 0x84) return EX_VERSION_UNSUPPORTED;
     lf->version = d[2];
@@ -357,18 +372,20 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
     // de-multiplex until the bytes run out (v1 has no end marker; the 4-byte size trailer never parses
     // as a complete packet -- MuxReader::nextDataPacket, MuxReader.hh:230-283)
     size_t at = 28 + (size_t)zsize + 3;
-    lf->streams.assign(16, {});
-    while (at + 3 <= n) {
-        uint8_t h = d[at];
-        if (d[at] == 0xFF && d[at + 1] == 0xFE && d[at + 2] == 0xFF) break;
-        int id = h & 15, fl = (h >> 4) & 3;
-        size_t len, hl;
-        if (fl == 0) { len = (size_t)d[at + 1] + ((size_t)d[at + 2] << 8) + 1; hl = 3; }
-        else { len = (size_t)1024 << (2 * fl); hl = 1; }
-        if (at + hl + len + 3 > n) break;   // the reader needs the next 3 header bytes too
-        lf->streams[id].insert(lf->streams[id].end(), d + at + hl, d + at + hl + len);
-        at += hl + len;
+    if (lf->segs.empty()) {
+        // pre-hand-off files: count byte + (count-1) LE16 luma split rows follow "CMP"
+        // (VP8ComponentDecoder::initialize_decoder_state, src/lepton/vp8_decoder.cc:337-364)
+        if (at >= n) return EX_SHORT_READ;
+        unsigned mark = d[at++];
+        if (mark == 0) return EX_THREADING_PARTIAL_MCU;
+        if (at + 2 * (mark - 1) > n) return EX_SHORT_READ;
+        Handoff th;
+        th.num_overhang_bits = 0xff;   // LEGACY_OVERHANG_BITS: state is carried from the previous segment
+        lf->segs.assign(mark, th);
+        for (unsigned i = 0; i + 1 < mark; ++i, at += 2) lf->segs[i].luma_y_end = (uint16_t)(d[at] | (d[at + 1] << 8));
+        for (unsigned i = 1; i < mark; ++i) lf->segs[i].luma_y_start = lf->segs[i - 1].luma_y_end;
     }
+    demux_packets(d, n, at, &lf->streams);
     return 0;
 }
 

@@ -34,6 +34,7 @@ void mux_streams(const std::vector<std::vector<uint8_t>>& streams, int version, 
 int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::vector<std::vector<uint8_t>>& streams,
               std::vector<uint8_t>* out);
 int parse_lep(const uint8_t* d, size_t n, LepFile* lf);
+void demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vector<uint8_t>>* streams);
 
 // decode side (jpeg_recode.cc): coefficients -> JPEG bytes
 int recode_jpeg(LepFile* lf, std::vector<uint8_t>* out);

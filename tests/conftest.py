@@ -1,0 +1,45 @@
+import glob
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REF_IMAGES = "/root/reference/images"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    import __graft_entry__ as g
+
+    g.build()
+
+
+def golden_cases():
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    return sorted(k for k, v in man.items() if v.get("encode_exit") == 0)
+
+
+def golden(name):
+    return (open(os.path.join(GOLDEN, name + ".jpg"), "rb").read(), open(os.path.join(GOLDEN, name + ".lep"), "rb").read())
+
+
+def reference_jpegs():
+    """baseline fixtures of the reference's own test-suite (present only in the build container)"""
+    skip = {"arithmetic", "badzerorun", "androidprogressive", "iphoneprogressive", "iphoneprogressive2"}
+    return sorted(p for p in glob.glob(os.path.join(REF_IMAGES, "*.jpg")) if os.path.basename(p)[:-4] not in skip)
+
+
+@pytest.fixture(scope="session")
+def gpu_codec():
+    from lepton_amd.codec import GpuCodec
+
+    return GpuCodec(0)

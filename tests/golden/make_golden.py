@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.jpg (small seeded PIL JPEGs covering the edge cases the reference's own
+test-suite covers: grayscale, 4:4:4 / 4:2:2 / 4:2:0, restart intervals, odd sizes, one-block-wide
+images, truncated files, trailing garbage) and, for each, the .lep the REAL reference produces
+(oracle/_ref/lepton, built from /root/reference by oracle/Makefile.ref) plus, for the decode
+direction, the JPEG the reference restores from that .lep (== input except for truncated inputs).
+Run here (where /root/reference exists); the fixtures travel to the GPU box."""
+import hashlib
+import io
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from lepton_amd import corpus  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "lepton")
+
+
+def pil_jpeg(w, h, seed, mode="RGB", **save):
+    import numpy as np
+    from PIL import Image
+
+    base = corpus.synth_jpeg(w, h, seed, quality=95, subsampling="4:4:4")
+    img = Image.open(io.BytesIO(base)).convert(mode)
+    buf = io.BytesIO()
+    img.save(buf, format="JPEG", **save)
+    return buf.getvalue()
+
+
+CASES = {
+    "c420_160x120": lambda: corpus.synth_jpeg(160, 120, 101),
+    "c420_odd_203x149": lambda: corpus.synth_jpeg(203, 149, 102, quality=85),
+    "c444_96x80": lambda: pil_jpeg(96, 80, 103, quality=92, subsampling="4:4:4"),
+    "c422_128x72": lambda: pil_jpeg(128, 72, 104, quality=80, subsampling="4:2:2"),
+    "gray_120x88": lambda: pil_jpeg(120, 88, 105, mode="L", quality=90),
+    "rst_c420_176x112": lambda: pil_jpeg(176, 112, 106, quality=88, subsampling="4:2:0", restart_marker_blocks=5),
+    "rst_rows_gray_64x96": lambda: pil_jpeg(64, 96, 107, mode="L", quality=75, restart_marker_rows=1),
+    "one_block_8x8": lambda: pil_jpeg(8, 8, 108, quality=90, subsampling="4:4:4"),
+    "one_col_8x64": lambda: pil_jpeg(8, 64, 109, quality=90, subsampling="4:4:4"),
+    "one_col_420_16x80": lambda: pil_jpeg(16, 80, 110, quality=90, subsampling="4:2:0"),
+    "q100_64x64": lambda: pil_jpeg(64, 64, 111, quality=100, subsampling="4:2:0"),
+    "q30_256x256_4seg": lambda: corpus.synth_jpeg(640, 480, 112, quality=97),   # > 125 kB of scan -> 2..4 segments
+    "trailing_garbage": lambda: corpus.synth_jpeg(96, 96, 113) + b"tail-bytes\x00\xff\xd9more",
+    "truncated": lambda: corpus.synth_jpeg(160, 160, 114)[:-1500],
+    "truncated_short": lambda: corpus.synth_jpeg(128, 128, 115)[:2600],
+}
+
+
+def main():
+    manifest = {}
+    for name, make in CASES.items():
+        jpg = make()
+        jp = os.path.join(HERE, name + ".jpg")
+        lp = os.path.join(HERE, name + ".lep")
+        open(jp, "wb").write(jpg)
+        if os.path.exists(lp):
+            os.unlink(lp)
+        r = subprocess.run([REF, "-unjailed", "-skipverify", jp, lp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        entry = {"jpg_md5": hashlib.md5(jpg).hexdigest(), "jpg_size": len(jpg), "encode_exit": r.returncode}
+        if r.returncode == 0:
+            lep = open(lp, "rb").read()
+            back = subprocess.run([REF, "-unjailed", lp, "/tmp/_golden_back.jpg"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            restored = open("/tmp/_golden_back.jpg", "rb").read() if back.returncode == 0 else b""
+            entry.update(lep_md5=hashlib.md5(lep).hexdigest(), lep_size=len(lep), segments=lep[4],
+                         restored_md5=hashlib.md5(restored).hexdigest(), restored_equals_input=restored == jpg)
+        elif os.path.exists(lp):
+            os.unlink(lp)
+        manifest[name] = entry
+        print(name, entry)
+    json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

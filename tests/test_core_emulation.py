@@ -1,0 +1,44 @@
+"""The kernel source (lepton_amd/csrc/lep_core.h) compiled with g++ and single-stepped on the CPU
+(tests/emu/core_emu.cc) must produce the oracle's streams and frames.  Catches logic errors in the
+device code without a GPU; the real GPU parity tests are in test_gpu_parity.py."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+import oracle_binding as ob
+from conftest import ROOT, golden, golden_cases
+from lepton_amd.codec import JpegImage
+
+EMU_SO = os.path.join(ROOT, "tests", "emu", "libcore_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    src = os.path.join(ROOT, "tests", "emu", "core_emu.cc")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", EMU_SO, src])
+    return C.CDLL(EMU_SO)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_kernel_source_on_cpu_matches_oracle(emu, name):
+    jpg, _ = golden(name)
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    for s, w in zip(segs, want):
+        cap = len(w) + 4096
+        buf = C.create_string_buffer(cap)
+        n, nb = C.c_uint32(0), C.c_uint32(0)
+        rc = emu.emu_encode_segment(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, cap, C.byref(n), C.byref(nb))
+        assert rc == 0 and buf.raw[: n.value] == w
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    for s, w in zip(segs, want):
+        assert emu.emu_decode_segment(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), None) == 0
+    for c in range(d.ncomp):
+        n = d.coded_blocks[c] * 128
+        assert C.string_at(d.blocks[c], n) == orig[c][:n]

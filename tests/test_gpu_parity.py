@@ -1,0 +1,94 @@
+"""Parity tests proper: the HIP path (through the C ABI) against (1) .lep files written by the real
+reference (tests/golden), (2) the CPU oracle on seeded inputs, (3) size-independent properties at
+BASELINE.json sizes (encode -> decode round trip, bit-exact JPEG restoration).  Bar: bit-exact."""
+import ctypes as C
+import hashlib
+
+import pytest
+
+import oracle_binding as ob
+from conftest import golden, golden_cases
+from lepton_amd import abi, corpus
+from lepton_amd.codec import GpuCodec, JpegImage, LepFile, LeptonError
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_loaded_and_gpu_present(gpu_codec):
+    assert b"gfx950" in abi.lib().lep_version()
+    assert gpu_codec.handle
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_gpu_encode_equals_reference_lep(gpu_codec, name):
+    jpg, lep = golden(name)
+    assert gpu_codec.compress(jpg) == lep
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_gpu_decode_restores_reference_jpeg(gpu_codec, name):
+    jpg, lep = golden(name)
+    assert gpu_codec.decompress(lep) == jpg
+
+
+def test_gpu_batch_streams_equal_oracle(gpu_codec):
+    """mixed geometry batch in ONE launch: every segment's stream equals the oracle's"""
+    jpgs = [corpus.synth_jpeg(w, h, s, quality=q) for (w, h, s, q) in
+            [(320, 240, 1, 90), (203, 149, 2, 75), (640, 360, 3, 95), (64, 64, 4, 50), (1280, 720, 5, 92)]]
+    imgs = [JpegImage(j) for j in jpgs]
+    plans = [im.plan() for im in imgs]
+    got = gpu_codec.encode(imgs, plans)
+    for im, p, g in zip(imgs, plans, got):
+        want, _ = ob.oracle_encode(im.desc, p)
+        assert g == want
+    # and the decode direction through whole files
+    for im, g, j in zip(imgs, got, jpgs):
+        assert gpu_codec.decompress(im.write_lep(g)) == j
+
+
+def test_gpu_1080p_equals_oracle_and_roundtrips(gpu_codec):
+    jpg = corpus.synth_jpeg(1920, 1080, 10000)
+    img = JpegImage(jpg)
+    plan = img.plan()
+    assert len(plan) == 8
+    streams = gpu_codec.encode([img], [plan])[0]
+    want, _ = ob.oracle_encode(img.desc, plan)
+    assert streams == want
+    assert gpu_codec.decompress(img.write_lep(streams)) == jpg
+
+
+def test_gpu_4k_roundtrip_property(gpu_codec):
+    """BASELINE config 2 (single 4K 4:2:0): no oracle at this size in the GPU suite -- the property is the
+    bit-exact round trip JPEG -> .lep -> JPEG plus decode(encode(frame)) == frame."""
+    jpg = corpus.synth_jpeg(3840, 2160, 1234)
+    img = JpegImage(jpg)
+    plan = img.plan()
+    assert len(plan) == 8 and img.desc.total_blocks() == 194400
+    lep = gpu_codec.compress(jpg)
+    f = LepFile(lep)
+    gpu_codec.decode([f])
+    for c in range(3):
+        n = img.desc.nblocks(c) * 128
+        assert hashlib.md5(C.string_at(f.desc.blocks[c], n)).digest() == hashlib.md5(C.string_at(img.desc.blocks[c], n)).digest()
+    assert f.recode() == jpg
+    assert int.from_bytes(lep[-4:], "little") == len(lep)
+
+
+def test_gpu_rejects_out_of_range_coefficient(gpu_codec):
+    """COEFFICIENT_OUT_OF_RANGE (exit code 6) like encoder.cc:124,265 when |coef| needs > 11 bits"""
+    img = JpegImage(corpus.synth_jpeg(64, 64, 9))
+    C.cast(img.desc.blocks[0], C.POINTER(C.c_int16))[5] = 4096
+    with pytest.raises(LeptonError) as e:
+        gpu_codec.encode([img], [img.plan()])
+    assert e.value.code == 6
+
+
+def test_gpu_decode_of_garbage_stream_is_contained(gpu_codec):
+    """a corrupt stream must come back as an error code or a (wrong) frame, never hang or crash"""
+    jpg, lep = golden("c420_160x120")
+    f = LepFile(lep)
+    f.streams[0] = bytes(len(f.streams[0]))
+    try:
+        gpu_codec.decode([f])
+    except LeptonError as e:
+        assert e.code in (6, 7, 39)
