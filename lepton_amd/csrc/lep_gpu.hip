@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@
 
 #define LEP_DEV __device__ __forceinline__
 #include "lep_core.h"
+#include "lep_enc2.h"
 
 using namespace lepdev;
 
@@ -63,6 +65,28 @@ __global__ __launch_bounds__(64) void lep_segment_kernel(const ImageDev* __restr
     bins[s] = sc.nbins;
 }
 
+// v2 encoder: wave-cooperative (lep_enc2.h); same arguments as lep_segment_kernel<false>
+__global__ __launch_bounds__(64) void lep_encode_v2_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
+                                                           uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
+                                                           uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
+    __shared__ EncShared sh;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const SegDev seg = segs[s];
+    const ImageDev* img = images + seg.image;
+    uint32_t* model = models + (size_t)s * kModelBranches;
+    NSum* ns = ns_area + ns_offsets[s];
+    reset_segment_state(model, ns, img->ns_total, lane);
+    __syncthreads();
+    EncWave w;
+    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, seg.stream_cap);
+    if (lane != 0) return;
+    uint32_t n = rc ? 0 : w.bc.finish();
+    if (!rc && w.bc.overflow) rc = LEP_BUFFER_TOO_SMALL;
+    stream_len[s] = n;
+    status[s] = rc;
+    bins[s] = w.nbins;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -71,6 +95,7 @@ struct lep_gpu {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int encode_kernel = 2;   // 2 = wave-cooperative (default), 1 = single-lane reference kernel (LEP_ENCODE_KERNEL=1)
     std::string err;
     // grow-only device workspace
     void* d_models = nullptr; size_t models_bytes = 0;
@@ -142,9 +167,14 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     g->d_bins = (uint32_t*)(meta + o_bins);
     g->h_bins.assign(nseg, 0);
     HIPCHK(g, hipEventRecord(g->ev0, st));
-    hipLaunchKernelGGL(lep_segment_kernel<DEC>, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                       (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
-                       d_streams, d_stream_len, d_status, g->d_bins);
+    if (!DEC && g->encode_kernel == 2)
+        hipLaunchKernelGGL(lep_encode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
+                           (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                           d_streams, d_stream_len, d_status, g->d_bins);
+    else
+        hipLaunchKernelGGL(lep_segment_kernel<DEC>, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
+                           (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                           d_streams, d_stream_len, d_status, g->d_bins);
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
@@ -156,6 +186,7 @@ extern "C" {
 int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
+    if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = atoi(e) == 1 ? 1 : 2;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||

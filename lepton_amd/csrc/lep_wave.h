@@ -1,0 +1,84 @@
+// lep_wave.h -- tiny SPMD layer so that wave-cooperative kernel code is written once and
+//   * compiles for gfx950 with hipcc (one wavefront = 64 lanes, cross-lane ops are ballot / DPP shuffles),
+//   * compiles with g++ as a lane-loop emulation (tests/emu) so kernel logic is checked without a GPU.
+// Rules the kernel code follows: per-lane state lives in LV() variables; code that touches it sits inside
+// LANES(l){...}; cross-lane primitives (wave_*) are called only BETWEEN LANES regions, in wave-uniform
+// control flow; data handed between lanes through shared memory is separated by WSYNC().
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)   // both hipcc passes: these are __device__ functions, never called from host code
+#define LEP_ON_GPU 1
+#define LEP_NL 1
+#define LEP_LI(l) 0
+#define LANES(l) for (int l = (int)(threadIdx.x & 63), lep_once_ = 1; lep_once_; lep_once_ = 0)
+#define WSYNC() __syncthreads()
+#define WDEV __device__ __forceinline__
+#else
+#define LEP_ON_GPU 0
+#define LEP_NL 64
+#define LEP_LI(l) (l)
+#define LANES(l) for (int l = 0; l < 64; ++l)
+#define WSYNC() ((void)0)
+#define WDEV inline
+#endif
+
+#define LV(T, name) T name[LEP_NL]
+#define L(name) name[LEP_LI(l)]
+
+namespace lepwave {
+
+WDEV uint64_t wave_ballot(const int* pred) {
+#if LEP_ON_GPU
+    return __ballot(pred[0] != 0);
+#else
+    uint64_t m = 0;
+    for (int i = 0; i < 64; ++i) m |= (uint64_t)(pred[i] != 0) << i;
+    return m;
+#endif
+}
+
+// exclusive prefix sum over lanes; returns the total
+WDEV int wave_excl_scan(const int* in, int* out) {
+#if LEP_ON_GPU
+    const int lane = (int)(threadIdx.x & 63);
+    int v = in[0], s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(s, d, 64);
+        if (lane >= d) s += t;
+    }
+    out[0] = s - v;
+    return __builtin_amdgcn_readfirstlane(__shfl(s, 63, 64));
+#else
+    int s = 0;
+    for (int i = 0; i < 64; ++i) { int v = in[i]; out[i] = s; s += v; }
+    return s;
+#endif
+}
+
+WDEV int wave_max(const int* in) {
+#if LEP_ON_GPU
+    int v = in[0];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { int t = __shfl_xor(v, d, 64); v = t > v ? t : v; }
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    int m = in[0];
+    for (int i = 1; i < 64; ++i) m = in[i] > m ? in[i] : m;
+    return m;
+#endif
+}
+
+// value of lane `src` (wave-uniform src)
+WDEV uint32_t wave_read(const uint32_t* v, int src) {
+#if LEP_ON_GPU
+    return (uint32_t)__builtin_amdgcn_readlane((int)v[0], src);
+#else
+    return v[src];
+#endif
+}
+
+WDEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
+
+}  // namespace lepwave

@@ -42,3 +42,38 @@ def test_kernel_source_on_cpu_matches_oracle(emu, name):
     for c in range(d.ncomp):
         n = d.coded_blocks[c] * 128
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
+
+
+def test_reciprocal_multiply_update_is_exact(emu):
+    """branch_update_fast (mul-hi by ceil(2^32/d)) == exact integer division for every count pair"""
+    assert emu.emu_check_fast_update() == 0
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_wave_cooperative_encoder_on_cpu_matches_oracle(emu, name):
+    """lep_enc2.h run as a 64-lane loop emulation (lep_wave.h) == oracle streams"""
+    jpg, _ = golden(name)
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    total = 0
+    for s, w in zip(segs, want):
+        cap = len(w) + 4096
+        buf = C.create_string_buffer(cap)
+        n, nb = C.c_uint32(0), C.c_uint32(0)
+        rc = emu.emu_encode_segment_v2(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, cap, C.byref(n), C.byref(nb))
+        assert rc == 0 and buf.raw[: n.value] == w
+        total += nb.value
+    assert total == bins
+
+
+def test_wave_cooperative_encoder_reports_out_of_range(emu):
+    from lepton_amd import corpus
+
+    img = JpegImage(corpus.synth_jpeg(64, 64, 9))
+    C.cast(img.desc.blocks[0], C.POINTER(C.c_int16))[5] = 4096
+    s = img.plan()[0]
+    buf = C.create_string_buffer(1 << 16)
+    n = C.c_uint32(0)
+    assert emu.emu_encode_segment_v2(C.byref(img.desc), s.luma_y_start, s.luma_y_end, s.is_last, buf, len(buf), C.byref(n), None) == 6

@@ -92,3 +92,15 @@ def test_gpu_decode_of_garbage_stream_is_contained(gpu_codec):
         gpu_codec.decode([f])
     except LeptonError as e:
         assert e.code in (6, 7, 39)
+
+
+def test_gpu_v1_and_v2_encoders_agree(monkeypatch):
+    """single-lane kernel (LEP_ENCODE_KERNEL=1) and wave-cooperative kernel produce identical streams"""
+    jpgs = [corpus.synth_jpeg(512, 384, 21), corpus.synth_jpeg(96, 200, 22, quality=60)]
+    imgs = [JpegImage(j) for j in jpgs]
+    plans = [im.plan() for im in imgs]
+    monkeypatch.setenv("LEP_ENCODE_KERNEL", "1")
+    a = GpuCodec(0).encode(imgs, plans)
+    monkeypatch.setenv("LEP_ENCODE_KERNEL", "2")
+    b = GpuCodec(0).encode(imgs, plans)
+    assert a == b
