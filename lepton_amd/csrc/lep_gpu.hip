@@ -16,6 +16,7 @@
 #define LEP_DEV __device__ __forceinline__
 #include "lep_core.h"
 #include "lep_enc2.h"
+#include "lep_dec2.h"
 
 using namespace lepdev;
 
@@ -87,6 +88,25 @@ __global__ __launch_bounds__(64) void lep_encode_v2_kernel(const ImageDev* __res
     bins[s] = w.nbins;
 }
 
+// v2 decoder: wave-cooperative with prefetch rounds (lep_dec2.h)
+__global__ __launch_bounds__(64) void lep_decode_v2_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
+                                                           uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
+                                                           uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
+    __shared__ DecShared sh;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const SegDev seg = segs[s];
+    const ImageDev* img = images + seg.image;
+    uint32_t* model = models + (size_t)s * kModelBranches;
+    NSum* ns = ns_area + ns_offsets[s];
+    reset_segment_state(model, ns, img->ns_total, lane);
+    __syncthreads();
+    DecWave w;
+    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, stream_len[s]);
+    if (lane != 0) return;
+    status[s] = rc;
+    bins[s] = w.nbins;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -95,6 +115,7 @@ struct lep_gpu {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int decode_kernel = 2;   // same switch for the decoder (LEP_DECODE_KERNEL=1)
     int encode_kernel = 2;   // 2 = wave-cooperative (default), 1 = single-lane reference kernel (LEP_ENCODE_KERNEL=1)
     std::string err;
     // grow-only device workspace
@@ -167,7 +188,11 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     g->d_bins = (uint32_t*)(meta + o_bins);
     g->h_bins.assign(nseg, 0);
     HIPCHK(g, hipEventRecord(g->ev0, st));
-    if (!DEC && g->encode_kernel == 2)
+    if (DEC && g->decode_kernel == 2)
+        hipLaunchKernelGGL(lep_decode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
+                           (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                           d_streams, d_stream_len, d_status, g->d_bins);
+    else if (!DEC && g->encode_kernel == 2)
         hipLaunchKernelGGL(lep_encode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
                            (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
@@ -187,6 +212,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
     if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) == 1 ? 1 : 2;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||

@@ -8,6 +8,7 @@
 #define LEP_DEV inline
 #include "../../lepton_amd/csrc/lep_derive.h"
 #include "../../lepton_amd/csrc/lep_enc2.h"
+#include "../../lepton_amd/csrc/lep_dec2.h"
 
 using namespace lepdev;
 
@@ -68,4 +69,20 @@ extern "C" int emu_check_fast_update() {
                     if (branch_update(w, obs) != branch_update_fast(w, obs, inv)) return 1;
                 }
     return 0;
+}
+
+extern "C" int emu_decode_segment_v2(const lep_image_desc* d, int y0, int y1, int is_last, const uint8_t* in, uint32_t len, uint32_t* bins) {
+    ImageDev img;
+    int rc = derive_image(*d, &img, false);
+    if (rc) return rc;
+    std::vector<uint32_t> model(kModelBranches, kBranchInit);
+    std::vector<NSum> ns(img.ns_total);
+    memset(ns.data(), 0, ns.size() * sizeof(NSum));
+    SegDev seg;
+    seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = 0;
+    static DecShared sh;
+    DecWave w;
+    rc = w.run(&img, seg, model.data(), ns.data(), &sh, in, len);
+    if (bins) *bins = w.nbins;
+    return rc;
 }

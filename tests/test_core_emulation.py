@@ -77,3 +77,25 @@ def test_wave_cooperative_encoder_reports_out_of_range(emu):
     buf = C.create_string_buffer(1 << 16)
     n = C.c_uint32(0)
     assert emu.emu_encode_segment_v2(C.byref(img.desc), s.luma_y_start, s.luma_y_end, s.is_last, buf, len(buf), C.byref(n), None) == 6
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_wave_cooperative_decoder_on_cpu_matches_oracle(emu, name):
+    """lep_dec2.h as a 64-lane loop emulation: decoding the oracle's streams returns the coefficient frame"""
+    jpg, _ = golden(name)
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    total = 0
+    for s, w in zip(segs, want):
+        nb = C.c_uint32(0)
+        assert emu.emu_decode_segment_v2(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0
+        total += nb.value
+    assert total == bins
+    for c in range(d.ncomp):
+        n = d.coded_blocks[c] * 128
+        assert C.string_at(d.blocks[c], n) == orig[c][:n]

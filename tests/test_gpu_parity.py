@@ -104,3 +104,17 @@ def test_gpu_v1_and_v2_encoders_agree(monkeypatch):
     monkeypatch.setenv("LEP_ENCODE_KERNEL", "2")
     b = GpuCodec(0).encode(imgs, plans)
     assert a == b
+
+
+def test_gpu_v1_and_v2_decoders_agree(monkeypatch):
+    jpg = corpus.synth_jpeg(640, 480, 31, quality=93)
+    img = JpegImage(jpg)
+    lep = img.write_lep(GpuCodec(0).encode([img], [img.plan()])[0])
+    out = []
+    for k in ("1", "2"):
+        monkeypatch.setenv("LEP_DECODE_KERNEL", k)
+        f = LepFile(lep)
+        GpuCodec(0).decode([f])
+        out.append([C.string_at(f.desc.blocks[c], f.desc.nblocks(c) * 128) for c in range(3)])
+        assert f.recode() == jpg
+    assert out[0] == out[1]
