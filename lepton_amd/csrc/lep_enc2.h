@@ -18,12 +18,14 @@
 namespace lepdev {
 
 constexpr int kMaxBins = 1440;   // 6 + 49*22 + 2*(3 + 7*22) + 22
-constexpr int kMaxDup = 256;     // 49 + 14 + 1 signs + 14*10 threshold bins
+constexpr int kMaxDup = 160;     // 14*10 threshold bins
+constexpr uint32_t kResidentFlag = 1u << 30;   // bin whose Branch lives in LDS (sign table); resolved by the serial lane
 
 struct EncShared {
     uint32_t bins[kMaxBins];   // P2: branch index | bit << 31;  after P3: probability | bit << 8
     uint16_t dup[kMaxDup];     // positions (into bins) of bins whose Branch may repeat within the block
     uint32_t inv[512];         // ceil(2^32 / d): exact division for the probability update
+    uint32_t sign[96];         // the sign Branches live in LDS for the whole segment (never written back)
     int32_t t[64];             // IDCT intermediate
     int32_t icos_x[64], icos_y[64];
     int16_t here[64], left[64], above[64], aleft[64];   // aligned order
@@ -62,6 +64,7 @@ struct EncWave {
         LANES(l) {
             sh->r2a[l] = kR2A[l]; sh->a2r[l] = kA2R[l]; sh->nzbin[l] = l < 50 ? kNzBin[l] : 9;
             for (int d = l; d < 512; d += 64) sh->inv[d] = d < 2 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d);
+            for (int d = l; d < 96; d += 64) sh->sign[d] = kBranchInit;
             if (l < (int)(sizeof(NSum) / 4)) { ((uint32_t*)&sh->ns_left)[l] = 0; ((uint32_t*)&sh->ns_above)[l] = 0; }
         }
         WSYNC();
@@ -259,7 +262,6 @@ struct EncWave {
                 if (len > 11) err = 6;
                 nexp = len < 11 ? len + 1 : 11;
                 n = nexp + (len ? 1 : 0) + (len > 1 ? len - 1 : 0);
-                nd += len ? 1 : 0;
             } else nd = 0;
             if (l == 0) n += 6;
             if (l == 49 || l == 56) n += 3;
@@ -295,7 +297,7 @@ struct EncWave {
             if (L(coded_)) {
                 const int len = L(len_), v = L(val_), nexp = L(nexp_);
                 for (int i = 0; i < nexp; ++i) S.bins[j++] = (L(expbase_) + i) | ((uint32_t)(len != i) << 31);
-                if (len) { S.dup[dj++] = (uint16_t)j; S.bins[j++] = L(signidx_) | ((uint32_t)L(pos_) << 31); }
+                if (len) S.bins[j++] = (L(signidx_) - kSign) | kResidentFlag | ((uint32_t)L(pos_) << 31);
                 if (len > 1) {
                     int b = len - 2;
                     if (L(isedge_) && b >= L(thr_)) {
@@ -314,22 +316,32 @@ struct EncWave {
         WSYNC();
 
         // ---- P3a: bins with a block-unique Branch: parallel load / adapt / store ------------------
-        for (int base = 0; base < N; base += 64) {
+        // (two rounds of loads are issued before the first use, so their HBM latencies overlap)
+        for (int base = 0; base < N; base += 128) {
+            LV(uint32_t, w0); LV(uint32_t, w1);
             LANES(l) {
-                const int j = base + l;
-                if (j < N) {
-                    const uint32_t e = S.bins[j], idx = e & 0x7fffffffu;
-                    const int bit = (int)(e >> 31);
-                    const bool dupclass = (idx >= kSign && idx < kExpDc) || idx >= kThresh;
-                    if (!dupclass) {
-                        const uint32_t w = model[idx];
-                        model[idx] = branch_update_fast(w, bit, S.inv);
-                        S.bins[j] = (w >> 16) | ((uint32_t)bit << 8);
+                const int j0 = base + l, j1 = base + 64 + l;
+                uint32_t a = 0, b = 0;
+                if (j0 < N) { const uint32_t e = S.bins[j0]; if (!(e & kResidentFlag) && (e & 0x3fffffffu) < kThresh) a = model[e & 0x3fffffffu]; }
+                if (j1 < N) { const uint32_t e = S.bins[j1]; if (!(e & kResidentFlag) && (e & 0x3fffffffu) < kThresh) b = model[e & 0x3fffffffu]; }
+                L(w0) = a; L(w1) = b;
+            }
+            LANES(l) {
+                for (int h = 0; h < 2; ++h) {
+                    const int j = base + h * 64 + l;
+                    if (j < N) {
+                        const uint32_t e = S.bins[j], idx = e & 0x3fffffffu;
+                        if (!(e & kResidentFlag) && idx < kThresh) {
+                            const uint32_t w = h ? L(w1) : L(w0);
+                            const int bit = (int)(e >> 31);
+                            model[idx] = branch_update_fast(w, bit, S.inv);
+                            S.bins[j] = (w >> 16) | ((uint32_t)bit << 8);
+                        }
                     }
                 }
             }
         }
-        // ---- P3b: sign / threshold bins: in-order forwarding inside the wave -----------------------
+        // ---- P3b: threshold bins (rare; their Branch can repeat inside a block): in-order forwarding ---
         for (int cb = 0; cb < D; cb += 64) {
             LV(uint32_t, didx); LV(uint32_t, dw); LV(uint32_t, dbit); LV(int, djpos); LV(int, dlast);
             const int n = D - cb < 64 ? D - cb : 64;
@@ -339,7 +351,7 @@ struct EncWave {
                 if (l < n) {
                     j = S.dup[cb + l];
                     const uint32_t e = S.bins[j];
-                    idx = e & 0x7fffffffu; bit = e >> 31;
+                    idx = e & 0x3fffffffu; bit = e >> 31;
                     w = model[idx];
                 }
                 L(didx) = idx; L(dw) = w; L(dbit) = bit; L(djpos) = j; L(dlast) = 1;
@@ -359,7 +371,16 @@ struct EncWave {
 
         // ---- P4: bool coder over the resolved (bit, probability) pairs ------------------------------
         LANES(l) if (l == 0) {
-            for (int j = 0; j < N; ++j) { const uint32_t e = S.bins[j]; bc.put((int)(e >> 8) & 1, e & 255); }
+            for (int j = 0; j < N; ++j) {
+                const uint32_t e = S.bins[j];
+                if (e & kResidentFlag) {
+                    uint32_t* slot = &S.sign[e & 127];
+                    const uint32_t w = *slot;
+                    const int bit = (int)(e >> 31);
+                    bc.put(bit, w >> 16);
+                    *slot = branch_update_fast(w, bit, S.inv);
+                } else bc.put((int)(e >> 8) & 1, e & 255);
+            }
         }
         nbins += (uint32_t)N;
 
