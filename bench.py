@@ -126,6 +126,7 @@ def main():
     dec_descs = (abi.ImageDesc * nimg)()
     flat = []
     nblocks = 0
+    first_copy = {}   # unique image -> its device frame: uploaded once over PCIe, replicated device-to-device
     for k, u in enumerate(order):
         d = imgs[u].desc
         C.memmove(C.byref(descs[k]), C.byref(d), C.sizeof(abi.ImageDesc))
@@ -133,7 +134,11 @@ def main():
         for c in range(d.ncomp):
             n = d.nblocks(c) * 128
             p = dmalloc(n)
-            assert L.lep_gpu_memcpy_h2d(g, p, d.blocks[c], n) == 0
+            if (u, c) in first_copy:
+                assert L.lep_gpu_memcpy_d2d(g, p, first_copy[(u, c)], n) == 0
+            else:
+                assert L.lep_gpu_memcpy_h2d(g, p, d.blocks[c], n) == 0
+                first_copy[(u, c)] = p
             descs[k].blocks[c] = p
             q = dmalloc(n)
             assert L.lep_gpu_memset(g, q, 0, n) == 0

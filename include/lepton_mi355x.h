@@ -96,10 +96,16 @@ int lep_gpu_decode_device(lep_gpu *g, const lep_image_desc *images, int nimg, co
 int lep_gpu_sync(lep_gpu *g);
 double lep_gpu_last_kernel_ms(lep_gpu *g);   /* HIP-event duration of the most recent encode/decode kernel */
 /* plain device memory helpers so non-torch callers need no HIP binding */
+/* Device self-test of kernel arithmetic that has no CPU twin (exhaustive: the float-reciprocal Branch probability of the
+ * v3 kernels against integer division, src/vp8/model/branch.hh:82-125).  0 = exact everywhere. */
+int lep_gpu_selftest(lep_gpu *g);
+/* Profiling builds (-DLEP_PROF) only: per-phase shader-clock totals [64 segments][32 slots] of the last v3 launch. */
+int lep_gpu_debug_prof(lep_gpu *g, uint64_t *out);
 int lep_gpu_malloc(lep_gpu *g, size_t bytes, void **dptr);
 int lep_gpu_free(lep_gpu *g, void *dptr);
 int lep_gpu_memcpy_h2d(lep_gpu *g, void *dst, const void *src, size_t bytes);
 int lep_gpu_memcpy_d2h(lep_gpu *g, void *dst, const void *src, size_t bytes);
+int lep_gpu_memcpy_d2d(lep_gpu *g, void *dst, const void *src, size_t bytes);
 int lep_gpu_memset(lep_gpu *g, void *dst, int value, size_t bytes);
 
 /* ---- layer 2: host-side callers of the hot path --------------------------------------------- */

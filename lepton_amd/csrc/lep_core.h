@@ -165,6 +165,9 @@ struct BoolCoder<true> {   // reader: 64-bit window, zero bits past the end of t
         uint64_t big = (uint64_t)split << 56;
         int bit = value >= big;
         if (bit) { range -= split; value -= big; } else range = split;
+#ifdef LEP_TRACE_GET
+        LEP_TRACE_GET(prob, bit);
+#endif
         int shift = __builtin_clz(range) - 24;
         range <<= shift; value <<= shift; count -= shift;
         return bit;

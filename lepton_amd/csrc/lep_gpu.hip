@@ -17,6 +17,7 @@
 #include "lep_core.h"
 #include "lep_enc2.h"
 #include "lep_dec2.h"
+#include "lep_dec3.h"
 
 using namespace lepdev;
 
@@ -30,11 +31,15 @@ __device__ inline bool stream_overflow(BoolCoder<true>&) { return false; }
 
 namespace {
 
+// every kernel generation has its own model layout; segments are spaced by the largest
+constexpr size_t kModelStride = lep3::kModelWords > kModelBranches ? lep3::kModelWords : kModelBranches;
+
+template <uint32_t WORDS = kModelBranches>
 __device__ void reset_segment_state(uint32_t* model, NSum* ns, int ns_count, int lane) {
     // model reset = Branch::identity() everywhere (model.hh:114-125); 16-byte coalesced stores
     uint4* m4 = reinterpret_cast<uint4*>(model);
     const uint4 init = make_uint4(kBranchInit, kBranchInit, kBranchInit, kBranchInit);
-    for (uint32_t i = lane; i < kModelBranches / 4; i += 64) m4[i] = init;
+    for (uint32_t i = lane; i < WORDS / 4; i += 64) m4[i] = init;
     uint32_t* n32 = reinterpret_cast<uint32_t*>(ns);
     const uint32_t words = (uint32_t)ns_count * (sizeof(NSum) / 4);
     for (uint32_t i = lane; i < words; i += 64) n32[i] = 0;
@@ -48,7 +53,7 @@ __global__ __launch_bounds__(64) void lep_segment_kernel(const ImageDev* __restr
     const int s = blockIdx.x, lane = threadIdx.x;
     const SegDev seg = segs[s];
     const ImageDev* img = images + seg.image;
-    uint32_t* model = models + (size_t)s * kModelBranches;
+    uint32_t* model = models + (size_t)s * kModelStride;
     NSum* ns = ns_area + ns_offsets[s];
     reset_segment_state(model, ns, img->ns_total, lane);
     __syncthreads();
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(64) void lep_encode_v2_kernel(const ImageDev* __res
     const int s = blockIdx.x, lane = threadIdx.x;
     const SegDev seg = segs[s];
     const ImageDev* img = images + seg.image;
-    uint32_t* model = models + (size_t)s * kModelBranches;
+    uint32_t* model = models + (size_t)s * kModelStride;
     NSum* ns = ns_area + ns_offsets[s];
     reset_segment_state(model, ns, img->ns_total, lane);
     __syncthreads();
@@ -96,12 +101,56 @@ __global__ __launch_bounds__(64) void lep_decode_v2_kernel(const ImageDev* __res
     const int s = blockIdx.x, lane = threadIdx.x;
     const SegDev seg = segs[s];
     const ImageDev* img = images + seg.image;
-    uint32_t* model = models + (size_t)s * kModelBranches;
+    uint32_t* model = models + (size_t)s * kModelStride;
     NSum* ns = ns_area + ns_offsets[s];
     reset_segment_state(model, ns, img->ns_total, lane);
     __syncthreads();
     DecWave w;
     int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, stream_len[s]);
+    if (lane != 0) return;
+    status[s] = rc;
+    bins[s] = w.nbins;
+}
+
+#ifdef LEP_PROF
+__device__ uint64_t g_prof[64][32];
+#endif
+
+// exhaustive check of the float-reciprocal Branch probability against integer division (all 255 x 255 count pairs)
+__global__ void lep_selftest_kernel(uint32_t* mismatches) {
+    const uint32_t f = blockIdx.x + 1, t = threadIdx.x + 1;
+    if (t > 255) return;
+    if (lep3::prob_of(f, t) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);
+    for (int obs = 0; obs < 2; ++obs) {
+        const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);
+        if (lep3::bupd(w, obs) != branch_update(w, obs)) atomicAdd(mismatches, 1u);
+    }
+}
+
+// v3 decoder: owner-lane model update, serial part on the scalar unit (lep_dec3.h).  WAVES = waves per SIMD the
+// register allocation is held to (4: 120 VGPRs, no spills; 5: 96; 6: 80; 8: 64 with spills to scratch).
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void lep_decode_v3_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
+                                                           uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
+                                                           uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
+    __shared__ lep3::Dec3Shared sh;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const SegDev seg = segs[s];
+    const ImageDev* img = images + seg.image;
+    uint32_t* model = models + (size_t)s * kModelStride;
+    NSum* ns = ns_area + ns_offsets[s];
+    reset_segment_state<lep3::kModelWords>(model, ns, img->ns_total, lane);
+    __syncthreads();
+    lep3::Dec3Wave w;
+#ifdef LEP_PROF
+    if (lane < 32) sh.prof[lane] = 0;
+    w.prof_last = __builtin_readcyclecounter();
+#endif
+    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, stream_len[s]);
+#ifdef LEP_PROF
+    __syncthreads();
+    if (s < 64 && lane < 32) g_prof[s][lane] = sh.prof[lane];
+#endif
     if (lane != 0) return;
     status[s] = rc;
     bins[s] = w.nbins;
@@ -115,7 +164,8 @@ struct lep_gpu {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    int decode_kernel = 2;   // same switch for the decoder (LEP_DECODE_KERNEL=1)
+    int decode_kernel = 3;   // 3 = v3 (default), 2 = v2 prefetch rounds, 1 = single-lane reference kernel (LEP_DECODE_KERNEL)
+    int dec3_waves = 0;      // register budget variant of the v3 decoder: 0 = by batch size, LEP_DEC3_WAVES = 4 | 5 | 6 | 8
     int encode_kernel = 2;   // 2 = wave-cooperative (default), 1 = single-lane reference kernel (LEP_ENCODE_KERNEL=1)
     std::string err;
     // grow-only device workspace
@@ -174,7 +224,7 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         ns_total += (uint64_t)himg[segs[s].image].ns_total;
     }
     HIPCHK(g, hipSetDevice(g->device));
-    if (int rc = ensure(g, &g->d_models, &g->models_bytes, (size_t)nseg * kModelBranches * 4)) return rc;
+    if (int rc = ensure(g, &g->d_models, &g->models_bytes, (size_t)nseg * kModelStride * 4)) return rc;
     if (int rc = ensure(g, &g->d_ns, &g->ns_bytes, (size_t)ns_total * sizeof(NSum) + 16)) return rc;
     const size_t o_img = 0, o_seg = o_img + ((nimg * sizeof(ImageDev) + 255) & ~(size_t)255),
                  o_ns = o_seg + ((nseg * sizeof(SegDev) + 255) & ~(size_t)255),
@@ -188,7 +238,25 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     g->d_bins = (uint32_t*)(meta + o_bins);
     g->h_bins.assign(nseg, 0);
     HIPCHK(g, hipEventRecord(g->ev0, st));
-    if (DEC && g->decode_kernel == 2)
+    if (DEC && g->decode_kernel == 3) {
+#define LEP_LAUNCH_DEC3(W)                                                                                                     \
+    hipLaunchKernelGGL((lep_decode_v3_kernel<W>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),                  \
+                       (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns), \
+                       d_streams, d_stream_len, d_status, g->d_bins)
+        // register-budget variant: more resident waves only pay once the batch can fill them (measured, MI355X, 4K
+        // corpus: 4096 segments 822 MB/s with the 4-wave build vs 742 with the 5-wave build; 8192 segments 867 vs 947
+        // with the 8-wave build); LEP_DEC3_WAVES overrides
+        int waves = g->dec3_waves;
+        if (!waves) waves = nseg > 6144 ? 8 : (nseg > 4608 ? 6 : 4);
+        switch (waves) {
+            case 8: LEP_LAUNCH_DEC3(8); break;
+            case 6: LEP_LAUNCH_DEC3(6); break;
+            case 5: LEP_LAUNCH_DEC3(5); break;
+            default: LEP_LAUNCH_DEC3(4); break;
+        }
+#undef LEP_LAUNCH_DEC3
+    }
+    else if (DEC && g->decode_kernel == 2)
         hipLaunchKernelGGL(lep_decode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
                            (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
@@ -212,7 +280,8 @@ int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
     if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = atoi(e) == 1 ? 1 : 2;
-    if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3;
+    if (const char* e = getenv("LEP_DEC3_WAVES")) g->dec3_waves = atoi(e);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||
@@ -263,10 +332,36 @@ double lep_gpu_last_kernel_ms(lep_gpu* g) {
     return ms;
 }
 
+// device self-test of the arithmetic that has no CPU twin (float-reciprocal division in lep3::prob_of); 0 = all exact
+int lep_gpu_selftest(lep_gpu* g) {
+    HIPCHK(g, hipSetDevice(g->device));
+    uint32_t* d = nullptr;
+    HIPCHK(g, hipMalloc((void**)&d, 4));
+    HIPCHK(g, hipMemset(d, 0, 4));
+    hipLaunchKernelGGL(lep_selftest_kernel, dim3(255), dim3(256), 0, g->stream, d);
+    uint32_t h = 1;
+    HIPCHK(g, hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    HIPCHK(g, hipFree(d));
+    return h == 0 ? 0 : LEP_ASSERTION_FAILURE;
+}
+
+// profiling builds (-DLEP_PROF) only: per-phase shader-clock totals of the first 64 segments of the last v3 launch
+int lep_gpu_debug_prof(lep_gpu* g, uint64_t* out /* [64][32] */) {
+#ifdef LEP_PROF
+    HIPCHK(g, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(uint64_t) * 64 * 32));
+    return 0;
+#else
+    (void)g; (void)out;
+    return LEP_GPU_ERROR;
+#endif
+}
+
 int lep_gpu_malloc(lep_gpu* g, size_t bytes, void** dptr) { HIPCHK(g, hipSetDevice(g->device)); HIPCHK(g, hipMalloc(dptr, bytes ? bytes : 16)); return 0; }
 int lep_gpu_free(lep_gpu* g, void* dptr) { HIPCHK(g, hipFree(dptr)); return 0; }
 int lep_gpu_memcpy_h2d(lep_gpu* g, void* dst, const void* src, size_t bytes) { HIPCHK(g, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
 int lep_gpu_memcpy_d2h(lep_gpu* g, void* dst, const void* src, size_t bytes) { HIPCHK(g, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
+int lep_gpu_memcpy_d2d(lep_gpu* g, void* dst, const void* src, size_t bytes) { HIPCHK(g, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice)); return 0; }
 int lep_gpu_memset(lep_gpu* g, void* dst, int value, size_t bytes) { HIPCHK(g, hipMemset(dst, value, bytes)); return 0; }
 
 // ---- host-buffer variants: stage frames through HBM, run the device path, fetch results --------------

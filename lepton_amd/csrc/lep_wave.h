@@ -13,13 +13,21 @@
 #define LEP_LI(l) 0
 #define LANES(l) for (int l = (int)(threadIdx.x & 63), lep_once_ = 1; lep_once_; lep_once_ = 0)
 #define WSYNC() __syncthreads()
+// One wavefront per workgroup: lanes run in lockstep and a wave's LDS / global accesses are performed in program
+// order, so handing data between lanes needs no s_barrier and no counter drain -- only that the COMPILER keeps the
+// accesses in order.  A wavefront-scope fence + wave_barrier does exactly that (no instructions are emitted).
+#define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define WDEV __device__ __forceinline__
 #else
 #define LEP_ON_GPU 0
 #define LEP_NL 64
 #define LEP_LI(l) (l)
-#define LANES(l) for (int l = 0; l < 64; ++l)
+// every lane is an independent program instance: the lane index is laundered through an empty asm so that the host
+// compiler cannot carry value-range facts from one lane's path into another's
+static inline int lep_lane_id(int i) { __asm__ volatile("" : "+r"(i)); return i; }
+#define LANES(l) for (int lep_i_ = 0; lep_i_ < 64; ++lep_i_) for (int l = lep_lane_id(lep_i_), lep_once_ = 1; lep_once_; lep_once_ = 0)
 #define WSYNC() ((void)0)
+#define LSYNC() ((void)0)
 #define WDEV inline
 #endif
 

@@ -99,3 +99,26 @@ def test_wave_cooperative_decoder_on_cpu_matches_oracle(emu, name):
     for c in range(d.ncomp):
         n = d.coded_blocks[c] * 128
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_v3_decoder_on_cpu_matches_oracle(emu, name):
+    """lep_dec3.h (owner-lane model update, 32-bit window) as a 64-lane loop emulation: decoding the
+    oracle's streams returns the coefficient frame and consumes exactly the oracle's number of bins"""
+    jpg, _ = golden(name)
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    total = 0
+    for s, w in zip(segs, want):
+        nb = C.c_uint32(0)
+        assert emu.emu_decode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0
+        total += nb.value
+    assert total == bins
+    for c in range(d.ncomp):
+        n = d.coded_blocks[c] * 128
+        assert C.string_at(d.blocks[c], n) == orig[c][:n]

@@ -19,6 +19,11 @@ def test_native_library_is_loaded_and_gpu_present(gpu_codec):
     assert gpu_codec.handle
 
 
+def test_gpu_kernel_arithmetic_selftest(gpu_codec):
+    """exhaustive on-device check: float-reciprocal Branch probability == integer division for all 255 x 255 count pairs"""
+    assert abi.lib().lep_gpu_selftest(gpu_codec.handle) == 0
+
+
 @pytest.mark.parametrize("name", golden_cases())
 def test_gpu_encode_equals_reference_lep(gpu_codec, name):
     jpg, lep = golden(name)
