@@ -71,12 +71,24 @@ def cpu_baseline(jpgs, budget_s=24.0):
     }
 
 
+def pmc_traffic(kernel, images):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/), scaled
+    from that run's batch to this one; None when the kernel has not been through a PMC pass."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+        per_image = table[kernel.split("<")[0]]["hbm_bytes_per_image"]
+        return int(per_image * images)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--images", type=int, default=32, help="4K images per GPU per step")
+    ap.add_argument("--images", type=int, default=1024,
+                    help="4K images per GPU per step (8 thread segments each; 1024 = 8192 segments = 8 wavefronts per SIMD)")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic images per GPU (replicated up to --images)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -157,16 +169,20 @@ def main():
     d_len = dmalloc(4 * nseg)
     d_status = dmalloc(4 * nseg)
 
+    names = {}
+
     def step():
         rc = L.lep_gpu_encode_device(g, descs, nimg, segs, nseg, d_streams, offs, d_len, d_status, None)
         assert rc == 0, (rc, codec.last_error())
         rc = L.lep_gpu_sync(g)
         assert rc == 0, codec.last_error()
         e_ms = L.lep_gpu_last_kernel_ms(g)
+        names["encode"] = L.lep_gpu_last_kernel_name(g).decode()
         rc = L.lep_gpu_decode_device(g, dec_descs, nimg, segs, nseg, d_streams, offs, d_len, d_status, None)
         assert rc == 0, (rc, codec.last_error())
         rc = L.lep_gpu_sync(g)
         assert rc == 0, codec.last_error()
+        names["decode"] = L.lep_gpu_last_kernel_name(g).decode()
         return e_ms, L.lep_gpu_last_kernel_ms(g)
 
     def barrier():
@@ -241,11 +257,12 @@ def main():
                    "images_per_gpu": args.images, "segments_per_gpu": int(agg["segments"] / world), "jpeg_MB_per_step": round(mb, 3),
                    "parallelism": "image-sharded x%d, one wavefront per thread segment" % world, "parity": parity},
         "encode_MBps": round(mb / (agg["enc_ms_max"] / K / 1e3), 3), "decode_MBps": round(mb / (agg["dec_ms_max"] / K / 1e3), 3),
-        "roofline": {"bound": "hbm", "kernel": "lep_segment_kernel<%s>" % dominant, "achieved": round(achieved, 4), "peak": 8000.0,
-                     "unit": "GB/s", "frac": round(achieved / 8000.0, 7), "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": names.get(dominant, dominant), "achieved": round(achieved, 4), "peak": 8000.0,
+                     "unit": "GB/s", "frac": round(achieved / 8000.0, 7), "traffic": pmc_traffic(names.get(dominant, ""), args.images),
                      "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms": round(dom_s * 1e3, 3),
                      "encode_kernel_ms": round(enc_kernel_s * 1e3, 3), "decode_kernel_ms": round(dec_kernel_s * 1e3, 3),
-                     "note": "dependency-latency bound integer coder; see bins_per_s"},
+                     "kernels": names,
+                     "note": "instruction-issue bound integer coder (about 1.2 instructions/cycle/CU, serial part on the scalar unit), not bandwidth bound; see bins_per_s and DESIGN.md"},
     }
     if bins_per_image:
         bins_launch = bins_per_image * args.images

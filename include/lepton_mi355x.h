@@ -94,7 +94,8 @@ int lep_gpu_decode_device(lep_gpu *g, const lep_image_desc *images, int nimg, co
                           const uint8_t *d_streams, const uint64_t *stream_offsets, const uint32_t *d_stream_len,
                           int32_t *d_status, void *hip_stream);
 int lep_gpu_sync(lep_gpu *g);
-double lep_gpu_last_kernel_ms(lep_gpu *g);   /* HIP-event duration of the most recent encode/decode kernel */
+double lep_gpu_last_kernel_ms(lep_gpu *g);
+const char *lep_gpu_last_kernel_name(lep_gpu *g);   /* which kernel generation / register-budget variant that launch used */   /* HIP-event duration of the most recent encode/decode kernel */
 /* plain device memory helpers so non-torch callers need no HIP binding */
 /* Device self-test of kernel arithmetic that has no CPU twin (exhaustive: the float-reciprocal Branch probability of the
  * v3 kernels against integer division, src/vp8/model/branch.hh:82-125).  0 = exact everywhere. */

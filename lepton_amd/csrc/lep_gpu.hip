@@ -168,6 +168,7 @@ struct lep_gpu {
     int dec3_waves = 0;      // register budget variant of the v3 decoder: 0 = by batch size, LEP_DEC3_WAVES = 4 | 5 | 6 | 8
     int encode_kernel = 2;   // 2 = wave-cooperative (default), 1 = single-lane reference kernel (LEP_ENCODE_KERNEL=1)
     std::string err;
+    const char* last_kernel = "";   // name of the kernel the most recent launch used
     // grow-only device workspace
     void* d_models = nullptr; size_t models_bytes = 0;
     void* d_ns = nullptr; size_t ns_bytes = 0;
@@ -248,6 +249,7 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         // with the 8-wave build); LEP_DEC3_WAVES overrides
         int waves = g->dec3_waves;
         if (!waves) waves = nseg > 6144 ? 8 : (nseg > 4608 ? 6 : 4);
+        g->last_kernel = waves >= 8 ? "lep_decode_v3_kernel<8>" : waves == 6 ? "lep_decode_v3_kernel<6>" : waves == 5 ? "lep_decode_v3_kernel<5>" : "lep_decode_v3_kernel<4>";
         switch (waves) {
             case 8: LEP_LAUNCH_DEC3(8); break;
             case 6: LEP_LAUNCH_DEC3(6); break;
@@ -256,18 +258,22 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         }
 #undef LEP_LAUNCH_DEC3
     }
-    else if (DEC && g->decode_kernel == 2)
+    else if (DEC && g->decode_kernel == 2) {
+        g->last_kernel = "lep_decode_v2_kernel";
         hipLaunchKernelGGL(lep_decode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
                            (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
-    else if (!DEC && g->encode_kernel == 2)
+    } else if (!DEC && g->encode_kernel == 2) {
+        g->last_kernel = "lep_encode_v2_kernel";
         hipLaunchKernelGGL(lep_encode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
                            (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
-    else
+    } else {
+        g->last_kernel = DEC ? "lep_segment_kernel<decode>" : "lep_segment_kernel<encode>";
         hipLaunchKernelGGL(lep_segment_kernel<DEC>, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
                            (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
+    }
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
@@ -323,6 +329,8 @@ int lep_gpu_sync(lep_gpu* g) {
     HIPCHK(g, hipDeviceSynchronize());
     return 0;
 }
+
+const char* lep_gpu_last_kernel_name(lep_gpu* g) { return g ? g->last_kernel : ""; }
 
 double lep_gpu_last_kernel_ms(lep_gpu* g) {
     if (!g->timed) return -1.0;

@@ -122,3 +122,28 @@ def test_v3_decoder_on_cpu_matches_oracle(emu, name):
     for c in range(d.ncomp):
         n = d.coded_blocks[c] * 128
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
+
+
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_v3_decoder_unaligned_stream_start(emu, shift):
+    """the 64-bit window reads aligned dwords only: a stream that starts 1..3 bytes into a dword (streams packed back to
+    back in the arena) and ends mid-dword must decode exactly like an aligned one, never touching bytes outside it"""
+    jpg, _ = golden("c420_odd_203x149")
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    for s, w in zip(segs, want):
+        arena = C.create_string_buffer(b"\xff" * 8 + b"\xa5" * shift + w + b"\x5a" * 9)   # poison either side
+        base = C.addressof(arena)
+        base += (-base) % 4 + 4   # a 4-aligned address inside the poison prefix ...
+        C.memmove(base + shift, w, len(w))   # ... so the stream itself starts `shift` bytes into a dword
+        C.memset(base, 0xA5, shift)
+        C.memset(base + shift + len(w), 0x5A, 8)
+        assert emu.emu_decode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, C.c_void_p(base + shift), len(w), None) == 0
+    for c in range(d.ncomp):
+        n = d.coded_blocks[c] * 128
+        assert C.string_at(d.blocks[c], n) == orig[c][:n]

@@ -123,3 +123,31 @@ def test_gpu_v1_and_v2_decoders_agree(monkeypatch):
         out.append([C.string_at(f.desc.blocks[c], f.desc.nblocks(c) * 128) for c in range(3)])
         assert f.recode() == jpg
     assert out[0] == out[1]
+
+
+@pytest.mark.parametrize("waves", ["4", "5", "6", "8"])
+def test_gpu_v3_decoder_register_budget_variants(waves, monkeypatch):
+    """every register-budget build of the v3 decode kernel (the 8-wave one spills to scratch) restores the same JPEGs"""
+    monkeypatch.setenv("LEP_DEC3_WAVES", waves)
+    codec = GpuCodec(0)
+    try:
+        for name in ("c420_odd_203x149", "q30_256x256_4seg", "rst_c420_176x112"):
+            jpg, lep = golden(name)
+            assert codec.decompress(lep) == jpg
+        jpg = corpus.synth_jpeg(1280, 720, 77, quality=95)
+        assert codec.decompress(codec.compress(jpg)) == jpg
+    finally:
+        codec.close()
+
+
+@pytest.mark.parametrize("kernel", ["1", "2"])
+def test_gpu_older_decode_kernels_still_agree(kernel, monkeypatch):
+    """the single-lane (v1) and prefetch-round (v2) decoders are kept as cross-checks of the v3 kernel"""
+    monkeypatch.setenv("LEP_DECODE_KERNEL", kernel)
+    codec = GpuCodec(0)
+    try:
+        for name in ("c420_odd_203x149", "q30_256x256_4seg"):
+            jpg, lep = golden(name)
+            assert codec.decompress(lep) == jpg
+    finally:
+        codec.close()
