@@ -1,0 +1,563 @@
+// lep_enc3.h -- "v3" encoder: the wave-cooperative block coder of lep_enc2.h re-cut for 8 wavefronts per SIMD.
+//
+// Measured on MI355X (profiles/r01c_*): the v2 encoder ran 15 workgroups per CU (10.4 KB of LDS each), spent its
+// serial phase as exec-masked lane-0 code (about 25 VALU + 12 SALU instructions per bin, the SALU ones only
+// juggling exec masks) and waited on HBM for every block's coefficients.  A micro-benchmark of the bool-coder
+// recurrence (profiles/r01_issue_microbench.txt) showed where serial work belongs on this chip: written as
+// "uniform vector" code -- every lane computes the same value, branches are taken on ballots -- it runs 1.85x
+// faster at 8 waves/SIMD than the same recurrence on the scalar unit, and much faster than exec-masked code.
+// So v3 keeps v2's phases (same reference citations) and changes how they are executed:
+//   * 4.6 KB of LDS per wavefront (bin list of 512 entries filled lane-range by lane-range, no reciprocal table:
+//     Branch probabilities come from lep3::prob_of) and __launch_bounds__(64, 8) -> 32 wavefronts per CU;
+//   * P4, the bool coder (boolwriter.hh:48-118), is uniform vector code: bins are read 64 at a time into a
+//     register, handed out by v_readlane, the coder state lives in VGPRs, branches are uniform;
+//   * the next block's coefficients / neighbour summary are fetched one block ahead;
+//   * LDS hand-offs inside the wavefront use compiler-only ordering (LSYNC), not s_barrier.
+// Model layout in HBM = lep_core.h's (one word per Branch, 11-word exponent rows); results are bit-identical.
+#pragma once
+#include "lep_v3.h"
+
+namespace lep3 {
+
+constexpr int kBinChunk = 512;
+constexpr int kMaxDup3 = 160;                  // 14 * 10 threshold bins
+constexpr uint32_t kResident3 = 1u << 30;      // bin whose Branch lives in LDS (sign table); resolved by the coder loop
+
+struct Enc3Shared {
+    uint32_t bins[kBinChunk];   // P2: branch index | bit << 31;  after P3: probability | bit << 8
+    uint16_t dup[kMaxDup3];     // positions (into bins) of bins whose Branch may repeat within the block
+    uint32_t sign[96];          // the sign Branches live in LDS for the whole segment (never written back)
+    int32_t t[64];              // IDCT intermediate
+    int32_t icos_x[64], icos_y[64];
+    int16_t here[64], left[64], above[64], aleft[64];   // aligned order
+    int16_t pix[64];
+    uint16_t q[64];
+    uint8_t thr[64];
+    uint8_t r2a[64], a2r[64], nzbin[64];
+    NSum ns_left, ns_above, ns_here;
+};
+
+// on the GPU: true when the (wave-uniform) condition holds; written as a ballot so that a value the compiler cannot
+// prove uniform still yields a scalar branch instead of exec-mask control flow
+WDEV bool ucond(bool c) {
+#if LEP_ON_GPU
+    return __builtin_amdgcn_ballot_w64(c) != 0;
+#else
+    return c;
+#endif
+}
+
+// bool writer (boolwriter.hh:48-118, boolwriter.cc:17-35) as uniform vector code: low / range / count are identical in
+// every lane (VGPRs), the byte position is scalar, stores are done by lane 0
+struct BoolEnc3 {
+    uint32_t low, range;
+    int count;
+    uint8_t* out;
+    uint32_t pos, cap;
+    bool overflow;
+    WDEV void emit(uint8_t b) {
+#if LEP_ON_GPU
+        if (threadIdx.x == 0) out[pos] = b;
+#else
+        out[pos] = b;
+#endif
+    }
+    WDEV void init_stream(uint8_t* o, uint32_t c) {
+        out = o; cap = c; pos = 0; overflow = false;
+        low = vec(0); range = vec(255); count = (int)vec((uint32_t)-24);
+        put(0, 128);
+    }
+    WDEV void carry() {
+        int x = (int)pos - 1;
+        while (x >= 0 && uload8(out + x) == 0xff) {
+#if LEP_ON_GPU
+            if (threadIdx.x == 0) out[x] = 0;
+#else
+            out[x] = 0;
+#endif
+            --x;
+        }
+        if (x >= 0) {
+            const uint8_t v = (uint8_t)(uload8(out + x) + 1);
+#if LEP_ON_GPU
+            if (threadIdx.x == 0) out[x] = v;
+#else
+            out[x] = v;
+#endif
+        }
+    }
+    static WDEV uint32_t uload8(const uint8_t* p) {
+#if LEP_ON_GPU
+        uintptr_t a = (uintptr_t)p;
+        __asm__ volatile("" : "+v"(a));
+        return uni(*reinterpret_cast<const uint8_t*>(a));
+#else
+        return *p;
+#endif
+    }
+    WDEV void put(uint32_t bit, uint32_t prob) {
+#if LEP_ON_GPU
+        const uint32_t split = 1 + (__umul24(range - 1, prob) >> 8);
+#else
+        const uint32_t split = 1 + (((range - 1) * prob) >> 8);
+#endif
+        const uint32_t m = 0u - bit;
+        uint32_t l = low + (split & m);
+        uint32_t r = split + ((range - 2 * split) & m);
+        int shift = __builtin_clz(r) - 24;
+        r <<= shift;
+        int c = count + shift;
+        if (ucond(c >= 0)) {
+            const int offset = shift - c;
+            if (pos + 2 > cap) overflow = true;
+            if (!overflow) {
+                if (ucond(((l << (offset - 1)) & 0x80000000u) != 0)) carry();
+                emit((uint8_t)(l >> (24 - offset)));
+                ++pos;
+            }
+            l <<= offset;
+            shift = c;
+            l &= 0xffffff;
+            c -= 8;
+        }
+        l <<= shift;
+        count = c; low = l; range = r;
+    }
+    WDEV uint32_t finish() {
+        for (int i = 0; i < 32; ++i) put(0, 128);
+        if (!overflow && pos && (uload8(out + pos - 1) & 0xe0) == 0xc0) { emit(0); ++pos; }
+        return pos;
+    }
+};
+
+struct Enc3Wave {
+    const ImageDev* img;
+    uint32_t* model;
+    Enc3Shared* sh;
+    int comp, ci;
+    BoolEnc3 bc;
+    uint32_t nbins;
+
+    WDEV void init_tables() {
+        LANES(l) {
+            sh->r2a[l] = kR2A[l]; sh->a2r[l] = kA2R[l]; sh->nzbin[l] = l < 50 ? kNzBin[l] : 9;
+            for (int d = l; d < 96; d += 64) sh->sign[d] = kBranchInit;
+            if (l < (int)(sizeof(NSum) / 4)) { ((uint32_t*)&sh->ns_left)[l] = 0; ((uint32_t*)&sh->ns_above)[l] = 0; }
+        }
+        LSYNC();
+    }
+    WDEV void stage_component(int c) {
+        comp = c; ci = c ? 1 : 0;
+        LANES(l) {
+            sh->q[l] = img->q[c][l]; sh->icos_x[l] = img->icos_x[c][l]; sh->icos_y[l] = img->icos_y[c][l];
+            sh->thr[l] = img->min_thresh[c][l];
+        }
+        LSYNC();
+    }
+
+    // integer IDCT without DC (idct.cc:35-161), rows then columns, 8 lanes each
+    WDEV void idct_rows() {
+        constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
+        constexpr int w1pw7 = w1 + w7, w1mw7 = w1 - w7, w2pw6 = w2 + w6, w2mw6 = w2 - w6, w3pw5 = w3 + w5, w3mw5 = w3 - w5;
+        LANES(l) if (l < 8) {
+            const int y8 = l * 8;
+#define LEP_CQ5(i) ((int32_t)sh->here[sh->r2a[i]] * (int32_t)sh->q[i])
+            int32_t x0 = (l == 0 ? 0 : (int32_t)((uint32_t)LEP_CQ5(y8) << 11)) + 128;
+            int32_t x1 = (int32_t)((uint32_t)LEP_CQ5(y8 + 4) << 11);
+            int32_t x2 = LEP_CQ5(y8 + 6), x3 = LEP_CQ5(y8 + 2), x4 = LEP_CQ5(y8 + 1), x5 = LEP_CQ5(y8 + 7), x6 = LEP_CQ5(y8 + 5),
+                    x7 = LEP_CQ5(y8 + 3), x8;
+#undef LEP_CQ5
+            x8 = w7 * (x4 + x5); x4 = x8 + w1mw7 * x4; x5 = x8 - w1pw7 * x5;
+            x8 = w3 * (x6 + x7); x6 = x8 - w3mw5 * x6; x7 = x8 - w3pw5 * x7;
+            x8 = x0 + x1; x0 -= x1;
+            x1 = w6 * (x3 + x2); x2 = x1 - w2pw6 * x2; x3 = x1 + w2mw6 * x3;
+            x1 = x4 + x6; x4 -= x6; x6 = x5 + x7; x5 -= x7;
+            x7 = x8 + x3; x8 -= x3; x3 = x0 + x2; x0 -= x2;
+            x2 = (r2 * (x4 + x5) + 128) >> 8;
+            x4 = (r2 * (x4 - x5) + 128) >> 8;
+            int32_t* t = sh->t + y8;
+            t[0] = (x7 + x1) >> 8; t[1] = (x3 + x2) >> 8; t[2] = (x0 + x4) >> 8; t[3] = (x8 + x6) >> 8;
+            t[4] = (x8 - x6) >> 8; t[5] = (x0 - x4) >> 8; t[6] = (x3 - x2) >> 8; t[7] = (x7 - x1) >> 8;
+        }
+        LSYNC();
+        LANES(l) if (l < 8) {
+            const int32_t* t = sh->t + l;
+            int32_t y0 = (int32_t)((uint32_t)t[0] << 8) + 8192, y1 = (int32_t)((uint32_t)t[32] << 8);
+            int32_t y2 = t[48], y3 = t[16], y4 = t[8], y5 = t[56], y6 = t[40], y7 = t[24], y8;
+            y8 = w7 * (y4 + y5) + 4; y4 = (y8 + w1mw7 * y4) >> 3; y5 = (y8 - w1pw7 * y5) >> 3;
+            y8 = w3 * (y6 + y7) + 4; y6 = (y8 - w3mw5 * y6) >> 3; y7 = (y8 - w3pw5 * y7) >> 3;
+            y8 = y0 + y1; y0 -= y1;
+            y1 = w6 * (y3 + y2) + 4; y2 = (y1 - w2pw6 * y2) >> 3; y3 = (y1 + w2mw6 * y3) >> 3;
+            y1 = y4 + y6; y4 -= y6; y6 = y5 + y7; y5 -= y7;
+            y7 = y8 + y3; y8 -= y3; y3 = y0 + y2; y0 -= y2;
+            y2 = (r2 * (y4 + y5) + 128) >> 8;
+            y4 = (r2 * (y4 - y5) + 128) >> 8;
+            int16_t* o = sh->pix + l;
+            o[0] = (int16_t)((y7 + y1) >> 11); o[8] = (int16_t)((y3 + y2) >> 11); o[16] = (int16_t)((y0 + y4) >> 11);
+            o[24] = (int16_t)((y8 + y6) >> 11); o[32] = (int16_t)((y8 - y6) >> 11); o[40] = (int16_t)((y0 - y4) >> 11);
+            o[48] = (int16_t)((y3 - y2) >> 11); o[56] = (int16_t)((y7 - y1) >> 11);
+        }
+        LSYNC();
+    }
+    static WDEV int half16(int d) { return (int16_t)d / 2; }
+
+    // Encodes the block staged in sh->here (+ left / above / aleft when present).  Returns 0 or an exit code (uniform).
+    WDEV int encode_block(bool has_left, bool has_above) {
+        Enc3Shared& S = *sh;
+        LV(int, nzf); LV(int, tx); LV(int, ty);
+        LV(int, cnt); LV(int, ndup); LV(int, off); LV(int, doff); LV(int, bad);
+        LV(int, len_); LV(int, val_); LV(int, pos_); LV(int, nexp_); LV(int, coded_); LV(int, thr_); LV(int, isedge_);
+        LV(uint32_t, expbase_); LV(uint32_t, signidx_); LV(uint32_t, resbase_); LV(uint32_t, thrbase_);
+
+        LANES(l) {
+            const int a = l < 49 ? l : (l == 63 ? 49 : l + 1);
+            L(nzf) = S.here[a] != 0;
+        }
+        const uint64_t m = lepwave::wave_ballot(nzf);
+        const uint64_t mask7 = m & ((1ull << 49) - 1);
+        const uint32_t maskh = (uint32_t)(m >> 49) & 0x7f, maskv = (uint32_t)(m >> 56) & 0x7f;
+        const int nz = lepwave::popc64(mask7), neh = __builtin_popcount(maskh), nev = __builtin_popcount(maskv);
+        LANES(l) {
+            int ex = 0, ey = 0;
+            if (l < 49 && L(nzf)) { int coord = S.a2r[l]; ex = coord & 7; ey = coord >> 3; }
+            L(tx) = ex; L(ty) = ey;
+        }
+        const int eob_x = lepwave::wave_max(tx), eob_y = lepwave::wave_max(ty);
+
+        idct_rows();   // S.pix = IDCT of the block without its DC
+
+        int nzctx = 0;
+        if (has_left && has_above) nzctx = (S.ns_above.nz + S.ns_left.nz + 2) / 4;
+        else if (has_above) nzctx = (S.ns_above.nz + 1) / 2;
+        else if (has_left) nzctx = (S.ns_left.nz + 1) / 2;
+
+        // ---- P1: per-lane analysis (lane = coefficient: 0..48 interior in zig-zag order, 49..55 / 56..62 edges, 63 DC)
+        LANES(l) {
+            const int a = l < 49 ? l : (l == 63 ? 49 : l + 1);
+            int c = S.here[a];
+            int v = c < 0 ? -c : c, len = bitlen((uint32_t)v), pos = c >= 0;
+            int coded = 0, n = 0, nd = 0, nexp = 0, thr = 0, isedge = 0, err = 0;
+            uint32_t expbase = 0, signidx = 0, resbase = 0, thrbase = 0;
+            if (l < 49) {
+                const int before = lepwave::popc64(mask7 & ((1ull << l) - 1));
+                const int left_before = nz - before;
+                coded = left_before > 0;
+                if (coded) {
+                    int prior;
+                    if (has_left && has_above) prior = (uint16_t)((iabs(S.left[l]) + iabs(S.above[l])) * 13 + 6 * iabs(S.aleft[l])) >> 5;
+                    else if (has_left) prior = (int16_t)iabs(S.left[l]);
+                    else if (has_above) prior = (int16_t)iabs(S.above[l]);
+                    else prior = 0;
+                    const int nb = S.nzbin[left_before];
+                    const int bsr = bitlen((uint32_t)imin(iabs(prior), 1023));
+                    expbase = lepdev::kExp7 + ((((uint32_t)ci * 10 + nb) * 49 + l) * 12 + bsr) * 11;
+                    signidx = (uint32_t)ci * 48;
+                    resbase = lepdev::kRes + (((uint32_t)ci * 64 + S.a2r[l]) * 10 + nb) * 10;
+                }
+            } else if (l < 63) {
+                const bool horizontal = l < 56;
+                const int j = horizontal ? l - 49 : l - 56;
+                const uint32_t mk = horizontal ? maskh : maskv;
+                const int ne = horizontal ? neh : nev;
+                const int ne_before = ne - __builtin_popcount(mk & ((1u << j) - 1));
+                coded = ne_before > 0;
+                isedge = 1;
+                if (coded) {
+                    const int coord = horizontal ? j + 1 : (j + 1) * 8;
+                    int32_t prior = 0;
+                    const bool nbr_ok = horizontal ? has_above : has_left;
+                    if (nbr_ok) {
+                        const int16_t* nbr = horizontal ? S.above : S.left;
+                        const int32_t* icos = horizontal ? S.icos_x + coord * 8 : S.icos_y + coord;
+                        const int step = horizontal ? 8 : 1;
+                        if (icos[0] == 0) err = 39;
+                        else {
+                            uint32_t acc = (uint32_t)(int32_t)nbr[S.r2a[coord]] * (uint32_t)icos[0];
+                            for (int i = 1; i < 8; ++i) {
+                                int32_t xi = S.here[S.r2a[coord + i * step]], ai = nbr[S.r2a[coord + i * step]];
+                                int32_t term = (i & 1) ? xi + ai : xi - ai;
+                                acc -= (uint32_t)icos[i] * (uint32_t)term;
+                            }
+                            prior = (int32_t)acc / icos[0];
+                        }
+                    }
+                    const uint32_t aprior = prior < 0 ? 0u - (uint32_t)prior : (uint32_t)prior;
+                    const int bsr = bitlen(aprior > 1023 ? 1023 : aprior);
+                    const int16_t p16 = (int16_t)prior;
+                    const int sctx = p16 == 0 ? 0 : (p16 > 0 ? 1 : 2);
+                    thr = S.thr[coord];
+                    expbase = lepdev::kExpX + ((((uint32_t)ci * 10 + ne_before) * 15 + (horizontal ? j : j + 7)) * 12 + bsr) * 11;
+                    signidx = ((uint32_t)ci * 4 + sctx) * 12 + bsr;
+                    resbase = lepdev::kRes + (((uint32_t)ci * 64 + coord) * 10 + ne_before) * 10;
+                    if (len > 1 && len - 2 >= thr) {
+                        nd = len - 1 - thr;
+                        thrbase = lepdev::kThresh + ((((uint32_t)ci * 256 + (uint32_t)imin((int)((aprior & 0xffff) >> thr), 255)) * 8) +
+                                                     (uint32_t)imin(len - thr, 7)) * 128;
+                    }
+                }
+            } else {   // DC
+                coded = 1;
+                int32_t avgmed = 0, unc = 0, unc2 = 0;
+                if (has_left || has_above) {
+                    int cntest = 0, sum0 = 0, sum1 = 0, mn = 0, mx = 0;
+                    for (int side = 0; side < 2; ++side) {
+                        if (side == 0 ? !has_left : !has_above) continue;
+                        for (int i = 0; i < 8; ++i, ++cntest) {
+                            int e;
+                            if (side == 0) e = (int16_t)(S.ns_left.vert[i] - half16(S.pix[i * 8] - S.pix[i * 8 + 1]) - (S.pix[i * 8] + 1024));
+                            else e = (int16_t)(S.ns_above.horiz[i] - half16(S.pix[i] - S.pix[i + 8]) - (S.pix[i] + 1024));
+                            if (cntest < 8) sum0 += e; else sum1 += e;
+                            if (cntest == 0) { mn = mx = e; }
+                            if (e < mn) mn = e;
+                            if (e > mx) mx = e;
+                        }
+                    }
+                    if (cntest == 8) sum1 = sum0;
+                    avgmed = (sum0 + sum1) >> 1;
+                    unc = (mx - mn) >> 3;
+                    sum0 -= avgmed; sum1 -= avgmed;
+                    unc2 = (iabs(sum0) < iabs(sum1) ? sum0 : sum1) >> 3;
+                }
+                const int pred = (avgmed / (int)S.q[0] + 4) >> 3;
+                const int ua = imin(bitlen((uint32_t)iabs(unc) & 0xffff), 11), ub = imin(bitlen((uint32_t)iabs(unc2) & 0xffff), 16);
+                int d = c - pred;
+                if (d < -1024) d += 2049;
+                if (d > 1024) d -= 2049;
+                int back = d + pred;
+                if (back < -1024) back += 2049;
+                if (back > 1024) back -= 2049;
+                if (back != c) err = 6;
+                v = iabs(d); len = bitlen((uint32_t)v & 0xffff); pos = d >= 0;
+                expbase = lepdev::kExpDc + ((uint32_t)ua * 17 + ub) * 11;
+                signidx = (uint32_t)ci * 48 + (unc2 >= 0 ? (unc2 == 0 ? 3 : 2) : 1);
+                resbase = lepdev::kResDc + (uint32_t)ua * 10;
+            }
+            if (coded) {
+                if (len > 11) err = 6;
+                nexp = len < 11 ? len + 1 : 11;
+                n = nexp + (len ? 1 : 0) + (len > 1 ? len - 1 : 0);
+            } else nd = 0;
+            if (l == 0) n += 6;
+            if (l == 49 || l == 56) n += 3;
+            L(cnt) = n; L(ndup) = nd; L(bad) = err;
+            L(len_) = len; L(val_) = v; L(pos_) = pos; L(nexp_) = nexp; L(coded_) = coded; L(thr_) = thr; L(isedge_) = isedge;
+            L(expbase_) = expbase; L(signidx_) = signidx; L(resbase_) = resbase; L(thrbase_) = thrbase;
+        }
+        const uint64_t badmask = lepwave::wave_ballot(bad);
+        if (badmask) {   // report what the serial coder would have hit first (lane order = stream order)
+            LV(int, bad39);
+            LANES(l) L(bad39) = L(bad) == 39;
+            const uint64_t m39 = lepwave::wave_ballot(bad39);
+            return ((m39 >> __builtin_ctzll(badmask)) & 1) ? 39 : 6;
+        }
+        const int N = lepwave::wave_excl_scan(cnt, off);
+        lepwave::wave_excl_scan(ndup, doff);
+
+        // The bin list is produced, resolved and coded lane-range by lane-range so that it never holds more than kBinChunk
+        // entries (a lane emits at most 28 bins; ordinary blocks are one range of all 64 lanes).
+        int lane0 = 0;
+        while (lane0 < 64) {
+            // largest lane range [lane0, lane1) whose bins fit
+            LV(int, fits);
+            const int base = (int)lepwave::wave_read((const uint32_t*)off, lane0);
+            LANES(l) L(fits) = l >= lane0 && L(off) + L(cnt) - base <= kBinChunk;
+            const uint64_t fm = lepwave::wave_ballot(fits) >> lane0;
+            const int lane1 = lane0 + (fm == ~0ull >> lane0 ? 64 - lane0 : __builtin_ctzll(~fm));
+            const int n = (lane1 < 64 ? (int)lepwave::wave_read((const uint32_t*)off, lane1) : N) - base;
+            const int dbase = (int)lepwave::wave_read((const uint32_t*)doff, lane0);
+            const int D = (lane1 < 64 ? (int)lepwave::wave_read((const uint32_t*)doff, lane1) : dbase + 0x7fffffff) ;
+            // ---- P2: bin emission ---------------------------------------------------------------------
+            LV(int, dcount);
+            LANES(l) {
+                int dj = L(doff) - dbase;
+                if (l >= lane0 && l < lane1) {
+                    int j = L(off) - base;
+                    if (l == 0) {
+                        const uint32_t T = lepdev::kNz7x7 + ((uint32_t)ci * 26 + S.nzbin[nzctx]) * 192;
+                        int so_far = 0;
+                        for (int i = 5; i >= 0; --i) { int b = (nz >> i) & 1; S.bins[j++] = (T + i * 32 + so_far) | ((uint32_t)b << 31); so_far = (so_far << 1) | b; }
+                    }
+                    if (l == 49 || l == 56) {
+                        const bool horizontal = l == 49;
+                        const uint32_t T = (horizontal ? lepdev::kNz8x1 : lepdev::kNz1x8) + (((uint32_t)ci * 8 + (horizontal ? eob_x : eob_y)) * 8 + (nz + 3) / 7) * 12;
+                        const int ne = horizontal ? neh : nev;
+                        int so_far = 0;
+                        for (int i = 2; i >= 0; --i) { int b = (ne >> i) & 1; S.bins[j++] = (T + i * 4 + so_far) | ((uint32_t)b << 31); so_far = (so_far << 1) | b; }
+                    }
+                    if (L(coded_)) {
+                        const int len = L(len_), v = L(val_), nexp = L(nexp_);
+                        for (int i = 0; i < nexp; ++i) S.bins[j++] = (L(expbase_) + i) | ((uint32_t)(len != i) << 31);
+                        if (len) S.bins[j++] = L(signidx_) | kResident3 | ((uint32_t)L(pos_) << 31);
+                        if (len > 1) {
+                            int b = len - 2;
+                            if (L(isedge_) && b >= L(thr_)) {
+                                int s = 1;
+                                for (; b >= L(thr_); --b) {
+                                    int bit = (v >> b) & 1;
+                                    S.dup[dj++] = (uint16_t)j;
+                                    S.bins[j++] = (L(thrbase_) + s) | ((uint32_t)bit << 31);
+                                    s = imin((s << 1) | bit, 127);
+                                }
+                            }
+                            for (; b >= 0; --b) S.bins[j++] = (L(resbase_) + b) | ((uint32_t)((v >> b) & 1) << 31);
+                        }
+                    }
+                }
+                L(dcount) = (l >= lane0 && l < lane1) ? L(ndup) : 0;
+            }
+            (void)D;
+            LV(int, dtmp);
+            const int Dn = lepwave::wave_excl_scan(dcount, dtmp);   // threshold bins in this range
+            LSYNC();
+
+            // ---- P3a: bins with a block-unique Branch: parallel load / adapt / store ------------------
+            // (two rounds of loads are issued before the first use, so their HBM latencies overlap)
+            for (int b0 = 0; b0 < n; b0 += 128) {
+                LV(uint32_t, w0); LV(uint32_t, w1);
+                LANES(l) {
+                    const int j0 = b0 + l, j1 = b0 + 64 + l;
+                    uint32_t a = 0, b = 0;
+                    if (j0 < n) { const uint32_t e = S.bins[j0]; if (!(e & kResident3) && (e & 0x3fffffffu) < lepdev::kThresh) a = model[e & 0x3fffffffu]; }
+                    if (j1 < n) { const uint32_t e = S.bins[j1]; if (!(e & kResident3) && (e & 0x3fffffffu) < lepdev::kThresh) b = model[e & 0x3fffffffu]; }
+                    L(w0) = a; L(w1) = b;
+                }
+                LANES(l) {
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = b0 + h * 64 + l;
+                        if (j < n) {
+                            const uint32_t e = S.bins[j], idx = e & 0x3fffffffu;
+                            if (!(e & kResident3) && idx < lepdev::kThresh) {
+                                const uint32_t w = h ? L(w1) : L(w0);
+                                const int bit = (int)(e >> 31);
+                                model[idx] = bupd(w, bit);
+                                S.bins[j] = (w >> 16) | ((uint32_t)bit << 8);
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- P3b: threshold bins (rare; their Branch can repeat inside a block): in-order forwarding ---
+            for (int cb = 0; cb < Dn; cb += 64) {
+                LV(uint32_t, didx); LV(uint32_t, dw); LV(uint32_t, dbit); LV(int, djpos); LV(int, dlast);
+                const int nn = Dn - cb < 64 ? Dn - cb : 64;
+                LANES(l) {
+                    uint32_t idx = 0xffffffffu, w = 0, bit = 0;
+                    int j = -1;
+                    if (l < nn) {
+                        j = S.dup[cb + l];
+                        const uint32_t e = S.bins[j];
+                        idx = e & 0x3fffffffu; bit = e >> 31;
+                        w = model[idx];
+                    }
+                    L(didx) = idx; L(dw) = w; L(dbit) = bit; L(djpos) = j; L(dlast) = 1;
+                }
+                for (int r = 0; r < nn; ++r) {
+                    const uint32_t ridx = lepwave::wave_read(didx, r), rw = lepwave::wave_read(dw, r), rbit = lepwave::wave_read(dbit, r);
+                    const uint32_t nw = bupd_s(rw, (int)rbit);
+                    LANES(l) {
+                        if (l == r) { S.bins[L(djpos)] = (rw >> 16) | (rbit << 8); L(dw) = nw; }
+                        else if (L(didx) == ridx) { if (l > r) L(dw) = nw; else L(dlast) = 0; }
+                    }
+                }
+                LANES(l) if (l < nn && L(dlast)) model[L(didx)] = L(dw);
+                LSYNC();
+            }
+            LSYNC();
+
+            // ---- P4: bool coder over the resolved (bit, probability) pairs: uniform vector code ------------
+            for (int b0 = 0; b0 < n; b0 += 64) {
+                LV(uint32_t, mybin);
+                LANES(l) L(mybin) = b0 + l < n ? S.bins[b0 + l] : 0u;
+                const int cntb = n - b0 < 64 ? n - b0 : 64;
+#pragma nounroll
+                for (int jj = 0; jj < cntb; ++jj) {
+                    const uint32_t e = lepwave::wave_read(mybin, jj);
+                    if (e & kResident3) {
+                        const uint32_t slot = e & 127, bit = e >> 31;
+                        const uint32_t w = vec(S.sign[slot]);
+                        bc.put(bit, w >> 16);
+                        S.sign[slot] = bupd(w, (int)bit);
+                    } else bc.put((e >> 8) & 1, e & 255);
+                }
+            }
+            LSYNC();
+            lane0 = lane1;
+        }
+        nbins += (uint32_t)N;
+
+        // ---- P5: neighbour summary of this block ----------------------------------------------------
+        LANES(l) {
+            if (l < 16) {
+                const int i = l & 7;
+                const int dcq = S.here[49] * (int)S.q[0];
+                if (l < 8) S.ns_here.horiz[i] = (int16_t)(dcq + S.pix[56 + i] + 1024 + half16(S.pix[56 + i] - S.pix[48 + i]));
+                else S.ns_here.vert[i] = (int16_t)(dcq + S.pix[i * 8 + 7] + 1024 + half16(S.pix[i * 8 + 7] - S.pix[i * 8 + 6]));
+            }
+            if (l == 16) S.ns_here.nz = nz;
+        }
+        LSYNC();
+        return 0;
+    }
+
+    // whole segment; ns = this segment's NSum area (zeroed); returns exit code
+    WDEV int run(const ImageDev* image, const SegDev& seg, uint32_t* model_words, NSum* ns, Enc3Shared* shared, uint8_t* stream,
+                 uint32_t cap) {
+        img = image; model = model_words; sh = shared; nbins = 0;
+        init_tables();
+        bc.init_stream(stream, cap);
+        bool top[3] = {true, true, true};
+        SegmentCoder<false> sched;   // only its row schedule is used
+        sched.img = image;
+        for (uint32_t idx = 0;; ++idx) {
+            SegmentCoder<false>::RowSpec r = sched.row_spec(idx);
+            if (r.done) break;
+            if (r.luma_y >= seg.y1 && !seg.is_last) break;
+            if (r.skip) continue;
+            if (r.luma_y < seg.y0) continue;
+            stage_component(r.component);
+            const int w = img->width[comp], yb = r.curr_y;
+            const int16_t* row = img->blocks[comp] + (int64_t)yb * w * 64;
+            const bool has_above = !top[comp];
+            const int16_t* arow = has_above ? row - (int64_t)w * 64 : nullptr;
+            NSum* nrow = ns + img->ns_offset[comp] + (yb & 1) * w;
+            const NSum* narow = ns + img->ns_offset[comp] + ((yb & 1) ^ 1) * w;
+            top[comp] = false;
+            LV(int16_t, nxt_here); LV(int16_t, nxt_above); LV(uint32_t, nxt_ns);
+            LANES(l) {   // block 0; later blocks are fetched one block ahead
+                L(nxt_here) = row[l];
+                L(nxt_above) = has_above ? arow[l] : (int16_t)0;
+                L(nxt_ns) = (has_above && l < (int)(sizeof(NSum) / 4)) ? ((const uint32_t*)&narow[0])[l] : 0u;
+            }
+            for (int x = 0; x < w; ++x) {
+                // P0: stage blocks.  left / above-left come from the previous block's LDS copies.
+                LANES(l) {
+                    if (x) { sh->left[l] = sh->here[l]; sh->aleft[l] = sh->above[l]; }
+                    if (l < (int)(sizeof(NSum) / 4)) {
+                        if (x) ((uint32_t*)&sh->ns_left)[l] = ((const uint32_t*)&sh->ns_here)[l];
+                        if (has_above) ((uint32_t*)&sh->ns_above)[l] = L(nxt_ns);
+                    }
+                }
+                LSYNC();
+                LANES(l) {
+                    sh->here[l] = L(nxt_here);
+                    if (has_above) sh->above[l] = L(nxt_above);
+                    if (x + 1 < w) {
+                        L(nxt_here) = row[(int64_t)(x + 1) * 64 + l];
+                        if (has_above) {
+                            L(nxt_above) = arow[(int64_t)(x + 1) * 64 + l];
+                            if (l < (int)(sizeof(NSum) / 4)) L(nxt_ns) = ((const uint32_t*)&narow[x + 1])[l];
+                        }
+                    }
+                }
+                LSYNC();
+                int rc = encode_block(x > 0, has_above);
+                if (rc) return rc;
+                LANES(l) if (l < (int)(sizeof(NSum) / 4)) ((uint32_t*)&nrow[x])[l] = ((const uint32_t*)&sh->ns_here)[l];
+                if (x + 1 < w && yb * w + x + 1 >= img->coded_blocks[comp]) break;
+            }
+        }
+        return 0;
+    }
+};
+
+}  // namespace lep3

@@ -18,6 +18,7 @@
 #include "lep_enc2.h"
 #include "lep_dec2.h"
 #include "lep_dec3.h"
+#include "lep_enc3.h"
 
 using namespace lepdev;
 
@@ -87,6 +88,28 @@ __global__ __launch_bounds__(64) void lep_encode_v2_kernel(const ImageDev* __res
     int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, seg.stream_cap);
     if (lane != 0) return;
     uint32_t n = rc ? 0 : w.bc.finish();
+    if (!rc && w.bc.overflow) rc = LEP_BUFFER_TOO_SMALL;
+    stream_len[s] = n;
+    status[s] = rc;
+    bins[s] = w.nbins;
+}
+
+// v3 encoder: v2's phases at 8 wavefronts per SIMD, bool coder as uniform vector code (lep_enc3.h)
+__global__ __launch_bounds__(64, 8) void lep_encode_v3_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
+                                                              uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
+                                                              uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
+    __shared__ lep3::Enc3Shared sh;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const SegDev seg = segs[s];
+    const ImageDev* img = images + seg.image;
+    uint32_t* model = models + (size_t)s * kModelStride;
+    NSum* ns = ns_area + ns_offsets[s];
+    reset_segment_state(model, ns, img->ns_total, lane);
+    __syncthreads();
+    lep3::Enc3Wave w;
+    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, seg.stream_cap);
+    uint32_t n = rc ? 0 : w.bc.finish();
+    if (lane != 0) return;
     if (!rc && w.bc.overflow) rc = LEP_BUFFER_TOO_SMALL;
     stream_len[s] = n;
     status[s] = rc;
@@ -166,7 +189,7 @@ struct lep_gpu {
     bool timed = false;
     int decode_kernel = 3;   // 3 = v3 (default), 2 = v2 prefetch rounds, 1 = single-lane reference kernel (LEP_DECODE_KERNEL)
     int dec3_waves = 0;      // register budget variant of the v3 decoder: 0 = by batch size, LEP_DEC3_WAVES = 4 | 5 | 6 | 8
-    int encode_kernel = 2;   // 2 = wave-cooperative (default), 1 = single-lane reference kernel (LEP_ENCODE_KERNEL=1)
+    int encode_kernel = 3;   // 3 = v3 (default), 2 = v2 wave-cooperative, 1 = single-lane reference kernel (LEP_ENCODE_KERNEL)
     std::string err;
     const char* last_kernel = "";   // name of the kernel the most recent launch used
     // grow-only device workspace
@@ -263,6 +286,11 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         hipLaunchKernelGGL(lep_decode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
                            (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
+    } else if (!DEC && g->encode_kernel == 3) {
+        g->last_kernel = "lep_encode_v3_kernel";
+        hipLaunchKernelGGL(lep_encode_v3_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
+                           (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                           d_streams, d_stream_len, d_status, g->d_bins);
     } else if (!DEC && g->encode_kernel == 2) {
         g->last_kernel = "lep_encode_v2_kernel";
         hipLaunchKernelGGL(lep_encode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
@@ -285,7 +313,7 @@ extern "C" {
 int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
-    if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3;
     if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3;
     if (const char* e = getenv("LEP_DEC3_WAVES")) g->dec3_waves = atoi(e);
     int n = 0;

@@ -104,3 +104,24 @@ extern "C" int emu_decode_segment_v3(const lep_image_desc* d, int y0, int y1, in
     if (bins) *bins = w.nbins;
     return rc;
 }
+
+// v3 encoder (lep_enc3.h) as a 64-lane loop emulation
+#include "../../lepton_amd/csrc/lep_enc3.h"
+extern "C" int emu_encode_segment_v3(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins) {
+    ImageDev img;
+    int rc = derive_image(*d, &img, true);
+    if (rc) return rc;
+    std::vector<uint32_t> model(kModelBranches, kBranchInit);
+    std::vector<NSum> ns(img.ns_total);
+    memset(ns.data(), 0, ns.size() * sizeof(NSum));
+    SegDev seg;
+    seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = cap;
+    static lep3::Enc3Shared sh;
+    lep3::Enc3Wave w;
+    rc = w.run(&img, seg, model.data(), ns.data(), &sh, out, cap);
+    if (rc) return rc;
+    *len = w.bc.finish();
+    if (w.bc.overflow) return LEP_BUFFER_TOO_SMALL;
+    if (bins) *bins = w.nbins;
+    return 0;
+}

@@ -147,3 +147,56 @@ def test_v3_decoder_unaligned_stream_start(emu, shift):
     for c in range(d.ncomp):
         n = d.coded_blocks[c] * 128
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_v3_encoder_on_cpu_matches_oracle(emu, name):
+    """lep_enc3.h (lane-range bin list, uniform-vector bool coder) as a 64-lane loop emulation == oracle streams"""
+    jpg, _ = golden(name)
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    total = 0
+    for s, w in zip(segs, want):
+        cap = len(w) + 4096
+        buf = C.create_string_buffer(cap)
+        n, nb = C.c_uint32(0), C.c_uint32(0)
+        rc = emu.emu_encode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, cap, C.byref(n), C.byref(nb))
+        assert rc == 0 and buf.raw[: n.value] == w
+        total += nb.value
+    assert total == bins
+
+
+def test_v3_encoder_many_bins_per_block(emu):
+    """blocks whose bin list does not fit one 512-entry lane range (large coefficients everywhere) are coded in several
+    ranges; streams must still equal the oracle's, and out-of-range coefficients are reported like the reference does"""
+    import numpy as np
+    from lepton_amd import corpus
+
+    img = JpegImage(corpus.synth_jpeg(64, 48, 11, quality=100))
+    d = img.desc
+    rng = np.random.default_rng(5)
+    for c in range(d.ncomp):
+        n = d.nblocks(c) * 64
+        arr = (C.c_int16 * n).from_address(d.blocks[c])
+        vals = rng.integers(-255, 256, n)
+        vals[rng.random(n) < 0.1] = 0
+        for i in range(n):
+            arr[i] = int(vals[i])
+        for b in range(d.nblocks(c)):
+            arr[b * 64 + 49] = 0
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    assert bins > 560 * sum(d.nblocks(c) for c in range(d.ncomp))   # really > 512 bins per block
+    for s, w in zip(segs, want):
+        cap = len(w) + 4096
+        buf = C.create_string_buffer(cap)
+        n = C.c_uint32(0)
+        rc = emu.emu_encode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, cap, C.byref(n), None)
+        assert rc == 0 and buf.raw[: n.value] == w
+    C.cast(d.blocks[0], C.POINTER(C.c_int16))[5] = 4096
+    s = segs[0]
+    buf = C.create_string_buffer(1 << 20)
+    n = C.c_uint32(0)
+    assert emu.emu_encode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, len(buf), C.byref(n), None) == 6

@@ -99,8 +99,8 @@ def test_gpu_decode_of_garbage_stream_is_contained(gpu_codec):
         assert e.code in (6, 7, 39)
 
 
-def test_gpu_v1_and_v2_encoders_agree(monkeypatch):
-    """single-lane kernel (LEP_ENCODE_KERNEL=1) and wave-cooperative kernel produce identical streams"""
+def test_gpu_encoder_generations_agree(monkeypatch):
+    """single-lane kernel (LEP_ENCODE_KERNEL=1), v2 wave-cooperative and v3 (default) kernels produce identical streams"""
     jpgs = [corpus.synth_jpeg(512, 384, 21), corpus.synth_jpeg(96, 200, 22, quality=60)]
     imgs = [JpegImage(j) for j in jpgs]
     plans = [im.plan() for im in imgs]
@@ -109,6 +109,33 @@ def test_gpu_v1_and_v2_encoders_agree(monkeypatch):
     monkeypatch.setenv("LEP_ENCODE_KERNEL", "2")
     b = GpuCodec(0).encode(imgs, plans)
     assert a == b
+    monkeypatch.setenv("LEP_ENCODE_KERNEL", "3")
+    c = GpuCodec(0).encode(imgs, plans)
+    assert a == c
+    for im, p, g in zip(imgs, plans, c):
+        want, _ = ob.oracle_encode(im.desc, p)
+        assert g == want
+
+
+def test_gpu_v3_encoder_many_bins_per_block(gpu_codec):
+    """blocks with more than 512 bins go through several lane ranges of the bin list (lep_enc3.h); streams == oracle"""
+    import numpy as np
+
+    img = JpegImage(corpus.synth_jpeg(64, 48, 11, quality=100))
+    d = img.desc
+    rng = np.random.default_rng(5)
+    for c in range(d.ncomp):
+        n = d.nblocks(c) * 64
+        arr = (C.c_int16 * n).from_address(d.blocks[c])
+        vals = rng.integers(-255, 256, n)
+        vals[rng.random(n) < 0.1] = 0
+        for i in range(n):
+            arr[i] = int(vals[i])
+        for b in range(d.nblocks(c)):
+            arr[b * 64 + 49] = 0
+    plan = img.plan()
+    want, _ = ob.oracle_encode(d, plan)
+    assert gpu_codec.encode([img], [plan])[0] == want
 
 
 def test_gpu_v1_and_v2_decoders_agree(monkeypatch):
