@@ -1,0 +1,722 @@
+// lep_dec4.h -- "v4" decoder.  Same boundary, model layout (lep_v3.h) and owner-lane scheme as v3; what changes, and
+// why (measured on MI355X, profiles/r01c_*, profiles/r01_issue_microbench.txt):
+//   * v3 ran the serial part wave-uniform on the scalar unit: 5.6k SALU instructions per block, and the CU's one scalar
+//     unit saturates at ~0.85 instructions/cycle.  The bool-decoder recurrence written as UNIFORM VECTOR code (every lane
+//     computes the same value in VGPRs, branches taken on ballots) runs 1.85x faster at 8 waves/SIMD.  v4's serial code is
+//     uniform vector code; the scalar unit only keeps loop counters and lane indices.
+//   * v3 needed 10.2 prefetch/serial/update rounds per block (5.15 of them for the 7x7 interior, because a round ended
+//     whenever "non-zeros left" moved to another bin).  v4 prefetches, per window position, the contexts of FOUR
+//     consecutive non-zero bins (lane = position + 16 * candidate), so an interior round normally runs to the end of its
+//     16-position window; and it codes both edge count trees and both edges in ONE round (lane = every reachable
+//     (position, edge-non-zeros-left) pair: 28 per edge).  Typical block: NZ + 1..2 interior + 1 edge + 1 DC round.
+//   * the DC residual Branches (LDS resident) are handed to lanes before the DC round and adapted by them afterwards.
+// Syntax / contexts: src/vp8/decoder/decoder.cc:27-141,167-318; src/vp8/model/model.hh:463-485,852-871,1033-1122,674-832
+// (the same citations as lep_core.h, whose results this kernel reproduces bit for bit).
+#pragma once
+#include "lep_v3.h"
+#include "lep_enc3.h"   // ucond()
+
+namespace lep4 {
+using namespace lep3;
+
+struct Dec4Shared {
+    uint32_t sign[kSignWords];    // resident Branches
+    uint32_t resdc[kResDcWords];
+    int32_t t[64];                // IDCT intermediate
+    int32_t icos_x[64], icos_y[64];
+    int32_t eprior[16];           // Lakhani priors of the 14 edge positions; [14] = bit mask of positions whose prior divides by zero
+    int16_t here[64], left[64], above[64], aleft[64];   // aligned order
+    int16_t pix[64];
+    uint16_t q[64];
+    uint8_t thr[64], r2a[64], a2r[64], nzbin[64], bsr[64];
+    uint8_t cj[32], cn[32];       // edge combo -> position / non-zeros-left
+    NSum ns_left, ns_above, ns_here;
+};
+
+// kNzBin for 0 <= left <= 49 without a memory access (scalar arithmetic on the GPU)
+WDEV int nzbin_of(int left) {
+    return left < 16 ? (int)((0x7776666555443210ull >> (4 * left)) & 15) : (left < 21 ? 7 : (left < 32 ? 8 : 9));
+}
+// first combo of edge position j (combos of a position = its reachable "non-zeros left" values 1 .. 7-j): 0,7,13,18,22,25,27
+WDEV int combo_base(int j) { return (int)((0x1b65648d1c0ull >> (6 * j)) & 63); }
+
+// Branch::record_obs_and_update (branch.hh:82-100) for a uniform-vector word and observation (0/1); rare paths on ballots
+WDEV uint32_t bupd_u(uint32_t w, uint32_t obs) {
+    uint32_t f = (w & 255) + (obs ^ 1), t = ((w >> 8) & 255) + obs;
+    if (ucond((f | t) > 255)) {   // the incremented count was 255
+        const uint32_t f0 = w & 255, t0 = (w >> 8) & 255;
+        if (ucond((obs ? f0 : t0) == 1)) return (w & 0xffff) | ((obs ? 0u : 255u) << 16);
+        f = obs ? (1 + f0) >> 1 : 129u;
+        t = obs ? 129u : (1 + t0) >> 1;
+    }
+    return f | (t << 8) | (prob_of(f, t) << 16);
+}
+
+// ---- bool decoder (boolreader.hh:184-258, 376-416; boolreader.cc:25-34) as uniform vector code ----------------------
+// 64-bit window (vhi:vlo) refilled with one ALIGNED dword at a time, the next dword requested one refill ahead.  Bytes
+// outside [0, len) of the stream are never loaded and read as zero bits (the reference's behaviour past the end).
+struct BoolDec4 {
+    uint32_t vhi, vlo;      // top-aligned window
+    int count;              // valid bits - 8
+    uint32_t range;
+    const uint32_t* words;  // aligned dword that holds stream byte 0
+    uint32_t first, end;    // stream bytes live at byte offsets [first, end) from `words`
+    uint32_t wi;            // index of the dword `raw` holds
+    uint32_t raw;           // words[wi] as loaded (0 if it holds no stream byte)
+
+    WDEV uint32_t fetch(uint32_t k) const { return k * 4 < end ? words[k] : 0u; }
+    WDEV void refill() {
+        const uint32_t lo = wi * 4;
+        uint32_t w = __builtin_bswap32(raw);
+        int nbits = 32;
+        if (lo + 4 > end) w = lo < end ? (w & ~(0xffffffffu >> ((end - lo) * 8))) : 0u;   // bytes past the end -> 0
+        if (lo < first) { w <<= (first - lo) * 8; nbits -= (int)(first - lo) * 8; }              // bytes before the start
+        const uint64_t add = ((uint64_t)w << 32) >> (count + 8);
+        vhi |= (uint32_t)(add >> 32); vlo |= (uint32_t)add;
+        count += nbits;
+        ++wi;
+        raw = fetch(wi);
+    }
+    WDEV void init_stream(const uint8_t* p, uint32_t n) {
+        const uint32_t mis = (uint32_t)((uintptr_t)p & 3);
+        words = reinterpret_cast<const uint32_t*>(p - mis);
+        first = mis; end = mis + n;
+        vhi = vec(0); vlo = vec(0); count = (int)vec((uint32_t)-8); range = vec(255); wi = 0;
+        raw = fetch(0);
+        refill();
+        get(128);
+    }
+    // returns the decoded bit (0 / 1) as a uniform vector value
+    WDEV uint32_t get(uint32_t prob) {
+#if LEP_ON_GPU
+        const uint32_t split = 1 + (__umul24(range - 1, prob) >> 8);
+#else
+        const uint32_t split = 1 + (((range - 1) * prob) >> 8);
+#endif
+        if (ucond(count < 0)) refill();
+        const uint32_t big = split << 24;
+        const uint32_t bit = vhi >= big ? 1u : 0u;
+        const uint32_t d = vhi - big;
+        vhi = d < vhi ? d : vhi;                 // subtract only when it does not wrap, i.e. when bit = 1 (d == vhi iff big == 0: never)
+        range = bit ? range - split : split;
+#ifdef LEP_TRACE_GET
+        LEP_TRACE_GET(prob, (int)bit);
+#endif
+        const int shift = __builtin_clz(range) - 24;
+        range <<= shift;
+        const uint64_t v = (((uint64_t)vhi << 32) | vlo) << shift;
+        vhi = (uint32_t)(v >> 32); vlo = (uint32_t)v;
+        count -= shift;
+        return bit;
+    }
+};
+
+struct Dec4Wave {
+    const ImageDev* img;
+    uint32_t* model;
+    Dec4Shared* sh;
+    int comp, ci;
+    BoolDec4 bc;
+    uint32_t nbins;   // bins decoded, accounted per coefficient: a coefficient of bit length len costs 2*len+1 bins (22 at len 11)
+
+    WDEV void init_tables() {
+        LANES(l) {
+            sh->r2a[l] = kR2A[l]; sh->a2r[l] = kA2R[l]; sh->nzbin[l] = l < 50 ? kNzBin[l] : 9;
+            for (int d = l; d < kSignWords; d += 64) sh->sign[d] = kBranchInit;
+            for (int d = l; d < kResDcWords; d += 64) sh->resdc[d] = kBranchInit;
+            if (l < (int)(sizeof(NSum) / 4)) { ((uint32_t*)&sh->ns_left)[l] = 0; ((uint32_t*)&sh->ns_above)[l] = 0; }
+            if (l < 32) {
+                int j = 0, c = l;
+                while (j < 6 && c >= 7 - j) { c -= 7 - j; ++j; }
+                sh->cj[l] = (uint8_t)(l < 28 ? j : 7); sh->cn[l] = (uint8_t)(l < 28 ? c + 1 : 0);
+            }
+        }
+        LSYNC();
+    }
+    WDEV void stage_component(int c) {
+        comp = c; ci = c ? 1 : 0;
+        LANES(l) {
+            sh->q[l] = img->q[c][l]; sh->icos_x[l] = img->icos_x[c][l]; sh->icos_y[l] = img->icos_y[c][l];
+            sh->thr[l] = img->min_thresh[c][l];
+        }
+        LSYNC();
+    }
+
+    // ---- serial helpers (uniform vector code) ------------------------------------------------------------------------
+    WDEV uint32_t dec_global(uint32_t idx) {   // a Branch outside the prefetched set: coded straight from HBM
+        const uint32_t w = vload(model + idx);
+        const uint32_t bit = bc.get(w >> 16);
+        const uint32_t nw = bupd_u(w, bit);
+#if LEP_ON_GPU
+        if (threadIdx.x == 0) model[idx] = nw;
+#else
+        model[idx] = nw;
+#endif
+        return bit;
+    }
+    static WDEV uint32_t vload(const uint32_t* p) {   // every lane loads the same word through the vector cache
+#if LEP_ON_GPU
+        uintptr_t a = (uintptr_t)p;
+        __asm__ volatile("" : "+v"(a));
+        return *reinterpret_cast<const uint32_t*>(a);
+#else
+        return *p;
+#endif
+    }
+    // up to four unary bins from the packed probabilities of one exponent group; returns the number of ones (0..4)
+    WDEV int dec_unary4(uint32_t pk) {
+        int i = 0;
+#pragma nounroll
+        for (; i < 4; ++i) {
+            if (!ucond(bc.get(pk & 255) != 0)) break;
+            pk >>= 8;
+        }
+        return i;
+    }
+    WDEV int dec_unary_tail(uint32_t gbase) {   // exponent bins 8..10 straight from HBM (|v| >= 128: rare)
+        int i = 8;
+#pragma nounroll
+        for (; i < 11; ++i) if (!ucond(dec_global(gbase + i) != 0)) break;
+        return i;
+    }
+    // residual bits b..0 (b <= 3) of |v| from the packed probabilities of the residual group
+    WDEV uint32_t dec_residual(uint32_t pk, int b, uint32_t v) {
+#pragma nounroll
+        for (; b >= 0; --b) v |= bc.get((pk >> (b * 8)) & 255) << b;
+        return v;
+    }
+    // a `levels`-level binary tree decoded MSB first; the d-th decoded level has 2^d nodes stored as whole groups owned
+    // by lanes base + first(d) .., first = 0,1,2,3,5,9 (1,1,1,2,4,8 groups per level)
+    WDEV int dec_tree(int levels, const uint32_t* PK, int base) {
+        int n = 0;
+#pragma nounroll
+        for (int d = 0; d < levels; ++d) {
+            const int g = d < 3 ? d : (1 << (d - 2)) + 1;
+            const uint32_t pk = lepwave::wave_read(PK, base + g + (n >> 2));
+            n = (n << 1) | (int)uni(bc.get((pk >> ((n & 3) * 8)) & 255));
+        }
+        nbins += (uint32_t)levels;
+        return n;
+    }
+
+    // integer IDCT without DC (idct.cc:35-161), 8 lanes per pass
+    WDEV void idct_rows() {
+        constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
+        constexpr int w1pw7 = w1 + w7, w1mw7 = w1 - w7, w2pw6 = w2 + w6, w2mw6 = w2 - w6, w3pw5 = w3 + w5, w3mw5 = w3 - w5;
+        LANES(l) if (l < 8) {
+            const int y8 = l * 8;
+#define LEP_CQ6(i) ((int32_t)sh->here[sh->r2a[i]] * (int32_t)sh->q[i])
+            int32_t x0 = (l == 0 ? 0 : (int32_t)((uint32_t)LEP_CQ6(y8) << 11)) + 128;
+            int32_t x1 = (int32_t)((uint32_t)LEP_CQ6(y8 + 4) << 11);
+            int32_t x2 = LEP_CQ6(y8 + 6), x3 = LEP_CQ6(y8 + 2), x4 = LEP_CQ6(y8 + 1), x5 = LEP_CQ6(y8 + 7), x6 = LEP_CQ6(y8 + 5),
+                    x7 = LEP_CQ6(y8 + 3), x8;
+#undef LEP_CQ6
+            x8 = w7 * (x4 + x5); x4 = x8 + w1mw7 * x4; x5 = x8 - w1pw7 * x5;
+            x8 = w3 * (x6 + x7); x6 = x8 - w3mw5 * x6; x7 = x8 - w3pw5 * x7;
+            x8 = x0 + x1; x0 -= x1;
+            x1 = w6 * (x3 + x2); x2 = x1 - w2pw6 * x2; x3 = x1 + w2mw6 * x3;
+            x1 = x4 + x6; x4 -= x6; x6 = x5 + x7; x5 -= x7;
+            x7 = x8 + x3; x8 -= x3; x3 = x0 + x2; x0 -= x2;
+            x2 = (r2 * (x4 + x5) + 128) >> 8;
+            x4 = (r2 * (x4 - x5) + 128) >> 8;
+            int32_t* t = sh->t + y8;
+            t[0] = (x7 + x1) >> 8; t[1] = (x3 + x2) >> 8; t[2] = (x0 + x4) >> 8; t[3] = (x8 + x6) >> 8;
+            t[4] = (x8 - x6) >> 8; t[5] = (x0 - x4) >> 8; t[6] = (x3 - x2) >> 8; t[7] = (x7 - x1) >> 8;
+        }
+        LSYNC();
+        LANES(l) if (l < 8) {
+            const int32_t* t = sh->t + l;
+            int32_t y0 = (int32_t)((uint32_t)t[0] << 8) + 8192, y1 = (int32_t)((uint32_t)t[32] << 8);
+            int32_t y2 = t[48], y3 = t[16], y4 = t[8], y5 = t[56], y6 = t[40], y7 = t[24], y8;
+            y8 = w7 * (y4 + y5) + 4; y4 = (y8 + w1mw7 * y4) >> 3; y5 = (y8 - w1pw7 * y5) >> 3;
+            y8 = w3 * (y6 + y7) + 4; y6 = (y8 - w3mw5 * y6) >> 3; y7 = (y8 - w3pw5 * y7) >> 3;
+            y8 = y0 + y1; y0 -= y1;
+            y1 = w6 * (y3 + y2) + 4; y2 = (y1 - w2pw6 * y2) >> 3; y3 = (y1 + w2mw6 * y3) >> 3;
+            y1 = y4 + y6; y4 -= y6; y6 = y5 + y7; y5 -= y7;
+            y7 = y8 + y3; y8 -= y3; y3 = y0 + y2; y0 -= y2;
+            y2 = (r2 * (y4 + y5) + 128) >> 8;
+            y4 = (r2 * (y4 - y5) + 128) >> 8;
+            int16_t* o = sh->pix + l;
+            o[0] = (int16_t)((y7 + y1) >> 11); o[8] = (int16_t)((y3 + y2) >> 11); o[16] = (int16_t)((y0 + y4) >> 11);
+            o[24] = (int16_t)((y8 + y6) >> 11); o[32] = (int16_t)((y8 - y6) >> 11); o[40] = (int16_t)((y0 - y4) >> 11);
+            o[48] = (int16_t)((y3 - y2) >> 11); o[56] = (int16_t)((y7 - y1) >> 11);
+        }
+        LSYNC();
+    }
+    static WDEV int half16(int d) { return (int16_t)d / 2; }
+
+    // ---- owner-side adaptation: (used, bits) masks over the 4 words of a group -------------------------------
+    // unary-exponent group holding words i0..i0+3 of a coefficient of bit length len (bins 0..min(len,10), bit = len != i)
+    static WDEV void mask_exp(int i0, int len, int& used, int& bits) {
+        int n = imin(len, 10) - i0 + 1;
+        n = n < 0 ? 0 : (n > 4 ? 4 : n);
+        used = (1 << n) - 1;
+        const int z = len - i0;
+        bits = (z >= 0 && z < 4) ? (used & ~(1 << z)) : used;
+    }
+    // residual group (words 0..3 = bits 0..3 of |v|), bits 0..top coded through it
+    static WDEV void mask_res(int top, int v, int& used, int& bits) {
+        top = top > 3 ? 3 : top;
+        used = top < 0 ? 0 : (1 << (top + 1)) - 1;
+        bits = v & used;
+    }
+    // tree group: level i (bit i of value), nodes 4k..4k+3 of that level
+    static WDEV void mask_tree(int i, int k, int value, int& used, int& bits) {
+        const int prefix = value >> (i + 1);
+        used = (prefix >> 2) == k ? 1 << (prefix & 3) : 0;
+        bits = ((value >> i) & 1) ? used : 0;
+    }
+    static WDEV void apply4(U4& W, int used, int bits) {
+        if (used & 1) W.x = bupd(W.x, bits & 1);
+        if (used & 2) W.y = bupd(W.y, (bits >> 1) & 1);
+        if (used & 4) W.z = bupd(W.z, (bits >> 2) & 1);
+        if (used & 8) W.w = bupd(W.w, (bits >> 3) & 1);
+    }
+
+    // ---- round 1: the 6-bit count of interior non-zeros (model.hh:463-485) --------------------------------------------
+    WDEV int round_nz(int nzbin_ctx) {
+        LV(U4, W0); LV(uint32_t, a0); LV(uint32_t, PK0);
+        LANES(l) {
+            uint32_t adr = 0, pk = 0;
+            if (l < 17) {
+                int i, k;
+                if (l < 3) { i = 5 - l; k = 0; } else if (l < 5) { i = 2; k = l - 3; } else if (l < 9) { i = 1; k = l - 5; } else { i = 0; k = l - 9; }
+                adr = ctx_nz7(ci, nzbin_ctx) + (uint32_t)i * 32 + (uint32_t)k * 4;
+                L(W0) = ld4(model + adr); pk = pack_probs(L(W0));
+            }
+            L(a0) = adr; L(PK0) = pk;
+        }
+        const int nz = dec_tree(6, PK0, 0);
+        LANES(l) if (l < 17) {
+            int i, k, u, b;
+            if (l < 3) { i = 5 - l; k = 0; } else if (l < 5) { i = 2; k = l - 3; } else if (l < 9) { i = 1; k = l - 5; } else { i = 0; k = l - 9; }
+            mask_tree(i, k, nz, u, b);
+            if (u) { apply4(L(W0), u, b); st4(model + L(a0), L(W0)); }
+        }
+        return nz;
+    }
+
+    // ---- round 2 (repeated): interior positions zz0 .. zz0+15 under up to four consecutive "non-zeros left" bins ----------
+    // lane = pi + 16 * cand: window position pi, candidate bin nb0 - cand.  W0 = exponent words 0..3, W1 = residual words
+    // 0..3 (both kept by the owner); exponent words 4..7 are only published (PK2) and re-read by the owner when used.
+    WDEV void round_77(int& zz_io, int& left_io) {
+        Dec4Shared& S = *sh;
+        const int zz0 = zz_io, left0 = left_io, nb0 = nzbin_of(left0);
+        LV(U4, W0); LV(U4, W1); LV(uint32_t, a0); LV(uint32_t, a1); LV(uint32_t, PK0); LV(uint32_t, PK1); LV(uint32_t, PK2); LV(int, ok);
+        LANES(l) {
+            const int pi = l & 15, cand = l >> 4, p = zz0 + pi, nb = nb0 - cand;
+            uint32_t adr0 = 0, adr1 = 0, pk0 = 0, pk1 = 0, pk2 = 0;
+            const int valid = p < 49 && nb >= 1;
+            if (valid) {
+                adr0 = ctx_exp7(ci, nb, p, S.bsr[p]);
+                adr1 = ctx_res(ci, S.a2r[p], nb);
+                L(W0) = ld4(model + adr0); L(W1) = ld4(model + adr1);
+                const U4 w2 = ld4(model + adr0 + 4);
+                pk0 = pack_probs(L(W0)); pk1 = pack_probs(L(W1)); pk2 = pack_probs(w2);
+            }
+            L(a0) = adr0; L(a1) = adr1; L(PK0) = pk0; L(PK1) = pk1; L(PK2) = pk2; L(ok) = valid;
+        }
+        LSYNC();
+        // ---- serial (uniform vector) -----------------------------------------------------------------------------
+        int zz = zz0, left = left0, cand = 0;
+        const int zz_end = zz0 + 16 < 49 ? zz0 + 16 : 49;
+        uint32_t sgw = vec(S.sign[ci * 48]);
+#pragma nounroll
+        while (zz < zz_end && left > 0 && cand < 4) {
+            const int lane = (zz - zz0) + 16 * cand;
+            int len = dec_unary4(lepwave::wave_read(PK0, lane));
+            ++nbins;
+            if (len) {
+                if (len == 4) {
+                    len += dec_unary4(lepwave::wave_read(PK2, lane));
+                    if (len == 8) len = dec_unary_tail(ctx_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])));
+                }
+                nbins += (uint32_t)(2 * len - (len == 11));
+                const uint32_t pos = bc.get(sgw >> 16);
+                sgw = bupd_u(sgw, pos);
+                --left;
+                uint32_t v = 1u << (len - 1);
+                if (len > 1) {
+                    int b = len - 2;
+                    if (b >= 4) {
+                        const uint32_t rbase = ctx_res(ci, (int)uni(S.a2r[zz]), nb0 - cand);
+#pragma nounroll
+                        for (; b >= 4; --b) v |= dec_global(rbase + b) << b;
+                    }
+                    v = dec_residual(lepwave::wave_read(PK1, lane), b, v);
+                }
+                S.here[zz] = (int16_t)(pos ? (int)v : -(int)v);
+                cand = nb0 - nzbin_of(left);
+            }
+            ++zz;
+        }
+        S.sign[ci * 48] = sgw;
+        LSYNC();
+        // ---- owners adapt ---------------------------------------------------------------------------------------------------
+        LV(int, nzw);
+        LANES(l) L(nzw) = l < 16 && zz0 + l < zz && S.here[zz0 + l] != 0;
+        const uint32_t nzmask = (uint32_t)lepwave::wave_ballot(nzw);
+        LANES(l) if (L(ok)) {
+            const int pi = l & 15, cand_l = l >> 4, p = zz0 + pi;
+            if (p < zz) {
+                const int left_at = left0 - __builtin_popcount(nzmask & ((1u << pi) - 1));
+                if (left_at > 0 && nb0 - (int)S.nzbin[left_at] == cand_l) {
+                    const int cf = S.here[p];
+                    const int v = cf < 0 ? -cf : cf, len = bitlen((uint32_t)v);
+                    int u, b;
+                    mask_exp(0, len, u, b);
+                    apply4(L(W0), u, b); st4(model + L(a0), L(W0));
+                    mask_res(len - 2, v, u, b);
+                    if (u) { apply4(L(W1), u, b); st4(model + L(a1), L(W1)); }
+                    mask_exp(4, len, u, b);
+                    if (u) { U4 w2 = ld4(model + L(a0) + 4); apply4(w2, u, b); st4(model + L(a0) + 4, w2); }
+                }
+            }
+        }
+        LSYNC();
+        zz_io = zz; left_io = left;
+    }
+
+    // ---- round 3: both edge count trees and both edges (decoder.cc:27-141) ------------------------------------------------
+    // lanes e*28 + combo: edge e (0 horizontal, 1 vertical), combo = (position j, non-zeros-left n) with 1 <= n <= 7-j;
+    // W0 / W1 = exponent words 0..3 / 4..7, W2 = residual words 0..3.  Lanes 56..58 / 59..61: the two 3-level count trees.
+    WDEV int round_edges(int nz, int eob_x, int eob_y, bool has_left, bool has_above) {
+        Dec4Shared& S = *sh;
+        LV(U4, W0); LV(U4, W1); LV(U4, W2); LV(uint32_t, a0); LV(uint32_t, a2); LV(uint32_t, PK0); LV(uint32_t, PK1); LV(uint32_t, PK2);
+        LV(uint32_t, INFO);   // lanes e*28 + combo_base(j): sign slot | threshold << 8 | threshold ctx << 16 | bsr << 24 | bad prior << 31
+        LANES(l) {
+            uint32_t adr0 = 0, adr2 = 0, pk0 = 0, pk1 = 0, pk2 = 0, info = 0;
+            if (l < 56) {
+                const int e = l >= 28 ? 1 : 0, c = l - e * 28, j = S.cj[c], n = S.cn[c];
+                const bool horizontal = e == 0;
+                const int coord = horizontal ? j + 1 : (j + 1) * 8;
+                const int32_t prior = S.eprior[e * 7 + j];
+                const uint32_t ap = prior < 0 ? 0u - (uint32_t)prior : (uint32_t)prior;
+                const int bsr = bitlen(ap > 1023 ? 1023 : ap);
+                adr0 = ctx_expx(ci, n, horizontal ? j : j + 7, bsr);
+                adr2 = ctx_res(ci, coord, n);
+                L(W0) = ld4(model + adr0); L(W1) = ld4(model + adr0 + 4); L(W2) = ld4(model + adr2);
+                pk0 = pack_probs(L(W0)); pk1 = pack_probs(L(W1)); pk2 = pack_probs(L(W2));
+                const int16_t p16 = (int16_t)prior;
+                const int thr = S.thr[coord];
+                const uint32_t tctx = (uint32_t)imin((int)((ap & 0xffff) >> thr), 255);
+                info = (uint32_t)((ci * 4 + (p16 == 0 ? 0 : (p16 > 0 ? 1 : 2))) * 12 + bsr) | ((uint32_t)thr << 8) | (tctx << 16) |
+                       ((uint32_t)bsr << 24) | ((S.eprior[14] >> (e * 7 + j)) & 1 ? 0x80000000u : 0u);
+            } else if (l < 62) {
+                const int e = l >= 59 ? 1 : 0, lv = l - 56 - 3 * e;
+                adr0 = ctx_nzedge(e == 0, ci, e == 0 ? eob_x : eob_y, (nz + 3) / 7) + (uint32_t)(2 - lv) * 4;
+                L(W0) = ld4(model + adr0); pk0 = pack_probs(L(W0));
+            }
+            L(a0) = adr0; L(a2) = adr2; L(PK0) = pk0; L(PK1) = pk1; L(PK2) = pk2; L(INFO) = info;
+        }
+        LSYNC();
+        // ---- serial (uniform vector) -----------------------------------------------------------------------------
+        int ne[2] = {0, 0}, rc = 0;
+#pragma nounroll
+        for (int e = 0; e < 2 && !rc; ++e) {
+            const bool horizontal = e == 0;
+            ne[e] = dec_tree(3, PK0, 56 + 3 * e);
+            int left = ne[e];
+            const int a_off = horizontal ? 50 : 57;
+#pragma nounroll
+            for (int j = 0; j < 7 && left; ++j) {
+                const int base = e * 28 + combo_base(j);
+                const uint32_t info = lepwave::wave_read(INFO, base);
+                if (info >> 31) { rc = 39; break; }
+                const int lane = base + left - 1;
+                int len = dec_unary4(lepwave::wave_read(PK0, lane));
+                ++nbins;
+                if (len) {
+                    const int coord = horizontal ? j + 1 : (j + 1) * 8;
+                    if (len == 4) {
+                        len += dec_unary4(lepwave::wave_read(PK1, lane));
+                        if (len == 8) len = dec_unary_tail(ctx_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)));
+                    }
+                    nbins += (uint32_t)(2 * len - (len == 11));
+                    const int sslot = (int)(info & 255);
+                    const uint32_t sgw = vec(S.sign[sslot]);
+                    const uint32_t pos = bc.get(sgw >> 16);
+                    S.sign[sslot] = bupd_u(sgw, pos);
+                    uint32_t v = 1u << (len - 1);
+                    if (len > 1) {
+                        int b = len - 2;
+                        const int thr = (int)((info >> 8) & 15);
+                        if (b >= thr) {
+                            const uint32_t Tt = ctx_thresh(ci, (int)((info >> 16) & 255), imin(len - thr, 7));
+                            int s = 1;
+#pragma nounroll
+                            for (; b >= thr; --b) {
+                                const uint32_t bit = dec_global(Tt + (uint32_t)s);
+                                v |= bit << b;
+                                s = imin((s << 1) | (int)uni(bit), 127);
+                            }
+                        }
+                        if (b >= 4) {
+                            const uint32_t rbase = ctx_res(ci, coord, left);
+#pragma nounroll
+                            for (; b >= 4; --b) v |= dec_global(rbase + b) << b;
+                        }
+                        v = dec_residual(lepwave::wave_read(PK2, lane), b, v);
+                    }
+                    --left;
+                    S.here[a_off + j] = (int16_t)(pos ? (int)v : -(int)v);
+                }
+            }
+        }
+        LSYNC();
+        if (rc) return rc;
+        // ---- owners adapt ---------------------------------------------------------------------------------------------------
+        LV(int, enz);
+        LANES(l) L(enz) = l >= 50 && S.here[l] != 0;   // aligned 50..56 horizontal, 57..63 vertical
+        const uint64_t em = lepwave::wave_ballot(enz);
+        const uint32_t mh = (uint32_t)(em >> 50) & 0x7f, mv = (uint32_t)(em >> 57) & 0x7f;
+        const int neh = ne[0], nev = ne[1];
+        LANES(l) {
+            if (l < 56) {
+                const int e = l >= 28 ? 1 : 0, c = l - e * 28, j = S.cj[c], n = S.cn[c];
+                const uint32_t mk = e ? mv : mh;
+                const int left_at = (e ? nev : neh) - __builtin_popcount(mk & ((1u << j) - 1));
+                if (left_at == n) {   // n >= 1: the position was visited with n non-zeros left
+                    const int cf = S.here[(e ? 57 : 50) + j];
+                    const int v = cf < 0 ? -cf : cf, len = bitlen((uint32_t)v);
+                    int u, b;
+                    mask_exp(0, len, u, b);
+                    apply4(L(W0), u, b); st4(model + L(a0), L(W0));
+                    mask_exp(4, len, u, b);
+                    if (u) { apply4(L(W1), u, b); st4(model + L(a0) + 4, L(W1)); }
+                    mask_res(imin(len - 2, (int)S.thr[e ? (j + 1) * 8 : j + 1] - 1), v, u, b);
+                    if (u) { apply4(L(W2), u, b); st4(model + L(a2), L(W2)); }
+                }
+            } else if (l < 62) {
+                const int e = l >= 59 ? 1 : 0, lv = l - 56 - 3 * e;
+                int u, b;
+                mask_tree(2 - lv, 0, e ? nev : neh, u, b);
+                if (u) { apply4(L(W0), u, b); st4(model + L(a0), L(W0)); }
+            }
+        }
+        LSYNC();
+        return 0;
+    }
+
+    // ---- round 4: DC (decoder.cc:240-318, model.hh:674-832) -----------------------------------------------------------------
+    WDEV void round_dc(int pred, int a, int b17, int sctx) {
+        Dec4Shared& S = *sh;
+        LV(U4, W0); LV(uint32_t, a0); LV(uint32_t, PK0); LV(uint32_t, RW);
+        LANES(l) {
+            uint32_t adr = 0, pk = 0, rw = 0;
+            if (l < 3) { adr = ctx_expdc(a, b17) + (uint32_t)l * 4; L(W0) = ld4(model + adr); pk = pack_probs(L(W0)); }
+            else if (l < 13) rw = S.resdc[a * 12 + (l - 3)];   // residual Branch of bit l-3
+            L(a0) = adr; L(PK0) = pk; L(RW) = rw;
+        }
+        const int sslot = ci * 48 + sctx;
+        int len = dec_unary4(lepwave::wave_read(PK0, 0));
+        if (len == 4) {
+            len += dec_unary4(lepwave::wave_read(PK0, 1));
+            if (len == 8) {
+                uint32_t pk = lepwave::wave_read(PK0, 2);
+#pragma nounroll
+                for (; len < 11; ++len) { if (!ucond(bc.get(pk & 255) != 0)) break; pk >>= 8; }
+            }
+        }
+        nbins += (uint32_t)(len ? 2 * len + 1 - (len == 11) : 1);
+        uint32_t v = 0, pos = 1;
+        if (len) {
+            const uint32_t sgw = vec(S.sign[sslot]);
+            pos = bc.get(sgw >> 16);
+            S.sign[sslot] = bupd_u(sgw, pos);
+            v = 1u << (len - 1);
+#pragma nounroll
+            for (int i = len - 2; i >= 0; --i) v |= bc.get(lepwave::wave_read(RW, 3 + i) >> 16) << i;
+        }
+        int d = (int16_t)(pos ? (int)v : -(int)v);
+        int dc = d + pred;
+        dc = dc < -1024 ? dc + 2049 : dc;
+        dc = dc > 1024 ? dc - 2049 : dc;
+        S.here[49] = (int16_t)dc;
+        LSYNC();
+        // owners: exponent groups (lanes 0..2), residual Branches (lanes 3..12)
+        LV(uint32_t, VV);
+        LANES(l) L(VV) = v;   // uniform -> per lane (identity on the GPU)
+        LANES(l) {
+            if (l < 3) {
+                int u, b;
+                mask_exp(l * 4, len, u, b);
+                if (u) { apply4(L(W0), u, b); st4(model + L(a0), L(W0)); }
+            } else if (l < 13 && l - 3 <= len - 2) {
+                S.resdc[a * 12 + (l - 3)] = bupd(L(RW), (int)((L(VV) >> (l - 3)) & 1));
+            }
+        }
+        LSYNC();
+    }
+
+    // Decodes one block into sh->here (aligned order). left / above / aleft / ns_* are staged by the caller.
+    WDEV int decode_block(bool has_left, bool has_above) {
+        Dec4Shared& S = *sh;
+        // ---- contexts that do not depend on this block's bits ---------------------------------------------
+        LANES(l) {
+            S.here[l] = 0;
+            if (l < 49) {
+                int prior;
+                if (has_left && has_above) prior = (uint16_t)((iabs(S.left[l]) + iabs(S.above[l])) * 13 + 6 * iabs(S.aleft[l])) >> 5;
+                else if (has_left) prior = (int16_t)iabs(S.left[l]);
+                else if (has_above) prior = (int16_t)iabs(S.above[l]);
+                else prior = 0;
+                S.bsr[l] = (uint8_t)bitlen((uint32_t)imin(iabs(prior), 1023));
+            }
+        }
+        int nzctx = 0;
+        if (has_left && has_above) nzctx = (S.ns_above.nz + S.ns_left.nz + 2) / 4;
+        else if (has_above) nzctx = (S.ns_above.nz + 1) / 2;
+        else if (has_left) nzctx = (S.ns_left.nz + 1) / 2;
+        const int nzbin_ctx = (int)uni((uint32_t)nzbin_of(nzctx));
+        LSYNC();
+
+        const int nz = round_nz(nzbin_ctx);
+        if (nz > 49) return 7;
+        {
+            int zz = 0, left = nz;
+#pragma nounroll
+            while (zz < 49 && left > 0) round_77(zz, left);
+        }
+        // the interior is complete: eob_x / eob_y (encoder.cc:246-250) and the Lakhani priors (model.hh:928-1071) of all
+        // 14 edge positions, lane-parallel
+        int eob_x, eob_y;
+        {
+            LV(int, tx); LV(int, ty); LV(int, badf);
+            LANES(l) {
+                int ex = 0, ey = 0, bad = 0;
+                if (l < 49 && S.here[l] != 0) { const int coord = S.a2r[l]; ex = coord & 7; ey = coord >> 3; }
+                if (l < 14) {
+                    const bool hz = l < 7;
+                    const int j = hz ? l : l - 7;
+                    const int coord = hz ? j + 1 : (j + 1) * 8;
+                    int32_t prior = 0;
+                    if (hz ? has_above : has_left) {
+                        const int16_t* nbr = hz ? S.above : S.left;
+                        const int32_t* icos = hz ? S.icos_x + coord * 8 : S.icos_y + coord;
+                        const int step = hz ? 8 : 1;
+                        if (icos[0] != 0) {
+                            uint32_t acc = (uint32_t)(int32_t)nbr[S.r2a[coord]] * (uint32_t)icos[0];
+                            for (int i = 1; i < 8; ++i) {
+                                int32_t xi = S.here[S.r2a[coord + i * step]], ai = nbr[S.r2a[coord + i * step]];
+                                int32_t term = (i & 1) ? xi + ai : xi - ai;
+                                acc -= (uint32_t)icos[i] * (uint32_t)term;
+                            }
+                            prior = (int32_t)acc / icos[0];
+                        } else bad = 1;
+                    }
+                    S.eprior[l] = prior;
+                }
+                L(tx) = ex; L(ty) = ey; L(badf) = bad;
+            }
+            eob_x = lepwave::wave_max(tx); eob_y = lepwave::wave_max(ty);
+            const uint64_t badmask = lepwave::wave_ballot(badf);
+            LANES(l) if (l == 0) S.eprior[14] = (int32_t)(uint32_t)badmask;   // bit p: position p's prior needs a division by zero
+            LSYNC();
+        }
+        {
+            const int rc = round_edges(nz, eob_x, eob_y, has_left, has_above);
+            if (rc) return rc;
+        }
+        // DC prediction (model.hh:674-832): IDCT of the ACs, 16 edge estimates on 16 lanes
+        idct_rows();
+        int pred, a, b17, sctx;
+        {
+            LV(int, emin); LV(int, emax); LV(int, s0); LV(int, s1); LV(int, tmp);
+            LANES(l) {
+                int ev = 0, have = 0;
+                if (l < 8 && has_left) { have = 1; ev = (int16_t)(S.ns_left.vert[l] - half16(S.pix[l * 8] - S.pix[l * 8 + 1]) - (S.pix[l * 8] + 1024)); }
+                if (l >= 8 && l < 16 && has_above) { const int i = l - 8; have = 1; ev = (int16_t)(S.ns_above.horiz[i] - half16(S.pix[i] - S.pix[i + 8]) - (S.pix[i] + 1024)); }
+                L(emax) = have ? ev : -0x7fffffff;
+                L(emin) = have ? -ev : -0x7fffffff;
+                L(s0) = l < 8 ? ev : 0;
+                L(s1) = (l >= 8 && l < 16) ? ev : 0;
+            }
+            const int mx = lepwave::wave_max(emax), mn = -lepwave::wave_max(emin);
+            const int sumL = lepwave::wave_excl_scan(s0, tmp), sumA = lepwave::wave_excl_scan(s1, tmp);
+            int32_t avgmed = 0, unc = 0, unc2 = 0;
+            if (has_left || has_above) {
+                int sum0 = has_left ? sumL : sumA, sum1 = (has_left && has_above) ? sumA : sum0;
+                avgmed = (sum0 + sum1) >> 1;
+                unc = (mx - mn) >> 3;
+                sum0 -= avgmed; sum1 -= avgmed;
+                unc2 = (iabs(sum0) < iabs(sum1) ? sum0 : sum1) >> 3;
+            }
+            pred = (avgmed / (int)S.q[0] + 4) >> 3;
+            a = imin(bitlen((uint32_t)iabs(unc) & 0xffff), 11);
+            b17 = imin(bitlen((uint32_t)iabs(unc2) & 0xffff), 16);
+            sctx = unc2 >= 0 ? (unc2 == 0 ? 3 : 2) : 1;
+        }
+        round_dc(pred, a, b17, sctx);
+        // ---- neighbour summary (block_context.hh:44-78) -------------------------------------------------------------
+        LANES(l) {
+            if (l < 16) {
+                const int i = l & 7;
+                const int dcq = S.here[49] * (int)S.q[0];
+                if (l < 8) S.ns_here.horiz[i] = (int16_t)(dcq + S.pix[56 + i] + 1024 + half16(S.pix[56 + i] - S.pix[48 + i]));
+                else S.ns_here.vert[i] = (int16_t)(dcq + S.pix[i * 8 + 7] + 1024 + half16(S.pix[i * 8 + 7] - S.pix[i * 8 + 6]));
+            }
+            if (l == 16) S.ns_here.nz = nz;
+        }
+        LSYNC();
+        return 0;
+    }
+
+    WDEV int run(const ImageDev* image, const SegDev& seg, uint32_t* model_words, NSum* ns, Dec4Shared* shared, const uint8_t* stream,
+                 uint32_t len) {
+        img = image; model = model_words; sh = shared; nbins = 0;
+        init_tables();
+        bc.init_stream(stream, len);
+        bool top[3] = {true, true, true};
+        SegmentCoder<false> sched;   // only its row schedule is used (lepton_codec.hh:41-100)
+        sched.img = image;
+        for (uint32_t idx = 0;; ++idx) {
+            SegmentCoder<false>::RowSpec r = sched.row_spec(idx);
+            if (r.done) break;
+            if (r.luma_y >= seg.y1 && !seg.is_last) break;
+            if (r.skip) continue;
+            if (r.luma_y < seg.y0) continue;
+            stage_component(r.component);
+            const int w = img->width[comp], yb = r.curr_y;
+            int16_t* row = img->blocks[comp] + (int64_t)yb * w * 64;
+            const bool has_above = !top[comp];
+            const int16_t* arow = has_above ? row - (int64_t)w * 64 : nullptr;
+            NSum* nrow = ns + img->ns_offset[comp] + (yb & 1) * w;
+            const NSum* narow = ns + img->ns_offset[comp] + ((yb & 1) ^ 1) * w;
+            top[comp] = false;
+            LV(int16_t, nxt_above); LV(uint32_t, nxt_ns);
+            LANES(l) {   // block 0's neighbours; later blocks' are fetched one block ahead
+                L(nxt_above) = has_above ? arow[l] : (int16_t)0;
+                L(nxt_ns) = (has_above && l < (int)(sizeof(NSum) / 4)) ? ((const uint32_t*)&narow[0])[l] : 0u;
+            }
+            for (int x = 0; x < w; ++x) {
+                LANES(l) {
+                    if (x) { sh->left[l] = sh->here[l]; sh->aleft[l] = sh->above[l]; }
+                    if (l < (int)(sizeof(NSum) / 4)) {
+                        if (x) ((uint32_t*)&sh->ns_left)[l] = ((const uint32_t*)&sh->ns_here)[l];
+                        if (has_above) ((uint32_t*)&sh->ns_above)[l] = L(nxt_ns);
+                    }
+                }
+                LSYNC();
+                LANES(l) {
+                    if (has_above) sh->above[l] = L(nxt_above);
+                    if (has_above && x + 1 < w) {
+                        L(nxt_above) = arow[(int64_t)(x + 1) * 64 + l];
+                        if (l < (int)(sizeof(NSum) / 4)) L(nxt_ns) = ((const uint32_t*)&narow[x + 1])[l];
+                    }
+                }
+                LSYNC();
+                int rc = decode_block(x > 0, has_above);
+                if (rc) return rc;
+                LANES(l) {
+                    row[(int64_t)x * 64 + l] = sh->here[l];
+                    if (l < (int)(sizeof(NSum) / 4)) ((uint32_t*)&nrow[x])[l] = ((const uint32_t*)&sh->ns_here)[l];
+                }
+                if (x + 1 < w && yb * w + x + 1 >= img->coded_blocks[comp]) break;
+            }
+        }
+        return 0;
+    }
+};
+
+}  // namespace lep4

@@ -19,6 +19,7 @@
 #include "lep_dec2.h"
 #include "lep_dec3.h"
 #include "lep_enc3.h"
+#include "lep_dec4.h"
 
 using namespace lepdev;
 
@@ -179,6 +180,27 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v3_kernel(const ImageDev
     bins[s] = w.nbins;
 }
 
+// v4 decoder: serial part as uniform vector code, multi-bin interior windows, one merged edge round (lep_dec4.h).
+// WAVES = waves per SIMD the register allocation is held to.
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
+                                                           uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
+                                                           uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
+    __shared__ lep4::Dec4Shared sh;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const SegDev seg = segs[s];
+    const ImageDev* img = images + seg.image;
+    uint32_t* model = models + (size_t)s * kModelStride;
+    NSum* ns = ns_area + ns_offsets[s];
+    reset_segment_state<lep3::kModelWords>(model, ns, img->ns_total, lane);
+    __syncthreads();
+    lep4::Dec4Wave w;
+    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, stream_len[s]);
+    if (lane != 0) return;
+    status[s] = rc;
+    bins[s] = w.nbins;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -187,8 +209,8 @@ struct lep_gpu {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    int decode_kernel = 3;   // 3 = v3 (default), 2 = v2 prefetch rounds, 1 = single-lane reference kernel (LEP_DECODE_KERNEL)
-    int dec3_waves = 0;      // register budget variant of the v3 decoder: 0 = by batch size, LEP_DEC3_WAVES = 4 | 5 | 6 | 8
+    int decode_kernel = 4;   // 4 = v4 (default), 3 = v3 scalar-unit serial part, 2 = v2 prefetch rounds, 1 = single-lane reference kernel (LEP_DECODE_KERNEL)
+    int dec3_waves = 0;      // register budget variant of the v3 / v4 decoder: 0 = by batch size, LEP_DEC3_WAVES = 4 | 5 | 6 | 8
     int encode_kernel = 3;   // 3 = v3 (default), 2 = v2 wave-cooperative, 1 = single-lane reference kernel (LEP_ENCODE_KERNEL)
     std::string err;
     const char* last_kernel = "";   // name of the kernel the most recent launch used
@@ -262,7 +284,19 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     g->d_bins = (uint32_t*)(meta + o_bins);
     g->h_bins.assign(nseg, 0);
     HIPCHK(g, hipEventRecord(g->ev0, st));
-    if (DEC && g->decode_kernel == 3) {
+    if (DEC && g->decode_kernel == 4) {
+#define LEP_LAUNCH_DEC4(W)                                                                                                     \
+    hipLaunchKernelGGL((lep_decode_v4_kernel<W>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),                  \
+                       (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns), \
+                       d_streams, d_stream_len, d_status, g->d_bins)
+        int waves = g->dec3_waves;
+        if (!waves) waves = nseg > 4608 ? 8 : 4;
+        if (waves >= 8) { g->last_kernel = "lep_decode_v4_kernel<8>"; LEP_LAUNCH_DEC4(8); }
+        else if (waves >= 6) { g->last_kernel = "lep_decode_v4_kernel<6>"; LEP_LAUNCH_DEC4(6); }
+        else { g->last_kernel = "lep_decode_v4_kernel<4>"; LEP_LAUNCH_DEC4(4); }
+#undef LEP_LAUNCH_DEC4
+    }
+    else if (DEC && g->decode_kernel == 3) {
 #define LEP_LAUNCH_DEC3(W)                                                                                                     \
     hipLaunchKernelGGL((lep_decode_v3_kernel<W>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),                  \
                        (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns), \
@@ -314,7 +348,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
     if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3;
-    if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3;
+    if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 4;
     if (const char* e = getenv("LEP_DEC3_WAVES")) g->dec3_waves = atoi(e);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }

@@ -125,3 +125,21 @@ extern "C" int emu_encode_segment_v3(const lep_image_desc* d, int y0, int y1, in
     if (bins) *bins = w.nbins;
     return 0;
 }
+
+// v4 decoder (lep_dec4.h) as a 64-lane loop emulation
+#include "../../lepton_amd/csrc/lep_dec4.h"
+extern "C" int emu_decode_segment_v4(const lep_image_desc* d, int y0, int y1, int is_last, const uint8_t* in, uint32_t len, uint32_t* bins) {
+    ImageDev img;
+    int rc = derive_image(*d, &img, false);
+    if (rc) return rc;
+    std::vector<lep3::U4> model(lep3::kModelWords / 4, lep3::U4{kBranchInit, kBranchInit, kBranchInit, kBranchInit});
+    std::vector<NSum> ns(img.ns_total);
+    memset(ns.data(), 0, ns.size() * sizeof(NSum));
+    SegDev seg;
+    seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = 0;
+    static lep4::Dec4Shared sh;
+    lep4::Dec4Wave w;
+    rc = w.run(&img, seg, reinterpret_cast<uint32_t*>(model.data()), ns.data(), &sh, in, len);
+    if (bins) *bins = w.nbins;
+    return rc;
+}

@@ -101,8 +101,9 @@ def test_wave_cooperative_decoder_on_cpu_matches_oracle(emu, name):
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
 
 
+@pytest.mark.parametrize("gen", ["v3", "v4"])
 @pytest.mark.parametrize("name", golden_cases())
-def test_v3_decoder_on_cpu_matches_oracle(emu, name):
+def test_v3_decoder_on_cpu_matches_oracle(emu, name, gen):
     """lep_dec3.h (owner-lane model update, 32-bit window) as a 64-lane loop emulation: decoding the
     oracle's streams returns the coefficient frame and consumes exactly the oracle's number of bins"""
     jpg, _ = golden(name)
@@ -116,7 +117,7 @@ def test_v3_decoder_on_cpu_matches_oracle(emu, name):
     total = 0
     for s, w in zip(segs, want):
         nb = C.c_uint32(0)
-        assert emu.emu_decode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0
+        assert getattr(emu, "emu_decode_segment_" + gen)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0
         total += nb.value
     assert total == bins
     for c in range(d.ncomp):
@@ -124,8 +125,9 @@ def test_v3_decoder_on_cpu_matches_oracle(emu, name):
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
 
 
+@pytest.mark.parametrize("gen", ["v3", "v4"])
 @pytest.mark.parametrize("shift", [1, 2, 3])
-def test_v3_decoder_unaligned_stream_start(emu, shift):
+def test_v3_decoder_unaligned_stream_start(emu, shift, gen):
     """the 64-bit window reads aligned dwords only: a stream that starts 1..3 bytes into a dword (streams packed back to
     back in the arena) and ends mid-dword must decode exactly like an aligned one, never touching bytes outside it"""
     jpg, _ = golden("c420_odd_203x149")
@@ -143,7 +145,7 @@ def test_v3_decoder_unaligned_stream_start(emu, shift):
         C.memmove(base + shift, w, len(w))   # ... so the stream itself starts `shift` bytes into a dword
         C.memset(base, 0xA5, shift)
         C.memset(base + shift + len(w), 0x5A, 8)
-        assert emu.emu_decode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, C.c_void_p(base + shift), len(w), None) == 0
+        assert getattr(emu, "emu_decode_segment_" + gen)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, C.c_void_p(base + shift), len(w), None) == 0
     for c in range(d.ncomp):
         n = d.coded_blocks[c] * 128
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
@@ -200,3 +202,37 @@ def test_v3_encoder_many_bins_per_block(emu):
     buf = C.create_string_buffer(1 << 20)
     n = C.c_uint32(0)
     assert emu.emu_encode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, len(buf), C.byref(n), None) == 6
+
+
+def test_v4_decoder_large_coefficients(emu):
+    """every rare path of lep_dec4.h at once: exponent bins beyond the prefetched groups, residual bits >= 4, threshold
+    bins, long interior runs (several windows, all non-zero bins)"""
+    import numpy as np
+    from lepton_amd import corpus
+
+    img = JpegImage(corpus.synth_jpeg(64, 48, 11, quality=100))
+    d = img.desc
+    rng = np.random.default_rng(5)
+    for c in range(d.ncomp):
+        n = d.nblocks(c) * 64
+        arr = (C.c_int16 * n).from_address(d.blocks[c])
+        vals = rng.integers(-255, 256, n)
+        vals[rng.random(n) < 0.1] = 0
+        for i in range(n):
+            arr[i] = int(vals[i])
+        for b in range(d.nblocks(c)):
+            arr[b * 64 + 49] = 0
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    total = 0
+    for s, w in zip(segs, want):
+        nb = C.c_uint32(0)
+        assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0
+        total += nb.value
+    assert total == bins
+    for c in range(d.ncomp):
+        n = d.coded_blocks[c] * 128
+        assert C.string_at(d.blocks[c], n) == orig[c][:n]

@@ -152,10 +152,12 @@ def test_gpu_v1_and_v2_decoders_agree(monkeypatch):
     assert out[0] == out[1]
 
 
+@pytest.mark.parametrize("kernel", ["3", "4"])
 @pytest.mark.parametrize("waves", ["4", "5", "6", "8"])
-def test_gpu_v3_decoder_register_budget_variants(waves, monkeypatch):
-    """every register-budget build of the v3 decode kernel (the 8-wave one spills to scratch) restores the same JPEGs"""
+def test_gpu_v3_decoder_register_budget_variants(waves, kernel, monkeypatch):
+    """every register-budget build of the v3 / v4 decode kernels (the 8-wave ones spill to scratch) restores the same JPEGs"""
     monkeypatch.setenv("LEP_DEC3_WAVES", waves)
+    monkeypatch.setenv("LEP_DECODE_KERNEL", kernel)
     codec = GpuCodec(0)
     try:
         for name in ("c420_odd_203x149", "q30_256x256_4seg", "rst_c420_176x112"):
@@ -167,9 +169,38 @@ def test_gpu_v3_decoder_register_budget_variants(waves, monkeypatch):
         codec.close()
 
 
-@pytest.mark.parametrize("kernel", ["1", "2"])
+def test_gpu_v4_decoder_large_coefficients(gpu_codec):
+    """rare paths of lep_dec4.h on the GPU: exponent bins beyond the prefetched groups, residual bits >= 4, threshold bins,
+    interior runs over several windows; decode(oracle streams) == frame, and the v3 encoder writes those streams"""
+    import numpy as np
+
+    img = JpegImage(corpus.synth_jpeg(64, 48, 11, quality=100))
+    d = img.desc
+    rng = np.random.default_rng(5)
+    for c in range(d.ncomp):
+        n = d.nblocks(c) * 64
+        arr = (C.c_int16 * n).from_address(d.blocks[c])
+        vals = rng.integers(-255, 256, n)
+        vals[rng.random(n) < 0.1] = 0
+        for i in range(n):
+            arr[i] = int(vals[i])
+        for b in range(d.nblocks(c)):
+            arr[b * 64 + 49] = 0
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    plan = img.plan()
+    streams = gpu_codec.encode([img], [plan])[0]
+    want, _ = ob.oracle_encode(d, plan)
+    assert streams == want
+    f = LepFile(img.write_lep(streams))
+    gpu_codec.decode([f])
+    for c in range(d.ncomp):
+        n = d.coded_blocks[c] * 128
+        assert C.string_at(f.desc.blocks[c], n) == orig[c][:n]
+
+
+@pytest.mark.parametrize("kernel", ["1", "2", "3"])
 def test_gpu_older_decode_kernels_still_agree(kernel, monkeypatch):
-    """the single-lane (v1) and prefetch-round (v2) decoders are kept as cross-checks of the v3 kernel"""
+    """the single-lane (v1), prefetch-round (v2) and scalar-unit (v3) decoders are kept as cross-checks of the v4 kernel"""
     monkeypatch.setenv("LEP_DECODE_KERNEL", kernel)
     codec = GpuCodec(0)
     try:
