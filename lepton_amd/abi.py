@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblepton_mi355x.so")
+LIB_PATH = os.environ.get("LEP_LIB_PATH") or os.path.join(_HERE, "liblepton_mi355x.so")   # LEP_LIB_PATH: experiment builds of the same library
 
 MAX_COMPONENTS = 3
 MAX_SEGMENTS = 16

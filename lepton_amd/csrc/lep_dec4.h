@@ -19,6 +19,12 @@
 namespace lep4 {
 using namespace lep3;
 
+#if LEP_ON_GPU && defined(LEP_MARKS)
+#define LEP_MARK(name) __asm__ volatile("; MARK " name)
+#else
+#define LEP_MARK(name) ((void)0)
+#endif
+
 struct Dec4Shared {
     uint32_t sign[kSignWords];    // resident Branches
     uint32_t resdc[kResDcWords];
@@ -31,6 +37,7 @@ struct Dec4Shared {
     uint8_t thr[64], r2a[64], a2r[64], nzbin[64], bsr[64];
     uint8_t cj[32], cn[32];       // edge combo -> position / non-zeros-left
     NSum ns_left, ns_above, ns_here;
+    uint32_t inv24[512];          // exact 24-bit reciprocals for the Branch probability (inv24_of)
 };
 
 // kNzBin for 0 <= left <= 49 without a memory access (scalar arithmetic on the GPU)
@@ -40,16 +47,45 @@ WDEV int nzbin_of(int left) {
 // first combo of edge position j (combos of a position = its reachable "non-zeros left" values 1 .. 7-j): 0,7,13,18,22,25,27
 WDEV int combo_base(int j) { return (int)((0x1b65648d1c0ull >> (6 * j)) & 63); }
 
-// Branch::record_obs_and_update (branch.hh:82-100) for a uniform-vector word and observation (0/1); rare paths on ballots
-WDEV uint32_t bupd_u(uint32_t w, uint32_t obs) {
-    uint32_t f = (w & 255) + (obs ^ 1), t = ((w >> 8) & 255) + obs;
-    if (ucond((f | t) > 255)) {   // the incremented count was 255
+// Reciprocal m[d] with ((f << 8) * m[d]) >> 24 == (f << 8) / d EXACTLY for every reachable count pair (1 <= f, t <= 255,
+// d = f + t), and the product's bits 24..31 (all a probability needs) inside the low 32 bits a v_mul_u32_u24 returns:
+// m = ceil(2^24 / d), except d = 337 and d = 469 where only ceil - 1 is exact (exhaustive check: tests/emu, lep_gpu_selftest).
+WDEV uint32_t inv24_of(uint32_t d) {
+    if (d < 2) return 0;
+    return (0x1000000u + d - 1) / d - ((d == 337 || d == 469) ? 1u : 0u);
+}
+WDEV uint32_t mul24(uint32_t a, uint32_t b) {
+#if LEP_ON_GPU
+    return __umul24(a, b);
+#else
+    return (uint32_t)(((uint64_t)(a & 0xffffff) * (b & 0xffffff)) & 0xffffffffu);
+#endif
+}
+// Branch::record_obs_and_update (branch.hh:82-100) on the packed word, per lane: straight-line common case (table
+// reciprocal), one divergent branch for the count-overflow case (once per ~250 observations of a Branch)
+WDEV uint32_t bupd_t(uint32_t w, uint32_t obs, const uint32_t* inv24) {
+    const uint32_t f = (w & 255) + (obs ^ 1), t = ((w >> 8) & 255) + obs;
+    uint32_t nw = f | (t << 8) | ((mul24(f << 8, inv24[f + t]) >> 24) << 16);
+    if ((f | t) > 255) {   // the incremented count was 255
+        const uint32_t f0 = w & 255, t0 = (w >> 8) & 255;
+        if ((obs ? f0 : t0) == 1) nw = (w & 0xffff) | ((obs ? 0u : 255u) << 16);
+        else {
+            const uint32_t f2 = obs ? (1 + f0) >> 1 : 129u, t2 = obs ? 129u : (1 + t0) >> 1;
+            nw = f2 | (t2 << 8) | ((mul24(f2 << 8, inv24[f2 + t2]) >> 24) << 16);
+        }
+    }
+    return nw;
+}
+// the same for a uniform-vector word and observation; the rare path is taken on a ballot
+WDEV uint32_t bupd_u(uint32_t w, uint32_t obs, const uint32_t* inv24) {
+    const uint32_t f = (w & 255) + (obs ^ 1), t = ((w >> 8) & 255) + obs;
+    if (ucond((f | t) > 255)) {
         const uint32_t f0 = w & 255, t0 = (w >> 8) & 255;
         if (ucond((obs ? f0 : t0) == 1)) return (w & 0xffff) | ((obs ? 0u : 255u) << 16);
-        f = obs ? (1 + f0) >> 1 : 129u;
-        t = obs ? 129u : (1 + t0) >> 1;
+        const uint32_t f2 = obs ? (1 + f0) >> 1 : 129u, t2 = obs ? 129u : (1 + t0) >> 1;
+        return f2 | (t2 << 8) | ((mul24(f2 << 8, inv24[f2 + t2]) >> 24) << 16);
     }
-    return f | (t << 8) | (prob_of(f, t) << 16);
+    return f | (t << 8) | ((mul24(f << 8, inv24[f + t]) >> 24) << 16);
 }
 
 // ---- bool decoder (boolreader.hh:184-258, 376-416; boolreader.cc:25-34) as uniform vector code ----------------------
@@ -125,6 +161,7 @@ struct Dec4Wave {
             for (int d = l; d < kSignWords; d += 64) sh->sign[d] = kBranchInit;
             for (int d = l; d < kResDcWords; d += 64) sh->resdc[d] = kBranchInit;
             if (l < (int)(sizeof(NSum) / 4)) { ((uint32_t*)&sh->ns_left)[l] = 0; ((uint32_t*)&sh->ns_above)[l] = 0; }
+            for (int d = l; d < 512; d += 64) sh->inv24[d] = inv24_of((uint32_t)d);
             if (l < 32) {
                 int j = 0, c = l;
                 while (j < 6 && c >= 7 - j) { c -= 7 - j; ++j; }
@@ -146,7 +183,7 @@ struct Dec4Wave {
     WDEV uint32_t dec_global(uint32_t idx) {   // a Branch outside the prefetched set: coded straight from HBM
         const uint32_t w = vload(model + idx);
         const uint32_t bit = bc.get(w >> 16);
-        const uint32_t nw = bupd_u(w, bit);
+        const uint32_t nw = bupd_u(w, bit, sh->inv24);
 #if LEP_ON_GPU
         if (threadIdx.x == 0) model[idx] = nw;
 #else
@@ -163,15 +200,16 @@ struct Dec4Wave {
         return *p;
 #endif
     }
-    // up to four unary bins from the packed probabilities of one exponent group; returns the number of ones (0..4)
+    // up to four unary bins from the packed probabilities of one exponent group; returns the number of ones (0..4).
+    // Fully unrolled with the probabilities extracted on the vector ALU: a SALU instruction costs about two VALU ones on
+    // this chip (profiles/r01_issue_microbench.txt), and the rolled loop spent 7 of them per bin on loop control.
     WDEV int dec_unary4(uint32_t pk) {
-        int i = 0;
-#pragma nounroll
-        for (; i < 4; ++i) {
-            if (!ucond(bc.get(pk & 255) != 0)) break;
-            pk >>= 8;
-        }
-        return i;
+        const uint32_t pkv = vec(pk);
+        if (!ucond(bc.get(pkv & 255) != 0)) return 0;
+        if (!ucond(bc.get((pkv >> 8) & 255) != 0)) return 1;
+        if (!ucond(bc.get((pkv >> 16) & 255) != 0)) return 2;
+        if (!ucond(bc.get(pkv >> 24) != 0)) return 3;
+        return 4;
     }
     WDEV int dec_unary_tail(uint32_t gbase) {   // exponent bins 8..10 straight from HBM (|v| >= 128: rare)
         int i = 8;
@@ -179,10 +217,14 @@ struct Dec4Wave {
         for (; i < 11; ++i) if (!ucond(dec_global(gbase + i) != 0)) break;
         return i;
     }
-    // residual bits b..0 (b <= 3) of |v| from the packed probabilities of the residual group
+    // residual bits b..0 (b <= 3) of |v| from the packed probabilities of the residual group (word i = bit i); unrolled, the
+    // probabilities extracted on the vector ALU
     WDEV uint32_t dec_residual(uint32_t pk, int b, uint32_t v) {
-#pragma nounroll
-        for (; b >= 0; --b) v |= bc.get((pk >> (b * 8)) & 255) << b;
+        const uint32_t pkv = vec(pk);
+        if (b >= 3) v |= bc.get(pkv >> 24) << 3;
+        if (b >= 2) v |= bc.get((pkv >> 16) & 255) << 2;
+        if (b >= 1) v |= bc.get((pkv >> 8) & 255) << 1;
+        if (b >= 0) v |= bc.get(pkv & 255);
         return v;
     }
     // a `levels`-level binary tree decoded MSB first; the d-th decoded level has 2^d nodes stored as whole groups owned
@@ -266,15 +308,23 @@ struct Dec4Wave {
         used = (prefix >> 2) == k ? 1 << (prefix & 3) : 0;
         bits = ((value >> i) & 1) ? used : 0;
     }
-    static WDEV void apply4(U4& W, int used, int bits) {
-        if (used & 1) W.x = bupd(W.x, bits & 1);
-        if (used & 2) W.y = bupd(W.y, (bits >> 1) & 1);
-        if (used & 4) W.z = bupd(W.z, (bits >> 2) & 1);
-        if (used & 8) W.w = bupd(W.w, (bits >> 3) & 1);
+    // owners adapt the used words of one group register: (used, bits) masks per lane (0 = lane not involved); a word slot
+    // that no lane needs is skipped on a ballot, the others are one straight-line bupd_t under the lanes' exec mask
+    WDEV void adapt_group(U4* W, const int* used, const int* bits) {
+        const uint32_t* inv = sh->inv24;
+        LV(int, any);
+#define LEP_SLOT(k, fld)                                                                                              \
+        LANES(l) L(any) = (L(used) >> k) & 1;                                                                        \
+        if (lepwave::wave_ballot(any)) {                                                                              \
+            LANES(l) if ((L(used) >> k) & 1) L(W).fld = bupd_t(L(W).fld, (uint32_t)(L(bits) >> k) & 1u, inv);        \
+        }
+        LEP_SLOT(0, x) LEP_SLOT(1, y) LEP_SLOT(2, z) LEP_SLOT(3, w)
+#undef LEP_SLOT
     }
 
     // ---- round 1: the 6-bit count of interior non-zeros (model.hh:463-485) --------------------------------------------
     WDEV int round_nz(int nzbin_ctx) {
+        LEP_MARK("nz_prefetch");
         LV(U4, W0); LV(uint32_t, a0); LV(uint32_t, PK0);
         LANES(l) {
             uint32_t adr = 0, pk = 0;
@@ -286,13 +336,21 @@ struct Dec4Wave {
             }
             L(a0) = adr; L(PK0) = pk;
         }
+        LEP_MARK("nz_serial");
         const int nz = dec_tree(6, PK0, 0);
-        LANES(l) if (l < 17) {
-            int i, k, u, b;
-            if (l < 3) { i = 5 - l; k = 0; } else if (l < 5) { i = 2; k = l - 3; } else if (l < 9) { i = 1; k = l - 5; } else { i = 0; k = l - 9; }
-            mask_tree(i, k, nz, u, b);
-            if (u) { apply4(L(W0), u, b); st4(model + L(a0), L(W0)); }
+        LEP_MARK("nz_update");
+        LV(int, u0); LV(int, b0);
+        LANES(l) {
+            int u = 0, b = 0;
+            if (l < 17) {
+                int i, k;
+                if (l < 3) { i = 5 - l; k = 0; } else if (l < 5) { i = 2; k = l - 3; } else if (l < 9) { i = 1; k = l - 5; } else { i = 0; k = l - 9; }
+                mask_tree(i, k, nz, u, b);
+            }
+            L(u0) = u; L(b0) = b;
         }
+        adapt_group(W0, u0, b0);
+        LANES(l) if (L(u0)) st4(model + L(a0), L(W0));
         return nz;
     }
 
@@ -301,6 +359,7 @@ struct Dec4Wave {
     // 0..3 (both kept by the owner); exponent words 4..7 are only published (PK2) and re-read by the owner when used.
     WDEV void round_77(int& zz_io, int& left_io) {
         Dec4Shared& S = *sh;
+        LEP_MARK("77_prefetch");
         const int zz0 = zz_io, left0 = left_io, nb0 = nzbin_of(left0);
         LV(U4, W0); LV(U4, W1); LV(uint32_t, a0); LV(uint32_t, a1); LV(uint32_t, PK0); LV(uint32_t, PK1); LV(uint32_t, PK2); LV(int, ok);
         LANES(l) {
@@ -318,11 +377,12 @@ struct Dec4Wave {
         }
         LSYNC();
         // ---- serial (uniform vector) -----------------------------------------------------------------------------
+        LEP_MARK("77_serial");
         int zz = zz0, left = left0, cand = 0;
         const int zz_end = zz0 + 16 < 49 ? zz0 + 16 : 49;
         uint32_t sgw = vec(S.sign[ci * 48]);
 #pragma nounroll
-        while (zz < zz_end && left > 0 && cand < 4) {
+        for (;;) {   // runs while zz < zz_end && left > 0 && cand < 4 (true on entry: the caller checks zz < 49 && left > 0)
             const int lane = (zz - zz0) + 16 * cand;
             int len = dec_unary4(lepwave::wave_read(PK0, lane));
             ++nbins;
@@ -333,7 +393,7 @@ struct Dec4Wave {
                 }
                 nbins += (uint32_t)(2 * len - (len == 11));
                 const uint32_t pos = bc.get(sgw >> 16);
-                sgw = bupd_u(sgw, pos);
+                sgw = bupd_u(sgw, pos, S.inv24);
                 --left;
                 uint32_t v = 1u << (len - 1);
                 if (len > 1) {
@@ -346,32 +406,46 @@ struct Dec4Wave {
                     v = dec_residual(lepwave::wave_read(PK1, lane), b, v);
                 }
                 S.here[zz] = (int16_t)(pos ? (int)v : -(int)v);
+                if (left == 0) { ++zz; break; }
                 cand = nb0 - nzbin_of(left);
+                if (cand >= 4) { ++zz; break; }
             }
-            ++zz;
+            if (++zz >= zz_end) break;
         }
         S.sign[ci * 48] = sgw;
         LSYNC();
         // ---- owners adapt ---------------------------------------------------------------------------------------------------
+        LEP_MARK("77_update");
         LV(int, nzw);
         LANES(l) L(nzw) = l < 16 && zz0 + l < zz && S.here[zz0 + l] != 0;
         const uint32_t nzmask = (uint32_t)lepwave::wave_ballot(nzw);
-        LANES(l) if (L(ok)) {
+        LV(int, u0); LV(int, b0); LV(int, u1); LV(int, b1); LV(int, u2); LV(int, b2);
+        LANES(l) {
+            int ua = 0, ba = 0, ub = 0, bb = 0, uc = 0, bcc = 0;
             const int pi = l & 15, cand_l = l >> 4, p = zz0 + pi;
-            if (p < zz) {
+            if (L(ok) && p < zz) {
                 const int left_at = left0 - __builtin_popcount(nzmask & ((1u << pi) - 1));
                 if (left_at > 0 && nb0 - (int)S.nzbin[left_at] == cand_l) {
                     const int cf = S.here[p];
                     const int v = cf < 0 ? -cf : cf, len = bitlen((uint32_t)v);
-                    int u, b;
-                    mask_exp(0, len, u, b);
-                    apply4(L(W0), u, b); st4(model + L(a0), L(W0));
-                    mask_res(len - 2, v, u, b);
-                    if (u) { apply4(L(W1), u, b); st4(model + L(a1), L(W1)); }
-                    mask_exp(4, len, u, b);
-                    if (u) { U4 w2 = ld4(model + L(a0) + 4); apply4(w2, u, b); st4(model + L(a0) + 4, w2); }
+                    mask_exp(0, len, ua, ba);
+                    mask_res(len - 2, v, ub, bb);
+                    mask_exp(4, len, uc, bcc);
                 }
             }
+            L(u0) = ua; L(b0) = ba; L(u1) = ub; L(b1) = bb; L(u2) = uc; L(b2) = bcc;
+        }
+        adapt_group(W0, u0, b0);
+        adapt_group(W1, u1, b1);
+        LANES(l) {
+            if (L(u0)) st4(model + L(a0), L(W0));
+            if (L(u1)) st4(model + L(a1), L(W1));
+        }
+        if (lepwave::wave_ballot(u2)) {   // exponent words 4..7: re-read by the owner (rare in the interior)
+            LV(U4, W2);
+            LANES(l) if (L(u2)) L(W2) = ld4(model + L(a0) + 4);
+            adapt_group(W2, u2, b2);
+            LANES(l) if (L(u2)) st4(model + L(a0) + 4, L(W2));
         }
         LSYNC();
         zz_io = zz; left_io = left;
@@ -382,6 +456,7 @@ struct Dec4Wave {
     // W0 / W1 = exponent words 0..3 / 4..7, W2 = residual words 0..3.  Lanes 56..58 / 59..61: the two 3-level count trees.
     WDEV int round_edges(int nz, int eob_x, int eob_y, bool has_left, bool has_above) {
         Dec4Shared& S = *sh;
+        LEP_MARK("edge_prefetch");
         LV(U4, W0); LV(U4, W1); LV(U4, W2); LV(uint32_t, a0); LV(uint32_t, a2); LV(uint32_t, PK0); LV(uint32_t, PK1); LV(uint32_t, PK2);
         LV(uint32_t, INFO);   // lanes e*28 + combo_base(j): sign slot | threshold << 8 | threshold ctx << 16 | bsr << 24 | bad prior << 31
         LANES(l) {
@@ -411,6 +486,7 @@ struct Dec4Wave {
         }
         LSYNC();
         // ---- serial (uniform vector) -----------------------------------------------------------------------------
+        LEP_MARK("edge_serial");
         int ne[2] = {0, 0}, rc = 0;
 #pragma nounroll
         for (int e = 0; e < 2 && !rc; ++e) {
@@ -436,7 +512,7 @@ struct Dec4Wave {
                     const int sslot = (int)(info & 255);
                     const uint32_t sgw = vec(S.sign[sslot]);
                     const uint32_t pos = bc.get(sgw >> 16);
-                    S.sign[sslot] = bupd_u(sgw, pos);
+                    S.sign[sslot] = bupd_u(sgw, pos, S.inv24);
                     uint32_t v = 1u << (len - 1);
                     if (len > 1) {
                         int b = len - 2;
@@ -466,12 +542,15 @@ struct Dec4Wave {
         LSYNC();
         if (rc) return rc;
         // ---- owners adapt ---------------------------------------------------------------------------------------------------
+        LEP_MARK("edge_update");
         LV(int, enz);
         LANES(l) L(enz) = l >= 50 && S.here[l] != 0;   // aligned 50..56 horizontal, 57..63 vertical
         const uint64_t em = lepwave::wave_ballot(enz);
         const uint32_t mh = (uint32_t)(em >> 50) & 0x7f, mv = (uint32_t)(em >> 57) & 0x7f;
         const int neh = ne[0], nev = ne[1];
+        LV(int, u0); LV(int, b0); LV(int, u1); LV(int, b1); LV(int, u2); LV(int, b2);
         LANES(l) {
+            int ua = 0, ba = 0, ub = 0, bb = 0, uc = 0, bcc = 0;
             if (l < 56) {
                 const int e = l >= 28 ? 1 : 0, c = l - e * 28, j = S.cj[c], n = S.cn[c];
                 const uint32_t mk = e ? mv : mh;
@@ -479,20 +558,25 @@ struct Dec4Wave {
                 if (left_at == n) {   // n >= 1: the position was visited with n non-zeros left
                     const int cf = S.here[(e ? 57 : 50) + j];
                     const int v = cf < 0 ? -cf : cf, len = bitlen((uint32_t)v);
-                    int u, b;
-                    mask_exp(0, len, u, b);
-                    apply4(L(W0), u, b); st4(model + L(a0), L(W0));
-                    mask_exp(4, len, u, b);
-                    if (u) { apply4(L(W1), u, b); st4(model + L(a0) + 4, L(W1)); }
-                    mask_res(imin(len - 2, (int)S.thr[e ? (j + 1) * 8 : j + 1] - 1), v, u, b);
-                    if (u) { apply4(L(W2), u, b); st4(model + L(a2), L(W2)); }
+                    mask_exp(0, len, ua, ba);
+                    mask_exp(4, len, ub, bb);
+                    mask_res(imin(len - 2, (int)S.thr[e ? (j + 1) * 8 : j + 1] - 1), v, uc, bcc);
                 }
             } else if (l < 62) {
                 const int e = l >= 59 ? 1 : 0, lv = l - 56 - 3 * e;
-                int u, b;
-                mask_tree(2 - lv, 0, e ? nev : neh, u, b);
-                if (u) { apply4(L(W0), u, b); st4(model + L(a0), L(W0)); }
+                mask_tree(2 - lv, 0, e ? nev : neh, ua, ba);
             }
+            L(u0) = ua; L(b0) = ba; L(u1) = ub; L(b1) = bb; L(u2) = uc; L(b2) = bcc;
+        }
+        adapt_group(W0, u0, b0);
+        LANES(l) if (L(u0)) st4(model + L(a0), L(W0));
+        if (lepwave::wave_ballot(u1)) {
+            adapt_group(W1, u1, b1);
+            LANES(l) if (L(u1)) st4(model + L(a0) + 4, L(W1));
+        }
+        if (lepwave::wave_ballot(u2)) {
+            adapt_group(W2, u2, b2);
+            LANES(l) if (L(u2)) st4(model + L(a2), L(W2));
         }
         LSYNC();
         return 0;
@@ -501,6 +585,7 @@ struct Dec4Wave {
     // ---- round 4: DC (decoder.cc:240-318, model.hh:674-832) -----------------------------------------------------------------
     WDEV void round_dc(int pred, int a, int b17, int sctx) {
         Dec4Shared& S = *sh;
+        LEP_MARK("dc_prefetch");
         LV(U4, W0); LV(uint32_t, a0); LV(uint32_t, PK0); LV(uint32_t, RW);
         LANES(l) {
             uint32_t adr = 0, pk = 0, rw = 0;
@@ -508,6 +593,7 @@ struct Dec4Wave {
             else if (l < 13) rw = S.resdc[a * 12 + (l - 3)];   // residual Branch of bit l-3
             L(a0) = adr; L(PK0) = pk; L(RW) = rw;
         }
+        LEP_MARK("dc_serial");
         const int sslot = ci * 48 + sctx;
         int len = dec_unary4(lepwave::wave_read(PK0, 0));
         if (len == 4) {
@@ -523,7 +609,7 @@ struct Dec4Wave {
         if (len) {
             const uint32_t sgw = vec(S.sign[sslot]);
             pos = bc.get(sgw >> 16);
-            S.sign[sslot] = bupd_u(sgw, pos);
+            S.sign[sslot] = bupd_u(sgw, pos, S.inv24);
             v = 1u << (len - 1);
 #pragma nounroll
             for (int i = len - 2; i >= 0; --i) v |= bc.get(lepwave::wave_read(RW, 3 + i) >> 16) << i;
@@ -535,16 +621,18 @@ struct Dec4Wave {
         S.here[49] = (int16_t)dc;
         LSYNC();
         // owners: exponent groups (lanes 0..2), residual Branches (lanes 3..12)
-        LV(uint32_t, VV);
+        LEP_MARK("dc_update");
+        LV(uint32_t, VV); LV(int, u0); LV(int, b0);
         LANES(l) L(VV) = v;   // uniform -> per lane (identity on the GPU)
         LANES(l) {
-            if (l < 3) {
-                int u, b;
-                mask_exp(l * 4, len, u, b);
-                if (u) { apply4(L(W0), u, b); st4(model + L(a0), L(W0)); }
-            } else if (l < 13 && l - 3 <= len - 2) {
-                S.resdc[a * 12 + (l - 3)] = bupd(L(RW), (int)((L(VV) >> (l - 3)) & 1));
-            }
+            int u = 0, b = 0;
+            if (l < 3) mask_exp(l * 4, len, u, b);
+            L(u0) = u; L(b0) = b;
+        }
+        adapt_group(W0, u0, b0);
+        LANES(l) {
+            if (L(u0)) st4(model + L(a0), L(W0));
+            if (l >= 3 && l < 13 && l - 3 <= len - 2) S.resdc[a * 12 + (l - 3)] = bupd_t(L(RW), (L(VV) >> (l - 3)) & 1u, S.inv24);
         }
         LSYNC();
     }
@@ -553,6 +641,7 @@ struct Dec4Wave {
     WDEV int decode_block(bool has_left, bool has_above) {
         Dec4Shared& S = *sh;
         // ---- contexts that do not depend on this block's bits ---------------------------------------------
+        LEP_MARK("prologue");
         LANES(l) {
             S.here[l] = 0;
             if (l < 49) {
@@ -580,6 +669,7 @@ struct Dec4Wave {
         }
         // the interior is complete: eob_x / eob_y (encoder.cc:246-250) and the Lakhani priors (model.hh:928-1071) of all
         // 14 edge positions, lane-parallel
+        LEP_MARK("lakhani");
         int eob_x, eob_y;
         {
             LV(int, tx); LV(int, ty); LV(int, badf);
@@ -619,6 +709,7 @@ struct Dec4Wave {
             if (rc) return rc;
         }
         // DC prediction (model.hh:674-832): IDCT of the ACs, 16 edge estimates on 16 lanes
+        LEP_MARK("idct_dcpred");
         idct_rows();
         int pred, a, b17, sctx;
         {
@@ -649,6 +740,7 @@ struct Dec4Wave {
         }
         round_dc(pred, a, b17, sctx);
         // ---- neighbour summary (block_context.hh:44-78) -------------------------------------------------------------
+        LEP_MARK("publish");
         LANES(l) {
             if (l < 16) {
                 const int i = l & 7;
@@ -690,7 +782,8 @@ struct Dec4Wave {
                 L(nxt_ns) = (has_above && l < (int)(sizeof(NSum) / 4)) ? ((const uint32_t*)&narow[0])[l] : 0u;
             }
             for (int x = 0; x < w; ++x) {
-                LANES(l) {
+                LEP_MARK("staging");
+        LANES(l) {
                     if (x) { sh->left[l] = sh->here[l]; sh->aleft[l] = sh->above[l]; }
                     if (l < (int)(sizeof(NSum) / 4)) {
                         if (x) ((uint32_t*)&sh->ns_left)[l] = ((const uint32_t*)&sh->ns_here)[l];
@@ -708,7 +801,8 @@ struct Dec4Wave {
                 LSYNC();
                 int rc = decode_block(x > 0, has_above);
                 if (rc) return rc;
-                LANES(l) {
+                LEP_MARK("store");
+        LANES(l) {
                     row[(int64_t)x * 64 + l] = sh->here[l];
                     if (l < (int)(sizeof(NSum) / 4)) ((uint32_t*)&nrow[x])[l] = ((const uint32_t*)&sh->ns_here)[l];
                 }

@@ -19,12 +19,18 @@
 
 namespace lep3 {
 
+#if LEP_ON_GPU && defined(LEP_MARKS)
+#define LEP_EMARK(name) __asm__ volatile("; MARK " name)
+#else
+#define LEP_EMARK(name) ((void)0)
+#endif
+
 constexpr int kBinChunk = 512;
 constexpr int kMaxDup3 = 160;                  // 14 * 10 threshold bins
 constexpr uint32_t kResident3 = 1u << 30;      // bin whose Branch lives in LDS (sign table); resolved by the coder loop
 
 struct Enc3Shared {
-    uint32_t bins[kBinChunk];   // P2: branch index | bit << 31;  after P3: probability | bit << 8
+    alignas(16) uint32_t bins[kBinChunk];   // P2: branch index | bit << 31;  after P3: probability | bit << 8
     uint16_t dup[kMaxDup3];     // positions (into bins) of bins whose Branch may repeat within the block
     uint32_t sign[96];          // the sign Branches live in LDS for the whole segment (never written back)
     int32_t t[64];              // IDCT intermediate
@@ -201,9 +207,31 @@ struct Enc3Wave {
     }
     static WDEV int half16(int d) { return (int16_t)d / 2; }
 
+    // Branch::record_obs_and_update (branch.hh:82-100) for a uniform-vector word and observation; rare paths on ballots
+    static WDEV uint32_t bupd_uv(uint32_t w, uint32_t obs) {
+        uint32_t f = (w & 255) + (obs ^ 1), t = ((w >> 8) & 255) + obs;
+        if (ucond((f | t) > 255)) {   // the incremented count was 255
+            const uint32_t f0 = w & 255, t0 = (w >> 8) & 255;
+            if (ucond((obs ? f0 : t0) == 1)) return (w & 0xffff) | ((obs ? 0u : 255u) << 16);
+            f = obs ? (1 + f0) >> 1 : 129u;
+            t = obs ? 129u : (1 + t0) >> 1;
+        }
+        return f | (t << 8) | (prob_of(f, t) << 16);
+    }
+    // one entry of the resolved bin list through the bool coder (uniform vector value e)
+    WDEV void code_bin(uint32_t e) {
+        if (ucond((e & kResident3) != 0)) {
+            const uint32_t slot = e & 127, bit = e >> 31;
+            const uint32_t w = sh->sign[slot];
+            bc.put(bit, w >> 16);
+            sh->sign[slot] = bupd_uv(w, bit);
+        } else bc.put((e >> 8) & 1, e & 255);
+    }
+
     // Encodes the block staged in sh->here (+ left / above / aleft when present).  Returns 0 or an exit code (uniform).
     WDEV int encode_block(bool has_left, bool has_above) {
         Enc3Shared& S = *sh;
+        LEP_EMARK("e_ballots");
         LV(int, nzf); LV(int, tx); LV(int, ty);
         LV(int, cnt); LV(int, ndup); LV(int, off); LV(int, doff); LV(int, bad);
         LV(int, len_); LV(int, val_); LV(int, pos_); LV(int, nexp_); LV(int, coded_); LV(int, thr_); LV(int, isedge_);
@@ -224,12 +252,38 @@ struct Enc3Wave {
         }
         const int eob_x = lepwave::wave_max(tx), eob_y = lepwave::wave_max(ty);
 
+        LEP_EMARK("e_idct");
         idct_rows();   // S.pix = IDCT of the block without its DC
 
+        LEP_EMARK("e_p1");
         int nzctx = 0;
         if (has_left && has_above) nzctx = (S.ns_above.nz + S.ns_left.nz + 2) / 4;
         else if (has_above) nzctx = (S.ns_above.nz + 1) / 2;
         else if (has_left) nzctx = (S.ns_left.nz + 1) / 2;
+
+        // DC prediction inputs (model.hh:674-784): the 16 edge estimates on 16 lanes, reduced with wave max / sums
+        int32_t dc_avgmed = 0, dc_unc = 0, dc_unc2 = 0;
+        {
+            LV(int, emin); LV(int, emax); LV(int, s0); LV(int, s1); LV(int, tmp);
+            LANES(l) {
+                int ev = 0, have = 0;
+                if (l < 8 && has_left) { have = 1; ev = (int16_t)(S.ns_left.vert[l] - half16(S.pix[l * 8] - S.pix[l * 8 + 1]) - (S.pix[l * 8] + 1024)); }
+                if (l >= 8 && l < 16 && has_above) { const int i = l - 8; have = 1; ev = (int16_t)(S.ns_above.horiz[i] - half16(S.pix[i] - S.pix[i + 8]) - (S.pix[i] + 1024)); }
+                L(emax) = have ? ev : -0x7fffffff;
+                L(emin) = have ? -ev : -0x7fffffff;
+                L(s0) = l < 8 ? ev : 0;
+                L(s1) = (l >= 8 && l < 16) ? ev : 0;
+            }
+            const int mx = lepwave::wave_max(emax), mn = -lepwave::wave_max(emin);
+            const int sumL = lepwave::wave_excl_scan(s0, tmp), sumA = lepwave::wave_excl_scan(s1, tmp);
+            if (has_left || has_above) {
+                int sum0 = has_left ? sumL : sumA, sum1 = (has_left && has_above) ? sumA : sum0;
+                dc_avgmed = (sum0 + sum1) >> 1;
+                dc_unc = (mx - mn) >> 3;
+                sum0 -= dc_avgmed; sum1 -= dc_avgmed;
+                dc_unc2 = (iabs(sum0) < iabs(sum1) ? sum0 : sum1) >> 3;
+            }
+        }
 
         // ---- P1: per-lane analysis (lane = coefficient: 0..48 interior in zig-zag order, 49..55 / 56..62 edges, 63 DC)
         LANES(l) {
@@ -297,27 +351,7 @@ struct Enc3Wave {
                 }
             } else {   // DC
                 coded = 1;
-                int32_t avgmed = 0, unc = 0, unc2 = 0;
-                if (has_left || has_above) {
-                    int cntest = 0, sum0 = 0, sum1 = 0, mn = 0, mx = 0;
-                    for (int side = 0; side < 2; ++side) {
-                        if (side == 0 ? !has_left : !has_above) continue;
-                        for (int i = 0; i < 8; ++i, ++cntest) {
-                            int e;
-                            if (side == 0) e = (int16_t)(S.ns_left.vert[i] - half16(S.pix[i * 8] - S.pix[i * 8 + 1]) - (S.pix[i * 8] + 1024));
-                            else e = (int16_t)(S.ns_above.horiz[i] - half16(S.pix[i] - S.pix[i + 8]) - (S.pix[i] + 1024));
-                            if (cntest < 8) sum0 += e; else sum1 += e;
-                            if (cntest == 0) { mn = mx = e; }
-                            if (e < mn) mn = e;
-                            if (e > mx) mx = e;
-                        }
-                    }
-                    if (cntest == 8) sum1 = sum0;
-                    avgmed = (sum0 + sum1) >> 1;
-                    unc = (mx - mn) >> 3;
-                    sum0 -= avgmed; sum1 -= avgmed;
-                    unc2 = (iabs(sum0) < iabs(sum1) ? sum0 : sum1) >> 3;
-                }
+                const int32_t avgmed = dc_avgmed, unc = dc_unc, unc2 = dc_unc2;   // from the 16-lane pass before P1
                 const int pred = (avgmed / (int)S.q[0] + 4) >> 3;
                 const int ua = imin(bitlen((uint32_t)iabs(unc) & 0xffff), 11), ub = imin(bitlen((uint32_t)iabs(unc2) & 0xffff), 16);
                 int d = c - pred;
@@ -343,6 +377,7 @@ struct Enc3Wave {
             L(len_) = len; L(val_) = v; L(pos_) = pos; L(nexp_) = nexp; L(coded_) = coded; L(thr_) = thr; L(isedge_) = isedge;
             L(expbase_) = expbase; L(signidx_) = signidx; L(resbase_) = resbase; L(thrbase_) = thrbase;
         }
+        LEP_EMARK("e_scan");
         const uint64_t badmask = lepwave::wave_ballot(bad);
         if (badmask) {   // report what the serial coder would have hit first (lane order = stream order)
             LV(int, bad39);
@@ -355,6 +390,7 @@ struct Enc3Wave {
 
         // The bin list is produced, resolved and coded lane-range by lane-range so that it never holds more than kBinChunk
         // entries (a lane emits at most 28 bins; ordinary blocks are one range of all 64 lanes).
+        LEP_EMARK("e_chunk");
         int lane0 = 0;
         while (lane0 < 64) {
             // largest lane range [lane0, lane1) whose bins fit
@@ -367,7 +403,8 @@ struct Enc3Wave {
             const int dbase = (int)lepwave::wave_read((const uint32_t*)doff, lane0);
             const int D = (lane1 < 64 ? (int)lepwave::wave_read((const uint32_t*)doff, lane1) : dbase + 0x7fffffff) ;
             // ---- P2: bin emission ---------------------------------------------------------------------
-            LV(int, dcount);
+            LEP_EMARK("e_p2");
+        LV(int, dcount);
             LANES(l) {
                 int dj = L(doff) - dbase;
                 if (l >= lane0 && l < lane1) {
@@ -406,7 +443,8 @@ struct Enc3Wave {
                 L(dcount) = (l >= lane0 && l < lane1) ? L(ndup) : 0;
             }
             (void)D;
-            LV(int, dtmp);
+            LEP_EMARK("e_p3a");
+        LV(int, dtmp);
             const int Dn = lepwave::wave_excl_scan(dcount, dtmp);   // threshold bins in this range
             LSYNC();
 
@@ -437,7 +475,8 @@ struct Enc3Wave {
                 }
             }
             // ---- P3b: threshold bins (rare; their Branch can repeat inside a block): in-order forwarding ---
-            for (int cb = 0; cb < Dn; cb += 64) {
+            LEP_EMARK("e_p3b");
+        for (int cb = 0; cb < Dn; cb += 64) {
                 LV(uint32_t, didx); LV(uint32_t, dw); LV(uint32_t, dbit); LV(int, djpos); LV(int, dlast);
                 const int nn = Dn - cb < 64 ? Dn - cb : 64;
                 LANES(l) {
@@ -465,24 +504,23 @@ struct Enc3Wave {
             LSYNC();
 
             // ---- P4: bool coder over the resolved (bit, probability) pairs: uniform vector code ------------
-            for (int b0 = 0; b0 < n; b0 += 64) {
-                LV(uint32_t, mybin);
-                LANES(l) L(mybin) = b0 + l < n ? S.bins[b0 + l] : 0u;
-                const int cntb = n - b0 < 64 ? n - b0 : 64;
+            LEP_EMARK("e_p4");
+            // (entries are read back from LDS at a uniform address, four at a time, and everything derived from them stays
+            // on the vector ALU: a SALU instruction costs about two VALU ones here, profiles/r01_issue_microbench.txt)
+            {
+                int j = 0;
 #pragma nounroll
-                for (int jj = 0; jj < cntb; ++jj) {
-                    const uint32_t e = lepwave::wave_read(mybin, jj);
-                    if (e & kResident3) {
-                        const uint32_t slot = e & 127, bit = e >> 31;
-                        const uint32_t w = vec(S.sign[slot]);
-                        bc.put(bit, w >> 16);
-                        S.sign[slot] = bupd(w, (int)bit);
-                    } else bc.put((e >> 8) & 1, e & 255);
+                for (; j + 4 <= n; j += 4) {
+                    const U4 q = ld4(S.bins + j);   // one 16-byte LDS read
+                    code_bin(vec(q.x)); code_bin(vec(q.y)); code_bin(vec(q.z)); code_bin(vec(q.w));
                 }
+#pragma nounroll
+                for (; j < n; ++j) code_bin(vec(S.bins[j]));
             }
             LSYNC();
             lane0 = lane1;
         }
+        LEP_EMARK("e_p5");
         nbins += (uint32_t)N;
 
         // ---- P5: neighbour summary of this block ----------------------------------------------------
@@ -530,7 +568,8 @@ struct Enc3Wave {
             }
             for (int x = 0; x < w; ++x) {
                 // P0: stage blocks.  left / above-left come from the previous block's LDS copies.
-                LANES(l) {
+                LEP_EMARK("e_staging");
+        LANES(l) {
                     if (x) { sh->left[l] = sh->here[l]; sh->aleft[l] = sh->above[l]; }
                     if (l < (int)(sizeof(NSum) / 4)) {
                         if (x) ((uint32_t*)&sh->ns_left)[l] = ((const uint32_t*)&sh->ns_here)[l];
@@ -552,7 +591,8 @@ struct Enc3Wave {
                 LSYNC();
                 int rc = encode_block(x > 0, has_above);
                 if (rc) return rc;
-                LANES(l) if (l < (int)(sizeof(NSum) / 4)) ((uint32_t*)&nrow[x])[l] = ((const uint32_t*)&sh->ns_here)[l];
+                LEP_EMARK("e_store");
+        LANES(l) if (l < (int)(sizeof(NSum) / 4)) ((uint32_t*)&nrow[x])[l] = ((const uint32_t*)&sh->ns_here)[l];
                 if (x + 1 < w && yb * w + x + 1 >= img->coded_blocks[comp]) break;
             }
         }

@@ -140,10 +140,17 @@ __global__ __launch_bounds__(64) void lep_decode_v2_kernel(const ImageDev* __res
 __device__ uint64_t g_prof[64][32];
 #endif
 
-// exhaustive check of the float-reciprocal Branch probability against integer division (all 255 x 255 count pairs)
+// exhaustive check of the float-reciprocal / table-reciprocal Branch probabilities against integer division (all 255 x 255 count pairs)
 __global__ void lep_selftest_kernel(uint32_t* mismatches) {
+    __shared__ uint32_t inv24[512];
+    for (uint32_t d = threadIdx.x; d < 512; d += blockDim.x) inv24[d] = lep4::inv24_of(d);
+    __syncthreads();
     const uint32_t f = blockIdx.x + 1, t = threadIdx.x + 1;
     if (t > 255) return;
+    for (uint32_t obs = 0; obs < 2; ++obs) {   // v4 decoder's table-reciprocal update (lep_dec4.h)
+        const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);
+        if (lep4::bupd_t(w, obs, inv24) != branch_update(w, (int)obs)) atomicAdd(mismatches, 1u);
+    }
     if (lep3::prob_of(f, t) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);
     for (int obs = 0; obs < 2; ++obs) {
         const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);

@@ -143,3 +143,21 @@ extern "C" int emu_decode_segment_v4(const lep_image_desc* d, int y0, int y1, in
     if (bins) *bins = w.nbins;
     return rc;
 }
+
+// exhaustive check of the 24-bit table reciprocal used by lep4::bupd_t / bupd_u against Branch::record_obs_and_update
+extern "C" int emu_check_inv24_update() {
+    static uint32_t inv[512];
+    for (uint32_t d = 0; d < 512; ++d) inv[d] = lep4::inv24_of(d);
+    for (uint32_t f = 1; f < 256; ++f)
+        for (uint32_t t = 1; t < 256; ++t) {
+            if (inv[f + t] >= (1u << 24)) return 2;
+            if ((lep4::mul24(f << 8, inv[f + t]) >> 24) != (f << 8) / (f + t)) return 3;
+            for (uint32_t p = 0; p < 256; p += 51)
+                for (uint32_t obs = 0; obs < 2; ++obs) {
+                    uint32_t w = f | (t << 8) | (p << 16);
+                    if (branch_update(w, (int)obs) != lep4::bupd_t(w, obs, inv)) return 4;
+                    if (branch_update(w, (int)obs) != lep4::bupd_u(w, obs, inv)) return 5;
+                }
+        }
+    return 0;
+}

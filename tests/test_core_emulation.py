@@ -236,3 +236,9 @@ def test_v4_decoder_large_coefficients(emu):
     for c in range(d.ncomp):
         n = d.coded_blocks[c] * 128
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
+
+
+def test_inv24_table_update_is_exact(emu):
+    """lep_dec4.h's Branch update (24-bit table reciprocal, v_mul_u32_u24) == branch.hh:82-100 for every count pair,
+    both observations, saturation and halving paths included"""
+    assert emu.emu_check_inv24_update() == 0
