@@ -24,44 +24,48 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(jpgs, budget_s=24.0):
-    """Reference binary (oracle/_ref/lepton, built from the real reference) timed on this host, one core:
-    `lepton -singlethread -unjailed -skipverify` encode then decode per file; also the arithmetic-coding
-    interval alone (TS_ARITH_STARTED..FINISHED from its stderr) for a like-for-like hot-path number."""
+def cpu_baseline(jpgs, budget_s=20.0):
+    """Reference binary (oracle/_ref/lepton, built from the real reference) timed on this host:
+    `lepton -singlethread -unjailed -skipverify` encode then decode per file (one core; also the arithmetic-coding
+    interval alone, TS_ARITH_STARTED..FINISHED from its stderr, for a like-for-like hot-path number), then the same
+    files with the reference's default thread pool (one thread per segment, 8 for these files)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "lepton")
     if not os.path.exists(ref):
         return None
     tmp = tempfile.mkdtemp(prefix="lepbench")
-    enc_s = dec_s = arith_enc = arith_dec = 0.0
-    nbytes = n = 0
-    t_start = time.perf_counter()
 
     def arith(err):
         st = [float(x) for x in re.findall(r"TS_ARITH_STARTED\s+\(\d+\)\s+([0-9.]+)", err)]
         fi = [float(x) for x in re.findall(r"TS_ARITH_FINISHED\s+\(\d+\)\s+([0-9.]+)", err)]
         return sum(f - s for s, f in zip(st, fi) if f > s)
 
-    for i, j in enumerate(jpgs):
-        jp, lp, bp = (os.path.join(tmp, "%d.%s" % (i, e)) for e in ("jpg", "lep", "back.jpg"))
-        open(jp, "wb").write(j)
-        t0 = time.perf_counter()
-        r = subprocess.run([ref, "-singlethread", "-unjailed", "-skipverify", jp, lp], capture_output=True, text=True)
-        t1 = time.perf_counter()
-        if r.returncode:
-            continue
-        r2 = subprocess.run([ref, "-singlethread", "-unjailed", lp, bp], capture_output=True, text=True)
-        t2 = time.perf_counter()
-        if r2.returncode or open(bp, "rb").read() != j:
-            continue
-        enc_s += t1 - t0; dec_s += t2 - t1
-        arith_enc += arith(r.stderr); arith_dec += arith(r2.stderr)
-        nbytes += len(j); n += 1
-        if time.perf_counter() - t_start > budget_s:
-            break
+    def run(flags, budget):
+        enc_s = dec_s = arith_enc = arith_dec = 0.0
+        nbytes = n = 0
+        t_start = time.perf_counter()
+        for i, j in enumerate(jpgs):
+            jp, lp, bp = (os.path.join(tmp, "%d.%s" % (i, e)) for e in ("jpg", "lep", "back.jpg"))
+            open(jp, "wb").write(j)
+            t0 = time.perf_counter()
+            r = subprocess.run([ref] + flags + ["-unjailed", "-skipverify", jp, lp], capture_output=True, text=True)
+            t1 = time.perf_counter()
+            if r.returncode:
+                continue
+            r2 = subprocess.run([ref] + flags + ["-unjailed", lp, bp], capture_output=True, text=True)
+            t2 = time.perf_counter()
+            if r2.returncode or open(bp, "rb").read() != j:
+                continue
+            enc_s += t1 - t0; dec_s += t2 - t1
+            arith_enc += arith(r.stderr); arith_dec += arith(r2.stderr)
+            nbytes += len(j); n += 1
+            if time.perf_counter() - t_start > budget:
+                break
+        return n, nbytes / 1e6, enc_s, dec_s, arith_enc, arith_dec
+
+    n, mb, enc_s, dec_s, arith_enc, arith_dec = run(["-singlethread"], budget_s)
     if not n:
         return None
-    mb = nbytes / 1e6
-    return {
+    out = {
         "value": round(mb / (enc_s + dec_s), 3), "unit": "MB/s", "cores": 1, "kind": "reference",
         "sample": "%d of the bench's 4K JPEGs (%.1f MB), reference `lepton -singlethread -unjailed -skipverify`, encode then decode, whole process wall clock" % (n, mb),
         "encode_MBps": round(mb / enc_s, 3), "decode_MBps": round(mb / dec_s, 3),
@@ -69,11 +73,17 @@ def cpu_baseline(jpgs, budget_s=24.0):
         "hot_path_only_decode_MBps": round(mb / arith_dec, 3) if arith_dec else None,
         "host_cpus": os.cpu_count(),
     }
+    n2, mb2, e2, d2, _, _ = run([], budget_s / 3)
+    if n2:
+        out["multithread"] = {"threads": 8, "value": round(mb2 / (e2 + d2), 3), "encode_MBps": round(mb2 / e2, 3), "decode_MBps": round(mb2 / d2, 3),
+                              "sample": "%d files, reference default thread pool (`lepton -unjailed -skipverify`, one thread per segment)" % n2}
+    return out
 
 
 def pmc_traffic(kernel, images):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/), scaled
-    from that run's batch to this one; None when the kernel has not been through a PMC pass."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes
+    (profiles/pmc_traffic.json, written by scripts/gpu_round.sh), scaled from that run's batch to this one; None when
+    the kernel has not been through a PMC pass."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
         per_image = table[kernel.split("<")[0]]["hbm_bytes_per_image"]
@@ -262,7 +272,7 @@ def main():
                      "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms": round(dom_s * 1e3, 3),
                      "encode_kernel_ms": round(enc_kernel_s * 1e3, 3), "decode_kernel_ms": round(dec_kernel_s * 1e3, 3),
                      "kernels": names,
-                     "note": "instruction-issue bound integer coder (about 1.2 instructions/cycle/CU, serial part on the scalar unit), not bandwidth bound; see bins_per_s and DESIGN.md"},
+                     "note": "instruction-issue / latency bound integer coder (19.4 M serially dependent bins per 4K image; one instruction per ~8 cycles per wavefront, ~1.4 instructions/cycle/CU), not bandwidth bound; traffic = PMC HBM bytes (profiles/pmc_traffic.json); see bins_per_s and DESIGN.md"},
     }
     if bins_per_image:
         bins_launch = bins_per_image * args.images

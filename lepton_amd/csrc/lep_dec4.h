@@ -19,11 +19,28 @@
 namespace lep4 {
 using namespace lep3;
 
+// LEP_MARK(name): phase boundary.  -DLEP_MARKS: a comment in the ISA (static instruction counts per phase, scripts/isa.sh);
+// -DLEP_PROF: lane 0 charges the shader-clock time since the previous boundary to the PREVIOUS phase's slot (wall-clock
+// share of each phase at the occupancy the kernel really runs at; read back with lep_gpu_debug_prof).
 #if LEP_ON_GPU && defined(LEP_MARKS)
 #define LEP_MARK(name) __asm__ volatile("; MARK " name)
+#elif LEP_ON_GPU && defined(LEP_PROF)
+#define LEP_MARK(name) prof_stamp(lep4::prof_slot(name))
 #else
 #define LEP_MARK(name) ((void)0)
 #endif
+constexpr int prof_slot(const char* n) {
+    // staging prologue nz_prefetch nz_serial nz_update 77_prefetch 77_serial 77_update lakhani edge_prefetch edge_serial
+    // edge_update idct_dcpred dc_prefetch dc_serial dc_update publish store
+    const char* names[18] = {"staging", "prologue", "nz_prefetch", "nz_serial", "nz_update", "77_prefetch", "77_serial", "77_update", "lakhani",
+                             "edge_prefetch", "edge_serial", "edge_update", "idct_dcpred", "dc_prefetch", "dc_serial", "dc_update", "publish", "store"};
+    for (int i = 0; i < 18; ++i) {
+        int k = 0;
+        while (names[i][k] && names[i][k] == n[k]) ++k;
+        if (!names[i][k] && !n[k]) return i;
+    }
+    return 31;
+}
 
 struct Dec4Shared {
     uint32_t sign[kSignWords];    // resident Branches
@@ -154,6 +171,30 @@ struct Dec4Wave {
     int comp, ci;
     BoolDec4 bc;
     uint32_t nbins;   // bins decoded, accounted per coefficient: a coefficient of bit length len costs 2*len+1 bins (22 at len 11)
+#if LEP_ON_GPU && defined(LEP_PROF)
+    uint64_t prof_last;
+    unsigned long long* prof_out;   // 32 accumulators of this wave in global memory, written once at the end
+    int prof_cur;
+    uint32_t prof_acc[20];          // registers: every index below is a compile-time constant
+    template <int I> __device__ __forceinline__ void prof_add(uint32_t dt) { if (prof_cur == I) prof_acc[I] += dt; }
+    __device__ __forceinline__ void prof_stamp(int slot) {
+        const uint64_t t = __builtin_readcyclecounter();
+        const uint32_t dt = (uint32_t)(t - prof_last);
+        prof_last = t;
+        prof_add<0>(dt); prof_add<1>(dt); prof_add<2>(dt); prof_add<3>(dt); prof_add<4>(dt); prof_add<5>(dt); prof_add<6>(dt);
+        prof_add<7>(dt); prof_add<8>(dt); prof_add<9>(dt); prof_add<10>(dt); prof_add<11>(dt); prof_add<12>(dt); prof_add<13>(dt);
+        prof_add<14>(dt); prof_add<15>(dt); prof_add<16>(dt); prof_add<17>(dt); prof_add<18>(dt);
+        prof_cur = slot;
+    }
+    __device__ __forceinline__ void prof_begin(unsigned long long* out) {
+        for (int i = 0; i < 20; ++i) prof_acc[i] = 0;
+        prof_out = out; prof_cur = 18; prof_last = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void prof_end() {
+        prof_stamp(18);
+        if (threadIdx.x == 0) for (int i = 0; i < 19; ++i) prof_out[i] = prof_acc[i];
+    }
+#endif
 
     WDEV void init_tables() {
         LANES(l) {
@@ -190,6 +231,15 @@ struct Dec4Wave {
         model[idx] = nw;
 #endif
         return bit;
+    }
+    static WDEV U4 vload4(const uint32_t* p) {   // every lane loads the same group through the vector cache
+#if LEP_ON_GPU
+        uintptr_t a = (uintptr_t)p;
+        __asm__ volatile("" : "+v"(a));
+        return ld4(reinterpret_cast<const uint32_t*>(a));
+#else
+        return ld4(p);
+#endif
     }
     static WDEV uint32_t vload(const uint32_t* p) {   // every lane loads the same word through the vector cache
 #if LEP_ON_GPU
@@ -356,24 +406,24 @@ struct Dec4Wave {
 
     // ---- round 2 (repeated): interior positions zz0 .. zz0+15 under up to four consecutive "non-zeros left" bins ----------
     // lane = pi + 16 * cand: window position pi, candidate bin nb0 - cand.  W0 = exponent words 0..3, W1 = residual words
-    // 0..3 (both kept by the owner); exponent words 4..7 are only published (PK2) and re-read by the owner when used.
+    // 0..3 (both kept by the owner); exponent words 4..7 are read on demand and re-read by the owner when used.
     WDEV void round_77(int& zz_io, int& left_io) {
         Dec4Shared& S = *sh;
         LEP_MARK("77_prefetch");
         const int zz0 = zz_io, left0 = left_io, nb0 = nzbin_of(left0);
-        LV(U4, W0); LV(U4, W1); LV(uint32_t, a0); LV(uint32_t, a1); LV(uint32_t, PK0); LV(uint32_t, PK1); LV(uint32_t, PK2); LV(int, ok);
+        LV(U4, W0); LV(U4, W1); LV(uint32_t, a0); LV(uint32_t, a1); LV(uint32_t, PK0); LV(uint32_t, PK1); LV(int, ok);
         LANES(l) {
             const int pi = l & 15, cand = l >> 4, p = zz0 + pi, nb = nb0 - cand;
-            uint32_t adr0 = 0, adr1 = 0, pk0 = 0, pk1 = 0, pk2 = 0;
+            uint32_t adr0 = 0, adr1 = 0, pk0 = 0, pk1 = 0;
             const int valid = p < 49 && nb >= 1;
             if (valid) {
                 adr0 = ctx_exp7(ci, nb, p, S.bsr[p]);
                 adr1 = ctx_res(ci, S.a2r[p], nb);
                 L(W0) = ld4(model + adr0); L(W1) = ld4(model + adr1);
-                const U4 w2 = ld4(model + adr0 + 4);
-                pk0 = pack_probs(L(W0)); pk1 = pack_probs(L(W1)); pk2 = pack_probs(w2);
+                pk0 = pack_probs(L(W0)); pk1 = pack_probs(L(W1));
+
             }
-            L(a0) = adr0; L(a1) = adr1; L(PK0) = pk0; L(PK1) = pk1; L(PK2) = pk2; L(ok) = valid;
+            L(a0) = adr0; L(a1) = adr1; L(PK0) = pk0; L(PK1) = pk1; L(ok) = valid;
         }
         LSYNC();
         // ---- serial (uniform vector) -----------------------------------------------------------------------------
@@ -388,7 +438,9 @@ struct Dec4Wave {
             ++nbins;
             if (len) {
                 if (len == 4) {
-                    len += dec_unary4(lepwave::wave_read(PK2, lane));
+                    // exponent words 4..7 (|v| >= 8: 5 % of the interior non-zeros) are not prefetched -- that third of the round's
+                    // traffic was almost all waste; the serial code reads the group when it gets there, the owner re-reads it to adapt
+                    len += dec_unary4(pack_probs(vload4(model + ctx_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])) + 4)));
                     if (len == 8) len = dec_unary_tail(ctx_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])));
                 }
                 nbins += (uint32_t)(2 * len - (len == 11));

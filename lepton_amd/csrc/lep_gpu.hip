@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64) void lep_decode_v2_kernel(const ImageDev* __res
 
 #ifdef LEP_PROF
 __device__ uint64_t g_prof[64][32];
+__device__ unsigned long long g_prof4[8192][32];   // v4: private accumulators per wave (no atomic contention)
 #endif
 
 // exhaustive check of the float-reciprocal / table-reciprocal Branch probabilities against integer division (all 255 x 255 count pairs)
@@ -202,7 +203,13 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
     reset_segment_state<lep3::kModelWords>(model, ns, img->ns_total, lane);
     __syncthreads();
     lep4::Dec4Wave w;
+#ifdef LEP_PROF
+    w.prof_begin(&g_prof4[s & 8191][0]);
+#endif
     int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, stream_len[s]);
+#ifdef LEP_PROF
+    w.prof_end();
+#endif
     if (lane != 0) return;
     status[s] = rc;
     bins[s] = w.nbins;
@@ -292,6 +299,9 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     g->h_bins.assign(nseg, 0);
     HIPCHK(g, hipEventRecord(g->ev0, st));
     if (DEC && g->decode_kernel == 4) {
+#ifdef LEP_PROF
+        { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_prof4)) == hipSuccess) (void)hipMemsetAsync(p, 0, sizeof(g_prof4), st); }
+#endif
 #define LEP_LAUNCH_DEC4(W)                                                                                                     \
     hipLaunchKernelGGL((lep_decode_v4_kernel<W>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),                  \
                        (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns), \
@@ -426,6 +436,14 @@ int lep_gpu_selftest(lep_gpu* g) {
 // profiling builds (-DLEP_PROF) only: per-phase shader-clock totals of the first 64 segments of the last v3 launch
 int lep_gpu_debug_prof(lep_gpu* g, uint64_t* out /* [64][32] */) {
 #ifdef LEP_PROF
+    if (g->decode_kernel == 4) {   // fold the per-wave accumulators into the 64 x 32 report
+        std::vector<unsigned long long> h(8192 * 32);
+        HIPCHK(g, hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_prof4), sizeof(unsigned long long) * 8192 * 32));
+        memset(out, 0, sizeof(uint64_t) * 64 * 32);
+        for (int s = 0; s < 8192; ++s)
+            for (int i = 0; i < 32; ++i) out[(s & 63) * 32 + i] += h[(size_t)s * 32 + i];
+        return 0;
+    }
     HIPCHK(g, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(uint64_t) * 64 * 32));
     return 0;
 #else

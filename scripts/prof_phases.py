@@ -58,7 +58,20 @@ def main():
     ms = L.lep_gpu_last_kernel_ms(codec.handle)
     prof = (C.c_uint64 * (64 * 32))()
     assert L.lep_gpu_debug_prof(codec.handle, prof) == 0
-    nseg = min(64, sum(len(f.segments) for f in files))
+    nseg_all = sum(len(f.segments) for f in files)
+    if os.environ.get("LEP_DECODE_KERNEL", "4") == "4":   # v4: 64 global buckets summed over all waves, slots named in lep_dec4.h
+        names = ["staging", "prologue", "nz_prefetch", "nz_serial", "nz_update", "77_prefetch", "77_serial", "77_update", "lakhani",
+                 "edge_prefetch", "edge_serial", "edge_update", "idct_dcpred", "dc_prefetch", "dc_serial", "dc_update", "publish", "store"]
+        tot = [sum(prof[s * 32 + i] for s in range(64)) / nseg_all for i in range(32)]
+        blocks = sum(f.desc.total_blocks() for f in files) / nseg_all
+        cyc = sum(tot)
+        print("decode kernel %.1f ms, %d segments, %.0f blocks/segment; accounted %.0f Mcycles/segment (%.0f shader-clock cycles/block)" %
+              (ms, nseg_all, blocks, cyc / 1e6, cyc / blocks))
+        for i, n in enumerate(names + ["other"]):
+            v = tot[i] if i < len(names) else sum(tot[len(names):])
+            print("  %-14s %8.0f cycles/block  %5.1f%%" % (n, v / blocks, 100 * v / cyc))
+        return
+    nseg = min(64, nseg_all)
     tot = [sum(prof[s * 32 + i] for s in range(nseg)) / nseg for i in range(32)]
     blocks = sum(f.desc.total_blocks() for f in files) / sum(len(f.segments) for f in files)
     cyc = sum(tot[:24])
