@@ -30,7 +30,7 @@ enum {
     LEP_UNSUPPORTED_4_COLORS = 4, LEP_COEFFICIENT_OUT_OF_RANGE = 6, LEP_STREAM_INCONSISTENT = 7,
     LEP_PROGRESSIVE_UNSUPPORTED = 8, LEP_SAMPLING_BEYOND_TWO_UNSUPPORTED = 10,
     LEP_THREADING_PARTIAL_MCU = 12, LEP_VERSION_UNSUPPORTED = 13, LEP_OS_ERROR = 33,
-    LEP_UNSUPPORTED_JPEG = 38, LEP_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 39,
+    LEP_ROUNDTRIP_FAILURE = 41, LEP_UNSUPPORTED_JPEG = 42, LEP_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 43,
     LEP_BUFFER_TOO_SMALL = 100, LEP_GPU_ERROR = 120
 };
 
@@ -115,8 +115,14 @@ typedef struct lep_file lep_file;   /* a parsed .lep: header sections, hand-offs
 
 /* JPEG -> coefficient frame (read_jpeg + decode_jpeg, src/lepton/jpgcoder.cc:2269-2466, 2799-3302) */
 int lep_jpeg_open(const uint8_t *jpg, size_t len, int allow_progressive, lep_jpeg **out);
+/* the same, with the coefficient frame decoded straight into caller-provided memory (frame_cap bytes, planes back to back,
+ * e.g. pinned staging memory): no allocation, page faults or later copy; falls back to owned storage when it is too small */
+int lep_jpeg_open_into(const uint8_t *jpg, size_t len, int allow_progressive, void *frame_mem, size_t frame_cap, lep_jpeg **out);
+/* frame size from the SOF marker alone (no scan decode) */
+int lep_jpeg_peek_frame_bytes(const uint8_t *jpg, size_t len, size_t *bytes);
 void lep_jpeg_close(lep_jpeg *j);
 int lep_jpeg_describe(const lep_jpeg *j, lep_image_desc *desc);          /* host pointers into j */
+int lep_jpeg_is_progressive(const lep_jpeg *j);   /* 1: not a single interleaved sequential scan (needs the progressive re-coder) */
 /* segment choice of write_ujpg (src/lepton/jpgcoder.cc:3856-3934); returns count, fills segs */
 int lep_jpeg_plan(const lep_jpeg *j, int max_threads, lep_segment *segs, int image_index);
 /* whole .lep file from the per-segment streams (header + mux + trailer) */
@@ -126,8 +132,10 @@ int lep_jpeg_write_lep(const lep_jpeg *j, int max_threads, const lep_bytes *stre
 int lep_file_open(const uint8_t *lepdata, size_t len, lep_file **out);
 void lep_file_close(lep_file *f);
 int lep_file_describe(lep_file *f, lep_image_desc *desc);                /* allocates zeroed host frame */
+int lep_file_describe_into(lep_file *f, void *frame_mem, size_t frame_cap, lep_image_desc *desc);   /* frame in caller memory */
 int lep_file_segments(const lep_file *f, lep_segment *segs, lep_bytes *streams, int image_index);
 uint32_t lep_file_jpeg_size(const lep_file *f);
+size_t lep_file_frame_bytes(const lep_file *f);   /* bytes of the coefficient frame lep_file_describe will expose */
 /* coefficient frame -> original JPEG bytes (recode_baseline_jpeg, src/lepton/recoder.cc:694-889) */
 int lep_file_recode(lep_file *f, lep_bytes *out);
 
@@ -150,6 +158,34 @@ int lep_demux(const uint8_t *data, size_t len, lep_bytes *streams16);
 /* ---- layer 3: whole files ------------------------------------------------------------------- */
 int lep_compress(lep_gpu *g, const uint8_t *jpg, size_t len, lep_bytes *out);
 int lep_decompress(lep_gpu *g, const uint8_t *lepdata, size_t len, lep_bytes *out);
+
+/* Whole batches of files as a pipeline (what `lepton -socket` workers / src/lepton/socket_serve.cc:312-390 would hand to
+ * the GPU): JPEG parsing + Huffman scan decode on a host thread pool, coefficient frames over PCIe on a copy stream while
+ * the previous chunk's coder kernels run, streams back, .lep containers written on the host pool -- and the mirror image
+ * for decompression.  verify != 0 restores the reference's default round-trip check (src/lepton/validation.cc:97-218) on
+ * the GPU: what was just encoded is decoded into a scratch frame and compared with the input frame before the .lep is
+ * released; a mismatch gives that file status LEP_ROUNDTRIP_FAILURE.
+ * status[i] = exit code of file i (0 = ok, outs[i] is malloc'd: release with lep_free); the return value is non-zero only
+ * for failures of the machinery itself (LEP_GPU_ERROR). */
+typedef struct lep_batch_options {
+    int32_t host_threads;        /* 0 = the CPUs this process may use (affinity mask capped by the cgroup CPU quota) */
+    int32_t verify;              /* compress: on-GPU round-trip verification */
+    size_t chunk_frame_bytes;    /* cap on coefficient-frame bytes per pipeline chunk; 0 = 24 GiB */
+    int32_t chunk_images;        /* images per pipeline chunk; 0 = 1024 (x 8 thread segments = one wavefront per SIMD slot of the
+                                    chip: a coder kernel takes as long for 100 segments as for 8192, so chunks must be this big) */
+} lep_batch_options;
+typedef struct lep_batch_stats {
+    double wall_s;               /* whole call */
+    double pipeline_s;           /* first upload .. last container (excludes stream / buffer creation and the first parse) */
+    double parse_s, stage_s, write_s;   /* host pool: parse, copies into pinned staging, container / Huffman re-code (summed) */
+    double h2d_bytes, d2h_bytes; /* PCIe traffic */
+    double alloc_s;              /* inside pipeline_s: (re)allocation of the pinned / device staging buffers (kept between calls) */
+} lep_batch_stats;
+int lep_compress_batch(lep_gpu *g, const lep_bytes *jpgs, int n, lep_bytes *outs, int32_t *status,
+                       const lep_batch_options *opt, lep_batch_stats *stats);
+int lep_decompress_batch(lep_gpu *g, const lep_bytes *leps, int n, lep_bytes *outs, int32_t *status,
+                         const lep_batch_options *opt, lep_batch_stats *stats);
+void lep_batch_release(void);   /* frees the staging buffers the two calls above keep between invocations (not re-entrant) */
 
 void lep_free(void *p);   /* frees lep_bytes.data returned by this library */
 const char *lep_version(void);

@@ -50,6 +50,15 @@ class Bytes(C.Structure):
         return C.string_at(self.data, self.len) if self.len else b""
 
 
+class BatchOptions(C.Structure):
+    _fields_ = [("host_threads", C.c_int32), ("verify", C.c_int32), ("chunk_frame_bytes", C.c_size_t), ("chunk_images", C.c_int32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("wall_s", C.c_double), ("pipeline_s", C.c_double), ("parse_s", C.c_double), ("stage_s", C.c_double),
+                ("write_s", C.c_double), ("h2d_bytes", C.c_double), ("d2h_bytes", C.c_double), ("alloc_s", C.c_double)]
+
+
 _lib = None
 
 
@@ -106,6 +115,11 @@ def lib():
         L.lep_gpu_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
         L.lep_compress.argtypes = [vp, vp, C.c_size_t, P(Bytes)]
         L.lep_decompress.argtypes = [vp, vp, C.c_size_t, P(Bytes)]
+        L.lep_jpeg_is_progressive.argtypes = [vp]
+        L.lep_compress_batch.argtypes = [vp, P(Bytes), C.c_int, P(Bytes), P(C.c_int32), P(BatchOptions), P(BatchStats)]
+        L.lep_decompress_batch.argtypes = [vp, P(Bytes), C.c_int, P(Bytes), P(C.c_int32), P(BatchOptions), P(BatchStats)]
+        L.lep_batch_release.argtypes = []
+        L.lep_batch_release.restype = None
         L.lep_handoffs_serialize.argtypes = [P(Handoff), C.c_int, vp, C.c_size_t]
         L.lep_handoffs_parse.argtypes = [vp, C.c_size_t, P(Handoff), C.c_int]
         L.lep_mux.argtypes = [P(Bytes), C.c_int, C.c_int, P(Bytes)]
@@ -121,5 +135,5 @@ EXPORTS = [
     "lep_gpu_free", "lep_gpu_memcpy_h2d", "lep_gpu_memcpy_d2h", "lep_gpu_memcpy_d2d", "lep_gpu_memset", "lep_jpeg_open", "lep_jpeg_close",
     "lep_jpeg_describe", "lep_jpeg_plan", "lep_jpeg_write_lep", "lep_file_open", "lep_file_close", "lep_file_describe",
     "lep_file_segments", "lep_file_jpeg_size", "lep_file_recode", "lep_compress", "lep_decompress", "lep_free",
-    "lep_version", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
+    "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
 ]

@@ -186,6 +186,37 @@ class GpuCodec:
         self._L.lep_free(out.data)
         return data
 
+    def _batch(self, fn, blobs, verify, threads, chunk_bytes, chunk_images=0):
+        n = len(blobs)
+        ins = (abi.Bytes * n)()
+        keep = []
+        for i, b in enumerate(blobs):
+            buf = C.create_string_buffer(bytes(b), max(1, len(b)))
+            keep.append(buf)
+            ins[i].data = C.cast(buf, C.c_void_p).value
+            ins[i].len = ins[i].cap = len(b)
+        outs = (abi.Bytes * n)()
+        status = (C.c_int32 * n)()
+        opt = abi.BatchOptions(threads, 1 if verify else 0, chunk_bytes, chunk_images)
+        stats = abi.BatchStats()
+        rc = fn(self.handle, ins, n, outs, status, C.byref(opt), C.byref(stats))
+        if rc:
+            raise LeptonError(rc, "batch pipeline [%s]" % self.last_error())
+        res = []
+        for i in range(n):
+            res.append(outs[i].tobytes() if not status[i] else None)
+            if outs[i].data:
+                self._L.lep_free(outs[i].data)
+        return res, list(status), {k: getattr(stats, k) for k, _ in abi.BatchStats._fields_}
+
+    def compress_batch(self, jpgs, verify=False, threads=0, chunk_bytes=0, chunk_images=0):
+        """[jpeg bytes] -> ([.lep bytes or None], [exit code per file], pipeline statistics)"""
+        return self._batch(self._L.lep_compress_batch, jpgs, verify, threads, chunk_bytes, chunk_images)
+
+    def decompress_batch(self, leps, threads=0, chunk_bytes=0, chunk_images=0):
+        """[.lep bytes] -> ([jpeg bytes or None], [exit code per file], pipeline statistics)"""
+        return self._batch(self._L.lep_decompress_batch, leps, False, threads, chunk_bytes, chunk_images)
+
     def close(self):
         if self.handle:
             self._L.lep_gpu_destroy(self.handle)

@@ -18,7 +18,7 @@ enum ExitCode : int {
     EX_SAMPLING_BEYOND_TWO_UNSUPPORTED = 10, EX_SAMPLING_BEYOND_FOUR_UNSUPPORTED = 11,
     EX_THREADING_PARTIAL_MCU = 12, EX_VERSION_UNSUPPORTED = 13, EX_ONLY_GARBAGE_NO_JPEG = 14,
     EX_OS_ERROR = 33, EX_HEADER_TOO_LARGE = 34, EX_BLOCK_OFFSET_OOM = 37,
-    EX_UNSUPPORTED_JPEG = 38, EX_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 39,
+    EX_TOO_MUCH_MEMORY_NEEDED = 38, EX_ROUNDTRIP_FAILURE = 41, EX_UNSUPPORTED_JPEG = 42, EX_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 43,
     EX_INVALID_RESET_MARKER_FOUND = 40, EX_UNSUPPORTED_4_COLORS_B = 4,
     EX_GPU_ERROR = 120,   // ours: HIP runtime failure (no reference equivalent)
 };
@@ -80,7 +80,22 @@ struct JpegFile {
     int cs_cmpc = 0, cs_cmp[4] = {0, 0, 0, 0}, cs_from = 0, cs_to = 0, cs_sah = 0, cs_sal = 0;
     int scan_count = 0;
     // --- coefficients
-    std::vector<int16_t> coef[4];       // bc * 64, aligned order
+    std::vector<int16_t> coef[4];       // bc * 64, aligned order (owned storage; unused when the frame lives in ext_mem)
+    int16_t* plane[4] = {nullptr, nullptr, nullptr, nullptr};   // where the frame is: coef[c].data() or inside ext_mem
+    int16_t* ext_mem = nullptr;         // optional caller-provided frame storage (e.g. pinned staging memory), planes back to back
+    size_t ext_cap = 0;                 // bytes
+    // points plane[] at zeroed storage for the frame geometry in comp[]; ext_mem is used when it is large enough
+    void place_frame(bool zero) {
+        size_t need = 0;
+        for (int c = 0; c < ncomp; ++c) need += (size_t)comp[c].bc * 128;
+        if (ext_mem && need <= ext_cap) {
+            size_t off = 0;
+            for (int c = 0; c < ncomp; ++c) { plane[c] = ext_mem + off / 2; off += (size_t)comp[c].bc * 128; }
+            if (zero) __builtin_memset(ext_mem, 0, need);
+        } else {
+            for (int c = 0; c < ncomp; ++c) { coef[c].assign((size_t)comp[c].bc * 64, 0); plane[c] = coef[c].data(); }
+        }
+    }
     std::vector<Handoff> rows;          // one per MCU row + final
     // truncation
     int max_cmp = 0, max_bpos = 0, max_sah = 0, max_dpos[4] = {0, 0, 0, 0};

@@ -76,7 +76,7 @@ struct RowCoder {
         while (!end_of_row) {
             int sta = 0;
             while (sta == 0) {
-                const int16_t* src = jf.coef[cmp].data() + (size_t)dpos * 64;
+                const int16_t* src = jf.plane[cmp] + (size_t)dpos * 64;
                 for (int b = 0; b < 64; ++b) blk[b] = src[kZigzagToAligned[b]];
                 int16_t dc = blk[0];
                 blk[0] = (int16_t)(blk[0] - lastdc[cmp]);

@@ -391,7 +391,7 @@ static int decode_scans(JpegFile* jf, bool allow_progressive) {
     size_t hdrs = jf->hdr.size(), hpos = 0;
     int lastdc[4] = {0, 0, 0, 0};
     int mcu = 0;
-    for (int c = 0; c < jf->ncomp; ++c) jf->coef[c].assign((size_t)jf->comp[c].bc * 64, 0);
+    jf->place_frame(true);
     jf->scan_count = 0;
     const int luma_mul = jf->comp[0].bcv / jf->mcuv;
     int16_t blk[64];
@@ -446,7 +446,7 @@ static int decode_scans(JpegFile* jf, bool allow_progressive) {
                     if (eob > 1 && !blk[eob - 1]) jf->warn = std::max(jf->warn, 1);
                     blk[0] = (int16_t)(blk[0] + lastdc[cmp]);
                     lastdc[cmp] = blk[0];
-                    int16_t* dst = jf->coef[cmp].data() + (size_t)dpos * 64;
+                    int16_t* dst = jf->plane[cmp] + (size_t)dpos * 64;
                     for (int b = 0; b < eob; ++b) dst[kZigzagToAligned[b]] = blk[b];
                     int old_mcu = mcu;
                     if (eob < 0) sta = -1;
@@ -465,7 +465,7 @@ static int decode_scans(JpegFile* jf, bool allow_progressive) {
                     if (eob > 1 && !blk[eob - 1]) jf->warn = std::max(jf->warn, 1);
                     blk[0] = (int16_t)(blk[0] + lastdc[cmp]);
                     lastdc[cmp] = blk[0];
-                    int16_t* dst = jf->coef[cmp].data() + (size_t)dpos * 64;
+                    int16_t* dst = jf->plane[cmp] + (size_t)dpos * 64;
                     for (int b = 0; b < eob; ++b) dst[kZigzagToAligned[b]] = blk[b];
                     if (eob < 0) sta = -1;
                     else sta = next_mcuposn(*jf, cmp, &dpos, &rstw);

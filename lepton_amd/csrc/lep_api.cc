@@ -47,7 +47,45 @@ const char* lep_version(void) { return "lepton-mi355x 0.1 (format v1, gfx950)"; 
 void lep_free(void* p) { free(p); }
 
 int lep_jpeg_open(const uint8_t* jpg, size_t len, int allow_progressive, lep_jpeg** out) {
+    return lep_jpeg_open_into(jpg, len, allow_progressive, nullptr, 0, out);
+}
+
+// SOF geometry only (no scan decode): bytes of the coefficient frame parse_jpeg will produce, MCU padding included
+int lep_jpeg_peek_frame_bytes(const uint8_t* d, size_t n, size_t* bytes) {
+    *bytes = 0;
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return LEP_UNSUPPORTED_JPEG;
+    size_t p = 2;
+    while (p + 4 <= n) {
+        if (d[p] != 0xFF) return LEP_UNSUPPORTED_JPEG;
+        const uint8_t m = d[p + 1];
+        if (m == 0xFF) { ++p; continue; }
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) { p += 2; continue; }
+        const size_t len = ((size_t)d[p + 2] << 8) | d[p + 3];
+        if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+            if (p + 2 + len > n || len < 8) return LEP_UNSUPPORTED_JPEG;
+            const int h = (d[p + 5] << 8) | d[p + 6], w = (d[p + 7] << 8) | d[p + 8], nc = d[p + 9];
+            if (nc < 1 || nc > 4 || len < 8 + 3 * (size_t)nc || !w || !h) return LEP_UNSUPPORTED_JPEG;
+            int hs[4], vs[4], hmax = 1, vmax = 1;
+            for (int c = 0; c < nc; ++c) {
+                hs[c] = d[p + 11 + 3 * c] >> 4; vs[c] = d[p + 11 + 3 * c] & 15;
+                if (!hs[c] || !vs[c]) return LEP_UNSUPPORTED_JPEG;
+                hmax = std::max(hmax, hs[c]); vmax = std::max(vmax, vs[c]);
+            }
+            const size_t mcuh = ((size_t)w + 8 * hmax - 1) / (8 * hmax), mcuv = ((size_t)h + 8 * vmax - 1) / (8 * vmax);
+            size_t b = 0;
+            for (int c = 0; c < nc; ++c) b += mcuh * hs[c] * mcuv * vs[c] * 128;
+            *bytes = b;
+            return 0;
+        }
+        if (m == 0xDA || m == 0xD9) break;
+        p += 2 + len;
+    }
+    return LEP_UNSUPPORTED_JPEG;
+}
+
+int lep_jpeg_open_into(const uint8_t* jpg, size_t len, int allow_progressive, void* frame_mem, size_t frame_cap, lep_jpeg** out) {
     std::unique_ptr<lep_jpeg> j(new lep_jpeg);
+    j->jf.ext_mem = (int16_t*)frame_mem; j->jf.ext_cap = frame_mem ? frame_cap : 0;
     j->opt.allow_progressive = allow_progressive != 0;
     int rc = lep::parse_jpeg(jpg, len, allow_progressive != 0, &j->jf);
     if (rc) return rc;
@@ -58,10 +96,12 @@ void lep_jpeg_close(lep_jpeg* j) { delete j; }
 
 int lep_jpeg_describe(const lep_jpeg* j, lep_image_desc* d) {
     int16_t* planes[4];
-    for (int c = 0; c < 4; ++c) planes[c] = const_cast<int16_t*>(j->jf.coef[c].data());
+    for (int c = 0; c < 4; ++c) planes[c] = j->jf.plane[c];
     fill_desc(j->jf, d, planes);
     return 0;
 }
+
+int lep_jpeg_is_progressive(const lep_jpeg* j) { return j->jf.progressive_needed ? 1 : 0; }
 
 int lep_jpeg_plan(const lep_jpeg* j, int max_threads, lep_segment* segs, int image_index) {
     lep::EncodeOptions o = j->opt;
@@ -114,16 +154,24 @@ int lep_file_open(const uint8_t* d, size_t len, lep_file** out) {
 }
 void lep_file_close(lep_file* f) { delete f; }
 uint32_t lep_file_jpeg_size(const lep_file* f) { return f->lf.jpeg_size; }
+size_t lep_file_frame_bytes(const lep_file* f) {
+    size_t b = 0;
+    for (int c = 0; c < f->lf.jpeg.ncomp; ++c) b += (size_t)f->lf.jpeg.comp[c].bc * 128;
+    return b;
+}
 
-int lep_file_describe(lep_file* f, lep_image_desc* d) {
+int lep_file_describe(lep_file* f, lep_image_desc* d) { return lep_file_describe_into(f, nullptr, 0, d); }
+
+// frame_mem (optional): caller-provided storage for the coefficient frame (planes back to back), not zeroed by this call --
+// the batch pipeline points it at the pinned buffer the decoded frame is copied into
+int lep_file_describe_into(lep_file* f, void* frame_mem, size_t frame_cap, lep_image_desc* d) {
     lep::JpegFile& jf = f->lf.jpeg;
-    if (!f->frame_ready) {
-        for (int c = 0; c < jf.ncomp; ++c) jf.coef[c].assign((size_t)jf.comp[c].bc * 64, 0);
+    if (!f->frame_ready || frame_mem) {
+        jf.ext_mem = (int16_t*)frame_mem; jf.ext_cap = frame_mem ? frame_cap : 0;
+        jf.place_frame(false);
         f->frame_ready = true;
     }
-    int16_t* planes[4];
-    for (int c = 0; c < 4; ++c) planes[c] = jf.coef[c].data();
-    fill_desc(jf, d, planes);
+    fill_desc(jf, d, jf.plane);
     return 0;
 }
 

@@ -1,0 +1,515 @@
+// lep_batch.hip -- layer 3 of the C ABI for whole batches: `lepton in.jpg out.lep` / `lepton in.lep out.jpg` for many files
+// at once, as a pipeline that keeps the GPU hot path fed (BASELINE.json configs[2]: hipStream-overlapped H2D / encode / D2H).
+//
+//   host pool      parse JPEG (Huffman scan decode, jpeg_scan.cc)  -> coefficient frames in pinned memory
+//   copy stream    frames of chunk k+1 go over PCIe while ...
+//   compute stream ... the coder kernels of chunk k run (one wavefront per thread segment, lep_gpu.hip)
+//                  [optional] on-GPU round-trip verification: decode what was just encoded into a scratch frame and
+//                  compare it with the input frame (the reference's default `-verify`, src/lepton/validation.cc:97-218,
+//                  costs it a second process and a full decode on the CPU)
+//   copy stream    streams of chunk k come back, host pool writes the .lep containers (lep_container.cc)
+// and the mirror image for decompression (streams up, frames down, Huffman re-encode on the host pool).
+// Only public entry points of the library are used for the GPU work (lep_gpu_encode_device / lep_gpu_decode_device).
+#include <hip/hip_runtime.h>
+#include <malloc.h>
+#include <sched.h>
+#include <cstdio>
+
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "../../include/lepton_mi355x.h"
+#include "jpeg_model.h"
+#include "lep_container.h"
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// CPUs this process may really use: affinity mask, capped by the cgroup CPU quota (a container can see 256 CPUs and be
+// allowed 16: a pool sized by hardware_concurrency() then runs 3x slower than one sized by the quota)
+int effective_cpus() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, std::min(n, CPU_COUNT(&set)));
+    double quota = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota|max> <period>"
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && q[0] != 'm' && period > 0) quota = atof(q) / (double)period;
+        fclose(f);
+    } else {
+        long q = -1, p = 0;
+        if (FILE* a = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(a, "%ld", &q) != 1) q = -1; fclose(a); }
+        if (FILE* b = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(b, "%ld", &p) != 1) p = 0; fclose(b); }
+        if (q > 0 && p > 0) quota = (double)q / (double)p;
+    }
+    if (quota >= 1.0) n = std::min(n, (int)(quota + 0.5));
+    return std::max(1, n);
+}
+
+// run fn(i) for i in [0, n) on `threads` host threads
+void parallel_for(int n, int threads, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    threads = std::max(1, std::min(threads, n));
+    std::atomic<int> next(0);
+    auto worker = [&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+}
+
+// 16 bytes per lane, grid-stride: frames are compared at HBM speed (2 x bytes read, nothing written unless they differ)
+__global__ void lep_compare_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, size_t n16, uint32_t* flag, uint32_t value) {
+    bool diff = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 x = a[i], y = b[i];
+        diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+    }
+    if (diff) atomicOr(flag, value);
+}
+
+// Hundreds of host threads each allocating and freeing MB-sized vectors (un-stuffed scan data, containers) serialise on
+// the process-wide mmap lock when glibc serves them with mmap/munmap; keep such blocks inside the per-thread arenas.
+void tune_malloc_for_pool() {
+    static std::atomic<bool> done(false);
+    if (done.exchange(true)) return;
+    mallopt(M_MMAP_THRESHOLD, 256 << 20);
+    mallopt(M_TRIM_THRESHOLD, 512 << 20);
+    mallopt(M_ARENA_MAX, 512);
+}
+
+struct Slot {   // one chunk's buffers (double-buffered)
+    char* h_frames = nullptr; char* d_frames = nullptr; char* d_scratch = nullptr; size_t frames_cap = 0;
+    uint8_t* d_streams = nullptr; uint8_t* h_streams = nullptr; size_t streams_cap = 0;
+    uint32_t* d_len = nullptr; int32_t* d_status = nullptr; uint32_t* d_flags = nullptr; size_t seg_cap = 0, img_cap = 0;
+    hipEvent_t up = nullptr, done = nullptr;
+    void release() {
+        if (h_frames) (void)hipHostFree(h_frames);
+        if (h_streams) (void)hipHostFree(h_streams);
+        for (void* p : {(void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags})
+            if (p) (void)hipFree(p);
+        if (up) (void)hipEventDestroy(up);
+        if (done) (void)hipEventDestroy(done);
+        *this = Slot();
+    }
+};
+
+#define HIPOK(call) do { if ((call) != hipSuccess) return LEP_GPU_ERROR; } while (0)
+
+double g_alloc_s = 0;   // time spent in (re)allocating staging buffers during the current call (single orchestrator thread)
+
+int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch);
+int slot_reserve(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch) {
+    const double t0 = now_s();
+    const int rc = slot_reserve_impl(s, frames, streams, nseg, nimg, scratch);
+    g_alloc_s += now_s() - t0;
+    return rc;
+}
+int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch) {
+    if (frames > s->frames_cap) {
+        if (s->h_frames) (void)hipHostFree(s->h_frames);
+        if (s->d_frames) (void)hipFree(s->d_frames);
+        if (s->d_scratch) (void)hipFree(s->d_scratch);
+        s->h_frames = s->d_frames = s->d_scratch = nullptr;
+        HIPOK(hipHostMalloc((void**)&s->h_frames, frames, hipHostMallocDefault));
+        HIPOK(hipMalloc((void**)&s->d_frames, frames));
+        s->frames_cap = frames;
+    }
+    if (scratch && !s->d_scratch) HIPOK(hipMalloc((void**)&s->d_scratch, s->frames_cap));
+    if (streams > s->streams_cap) {
+        if (s->h_streams) (void)hipHostFree(s->h_streams);
+        if (s->d_streams) (void)hipFree(s->d_streams);
+        HIPOK(hipHostMalloc((void**)&s->h_streams, streams, hipHostMallocDefault));
+        HIPOK(hipMalloc((void**)&s->d_streams, streams));
+        s->streams_cap = streams;
+    }
+    if (nseg > s->seg_cap) {
+        if (s->d_len) (void)hipFree(s->d_len);
+        if (s->d_status) (void)hipFree(s->d_status);
+        HIPOK(hipMalloc((void**)&s->d_len, nseg * 4));
+        HIPOK(hipMalloc((void**)&s->d_status, nseg * 8));   // [nseg] coder statuses + [nseg] verification-decode statuses
+        s->seg_cap = nseg;
+    }
+    if (nimg > s->img_cap) {
+        if (s->d_flags) (void)hipFree(s->d_flags);
+        HIPOK(hipMalloc((void**)&s->d_flags, nimg * 4));
+        s->img_cap = nimg;
+    }
+    if (!s->up) HIPOK(hipEventCreateWithFlags(&s->up, hipEventDisableTiming));
+    if (!s->done) HIPOK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    return 0;
+}
+
+struct Chunk {
+    int first = 0, count = 0;
+    std::vector<int> live;                 // indices (into the batch) of the images that go to the GPU
+    std::vector<lep_image_desc> host_desc, dev_desc, scratch_desc;
+    std::vector<size_t> frame_off;         // per live image: offset of its frame in the slot
+    std::vector<lep_segment> segs;
+    std::vector<uint64_t> offs;            // stream arena offsets (nseg + 1)
+    std::vector<int> seg_first;            // per live image: first segment index
+    size_t frame_bytes = 0;
+};
+
+Slot g_slots[2];         // one batch call at a time (the calls are not re-entrant)
+
+size_t frame_bytes_of(const lep_image_desc& d) {
+    size_t b = 0;
+    for (int c = 0; c < d.ncomp; ++c) b += (size_t)d.width_blocks[c] * d.height_blocks[c] * 128;
+    return (b + 255) & ~(size_t)255;
+}
+
+}  // namespace
+
+extern "C" {
+
+// frees the pinned / device staging buffers the batch calls keep between invocations
+void lep_batch_release(void) { for (Slot& s : g_slots) s.release(); }
+
+// ---- JPEG -> .lep, batch ---------------------------------------------------------------------------------------------
+int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs, int32_t* status, const lep_batch_options* o,
+                       lep_batch_stats* stats) {
+    if (!g || n < 0) return LEP_GPU_ERROR;
+    const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
+    const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
+    const size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
+    const bool verify = o && o->verify;
+    tune_malloc_for_pool();
+    const double t_begin = now_s();
+    lep_batch_stats st;
+    memset(&st, 0, sizeof st);
+    for (int i = 0; i < n; ++i) { outs[i].data = nullptr; outs[i].len = outs[i].cap = 0; status[i] = 0; }
+
+    // 1. frame sizes from the SOF markers -> the whole batch is cut into chunks before anything is decoded, so that every
+    //    image can be Huffman-decoded straight into its place in a pinned staging buffer (no page faults, no second copy)
+    std::vector<size_t> fbytes(n, 0);
+    parallel_for(n, threads, [&](int i) { if (int rc = lep_jpeg_peek_frame_bytes(jpgs[i].data, jpgs[i].len, &fbytes[i])) status[i] = rc; });
+    std::vector<std::unique_ptr<Chunk>> chunks;
+    for (int i = 0; i < n;) {
+        std::unique_ptr<Chunk> c(new Chunk);
+        c->first = i;
+        size_t bytes = 0;
+        for (; i < n; ++i) {
+            if (status[i]) continue;
+            const size_t fb = (fbytes[i] + 255) & ~(size_t)255;
+            if (!c->live.empty() && (bytes + fb > chunk_budget || c->live.size() >= chunk_images)) break;
+            c->live.push_back(i); c->frame_off.push_back(bytes);
+            bytes += fb;
+        }
+        c->count = i - c->first;
+        c->frame_bytes = bytes;
+        chunks.push_back(std::move(c));
+    }
+    hipStream_t s_copy = nullptr, s_compute = nullptr, s_down = nullptr;
+    HIPOK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+    HIPOK(hipStreamCreateWithFlags(&s_compute, hipStreamNonBlocking));
+    HIPOK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+    Slot* slots = g_slots;   // grow-only staging cache shared by the batch calls (lep_batch_release frees it)
+    g_alloc_s = 0;
+    int rc_all = 0;
+    std::vector<lep_jpeg*> parsed(n, nullptr);
+
+    // 2. per chunk: parse into the slot's pinned frames (host pool), plan segments, start the upload
+    auto parse_and_upload = [&](Chunk* c, Slot* s) -> int {
+        if (c->live.empty()) return 0;
+        if (int rc = slot_reserve(s, c->frame_bytes, 0, 0, c->live.size(), verify)) return rc;
+        const double t0 = now_s();
+        c->host_desc.resize(c->live.size());
+        std::vector<char> fits(c->live.size(), 1);
+        parallel_for((int)c->live.size(), threads, [&](int k) {
+            const int i = c->live[k];
+            const size_t room = (k + 1 < (int)c->live.size() ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
+            int rc = lep_jpeg_open_into(jpgs[i].data, jpgs[i].len, 1, s->h_frames + c->frame_off[k], room, &parsed[i]);
+            if (!rc && lep_jpeg_is_progressive(parsed[i])) rc = LEP_PROGRESSIVE_UNSUPPORTED;   // host re-coder is sequential-only so far
+            if (!rc) {
+                lep_jpeg_describe(parsed[i], &c->host_desc[k]);
+                if ((char*)c->host_desc[k].blocks[0] != s->h_frames + c->frame_off[k]) fits[k] = 0;   // SOF peek disagreed with the parser
+            }
+            if (rc) { status[i] = rc; if (parsed[i]) { lep_jpeg_close(parsed[i]); parsed[i] = nullptr; } }
+        });
+        st.parse_s += now_s() - t0;
+        // drop failed images from the chunk; copy the (never expected) misfits into place if they fit, else fail them
+        Chunk keep;
+        for (size_t k = 0; k < c->live.size(); ++k) {
+            const int i = c->live[k];
+            if (!parsed[i]) continue;
+            if (!fits[k]) {
+                const lep_image_desc& d = c->host_desc[k];
+                const size_t room = (k + 1 < c->live.size() ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
+                if (frame_bytes_of(d) > room) { status[i] = LEP_ASSERTION_FAILURE; lep_jpeg_close(parsed[i]); parsed[i] = nullptr; continue; }
+                size_t off = c->frame_off[k];
+                for (int cc = 0; cc < d.ncomp; ++cc) {
+                    const size_t b = (size_t)d.width_blocks[cc] * d.height_blocks[cc] * 128;
+                    memcpy(s->h_frames + off, d.blocks[cc], b);
+                    off += b;
+                }
+            }
+            keep.live.push_back(i); keep.frame_off.push_back(c->frame_off[k]); keep.host_desc.push_back(c->host_desc[k]);
+        }
+        c->live.swap(keep.live); c->frame_off.swap(keep.frame_off); c->host_desc.swap(keep.host_desc);
+        c->segs.clear(); c->offs.assign(1, 0); c->seg_first.clear();
+        for (size_t k = 0; k < c->live.size(); ++k) {
+            lep_segment sg[LEP_MAX_SEGMENTS];
+            const int ns = lep_jpeg_plan(parsed[c->live[k]], 0, sg, (int)k);
+            c->seg_first.push_back((int)c->segs.size());
+            const lep_image_desc& d = c->host_desc[k];
+            size_t blocks = 0;
+            for (int cc = 0; cc < d.ncomp; ++cc) blocks += (size_t)d.width_blocks[cc] * d.height_blocks[cc];
+            for (int q = 0; q < ns; ++q) {
+                c->segs.push_back(sg[q]);
+                c->offs.push_back(c->offs.back() + ((blocks * 40 / ns + 65536 + 255) & ~(size_t)255));
+            }
+        }
+        c->seg_first.push_back((int)c->segs.size());
+        if (c->live.empty()) return 0;
+        if (int rc = slot_reserve(s, c->frame_bytes, c->offs.back() + 256, c->segs.size(), c->live.size(), verify)) return rc;
+        c->dev_desc = c->host_desc; c->scratch_desc = c->host_desc;
+        for (size_t k = 0; k < c->live.size(); ++k) {
+            size_t off = c->frame_off[k];
+            for (int cc = 0; cc < c->host_desc[k].ncomp; ++cc) {
+                c->dev_desc[k].blocks[cc] = (int16_t*)(s->d_frames + off);
+                if (verify) c->scratch_desc[k].blocks[cc] = (int16_t*)(s->d_scratch + off);
+                off += (size_t)c->host_desc[k].width_blocks[cc] * c->host_desc[k].height_blocks[cc] * 128;
+            }
+        }
+        HIPOK(hipMemcpyAsync(s->d_frames, s->h_frames, c->frame_bytes, hipMemcpyHostToDevice, s_copy));
+        HIPOK(hipEventRecord(s->up, s_copy));
+        st.h2d_bytes += (double)c->frame_bytes;
+        return 0;
+    };
+
+    std::thread writer;   // writes chunk k-1's containers while chunk k is on the GPU
+    size_t ci = 0;
+    int slot_i = 0;
+    const double t_pipe = now_s();
+    if (!chunks.empty()) { if (int rc = parse_and_upload(chunks[0].get(), &slots[0])) rc_all = rc; }
+    for (; !rc_all && ci < chunks.size(); ++ci, slot_i ^= 1) {
+        Slot* s = &slots[slot_i];
+        Chunk* c = chunks[ci].get();
+        const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
+        if (nimg) {
+            // kernels of this chunk
+            HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
+            int rc = lep_gpu_encode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
+            if (rc) { rc_all = rc; break; }
+            if (verify) {
+                HIPOK(hipMemsetAsync(s->d_scratch, 0, c->frame_bytes, s_compute));
+                HIPOK(hipMemsetAsync(s->d_flags, 0, (size_t)nimg * 4, s_compute));
+                rc = lep_gpu_decode_device(g, c->scratch_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status + nseg, s_compute);
+                if (rc) { rc_all = rc; break; }
+                for (int k = 0; k < nimg; ++k) {
+                    const size_t fb = frame_bytes_of(c->host_desc[k]);
+                    hipLaunchKernelGGL(lep_compare_kernel, dim3(256), dim3(256), 0, s_compute, (const uint4*)(s->d_frames + c->frame_off[k]),
+                                       (const uint4*)(s->d_scratch + c->frame_off[k]), fb / 16, s->d_flags + k, 1u);
+                }
+            }
+            HIPOK(hipEventRecord(s->done, s_compute));
+        }
+        // while they run: Huffman-decode the next chunk into the other slot (its previous user has been written out) and upload it
+        if (writer.joinable()) writer.join();
+        if (ci + 1 < chunks.size()) { if (int rc = parse_and_upload(chunks[ci + 1].get(), &slots[slot_i ^ 1])) { rc_all = rc; break; } }
+        // fetch this chunk's results
+        std::vector<uint32_t> lens(nseg);
+        std::vector<int32_t> sts((size_t)nseg * 2, 0);
+        std::vector<uint32_t> flags(nimg, 0);
+        if (nimg) {
+            HIPOK(hipStreamWaitEvent(s_down, s->done, 0));
+            HIPOK(hipMemcpyAsync(lens.data(), s->d_len, (size_t)nseg * 4, hipMemcpyDeviceToHost, s_down));
+            HIPOK(hipMemcpyAsync(sts.data(), s->d_status, (size_t)nseg * (verify ? 8 : 4), hipMemcpyDeviceToHost, s_down));
+            if (verify) HIPOK(hipMemcpyAsync(flags.data(), s->d_flags, (size_t)nimg * 4, hipMemcpyDeviceToHost, s_down));
+            HIPOK(hipStreamSynchronize(s_down));
+            for (int k = 0; k < nseg; ++k)
+                if (!sts[k] && lens[k]) {
+                    HIPOK(hipMemcpyAsync(s->h_streams + c->offs[k], s->d_streams + c->offs[k], lens[k], hipMemcpyDeviceToHost, s_down));
+                    st.d2h_bytes += lens[k];
+                }
+            HIPOK(hipStreamSynchronize(s_down));
+        }
+        // containers on the host pool, in the background
+        writer = std::thread([&, c, s, lens, sts, flags]() {
+            const double t0 = now_s();
+            parallel_for((int)c->live.size(), threads, [&](int k) {
+                const int i = c->live[k];
+                const int s0 = c->seg_first[k], s1 = c->seg_first[k + 1];
+                int rc = 0;
+                lep_bytes strs[LEP_MAX_SEGMENTS];
+                for (int q = s0; q < s1; ++q) {
+                    if (sts[q] && !rc) rc = sts[q];
+                    strs[q - s0].data = s->h_streams + c->offs[q];
+                    strs[q - s0].len = strs[q - s0].cap = lens[q];
+                }
+                if (!rc && verify) {
+                    for (int q = s0; q < s1; ++q) if (sts[c->segs.size() + (size_t)q]) rc = LEP_ROUNDTRIP_FAILURE;
+                    if (flags[k]) rc = LEP_ROUNDTRIP_FAILURE;
+                }
+                if (!rc) rc = lep_jpeg_write_lep(parsed[i], 0, strs, s1 - s0, &outs[i]);
+                status[i] = rc;
+                lep_jpeg_close(parsed[i]);
+                parsed[i] = nullptr;
+            });
+            st.write_s += now_s() - t0;
+        });
+    }
+    if (writer.joinable()) writer.join();
+    st.pipeline_s = now_s() - t_pipe;
+    for (int i = 0; i < n; ++i) if (parsed[i]) lep_jpeg_close(parsed[i]);
+    st.alloc_s = g_alloc_s;
+    (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_compute); (void)hipStreamDestroy(s_down);
+    st.wall_s = now_s() - t_begin;
+    if (stats) *stats = st;
+    return rc_all;
+}
+
+// ---- .lep -> JPEG, batch ---------------------------------------------------------------------------------------------
+int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* outs, int32_t* status, const lep_batch_options* o,
+                         lep_batch_stats* stats) {
+    if (!g || n < 0) return LEP_GPU_ERROR;
+    const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
+    const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
+    const size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
+    tune_malloc_for_pool();
+    const double t_begin = now_s();
+    lep_batch_stats st;
+    memset(&st, 0, sizeof st);
+    for (int i = 0; i < n; ++i) { outs[i].data = nullptr; outs[i].len = outs[i].cap = 0; status[i] = 0; }
+    std::vector<lep_file*> files(n, nullptr);
+    std::vector<size_t> fbytes(n, 0);
+    {
+        const double t0 = now_s();
+        parallel_for(n, threads, [&](int i) {
+            int rc = lep_file_open(leps[i].data, leps[i].len, &files[i]);
+            if (!rc) fbytes[i] = (lep_file_frame_bytes(files[i]) + 255) & ~(size_t)255;
+            if (rc) { status[i] = rc; if (files[i]) { lep_file_close(files[i]); files[i] = nullptr; } }
+        });
+        st.parse_s += now_s() - t0;
+    }
+    hipStream_t s_copy = nullptr, s_compute = nullptr, s_down = nullptr;
+    HIPOK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
+    HIPOK(hipStreamCreateWithFlags(&s_compute, hipStreamNonBlocking));
+    HIPOK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+    Slot* slots = g_slots;
+    g_alloc_s = 0;
+    int rc_all = 0;
+
+    auto cut_chunk = [&](int first) -> std::unique_ptr<Chunk> {
+        std::unique_ptr<Chunk> c(new Chunk);
+        c->first = first;
+        size_t bytes = 0;
+        int i = first;
+        for (; i < n; ++i) {
+            if (!files[i]) continue;
+            const size_t fb = fbytes[i];
+            if (!c->live.empty() && (bytes + fb > chunk_budget || c->live.size() >= chunk_images)) break;
+            c->live.push_back(i); c->frame_off.push_back(bytes);
+            bytes += fb;
+        }
+        c->count = i - first;
+        c->frame_bytes = bytes;
+        c->offs.push_back(0);
+        return c;
+    };
+    // streams into the slot's pinned arena (packed back to back), upload, frames zeroed on the device
+    std::vector<std::vector<uint32_t>> chunk_lens(2);
+    auto stage_and_upload = [&](Chunk* c, Slot* s, std::vector<uint32_t>* lens) -> int {
+        if (c->live.empty()) return 0;
+        c->segs.clear(); c->offs.assign(1, 0); c->seg_first.clear(); lens->clear();
+        std::vector<const uint8_t*> src;
+        for (size_t k = 0; k < c->live.size(); ++k) {
+            lep_segment sg[LEP_MAX_SEGMENTS];
+            lep_bytes sb[LEP_MAX_SEGMENTS];
+            const int ns = lep_file_segments(files[c->live[k]], sg, sb, (int)k);
+            c->seg_first.push_back((int)c->segs.size());
+            for (int q = 0; q < ns; ++q) {
+                c->segs.push_back(sg[q]);
+                lens->push_back((uint32_t)sb[q].len);
+                src.push_back(sb[q].data);
+                c->offs.push_back(c->offs.back() + sb[q].len);
+            }
+        }
+        c->seg_first.push_back((int)c->segs.size());
+        if (int rc = slot_reserve(s, c->frame_bytes, c->offs.back() + 256, c->segs.size(), c->live.size(), false)) return rc;
+        const double t0 = now_s();
+        parallel_for((int)c->segs.size(), threads, [&](int q) { if ((*lens)[q]) memcpy(s->h_streams + c->offs[q], src[q], (*lens)[q]); });
+        st.stage_s += now_s() - t0;
+        // the Huffman re-coder will read the frame where the D2H copy puts it: the slot's pinned buffer
+        c->host_desc.resize(c->live.size());
+        for (size_t k = 0; k < c->live.size(); ++k)
+            lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
+        c->dev_desc = c->host_desc;
+        for (size_t k = 0; k < c->live.size(); ++k) {
+            size_t off = c->frame_off[k];
+            for (int cc = 0; cc < c->host_desc[k].ncomp; ++cc) {
+                c->dev_desc[k].blocks[cc] = (int16_t*)(s->d_frames + off);
+                off += (size_t)c->host_desc[k].width_blocks[cc] * c->host_desc[k].height_blocks[cc] * 128;
+            }
+        }
+        HIPOK(hipMemcpyAsync(s->d_streams, s->h_streams, c->offs.back(), hipMemcpyHostToDevice, s_copy));
+        HIPOK(hipMemcpyAsync(s->d_len, lens->data(), lens->size() * 4, hipMemcpyHostToDevice, s_copy));
+        HIPOK(hipMemsetAsync(s->d_frames, 0, c->frame_bytes, s_copy));
+        HIPOK(hipEventRecord(s->up, s_copy));
+        HIPOK(hipStreamSynchronize(s_copy));   // `lens` / pinned arena are reused by the caller
+        st.h2d_bytes += (double)c->offs.back();
+        return 0;
+    };
+
+    std::thread writer;
+    std::unique_ptr<Chunk> cur = cut_chunk(0), nxt;
+    int slot_i = 0;
+    if (int rc = stage_and_upload(cur.get(), &slots[0], &chunk_lens[0])) rc_all = rc;
+    const double t_pipe = now_s();
+    while (!rc_all && cur && cur->count > 0) {
+        Slot* s = &slots[slot_i];
+        Chunk* c = cur.get();
+        const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
+        if (nimg) {
+            HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
+            int rc = lep_gpu_decode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
+            if (rc) { rc_all = rc; break; }
+            HIPOK(hipEventRecord(s->done, s_compute));
+        }
+        if (writer.joinable()) writer.join();
+        nxt = c->first + c->count < n ? cut_chunk(c->first + c->count) : nullptr;
+        if (nxt) { if (int rc = stage_and_upload(nxt.get(), &slots[slot_i ^ 1], &chunk_lens[slot_i ^ 1])) { rc_all = rc; break; } }
+        std::vector<int32_t> sts(nseg);
+        if (nimg) {
+            HIPOK(hipStreamWaitEvent(s_down, s->done, 0));
+            HIPOK(hipMemcpyAsync(sts.data(), s->d_status, (size_t)nseg * 4, hipMemcpyDeviceToHost, s_down));
+            HIPOK(hipMemcpyAsync(s->h_frames, s->d_frames, c->frame_bytes, hipMemcpyDeviceToHost, s_down));
+            HIPOK(hipStreamSynchronize(s_down));
+            st.d2h_bytes += (double)c->frame_bytes;
+        }
+        std::shared_ptr<Chunk> keep(cur.release());
+        writer = std::thread([&, keep, s, sts]() {
+            const double t0 = now_s();
+            parallel_for((int)keep->live.size(), threads, [&](int k) {
+                const int i = keep->live[k];
+                int rc = 0;
+                for (int q = keep->seg_first[k]; q < keep->seg_first[k + 1]; ++q) if (sts[q] && !rc) rc = sts[q];
+                if (!rc) rc = lep_file_recode(files[i], &outs[i]);   // reads the frame in place (pinned D2H buffer)
+                status[i] = rc;
+                lep_file_close(files[i]);
+                files[i] = nullptr;
+            });
+            st.write_s += now_s() - t0;
+        });
+        cur = std::move(nxt);
+        slot_i ^= 1;
+    }
+    if (writer.joinable()) writer.join();
+    st.pipeline_s = now_s() - t_pipe;
+    for (int i = 0; i < n; ++i) if (files[i]) lep_file_close(files[i]);
+    st.alloc_s = g_alloc_s;
+    (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_compute); (void)hipStreamDestroy(s_down);
+    st.wall_s = now_s() - t_begin;
+    if (stats) *stats = st;
+    return rc_all;
+}
+
+}  // extern "C"

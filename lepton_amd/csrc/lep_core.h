@@ -257,7 +257,7 @@ struct SegmentCoder {
             int32_t prior = 0;
             if (nbr) {
                 const int32_t* icos = horizontal ? img->icos_x[comp] + coord * 8 : img->icos_y[comp] + coord;
-                if (icos[0] == 0) return 39;
+                if (icos[0] == 0) return 43;
                 prior = lakhani(here, nbr, icos, coord, horizontal ? 8 : 1);
             }
             uint32_t aprior = prior < 0 ? 0u - (uint32_t)prior : (uint32_t)prior;

@@ -280,7 +280,7 @@ struct DecWave {
                 const int delta = horizontal ? 1 : 8, a_off = horizontal ? 50 : 57;
                 int coord = delta;
                 for (int j = 0; j < 7 && ne; ++j, coord += delta) {
-                    if (S.ebad[e * 7 + j]) { rc = 39; break; }
+                    if (S.ebad[e * 7 + j]) { rc = 43; break; }
                     const int32_t prior = S.eprior[e * 7 + j];
                     const uint32_t ap = prior < 0 ? 0u - (uint32_t)prior : (uint32_t)prior;
                     const int bsr = bitlen(ap > 1023 ? 1023 : ap);

@@ -382,7 +382,7 @@ struct Dec3Wave {
 #pragma nounroll
                     for (int j = 0; j < 7 && left; ++j) {
                         const uint32_t info = lepwave::wave_read(INFO, j * 4);
-                        if (info >> 31) { rc = 39; break; }
+                        if (info >> 31) { rc = 43; break; }
                         const int combo = j * 4 + (imin(ne, 7 - j) - left);
                         const int sslot = (int)(info & 255);
                         const uint32_t sgw = uni(S.sign[sslot]);

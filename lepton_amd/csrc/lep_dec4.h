@@ -550,7 +550,7 @@ struct Dec4Wave {
             for (int j = 0; j < 7 && left; ++j) {
                 const int base = e * 28 + combo_base(j);
                 const uint32_t info = lepwave::wave_read(INFO, base);
-                if (info >> 31) { rc = 39; break; }
+                if (info >> 31) { rc = 43; break; }
                 const int lane = base + left - 1;
                 int len = dec_unary4(lepwave::wave_read(PK0, lane));
                 ++nbins;

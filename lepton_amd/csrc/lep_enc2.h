@@ -196,7 +196,7 @@ struct EncWave {
                         const int16_t* nbr = horizontal ? S.above : S.left;
                         const int32_t* icos = horizontal ? S.icos_x + coord * 8 : S.icos_y + coord;
                         const int step = horizontal ? 8 : 1;
-                        if (icos[0] == 0) err = 39;
+                        if (icos[0] == 0) err = 43;
                         else {
                             uint32_t acc = (uint32_t)(int32_t)nbr[S.r2a[coord]] * (uint32_t)icos[0];
                             for (int i = 1; i < 8; ++i) {
@@ -271,10 +271,10 @@ struct EncWave {
         }
         const uint64_t badmask = lepwave::wave_ballot(bad);
         if (badmask) {   // report what the serial coder would have hit first (lane order = stream order)
-            LV(int, bad39);
-            LANES(l) L(bad39) = L(bad) == 39;
-            const uint64_t m39 = lepwave::wave_ballot(bad39);
-            return ((m39 >> __builtin_ctzll(badmask)) & 1) ? 39 : 6;
+            LV(int, bad43);
+            LANES(l) L(bad43) = L(bad) == 43;
+            const uint64_t m43 = lepwave::wave_ballot(bad43);
+            return ((m43 >> __builtin_ctzll(badmask)) & 1) ? 43 : 6;
         }
         const int N = lepwave::wave_excl_scan(cnt, off);
         const int D = lepwave::wave_excl_scan(ndup, doff);

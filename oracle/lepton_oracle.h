@@ -32,7 +32,7 @@ typedef struct lor_image {
 /* exit codes mirror src/vp8/util/memory.hh:13-40 */
 enum { LOR_OK = 0, LOR_ASSERTION_FAILURE = 1, LOR_CODING_ERROR = 2,
        LOR_COEFFICIENT_OUT_OF_RANGE = 6, LOR_STREAM_INCONSISTENT = 7,
-       LOR_UNSUPPORTED_ZERO_IDCT_0 = 39, LOR_BUFFER_TOO_SMALL = 100 };
+       LOR_UNSUPPORTED_ZERO_IDCT_0 = 43, LOR_BUFFER_TOO_SMALL = 100 };
 
 /* Encode one thread segment (rows with luma_y in [luma_y_start, luma_y_end); the last segment runs
  * to the end of the image) into one raw bool-coder stream, including the start marker bin, the 32

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""End-to-end batch pipeline (BASELINE.json configs[2]): JPEG files in host memory -> .lep files in host memory and back,
+through lep_compress_batch / lep_decompress_batch (host-pool Huffman, overlapped PCIe copies, GPU coder kernels).
+PCIe- and host-inclusive: this is NOT bench.py's `value` (which keeps frames resident in HBM); see DESIGN.md.
+usage: python scripts/bench_batch.py [--images 1024] [--unique 64] [--width 1920 --height 1080] [--verify] [--threads 0]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=1024)
+    ap.add_argument("--unique", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--chunk-mb", type=int, default=0)
+    ap.add_argument("--chunk-images", type=int, default=0)
+    ap.add_argument("--verify", action="store_true")
+    args = ap.parse_args()
+    import __graft_entry__ as ge
+    ge.build()
+    from lepton_amd import corpus
+    from lepton_amd.codec import GpuCodec
+
+    codec = GpuCodec(0)
+    nu = max(1, min(args.unique, args.images))
+    uniq = corpus.make_corpus(nu, args.width, args.height, 10000)
+    jpgs = [uniq[i % nu] for i in range(args.images)]
+    mb = sum(map(len, jpgs)) / 1e6
+    leps_w, _, _ = codec.compress_batch(jpgs[: min(len(jpgs), args.chunk_images or 1024)], verify=args.verify, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images)   # warm-up: kernel load, staging buffers
+    codec.decompress_batch(leps_w, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images)
+    t0 = time.perf_counter()
+    leps, st, cs = codec.compress_batch(jpgs, verify=args.verify, threads=args.threads, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images)
+    t1 = time.perf_counter()
+    assert not any(st), sorted(set(st))
+    back, st2, ds = codec.decompress_batch(leps, threads=args.threads, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images)
+    t2 = time.perf_counter()
+    assert not any(st2) and back == jpgs, "round trip is not bit exact"
+    out = {
+        "workload": "%d x %dx%d 4:2:0 baseline JPEGs (%d distinct), host memory -> host memory, %s" % (
+            args.images, args.width, args.height, nu, "with on-GPU round-trip verification" if args.verify else "no verification"),
+        "jpeg_MB": round(mb, 1), "lep_MB": round(sum(map(len, leps)) / 1e6, 1), "host_threads": args.threads or "cgroup quota",
+        "compress": {"MBps_pipeline": round(mb / cs["pipeline_s"], 1), "MBps_wall": round(mb / cs["wall_s"], 1), "python_wall_s": round(t1 - t0, 3),
+                     "h2d_GBps": round(cs["h2d_bytes"] / cs["pipeline_s"] / 1e9, 2), **{k: round(v, 3) for k, v in cs.items()}},
+        "decompress": {"MBps_pipeline": round(mb / ds["pipeline_s"], 1), "MBps_wall": round(mb / ds["wall_s"], 1), "python_wall_s": round(t2 - t1, 3),
+                       "d2h_GBps": round(ds["d2h_bytes"] / ds["pipeline_s"] / 1e9, 2), **{k: round(v, 3) for k, v in ds.items()}},
+        "roundtrip": "bit exact (%d files)" % args.images,
+    }
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

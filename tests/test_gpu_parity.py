@@ -96,7 +96,7 @@ def test_gpu_decode_of_garbage_stream_is_contained(gpu_codec):
     try:
         gpu_codec.decode([f])
     except LeptonError as e:
-        assert e.code in (6, 7, 39)
+        assert e.code in (6, 7, 43)
 
 
 def test_gpu_encoder_generations_agree(monkeypatch):
@@ -209,3 +209,32 @@ def test_gpu_older_decode_kernels_still_agree(kernel, monkeypatch):
             assert codec.decompress(lep) == jpg
     finally:
         codec.close()
+
+
+def test_gpu_batch_pipeline_equals_per_file_and_reference(gpu_codec):
+    """lep_compress_batch / lep_decompress_batch (host pool + overlapped copies + kernels) give exactly the per-file
+    results: reference-written .lep bytes for the golden fixtures, original JPEGs back; small chunks force several
+    pipeline iterations; a broken file and a progressive file only fail themselves"""
+    names = golden_cases()
+    jpgs = [golden(n)[0] for n in names]
+    leps = [golden(n)[1] for n in names]
+    extra = [corpus.synth_jpeg(512, 384, 41), b"not a jpeg at all", corpus.synth_jpeg(256, 256, 42, progressive=True)]
+    got, status, stats = gpu_codec.compress_batch(jpgs + extra, chunk_bytes=300000)
+    assert status[: len(names)] == [0] * len(names)
+    assert got[: len(names)] == leps
+    assert status[len(names)] == 0 and got[len(names)] == gpu_codec.compress(extra[0])
+    assert status[len(names) + 1] == 42 and got[len(names) + 1] is None      # UNSUPPORTED_JPEG, like the reference
+    assert status[len(names) + 2] == 8 and got[len(names) + 2] is None       # PROGRESSIVE_UNSUPPORTED (host re-coder: sequential only)
+    assert stats["h2d_bytes"] > 0 and stats["d2h_bytes"] > 0
+    back, status2, _ = gpu_codec.decompress_batch(leps + [got[len(names)], b"\xcf\x84garbage"], chunk_bytes=300000)
+    assert status2[: len(names) + 1] == [0] * (len(names) + 1)
+    assert back[: len(names)] == jpgs and back[len(names)] == extra[0]
+    assert status2[-1] != 0 and back[-1] is None
+
+
+def test_gpu_batch_pipeline_verifies_on_the_gpu(gpu_codec):
+    """verify=1: every file is decoded again on the GPU and compared with its input frame before its .lep is released"""
+    jpgs = [corpus.synth_jpeg(640, 480, 51), corpus.synth_jpeg(320, 200, 52, quality=75), golden("c420_odd_203x149")[0]]
+    got, status, _ = gpu_codec.compress_batch(jpgs, verify=True)
+    assert status == [0, 0, 0]
+    assert got == [gpu_codec.compress(j) for j in jpgs]
