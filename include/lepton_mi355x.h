@@ -96,6 +96,31 @@ int lep_gpu_decode_device(lep_gpu *g, const lep_image_desc *images, int nimg, co
 int lep_gpu_sync(lep_gpu *g);
 double lep_gpu_last_kernel_ms(lep_gpu *g);
 const char *lep_gpu_last_kernel_name(lep_gpu *g);   /* which kernel generation / register-budget variant that launch used */   /* HIP-event duration of the most recent encode/decode kernel */
+/* JPEG Huffman re-encode of decoded coefficient frames on the GPU (replaces recode_one_mcu_row / encode_block_seq,
+ * src/lepton/recoder.cc:316-412, 245-314, for whole, untruncated sequential scans): one wavefront per thread segment writes
+ * that segment's scan bytes (FF00-stuffed, RST markers included) to d_out + segs[i].out_off, at most segs[i].out_cap of
+ * them; d_out_len[i] receives the count.  images[].blocks are device pointers.  lep_file_recode_plan fills both structs. */
+typedef struct lep_huff_image {
+    int32_t ncomp, mcuh, mcuv, mcuc;
+    int32_t rsti, padbit;
+    uint32_t rst_limit;
+    int32_t interleaved;
+    int32_t hs[4], vs[4], bch[4];
+    int32_t dc_tbl[4], ac_tbl[4];
+    int32_t scan_cmp[4];
+    const int16_t *blocks[4];
+    uint32_t code[4][256];               /* [0..1] DC, [2..3] AC tables: code length << 16 | code */
+} lep_huff_image;
+typedef struct lep_huff_segment {
+    int32_t image, mcu_row0, mcu_row1;
+    uint32_t overhang;                   /* overhang_byte | num_overhang_bits << 8 (ThreadHandoff) */
+    int16_t last_dc[4];
+    uint64_t out_off;
+    uint32_t out_cap;
+    uint32_t pad;
+} lep_huff_segment;
+int lep_gpu_huffman_encode_device(lep_gpu *g, const lep_huff_image *images, int nimg, const lep_huff_segment *segs, int nseg,
+                                  uint8_t *d_out, uint32_t *d_out_len, void *hip_stream);
 /* plain device memory helpers so non-torch callers need no HIP binding */
 /* Device self-test of kernel arithmetic that has no CPU twin (exhaustive: the float-reciprocal Branch probability of the
  * v3 kernels against integer division, src/vp8/model/branch.hh:82-125).  0 = exact everywhere. */
@@ -138,6 +163,11 @@ uint32_t lep_file_jpeg_size(const lep_file *f);
 size_t lep_file_frame_bytes(const lep_file *f);   /* bytes of the coefficient frame lep_file_describe will expose */
 /* coefficient frame -> original JPEG bytes (recode_baseline_jpeg, src/lepton/recoder.cc:694-889) */
 int lep_file_recode(lep_file *f, lep_bytes *out);
+/* The same with the Huffman coding done by lep_gpu_huffman_encode_device: _plan walks the header and, if the file is
+ * eligible (*gpu_ok = 1), fills the image / per-segment parameters (blocks[], image index and out_off are the caller's to
+ * set; out_cap is the segment's byte bound); _finish glues header, the segments' scan bytes and the trailer together. */
+int lep_file_recode_plan(lep_file *f, lep_huff_image *image, lep_huff_segment *segs, int *nseg, int *gpu_ok);
+int lep_file_recode_finish(lep_file *f, const lep_bytes *seg_bytes, int nseg, lep_bytes *out);
 
 
 /* .lep framing pieces, exposed for callers that assemble containers themselves */
@@ -171,6 +201,7 @@ typedef struct lep_batch_options {
     int32_t host_threads;        /* 0 = the CPUs this process may use (affinity mask capped by the cgroup CPU quota) */
     int32_t verify;              /* compress: on-GPU round-trip verification */
     size_t chunk_frame_bytes;    /* cap on coefficient-frame bytes per pipeline chunk; 0 = 24 GiB */
+    int32_t host_huffman;        /* decompress: 1 = JPEG Huffman re-encode on the host pool (frames cross PCIe) instead of on the GPU */
     int32_t chunk_images;        /* images per pipeline chunk; 0 = 1024 (x 8 thread segments = one wavefront per SIMD slot of the
                                     chip: a coder kernel takes as long for 100 segments as for 8192, so chunks must be this big) */
 } lep_batch_options;

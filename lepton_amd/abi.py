@@ -50,8 +50,20 @@ class Bytes(C.Structure):
         return C.string_at(self.data, self.len) if self.len else b""
 
 
+class HuffImage(C.Structure):
+    _fields_ = [("ncomp", C.c_int32), ("mcuh", C.c_int32), ("mcuv", C.c_int32), ("mcuc", C.c_int32), ("rsti", C.c_int32), ("padbit", C.c_int32),
+                ("rst_limit", C.c_uint32), ("interleaved", C.c_int32), ("hs", C.c_int32 * 4), ("vs", C.c_int32 * 4), ("bch", C.c_int32 * 4),
+                ("dc_tbl", C.c_int32 * 4), ("ac_tbl", C.c_int32 * 4), ("scan_cmp", C.c_int32 * 4), ("blocks", C.c_void_p * 4),
+                ("code", (C.c_uint32 * 256) * 4)]
+
+
+class HuffSegment(C.Structure):
+    _fields_ = [("image", C.c_int32), ("mcu_row0", C.c_int32), ("mcu_row1", C.c_int32), ("overhang", C.c_uint32), ("last_dc", C.c_int16 * 4),
+                ("out_off", C.c_uint64), ("out_cap", C.c_uint32), ("pad", C.c_uint32)]
+
+
 class BatchOptions(C.Structure):
-    _fields_ = [("host_threads", C.c_int32), ("verify", C.c_int32), ("chunk_frame_bytes", C.c_size_t), ("chunk_images", C.c_int32)]
+    _fields_ = [("host_threads", C.c_int32), ("verify", C.c_int32), ("chunk_frame_bytes", C.c_size_t), ("host_huffman", C.c_int32), ("chunk_images", C.c_int32)]
 
 
 class BatchStats(C.Structure):
@@ -118,6 +130,9 @@ def lib():
         L.lep_jpeg_is_progressive.argtypes = [vp]
         L.lep_compress_batch.argtypes = [vp, P(Bytes), C.c_int, P(Bytes), P(C.c_int32), P(BatchOptions), P(BatchStats)]
         L.lep_decompress_batch.argtypes = [vp, P(Bytes), C.c_int, P(Bytes), P(C.c_int32), P(BatchOptions), P(BatchStats)]
+        L.lep_file_recode_plan.argtypes = [vp, P(HuffImage), P(HuffSegment), P(C.c_int), P(C.c_int)]
+        L.lep_file_recode_finish.argtypes = [vp, P(Bytes), C.c_int, P(Bytes)]
+        L.lep_gpu_huffman_encode_device.argtypes = [vp, P(HuffImage), C.c_int, P(HuffSegment), C.c_int, vp, vp, vp]
         L.lep_batch_release.argtypes = []
         L.lep_batch_release.restype = None
         L.lep_handoffs_serialize.argtypes = [P(Handoff), C.c_int, vp, C.c_size_t]
@@ -135,5 +150,5 @@ EXPORTS = [
     "lep_gpu_free", "lep_gpu_memcpy_h2d", "lep_gpu_memcpy_d2h", "lep_gpu_memcpy_d2d", "lep_gpu_memset", "lep_jpeg_open", "lep_jpeg_close",
     "lep_jpeg_describe", "lep_jpeg_plan", "lep_jpeg_write_lep", "lep_file_open", "lep_file_close", "lep_file_describe",
     "lep_file_segments", "lep_file_jpeg_size", "lep_file_recode", "lep_compress", "lep_decompress", "lep_free",
-    "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
+    "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_file_recode_plan", "lep_file_recode_finish", "lep_gpu_huffman_encode_device", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
 ]

@@ -186,7 +186,7 @@ class GpuCodec:
         self._L.lep_free(out.data)
         return data
 
-    def _batch(self, fn, blobs, verify, threads, chunk_bytes, chunk_images=0):
+    def _batch(self, fn, blobs, verify, threads, chunk_bytes, chunk_images=0, host_huffman=False):
         n = len(blobs)
         ins = (abi.Bytes * n)()
         keep = []
@@ -197,7 +197,7 @@ class GpuCodec:
             ins[i].len = ins[i].cap = len(b)
         outs = (abi.Bytes * n)()
         status = (C.c_int32 * n)()
-        opt = abi.BatchOptions(threads, 1 if verify else 0, chunk_bytes, chunk_images)
+        opt = abi.BatchOptions(threads, 1 if verify else 0, chunk_bytes, 1 if host_huffman else 0, chunk_images)
         stats = abi.BatchStats()
         rc = fn(self.handle, ins, n, outs, status, C.byref(opt), C.byref(stats))
         if rc:
@@ -213,9 +213,10 @@ class GpuCodec:
         """[jpeg bytes] -> ([.lep bytes or None], [exit code per file], pipeline statistics)"""
         return self._batch(self._L.lep_compress_batch, jpgs, verify, threads, chunk_bytes, chunk_images)
 
-    def decompress_batch(self, leps, threads=0, chunk_bytes=0, chunk_images=0):
-        """[.lep bytes] -> ([jpeg bytes or None], [exit code per file], pipeline statistics)"""
-        return self._batch(self._L.lep_decompress_batch, leps, False, threads, chunk_bytes, chunk_images)
+    def decompress_batch(self, leps, threads=0, chunk_bytes=0, chunk_images=0, host_huffman=False):
+        """[.lep bytes] -> ([jpeg bytes or None], [exit code per file], pipeline statistics); the JPEG Huffman re-encode runs
+        on the GPU for eligible files unless host_huffman is set"""
+        return self._batch(self._L.lep_decompress_batch, leps, False, threads, chunk_bytes, chunk_images, host_huffman)
 
     def close(self):
         if self.handle:

@@ -111,6 +111,120 @@ struct RowCoder {
 
 }  // namespace
 
+// ---- split form of recode_jpeg: everything except the Huffman coding of the segments ---------------------------------------
+// recode_prepare: header walk (DHT / DRI / SOS), the bytes in front of the scan, and -- when the file is eligible -- the
+// parameters the GPU Huffman encoder (lep_huff.h) needs per image and per thread segment.
+int recode_prepare(LepFile* lf, RecodePlan* plan) {
+    JpegFile& jf = lf->jpeg;
+    if (lf->flag != 'Z') return EX_PROGRESSIVE_UNSUPPORTED;   // progressive re-coding: jpeg_progressive.cc
+    const size_t max_file_size = lf->jpeg_size;
+    if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
+    plan->scan_bound = max_file_size - jf.garbage.size();
+    size_t pos = 0;
+    const uint8_t* h = jf.hdr.data();
+    const size_t hdrs = jf.hdr.size();
+    for (;;) {
+        if (pos + 3 >= hdrs) return EX_CODING_ERROR;
+        if (h[pos] != 0xff) return EX_CODING_ERROR;
+        uint8_t type = h[pos + 1];
+        unsigned len = 2 + ((unsigned)h[pos + 2] << 8) + h[pos + 3];
+        if (type == 0xC4 || type == 0xDD || type == 0xDA)
+            if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - pos), h + pos, false)) return EX_CODING_ERROR;
+        pos += len;
+        if (type == 0xDA) break;
+    }
+    plan->hdr_pos = pos;
+    plan->head.clear();
+    if (lf->has_prefix) plan->head.insert(plan->head.end(), lf->prefix_garbage.begin(), lf->prefix_garbage.end());
+    if (lf->embedded || !lf->has_prefix) {
+        plan->head.push_back(0xFF); plan->head.push_back(0xD8);
+        plan->head.insert(plan->head.end(), h, h + std::min(pos, hdrs));
+    }
+    if (plan->head.size() > plan->scan_bound) plan->head.resize(plan->scan_bound);
+
+    // eligibility for the GPU encoder: whole, untruncated frames; modern hand-offs; an MCU-interleaved scan of all
+    // components or a plain single-component scan.  Everything else takes the host path (recode_jpeg).
+    plan->gpu_ok = false;
+    plan->segs.clear();
+    bool ok = !jf.early_eof && jf.ncomp >= 1 && jf.ncomp <= 3 && jf.cs_cmpc == jf.ncomp && jf.mcuh > 0 && jf.mcuv > 0 &&
+              jf.trunc_bcv[0] >= jf.comp[0].bcv && !lf->segs.empty();
+    for (const Handoff& th : lf->segs) if (th.num_overhang_bits == 0xff || th.num_overhang_bits > 7) ok = false;
+    if (ok && jf.ncomp == 1) {
+        const Component& k = jf.comp[jf.cs_cmp[0]];
+        ok = k.hs == 1 && k.vs == 1 && k.bch == k.nch && k.bcv == k.ncv && k.bc == jf.mcuc;
+    }
+    for (int c = 0; ok && c < jf.ncomp; ++c) {
+        const Component& k = jf.comp[c];
+        if (!jf.htab[0][k.dc_tbl].set || !jf.htab[1][k.ac_tbl].set || k.dc_tbl > 1 || k.ac_tbl > 1) ok = false;
+        if (jf.ncomp > 1 && (k.bch != jf.mcuh * k.hs || k.bcv != jf.mcuv * k.vs)) ok = false;
+    }
+    if (!ok) return 0;
+    RecodeImage& im = plan->image;
+    memset(&im, 0, sizeof im);
+    im.ncomp = jf.ncomp; im.mcuh = jf.mcuh; im.mcuv = jf.mcuv; im.mcuc = jf.mcuc; im.rsti = jf.rsti; im.padbit = jf.padbit;
+    im.rst_limit = (jf.rst_cnt.empty() || !lf->rst_cnt_set) ? 0xffffffffu : jf.rst_cnt[0];
+    im.interleaved = jf.ncomp > 1 ? 1 : 0;
+    for (int c = 0; c < jf.ncomp; ++c) {
+        im.hs[c] = jf.comp[c].hs; im.vs[c] = jf.comp[c].vs; im.bch[c] = jf.comp[c].bch;
+        im.dc_tbl[c] = jf.comp[c].dc_tbl; im.ac_tbl[c] = jf.comp[c].ac_tbl;
+        im.scan_cmp[c] = jf.cs_cmp[c];
+    }
+    for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < 256; ++i) {
+            im.code[t][i] = jf.htab[0][t].set ? ((uint32_t)jf.htab[0][t].clen[i] << 16) | jf.htab[0][t].cval[i] : 0u;
+            im.code[2 + t][i] = jf.htab[1][t].set ? ((uint32_t)jf.htab[1][t].clen[i] << 16) | jf.htab[1][t].cval[i] : 0u;
+        }
+    const int luma_mul = jf.comp[0].bcv / jf.mcuv;
+    for (size_t s = 0; s < lf->segs.size(); ++s) {
+        const Handoff& th = lf->segs[s];
+        RecodeSegment g;
+        memset(&g, 0, sizeof g);
+        int r0 = jf.mcuv, r1 = 0;
+        for (int row = 0; row < jf.mcuv; ++row) {
+            const int y0 = row * luma_mul, y1 = y0 + luma_mul;
+            if (y0 >= jf.trunc_bcv[0]) break;
+            if (y0 < th.luma_y_start) continue;
+            if (y1 > th.luma_y_end) break;
+            r0 = std::min(r0, row); r1 = row + 1;
+        }
+        if (r1 <= r0) { r0 = r1 = 0; }
+        g.mcu_row0 = r0; g.mcu_row1 = r1;
+        g.overhang = (uint32_t)th.overhang_byte | ((uint32_t)th.num_overhang_bits << 8);
+        memcpy(g.last_dc, th.last_dc, sizeof g.last_dc);
+        const size_t room = plan->scan_bound - plan->head.size();
+        size_t cap = s == 0 ? room : (th.segment_size ? (size_t)th.segment_size : max_file_size);
+        // natural upper bound of a segment's bytes: 2 bytes per coefficient bit-wise worst case is far above real data;
+        // the arena slot is sized by the caller from this cap
+        g.out_cap = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
+        plan->segs.push_back(g);
+    }
+    plan->gpu_ok = true;
+    return 0;
+}
+
+// recode_finish: glue head + per-segment scan bytes + misplaced RST markers + the rest of the header + garbage together
+int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& seg_bytes,
+                  std::vector<uint8_t>* result) {
+    JpegFile& jf = lf->jpeg;
+    const size_t max_file_size = lf->jpeg_size;
+    BoundedOut out;
+    out.bound = plan.scan_bound;
+    out.buf.reserve(max_file_size + 16);
+    out.write(plan.head.data(), plan.head.size());
+    for (const auto& sb : seg_bytes) out.write(sb.first, sb.second);
+    if (!jf.rst_err.empty()) {
+        unsigned cum = jf.rsti ? (unsigned)((jf.mcuh * jf.mcuv - 1) / jf.rsti) : 0;
+        for (unsigned i = 0; i < jf.rst_err[0]; ++i) { out.put(0xFF); out.put((uint8_t)(0xD0 + ((cum + i) & 7))); }
+    }
+    const uint8_t* h = jf.hdr.data();
+    const size_t hdrs = jf.hdr.size();
+    if (!out.reached() && plan.hdr_pos < hdrs) out.write(h + plan.hdr_pos, hdrs - plan.hdr_pos);
+    out.bound = max_file_size;
+    out.write(jf.garbage.data(), jf.garbage.size());
+    result->swap(out.buf);
+    return 0;
+}
+
 int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
     JpegFile& jf = lf->jpeg;
     if (lf->flag != 'Z') return EX_PROGRESSIVE_UNSUPPORTED;   // progressive re-coding: jpeg_progressive.cc

@@ -17,7 +17,10 @@ struct lep_jpeg {
 struct lep_file {
     lep::LepFile lf;
     bool frame_ready = false;
+    lep::RecodePlan plan;
+    bool planned = false;
 };
+static_assert(sizeof(lep_huff_image) == sizeof(lep::RecodeImage) && sizeof(lep_huff_segment) == sizeof(lep::RecodeSegment), "C ABI mirrors");
 
 static void fill_desc(const lep::JpegFile& jf, lep_image_desc* d, int16_t* const* planes) {
     memset(d, 0, sizeof *d);
@@ -191,6 +194,31 @@ int lep_file_segments(const lep_file* f, lep_segment* segs, lep_bytes* streams, 
 int lep_file_recode(lep_file* f, lep_bytes* out) {
     std::vector<uint8_t> jpg;
     int rc = lep::recode_jpeg(&f->lf, &jpg);
+    if (rc) return rc;
+    return to_bytes(jpg, out);
+}
+
+int lep_file_recode_plan(lep_file* f, lep_huff_image* image, lep_huff_segment* segs, int* nseg, int* gpu_ok) {
+    int rc = lep::recode_prepare(&f->lf, &f->plan);
+    if (rc) return rc;
+    f->planned = true;
+    *gpu_ok = f->plan.gpu_ok ? 1 : 0;
+    *nseg = 0;
+    if (f->plan.gpu_ok) {
+        memcpy(image, &f->plan.image, sizeof *image);
+        for (int c = 0; c < f->lf.jpeg.ncomp; ++c) image->blocks[c] = f->lf.jpeg.plane[c];
+        *nseg = (int)f->plan.segs.size();
+        memcpy(segs, f->plan.segs.data(), sizeof(lep_huff_segment) * f->plan.segs.size());
+    }
+    return 0;
+}
+
+int lep_file_recode_finish(lep_file* f, const lep_bytes* seg_bytes, int nseg, lep_bytes* out) {
+    if (!f->planned) return LEP_ASSERTION_FAILURE;
+    std::vector<std::pair<const uint8_t*, size_t>> sb;
+    for (int i = 0; i < nseg; ++i) sb.emplace_back(seg_bytes[i].data, seg_bytes[i].len);
+    std::vector<uint8_t> jpg;
+    int rc = lep::recode_finish(&f->lf, f->plan, sb, &jpg);
     if (rc) return rc;
     return to_bytes(jpg, out);
 }

@@ -89,11 +89,14 @@ struct Slot {   // one chunk's buffers (double-buffered)
     char* h_frames = nullptr; char* d_frames = nullptr; char* d_scratch = nullptr; size_t frames_cap = 0;
     uint8_t* d_streams = nullptr; uint8_t* h_streams = nullptr; size_t streams_cap = 0;
     uint32_t* d_len = nullptr; int32_t* d_status = nullptr; uint32_t* d_flags = nullptr; size_t seg_cap = 0, img_cap = 0;
+    uint8_t* d_scan = nullptr; uint8_t* h_scan = nullptr; size_t scan_cap = 0;   // JPEG scan bytes of the GPU Huffman encoder
+    uint32_t* d_scanlen = nullptr; size_t scanlen_cap = 0;
     hipEvent_t up = nullptr, done = nullptr;
     void release() {
         if (h_frames) (void)hipHostFree(h_frames);
         if (h_streams) (void)hipHostFree(h_streams);
-        for (void* p : {(void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags})
+        if (h_scan) (void)hipHostFree(h_scan);
+        for (void* p : {(void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags, (void*)d_scan, (void*)d_scanlen})
             if (p) (void)hipFree(p);
         if (up) (void)hipEventDestroy(up);
         if (done) (void)hipEventDestroy(done);
@@ -147,6 +150,25 @@ int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_
     return 0;
 }
 
+int scan_reserve(Slot* s, size_t bytes, size_t nseg) {
+    const double t0 = now_s();
+    if (bytes > s->scan_cap) {
+        if (s->h_scan) (void)hipHostFree(s->h_scan);
+        if (s->d_scan) (void)hipFree(s->d_scan);
+        s->h_scan = s->d_scan = nullptr; s->scan_cap = 0;
+        HIPOK(hipHostMalloc((void**)&s->h_scan, bytes, hipHostMallocDefault));
+        HIPOK(hipMalloc((void**)&s->d_scan, bytes));
+        s->scan_cap = bytes;
+    }
+    if (nseg > s->scanlen_cap) {
+        if (s->d_scanlen) (void)hipFree(s->d_scanlen);
+        HIPOK(hipMalloc((void**)&s->d_scanlen, nseg * 4));
+        s->scanlen_cap = nseg;
+    }
+    g_alloc_s += now_s() - t0;
+    return 0;
+}
+
 struct Chunk {
     int first = 0, count = 0;
     std::vector<int> live;                 // indices (into the batch) of the images that go to the GPU
@@ -156,6 +178,13 @@ struct Chunk {
     std::vector<uint64_t> offs;            // stream arena offsets (nseg + 1)
     std::vector<int> seg_first;            // per live image: first segment index
     size_t frame_bytes = 0;
+    // decompression: GPU Huffman re-encode plan
+    std::vector<lep_huff_image> himg;      // eligible images only
+    std::vector<lep_huff_segment> hseg;
+    std::vector<int> hfirst;               // per live image: first entry of hseg, -1 = host re-coder
+    std::vector<uint32_t> hslot;           // per hseg: bytes reserved in the scan arena
+    std::vector<uint32_t> hbound;          // per hseg: the segment's real byte bound (larger than the slot for segment 0)
+    size_t scan_bytes = 0;
 };
 
 Slot g_slots[2];         // one batch call at a time (the calls are not re-entrant)
@@ -374,6 +403,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
     const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
     const size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
+    const bool gpu_huffman = !(o && o->host_huffman);
     tune_malloc_for_pool();
     const double t_begin = now_s();
     lep_batch_stats st;
@@ -450,6 +480,36 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                 off += (size_t)c->host_desc[k].width_blocks[cc] * c->host_desc[k].height_blocks[cc] * 128;
             }
         }
+        // GPU Huffman re-encode plan: eligible files get their scan bytes back instead of their frames
+        c->himg.clear(); c->hseg.clear(); c->hfirst.assign(c->live.size(), -1); c->hslot.clear(); c->hbound.clear(); c->scan_bytes = 0;
+        if (gpu_huffman) {
+            for (size_t k = 0; k < c->live.size(); ++k) {
+                lep_huff_image hi;
+                lep_huff_segment hs[LEP_MAX_SEGMENTS];
+                int ns = 0, ok = 0;
+                if (lep_file_recode_plan(files[c->live[k]], &hi, hs, &ns, &ok) || !ok) continue;
+                for (int cc = 0; cc < 4; ++cc) hi.blocks[cc] = cc < c->dev_desc[k].ncomp ? c->dev_desc[k].blocks[cc] : nullptr;
+                c->hfirst[k] = (int)c->hseg.size();
+                size_t later = 0;
+                for (int q = 1; q < ns; ++q) later += hs[q].out_cap;
+                for (int q = 0; q < ns; ++q) {
+                    size_t slot = hs[q].out_cap;
+                    if (q == 0) {   // segment 0 is only bounded by the file: give it what the others leave, plus slack
+                        const size_t room = hs[0].out_cap;
+                        slot = std::min(room, (room > later ? room - later : 0) + 8192);
+                    }
+                    c->hbound.push_back(hs[q].out_cap);
+                    hs[q].image = (int32_t)c->himg.size();
+                    hs[q].out_off = c->scan_bytes;
+                    hs[q].out_cap = (uint32_t)slot;
+                    c->hslot.push_back((uint32_t)slot);
+                    c->scan_bytes += (slot + 15) & ~(size_t)15;
+                    c->hseg.push_back(hs[q]);
+                }
+                c->himg.push_back(hi);
+            }
+            if (!c->hseg.empty()) { if (int rc = scan_reserve(s, c->scan_bytes + 256, c->hseg.size())) return rc; }
+        }
         HIPOK(hipMemcpyAsync(s->d_streams, s->h_streams, c->offs.back(), hipMemcpyHostToDevice, s_copy));
         HIPOK(hipMemcpyAsync(s->d_len, lens->data(), lens->size() * 4, hipMemcpyHostToDevice, s_copy));
         HIPOK(hipMemsetAsync(s->d_frames, 0, c->frame_bytes, s_copy));
@@ -472,27 +532,52 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
             HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
             int rc = lep_gpu_decode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
             if (rc) { rc_all = rc; break; }
+            if (!c->hseg.empty()) {
+                rc = lep_gpu_huffman_encode_device(g, c->himg.data(), (int)c->himg.size(), c->hseg.data(), (int)c->hseg.size(), s->d_scan, s->d_scanlen, s_compute);
+                if (rc) { rc_all = rc; break; }
+            }
             HIPOK(hipEventRecord(s->done, s_compute));
         }
         if (writer.joinable()) writer.join();
         nxt = c->first + c->count < n ? cut_chunk(c->first + c->count) : nullptr;
         if (nxt) { if (int rc = stage_and_upload(nxt.get(), &slots[slot_i ^ 1], &chunk_lens[slot_i ^ 1])) { rc_all = rc; break; } }
         std::vector<int32_t> sts(nseg);
+        std::vector<uint32_t> slens(c->hseg.size());
         if (nimg) {
             HIPOK(hipStreamWaitEvent(s_down, s->done, 0));
             HIPOK(hipMemcpyAsync(sts.data(), s->d_status, (size_t)nseg * 4, hipMemcpyDeviceToHost, s_down));
-            HIPOK(hipMemcpyAsync(s->h_frames, s->d_frames, c->frame_bytes, hipMemcpyDeviceToHost, s_down));
+            if (!c->hseg.empty()) HIPOK(hipMemcpyAsync(slens.data(), s->d_scanlen, c->hseg.size() * 4, hipMemcpyDeviceToHost, s_down));
             HIPOK(hipStreamSynchronize(s_down));
-            st.d2h_bytes += (double)c->frame_bytes;
+            for (int k = 0; k < nimg; ++k) {
+                bool on_gpu = c->hfirst[k] >= 0;
+                if (on_gpu) {   // a segment that filled its reserved slot may have been cut short: let the host redo that file
+                    const int h0 = c->hfirst[k], h1 = h0 + (c->seg_first[k + 1] - c->seg_first[k]);
+                    for (int q = h0; q < h1; ++q) if (slens[q] >= c->hslot[q] && c->hslot[q] < c->hbound[q]) on_gpu = false;
+                    if (!on_gpu) c->hfirst[k] = -1;
+                    else for (int q = h0; q < h1; ++q)
+                        if (slens[q]) { HIPOK(hipMemcpyAsync(s->h_scan + c->hseg[q].out_off, s->d_scan + c->hseg[q].out_off, slens[q], hipMemcpyDeviceToHost, s_down)); st.d2h_bytes += slens[q]; }
+                }
+                if (!on_gpu) {
+                    const size_t fb = (k + 1 < nimg ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
+                    HIPOK(hipMemcpyAsync(s->h_frames + c->frame_off[k], s->d_frames + c->frame_off[k], fb, hipMemcpyDeviceToHost, s_down));
+                    st.d2h_bytes += (double)fb;
+                }
+            }
+            HIPOK(hipStreamSynchronize(s_down));
         }
         std::shared_ptr<Chunk> keep(cur.release());
-        writer = std::thread([&, keep, s, sts]() {
+        writer = std::thread([&, keep, s, sts, slens]() {
             const double t0 = now_s();
             parallel_for((int)keep->live.size(), threads, [&](int k) {
                 const int i = keep->live[k];
                 int rc = 0;
                 for (int q = keep->seg_first[k]; q < keep->seg_first[k + 1]; ++q) if (sts[q] && !rc) rc = sts[q];
-                if (!rc) rc = lep_file_recode(files[i], &outs[i]);   // reads the frame in place (pinned D2H buffer)
+                if (!rc && keep->hfirst[k] >= 0) {   // GPU-coded scan bytes: glue header, segments, trailer
+                    const int h0 = keep->hfirst[k], ns = keep->seg_first[k + 1] - keep->seg_first[k];
+                    lep_bytes sb[LEP_MAX_SEGMENTS];
+                    for (int q = 0; q < ns; ++q) { sb[q].data = s->h_scan + keep->hseg[h0 + q].out_off; sb[q].len = sb[q].cap = slens[h0 + q]; }
+                    rc = lep_file_recode_finish(files[i], sb, ns, &outs[i]);
+                } else if (!rc) rc = lep_file_recode(files[i], &outs[i]);   // host re-coder reads the frame in place (pinned D2H buffer)
                 status[i] = rc;
                 lep_file_close(files[i]);
                 files[i] = nullptr;

@@ -39,4 +39,37 @@ void demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vecto
 // decode side (jpeg_recode.cc): coefficients -> JPEG bytes
 int recode_jpeg(LepFile* lf, std::vector<uint8_t>* out);
 
+// The same in three steps, with the Huffman coding of the segments done elsewhere (the GPU encoder, lep_huff.h).
+// RecodeImage / RecodeSegment are laid out exactly like lephuff::HuffImage / HuffSegment and lep_huff_image / lep_huff_segment.
+struct RecodeImage {
+    int32_t ncomp, mcuh, mcuv, mcuc;
+    int32_t rsti, padbit;
+    uint32_t rst_limit;
+    int32_t interleaved;
+    int32_t hs[4], vs[4], bch[4];
+    int32_t dc_tbl[4], ac_tbl[4];
+    int32_t scan_cmp[4];
+    const int16_t* blocks[4];
+    uint32_t code[4][256];
+};
+struct RecodeSegment {
+    int32_t image, mcu_row0, mcu_row1;
+    uint32_t overhang;
+    int16_t last_dc[4];
+    uint64_t out_off;
+    uint32_t out_cap;
+    uint32_t pad;
+};
+struct RecodePlan {
+    std::vector<uint8_t> head;      // everything in front of the scan (prefix garbage, SOI, header up to the first SOS)
+    size_t hdr_pos = 0;             // header bytes consumed by `head`
+    size_t scan_bound = 0;          // bytes the file may hold before the trailing garbage
+    bool gpu_ok = false;            // eligible for the GPU Huffman encoder; image / segs are filled
+    RecodeImage image;
+    std::vector<RecodeSegment> segs;
+};
+int recode_prepare(LepFile* lf, RecodePlan* plan);
+int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& seg_bytes,
+                  std::vector<uint8_t>* out);
+
 }  // namespace lep

@@ -20,6 +20,7 @@
 #include "lep_dec3.h"
 #include "lep_enc3.h"
 #include "lep_dec4.h"
+#include "lep_huff.h"
 
 using namespace lepdev;
 
@@ -215,6 +216,18 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
     bins[s] = w.nbins;
 }
 
+// JPEG Huffman re-encode of decoded frames: one wavefront per thread segment (lep_huff.h)
+__global__ __launch_bounds__(64, 8) void lep_huffman_encode_kernel(const lephuff::HuffImage* __restrict__ images,
+                                                                   const lephuff::HuffSegment* __restrict__ segs, uint8_t* out,
+                                                                   uint32_t* out_len) {
+    __shared__ lephuff::HuffShared sh;
+    const int s = blockIdx.x;
+    const lephuff::HuffSegment seg = segs[s];
+    lephuff::HuffWave w;
+    const uint32_t n = w.run(images + seg.image, seg, &sh, out);
+    if (threadIdx.x == 0) out_len[s] = n;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -238,6 +251,9 @@ struct lep_gpu {
     void* d_blocks = nullptr; size_t blocks_bytes = 0;
     void* d_streams = nullptr; size_t streams_bytes = 0;
     void* d_lens = nullptr; size_t lens_bytes = 0;
+    void* d_huff = nullptr; size_t huff_bytes = 0;      // HuffImage[] | HuffSegment[]
+    void* d_scan = nullptr; size_t scan_bytes = 0;      // scan bytes of the Huffman encoder (host variant)
+    void* d_scanlen = nullptr; size_t scanlen_bytes = 0;
 };
 
 #define HIPCHK(g, call)                                                                        \
@@ -379,7 +395,7 @@ void lep_gpu_destroy(lep_gpu* g) {
     if (!g) return;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    for (void* p : {g->d_models, g->d_ns, g->d_meta, g->d_blocks, g->d_streams, g->d_lens})
+    for (void* p : {g->d_models, g->d_ns, g->d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_scan, g->d_scanlen})
         if (p) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -401,6 +417,29 @@ int lep_gpu_decode_device(lep_gpu* g, const lep_image_desc* images, int nimg, co
                           int32_t* d_status, void* hip_stream) {
     return launch<true>(g, images, nimg, segs, nseg, const_cast<uint8_t*>(d_streams), stream_offsets,
                         const_cast<uint32_t*>(d_stream_len), d_status, hip_stream ? (hipStream_t)hip_stream : g->stream);
+}
+
+static_assert(sizeof(lep_huff_image) == sizeof(lephuff::HuffImage) && sizeof(lep_huff_segment) == sizeof(lephuff::HuffSegment), "C ABI mirrors");
+
+int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int nimg, const lep_huff_segment* segs, int nseg,
+                                  uint8_t* d_out, uint32_t* d_out_len, void* hip_stream) {
+    if (!g) return LEP_GPU_ERROR;
+    if (nseg <= 0) return 0;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
+    HIPCHK(g, hipSetDevice(g->device));
+    const size_t o_seg = (nimg * sizeof(lep_huff_image) + 255) & ~(size_t)255, total = o_seg + nseg * sizeof(lep_huff_segment);
+    if (int rc = ensure(g, &g->d_huff, &g->huff_bytes, total)) return rc;
+    HIPCHK(g, hipMemcpyAsync(g->d_huff, images, nimg * sizeof(lep_huff_image), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipMemcpyAsync((char*)g->d_huff + o_seg, segs, nseg * sizeof(lep_huff_segment), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipStreamSynchronize(st));   // the caller's arrays may go away
+    HIPCHK(g, hipEventRecord(g->ev0, st));
+    hipLaunchKernelGGL(lep_huffman_encode_kernel, dim3(nseg), dim3(64), 0, st, (const lephuff::HuffImage*)g->d_huff,
+                       (const lephuff::HuffSegment*)((char*)g->d_huff + o_seg), d_out, d_out_len);
+    HIPCHK(g, hipGetLastError());
+    HIPCHK(g, hipEventRecord(g->ev1, st));
+    g->timed = true;
+    g->last_kernel = "lep_huffman_encode_kernel";
+    return 0;
 }
 
 int lep_gpu_sync(lep_gpu* g) {

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--chunk-mb", type=int, default=0)
     ap.add_argument("--chunk-images", type=int, default=0)
     ap.add_argument("--verify", action="store_true")
+    ap.add_argument("--host-huffman", action="store_true", help="decompress: JPEG Huffman re-encode on the host pool instead of the GPU")
     args = ap.parse_args()
     import __graft_entry__ as ge
     ge.build()
@@ -35,12 +36,14 @@ def main():
     jpgs = [uniq[i % nu] for i in range(args.images)]
     mb = sum(map(len, jpgs)) / 1e6
     leps_w, _, _ = codec.compress_batch(jpgs[: min(len(jpgs), args.chunk_images or 1024)], verify=args.verify, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images)   # warm-up: kernel load, staging buffers
-    codec.decompress_batch(leps_w, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images)
+    codec.decompress_batch(leps_w, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images, host_huffman=args.host_huffman)
     t0 = time.perf_counter()
     leps, st, cs = codec.compress_batch(jpgs, verify=args.verify, threads=args.threads, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images)
     t1 = time.perf_counter()
     assert not any(st), sorted(set(st))
-    back, st2, ds = codec.decompress_batch(leps, threads=args.threads, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images)
+    back, st2, ds = codec.decompress_batch(leps, threads=args.threads, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images, host_huffman=args.host_huffman)
+    from lepton_amd import abi
+    last_kernel = (abi.lib().lep_gpu_last_kernel_name(codec.handle).decode(), round(abi.lib().lep_gpu_last_kernel_ms(codec.handle), 3))
     t2 = time.perf_counter()
     assert not any(st2) and back == jpgs, "round trip is not bit exact"
     out = {
@@ -51,7 +54,7 @@ def main():
                      "h2d_GBps": round(cs["h2d_bytes"] / cs["pipeline_s"] / 1e9, 2), **{k: round(v, 3) for k, v in cs.items()}},
         "decompress": {"MBps_pipeline": round(mb / ds["pipeline_s"], 1), "MBps_wall": round(mb / ds["wall_s"], 1), "python_wall_s": round(t2 - t1, 3),
                        "d2h_GBps": round(ds["d2h_bytes"] / ds["pipeline_s"] / 1e9, 2), **{k: round(v, 3) for k, v in ds.items()}},
-        "roundtrip": "bit exact (%d files)" % args.images,
+        "roundtrip": "bit exact (%d files)" % args.images, "huffman_reencode": "host pool" if args.host_huffman else "GPU (lep_huffman_encode_kernel)", "last_kernel_of_last_chunk_ms": last_kernel,
     }
     print(json.dumps(out), flush=True)
 

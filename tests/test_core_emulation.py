@@ -242,3 +242,41 @@ def test_inv24_table_update_is_exact(emu):
     """lep_dec4.h's Branch update (24-bit table reciprocal, v_mul_u32_u24) == branch.hh:82-100 for every count pair,
     both observations, saturation and halving paths included"""
     assert emu.emu_check_inv24_update() == 0
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_gpu_huffman_encoder_on_cpu_restores_the_jpeg(emu, name):
+    """lep_huff.h (wave-cooperative JPEG Huffman re-encode) as a 64-lane loop emulation: for every eligible fixture the
+    segments' scan bytes glued by recode_finish == the original JPEG == what the host re-encoder produces"""
+    from lepton_amd import abi
+    from lepton_amd.codec import LepFile
+
+    jpg, lep = golden(name)
+    L = abi.lib()
+    f = LepFile(lep)
+    src = JpegImage(jpg)          # coefficient frame from the JPEG itself (what the arithmetic decoder would restore)
+    for c in range(f.desc.ncomp):
+        C.memmove(f.desc.blocks[c], src.desc.blocks[c], f.desc.nblocks(c) * 128)
+    assert f.recode() == jpg      # host path
+    img = abi.HuffImage()
+    segs = (abi.HuffSegment * abi.MAX_SEGMENTS)()
+    nseg, ok = C.c_int(0), C.c_int(0)
+    assert L.lep_file_recode_plan(f.handle, C.byref(img), segs, C.byref(nseg), C.byref(ok)) == 0
+    if not ok.value:
+        pytest.skip("not eligible for the GPU Huffman encoder (truncated file, legacy hand-offs, ...): host path only")
+    outs = (abi.Bytes * nseg.value)()
+    keep = []
+    for i in range(nseg.value):
+        cap = min(segs[i].out_cap, len(jpg) + 1024)
+        segs[i].out_cap = cap
+        buf = C.create_string_buffer(cap + 8)
+        keep.append(buf)
+        n = C.c_uint32(0)
+        assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(segs[i]), buf, C.byref(n)) == 0
+        outs[i].data = C.cast(buf, C.c_void_p).value
+        outs[i].len = outs[i].cap = n.value
+    out = abi.Bytes()
+    assert L.lep_file_recode_finish(f.handle, outs, nseg.value, C.byref(out)) == 0
+    got = out.tobytes()
+    L.lep_free(out.data)
+    assert got == jpg

@@ -238,3 +238,33 @@ def test_gpu_batch_pipeline_verifies_on_the_gpu(gpu_codec):
     got, status, _ = gpu_codec.compress_batch(jpgs, verify=True)
     assert status == [0, 0, 0]
     assert got == [gpu_codec.compress(j) for j in jpgs]
+
+
+def test_gpu_huffman_reencode_matches_host_and_reference(gpu_codec):
+    """decode direction end to end on the GPU: arithmetic decode + JPEG Huffman re-encode (lep_huff.h); eligible fixtures
+    come back as scan bytes only and must equal the reference's input JPEGs, like the host re-coder's output"""
+    names = golden_cases()
+    leps = [golden(n)[1] for n in names]
+    jpgs = [golden(n)[0] for n in names]
+    extra = corpus.synth_jpeg(1280, 720, 61, quality=85)
+    leps.append(gpu_codec.compress(extra)); jpgs.append(extra)
+    a, sa, stats_gpu = gpu_codec.decompress_batch(leps)
+    b, sb, stats_host = gpu_codec.decompress_batch(leps, host_huffman=True)
+    assert sa == [0] * len(leps) and sb == sa
+    assert a == jpgs and b == jpgs
+    assert stats_gpu["d2h_bytes"] < stats_host["d2h_bytes"] / 3      # frames no longer cross PCIe for the eligible files
+
+
+def test_gpu_huffman_reencode_restart_markers_and_grey(gpu_codec):
+    from PIL import Image
+    import io
+    import numpy as np
+
+    rng = np.random.default_rng(3)
+    img = Image.fromarray(rng.integers(0, 256, (120, 200), dtype=np.uint8), "L")
+    buf = io.BytesIO(); img.save(buf, format="JPEG", quality=80)
+    grey = buf.getvalue()
+    cases = [grey, golden("rst_c420_176x112")[0]]
+    leps = [gpu_codec.compress(j) for j in cases]
+    out, st, _ = gpu_codec.decompress_batch(leps)
+    assert st == [0, 0] and out == cases
