@@ -121,6 +121,26 @@ typedef struct lep_huff_segment {
 } lep_huff_segment;
 int lep_gpu_huffman_encode_device(lep_gpu *g, const lep_huff_image *images, int nimg, const lep_huff_segment *segs, int nseg,
                                   uint8_t *d_out, uint32_t *d_out_len, void *hip_stream);
+/* JPEG Huffman scan decode on the GPU (replaces decode_jpeg / decode_block_seq, src/lepton/jpgcoder.cc:2799-3302,
+ * 4893-4966, for whole single-scan interleaved sequential files): one wavefront per image decodes the un-stuffed scan into
+ * the zero-filled device frame images[i].blocks and writes images[i].mcuv + 1 records (bit position + last DC per MCU row,
+ * final record: pad-bit pattern and status) at d_rows + images[i].rows_off.  lep_jpeg_open_gpu fills the struct. */
+typedef struct lep_huffdec_image {
+    const uint8_t *scan;                 /* device: un-stuffed scan bytes, 16-byte aligned, followed by >= 32 zero bytes */
+    uint32_t scan_len;
+    int32_t ncomp, mcuh, mcuv, mcuc, rsti;
+    int32_t hs[4], vs[4], bch[4], dc_tbl[4], ac_tbl[4], scan_cmp[4];
+    int16_t *blocks[4];                  /* device: zero-filled coefficient frame */
+    uint64_t rows_off;
+    uint16_t lut[4][512];
+    uint16_t tl[4][256], tr[4][256];
+} lep_huffdec_image;
+typedef struct lep_huffdec_row {
+    uint32_t bitpos;
+    int16_t last_dc[4];
+    int32_t aux;
+} lep_huffdec_row;
+int lep_gpu_huffman_decode_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, lep_huffdec_row *d_rows, void *hip_stream);
 /* plain device memory helpers so non-torch callers need no HIP binding */
 /* Device self-test of kernel arithmetic that has no CPU twin (exhaustive: the float-reciprocal Branch probability of the
  * v3 kernels against integer division, src/vp8/model/branch.hh:82-125).  0 = exact everywhere. */
@@ -145,6 +165,13 @@ int lep_jpeg_open(const uint8_t *jpg, size_t len, int allow_progressive, lep_jpe
 int lep_jpeg_open_into(const uint8_t *jpg, size_t len, int allow_progressive, void *frame_mem, size_t frame_cap, lep_jpeg **out);
 /* frame size from the SOF marker alone (no scan decode) */
 int lep_jpeg_peek_frame_bytes(const uint8_t *jpg, size_t len, size_t *bytes);
+/* JPEG parse with the scan decode left to lep_gpu_huffman_decode_device: splits the file and reads the tables only.
+ * *eligible = 0: the file needs the host decoder (call lep_jpeg_open / lep_jpeg_open_into instead).  Otherwise *image is
+ * filled except for scan / blocks / rows_off (device addresses, the caller's), lep_jpeg_scan_bytes gives the bytes to
+ * upload, and lep_jpeg_finish_gpu turns the kernel's row records into hand-offs (non-zero: irregular scan, use the host). */
+int lep_jpeg_open_gpu(const uint8_t *jpg, size_t len, lep_jpeg **out, lep_huffdec_image *image, int *eligible);
+int lep_jpeg_scan_bytes(const lep_jpeg *j, const uint8_t **data, size_t *len);
+int lep_jpeg_finish_gpu(lep_jpeg *j, const lep_huffdec_row *rows);
 void lep_jpeg_close(lep_jpeg *j);
 int lep_jpeg_describe(const lep_jpeg *j, lep_image_desc *desc);          /* host pointers into j */
 int lep_jpeg_is_progressive(const lep_jpeg *j);   /* 1: not a single interleaved sequential scan (needs the progressive re-coder) */
@@ -157,7 +184,7 @@ int lep_jpeg_write_lep(const lep_jpeg *j, int max_threads, const lep_bytes *stre
 int lep_file_open(const uint8_t *lepdata, size_t len, lep_file **out);
 void lep_file_close(lep_file *f);
 int lep_file_describe(lep_file *f, lep_image_desc *desc);                /* allocates zeroed host frame */
-int lep_file_describe_into(lep_file *f, void *frame_mem, size_t frame_cap, lep_image_desc *desc);   /* frame in caller memory */
+int lep_file_describe_into(lep_file *f, void *frame_mem, size_t frame_cap, lep_image_desc *desc);   /* frame in caller memory; (NULL, (size_t)-1) = geometry only */
 int lep_file_segments(const lep_file *f, lep_segment *segs, lep_bytes *streams, int image_index);
 uint32_t lep_file_jpeg_size(const lep_file *f);
 size_t lep_file_frame_bytes(const lep_file *f);   /* bytes of the coefficient frame lep_file_describe will expose */
@@ -201,7 +228,7 @@ typedef struct lep_batch_options {
     int32_t host_threads;        /* 0 = the CPUs this process may use (affinity mask capped by the cgroup CPU quota) */
     int32_t verify;              /* compress: on-GPU round-trip verification */
     size_t chunk_frame_bytes;    /* cap on coefficient-frame bytes per pipeline chunk; 0 = 24 GiB */
-    int32_t host_huffman;        /* decompress: 1 = JPEG Huffman re-encode on the host pool (frames cross PCIe) instead of on the GPU */
+    int32_t host_huffman;        /* 1 = JPEG Huffman decode / re-encode on the host pool (frames cross PCIe) instead of on the GPU */
     int32_t chunk_images;        /* images per pipeline chunk; 0 = 1024 (x 8 thread segments = one wavefront per SIMD slot of the
                                     chip: a coder kernel takes as long for 100 segments as for 8192, so chunks must be this big) */
 } lep_batch_options;

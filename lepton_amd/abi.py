@@ -62,6 +62,17 @@ class HuffSegment(C.Structure):
                 ("out_off", C.c_uint64), ("out_cap", C.c_uint32), ("pad", C.c_uint32)]
 
 
+class HuffDecImage(C.Structure):
+    _fields_ = [("scan", C.c_void_p), ("scan_len", C.c_uint32), ("ncomp", C.c_int32), ("mcuh", C.c_int32), ("mcuv", C.c_int32), ("mcuc", C.c_int32),
+                ("rsti", C.c_int32), ("hs", C.c_int32 * 4), ("vs", C.c_int32 * 4), ("bch", C.c_int32 * 4), ("dc_tbl", C.c_int32 * 4),
+                ("ac_tbl", C.c_int32 * 4), ("scan_cmp", C.c_int32 * 4), ("blocks", C.c_void_p * 4), ("rows_off", C.c_uint64),
+                ("lut", (C.c_uint16 * 512) * 4), ("tl", (C.c_uint16 * 256) * 4), ("tr", (C.c_uint16 * 256) * 4)]
+
+
+class HuffDecRow(C.Structure):
+    _fields_ = [("bitpos", C.c_uint32), ("last_dc", C.c_int16 * 4), ("aux", C.c_int32)]
+
+
 class BatchOptions(C.Structure):
     _fields_ = [("host_threads", C.c_int32), ("verify", C.c_int32), ("chunk_frame_bytes", C.c_size_t), ("host_huffman", C.c_int32), ("chunk_images", C.c_int32)]
 
@@ -130,6 +141,10 @@ def lib():
         L.lep_jpeg_is_progressive.argtypes = [vp]
         L.lep_compress_batch.argtypes = [vp, P(Bytes), C.c_int, P(Bytes), P(C.c_int32), P(BatchOptions), P(BatchStats)]
         L.lep_decompress_batch.argtypes = [vp, P(Bytes), C.c_int, P(Bytes), P(C.c_int32), P(BatchOptions), P(BatchStats)]
+        L.lep_jpeg_open_gpu.argtypes = [vp, C.c_size_t, P(vp), P(HuffDecImage), P(C.c_int)]
+        L.lep_jpeg_scan_bytes.argtypes = [vp, P(vp), P(C.c_size_t)]
+        L.lep_jpeg_finish_gpu.argtypes = [vp, P(HuffDecRow)]
+        L.lep_gpu_huffman_decode_device.argtypes = [vp, P(HuffDecImage), C.c_int, vp, vp]
         L.lep_file_recode_plan.argtypes = [vp, P(HuffImage), P(HuffSegment), P(C.c_int), P(C.c_int)]
         L.lep_file_recode_finish.argtypes = [vp, P(Bytes), C.c_int, P(Bytes)]
         L.lep_gpu_huffman_encode_device.argtypes = [vp, P(HuffImage), C.c_int, P(HuffSegment), C.c_int, vp, vp, vp]
@@ -150,5 +165,5 @@ EXPORTS = [
     "lep_gpu_free", "lep_gpu_memcpy_h2d", "lep_gpu_memcpy_d2h", "lep_gpu_memcpy_d2d", "lep_gpu_memset", "lep_jpeg_open", "lep_jpeg_close",
     "lep_jpeg_describe", "lep_jpeg_plan", "lep_jpeg_write_lep", "lep_file_open", "lep_file_close", "lep_file_describe",
     "lep_file_segments", "lep_file_jpeg_size", "lep_file_recode", "lep_compress", "lep_decompress", "lep_free",
-    "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_file_recode_plan", "lep_file_recode_finish", "lep_gpu_huffman_encode_device", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
+    "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_file_recode_plan", "lep_file_recode_finish", "lep_gpu_huffman_encode_device", "lep_jpeg_open_gpu", "lep_jpeg_scan_bytes", "lep_jpeg_finish_gpu", "lep_gpu_huffman_decode_device", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
 ]

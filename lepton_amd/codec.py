@@ -209,9 +209,10 @@ class GpuCodec:
                 self._L.lep_free(outs[i].data)
         return res, list(status), {k: getattr(stats, k) for k, _ in abi.BatchStats._fields_}
 
-    def compress_batch(self, jpgs, verify=False, threads=0, chunk_bytes=0, chunk_images=0):
-        """[jpeg bytes] -> ([.lep bytes or None], [exit code per file], pipeline statistics)"""
-        return self._batch(self._L.lep_compress_batch, jpgs, verify, threads, chunk_bytes, chunk_images)
+    def compress_batch(self, jpgs, verify=False, threads=0, chunk_bytes=0, chunk_images=0, host_huffman=False):
+        """[jpeg bytes] -> ([.lep bytes or None], [exit code per file], pipeline statistics); the JPEG Huffman scan decode runs
+        on the GPU for eligible files unless host_huffman is set"""
+        return self._batch(self._L.lep_compress_batch, jpgs, verify, threads, chunk_bytes, chunk_images, host_huffman)
 
     def decompress_batch(self, leps, threads=0, chunk_bytes=0, chunk_images=0, host_huffman=False):
         """[.lep bytes] -> ([jpeg bytes or None], [exit code per file], pipeline statistics); the JPEG Huffman re-encode runs

@@ -109,6 +109,26 @@ struct JpegFile {
 // EX_PROGRESSIVE_UNSUPPORTED like the reference does.
 int parse_jpeg(const uint8_t* data, size_t size, bool allow_progressive, JpegFile* out);
 
+// GPU Huffman scan decode (lep_huffdec.h): host-side halves.  ScanDecodePlan / ScanDecodeRow are laid out exactly like
+// lephuff::HuffDecImage / HuffDecRow and the C ABI's lep_huffdec_image / lep_huffdec_row.
+struct ScanDecodePlan {
+    const uint8_t* scan;
+    uint32_t scan_len;
+    int32_t ncomp, mcuh, mcuv, mcuc, rsti;
+    int32_t hs[4], vs[4], bch[4], dc_tbl[4], ac_tbl[4], scan_cmp[4];
+    int16_t* blocks[4];
+    uint64_t rows_off;
+    uint16_t lut[4][512];
+    uint16_t tl[4][256], tr[4][256];
+};
+struct ScanDecodeRow {
+    uint32_t bitpos;
+    int16_t last_dc[4];
+    int32_t aux;
+};
+int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanDecodePlan* plan, bool* eligible);
+int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows);
+
 bool build_huff_table(const uint8_t* clen, size_t clen_avail, const uint8_t* cval, size_t cval_avail,
                       HuffTable* t, bool strict);
 bool parse_segment(JpegFile* jf, uint8_t type, unsigned len, unsigned avail, const uint8_t* seg, bool strict);

@@ -511,6 +511,102 @@ int decode_progressive_scan(JpegFile*, BitReader&, int*, int*, int*, int*, int*,
 }
 #endif
 
+// ---- GPU Huffman decode (lep_huffdec.h): the host does everything except decoding the scan ---------------------------------------
+// parse_jpeg_prepare_gpu: split the file, set up the frame, read the tables of the first scan; *eligible when the scan is a
+// single MCU-interleaved sequential scan of all (2..3) components with at most two tables per class and the file is whole.
+int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanDecodePlan* plan, bool* eligible) {
+    *eligible = false;
+    if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) { jf->error = "not a jpeg"; return EX_UNSUPPORTED_JPEG; }
+    memset(jf->qtables, 0, sizeof jf->qtables);
+    int rc = split_file(data, size, jf);
+    if (rc) return rc;
+    if (!setup_frame(jf)) return jf->warn < 0 ? -jf->warn : EX_UNSUPPORTED_JPEG;
+    if (jf->ncomp > 3) return EX_UNSUPPORTED_4_COLORS;
+    if (jf->early_eof || jf->jpegtype != 1 || jf->ncomp < 2) return 0;
+    const uint8_t* h = jf->hdr.data();
+    const size_t hdrs = jf->hdr.size();
+    size_t hpos = 0;
+    int nsos = 0;
+    while (3 + (uint64_t)hpos < hdrs) {
+        const uint8_t type = h[hpos + 1];
+        const unsigned len = 2 + be16(h[hpos + 2], h[hpos + 3]);
+        if ((uint64_t)hpos + len > hdrs) return 0;             // truncated segment: host parser
+        if (type == 0xDA) ++nsos;
+        if (nsos <= 1 && (type == 0xC4 || type == 0xDA || type == 0xDD))
+            if (!parse_segment(jf, type, len, len, h + hpos, true)) return 0;
+        if (nsos > 1) return 0;
+        hpos += len;
+    }
+    if (nsos != 1 || jf->cs_cmpc != jf->ncomp || jf->scan.empty()) return 0;
+    memset(plan, 0, sizeof *plan);
+    plan->scan_len = (uint32_t)jf->scan.size();
+    plan->ncomp = jf->ncomp; plan->mcuh = jf->mcuh; plan->mcuv = jf->mcuv; plan->mcuc = jf->mcuc; plan->rsti = jf->rsti;
+    for (int i = 0; i < jf->ncomp; ++i) {
+        const Component& k = jf->comp[i];
+        if (k.dc_tbl > 1 || k.ac_tbl > 1 || !jf->htab[0][k.dc_tbl].set || !jf->htab[1][k.ac_tbl].set) return 0;
+        if (k.bch != jf->mcuh * k.hs || k.bcv != jf->mcuv * k.vs || k.hs < 1 || k.vs < 1) return 0;
+        plan->hs[i] = k.hs; plan->vs[i] = k.vs; plan->bch[i] = k.bch; plan->dc_tbl[i] = k.dc_tbl; plan->ac_tbl[i] = k.ac_tbl;
+        plan->scan_cmp[i] = jf->cs_cmp[i];
+    }
+    for (int cls = 0; cls < 2; ++cls)
+        for (int id = 0; id < 2; ++id) {
+            const HuffTable& t = jf->htab[cls][id];
+            if (!t.set) continue;
+            uint16_t* lut = plan->lut[cls * 2 + id];
+            for (int sym = 0; sym < 256; ++sym) {
+                const int len = t.clen[sym];
+                if (len < 1 || len > 9) continue;
+                const unsigned first = (unsigned)t.cval[sym] << (9 - len);
+                for (unsigned x = 0; x < (1u << (9 - len)); ++x) lut[first + x] = (uint16_t)((len << 8) | sym);
+            }
+            memcpy(plan->tl[cls * 2 + id], t.l, sizeof t.l);
+            memcpy(plan->tr[cls * 2 + id], t.r, sizeof t.r);
+        }
+    *eligible = true;
+    return 0;
+}
+
+// parse_jpeg_finish_gpu: what decode_scans leaves behind besides the coefficients -- hand-off records from the bit
+// positions the kernel recorded per MCU row, the pad-bit pattern, the scan bookkeeping.  A non-zero kernel status (or a
+// record that makes no sense) is returned as -1: the caller re-parses the file on the host.
+int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows) {
+    const int mcuv = jf->mcuv;
+    const int status = rows[mcuv].aux >> 8;
+    if (status) return -1;
+    const uint32_t total_bits = (uint32_t)jf->scan.size() * 8u;
+    const int luma_mul = jf->comp[0].bcv / jf->mcuv;
+    jf->rows.clear();
+    const auto& offs = jf->scan_to_file;
+    for (int r = 0; r <= mcuv; ++r) {
+        const uint32_t bp = rows[r].bitpos;
+        if (bp > total_bits) return -1;
+        const uint32_t p = (bp >> 3) + 1;   // BitReader::getpos: 1 + index of the byte holding the next unread bit
+        auto it = std::lower_bound(offs.begin(), offs.end(), std::pair<uint32_t, uint32_t>(p, p));
+        if (it != offs.begin()) --it;
+        uint32_t mapped = 0;
+        if (it != offs.end()) mapped = it->second + (p - it->first);
+        Handoff hnd;
+        hnd.segment_size = mapped;
+        for (int i = 0; i < 4; ++i) hnd.last_dc[i] = rows[r].last_dc[i];
+        hnd.luma_y_start = (uint16_t)(luma_mul * r);
+        hnd.luma_y_end = (uint16_t)(luma_mul * (r + 1));
+        const int rem = (int)(bp & 7u);
+        hnd.num_overhang_bits = (uint8_t)rem;
+        hnd.overhang_byte = rem ? (uint8_t)(jf->scan[bp >> 3] & (uint8_t)(((1 << rem) - 1) << (8 - rem))) : 0;
+        jf->rows.push_back(hnd);
+    }
+    for (size_t i = 1; i < jf->rows.size(); ++i)
+        if (jf->rows[i].luma_y_start < jf->rows[i - 1].luma_y_end) jf->rows[i].luma_y_start = jf->rows[i - 1].luma_y_end;
+    jf->padbit = (int8_t)(rows[mcuv].aux & 255);
+    jf->scan_count = 1;
+    jf->max_bpos = std::max(jf->max_bpos, jf->cs_to);
+    jf->max_sah = std::max(jf->max_sah, std::max(jf->cs_sal, jf->cs_sah));
+    for (int i = 0; i < jf->cs_cmpc; ++i) jf->max_cmp = std::max(jf->max_cmp, jf->cs_cmp[i]);
+    for (int c = 0; c < jf->ncomp; ++c) jf->max_dpos[c] = jf->comp[c].bc - 1;
+    jf->progressive_needed = false;
+    return 0;
+}
+
 int parse_jpeg(const uint8_t* data, size_t size, bool allow_progressive, JpegFile* jf) {
     if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) { jf->error = "not a jpeg"; return EX_UNSUPPORTED_JPEG; }
     memset(jf->qtables, 0, sizeof jf->qtables);

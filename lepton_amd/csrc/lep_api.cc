@@ -20,6 +20,7 @@ struct lep_file {
     lep::RecodePlan plan;
     bool planned = false;
 };
+static_assert(sizeof(lep_huffdec_image) == sizeof(lep::ScanDecodePlan) && sizeof(lep_huffdec_row) == sizeof(lep::ScanDecodeRow), "C ABI mirrors");
 static_assert(sizeof(lep_huff_image) == sizeof(lep::RecodeImage) && sizeof(lep_huff_segment) == sizeof(lep::RecodeSegment), "C ABI mirrors");
 
 static void fill_desc(const lep::JpegFile& jf, lep_image_desc* d, int16_t* const* planes) {
@@ -95,6 +96,23 @@ int lep_jpeg_open_into(const uint8_t* jpg, size_t len, int allow_progressive, vo
     *out = j.release();
     return 0;
 }
+int lep_jpeg_open_gpu(const uint8_t* jpg, size_t len, lep_jpeg** out, lep_huffdec_image* image, int* eligible) {
+    std::unique_ptr<lep_jpeg> j(new lep_jpeg);
+    j->opt.allow_progressive = true;
+    bool ok = false;
+    int rc = lep::parse_jpeg_prepare_gpu(jpg, len, &j->jf, reinterpret_cast<lep::ScanDecodePlan*>(image), &ok);
+    if (rc) return rc;
+    *eligible = ok ? 1 : 0;
+    *out = j.release();
+    return 0;
+}
+int lep_jpeg_scan_bytes(const lep_jpeg* j, const uint8_t** data, size_t* len) {
+    *data = j->jf.scan.data(); *len = j->jf.scan.size();
+    return 0;
+}
+int lep_jpeg_finish_gpu(lep_jpeg* j, const lep_huffdec_row* rows) {
+    return lep::parse_jpeg_finish_gpu(&j->jf, reinterpret_cast<const lep::ScanDecodeRow*>(rows)) ? LEP_UNSUPPORTED_JPEG : 0;
+}
 void lep_jpeg_close(lep_jpeg* j) { delete j; }
 
 int lep_jpeg_describe(const lep_jpeg* j, lep_image_desc* d) {
@@ -169,6 +187,11 @@ int lep_file_describe(lep_file* f, lep_image_desc* d) { return lep_file_describe
 // the batch pipeline points it at the pinned buffer the decoded frame is copied into
 int lep_file_describe_into(lep_file* f, void* frame_mem, size_t frame_cap, lep_image_desc* d) {
     lep::JpegFile& jf = f->lf.jpeg;
+    if (!frame_mem && frame_cap == (size_t)-1) {   // geometry only: the frame lives elsewhere (device memory)
+        int16_t* none[4] = {nullptr, nullptr, nullptr, nullptr};
+        fill_desc(jf, d, none);
+        return 0;
+    }
     if (!f->frame_ready || frame_mem) {
         jf.ext_mem = (int16_t*)frame_mem; jf.ext_cap = frame_mem ? frame_cap : 0;
         jf.place_frame(false);

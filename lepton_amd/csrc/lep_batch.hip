@@ -86,17 +86,18 @@ void tune_malloc_for_pool() {
 }
 
 struct Slot {   // one chunk's buffers (double-buffered)
-    char* h_frames = nullptr; char* d_frames = nullptr; char* d_scratch = nullptr; size_t frames_cap = 0;
+    char* h_frames = nullptr; char* d_frames = nullptr; char* d_scratch = nullptr; size_t frames_cap = 0, hframes_cap = 0;
     uint8_t* d_streams = nullptr; uint8_t* h_streams = nullptr; size_t streams_cap = 0;
     uint32_t* d_len = nullptr; int32_t* d_status = nullptr; uint32_t* d_flags = nullptr; size_t seg_cap = 0, img_cap = 0;
     uint8_t* d_scan = nullptr; uint8_t* h_scan = nullptr; size_t scan_cap = 0;   // JPEG scan bytes of the GPU Huffman encoder
     uint32_t* d_scanlen = nullptr; size_t scanlen_cap = 0;
+    char* d_rows = nullptr; size_t rows_cap = 0;   // row records of the GPU Huffman decoder
     hipEvent_t up = nullptr, done = nullptr;
     void release() {
         if (h_frames) (void)hipHostFree(h_frames);
         if (h_streams) (void)hipHostFree(h_streams);
         if (h_scan) (void)hipHostFree(h_scan);
-        for (void* p : {(void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags, (void*)d_scan, (void*)d_scanlen})
+        for (void* p : {(void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags, (void*)d_scan, (void*)d_scanlen, (void*)d_rows})
             if (p) (void)hipFree(p);
         if (up) (void)hipEventDestroy(up);
         if (done) (void)hipEventDestroy(done);
@@ -117,11 +118,9 @@ int slot_reserve(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nim
 }
 int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch) {
     if (frames > s->frames_cap) {
-        if (s->h_frames) (void)hipHostFree(s->h_frames);
         if (s->d_frames) (void)hipFree(s->d_frames);
         if (s->d_scratch) (void)hipFree(s->d_scratch);
-        s->h_frames = s->d_frames = s->d_scratch = nullptr;
-        HIPOK(hipHostMalloc((void**)&s->h_frames, frames, hipHostMallocDefault));
+        s->d_frames = s->d_scratch = nullptr;
         HIPOK(hipMalloc((void**)&s->d_frames, frames));
         s->frames_cap = frames;
     }
@@ -165,6 +164,18 @@ int scan_reserve(Slot* s, size_t bytes, size_t nseg) {
         HIPOK(hipMalloc((void**)&s->d_scanlen, nseg * 4));
         s->scanlen_cap = nseg;
     }
+    g_alloc_s += now_s() - t0;
+    return 0;
+}
+
+// pinned host staging for whole frames: only needed for files the host Huffman coder handles
+int host_frames_reserve(Slot* s, size_t frames) {
+    if (frames <= s->hframes_cap) return 0;
+    const double t0 = now_s();
+    if (s->h_frames) (void)hipHostFree(s->h_frames);
+    s->h_frames = nullptr; s->hframes_cap = 0;
+    HIPOK(hipHostMalloc((void**)&s->h_frames, frames, hipHostMallocDefault));
+    s->hframes_cap = frames;
     g_alloc_s += now_s() - t0;
     return 0;
 }
@@ -245,41 +256,143 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     int rc_all = 0;
     std::vector<lep_jpeg*> parsed(n, nullptr);
 
-    // 2. per chunk: parse into the slot's pinned frames (host pool), plan segments, start the upload
+    // 2. per chunk: split the files on the host pool; eligible scans are Huffman-decoded ON THE GPU straight into the device
+    //    frame (only the 2 MB of scan bytes cross PCIe), the others by the host parser into the slot's pinned frames; then the
+    //    hand-offs are finished, segments planned and the upload event recorded
+    const bool gpu_huffman = !(o && o->host_huffman);
+    auto host_parse_one = [&](Chunk* c, Slot* s, int k) -> int {   // host Huffman decode of live image k into its pinned frame
+        const int i = c->live[k];
+        const size_t room = (k + 1 < (int)c->live.size() ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
+        if (parsed[i]) { lep_jpeg_close(parsed[i]); parsed[i] = nullptr; }
+        int rc = lep_jpeg_open_into(jpgs[i].data, jpgs[i].len, 1, s->h_frames + c->frame_off[k], room, &parsed[i]);
+        if (!rc && lep_jpeg_is_progressive(parsed[i])) rc = LEP_PROGRESSIVE_UNSUPPORTED;   // host re-coder is sequential-only so far
+        if (!rc) {
+            lep_jpeg_describe(parsed[i], &c->host_desc[k]);
+            const lep_image_desc& d = c->host_desc[k];
+            if ((char*)d.blocks[0] != s->h_frames + c->frame_off[k]) {   // SOF peek disagreed with the parser: copy into place
+                if (frame_bytes_of(d) > room) rc = LEP_ASSERTION_FAILURE;
+                else {
+                    size_t off = c->frame_off[k];
+                    for (int cc = 0; cc < d.ncomp; ++cc) {
+                        const size_t b = (size_t)d.width_blocks[cc] * d.height_blocks[cc] * 128;
+                        memcpy(s->h_frames + off, d.blocks[cc], b);
+                        off += b;
+                    }
+                }
+            }
+        }
+        if (rc) { status[i] = rc; if (parsed[i]) { lep_jpeg_close(parsed[i]); parsed[i] = nullptr; } }
+        return rc;
+    };
     auto parse_and_upload = [&](Chunk* c, Slot* s) -> int {
         if (c->live.empty()) return 0;
         if (int rc = slot_reserve(s, c->frame_bytes, 0, 0, c->live.size(), verify)) return rc;
-        const double t0 = now_s();
-        c->host_desc.resize(c->live.size());
-        std::vector<char> fits(c->live.size(), 1);
-        parallel_for((int)c->live.size(), threads, [&](int k) {
-            const int i = c->live[k];
-            const size_t room = (k + 1 < (int)c->live.size() ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
-            int rc = lep_jpeg_open_into(jpgs[i].data, jpgs[i].len, 1, s->h_frames + c->frame_off[k], room, &parsed[i]);
-            if (!rc && lep_jpeg_is_progressive(parsed[i])) rc = LEP_PROGRESSIVE_UNSUPPORTED;   // host re-coder is sequential-only so far
-            if (!rc) {
-                lep_jpeg_describe(parsed[i], &c->host_desc[k]);
-                if ((char*)c->host_desc[k].blocks[0] != s->h_frames + c->frame_off[k]) fits[k] = 0;   // SOF peek disagreed with the parser
+        const int nl = (int)c->live.size();
+        double t0 = now_s();
+        c->host_desc.assign(nl, lep_image_desc());
+        std::vector<lep_huffdec_image> himg(nl);
+        std::vector<char> on_gpu(nl, 0);
+        std::vector<char> need_host(nl, gpu_huffman ? 0 : 1);
+        if (gpu_huffman)
+            parallel_for(nl, threads, [&](int k) {
+                const int i = c->live[k];
+                int ok = 0;
+                int rc = lep_jpeg_open_gpu(jpgs[i].data, jpgs[i].len, &parsed[i], &himg[k], &ok);
+                if (rc) { status[i] = rc; return; }      // not a JPEG the reference would take either
+                if (ok) on_gpu[k] = 1; else need_host[k] = 1;
+            });
+        bool any_host = false;
+        for (int k = 0; k < nl; ++k) any_host |= need_host[k] != 0;
+        if (any_host) {
+            if (int rc = host_frames_reserve(s, c->frame_bytes)) return rc;
+            parallel_for(nl, threads, [&](int k) { if (need_host[k]) host_parse_one(c, s, k); });
+        }
+        // scan arena (pinned -> device), row records
+        std::vector<size_t> scan_off(nl, 0), row_off(nl, 0);
+        size_t scan_total = 0, rows_total = 0;
+        int ngpu = 0;
+        for (int k = 0; k < nl; ++k) if (on_gpu[k]) {
+            scan_off[k] = scan_total; scan_total += ((size_t)himg[k].scan_len + 64 + 15) & ~(size_t)15;
+            row_off[k] = rows_total; rows_total += (size_t)himg[k].mcuv + 1;
+            ++ngpu;
+        }
+        std::vector<lep_huffdec_row> rows(rows_total);
+        if (ngpu) {
+            if (int rc = scan_reserve(s, scan_total + 256, 0)) return rc;
+            const double ta = now_s();
+            if (rows_total * sizeof(lep_huffdec_row) > s->rows_cap) {
+                if (s->d_rows) (void)hipFree(s->d_rows);
+                s->d_rows = nullptr; s->rows_cap = 0;
+                HIPOK(hipMalloc((void**)&s->d_rows, rows_total * sizeof(lep_huffdec_row)));
+                s->rows_cap = rows_total * sizeof(lep_huffdec_row);
             }
-            if (rc) { status[i] = rc; if (parsed[i]) { lep_jpeg_close(parsed[i]); parsed[i] = nullptr; } }
-        });
+            g_alloc_s += now_s() - ta;
+            parallel_for(nl, threads, [&](int k) {
+                if (!on_gpu[k]) return;
+                const uint8_t* p = nullptr; size_t len = 0;
+                lep_jpeg_scan_bytes(parsed[c->live[k]], &p, &len);
+                memcpy(s->h_scan + scan_off[k], p, len);
+                memset(s->h_scan + scan_off[k] + len, 0, (((size_t)himg[k].scan_len + 64 + 15) & ~(size_t)15) - len);
+            });
+        }
         st.parse_s += now_s() - t0;
-        // drop failed images from the chunk; copy the (never expected) misfits into place if they fit, else fail them
+        // uploads: zero frames for the GPU-decoded images, host-decoded frames as they are
+        HIPOK(hipMemsetAsync(s->d_frames, 0, c->frame_bytes, s_copy));
+        for (int k = 0; k < nl; ++k) if (!on_gpu[k] && parsed[c->live[k]]) {
+            const size_t fb = (k + 1 < nl ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
+            HIPOK(hipMemcpyAsync(s->d_frames + c->frame_off[k], s->h_frames + c->frame_off[k], fb, hipMemcpyHostToDevice, s_copy));
+            st.h2d_bytes += (double)fb;
+        }
+        if (ngpu) {
+            HIPOK(hipMemcpyAsync(s->d_scan, s->h_scan, scan_total, hipMemcpyHostToDevice, s_copy));
+            st.h2d_bytes += (double)scan_total;
+            HIPOK(hipEventRecord(s->up, s_copy));
+            // Huffman scan decode on the GPU: one wavefront per image
+            std::vector<lep_huffdec_image> launch;
+            std::vector<int> which;
+            for (int k = 0; k < nl; ++k) if (on_gpu[k]) {
+                lep_huffdec_image hi = himg[k];
+                hi.scan = s->d_scan + scan_off[k];
+                hi.rows_off = row_off[k];
+                size_t off = c->frame_off[k];
+                for (int cc = 0; cc < hi.ncomp; ++cc) {
+                    hi.blocks[cc] = (int16_t*)(s->d_frames + off);
+                    off += (size_t)hi.bch[cc] * hi.vs[cc] * hi.mcuv * 128;
+                }
+                launch.push_back(hi); which.push_back(k);
+            }
+            HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
+            if (int rc = lep_gpu_huffman_decode_device(g, launch.data(), (int)launch.size(), (lep_huffdec_row*)s->d_rows, s_compute)) return rc;
+            HIPOK(hipMemcpyAsync(rows.data(), s->d_rows, rows_total * sizeof(lep_huffdec_row), hipMemcpyDeviceToHost, s_compute));
+            HIPOK(hipStreamSynchronize(s_compute));
+            st.d2h_bytes += (double)(rows_total * sizeof(lep_huffdec_row));
+            // hand-offs from the row records; irregular scans go back to the host parser (and their frames up again)
+            t0 = now_s();
+            std::vector<char> redo(nl, 0);
+            parallel_for(nl, threads, [&](int k) {
+                if (!on_gpu[k]) return;
+                const int i = c->live[k];
+                if (lep_jpeg_finish_gpu(parsed[i], rows.data() + row_off[k])) { redo[k] = 1; on_gpu[k] = 0; return; }
+                lep_jpeg_describe(parsed[i], &c->host_desc[k]);   // geometry; the frame itself only exists on the device
+            });
+            bool any_redo = false;
+            for (int k = 0; k < nl; ++k) any_redo |= redo[k] != 0;
+            if (any_redo) {
+                if (int rc = host_frames_reserve(s, c->frame_bytes)) return rc;
+                parallel_for(nl, threads, [&](int k) { if (redo[k]) host_parse_one(c, s, k); });
+            }
+            st.parse_s += now_s() - t0;
+            for (int k = 0; k < nl; ++k) if (redo[k] && parsed[c->live[k]]) {
+                const size_t fb = (k + 1 < nl ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
+                HIPOK(hipMemcpyAsync(s->d_frames + c->frame_off[k], s->h_frames + c->frame_off[k], fb, hipMemcpyHostToDevice, s_copy));
+                st.h2d_bytes += (double)fb;
+            }
+        }
+        // drop failed images from the chunk
         Chunk keep;
-        for (size_t k = 0; k < c->live.size(); ++k) {
+        for (int k = 0; k < nl; ++k) {
             const int i = c->live[k];
             if (!parsed[i]) continue;
-            if (!fits[k]) {
-                const lep_image_desc& d = c->host_desc[k];
-                const size_t room = (k + 1 < c->live.size() ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
-                if (frame_bytes_of(d) > room) { status[i] = LEP_ASSERTION_FAILURE; lep_jpeg_close(parsed[i]); parsed[i] = nullptr; continue; }
-                size_t off = c->frame_off[k];
-                for (int cc = 0; cc < d.ncomp; ++cc) {
-                    const size_t b = (size_t)d.width_blocks[cc] * d.height_blocks[cc] * 128;
-                    memcpy(s->h_frames + off, d.blocks[cc], b);
-                    off += b;
-                }
-            }
             keep.live.push_back(i); keep.frame_off.push_back(c->frame_off[k]); keep.host_desc.push_back(c->host_desc[k]);
         }
         c->live.swap(keep.live); c->frame_off.swap(keep.frame_off); c->host_desc.swap(keep.host_desc);
@@ -308,9 +421,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 off += (size_t)c->host_desc[k].width_blocks[cc] * c->host_desc[k].height_blocks[cc] * 128;
             }
         }
-        HIPOK(hipMemcpyAsync(s->d_frames, s->h_frames, c->frame_bytes, hipMemcpyHostToDevice, s_copy));
         HIPOK(hipEventRecord(s->up, s_copy));
-        st.h2d_bytes += (double)c->frame_bytes;
         return 0;
     };
 
@@ -468,10 +579,9 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         const double t0 = now_s();
         parallel_for((int)c->segs.size(), threads, [&](int q) { if ((*lens)[q]) memcpy(s->h_streams + c->offs[q], src[q], (*lens)[q]); });
         st.stage_s += now_s() - t0;
-        // the Huffman re-coder will read the frame where the D2H copy puts it: the slot's pinned buffer
+        // geometry of every frame (the frames themselves are decoded into device memory)
         c->host_desc.resize(c->live.size());
-        for (size_t k = 0; k < c->live.size(); ++k)
-            lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
+        for (size_t k = 0; k < c->live.size(); ++k) lep_file_describe_into(files[c->live[k]], nullptr, (size_t)-1, &c->host_desc[k]);
         c->dev_desc = c->host_desc;
         for (size_t k = 0; k < c->live.size(); ++k) {
             size_t off = c->frame_off[k];
@@ -509,6 +619,14 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                 c->himg.push_back(hi);
             }
             if (!c->hseg.empty()) { if (int rc = scan_reserve(s, c->scan_bytes + 256, c->hseg.size())) return rc; }
+        }
+        // files the host re-coder handles read their frame where the D2H copy puts it: the slot's pinned buffer
+        bool any_host = false;
+        for (size_t k = 0; k < c->live.size(); ++k) any_host |= c->hfirst[k] < 0;
+        if (any_host) {
+            if (int rc = host_frames_reserve(s, c->frame_bytes)) return rc;
+            for (size_t k = 0; k < c->live.size(); ++k)
+                if (c->hfirst[k] < 0) lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
         }
         HIPOK(hipMemcpyAsync(s->d_streams, s->h_streams, c->offs.back(), hipMemcpyHostToDevice, s_copy));
         HIPOK(hipMemcpyAsync(s->d_len, lens->data(), lens->size() * 4, hipMemcpyHostToDevice, s_copy));
@@ -553,7 +671,11 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                 if (on_gpu) {   // a segment that filled its reserved slot may have been cut short: let the host redo that file
                     const int h0 = c->hfirst[k], h1 = h0 + (c->seg_first[k + 1] - c->seg_first[k]);
                     for (int q = h0; q < h1; ++q) if (slens[q] >= c->hslot[q] && c->hslot[q] < c->hbound[q]) on_gpu = false;
-                    if (!on_gpu) c->hfirst[k] = -1;
+                    if (!on_gpu) {
+                        c->hfirst[k] = -1;
+                        if (int rc = host_frames_reserve(s, c->frame_bytes)) return rc;
+                        lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
+                    }
                     else for (int q = h0; q < h1; ++q)
                         if (slens[q]) { HIPOK(hipMemcpyAsync(s->h_scan + c->hseg[q].out_off, s->d_scan + c->hseg[q].out_off, slens[q], hipMemcpyDeviceToHost, s_down)); st.d2h_bytes += slens[q]; }
                 }

@@ -21,6 +21,7 @@
 #include "lep_enc3.h"
 #include "lep_dec4.h"
 #include "lep_huff.h"
+#include "lep_huffdec.h"
 
 using namespace lepdev;
 
@@ -228,6 +229,13 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_encode_kernel(const lephuff
     if (threadIdx.x == 0) out_len[s] = n;
 }
 
+// JPEG Huffman scan decode: one wavefront per image (lep_huffdec.h)
+__global__ __launch_bounds__(64) void lep_huffman_decode_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffDecRow* rows) {
+    __shared__ lephuff::HuffDecShared sh;
+    lephuff::HuffDecWave w;
+    w.run(images + blockIdx.x, &sh, rows);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -252,6 +260,7 @@ struct lep_gpu {
     void* d_streams = nullptr; size_t streams_bytes = 0;
     void* d_lens = nullptr; size_t lens_bytes = 0;
     void* d_huff = nullptr; size_t huff_bytes = 0;      // HuffImage[] | HuffSegment[]
+    void* d_huffdec = nullptr; size_t huffdec_bytes = 0;   // HuffDecImage[]
     void* d_scan = nullptr; size_t scan_bytes = 0;      // scan bytes of the Huffman encoder (host variant)
     void* d_scanlen = nullptr; size_t scanlen_bytes = 0;
 };
@@ -395,7 +404,7 @@ void lep_gpu_destroy(lep_gpu* g) {
     if (!g) return;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    for (void* p : {g->d_models, g->d_ns, g->d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_scan, g->d_scanlen})
+    for (void* p : {g->d_models, g->d_ns, g->d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffdec, g->d_scan, g->d_scanlen})
         if (p) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -439,6 +448,26 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
     g->last_kernel = "lep_huffman_encode_kernel";
+    return 0;
+}
+
+static_assert(sizeof(lep_huffdec_image) == sizeof(lephuff::HuffDecImage) && sizeof(lep_huffdec_row) == sizeof(lephuff::HuffDecRow), "C ABI mirrors");
+
+int lep_gpu_huffman_decode_device(lep_gpu* g, const lep_huffdec_image* images, int nimg, lep_huffdec_row* d_rows, void* hip_stream) {
+    if (!g) return LEP_GPU_ERROR;
+    if (nimg <= 0) return 0;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
+    HIPCHK(g, hipSetDevice(g->device));
+    if (int rc = ensure(g, &g->d_huffdec, &g->huffdec_bytes, (size_t)nimg * sizeof(lep_huffdec_image))) return rc;
+    HIPCHK(g, hipMemcpyAsync(g->d_huffdec, images, (size_t)nimg * sizeof(lep_huffdec_image), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipStreamSynchronize(st));   // the caller's array may go away
+    HIPCHK(g, hipEventRecord(g->ev0, st));
+    hipLaunchKernelGGL(lep_huffman_decode_kernel, dim3(nimg), dim3(64), 0, st, (const lephuff::HuffDecImage*)g->d_huffdec,
+                       (lephuff::HuffDecRow*)d_rows);
+    HIPCHK(g, hipGetLastError());
+    HIPCHK(g, hipEventRecord(g->ev1, st));
+    g->timed = true;
+    g->last_kernel = "lep_huffman_decode_kernel";
     return 0;
 }
 

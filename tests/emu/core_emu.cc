@@ -173,3 +173,15 @@ extern "C" int emu_huffman_encode_segment(const lep_huff_image* img, const lep_h
     *len = w.run(reinterpret_cast<const lephuff::HuffImage*>(img), s, &sh, out);
     return 0;
 }
+
+// GPU Huffman scan decoder (lep_huffdec.h) as a 64-lane loop emulation: one image
+#include "../../lepton_amd/csrc/lep_huffdec.h"
+extern "C" int emu_huffman_decode_image(const lep_huffdec_image* img, lep_huffdec_row* rows) {
+    static lephuff::HuffDecShared sh;
+    lephuff::HuffDecWave w;
+    lephuff::HuffDecImage im;
+    memcpy(&im, img, sizeof im);
+    im.rows_off = 0;
+    w.run(&im, &sh, reinterpret_cast<lephuff::HuffDecRow*>(rows));
+    return 0;
+}

@@ -280,3 +280,69 @@ def test_gpu_huffman_encoder_on_cpu_restores_the_jpeg(emu, name):
     got = out.tobytes()
     L.lep_free(out.data)
     assert got == jpg
+
+
+@pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "synth_rst"])
+def test_gpu_huffman_decoder_on_cpu_matches_host_parser(emu, name):
+    """lep_huffdec.h (wave-per-image JPEG Huffman scan decode) as a 64-lane loop emulation + parse_jpeg_finish_gpu: for
+    every eligible file the coefficient frame, the hand-off records and the pad bit equal the host parser's, so the .lep
+    written from them is the reference's"""
+    import io
+    from lepton_amd import abi, corpus
+
+    if name == "synth_640x360":
+        jpg = corpus.synth_jpeg(640, 360, 71, quality=88)
+    elif name == "synth_rst":
+        from PIL import Image
+        import numpy as np
+        rng = np.random.default_rng(9)
+        im = Image.fromarray(rng.integers(0, 256, (96, 160, 3), dtype=np.uint8), "RGB")
+        buf = io.BytesIO(); im.save(buf, format="JPEG", quality=70, subsampling="4:2:0", restart_marker_blocks=3)
+        jpg = buf.getvalue()
+    else:
+        jpg, _ = golden(name)
+    L = abi.lib()
+    host = JpegImage(jpg)
+    h = C.c_void_p()
+    img = abi.HuffDecImage()
+    ok = C.c_int(0)
+    rc = L.lep_jpeg_open_gpu(jpg, len(jpg), C.byref(h), C.byref(img), C.byref(ok))
+    assert rc == 0
+    if not ok.value:
+        L.lep_jpeg_close(h)
+        pytest.skip("not eligible for the GPU Huffman decoder (grey, truncated, multi-scan, ...): host parser only")
+    p, n = C.c_void_p(), C.c_size_t(0)
+    L.lep_jpeg_scan_bytes(h, C.byref(p), C.byref(n))
+    scan = C.create_string_buffer(C.string_at(p, n.value) + b"\0" * 64, n.value + 64)   # zero padded copy ("device" arena)
+    base = C.addressof(scan)
+    assert base % 8 == 0
+    img.scan = base
+    d = host.desc
+    planes = []
+    for c in range(d.ncomp):
+        b = C.create_string_buffer(d.nblocks(c) * 128)
+        planes.append(b)
+        img.blocks[c] = C.cast(b, C.c_void_p).value
+    rows = (abi.HuffDecRow * (img.mcuv + 1))()
+    assert emu.emu_huffman_decode_image(C.byref(img), rows) == 0
+    assert rows[img.mcuv].aux >> 8 == 0, "kernel reported an irregular scan on a clean fixture"
+    for c in range(d.ncomp):
+        assert planes[c].raw == C.string_at(d.blocks[c], d.nblocks(c) * 128)
+    assert L.lep_jpeg_finish_gpu(h, rows) == 0
+    # the container written from the GPU-side parse == the one from the host parse (== the reference's for the fixtures)
+    segs = host.plan()
+    streams, _ = ob.oracle_encode(d, segs)
+    want = host.write_lep(streams)
+    arr = (abi.Bytes * len(streams))()
+    keep = []
+    for i, s in enumerate(streams):
+        b = C.create_string_buffer(bytes(s), max(1, len(s)))
+        keep.append(b)
+        arr[i].data = C.cast(b, C.c_void_p).value
+        arr[i].len = arr[i].cap = len(s)
+    out = abi.Bytes()
+    assert L.lep_jpeg_write_lep(h, 0, arr, len(streams), C.byref(out)) == 0
+    got = out.tobytes()
+    L.lep_free(out.data)
+    L.lep_jpeg_close(h)
+    assert got == want
