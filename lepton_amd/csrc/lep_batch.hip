@@ -247,10 +247,11 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         c->frame_bytes = bytes;
         chunks.push_back(std::move(c));
     }
-    hipStream_t s_copy = nullptr, s_compute = nullptr, s_down = nullptr;
+    hipStream_t s_copy = nullptr, s_compute = nullptr, s_down = nullptr, s_huff = nullptr;
     HIPOK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
     HIPOK(hipStreamCreateWithFlags(&s_compute, hipStreamNonBlocking));
     HIPOK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+    HIPOK(hipStreamCreateWithFlags(&s_huff, hipStreamNonBlocking));   // Huffman decode of chunk k+1 beside the coder kernels of chunk k
     Slot* slots = g_slots;   // grow-only staging cache shared by the batch calls (lep_batch_release frees it)
     g_alloc_s = 0;
     int rc_all = 0;
@@ -361,10 +362,10 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 }
                 launch.push_back(hi); which.push_back(k);
             }
-            HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
-            if (int rc = lep_gpu_huffman_decode_device(g, launch.data(), (int)launch.size(), (lep_huffdec_row*)s->d_rows, s_compute)) return rc;
-            HIPOK(hipMemcpyAsync(rows.data(), s->d_rows, rows_total * sizeof(lep_huffdec_row), hipMemcpyDeviceToHost, s_compute));
-            HIPOK(hipStreamSynchronize(s_compute));
+            HIPOK(hipStreamWaitEvent(s_huff, s->up, 0));
+            if (int rc = lep_gpu_huffman_decode_device(g, launch.data(), (int)launch.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc;
+            HIPOK(hipMemcpyAsync(rows.data(), s->d_rows, rows_total * sizeof(lep_huffdec_row), hipMemcpyDeviceToHost, s_huff));
+            HIPOK(hipStreamSynchronize(s_huff));
             st.d2h_bytes += (double)(rows_total * sizeof(lep_huffdec_row));
             // hand-offs from the row records; irregular scans go back to the host parser (and their frames up again)
             t0 = now_s();
@@ -501,7 +502,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     st.pipeline_s = now_s() - t_pipe;
     for (int i = 0; i < n; ++i) if (parsed[i]) lep_jpeg_close(parsed[i]);
     st.alloc_s = g_alloc_s;
-    (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_compute); (void)hipStreamDestroy(s_down);
+    (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_compute); (void)hipStreamDestroy(s_down); (void)hipStreamDestroy(s_huff);
     st.wall_s = now_s() - t_begin;
     if (stats) *stats = st;
     return rc_all;

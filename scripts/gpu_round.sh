@@ -61,3 +61,10 @@ echo "rocprof rc=$?"; find $OUT/prof -name '*kernel_stats*' | head -1 | xargs -r
 # keep only the summaries (the per-dispatch trace is large)
 find $OUT/prof -name '*kernel_trace*' -size +8M -delete
 
+
+# end-to-end batch pipeline (host memory -> host memory) and the kernel times of its Huffman stages
+timeout 600 python scripts/bench_batch.py --images 4096 --unique 64 > $OUT/batch_1080p_4096.json 2> $OUT/batch.err; echo "batch 1080p rc=$?"
+timeout 600 python scripts/bench_batch.py --images 2048 --unique 16 --width 3840 --height 2160 > $OUT/batch_4k_2048.json 2>> $OUT/batch.err; echo "batch 4k rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_batch -o trace --output-format csv -- python scripts/bench_batch.py --images 1024 --unique 16 --width 3840 --height 2160 > $OUT/batch_4k_1024_under_rocprof.json 2>> $OUT/batch.err
+find $OUT/prof_batch -name '*kernel_stats*' | head -1 | xargs -r head -8; find $OUT/prof_batch -name '*kernel_trace*' -size +8M -delete
+tail -n1 $OUT/batch_1080p_4096.json | cut -c1-600; tail -n1 $OUT/batch_4k_2048.json | cut -c1-600; stamp batch
