@@ -61,6 +61,11 @@ struct Dec4Shared {
 WDEV int nzbin_of(int left) {
     return left < 16 ? (int)((0x7776666555443210ull >> (4 * left)) & 15) : (left < 21 ? 7 : (left < 32 ? 8 : 9));
 }
+// largest "non-zeros left" that still maps to bin b (inverse of kNzBin): 0,1,2,3,5,8,12,20,31,49
+WDEV int nzhi_of(int b) { return (int)((0xc5f50c2050c2040ull >> (6 * b)) & 63); }
+#ifndef LEP_DEC4_CANDS
+#define LEP_DEC4_CANDS 4
+#endif
 // first combo of edge position j (combos of a position = its reachable "non-zeros left" values 1 .. 7-j): 0,7,13,18,22,25,27
 WDEV int combo_base(int j) { return (int)((0x1b65648d1c0ull >> (6 * j)) & 63); }
 
@@ -415,12 +420,14 @@ struct Dec4Wave {
         LANES(l) {
             const int pi = l & 15, cand = l >> 4, p = zz0 + pi, nb = nb0 - cand;
             uint32_t adr0 = 0, adr1 = 0, pk0 = 0, pk1 = 0;
-            const int valid = p < 49 && nb >= 1;
+            // candidate `cand` can only be in force at window position pi if enough non-zeros can have come before it
+            const int valid = p < 49 && nb >= 1 && cand < LEP_DEC4_CANDS && pi >= left0 - nzhi_of(nb < 0 ? 0 : nb);
             if (valid) {
                 adr0 = ctx_exp7(ci, nb, p, S.bsr[p]);
                 adr1 = ctx_res(ci, S.a2r[p], nb);
-                L(W0) = ld4(model + adr0); L(W1) = ld4(model + adr1);
-                pk0 = pack_probs(L(W0)); pk1 = pack_probs(L(W1));
+                L(W0) = ld4(model + adr0);
+                pk0 = pack_probs(L(W0));
+                L(W1) = ld4(model + adr1); pk1 = pack_probs(L(W1));
 
             }
             L(a0) = adr0; L(a1) = adr1; L(PK0) = pk0; L(PK1) = pk1; L(ok) = valid;
@@ -460,7 +467,7 @@ struct Dec4Wave {
                 S.here[zz] = (int16_t)(pos ? (int)v : -(int)v);
                 if (left == 0) { ++zz; break; }
                 cand = nb0 - nzbin_of(left);
-                if (cand >= 4) { ++zz; break; }
+                if (cand >= LEP_DEC4_CANDS) { ++zz; break; }
             }
             if (++zz >= zz_end) break;
         }
@@ -522,8 +529,9 @@ struct Dec4Wave {
                 const int bsr = bitlen(ap > 1023 ? 1023 : ap);
                 adr0 = ctx_expx(ci, n, horizontal ? j : j + 7, bsr);
                 adr2 = ctx_res(ci, coord, n);
-                L(W0) = ld4(model + adr0); L(W1) = ld4(model + adr0 + 4); L(W2) = ld4(model + adr2);
-                pk0 = pack_probs(L(W0)); pk1 = pack_probs(L(W1)); pk2 = pack_probs(L(W2));
+                L(W0) = ld4(model + adr0); L(W2) = ld4(model + adr2);
+                pk0 = pack_probs(L(W0)); pk2 = pack_probs(L(W2));
+                L(W1) = U4{0, 0, 0, 0};   // exponent words 4..7 (|v| >= 8) are read on demand, like the interior's
                 const int16_t p16 = (int16_t)prior;
                 const int thr = S.thr[coord];
                 const uint32_t tctx = (uint32_t)imin((int)((ap & 0xffff) >> thr), 255);
@@ -557,7 +565,7 @@ struct Dec4Wave {
                 if (len) {
                     const int coord = horizontal ? j + 1 : (j + 1) * 8;
                     if (len == 4) {
-                        len += dec_unary4(lepwave::wave_read(PK1, lane));
+                        len += dec_unary4(pack_probs(vload4(model + ctx_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)) + 4)));
                         if (len == 8) len = dec_unary_tail(ctx_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)));
                     }
                     nbins += (uint32_t)(2 * len - (len == 11));
@@ -623,6 +631,7 @@ struct Dec4Wave {
         adapt_group(W0, u0, b0);
         LANES(l) if (L(u0)) st4(model + L(a0), L(W0));
         if (lepwave::wave_ballot(u1)) {
+            LANES(l) if (L(u1)) L(W1) = ld4(model + L(a0) + 4);   // read on demand by the serial code: the owner re-reads it
             adapt_group(W1, u1, b1);
             LANES(l) if (L(u1)) st4(model + L(a0) + 4, L(W1));
         }

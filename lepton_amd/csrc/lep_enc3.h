@@ -448,8 +448,23 @@ struct Enc3Wave {
             const int Dn = lepwave::wave_excl_scan(dcount, dtmp);   // threshold bins in this range
             LSYNC();
 
+            // ---- P3: model words of all bins of the range in ONE HBM round trip ------------------------------
+            // threshold bins (their Branch can repeat inside a block: in-order forwarding below) are requested first, then the
+            // bins with a block-unique Branch, two rounds of loads in flight before the first use
+            LV(uint32_t, didx); LV(uint32_t, dw); LV(uint32_t, dbit); LV(int, djpos); LV(int, dlast);
+            const int nn0 = Dn < 64 ? Dn : 64;
+            LANES(l) {
+                uint32_t idx = 0xffffffffu, w = 0, bit = 0;
+                int j = -1;
+                if (l < nn0) {
+                    j = S.dup[l];
+                    const uint32_t e = S.bins[j];
+                    idx = e & 0x3fffffffu; bit = e >> 31;
+                    w = model[idx];
+                }
+                L(didx) = idx; L(dw) = w; L(dbit) = bit; L(djpos) = j; L(dlast) = 1;
+            }
             // ---- P3a: bins with a block-unique Branch: parallel load / adapt / store ------------------
-            // (two rounds of loads are issued before the first use, so their HBM latencies overlap)
             for (int b0 = 0; b0 < n; b0 += 128) {
                 LV(uint32_t, w0); LV(uint32_t, w1);
                 LANES(l) {
@@ -474,31 +489,46 @@ struct Enc3Wave {
                     }
                 }
             }
-            // ---- P3b: threshold bins (rare; their Branch can repeat inside a block): in-order forwarding ---
+            // ---- P3b: threshold bins ---------------------------------------------------------------------------
             LEP_EMARK("e_p3b");
-        for (int cb = 0; cb < Dn; cb += 64) {
-                LV(uint32_t, didx); LV(uint32_t, dw); LV(uint32_t, dbit); LV(int, djpos); LV(int, dlast);
+            for (int cb = 0; cb < Dn; cb += 64) {
                 const int nn = Dn - cb < 64 ? Dn - cb : 64;
-                LANES(l) {
-                    uint32_t idx = 0xffffffffu, w = 0, bit = 0;
-                    int j = -1;
-                    if (l < nn) {
-                        j = S.dup[cb + l];
-                        const uint32_t e = S.bins[j];
-                        idx = e & 0x3fffffffu; bit = e >> 31;
-                        w = model[idx];
-                    }
-                    L(didx) = idx; L(dw) = w; L(dbit) = bit; L(djpos) = j; L(dlast) = 1;
-                }
-                for (int r = 0; r < nn; ++r) {
-                    const uint32_t ridx = lepwave::wave_read(didx, r), rw = lepwave::wave_read(dw, r), rbit = lepwave::wave_read(dbit, r);
-                    const uint32_t nw = bupd_s(rw, (int)rbit);
+                if (cb) {   // further groups of 64 (blocks with very large edge coefficients)
                     LANES(l) {
-                        if (l == r) { S.bins[L(djpos)] = (rw >> 16) | (rbit << 8); L(dw) = nw; }
-                        else if (L(didx) == ridx) { if (l > r) L(dw) = nw; else L(dlast) = 0; }
+                        uint32_t idx = 0xffffffffu, w = 0, bit = 0;
+                        int j = -1;
+                        if (l < nn) {
+                            j = S.dup[cb + l];
+                            const uint32_t e = S.bins[j];
+                            idx = e & 0x3fffffffu; bit = e >> 31;
+                            w = model[idx];
+                        }
+                        L(didx) = idx; L(dw) = w; L(dbit) = bit; L(djpos) = j; L(dlast) = 1;
                     }
                 }
-                LANES(l) if (l < nn && L(dlast)) model[L(didx)] = L(dw);
+                // do two of them share a Branch?  (almost never: then every lane adapts its own word, no forwarding)
+                LV(int, conf);
+                LANES(l) L(conf) = 0;
+                for (int r = 0; r + 1 < nn; ++r) {
+                    const uint32_t ridx = lepwave::wave_read(didx, r);
+                    LANES(l) if (l > r && l < nn && L(didx) == ridx) L(conf) = 1;
+                }
+                if (!lepwave::wave_ballot(conf)) {
+                    LANES(l) if (l < nn) {
+                        S.bins[L(djpos)] = (L(dw) >> 16) | (L(dbit) << 8);
+                        model[L(didx)] = bupd(L(dw), (int)L(dbit));
+                    }
+                } else {
+                    for (int r = 0; r < nn; ++r) {
+                        const uint32_t ridx = lepwave::wave_read(didx, r), rw = lepwave::wave_read(dw, r), rbit = lepwave::wave_read(dbit, r);
+                        const uint32_t nw = bupd_s(rw, (int)rbit);
+                        LANES(l) {
+                            if (l == r) { S.bins[L(djpos)] = (rw >> 16) | (rbit << 8); L(dw) = nw; }
+                            else if (L(didx) == ridx) { if (l > r) L(dw) = nw; else L(dlast) = 0; }
+                        }
+                    }
+                    LANES(l) if (l < nn && L(dlast)) model[L(didx)] = L(dw);
+                }
                 LSYNC();
             }
             LSYNC();

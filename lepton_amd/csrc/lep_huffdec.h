@@ -100,22 +100,39 @@ struct HuffDecWave {
     }
     static WDEV int devli(uint32_t s, uint32_t n) { return s == 0 ? (int)n : (n >= (1u << (s - 1)) ? (int)n : (int)n + 1 - (1 << s)); }
 
+    // Huffman symbol of table t AND the `s` magnitude bits that follow it in one window step (code <= 9 bits through the
+    // LUT, s <= 15: both inside the top 32 bits of the window); the code-tree walk handles longer codes.  dc: s = symbol,
+    // else s = low nibble.  Returns the symbol (-1 invalid) and the raw magnitude bits through *n.
+    WDEV int symbol_and_bits(int t, bool dc, uint32_t* n) {
+        const uint32_t e = sh->lut[t][hi >> 23];
+        if (ucond((e >> 8) != 0)) {
+            const uint32_t len = e >> 8, sym = e & 255u, s = dc ? sym : (sym & 15u);
+            if (ucond(s > 16)) return -1;
+            *n = s ? (hi << len) >> (32 - s) : 0u;
+            consume(len + s);
+            return (int)sym;
+        }
+        const int sym = symbol(t);
+        if (ucond(sym < 0)) return -1;
+        const uint32_t s = dc ? (uint32_t)sym : ((uint32_t)sym & 15u);
+        if (ucond(s > 16)) return -1;
+        *n = read(s);
+        return sym;
+    }
+
     // decode_block_seq (jpgcoder.cc:4893-4966) into sh->blk; returns the DC difference through *diff; false = irregular
     WDEV bool decode_block(int dct, int act, int* diff) {
-        int hc = symbol(dct);
-        if (hc < 0) return false;
-        uint32_t s = (uint32_t)hc & 255u;
-        if (s > 16) return false;
-        *diff = devli(s, read(s));
+        uint32_t n = 0;
+        int hc = symbol_and_bits(dct, true, &n);
+        if (ucond(hc < 0)) return false;
+        *diff = devli((uint32_t)hc & 255u, n);
         uint32_t bpos = vec(1);
 #pragma nounroll
         while (ucond(bpos < 64)) {
-            hc = symbol(act);
-            if (hc < 0) return false;
-            if (hc == 0) break;                       // EOB
-            const uint32_t z = ((uint32_t)hc >> 4) & 15u;
-            s = (uint32_t)hc & 15u;
-            const uint32_t n = read(s);
+            hc = symbol_and_bits(act, false, &n);
+            if (ucond(hc < 0)) return false;
+            if (ucond(hc == 0)) break;                // EOB
+            const uint32_t z = ((uint32_t)hc >> 4) & 15u, s = (uint32_t)hc & 15u;
             if (ucond(z + bpos >= 64)) return false;  // zero run past the block: the host parser knows what the reference does
             bpos += z;
             sh->blk[sh->z2a[bpos]] = (int16_t)devli(s, n);
