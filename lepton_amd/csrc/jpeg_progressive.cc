@@ -1,0 +1,458 @@
+// jpeg_progressive.cc -- progressive JPEG scans on the host (BASELINE.json configs[4]): Huffman decode of DC / AC first
+// and refinement scans into the coefficient frame, and the re-encode that restores the original scan bytes.  The GPU hot
+// path (the arithmetic coder over the finished coefficient frame) is identical for progressive files; only this
+// Huffman side differs.  Behaviour follows the reference's packJPG-derived scan coders:
+//   decode: decode_jpeg's scan loop            src/lepton/jpgcoder.cc:2975-3260
+//           decode_dc_prg_fs / _sa, decode_ac_prg_fs / _sa, decode_eobrun_sa, skip_eobrun   :4968-5335, :5462-5500
+//   encode: recode_jpeg                         src/lepton/jpgcoder.cc:3309-3716
+//           encode_dc_prg_*, encode_ac_prg_fs / _sa, encode_eobrun, encode_crbits            :4991-5400
+//   output: merge_jpeg_streaming (scan bytes + FF00 stuffing + RSTn at the recorded positions)  :2562-2730
+// Successive approximation keeps every coefficient at full scale in the frame: a first-stage scan stores value << Al,
+// a refinement scan adds bit << Al (jpgcoder.cc:3001-3006, 3178-3182, 3243-3247).
+#include <algorithm>
+#include <cstring>
+
+#include "jpeg_bits.h"
+#include "lep_container.h"
+
+namespace lep {
+
+int next_mcupos(const JpegFile& jf, int* mcu, int* cmp, int* csc, int* sub, int* dpos, int* rstw, int cs_cmpc);
+int next_mcuposn(const JpegFile& jf, int cmp, int* dpos, int* rstw);
+Handoff make_handoff_public(BitReader& br, const JpegFile& jf, int mcu_y, const int lastdc[4], int luma_mul);
+
+namespace {
+
+inline int devli(int s, int n) { return s == 0 ? n : (n >= (1 << (s - 1)) ? n : n + 1 - (1 << s)); }
+inline unsigned envli(int s, int v) { return (unsigned)((v > 0) ? v : (v - 1) + (1 << s)) & ((1u << s) - 1); }
+inline int blen16(unsigned v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+inline int fdiv2(int v, int p) { return v < 0 ? -((-v) >> p) : (v >> p); }
+
+// ---- decoding one block of a scan ----------------------------------------------------------------------------------
+// AC first stage: coefficients from..to, or an end-of-band run (returns the eob position, -1 on error)
+int decode_ac_first(BitReader& br, const HuffTable& ac, int16_t* blk, unsigned* eobrun, int from, int to) {
+    int eob = to + 1;
+    if (*eobrun > 0) {
+        for (int b = from; b <= to; ++b) blk[b] = 0;
+        --*eobrun;
+        return from;
+    }
+    for (int bpos = from; bpos <= to;) {
+        const int hc = next_huffcode(br, ac);
+        if (hc < 0) return -1;
+        const int l = (hc >> 4) & 15, r = hc & 15;
+        if (l == 15 || r > 0) {
+            int z = l;
+            const int n = (int)br.read(r);
+            if (z + bpos > to) return -1;
+            while (z > 0) { blk[bpos++] = 0; --z; }
+            blk[bpos++] = (int16_t)devli(r, n);
+        } else {
+            eob = bpos;
+            const int n = (int)br.read(l);
+            *eobrun = (unsigned)(n + (1 << l));
+            --*eobrun;
+            break;
+        }
+    }
+    return eob;
+}
+
+// AC refinement: new +-1 coefficients and correction bits of the already non-zero ones
+int decode_ac_refine(BitReader& br, const HuffTable& ac, int16_t* blk, unsigned* eobrun, int from, int to) {
+    int bpos = from, eob = to;
+    if (*eobrun == 0)
+        while (bpos <= to) {
+            const int hc = next_huffcode(br, ac);
+            if (hc < 0) return -1;
+            const int l = (hc >> 4) & 15, r = hc & 15;
+            if (l == 15 || r > 0) {
+                int z = (int8_t)l, v;
+                if (r == 0) v = 0;
+                else if (r == 1) v = br.read(1) == 0 ? -1 : 1;
+                else return -1;
+                for (;;) {
+                    if (blk[bpos] == 0) {
+                        if (z > 0) --z;
+                        else { blk[bpos++] = (int16_t)v; break; }
+                    } else {
+                        const int n = (int)br.read(1);
+                        blk[bpos] = (int16_t)(blk[bpos] > 0 ? n : -n);
+                    }
+                    if (bpos++ >= to) return -1;
+                }
+            } else {
+                eob = bpos;
+                const int n = (int)br.read(l);
+                *eobrun = (unsigned)(n + (1 << l));
+                break;
+            }
+        }
+    if (*eobrun > 0) {
+        for (; bpos <= to; ++bpos)
+            if (blk[bpos] != 0) {
+                const int n = (int)br.read(1);
+                blk[bpos] = (int16_t)(blk[bpos] > 0 ? n : -n);
+            }
+        --*eobrun;
+    }
+    return eob;
+}
+
+int decode_eobrun_refine(BitReader& br, int16_t* blk, unsigned* eobrun, int from, int to) {
+    for (int bpos = from; bpos <= to; ++bpos)
+        if (blk[bpos] != 0) {
+            const int n = (int)br.read(1);
+            blk[bpos] = (int16_t)(blk[bpos] > 0 ? n : -n);
+        }
+    --*eobrun;
+    return 0;
+}
+
+// blocks covered by an end-of-band run are skipped as a whole (jpgcoder.cc:5462-5500)
+int skip_eobrun(const JpegFile& jf, int cmp, int* dpos, int* rstw, unsigned* eobrun) {
+    if (*eobrun == 0) return 0;
+    const Component& k = jf.comp[cmp];
+    if (jf.rsti > 0) {
+        if ((int)*eobrun > *rstw) return -1;
+        *rstw -= (int)*eobrun;
+    }
+    if (k.bch != k.nch) *dpos += (int)((((unsigned)(*dpos % k.bch) + *eobrun) / (unsigned)k.nch) * (unsigned)(k.bch - k.nch));
+    if (k.bcv != k.ncv && *dpos / k.bch >= k.ncv) *dpos += (k.bcv - k.ncv) * k.bch;
+    *dpos += (int)*eobrun;
+    *eobrun = 0;
+    if (*dpos == k.bc) return 2;
+    if (*dpos > k.bc) return -1;
+    if (jf.rsti > 0 && *rstw == 0) return 1;
+    return 0;
+}
+
+}  // namespace
+
+// One restart interval of one progressive scan (the caller, decode_scans, owns the interval loop, the pad-bit check and
+// the scan bookkeeping).  Returns an ExitCode; *sta_io = 0 / 1 restart / 2 scan done / -1 decode error.
+int decode_progressive_scan(JpegFile* jf, BitReader& br, int* lastdc, int* sta_io, int* cmp_io, int* dpos_io, int* mcu_io,
+                            int* csc_io, int* sub_io, int* rstw_io, unsigned* eobrun_io, int* peobrun_io, bool* do_handoff) {
+    int sta = *sta_io, cmp = *cmp_io, dpos = *dpos_io, mcu = *mcu_io, csc = *csc_io, sub = *sub_io, rstw = *rstw_io;
+    unsigned eobrun = *eobrun_io;
+    int peobrun = *peobrun_io;
+    const int luma_mul = jf->comp[0].bcv / jf->mcuv;
+    const int from = jf->cs_from, to = jf->cs_to, sal = jf->cs_sal;
+    int16_t blk[64];
+    auto dc_of = [&](int c, int d) -> int16_t& { return jf->plane[c][(size_t)d * 64 + kZigzagToAligned[0]]; };
+    auto note_max = [&]() { if (!br.eof) jf->max_dpos[cmp] = std::max(dpos, jf->max_dpos[cmp]); };
+
+    if (jf->cs_cmpc > 1) {   // interleaved: DC only
+        if (jf->cs_sah == 0) {
+            while (sta == 0) {
+                if (*do_handoff) { jf->rows.push_back(make_handoff_public(br, *jf, mcu / jf->mcuh, lastdc, luma_mul)); *do_handoff = false; }
+                note_max();
+                const HuffTable& t = jf->htab[0][jf->comp[cmp].dc_tbl];
+                const int hc = next_huffcode(br, t);
+                int diff = 0;
+                if (hc < 0) sta = -1;
+                else diff = devli(hc & 255, (int)br.read(hc & 255));
+                const int16_t v = (int16_t)((int16_t)diff + lastdc[cmp]);
+                lastdc[cmp] = v;
+                dc_of(cmp, dpos) = (int16_t)((uint16_t)v << sal);
+                const int old_mcu = mcu;
+                if (sta != -1) sta = next_mcupos(*jf, &mcu, &cmp, &csc, &sub, &dpos, &rstw, jf->cs_cmpc);
+                if (mcu % jf->mcuh == 0 && old_mcu != mcu) *do_handoff = true;
+                if (br.eof) { sta = 2; break; }
+            }
+        } else {
+            while (sta == 0) {
+                note_max();
+                const int bit = (int)br.read(1);
+                dc_of(cmp, dpos) = (int16_t)(dc_of(cmp, dpos) + (int16_t)(bit << sal));
+                sta = next_mcupos(*jf, &mcu, &cmp, &csc, &sub, &dpos, &rstw, jf->cs_cmpc);
+                if (br.eof) { sta = 2; break; }
+            }
+        }
+    } else if (to == 0) {    // non-interleaved DC
+        if (jf->cs_sah == 0) {
+            while (sta == 0) {
+                if (*do_handoff) { jf->rows.push_back(make_handoff_public(br, *jf, dpos / jf->comp[cmp].bch, lastdc, luma_mul)); *do_handoff = false; }
+                note_max();
+                const HuffTable& t = jf->htab[0][jf->comp[cmp].dc_tbl];
+                const int hc = next_huffcode(br, t);
+                int diff = 0;
+                if (hc < 0) sta = -1;
+                else diff = devli(hc & 255, (int)br.read(hc & 255));
+                const int16_t v = (int16_t)((int16_t)diff + lastdc[cmp]);
+                lastdc[cmp] = v;
+                dc_of(cmp, dpos) = (int16_t)((uint16_t)v << sal);
+                if (sta != -1) sta = next_mcuposn(*jf, cmp, &dpos, &rstw);
+                if (cmp == 0 && dpos % jf->comp[cmp].bch == 0) *do_handoff = true;
+                if (br.eof) { sta = 2; break; }
+            }
+        } else {
+            while (sta == 0) {
+                note_max();
+                const int bit = (int)br.read(1);
+                dc_of(cmp, dpos) = (int16_t)(dc_of(cmp, dpos) + (int16_t)(bit << sal));
+                sta = next_mcuposn(*jf, cmp, &dpos, &rstw);
+                if (br.eof) { sta = 2; break; }
+            }
+        }
+    } else {                 // non-interleaved AC
+        const HuffTable& t = jf->htab[1][jf->comp[cmp].ac_tbl];
+        if (jf->cs_sah == 0) {
+            while (sta == 0) {
+                note_max();
+                const int eob = decode_ac_first(br, t, blk, &eobrun, from, to);
+                if (eob == from && eobrun > 0 && peobrun > 0 && peobrun < t.max_eobrun - 1) jf->warn = std::max(jf->warn, 1);
+                int16_t* dst = jf->plane[cmp] + (size_t)dpos * 64;
+                for (int b = from; b < eob; ++b) dst[kZigzagToAligned[b]] = (int16_t)((uint16_t)blk[b] << sal);
+                if (eob < 0) sta = -1;
+                else sta = skip_eobrun(*jf, cmp, &dpos, &rstw, &eobrun);
+                if (sta == 0) sta = next_mcuposn(*jf, cmp, &dpos, &rstw);
+                if (br.eof) { sta = 2; break; }
+            }
+        } else {
+            while (sta == 0) {
+                int16_t* dst = jf->plane[cmp] + (size_t)dpos * 64;
+                for (int b = from; b <= to; ++b) blk[b] = dst[kZigzagToAligned[b]];
+                int eob;
+                if (eobrun == 0) {
+                    note_max();
+                    eob = decode_ac_refine(br, t, blk, &eobrun, from, to);
+                    if (eob == from && eobrun > 0 && peobrun > 0 && peobrun < t.max_eobrun - 1) jf->warn = std::max(jf->warn, 1);
+                } else {
+                    note_max();
+                    eob = decode_eobrun_refine(br, blk, &eobrun, from, to);
+                }
+                peobrun = (int)eobrun;
+                for (int b = from; b <= to; ++b) dst[kZigzagToAligned[b]] = (int16_t)(dst[kZigzagToAligned[b]] + (int16_t)((uint16_t)blk[b] << sal));
+                if (eob < 0) sta = -1;
+                else sta = next_mcuposn(*jf, cmp, &dpos, &rstw);
+                if (br.eof) { sta = 2; break; }
+            }
+        }
+    }
+    *sta_io = sta; *cmp_io = cmp; *dpos_io = dpos; *mcu_io = mcu; *csc_io = csc; *sub_io = sub; *rstw_io = rstw;
+    *eobrun_io = eobrun; *peobrun_io = peobrun;
+    return 0;
+}
+
+// ---- re-encoding ----------------------------------------------------------------------------------------------------
+namespace {
+
+struct ScanWriter {
+    BitWriter w;
+    std::vector<uint8_t> corr;   // correction bits waiting for the next code (abytewriter storw)
+    void put(unsigned v, int n) { w.put(v, n); }
+    void code(const HuffTable& t, int sym) { w.put(t.cval[sym & 255], t.clen[sym & 255]); }
+    void flush_corr() { for (uint8_t b : corr) w.put(b, 1); corr.clear(); }
+    void eobrun(const HuffTable& ac, unsigned* run) {
+        if (*run == 0) return;
+        while (*run > (unsigned)ac.max_eobrun) {
+            code(ac, 0xE0);
+            put((unsigned)(32767 - (1 << 14)), 14);
+            *run -= (unsigned)ac.max_eobrun;
+        }
+        int s = blen16(*run & 0xffff);
+        if (s) --s;
+        code(ac, s << 4);
+        put(*run - (1u << s), s);
+        *run = 0;
+    }
+};
+
+int encode_ac_first(ScanWriter& sw, const HuffTable& ac, const int16_t* blk, unsigned* eobrun, int from, int to) {
+    int z = 0;
+    for (int bpos = from; bpos <= to; ++bpos) {
+        const int t = blk[bpos];
+        if (t != 0) {
+            sw.eobrun(ac, eobrun);
+            while (z >= 16) { sw.code(ac, 0xF0); z -= 16; }
+            const int s = blen16((unsigned)(t > 0 ? t : -t) & 0xffff);
+            sw.code(ac, (z << 4) + s);
+            sw.put(envli(s, t), s);
+            z = 0;
+        } else ++z;
+    }
+    if (z > 0) {
+        ++*eobrun;
+        if (*eobrun == (unsigned)ac.max_eobrun) sw.eobrun(ac, eobrun);
+        return 1 + to - z;
+    }
+    return 1 + to;
+}
+
+int encode_ac_refine(ScanWriter& sw, const HuffTable& ac, const int16_t* blk, unsigned* eobrun, int from, int to) {
+    int eob = from;
+    for (int bpos = to; bpos >= from; --bpos)
+        if (blk[bpos] == 1 || blk[bpos] == -1) { eob = bpos + 1; break; }
+    if (eob > from && *eobrun > 0) { sw.eobrun(ac, eobrun); sw.flush_corr(); }
+    int z = 0, bpos = from;
+    for (; bpos < eob; ++bpos) {
+        const int t = blk[bpos];
+        if (t == 0) {
+            if (++z == 16) { sw.code(ac, 0xF0); sw.flush_corr(); z = 0; }
+        } else if (t == 1 || t == -1) {
+            sw.code(ac, (z << 4) + 1);
+            sw.put(envli(1, t), 1);
+            sw.flush_corr();
+            z = 0;
+        } else sw.corr.push_back((uint8_t)(t & 1));
+    }
+    for (; bpos <= to; ++bpos)
+        if (blk[bpos] != 0) sw.corr.push_back((uint8_t)(blk[bpos] & 1));
+    if (eob <= to) {
+        ++*eobrun;
+        if (*eobrun == (unsigned)ac.max_eobrun) { sw.eobrun(ac, eobrun); sw.flush_corr(); }
+    }
+    return eob;
+}
+
+}  // namespace
+
+// recode_jpeg + merge_jpeg for files that are not a single interleaved sequential scan ('X' files)
+int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
+    JpegFile& jf = lf->jpeg;
+    const size_t max_file_size = lf->jpeg_size;
+    if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
+    if (jf.early_eof) return EX_PROGRESSIVE_UNSUPPORTED;   // truncated progressive files: not supported yet
+    const uint8_t* h = jf.hdr.data();
+    const size_t hdrs = jf.hdr.size();
+
+    // 1. all scans into one un-stuffed byte string, remembering where scans start and restart markers go
+    ScanWriter sw;
+    sw.w.fillbit = (uint8_t)jf.padbit;
+    std::vector<size_t> scnp, rstp;
+    std::vector<size_t> scan_hdr_end;   // header position after each SOS
+    size_t hpos = 0;
+    int16_t blk[64];
+    for (;;) {
+        uint8_t type = 0;
+        while (type != 0xDA) {
+            if (hpos >= hdrs) break;
+            type = hpos + 1 < hdrs ? h[hpos + 1] : 0;
+            const unsigned len = 2 + (((unsigned)(hpos + 2 < hdrs ? h[hpos + 2] : 0)) << 8) + (hpos + 3 < hdrs ? h[hpos + 3] : 0);
+            if (type == 0xC4 || type == 0xDA || type == 0xDD)
+                if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - hpos), h + hpos, false)) return EX_CODING_ERROR;
+            hpos += len;
+        }
+        if (type != 0xDA) break;
+        scan_hdr_end.push_back(std::min(hpos, hdrs));
+        scnp.push_back(sw.w.bytes.size());
+        int cmp = jf.cs_cmp[0], csc = 0, mcu = 0, sub = 0, dpos = 0;
+        const int from = jf.cs_from, to = jf.cs_to, sal = jf.cs_sal;
+        for (;;) {   // one restart interval per iteration
+            int lastdc[4] = {0, 0, 0, 0};
+            int sta = 0, rstw = jf.rsti;
+            unsigned eobrun = 0;
+            auto dc_of = [&](int c, int d) -> int { return jf.plane[c][(size_t)d * 64 + kZigzagToAligned[0]]; };
+            if (jf.cs_cmpc > 1) {
+                if (jf.jpegtype == 1) return EX_CODING_ERROR;   // 'X' files with interleaved sequential scans of a component subset: not handled
+                if (jf.cs_sah == 0) {
+                    while (sta == 0) {
+                        const int tmp = dc_of(cmp, dpos) >> sal;
+                        const int d = (int16_t)(tmp - lastdc[cmp]);
+                        lastdc[cmp] = tmp;
+                        const int s = blen16((unsigned)(d > 0 ? d : -d) & 0xffff);
+                        sw.code(jf.htab[0][jf.comp[cmp].dc_tbl], s);
+                        sw.put(envli(s, d), s);
+                        sta = next_mcupos(jf, &mcu, &cmp, &csc, &sub, &dpos, &rstw, jf.cs_cmpc);
+                    }
+                } else {
+                    while (sta == 0) {
+                        sw.put((unsigned)((dc_of(cmp, dpos) >> sal) & 1), 1);
+                        sta = next_mcupos(jf, &mcu, &cmp, &csc, &sub, &dpos, &rstw, jf.cs_cmpc);
+                    }
+                }
+            } else if (jf.jpegtype == 1) {
+                while (sta == 0) {   // sequential, one component per scan
+                    const int16_t* src = jf.plane[cmp] + (size_t)dpos * 64;
+                    for (int b = 0; b < 64; ++b) blk[b] = src[kZigzagToAligned[b]];
+                    const int16_t dc = blk[0];
+                    blk[0] = (int16_t)(blk[0] - lastdc[cmp]);
+                    lastdc[cmp] = dc;
+                    const HuffTable& dct = jf.htab[0][jf.comp[cmp].dc_tbl];
+                    const HuffTable& act = jf.htab[1][jf.comp[cmp].ac_tbl];
+                    int t = blk[0], s = blen16((unsigned)(t > 0 ? t : -t) & 0xffff);
+                    sw.code(dct, s); sw.put(envli(s, t), s);
+                    int end = 63, z = 0;
+                    while (end && !blk[end]) --end;
+                    for (int b = 1; b <= end; ++b) {
+                        t = blk[b];
+                        if (!t) { ++z; continue; }
+                        s = blen16((unsigned)(t > 0 ? t : -t) & 0xffff);
+                        while (z & 0xf0) { sw.code(act, 0xF0); z -= 16; }
+                        sw.code(act, ((z & 0xf) << 4) + s);
+                        sw.put(envli(s, t), s);
+                        z = 0;
+                    }
+                    if (end != 63) sw.code(act, 0);
+                    sta = next_mcuposn(jf, cmp, &dpos, &rstw);
+                }
+            } else if (to == 0) {
+                if (jf.cs_sah == 0) {
+                    while (sta == 0) {
+                        const int tmp = dc_of(cmp, dpos) >> sal;
+                        const int d = (int16_t)(tmp - lastdc[cmp]);
+                        lastdc[cmp] = tmp;
+                        const int s = blen16((unsigned)(d > 0 ? d : -d) & 0xffff);
+                        sw.code(jf.htab[0][jf.comp[cmp].dc_tbl], s);
+                        sw.put(envli(s, d), s);
+                        sta = next_mcuposn(jf, cmp, &dpos, &rstw);
+                    }
+                } else {
+                    while (sta == 0) {
+                        sw.put((unsigned)((dc_of(cmp, dpos) >> sal) & 1), 1);
+                        sta = next_mcuposn(jf, cmp, &dpos, &rstw);
+                    }
+                }
+            } else {
+                const HuffTable& act = jf.htab[1][jf.comp[cmp].ac_tbl];
+                while (sta == 0) {
+                    const int16_t* src = jf.plane[cmp] + (size_t)dpos * 64;
+                    for (int b = from; b <= to; ++b) blk[b] = (int16_t)fdiv2(src[kZigzagToAligned[b]], sal);
+                    if (jf.cs_sah == 0) encode_ac_first(sw, act, blk, &eobrun, from, to);
+                    else encode_ac_refine(sw, act, blk, &eobrun, from, to);
+                    sta = next_mcuposn(jf, cmp, &dpos, &rstw);
+                }
+                sw.eobrun(act, &eobrun);
+                if (jf.cs_sah != 0) sw.flush_corr();
+            }
+            sw.w.pad((uint8_t)jf.padbit);
+            if (sta == 2) break;
+            if (sta == 1 && jf.rsti > 0) rstp.push_back(sw.w.bytes.size() - 1);
+            if (sta < 0) return EX_CODING_ERROR;
+        }
+    }
+    scnp.push_back(sw.w.bytes.size());
+    const std::vector<uint8_t>& huff = sw.w.bytes;
+
+    // 2. merge: SOI, then per scan the header part up to its SOS, the scan bytes (FF00 stuffing, RSTn after the recorded
+    //    bytes while the scan's marker budget lasts), misplaced RSTn at the scan end; then the rest of the header, garbage
+    std::vector<uint8_t> out;
+    out.reserve(max_file_size + 16);
+    const size_t bound = max_file_size - jf.garbage.size();
+    auto put = [&](uint8_t b) { if (out.size() < bound) out.push_back(b); };
+    if (lf->has_prefix) for (uint8_t b : lf->prefix_garbage) put(b);
+    if (lf->embedded || !lf->has_prefix) { put(0xFF); put(0xD8); }
+    size_t hp = 0, rpos = 0;
+    for (size_t scan = 0; scan < scan_hdr_end.size(); ++scan) {
+        for (size_t i = hp; i < scan_hdr_end[scan]; ++i) put(h[i]);
+        hp = scan_hdr_end[scan];
+        unsigned cpos = 0, nrst = 0;
+        for (size_t i = scnp[scan]; i < scnp[scan + 1]; ++i) {
+            put(huff[i]);
+            if (huff[i] == 0xFF) put(0x00);
+            if (rpos < rstp.size() && i == rstp[rpos]) {
+                const bool ok = !lf->rst_cnt_set || (jf.rst_cnt.size() > scan && nrst < jf.rst_cnt[scan]);
+                if (ok) { put(0xFF); put((uint8_t)(0xD0 + (cpos & 7))); ++rpos; ++cpos; ++nrst; }
+            }
+        }
+        if (scan < jf.rst_err.size())
+            for (unsigned k = 0; k < jf.rst_err[scan]; ++k) { put(0xFF); put((uint8_t)(0xD0 + (cpos & 7))); ++cpos; }
+    }
+    for (size_t i = hp; i < hdrs; ++i) put(h[i]);
+    for (size_t i = 0; i < jf.garbage.size() && out.size() < max_file_size; ++i) out.push_back(jf.garbage[i]);
+    result->swap(out);
+    return 0;
+}
+
+}  // namespace lep

@@ -116,7 +116,9 @@ struct RowCoder {
 // parameters the GPU Huffman encoder (lep_huff.h) needs per image and per thread segment.
 int recode_prepare(LepFile* lf, RecodePlan* plan) {
     JpegFile& jf = lf->jpeg;
-    if (lf->flag != 'Z') return EX_PROGRESSIVE_UNSUPPORTED;   // progressive re-coding: jpeg_progressive.cc
+    plan->gpu_ok = false;
+    plan->segs.clear();
+    if (lf->flag != 'Z') return 0;   // progressive / multi-scan files: recode_progressive (jpeg_progressive.cc), host only
     const size_t max_file_size = lf->jpeg_size;
     if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
     plan->scan_bound = max_file_size - jf.garbage.size();
@@ -225,9 +227,11 @@ int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pa
     return 0;
 }
 
+int recode_progressive(LepFile* lf, std::vector<uint8_t>* result);   // jpeg_progressive.cc
+
 int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
     JpegFile& jf = lf->jpeg;
-    if (lf->flag != 'Z') return EX_PROGRESSIVE_UNSUPPORTED;   // progressive re-coding: jpeg_progressive.cc
+    if (lf->flag != 'Z') return recode_progressive(lf, result);
     const size_t max_file_size = lf->jpeg_size;
     if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
     BoundedOut out;

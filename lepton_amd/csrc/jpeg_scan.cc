@@ -505,11 +505,9 @@ static int decode_scans(JpegFile* jf, bool allow_progressive) {
     return 0;
 }
 
-#ifndef LEP_HAVE_PROGRESSIVE
-int decode_progressive_scan(JpegFile*, BitReader&, int*, int*, int*, int*, int*, int*, int*, int*, unsigned*, int*, bool*) {
-    return EX_PROGRESSIVE_UNSUPPORTED;
+Handoff make_handoff_public(BitReader& br, const JpegFile& jf, int mcu_y, const int lastdc[4], int luma_mul) {
+    return make_handoff(br, jf, mcu_y, lastdc, luma_mul);
 }
-#endif
 
 // ---- GPU Huffman decode (lep_huffdec.h): the host does everything except decoding the scan ---------------------------------------
 // parse_jpeg_prepare_gpu: split the file, set up the frame, read the tables of the first scan; *eligible when the scan is a

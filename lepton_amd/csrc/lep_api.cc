@@ -257,7 +257,6 @@ int lep_compress(lep_gpu* g, const uint8_t* jpg, size_t len, lep_bytes* out) {
     int rc = lep_jpeg_open(jpg, len, 1, &j);
     if (rc) return rc;
     std::unique_ptr<lep_jpeg> hold(j);
-    if (j->jf.progressive_needed) return LEP_PROGRESSIVE_UNSUPPORTED;   // hot path is identical; host re-coder is sequential-only so far
     lep_image_desc d;
     lep_jpeg_describe(j, &d);
     lep_segment segs[LEP_MAX_SEGMENTS];

@@ -266,7 +266,6 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         const size_t room = (k + 1 < (int)c->live.size() ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
         if (parsed[i]) { lep_jpeg_close(parsed[i]); parsed[i] = nullptr; }
         int rc = lep_jpeg_open_into(jpgs[i].data, jpgs[i].len, 1, s->h_frames + c->frame_off[k], room, &parsed[i]);
-        if (!rc && lep_jpeg_is_progressive(parsed[i])) rc = LEP_PROGRESSIVE_UNSUPPORTED;   // host re-coder is sequential-only so far
         if (!rc) {
             lep_jpeg_describe(parsed[i], &c->host_desc[k]);
             const lep_image_desc& d = c->host_desc[k];

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "lepton_amd", "csrc")
 PROF_LIB = os.path.join(ROOT, "lepton_amd", "liblepton_mi355x_prof.so")
-SOURCES = ["lep_gpu.hip", "lep_batch.hip", "lep_api.cc", "jpeg_scan.cc", "lep_container.cc", "jpeg_recode.cc"]
+SOURCES = ["lep_gpu.hip", "lep_batch.hip", "lep_api.cc", "jpeg_scan.cc", "jpeg_progressive.cc", "lep_container.cc", "jpeg_recode.cc"]
 
 
 def build():

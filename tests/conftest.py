@@ -34,7 +34,7 @@ def golden(name):
 
 def reference_jpegs():
     """baseline fixtures of the reference's own test-suite (present only in the build container)"""
-    skip = {"arithmetic", "badzerorun", "androidprogressive", "iphoneprogressive", "iphoneprogressive2"}
+    skip = {"arithmetic", "badzerorun"}
     return sorted(p for p in glob.glob(os.path.join(REF_IMAGES, "*.jpg")) if os.path.basename(p)[:-4] not in skip)
 
 

@@ -47,12 +47,23 @@ CASES = {
     "trailing_garbage": lambda: corpus.synth_jpeg(96, 96, 113) + b"tail-bytes\x00\xff\xd9more",
     "truncated": lambda: corpus.synth_jpeg(160, 160, 114)[:-1500],
     "truncated_short": lambda: corpus.synth_jpeg(128, 128, 115)[:2600],
+    # progressive files (BASELINE.json configs[4]): libjpeg's 10-scan script with successive approximation
+    "prog_c420_320x240": lambda: corpus.synth_jpeg(320, 240, 116, progressive=True),
+    "prog_c444_203x149": lambda: corpus.synth_jpeg(203, 149, 117, progressive=True, subsampling="4:4:4", quality=75),
+    "prog_gray_120x88": lambda: pil_jpeg(120, 88, 118, mode="L", quality=90, progressive=True),
+    "prog_c422_rst_176x112": lambda: pil_jpeg(176, 112, 119, quality=88, subsampling="4:2:2", progressive=True, restart_marker_blocks=4),
+    "prog_c420_q97_800x600": lambda: corpus.synth_jpeg(800, 600, 120, quality=97, progressive=True),   # several thread segments
+    "prog_trailing_garbage": lambda: corpus.synth_jpeg(96, 96, 121, progressive=True) + b"tail\x00\xff\xd9more",
 }
 
 
 def main():
-    manifest = {}
+    only = set(sys.argv[1:])   # names to (re)generate; default: all
+    mpath = os.path.join(HERE, "manifest.json")
+    manifest = json.load(open(mpath)) if only and os.path.exists(mpath) else {}
     for name, make in CASES.items():
+        if only and name not in only:
+            continue
         jpg = make()
         jp = os.path.join(HERE, name + ".jpg")
         lp = os.path.join(HERE, name + ".lep")

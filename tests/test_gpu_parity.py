@@ -219,16 +219,17 @@ def test_gpu_batch_pipeline_equals_per_file_and_reference(gpu_codec):
     jpgs = [golden(n)[0] for n in names]
     leps = [golden(n)[1] for n in names]
     extra = [corpus.synth_jpeg(512, 384, 41), b"not a jpeg at all", corpus.synth_jpeg(256, 256, 42, progressive=True)]
+    prog_ref = gpu_codec.compress(extra[2])   # progressive files: host Huffman coders (jpeg_progressive.cc), same GPU hot path
     got, status, stats = gpu_codec.compress_batch(jpgs + extra, chunk_bytes=300000)
     assert status[: len(names)] == [0] * len(names)
     assert got[: len(names)] == leps
     assert status[len(names)] == 0 and got[len(names)] == gpu_codec.compress(extra[0])
     assert status[len(names) + 1] == 42 and got[len(names) + 1] is None      # UNSUPPORTED_JPEG, like the reference
-    assert status[len(names) + 2] == 8 and got[len(names) + 2] is None       # PROGRESSIVE_UNSUPPORTED (host re-coder: sequential only)
+    assert status[len(names) + 2] == 0 and got[len(names) + 2] == prog_ref
     assert stats["h2d_bytes"] > 0 and stats["d2h_bytes"] > 0
-    back, status2, _ = gpu_codec.decompress_batch(leps + [got[len(names)], b"\xcf\x84garbage"], chunk_bytes=300000)
-    assert status2[: len(names) + 1] == [0] * (len(names) + 1)
-    assert back[: len(names)] == jpgs and back[len(names)] == extra[0]
+    back, status2, _ = gpu_codec.decompress_batch(leps + [got[len(names)], prog_ref, b"\xcf\x84garbage"], chunk_bytes=300000)
+    assert status2[: len(names) + 2] == [0] * (len(names) + 2)
+    assert back[: len(names)] == jpgs and back[len(names)] == extra[0] and back[len(names) + 1] == extra[2]
     assert status2[-1] != 0 and back[-1] is None
 
 
@@ -252,7 +253,10 @@ def test_gpu_huffman_reencode_matches_host_and_reference(gpu_codec):
     b, sb, stats_host = gpu_codec.decompress_batch(leps, host_huffman=True)
     assert sa == [0] * len(leps) and sb == sa
     assert a == jpgs and b == jpgs
-    assert stats_gpu["d2h_bytes"] < stats_host["d2h_bytes"] / 3      # frames no longer cross PCIe for the eligible files
+    # frames no longer cross PCIe for the eligible files (progressive / truncated / grey fixtures keep the host path)
+    _, _, stats_gpu = gpu_codec.decompress_batch([leps[-1]] * 4)
+    _, _, stats_host = gpu_codec.decompress_batch([leps[-1]] * 4, host_huffman=True)
+    assert stats_gpu["d2h_bytes"] < stats_host["d2h_bytes"] / 3
 
 
 def test_gpu_huffman_reencode_restart_markers_and_grey(gpu_codec):
@@ -288,6 +292,8 @@ def test_gpu_huffman_decode_matches_host_and_reference(gpu_codec):
     b, sb, stats_host = gpu_codec.compress_batch(jpgs, host_huffman=True)
     assert sa == [0] * len(jpgs) and sb == sa
     assert a == b and a[: len(names)] == leps
+    _, _, stats_gpu = gpu_codec.compress_batch([jpgs[len(names)]] * 4)
+    _, _, stats_host = gpu_codec.compress_batch([jpgs[len(names)]] * 4, host_huffman=True)
     assert stats_gpu["h2d_bytes"] < stats_host["h2d_bytes"] / 2
     back, st, _ = gpu_codec.decompress_batch(a)
     assert st == [0] * len(jpgs) and back == jpgs
