@@ -70,6 +70,7 @@ typedef struct lep_gpu lep_gpu;   /* owns a HIP stream, per-segment models and s
 int lep_gpu_create(int device, lep_gpu **out);
 void lep_gpu_destroy(lep_gpu *g);
 const char *lep_gpu_last_error(lep_gpu *g);
+int lep_gpu_device(lep_gpu *g);   /* the HIP device this object was created on */
 
 /* Encode nseg segments of nimg images.  Host variant: blocks[] are host pointers, copied to HBM,
  * coded, streams copied back into out[i] (out[i].data with capacity out[i].cap; len is set).

@@ -520,7 +520,7 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
     if (rc) return rc;
     if (!setup_frame(jf)) return jf->warn < 0 ? -jf->warn : EX_UNSUPPORTED_JPEG;
     if (jf->ncomp > 3) return EX_UNSUPPORTED_4_COLORS;
-    if (jf->early_eof || jf->jpegtype != 1 || jf->ncomp < 2) return 0;
+    if (jf->early_eof || jf->jpegtype != 1) return 0;
     const uint8_t* h = jf->hdr.data();
     const size_t hdrs = jf->hdr.size();
     size_t hpos = 0;
@@ -543,6 +543,7 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
         const Component& k = jf->comp[i];
         if (k.dc_tbl > 1 || k.ac_tbl > 1 || !jf->htab[0][k.dc_tbl].set || !jf->htab[1][k.ac_tbl].set) return 0;
         if (k.bch != jf->mcuh * k.hs || k.bcv != jf->mcuv * k.vs || k.hs < 1 || k.vs < 1) return 0;
+        if (jf->ncomp == 1 && (k.hs != 1 || k.vs != 1 || k.bch != k.nch || k.bcv != k.ncv || k.bc != jf->mcuc)) return 0;   // grey: one block per MCU, no padding blocks
         plan->hs[i] = k.hs; plan->vs[i] = k.vs; plan->bch[i] = k.bch; plan->dc_tbl[i] = k.dc_tbl; plan->ac_tbl[i] = k.ac_tbl;
         plan->scan_cmp[i] = jf->cs_cmp[i];
     }

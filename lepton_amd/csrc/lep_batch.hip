@@ -221,6 +221,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
     const size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
     const bool verify = o && o->verify;
+    HIPOK(hipSetDevice(lep_gpu_device(g)));
     tune_malloc_for_pool();
     const double t_begin = now_s();
     lep_batch_stats st;
@@ -515,6 +516,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
     const size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
     const bool gpu_huffman = !(o && o->host_huffman);
+    HIPOK(hipSetDevice(lep_gpu_device(g)));
     tune_malloc_for_pool();
     const double t_begin = now_s();
     lep_batch_stats st;

@@ -478,6 +478,7 @@ int lep_gpu_sync(lep_gpu* g) {
 }
 
 const char* lep_gpu_last_kernel_name(lep_gpu* g) { return g ? g->last_kernel : ""; }
+int lep_gpu_device(lep_gpu* g) { return g ? g->device : -1; }
 
 double lep_gpu_last_kernel_ms(lep_gpu* g) {
     if (!g->timed) return -1.0;

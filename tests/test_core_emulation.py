@@ -346,3 +346,58 @@ def test_gpu_huffman_decoder_on_cpu_matches_host_parser(emu, name):
     L.lep_free(out.data)
     L.lep_jpeg_close(h)
     assert got == want
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_decoders_survive_garbage_streams(emu, seed):
+    """corrupt / random arithmetic-coded streams must make the decoder kernels return (0 or an exit code such as
+    STREAM_INCONSISTENT) -- never loop or index outside the model / frame: a hang on the GPU box would take the node down"""
+    import numpy as np
+    from lepton_amd import corpus
+
+    img = JpegImage(corpus.synth_jpeg(96, 64, 77))
+    d = img.desc
+    segs = img.plan()
+    rng = np.random.default_rng(seed)
+    for fn in ("emu_decode_segment_v4", "emu_decode_segment_v3", "emu_decode_segment_v2", "emu_decode_segment"):
+        for kind in range(3):
+            n = int(rng.integers(0, 400))
+            if kind == 0:
+                data = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+            elif kind == 1:
+                data = b"\\xff" * n
+            else:
+                data = b"\\x00" * n
+            for c in range(d.ncomp):
+                C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+            s = segs[0]
+            rc = getattr(emu, fn)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, data, len(data), None)
+            assert rc in (0, 6, 7, 43), (fn, kind, rc)
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_gpu_huffman_decoder_survives_garbage_scans(emu, seed):
+    """random bytes in place of the entropy-coded scan: the Huffman decode kernel logic reports an irregular scan (or
+    decodes garbage) but terminates and stays inside the scan / frame"""
+    import numpy as np
+    from lepton_amd import abi, corpus
+
+    jpg = corpus.synth_jpeg(96, 64, 78)
+    L = abi.lib()
+    h = C.c_void_p()
+    img = abi.HuffDecImage()
+    ok = C.c_int(0)
+    assert L.lep_jpeg_open_gpu(jpg, len(jpg), C.byref(h), C.byref(img), C.byref(ok)) == 0 and ok.value
+    rng = np.random.default_rng(seed)
+    n = img.scan_len
+    scan = C.create_string_buffer(bytes(rng.integers(0, 256, n, dtype=np.uint8)) + b"\\0" * 64, n + 64)
+    img.scan = C.addressof(scan)
+    d = JpegImage(jpg).desc
+    planes = [C.create_string_buffer(d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        img.blocks[c] = C.cast(planes[c], C.c_void_p).value
+    rows = (abi.HuffDecRow * (img.mcuv + 1))()
+    assert emu.emu_huffman_decode_image(C.byref(img), rows) == 0
+    if rows[img.mcuv].aux >> 8 == 0:
+        assert L.lep_jpeg_finish_gpu(h, rows) in (0, 42)
+    L.lep_jpeg_close(h)
