@@ -365,9 +365,9 @@ def test_decoders_survive_garbage_streams(emu, seed):
             if kind == 0:
                 data = bytes(rng.integers(0, 256, n, dtype=np.uint8))
             elif kind == 1:
-                data = b"\\xff" * n
+                data = bytes([255]) * n
             else:
-                data = b"\\x00" * n
+                data = bytes(n)
             for c in range(d.ncomp):
                 C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
             s = segs[0]
@@ -390,7 +390,7 @@ def test_gpu_huffman_decoder_survives_garbage_scans(emu, seed):
     assert L.lep_jpeg_open_gpu(jpg, len(jpg), C.byref(h), C.byref(img), C.byref(ok)) == 0 and ok.value
     rng = np.random.default_rng(seed)
     n = img.scan_len
-    scan = C.create_string_buffer(bytes(rng.integers(0, 256, n, dtype=np.uint8)) + b"\\0" * 64, n + 64)
+    scan = C.create_string_buffer(bytes(rng.integers(0, 256, n, dtype=np.uint8)) + bytes(64), n + 72)
     img.scan = C.addressof(scan)
     d = JpegImage(jpg).desc
     planes = [C.create_string_buffer(d.nblocks(c) * 128) for c in range(d.ncomp)]
