@@ -313,7 +313,6 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
     JpegFile& jf = lf->jpeg;
     const size_t max_file_size = lf->jpeg_size;
     if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
-    if (jf.early_eof) return EX_PROGRESSIVE_UNSUPPORTED;   // truncated progressive files: not supported yet
     const uint8_t* h = jf.hdr.data();
     const size_t hdrs = jf.hdr.size();
 

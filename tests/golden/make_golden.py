@@ -54,6 +54,11 @@ CASES = {
     "prog_c422_rst_176x112": lambda: pil_jpeg(176, 112, 119, quality=88, subsampling="4:2:2", progressive=True, restart_marker_blocks=4),
     "prog_c420_q97_800x600": lambda: corpus.synth_jpeg(800, 600, 120, quality=97, progressive=True),   # several thread segments
     "prog_trailing_garbage": lambda: corpus.synth_jpeg(96, 96, 121, progressive=True) + b"tail\x00\xff\xd9more",
+    # truncated progressive files: cut in the last refinement scan, in the middle of an AC scan, inside the first DC scan
+    "prog_truncated_tail": lambda: corpus.synth_jpeg(320, 240, 131, progressive=True)[:-700],
+    "prog_truncated_mid": lambda: (lambda b: b[:len(b) // 2])(corpus.synth_jpeg(320, 240, 132, progressive=True)),
+    "prog_truncated_dc": lambda: corpus.synth_jpeg(320, 240, 133, progressive=True)[:1100],
+    "prog_truncated_q97_800x600": lambda: (lambda b: b[:len(b) * 2 // 3])(corpus.synth_jpeg(800, 600, 134, quality=97, progressive=True)),
 }
 
 
