@@ -246,6 +246,51 @@ int lep_decompress_batch(lep_gpu *g, const lep_bytes *leps, int n, lep_bytes *ou
                          const lep_batch_options *opt, lep_batch_stats *stats);
 void lep_batch_release(void);   /* frees the staging buffers the two calls above keep between invocations (not re-entrant) */
 
+/* ---- serving surface ------------------------------------------------------------------------------
+ * The `lepton -socket[=name] / -listen[=port]` protocol (src/lepton/socket_serve.cc:312-390, jpgcoder.cc:1162-1186):
+ * a client connects, sends one whole file, half-closes (shutdown(SHUT_WR)) and reads the converted file until EOF --
+ * JPEG in -> .lep out, .lep in -> JPEG out, chosen by the first two bytes (jpgcoder.cc:2178-2235).  The zlib socket
+ * (<name>.z0 / -zliblisten) returns a decoded JPEG as a zlib stream of stored blocks (src/io/Zlib0.cc:36-120); so does a
+ * .lep whose magic is 0xce 0xb6 (jpgcoder.cc:552).  A failed request gets no bytes, only the close; the exit code the
+ * reference's forked child would have died with is logged and counted.  -timebound: time_bound_ms after a request's
+ * first byte the connection is closed, answered or not (the reference's SIGALRM, jpgcoder.cc:1740-1752).
+ * Where the reference forks one process per connection (accept_new_connection, socket_serve.cc:86-116) and bounds them
+ * with -maxchildren, this server gathers the requests that arrive within batch_window_us (or until max_batch are
+ * waiting) and hands them to lep_compress_batch / lep_decompress_batch as ONE GPU batch; max_connections plays
+ * -maxchildren's part (further clients wait in the listen backlog).  One server per GPU: run one process per device. */
+typedef int (*lep_serve_process_fn)(void *user, int kind /* 0: JPEG -> .lep, 1: .lep -> JPEG */, const lep_bytes *in, int n,
+                                    lep_bytes *outs /* malloc'd by the callee */, int32_t *status);
+typedef struct lep_serve_options {
+    const char *uds_path;        /* -socket=<name>; the zlib socket is <name>.z0, the lock file <name>.lock; NULL = no UDS */
+    const char *zlib_uds_path;   /* NULL = <uds_path>.z0 (the reference's random names are /tmp/<id>.uport and /tmp/<id>.z0) */
+    int32_t tcp_port;            /* -listen=<port>; 0 = no TCP listener */
+    int32_t zlib_tcp_port;       /* -zliblisten=<port>; 0 = none */
+    int32_t listen_backlog;      /* -listenbacklog (default 16) */
+    int32_t max_connections;     /* -maxchildren: connections in flight before accept() pauses; 0 = unbounded */
+    uint32_t max_file_bytes;     /* larger uploads are dropped; 0 = 256 MiB */
+    uint32_t time_bound_ms;      /* -timebound; 0 = none */
+    int32_t max_batch;           /* files per GPU batch; 0 = 1024 */
+    int32_t batch_window_us;     /* how long the batcher waits for company once a request is complete; 0 = 2000 */
+    lep_gpu *gpu;                /* used by the default processor */
+    lep_batch_options batch;     /* passed through to lep_*_batch (verify = the reference's default round-trip check) */
+    lep_serve_process_fn process;   /* NULL = the GPU batch pipeline; tests substitute the CPU oracle here */
+    void *process_user;
+} lep_serve_options;
+typedef struct lep_serve_stats {
+    uint64_t accepted, answered, failed, timed_out, rejected;   /* connections */
+    uint64_t batches, largest_batch;
+    uint64_t bytes_in, bytes_out;
+    int32_t last_failure_code;   /* exit code of the most recent failed request */
+} lep_serve_stats;
+typedef struct lep_server lep_server;
+/* binds and starts the IO + batcher threads; LEP_OS_ERROR if a socket cannot be bound (or the lock is held: another
+ * server owns <name>, socket_serve.cc:331-356) */
+int lep_serve_start(const lep_serve_options *opt, lep_server **out);
+void lep_serve_get_stats(lep_server *s, lep_serve_stats *out);
+void lep_serve_stop(lep_server *s);   /* closes listeners and connections, joins, removes the socket files it owns */
+/* zlib stream of stored blocks exactly as Zlib0Writer emits it (src/io/Zlib0.cc) */
+int lep_zlib0_wrap(const uint8_t *data, size_t len, lep_bytes *out);
+
 void lep_free(void *p);   /* frees lep_bytes.data returned by this library */
 const char *lep_version(void);
 

@@ -82,6 +82,22 @@ class BatchStats(C.Structure):
                 ("write_s", C.c_double), ("h2d_bytes", C.c_double), ("d2h_bytes", C.c_double), ("alloc_s", C.c_double)]
 
 
+SERVE_PROCESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Bytes), C.c_int, C.POINTER(Bytes), C.POINTER(C.c_int32))
+
+
+class ServeOptions(C.Structure):
+    _fields_ = [("uds_path", C.c_char_p), ("zlib_uds_path", C.c_char_p), ("tcp_port", C.c_int32), ("zlib_tcp_port", C.c_int32),
+                ("listen_backlog", C.c_int32), ("max_connections", C.c_int32), ("max_file_bytes", C.c_uint32),
+                ("time_bound_ms", C.c_uint32), ("max_batch", C.c_int32), ("batch_window_us", C.c_int32), ("gpu", C.c_void_p),
+                ("batch", BatchOptions), ("process", SERVE_PROCESS_FN), ("process_user", C.c_void_p)]
+
+
+class ServeStats(C.Structure):
+    _fields_ = [("accepted", C.c_uint64), ("answered", C.c_uint64), ("failed", C.c_uint64), ("timed_out", C.c_uint64),
+                ("rejected", C.c_uint64), ("batches", C.c_uint64), ("largest_batch", C.c_uint64), ("bytes_in", C.c_uint64),
+                ("bytes_out", C.c_uint64), ("last_failure_code", C.c_int32)]
+
+
 _lib = None
 
 
@@ -98,6 +114,12 @@ def lib():
         P = C.POINTER
         vp = C.c_void_p
         L.lep_version.restype = C.c_char_p
+        L.lep_serve_start.argtypes = [P(ServeOptions), P(vp)]
+        L.lep_serve_get_stats.argtypes = [vp, P(ServeStats)]
+        L.lep_serve_get_stats.restype = None
+        L.lep_serve_stop.argtypes = [vp]
+        L.lep_serve_stop.restype = None
+        L.lep_zlib0_wrap.argtypes = [C.c_char_p, C.c_size_t, P(Bytes)]
         L.lep_free.argtypes = [vp]
         L.lep_free.restype = None
         L.lep_jpeg_open.argtypes = [vp, C.c_size_t, C.c_int, P(vp)]
@@ -166,4 +188,5 @@ EXPORTS = [
     "lep_jpeg_describe", "lep_jpeg_plan", "lep_jpeg_write_lep", "lep_file_open", "lep_file_close", "lep_file_describe",
     "lep_file_segments", "lep_file_jpeg_size", "lep_file_recode", "lep_compress", "lep_decompress", "lep_free",
     "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_file_recode_plan", "lep_file_recode_finish", "lep_gpu_huffman_encode_device", "lep_jpeg_open_gpu", "lep_jpeg_scan_bytes", "lep_jpeg_finish_gpu", "lep_gpu_huffman_decode_device", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
+    "lep_serve_start", "lep_serve_get_stats", "lep_serve_stop", "lep_zlib0_wrap",
 ]
