@@ -134,7 +134,8 @@ typedef struct lep_huffdec_image {
     int16_t *blocks[4];                  /* device: zero-filled coefficient frame */
     uint64_t rows_off;
     uint16_t lut[4][512];
-    uint16_t tl[4][256], tr[4][256];
+    int32_t maxcode[4][8], valoff[4][8];   /* codes of 9..16 bits: largest code per length (-1 none), symbol index - code */
+    uint8_t longsym[4][256];               /* their symbols in canonical order */
 } lep_huffdec_image;
 typedef struct lep_huffdec_row {
     uint32_t bitpos;
@@ -230,8 +231,10 @@ typedef struct lep_batch_options {
     int32_t verify;              /* compress: on-GPU round-trip verification */
     size_t chunk_frame_bytes;    /* cap on coefficient-frame bytes per pipeline chunk; 0 = 24 GiB */
     int32_t host_huffman;        /* 1 = JPEG Huffman decode / re-encode on the host pool (frames cross PCIe) instead of on the GPU */
-    int32_t chunk_images;        /* images per pipeline chunk; 0 = 1024 (x 8 thread segments = one wavefront per SIMD slot of the
-                                    chip: a coder kernel takes as long for 100 segments as for 8192, so chunks must be this big) */
+    int32_t chunk_images;        /* images per pipeline chunk; 0 = automatic: at most 1024 images, and for compression with the
+                                    GPU Huffman decoder at most 7168 thread segments (7 coder wavefronts per SIMD; the eighth
+                                    slot decodes the next chunk's scans meanwhile).  A coder kernel takes as long for 100
+                                    segments as for 8192, so chunks must be this big */
 } lep_batch_options;
 typedef struct lep_batch_stats {
     double wall_s;               /* whole call */

@@ -119,7 +119,8 @@ struct ScanDecodePlan {
     int16_t* blocks[4];
     uint64_t rows_off;
     uint16_t lut[4][512];
-    uint16_t tl[4][256], tr[4][256];
+    int32_t maxcode[4][8], valoff[4][8];   /* codes of 9..16 bits: largest code per length (-1 none), symbol index - code */
+    uint8_t longsym[4][256];               /* their symbols in canonical order */
 };
 struct ScanDecodeRow {
     uint32_t bitpos;

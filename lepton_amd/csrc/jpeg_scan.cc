@@ -558,8 +558,31 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
                 const unsigned first = (unsigned)t.cval[sym] << (9 - len);
                 for (unsigned x = 0; x < (1u << (9 - len)); ++x) lut[first + x] = (uint16_t)((len << 8) | sym);
             }
-            memcpy(plan->tl[cls * 2 + id], t.l, sizeof t.l);
-            memcpy(plan->tr[cls * 2 + id], t.r, sizeof t.r);
+            // codes of 9..16 bits, for the kernel's one-step canonical test.  That test equals the code tree only if the
+            // table IS canonical (Annex C: codes of one length consecutive, the next length continues at (last + 1) << 1, no
+            // overflow); a DHT that breaks this stays with the host parser.
+            int order[256], no = 0;
+            for (int len = 1; len <= 16; ++len)
+                for (int sym = 0; sym < 256; ++sym)
+                    if (t.clen[sym] == len) order[no++] = sym;
+            std::stable_sort(order, order + no, [&](int a, int b) { return t.clen[a] != t.clen[b] ? t.clen[a] < t.clen[b] : t.cval[a] < t.cval[b]; });
+            unsigned next = 0;
+            int prev_len = no ? t.clen[order[0]] : 0, nlong = 0;
+            int32_t* maxcode = plan->maxcode[cls * 2 + id];
+            int32_t* valoff = plan->valoff[cls * 2 + id];
+            for (int k = 0; k < 8; ++k) { maxcode[k] = -1; valoff[k] = 0; }
+            for (int q = 0; q < no; ++q) {
+                const int sym = order[q], len = t.clen[sym];
+                next <<= (len - prev_len);
+                prev_len = len;
+                if (t.cval[sym] != next || next >= (1u << len)) return 0;   // not canonical: *eligible stays false
+                if (len >= 9) {
+                    if (maxcode[len - 9] < 0) valoff[len - 9] = nlong - (int)next;
+                    maxcode[len - 9] = (int32_t)next;
+                    plan->longsym[cls * 2 + id][nlong++] = (uint8_t)sym;
+                }
+                ++next;
+            }
         }
     *eligible = true;
     return 0;

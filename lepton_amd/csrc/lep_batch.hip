@@ -220,6 +220,11 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
     const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
     const size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
+    // With the Huffman decode on the GPU, chunk k+1 is decoded WHILE the arithmetic coder of chunk k runs: a chunk's thread
+    // segments (one coder wavefront each) fill 7 of the 8 wave slots of every SIMD (7 x 4 x 256 = 7168), the eighth holds
+    // the next chunk's Huffman wavefronts (one per image, raised priority, sized to fit: lep_gpu.hip).  Explicit
+    // chunk_images overrides the segment budget.
+    const size_t chunk_segments = (o && o->chunk_images > 0) || (o && o->host_huffman) ? (size_t)1 << 30 : 7168;
     const bool verify = o && o->verify;
     HIPOK(hipSetDevice(lep_gpu_device(g)));
     tune_malloc_for_pool();
@@ -227,6 +232,9 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     lep_batch_stats st;
     memset(&st, 0, sizeof st);
     for (int i = 0; i < n; ++i) { outs[i].data = nullptr; outs[i].len = outs[i].cap = 0; status[i] = 0; }
+    // thread segments a file will get, from its size (write_ujpg's rule on the scan size, jpgcoder.cc:3856-3871; the file
+    // size over-estimates the scan a little, which only makes a chunk slightly smaller)
+    auto segments_guess = [&](int i) -> size_t { const size_t b = jpgs[i].len; return b < 125000 ? 1 : b < 250000 ? 2 : b < 500000 ? 4 : 8; };
 
     // 1. frame sizes from the SOF markers -> the whole batch is cut into chunks before anything is decoded, so that every
     //    image can be Huffman-decoded straight into its place in a pinned staging buffer (no page faults, no second copy)
@@ -236,13 +244,14 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     for (int i = 0; i < n;) {
         std::unique_ptr<Chunk> c(new Chunk);
         c->first = i;
-        size_t bytes = 0;
+        size_t bytes = 0, nsegs = 0;
         for (; i < n; ++i) {
             if (status[i]) continue;
             const size_t fb = (fbytes[i] + 255) & ~(size_t)255;
-            if (!c->live.empty() && (bytes + fb > chunk_budget || c->live.size() >= chunk_images)) break;
+            const size_t sg = segments_guess(i);
+            if (!c->live.empty() && (bytes + fb > chunk_budget || c->live.size() >= chunk_images || nsegs + sg > chunk_segments)) break;
             c->live.push_back(i); c->frame_off.push_back(bytes);
-            bytes += fb;
+            bytes += fb; nsegs += sg;
         }
         c->count = i - c->first;
         c->frame_bytes = bytes;
@@ -252,7 +261,11 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     HIPOK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
     HIPOK(hipStreamCreateWithFlags(&s_compute, hipStreamNonBlocking));
     HIPOK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
-    HIPOK(hipStreamCreateWithFlags(&s_huff, hipStreamNonBlocking));   // Huffman decode of chunk k+1 beside the coder kernels of chunk k
+    {   // Huffman decode of chunk k+1 beside the coder kernels of chunk k: its workgroups go first whenever a slot is free
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPOK(hipStreamCreateWithPriority(&s_huff, hipStreamNonBlocking, hi));
+    }
     Slot* slots = g_slots;   // grow-only staging cache shared by the batch calls (lep_batch_release frees it)
     g_alloc_s = 0;
     int rc_all = 0;

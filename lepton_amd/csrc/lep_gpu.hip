@@ -230,8 +230,11 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_encode_kernel(const lephuff
 }
 
 // JPEG Huffman scan decode: one wavefront per image (lep_huffdec.h)
-__global__ __launch_bounds__(64) void lep_huffman_decode_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffDecRow* rows) {
+// <= 64 VGPRs and 4.5 KB of LDS: one of these waves fits on a SIMD beside seven coder waves, and it runs at raised priority
+// there (it is one long dependency chain per image; the coder waves around it are the throughput work)
+__global__ __launch_bounds__(64, 8) void lep_huffman_decode_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffDecRow* rows) {
     __shared__ lephuff::HuffDecShared sh;
+    __builtin_amdgcn_s_setprio(3);
     lephuff::HuffDecWave w;
     w.run(images + blockIdx.x, &sh, rows);
 }

@@ -7,7 +7,11 @@
 // parallelism is the image: one wavefront per image, thousands of images per launch.  The wave decodes serially as
 // uniform vector code (the recurrence is "window -> table entry -> shift", a scalar chain like the bool coder's); the
 // lanes are used for what is parallel: the decoded block is assembled in LDS and leaves as one coalesced 128-byte
-// store in the coder's AlignedBlock order, tables live in LDS (9-bit first-level look-up + the code tree for long codes).
+// store in the coder's AlignedBlock order, tables live in LDS (first-level look-up: 9 bits for AC codes, 8 for DC; longer
+// codes are resolved in ONE step by seven lanes testing "are the first L bits <= the largest code of length L" side by
+// side, the canonical-code test of Annex F.2.2.3 turned sideways).  The wave runs at raised priority with <= 64 VGPRs and
+// 4.5 KB of LDS so that it fits beside seven coder wavefronts per SIMD: the batch pipeline decodes chunk k+1 in the wave
+// slots that the arithmetic coder of chunk k leaves free (lep_batch.hip).
 // Per MCU row the wave records (bit position, last DC per component): exactly what the ThreadHandoff records of the
 // .lep header are made of (src/lepton/jpgcoder.cc:2520-2560); the host turns them into file offsets / overhang bits.
 // Anything irregular (decode error, zero run past the block, data running out, grey or non-interleaved scans,
@@ -29,7 +33,11 @@ struct HuffDecImage {       // one image, device-visible
     int16_t* blocks[4];     // zero-filled frame (device)
     uint64_t rows_off;      // this image's first record in the row arena (mcuv + 1 records)
     uint16_t lut[4][512];   // [0..1] DC, [2..3] AC: first 9 bits of the window -> code length << 8 | symbol; 0 = longer code
-    uint16_t tl[4][256], tr[4][256];   // code tree (HuffTable::l / r): child for a 0 / 1 bit; >= 256 = leaf (symbol + 256); 0 = invalid
+    // codes of 9..16 bits ([k] = length 9 + k), canonical order: a window whose first L bits are <= maxcode is a code of
+    // length L (no shorter one matched), its symbol is longsym[valoff + those bits]; maxcode = -1: no code of that length
+    int32_t maxcode[4][8];
+    int32_t valoff[4][8];
+    uint8_t longsym[4][256];
 };
 
 struct HuffDecRow {         // one per MCU row + one final
@@ -38,9 +46,12 @@ struct HuffDecRow {         // one per MCU row + one final
     int32_t aux;            // final record: padbit in bits 0..7 (0xff = never determined), status in bits 8..
 };
 
-struct HuffDecShared {
-    uint16_t lut[4][512];
-    uint16_t tl[4][256], tr[4][256];
+struct HuffDecShared {      // 4544 bytes
+    uint16_t lut_ac[2][512];
+    uint16_t lut_dc[2][256];   // DC codes: 8-bit first level (a 9-bit DC code takes the long path)
+    int32_t maxcode[4][8];
+    int32_t valoff[4][8];
+    uint8_t longsym[4][256];
     int16_t blk[64];        // aligned order
     uint8_t z2a[64];
 };
@@ -84,40 +95,41 @@ struct HuffDecWave {
         consume(n);
         return v;
     }
-    // next Huffman symbol of table t; -1 on an invalid code
-    WDEV int symbol(int t) {
-        const uint32_t e = sh->lut[t][hi >> 23];
-        if (ucond((e >> 8) != 0)) { consume(e >> 8); return (int)(e & 255u); }
-        uint32_t node = 0;
-        for (int i = 0; i < 16; ++i) {   // code tree walk, one bit at a time (codes longer than 9 bits)
-            const uint32_t bit = hi >> 31;
-            consume(1);
-            node = bit ? sh->tr[t][node] : sh->tl[t][node];
-            if (ucond(node == 0)) return -1;
-            if (ucond(node >= 256)) return (int)node - 256;
+    // a code of 9..16 bits: lane k tests length 9 + k; the shortest length that fits is the code (canonical Huffman codes:
+    // the codes of one length are consecutive and larger than every shorter code extended with zeros).  -1 = not a code.
+    WDEV int symbol_long(int t, uint32_t* len) {
+        LV(int, ok);
+        LV(uint32_t, cand);
+        LANES(l) {
+            const int k = l & 7;
+            const uint32_t code = hi >> (23 - k);
+            L(ok) = l < 8 && (int)code <= sh->maxcode[t][k];
+            L(cand) = (uint32_t)(sh->valoff[t][k] + (int)code);
         }
-        return -1;
+        const uint64_t m = lepwave::wave_ballot(ok);
+        if (!m) return -1;
+        const int k = __builtin_ctzll(m);
+        *len = 9u + (uint32_t)k;
+        return (int)sh->longsym[t][lepwave::wave_read(cand, k) & 255u];
     }
     static WDEV int devli(uint32_t s, uint32_t n) { return s == 0 ? (int)n : (n >= (1u << (s - 1)) ? (int)n : (int)n + 1 - (1 << s)); }
 
-    // Huffman symbol of table t AND the `s` magnitude bits that follow it in one window step (code <= 9 bits through the
-    // LUT, s <= 15: both inside the top 32 bits of the window); the code-tree walk handles longer codes.  dc: s = symbol,
-    // else s = low nibble.  Returns the symbol (-1 invalid) and the raw magnitude bits through *n.
+    // Huffman symbol of table t AND the `s` magnitude bits that follow it in one window step (code <= 16 bits, s <= 15:
+    // both inside the top 32 bits of the window).  dc: s = symbol, else s = low nibble.  Returns the symbol (-1 invalid)
+    // and the raw magnitude bits through *n.
     WDEV int symbol_and_bits(int t, bool dc, uint32_t* n) {
-        const uint32_t e = sh->lut[t][hi >> 23];
-        if (ucond((e >> 8) != 0)) {
-            const uint32_t len = e >> 8, sym = e & 255u, s = dc ? sym : (sym & 15u);
-            if (ucond(s > 16)) return -1;
-            *n = s ? (hi << len) >> (32 - s) : 0u;
-            consume(len + s);
-            return (int)sym;
+        const uint32_t e = dc ? sh->lut_dc[t][hi >> 24] : sh->lut_ac[t - 2][hi >> 23];
+        uint32_t len = e >> 8, sym = e & 255u;
+        if (ucond(len == 0)) {
+            const int r = symbol_long(t, &len);
+            if (r < 0) return -1;
+            sym = (uint32_t)r;
         }
-        const int sym = symbol(t);
-        if (ucond(sym < 0)) return -1;
-        const uint32_t s = dc ? (uint32_t)sym : ((uint32_t)sym & 15u);
-        if (ucond(s > 16)) return -1;
-        *n = read(s);
-        return sym;
+        const uint32_t s = dc ? sym : (sym & 15u);
+        if (ucond(s > 15)) return -1;
+        *n = s ? (hi << len) >> (32 - s) : 0u;
+        consume(len + s);
+        return (int)sym;
     }
 
     // decode_block_seq (jpgcoder.cc:4893-4966) into sh->blk; returns the DC difference through *diff; false = irregular
@@ -155,8 +167,13 @@ struct HuffDecWave {
     WDEV void run(const HuffDecImage* image, HuffDecShared* shared, HuffDecRow* rows_arena) {
         img = image; sh = shared; status = 0;
         LANES(l) {
-            for (int i = l; i < 4 * 512; i += 64) (&sh->lut[0][0])[i] = (&img->lut[0][0])[i];
-            for (int i = l; i < 4 * 256; i += 64) { (&sh->tl[0][0])[i] = (&img->tl[0][0])[i]; (&sh->tr[0][0])[i] = (&img->tr[0][0])[i]; }
+            for (int i = l; i < 2 * 512; i += 64) (&sh->lut_ac[0][0])[i] = (&img->lut[2][0])[i];
+            for (int i = l; i < 2 * 256; i += 64) {   // 8-bit DC table from the 9-bit one: entries of codes up to 8 bits come in pairs
+                const uint16_t e = img->lut[i >> 8][(i & 255) * 2];
+                (&sh->lut_dc[0][0])[i] = (e >> 8) <= 8 ? e : (uint16_t)0;
+            }
+            if (l < 32) { (&sh->maxcode[0][0])[l] = (&img->maxcode[0][0])[l]; (&sh->valoff[0][0])[l] = (&img->valoff[0][0])[l]; }
+            for (int i = l; i < 4 * 256; i += 64) (&sh->longsym[0][0])[i] = (&img->longsym[0][0])[i];
             sh->z2a[l] = kZ2A[l];
             sh->blk[l] = 0;
         }

@@ -282,7 +282,7 @@ def test_gpu_huffman_encoder_on_cpu_restores_the_jpeg(emu, name):
     assert got == jpg
 
 
-@pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "synth_rst"])
+@pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "synth_rst", "optimized_q95", "optimized_q30", "optimized_noise_444"])
 def test_gpu_huffman_decoder_on_cpu_matches_host_parser(emu, name):
     """lep_huffdec.h (wave-per-image JPEG Huffman scan decode) as a 64-lane loop emulation + parse_jpeg_finish_gpu: for
     every eligible file the coefficient frame, the hand-off records and the pad bit equal the host parser's, so the .lep
@@ -292,6 +292,22 @@ def test_gpu_huffman_decoder_on_cpu_matches_host_parser(emu, name):
 
     if name == "synth_640x360":
         jpg = corpus.synth_jpeg(640, 360, 71, quality=88)
+    elif name.startswith("optimized"):
+        # per-image Huffman tables (libjpeg optimize_coding): code lengths differ from the Annex K tables, long DC codes,
+        # rare symbols with 14..16-bit codes -- the kernel's long-code path (canonical test across lanes)
+        from PIL import Image
+        import numpy as np
+        rng = np.random.default_rng(31)
+        if name == "optimized_noise_444":
+            a = rng.integers(0, 256, (120, 168, 3), dtype=np.uint8)
+            q, sub = 98, "4:4:4"
+        else:
+            base = rng.integers(0, 256, (30, 40, 3), dtype=np.uint8)
+            a = np.asarray(Image.fromarray(base, "RGB").resize((320, 240), Image.BICUBIC)).astype(np.int16)
+            a = np.clip(a + rng.normal(0, 12, a.shape), 0, 255).astype(np.uint8)
+            q, sub = (95, "4:2:0") if name.endswith("95") else (30, "4:2:2")
+        buf = io.BytesIO(); Image.fromarray(a, "RGB").save(buf, format="JPEG", quality=q, subsampling=sub, optimize=True)
+        jpg = buf.getvalue()
     elif name == "synth_rst":
         from PIL import Image
         import numpy as np
