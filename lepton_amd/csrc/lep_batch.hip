@@ -87,7 +87,7 @@ void tune_malloc_for_pool() {
 
 struct Slot {   // one chunk's buffers (double-buffered)
     char* h_frames = nullptr; char* d_frames = nullptr; char* d_scratch = nullptr; size_t frames_cap = 0, hframes_cap = 0;
-    uint8_t* d_streams = nullptr; uint8_t* h_streams = nullptr; size_t streams_cap = 0;
+    uint8_t* d_streams = nullptr; uint8_t* h_streams = nullptr; size_t streams_cap = 0, hstreams_cap = 0;   // device arena (worst-case sized for encode) / pinned mirror (actual bytes)
     uint32_t* d_len = nullptr; int32_t* d_status = nullptr; uint32_t* d_flags = nullptr; size_t seg_cap = 0, img_cap = 0;
     uint8_t* d_scan = nullptr; uint8_t* h_scan = nullptr; size_t scan_cap = 0;   // JPEG scan bytes of the GPU Huffman encoder
     uint32_t* d_scanlen = nullptr; size_t scanlen_cap = 0;
@@ -109,14 +109,16 @@ struct Slot {   // one chunk's buffers (double-buffered)
 
 double g_alloc_s = 0;   // time spent in (re)allocating staging buffers during the current call (single orchestrator thread)
 
-int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch);
-int slot_reserve(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch) {
+int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch, size_t host_streams);
+// host_streams: bytes of the pinned mirror of the stream arena (decompress: all of it; compress: reserved later, once the
+// encoder has reported how many bytes it really wrote -- the arena itself is sized for the worst case, 5x more)
+int slot_reserve(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch, size_t host_streams) {
     const double t0 = now_s();
-    const int rc = slot_reserve_impl(s, frames, streams, nseg, nimg, scratch);
+    const int rc = slot_reserve_impl(s, frames, streams, nseg, nimg, scratch, host_streams);
     g_alloc_s += now_s() - t0;
     return rc;
 }
-int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch) {
+int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch, size_t host_streams) {
     if (frames > s->frames_cap) {
         if (s->d_frames) (void)hipFree(s->d_frames);
         if (s->d_scratch) (void)hipFree(s->d_scratch);
@@ -126,11 +128,17 @@ int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_
     }
     if (scratch && !s->d_scratch) HIPOK(hipMalloc((void**)&s->d_scratch, s->frames_cap));
     if (streams > s->streams_cap) {
-        if (s->h_streams) (void)hipHostFree(s->h_streams);
         if (s->d_streams) (void)hipFree(s->d_streams);
-        HIPOK(hipHostMalloc((void**)&s->h_streams, streams, hipHostMallocDefault));
+        s->d_streams = nullptr; s->streams_cap = 0;
         HIPOK(hipMalloc((void**)&s->d_streams, streams));
         s->streams_cap = streams;
+    }
+    if (host_streams > s->hstreams_cap) {
+        if (s->h_streams) (void)hipHostFree(s->h_streams);
+        s->h_streams = nullptr; s->hstreams_cap = 0;
+        const size_t want = host_streams + host_streams / 4;   // head room: the next chunk of similar files should not reallocate
+        HIPOK(hipHostMalloc((void**)&s->h_streams, want, hipHostMallocDefault));
+        s->hstreams_cap = want;
     }
     if (nseg > s->seg_cap) {
         if (s->d_len) (void)hipFree(s->d_len);
@@ -224,7 +232,12 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     // segments (one coder wavefront each) fill 7 of the 8 wave slots of every SIMD (7 x 4 x 256 = 7168), the eighth holds
     // the next chunk's Huffman wavefronts (one per image, raised priority, sized to fit: lep_gpu.hip).  Explicit
     // chunk_images overrides the segment budget.
-    const size_t chunk_segments = (o && o->chunk_images > 0) || (o && o->host_huffman) ? (size_t)1 << 30 : 7168;
+    // chunk_images overrides the segment budget.  A kernel takes as long for a small chunk as for a full one, so the
+    // chunks are balanced (k equal chunks rather than k - 1 full ones and a remainder), and a batch that fits one launch
+    // (<= 1024 images, <= 8192 segments) is not split at all: there is nothing to overlap with.
+    const bool auto_chunks = !(o && o->chunk_images > 0) && !(o && o->host_huffman);
+    size_t chunk_segments = auto_chunks ? 7168 : (size_t)1 << 30;
+    size_t chunk_images_eff = chunk_images;
     const bool verify = o && o->verify;
     HIPOK(hipSetDevice(lep_gpu_device(g)));
     tune_malloc_for_pool();
@@ -241,6 +254,17 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     std::vector<size_t> fbytes(n, 0);
     parallel_for(n, threads, [&](int i) { if (int rc = lep_jpeg_peek_frame_bytes(jpgs[i].data, jpgs[i].len, &fbytes[i])) status[i] = rc; });
     std::vector<std::unique_ptr<Chunk>> chunks;
+    if (auto_chunks) {
+        size_t live = 0, segs = 0, bytes = 0;
+        for (int i = 0; i < n; ++i) if (!status[i]) { ++live; segs += segments_guess(i); bytes += (fbytes[i] + 255) & ~(size_t)255; }
+        if (live <= 1024 && segs <= 8192) chunk_segments = 8192;
+        else {
+            const size_t k = std::max({(segs + 7167) / 7168, (live + 1023) / 1024, (size_t)1});
+            chunk_segments = std::min<size_t>(7168, (segs + k - 1) / k + 8);
+            chunk_images_eff = std::min<size_t>(1024, (live + k - 1) / k + 1);
+        }
+        (void)bytes;
+    }
     for (int i = 0; i < n;) {
         std::unique_ptr<Chunk> c(new Chunk);
         c->first = i;
@@ -249,7 +273,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             if (status[i]) continue;
             const size_t fb = (fbytes[i] + 255) & ~(size_t)255;
             const size_t sg = segments_guess(i);
-            if (!c->live.empty() && (bytes + fb > chunk_budget || c->live.size() >= chunk_images || nsegs + sg > chunk_segments)) break;
+            if (!c->live.empty() && (bytes + fb > chunk_budget || c->live.size() >= chunk_images_eff || nsegs + sg > chunk_segments)) break;
             c->live.push_back(i); c->frame_off.push_back(bytes);
             bytes += fb; nsegs += sg;
         }
@@ -300,7 +324,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     };
     auto parse_and_upload = [&](Chunk* c, Slot* s) -> int {
         if (c->live.empty()) return 0;
-        if (int rc = slot_reserve(s, c->frame_bytes, 0, 0, c->live.size(), verify)) return rc;
+        if (int rc = slot_reserve(s, c->frame_bytes, 0, 0, c->live.size(), verify, 0)) return rc;
         const int nl = (int)c->live.size();
         double t0 = now_s();
         c->host_desc.assign(nl, lep_image_desc());
@@ -425,7 +449,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         }
         c->seg_first.push_back((int)c->segs.size());
         if (c->live.empty()) return 0;
-        if (int rc = slot_reserve(s, c->frame_bytes, c->offs.back() + 256, c->segs.size(), c->live.size(), verify)) return rc;
+        if (int rc = slot_reserve(s, c->frame_bytes, c->offs.back() + 256, c->segs.size(), c->live.size(), verify, 0)) return rc;
         c->dev_desc = c->host_desc; c->scratch_desc = c->host_desc;
         for (size_t k = 0; k < c->live.size(); ++k) {
             size_t off = c->frame_off[k];
@@ -471,6 +495,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         if (ci + 1 < chunks.size()) { if (int rc = parse_and_upload(chunks[ci + 1].get(), &slots[slot_i ^ 1])) { rc_all = rc; break; } }
         // fetch this chunk's results
         std::vector<uint32_t> lens(nseg);
+        std::vector<size_t> hoff(nseg, 0);
         std::vector<int32_t> sts((size_t)nseg * 2, 0);
         std::vector<uint32_t> flags(nimg, 0);
         if (nimg) {
@@ -479,15 +504,19 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             HIPOK(hipMemcpyAsync(sts.data(), s->d_status, (size_t)nseg * (verify ? 8 : 4), hipMemcpyDeviceToHost, s_down));
             if (verify) HIPOK(hipMemcpyAsync(flags.data(), s->d_flags, (size_t)nimg * 4, hipMemcpyDeviceToHost, s_down));
             HIPOK(hipStreamSynchronize(s_down));
+            // pinned mirror packed by the bytes actually written
+            size_t total = 0;
+            for (int k = 0; k < nseg; ++k) { hoff[k] = total; if (!sts[k]) total += ((size_t)lens[k] + 15) & ~(size_t)15; }
+            if (int rc = slot_reserve(s, 0, 0, 0, 0, false, total + 256)) { rc_all = rc; break; }
             for (int k = 0; k < nseg; ++k)
                 if (!sts[k] && lens[k]) {
-                    HIPOK(hipMemcpyAsync(s->h_streams + c->offs[k], s->d_streams + c->offs[k], lens[k], hipMemcpyDeviceToHost, s_down));
+                    HIPOK(hipMemcpyAsync(s->h_streams + hoff[k], s->d_streams + c->offs[k], lens[k], hipMemcpyDeviceToHost, s_down));
                     st.d2h_bytes += lens[k];
                 }
             HIPOK(hipStreamSynchronize(s_down));
         }
         // containers on the host pool, in the background
-        writer = std::thread([&, c, s, lens, sts, flags]() {
+        writer = std::thread([&, c, s, lens, sts, flags, hoff]() {
             const double t0 = now_s();
             parallel_for((int)c->live.size(), threads, [&](int k) {
                 const int i = c->live[k];
@@ -496,7 +525,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 lep_bytes strs[LEP_MAX_SEGMENTS];
                 for (int q = s0; q < s1; ++q) {
                     if (sts[q] && !rc) rc = sts[q];
-                    strs[q - s0].data = s->h_streams + c->offs[q];
+                    strs[q - s0].data = s->h_streams + hoff[q];
                     strs[q - s0].len = strs[q - s0].cap = lens[q];
                 }
                 if (!rc && verify) {
@@ -590,7 +619,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
             }
         }
         c->seg_first.push_back((int)c->segs.size());
-        if (int rc = slot_reserve(s, c->frame_bytes, c->offs.back() + 256, c->segs.size(), c->live.size(), false)) return rc;
+        if (int rc = slot_reserve(s, c->frame_bytes, c->offs.back() + 256, c->segs.size(), c->live.size(), false, c->offs.back() + 256)) return rc;
         const double t0 = now_s();
         parallel_for((int)c->segs.size(), threads, [&](int q) { if ((*lens)[q]) memcpy(s->h_streams + c->offs[q], src[q], (*lens)[q]); });
         st.stage_s += now_s() - t0;

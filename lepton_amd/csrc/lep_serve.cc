@@ -12,6 +12,7 @@
 #include <poll.h>
 #include <signal.h>
 #include <sys/file.h>
+#include <sys/resource.h>
 #include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/un.h>
@@ -347,6 +348,10 @@ int lep_serve_start(const lep_serve_options* opt, lep_server** out) {
     if (!opt->uds_path && !opt->tcp_port && !opt->zlib_tcp_port) return LEP_ASSERTION_FAILURE;
     std::unique_ptr<lep_server> s(new lep_server);
     s->opt = *opt;
+    {   // one descriptor per connection in flight (the reference spends a process on each): lift the soft limit
+        rlimit rl;
+        if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < rl.rlim_max) { rl.rlim_cur = rl.rlim_max; (void)setrlimit(RLIMIT_NOFILE, &rl); }
+    }
     const int backlog = opt->listen_backlog > 0 ? opt->listen_backlog : 16;
     auto fail = [&](int code) {
         for (auto& l : s->listeners) close_retry(l.fd);

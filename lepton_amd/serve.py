@@ -19,9 +19,9 @@ def request(address, data, timeout=60.0):
         s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
     else:
         s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-    s.settimeout(timeout)
     try:
-        s.connect(address)
+        s.connect(address)     # blocking: with the listen backlog full a Unix-socket connect waits (a timed one fails with EAGAIN)
+        s.settimeout(timeout)
         try:
             s.sendall(data)
             s.shutdown(socket.SHUT_WR)
