@@ -301,8 +301,9 @@ def main():
             assert not any(st1) and not any(st2) and back == ejpgs, "end-to-end round trip is not bit exact"
             out["end_to_end"] = {
                 "workload": "%d of the bench's 4K JPEGs, host memory -> host memory (lep_compress_batch / lep_decompress_batch), staging buffers warm (second call)" % len(ejpgs),
-                "compress_MBps": round(emb / (t1 - t0), 1), "decompress_MBps": round(emb / (t2 - t1), 1),
-                "value": round(2 * emb / (t2 - t0), 1), "unit": "MB/s (JPEG bytes, compress + decompress)",
+                "compress_MBps": round(emb / cs["wall_s"], 1), "decompress_MBps": round(emb / ds["wall_s"], 1),
+                "value": round(2 * emb / (cs["wall_s"] + ds["wall_s"]), 1), "unit": "MB/s (JPEG bytes, compress + decompress; wall clock of the two C-ABI calls)",
+                "through_the_python_binding_MBps": {"compress": round(emb / (t1 - t0), 1), "decompress": round(emb / (t2 - t1), 1)},
                 "h2d_GB": round((cs["h2d_bytes"] + ds["h2d_bytes"]) / 1e9, 2), "d2h_GB": round((cs["d2h_bytes"] + ds["d2h_bytes"]) / 1e9, 2),
                 "host_pool_seconds": {"compress_parse": round(cs["parse_s"], 3), "compress_write": round(cs["write_s"], 3),
                                       "decompress_parse": round(ds["parse_s"], 3), "decompress_write": round(ds["write_s"], 3)},

@@ -107,6 +107,11 @@ struct Slot {   // one chunk's buffers (double-buffered)
 
 #define HIPOK(call) do { if ((call) != hipSuccess) return LEP_GPU_ERROR; } while (0)
 
+struct Joiner {   // a background thread that is joined on every way out of the function, error returns included
+    std::thread t;
+    ~Joiner() { if (t.joinable()) t.join(); }
+};
+
 double g_alloc_s = 0;   // time spent in (re)allocating staging buffers during the current call (single orchestrator thread)
 
 int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch, size_t host_streams);
@@ -463,36 +468,50 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         return 0;
     };
 
-    std::thread writer;   // writes chunk k-1's containers while chunk k is on the GPU
+    // coder kernels of one chunk, stream-ordered behind the previous chunk's (the call returns once they are enqueued, i.e.
+    // after the previous chunk's kernels have finished: the descriptor upload inside lep_gpu_encode_device is synchronous)
+    auto launch_chunk = [&](Chunk* c, Slot* s) -> int {
+        const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
+        if (!nimg) return 0;
+        HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
+        int rc = lep_gpu_encode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
+        if (rc) return rc;
+        if (verify) {
+            HIPOK(hipMemsetAsync(s->d_scratch, 0, c->frame_bytes, s_compute));
+            HIPOK(hipMemsetAsync(s->d_flags, 0, (size_t)nimg * 4, s_compute));
+            rc = lep_gpu_decode_device(g, c->scratch_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status + nseg, s_compute);
+            if (rc) return rc;
+            for (int k = 0; k < nimg; ++k) {
+                const size_t fb = frame_bytes_of(c->host_desc[k]);
+                hipLaunchKernelGGL(lep_compare_kernel, dim3(256), dim3(256), 0, s_compute, (const uint4*)(s->d_frames + c->frame_off[k]),
+                                   (const uint4*)(s->d_scratch + c->frame_off[k]), fb / 16, s->d_flags + k, 1u);
+            }
+        }
+        HIPOK(hipEventRecord(s->done, s_compute));
+        return 0;
+    };
+
+    Joiner writer_guard;   // writes chunk k-1's containers while chunk k is on the GPU
+    std::thread& writer = writer_guard.t;
     size_t ci = 0;
     int slot_i = 0;
     const double t_pipe = now_s();
-    if (!chunks.empty()) { if (int rc = parse_and_upload(chunks[0].get(), &slots[0])) rc_all = rc; }
+    if (!chunks.empty()) {
+        if (int rc = parse_and_upload(chunks[0].get(), &slots[0])) rc_all = rc;
+        else if (int rc2 = launch_chunk(chunks[0].get(), &slots[0])) rc_all = rc2;
+    }
     for (; !rc_all && ci < chunks.size(); ++ci, slot_i ^= 1) {
         Slot* s = &slots[slot_i];
         Chunk* c = chunks[ci].get();
         const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
-        if (nimg) {
-            // kernels of this chunk
-            HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
-            int rc = lep_gpu_encode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
-            if (rc) { rc_all = rc; break; }
-            if (verify) {
-                HIPOK(hipMemsetAsync(s->d_scratch, 0, c->frame_bytes, s_compute));
-                HIPOK(hipMemsetAsync(s->d_flags, 0, (size_t)nimg * 4, s_compute));
-                rc = lep_gpu_decode_device(g, c->scratch_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status + nseg, s_compute);
-                if (rc) { rc_all = rc; break; }
-                for (int k = 0; k < nimg; ++k) {
-                    const size_t fb = frame_bytes_of(c->host_desc[k]);
-                    hipLaunchKernelGGL(lep_compare_kernel, dim3(256), dim3(256), 0, s_compute, (const uint4*)(s->d_frames + c->frame_off[k]),
-                                       (const uint4*)(s->d_scratch + c->frame_off[k]), fb / 16, s->d_flags + k, 1u);
-                }
-            }
-            HIPOK(hipEventRecord(s->done, s_compute));
-        }
-        // while they run: Huffman-decode the next chunk into the other slot (its previous user has been written out) and upload it
+        // while this chunk's coder kernels run: Huffman-decode the next chunk into the other slot (its previous user has been
+        // written out), beside them on the GPU, and queue ITS coder kernels right behind -- only then fetch this chunk's results,
+        // so that the download and the container writing hide under the next chunk's kernels
         if (writer.joinable()) writer.join();
-        if (ci + 1 < chunks.size()) { if (int rc = parse_and_upload(chunks[ci + 1].get(), &slots[slot_i ^ 1])) { rc_all = rc; break; } }
+        if (ci + 1 < chunks.size()) {
+            if (int rc = parse_and_upload(chunks[ci + 1].get(), &slots[slot_i ^ 1])) { rc_all = rc; break; }
+            if (int rc = launch_chunk(chunks[ci + 1].get(), &slots[slot_i ^ 1])) { rc_all = rc; break; }
+        }
         // fetch this chunk's results
         std::vector<uint32_t> lens(nseg);
         std::vector<size_t> hoff(nseg, 0);
@@ -681,28 +700,38 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         return 0;
     };
 
-    std::thread writer;
+    // decoder + Huffman re-encode kernels of one chunk, stream-ordered behind the previous chunk's
+    auto launch_chunk = [&](Chunk* c, Slot* s) -> int {
+        const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
+        if (!nimg) return 0;
+        HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
+        int rc = lep_gpu_decode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
+        if (rc) return rc;
+        if (!c->hseg.empty()) {
+            rc = lep_gpu_huffman_encode_device(g, c->himg.data(), (int)c->himg.size(), c->hseg.data(), (int)c->hseg.size(), s->d_scan, s->d_scanlen, s_compute);
+            if (rc) return rc;
+        }
+        HIPOK(hipEventRecord(s->done, s_compute));
+        return 0;
+    };
+    Joiner writer_guard;
+    std::thread& writer = writer_guard.t;
     std::unique_ptr<Chunk> cur = cut_chunk(0), nxt;
     int slot_i = 0;
     if (int rc = stage_and_upload(cur.get(), &slots[0], &chunk_lens[0])) rc_all = rc;
     const double t_pipe = now_s();
+    if (!rc_all && cur && cur->count > 0) rc_all = launch_chunk(cur.get(), &slots[0]);
     while (!rc_all && cur && cur->count > 0) {
         Slot* s = &slots[slot_i];
         Chunk* c = cur.get();
         const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
-        if (nimg) {
-            HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
-            int rc = lep_gpu_decode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
-            if (rc) { rc_all = rc; break; }
-            if (!c->hseg.empty()) {
-                rc = lep_gpu_huffman_encode_device(g, c->himg.data(), (int)c->himg.size(), c->hseg.data(), (int)c->hseg.size(), s->d_scan, s->d_scanlen, s_compute);
-                if (rc) { rc_all = rc; break; }
-            }
-            HIPOK(hipEventRecord(s->done, s_compute));
-        }
+        // stage the next chunk and queue its kernels behind this chunk's before fetching this chunk's results
         if (writer.joinable()) writer.join();
         nxt = c->first + c->count < n ? cut_chunk(c->first + c->count) : nullptr;
-        if (nxt) { if (int rc = stage_and_upload(nxt.get(), &slots[slot_i ^ 1], &chunk_lens[slot_i ^ 1])) { rc_all = rc; break; } }
+        if (nxt) {
+            if (int rc = stage_and_upload(nxt.get(), &slots[slot_i ^ 1], &chunk_lens[slot_i ^ 1])) { rc_all = rc; break; }
+            if (nxt->count > 0) { if (int rc = launch_chunk(nxt.get(), &slots[slot_i ^ 1])) { rc_all = rc; break; } }
+        }
         std::vector<int32_t> sts(nseg);
         std::vector<uint32_t> slens(c->hseg.size());
         if (nimg) {
@@ -717,7 +746,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                     for (int q = h0; q < h1; ++q) if (slens[q] >= c->hslot[q] && c->hslot[q] < c->hbound[q]) on_gpu = false;
                     if (!on_gpu) {
                         c->hfirst[k] = -1;
-                        if (int rc = host_frames_reserve(s, c->frame_bytes)) return rc;
+                        if (int rc = host_frames_reserve(s, c->frame_bytes)) { rc_all = rc; break; }
                         lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
                     }
                     else for (int q = h0; q < h1; ++q)
@@ -730,6 +759,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                 }
             }
             HIPOK(hipStreamSynchronize(s_down));
+            if (rc_all) break;
         }
         std::shared_ptr<Chunk> keep(cur.release());
         writer = std::thread([&, keep, s, sts, slens]() {
