@@ -27,7 +27,9 @@ struct BitReader {
         unsigned out;
         if (nbits >= avail) {
             int took = avail;
-            out = (unsigned)((low_bits(window, avail) << (nbits - took)) & ((1u << nbits) - 1));
+            // nbits can be anything up to 255 on a corrupt DHT (a DC category is used as a bit count unchecked, like the
+            // reference does, bitops.hh:262-270): shift counts are reduced the way x86 reduces them instead of being undefined
+            out = (unsigned)((low_bits(window, avail) << ((nbits - took) & 63)) & ((1u << (nbits & 31)) - 1));
             int want = nbits - took;
             window = took >= 64 ? 0 : window >> took;
             avail = 0;

@@ -47,6 +47,8 @@ struct Handoff {
     int16_t last_dc[4] = {0, 0, 0, 0};
 };
 
+constexpr uint64_t kMaxFrameBlocks = 4423680;   // (576 MiB - 36 MiB) / 128 B, the reference's default frame budget
+
 struct HuffTable {
     bool set = false;
     uint16_t clen[256];

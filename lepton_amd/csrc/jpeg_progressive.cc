@@ -23,7 +23,9 @@ Handoff make_handoff_public(BitReader& br, const JpegFile& jf, int mcu_y, const 
 
 namespace {
 
-inline int devli(int s, int n) { return s == 0 ? n : (n >= (1 << (s - 1)) ? n : n + 1 - (1 << s)); }
+inline int devli(int s, int n) {   // s > 16 only on a corrupt DHT; shift counts reduced as x86 does (the reference's DEVLI is the same expression)
+    return s == 0 ? n : (n >= (int)(1u << ((s - 1) & 31)) ? n : (int)((unsigned)n + 1u - (1u << (s & 31))));
+}
 inline unsigned envli(int s, int v) { return (unsigned)((v > 0) ? v : (v - 1) + (1 << s)) & ((1u << s) - 1); }
 inline int blen16(unsigned v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
 inline int fdiv2(int v, int p) { return v < 0 ? -((-v) >> p) : (v >> p); }

@@ -209,6 +209,13 @@ bool setup_frame(JpegFile* jf) {
         jf->trunc_bcv[c] = k.bcv;
         jf->trunc_bc[c] = k.bc;
     }
+    // The reference's default build budgets (576 - 36) MiB for the coefficient frame = 4,423,680 blocks
+    // (UncompressedComponents::max_number_of_blocks, jpgcoder.cc:826-885; ~190 Mpixel 4:2:0) and squeezes a larger image into
+    // that budget as if it were a truncated file (uncompressed_components.hh:109-139).  We refuse such a frame instead
+    // (TOO_MUCH_MEMORY_NEEDED): a serving process must not allocate 12 GB because a 5 KB header says 65500 x 65500.
+    uint64_t total_blocks = 0;
+    for (int c = 0; c < jf->ncomp; ++c) total_blocks += (uint64_t)jf->comp[c].bc;
+    if (total_blocks > kMaxFrameBlocks) { jf->error = "coefficient frame beyond the memory budget"; jf->warn = -EX_TOO_MUCH_MEMORY_NEEDED; return false; }
     return true;
 }
 
@@ -313,7 +320,9 @@ static Handoff make_handoff(BitReader& br, const JpegFile& jf, int mcu_y, const 
     return h;
 }
 
-static inline int devli(int s, int n) { return s == 0 ? n : (n >= (1 << (s - 1)) ? n : n + 1 - (1 << s)); }
+static inline int devli(int s, int n) {   // s > 16 only on a corrupt DHT; shift counts reduced as x86 does (the reference's DEVLI is the same expression)
+    return s == 0 ? n : (n >= (int)(1u << ((s - 1) & 31)) ? n : (int)((unsigned)n + 1u - (1u << (s & 31))));
+}
 
 // returns eob (1..64) or -1
 static int decode_block_seq(BitReader& br, const HuffTable& dc, const HuffTable& ac, int16_t* blk) {

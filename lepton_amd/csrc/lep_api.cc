@@ -78,6 +78,7 @@ int lep_jpeg_peek_frame_bytes(const uint8_t* d, size_t n, size_t* bytes) {
             const size_t mcuh = ((size_t)w + 8 * hmax - 1) / (8 * hmax), mcuv = ((size_t)h + 8 * vmax - 1) / (8 * vmax);
             size_t b = 0;
             for (int c = 0; c < nc; ++c) b += mcuh * hs[c] * mcuv * vs[c] * 128;
+            if (b > lep::kMaxFrameBlocks * 128) return lep::EX_TOO_MUCH_MEMORY_NEEDED;   // the frame budget of setup_frame
             *bytes = b;
             return 0;
         }
@@ -156,7 +157,7 @@ int lep_file_open(const uint8_t* d, size_t len, lep_file** out) {
     if (rc) return rc;
     lep::JpegFile& jf = f->lf.jpeg;
     memset(jf.qtables, 0, sizeof jf.qtables);
-    if (!lep::setup_frame(&jf)) return LEP_UNSUPPORTED_JPEG;
+    if (!lep::setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : LEP_UNSUPPORTED_JPEG;
     if (jf.ncomp > 3) return LEP_UNSUPPORTED_4_COLORS;
     if (jf.early_eof) {
         for (int c = 0; c < jf.ncomp; ++c) {

@@ -1,0 +1,72 @@
+"""Memory safety of the host-side parsers on hostile input (they run in-process in the serving daemon, where the reference
+forks a seccomp-jailed child per request): tests/fuzz/host_fuzz.cc built from the library's host sources with
+-fsanitize=address,undefined, fed seeded mutations of the golden JPEG / .lep files plus a few hand-made killers."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, golden
+
+FUZZ = os.path.join(ROOT, "tests", "fuzz")
+CSRC = os.path.join(ROOT, "lepton_amd", "csrc")
+HOST_SOURCES = ["lep_api.cc", "jpeg_scan.cc", "jpeg_progressive.cc", "lep_container.cc", "jpeg_recode.cc"]
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("fuzz") / "host_fuzz")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-o", exe, os.path.join(FUZZ, "host_fuzz.cc")] + [os.path.join(CSRC, s) for s in HOST_SOURCES] + ["-lz"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here: " + r.stderr[-200:])
+    return exe
+
+
+def _run(exe, files, cwd):
+    for i in range(0, len(files), 200):
+        r = subprocess.run([exe] + files[i:i + 200], cwd=cwd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, "sanitizer finding:\n" + r.stderr[-3000:]
+
+
+def test_host_parsers_survive_mutated_files(harness, tmp_path):
+    subprocess.check_call([sys.executable, os.path.join(FUZZ, "mutate.py"), str(tmp_path), "1500", "20260923"])
+    _run(harness, sorted(os.listdir(tmp_path)), str(tmp_path))
+
+
+def test_host_parsers_survive_hand_made_killers(harness, tmp_path):
+    j, l = golden("c420_160x120")
+    sof = j.find(b"\xff\xc0")
+    dht = j.find(b"\xff\xc4")
+    cases = {}
+    big = bytearray(j); big[sof + 5:sof + 9] = (65500).to_bytes(2, "big") * 2
+    cases["huge_dims.jpg"] = bytes(big)                         # 12 GB frame announced by a 5 KB file
+    cat = bytearray(j); cat[dht + 21:dht + 33] = bytes([255]) * 12
+    cases["dc_category_255.jpg"] = bytes(cat)                   # DC symbols used as bit counts
+    cases["soi_only.jpg"] = b"\xff\xd8"
+    cases["soi_sof_cut.jpg"] = j[:sof + 7]
+    cases["no_scan.jpg"] = j[:j.find(b"\xff\xda")]
+    cases["empty.lep"] = b""
+    cases["magic_only.lep"] = l[:4]
+    cases["header_cut.lep"] = l[:40]
+    cases["huge_sizes.lep"] = l[:20] + b"\xff\xff\xff\x7f" * 4 + l[36:]
+    for name, data in cases.items():
+        (tmp_path / name).write_bytes(data)
+    _run(harness, sorted(cases), str(tmp_path))
+
+
+def test_frame_budget_is_the_references():
+    # 4,423,680 blocks = (576 MiB - 36 MiB) / 128 B: UncompressedComponents::max_number_of_blocks of the default build
+    from lepton_amd.codec import JpegImage, LeptonError
+
+    j, _ = golden("c420_160x120")
+    sof = j.find(b"\xff\xc0")
+    big = bytearray(j); big[sof + 5:sof + 9] = (65500).to_bytes(2, "big") * 2
+    with pytest.raises(LeptonError) as e:
+        JpegImage(bytes(big))
+    assert e.value.code == 38   # TOO_MUCH_MEMORY_NEEDED
+    ok = bytearray(j); ok[sof + 5:sof + 7] = (9000).to_bytes(2, "big"); ok[sof + 7:sof + 9] = (12000).to_bytes(2, "big")
+    img = JpegImage(bytes(ok))    # 2.5 M blocks: inside the budget; the short scan simply ends early, like in the reference
+    assert img.desc.width_blocks[0] == 1500
