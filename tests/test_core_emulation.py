@@ -17,7 +17,8 @@ EMU_SO = os.path.join(ROOT, "tests", "emu", "libcore_emu.so")
 @pytest.fixture(scope="module")
 def emu():
     src = os.path.join(ROOT, "tests", "emu", "core_emu.cc")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", EMU_SO, src])
+    extra = os.environ.get("LEP_EMU_DEFINES", "").split()   # experiment variants of the kernels (-DLEP_...)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared"] + extra + ["-o", EMU_SO, src])
     return C.CDLL(EMU_SO)
 
 
