@@ -1,16 +1,21 @@
 // lepton_served -- the daemon around lep_serve_start: the reference's serving flags
 // (src/lepton/jpgcoder.cc:1026-1186, help text :2089-2110) in front of the GPU batch pipeline.  One process per GPU.
 //   lepton_served -socket[=name] [-listen[=port]] [-zliblisten=port] [-listenbacklog=n] [-maxchildren=n]
-//                 [-timebound=<n>ms|s|us] [-skipverify|-verify] [-device=k] [-maxbatch=n] [-batchwindow=<us>] [-hosthuffman]
+//                 [-timebound=<n>ms|s|us] [-skipverify|-verify] [-device=k | -devices=a,b,...] [-maxbatch=n]
+//                 [-batchwindow=<us>] [-hosthuffman]
+// -devices=0,1,...: one serving process per GPU (forked before any HIP call), sockets <name>.<device> (TCP: port + device,
+// zlib port + device); the parent only waits and passes SIGTERM / SIGINT / SIGQUIT on.
 // Prints the socket name on stdout once it is listening (socket_serve.cc:383-384) and serves until SIGINT / SIGTERM /
 // SIGQUIT, removing its socket files on the way out (cleanup_socket, socket_serve.cc:71-84).
 #include <signal.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/lepton_mi355x.h"
 
@@ -26,6 +31,7 @@ int main(int argc, char** argv) {
     std::string uds, zuds;
     bool want_uds = false;
     int device = 0;
+    std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         const char* a = argv[i];
         if (starts(a, "-socket")) { want_uds = true; if (a[7] == '=') uds = a + 8; }
@@ -42,6 +48,7 @@ int main(int argc, char** argv) {
         }
         else if (!strcmp(a, "-skipverify") || !strcmp(a, "-skipvalidate")) o.batch.verify = 0;
         else if (!strcmp(a, "-verify") || !strcmp(a, "-validate")) o.batch.verify = 1;
+        else if (starts(a, "-devices=")) { for (const char* q = a + 9; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; } }
         else if (starts(a, "-device=")) device = atoi(a + 8);
         else if (starts(a, "-maxbatch=")) o.max_batch = atoi(a + 10);
         else if (starts(a, "-batchwindow=")) o.batch_window_us = atoi(a + 13);
@@ -51,6 +58,42 @@ int main(int argc, char** argv) {
     }
     if (!want_uds && !o.tcp_port) { fprintf(stderr, "usage: lepton_served -socket[=name] | -listen[=port] [...]\n"); return 1; }
     if (o.time_bound_ms && !want_uds) { fprintf(stderr, "Time bound action only supported with UNIX domain sockets\n"); return 1; }   // jpgcoder.cc:1209-1212
+    if (devices.size() > 1) {   // one process per GPU, each with its own sockets; this process only supervises
+        if (want_uds && uds.empty()) { fprintf(stderr, "lepton_served: -devices needs -socket=<name> (children listen on <name>.<device>)\n"); return 1; }
+        std::vector<pid_t> kids;
+        for (int dev : devices) {
+            const pid_t pid = fork();
+            if (pid == 0) {
+                device = dev;
+                if (want_uds) uds += "." + std::to_string(dev);
+                if (o.tcp_port) o.tcp_port += dev;
+                if (o.zlib_tcp_port) o.zlib_tcp_port += dev;
+                devices.clear();
+                break;
+            }
+            if (pid > 0) kids.push_back(pid);
+        }
+        if (!devices.empty()) {
+            struct sigaction sa;
+            memset(&sa, 0, sizeof sa);
+            sa.sa_handler = on_signal;
+            sigaction(SIGINT, &sa, nullptr); sigaction(SIGTERM, &sa, nullptr); sigaction(SIGQUIT, &sa, nullptr);
+            int worst = 0;
+            size_t alive = kids.size();
+            while (alive && !g_quit) {   // a child that dies on its own (no such device, socket taken) is reported, the others keep serving
+                int st = 0;
+                const pid_t r = waitpid(-1, &st, 0);
+                if (r > 0) {
+                    --alive;
+                    if (WIFEXITED(st) && WEXITSTATUS(st)) worst = WEXITSTATUS(st);
+                    fprintf(stderr, "lepton_served: child %d ended (status %d)\n", (int)r, st);
+                }
+            }
+            for (pid_t k : kids) kill(k, SIGTERM);
+            for (;;) { int st = 0; const pid_t r = waitpid(-1, &st, 0); if (r <= 0) break; if (WIFEXITED(st) && WEXITSTATUS(st)) worst = WEXITSTATUS(st); }
+            return worst;
+        }
+    } else if (devices.size() == 1) device = devices[0];
     if (want_uds && uds.empty()) {   // /tmp/<random id>.uport and .z0 (name_socket, socket_serve.cc:40-69)
         unsigned char r[16] = {0};
         if (FILE* f = fopen("/dev/urandom", "rb")) { size_t n = fread(r, 1, sizeof r, f); (void)n; fclose(f); }
