@@ -97,8 +97,10 @@ __global__ __launch_bounds__(64) void lep_encode_v2_kernel(const ImageDev* __res
     bins[s] = w.nbins;
 }
 
-// v3 encoder: v2's phases at 8 wavefronts per SIMD, bool coder as uniform vector code (lep_enc3.h)
-__global__ __launch_bounds__(64, 8) void lep_encode_v3_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
+// v3 encoder: v2's phases at 8 wavefronts per SIMD, bool coder as uniform vector code (lep_enc3.h).  WAVES = waves per SIMD
+// the register allocation is held to (8 = 64 VGPRs, the default; 7 = 72 VGPRs, LEP_ENC_WAVES, an experiment)
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void lep_encode_v3_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
                                                               uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
                                                               uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
     __shared__ lep3::Enc3Shared sh;
@@ -249,6 +251,7 @@ struct lep_gpu {
     bool timed = false;
     int decode_kernel = 4;   // 4 = v4 (default), 3 = v3 scalar-unit serial part, 2 = v2 prefetch rounds, 1 = single-lane reference kernel (LEP_DECODE_KERNEL)
     int dec3_waves = 0;      // register budget variant of the v3 / v4 decoder: 0 = by batch size, LEP_DEC3_WAVES = 4 | 5 | 6 | 8
+    int enc_waves = 8;       // register budget variant of the v3 encoder (LEP_ENC_WAVES = 7 | 8)
     int encode_kernel = 3;   // 3 = v3 (default), 2 = v2 wave-cooperative, 1 = single-lane reference kernel (LEP_ENCODE_KERNEL)
     std::string err;
     const char* last_kernel = "";   // name of the kernel the most recent launch used
@@ -337,6 +340,7 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         int waves = g->dec3_waves;
         if (!waves) waves = nseg > 4608 ? 8 : 4;
         if (waves >= 8) { g->last_kernel = "lep_decode_v4_kernel<8>"; LEP_LAUNCH_DEC4(8); }
+        else if (waves == 7) { g->last_kernel = "lep_decode_v4_kernel<7>"; LEP_LAUNCH_DEC4(7); }
         else if (waves >= 6) { g->last_kernel = "lep_decode_v4_kernel<6>"; LEP_LAUNCH_DEC4(6); }
         else { g->last_kernel = "lep_decode_v4_kernel<4>"; LEP_LAUNCH_DEC4(4); }
 #undef LEP_LAUNCH_DEC4
@@ -366,10 +370,15 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
                            (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
     } else if (!DEC && g->encode_kernel == 3) {
-        g->last_kernel = "lep_encode_v3_kernel";
-        hipLaunchKernelGGL(lep_encode_v3_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                           (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
-                           d_streams, d_stream_len, d_status, g->d_bins);
+        g->last_kernel = g->enc_waves == 7 ? "lep_encode_v3_kernel<7>" : "lep_encode_v3_kernel";
+        if (g->enc_waves == 7)
+            hipLaunchKernelGGL((lep_encode_v3_kernel<7>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
+                               (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                               d_streams, d_stream_len, d_status, g->d_bins);
+        else
+            hipLaunchKernelGGL((lep_encode_v3_kernel<8>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
+                               (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                               d_streams, d_stream_len, d_status, g->d_bins);
     } else if (!DEC && g->encode_kernel == 2) {
         g->last_kernel = "lep_encode_v2_kernel";
         hipLaunchKernelGGL(lep_encode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
@@ -395,6 +404,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3;
     if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 4;
     if (const char* e = getenv("LEP_DEC3_WAVES")) g->dec3_waves = atoi(e);
+    if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 7 ? 7 : 8;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||

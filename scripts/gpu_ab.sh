@@ -1,12 +1,14 @@
 #!/bin/bash
-# A/B of library builds on one box: scripts/gpu_ab.sh <tag> <lib>...   (each lib = path of a liblepton_mi355x*.so variant)
+# A/B of library builds / run-time variants on one box: scripts/gpu_ab.sh <tag> <lib>[@ENV=VAL[,ENV=VAL]]...
+# (each lib = path of a liblepton_mi355x*.so variant; the optional environment selects kernel variants inside it)
 set -u
 TAG=$1; shift; export TMPDIR=/tmp
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 for round in 1 2; do
-for lib in "$@"; do
-  name=$(basename $lib .so)
-  LEP_LIB_PATH=$PWD/$lib timeout 300 python bench.py --steps 2 --warmup 1 --no-end-to-end --no-cpu-baseline > $OUT/${name}_$round.json 2> $OUT/${name}_$round.err
+for spec in "$@"; do
+  lib=${spec%%@*}; envs=""; [ "$spec" != "$lib" ] && envs=$(echo "${spec#*@}" | tr ',' ' ')
+  name=$(basename $lib .so)$(echo "$envs" | tr -d ' ' | tr '=' '_')
+  env $envs LEP_LIB_PATH=$PWD/$lib timeout 300 python bench.py --steps 2 --warmup 1 --no-end-to-end --no-cpu-baseline > $OUT/${name}_$round.json 2> $OUT/${name}_$round.err
   python - $OUT/${name}_$round.json $name <<'PY'
 import json, sys
 try:
