@@ -124,3 +124,17 @@ def test_lep_header_fields():
     assert abi.lib().lep_file_jpeg_size(f.handle) == len(jpg)
     assert int.from_bytes(lep[-4:], "little") == len(lep)
     assert len(f.segments) == lep[4] and f.segments[-1].is_last == 1
+
+
+def test_bytes_after_a_lep_file_are_ignored_like_the_reference():
+    # Concatenated .lep files (jpgcoder.cc:1881-1897, test_suite/test_concat.sh) only chain with the brotli container
+    # (v2+); for the v1 files written here the reference binary decodes the first file and ignores whatever follows
+    # (checked against it: another .lep, zeros, 0xff, a ramp).  Same here.
+    import oracle_binding as ob
+
+    jpg, lep = golden("c420_160x120")
+    _, other = golden("gray_120x88")
+    for tail in (other, bytes(100), bytes([255]) * 50, bytes(range(256)) * 3, b"\x01"):
+        f = LepFile(lep + tail)
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        assert f.recode() == jpg
