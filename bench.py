@@ -73,6 +73,44 @@ def cpu_baseline(jpgs, budget_s=20.0):
         "hot_path_only_decode_MBps": round(mb / arith_dec, 3) if arith_dec else None,
         "host_cpus": os.cpu_count(),
     }
+    # throughput mode (SURVEY.md 8d iii, what `lepton -benchmark` does with its "Loaded N" rows): P single-threaded
+    # processes side by side, P = the CPUs this container may use (affinity mask capped by the cgroup quota)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+
+        P = len(os.sched_getaffinity(0))
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                P = max(1, min(P, int(int(q) / int(per))))
+        except Exception:
+            pass
+        deadline = time.perf_counter() + budget_s / 2
+
+        def worker(w):
+            done = 0
+            k = w
+            while time.perf_counter() < deadline:
+                j = jpgs[k % len(jpgs)]
+                jp, lp, bp = (os.path.join(tmp, "p%d.%s" % (w, e)) for e in ("jpg", "lep", "back.jpg"))
+                open(jp, "wb").write(j)
+                if subprocess.run([ref, "-singlethread", "-unjailed", "-skipverify", jp, lp], capture_output=True).returncode:
+                    break
+                if subprocess.run([ref, "-singlethread", "-unjailed", lp, bp], capture_output=True).returncode:
+                    break
+                done += len(j)
+                k += P
+            return done
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(P) as ex:
+            total = sum(ex.map(worker, range(P)))
+        wall = time.perf_counter() - t0
+        if total:
+            out["all_cores"] = {"processes": P, "value": round(total / 1e6 / wall, 3), "unit": "MB/s (encode + decode of every file, aggregate)",
+                                "sample": "%d single-threaded reference processes side by side for %.1f s (%.1f MB round-tripped)" % (P, wall, total / 1e6)}
+    except Exception as e:
+        out["all_cores"] = {"error": repr(e)[:200]}
     n2, mb2, e2, d2, _, _ = run([], budget_s / 3)
     if n2:
         out["multithread"] = {"threads": 8, "value": round(mb2 / (e2 + d2), 3), "encode_MBps": round(mb2 / e2, 3), "decode_MBps": round(mb2 / d2, 3),
