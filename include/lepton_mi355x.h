@@ -29,7 +29,7 @@ enum {
     LEP_SUCCESS = 0, LEP_ASSERTION_FAILURE = 1, LEP_CODING_ERROR = 2, LEP_SHORT_READ = 3,
     LEP_UNSUPPORTED_4_COLORS = 4, LEP_COEFFICIENT_OUT_OF_RANGE = 6, LEP_STREAM_INCONSISTENT = 7,
     LEP_PROGRESSIVE_UNSUPPORTED = 8, LEP_SAMPLING_BEYOND_TWO_UNSUPPORTED = 10,
-    LEP_THREADING_PARTIAL_MCU = 12, LEP_VERSION_UNSUPPORTED = 13, LEP_OS_ERROR = 33,
+    LEP_THREADING_PARTIAL_MCU = 12, LEP_VERSION_UNSUPPORTED = 13, LEP_ONLY_GARBAGE_NO_JPEG = 14, LEP_OS_ERROR = 33,
     LEP_TOO_MUCH_MEMORY_NEEDED = 38,   /* coefficient frame beyond the reference's default budget of 4,423,680 blocks (566 MB) */
     LEP_ROUNDTRIP_FAILURE = 41, LEP_UNSUPPORTED_JPEG = 42, LEP_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 43,
     LEP_BUFFER_TOO_SMALL = 100, LEP_GPU_ERROR = 120
@@ -173,6 +173,8 @@ int lep_jpeg_peek_frame_bytes(const uint8_t *jpg, size_t len, size_t *bytes);
  * filled except for scan / blocks / rows_off (device addresses, the caller's), lep_jpeg_scan_bytes gives the bytes to
  * upload, and lep_jpeg_finish_gpu turns the kernel's row records into hand-offs (non-zero: irregular scan, use the host). */
 int lep_jpeg_open_gpu(const uint8_t *jpg, size_t len, lep_jpeg **out, lep_huffdec_image *image, int *eligible);
+/* the parse behind lep_compress_slice: len already bounded by -trunc; lep_jpeg_plan / lep_jpeg_write_lep then produce the 'Y' file */
+int lep_jpeg_open_slice(const uint8_t *jpg, size_t len, size_t start_byte, lep_jpeg **out);
 int lep_jpeg_scan_bytes(const lep_jpeg *j, const uint8_t **data, size_t *len);
 int lep_jpeg_finish_gpu(lep_jpeg *j, const lep_huffdec_row *rows);
 void lep_jpeg_close(lep_jpeg *j);
@@ -217,6 +219,12 @@ int lep_demux(const uint8_t *data, size_t len, lep_bytes *streams16);
 
 /* ---- layer 3: whole files ------------------------------------------------------------------- */
 int lep_compress(lep_gpu *g, const uint8_t *jpg, size_t len, lep_bytes *out);
+/* `lepton -startbyte=<start_byte> -trunc=<trunc>` (jpgcoder.cc:1132-1140, 3801-3843; test_suite/test_2nd_block.sh): the .lep
+ * restores bytes [start_byte, trunc) of the JPEG (trunc 0 = to the end) -- how a JPEG stored as fixed-size blocks is
+ * compressed block by block.  Format flag 'Y': header segments reduced to the ones the scan needs, hand-off rows in front of
+ * start_byte dropped, the bytes up to the first remaining MCU row kept verbatim.  lep_decompress reads such files like any
+ * other.  Progressive files cannot be sliced (PROGRESSIVE_UNSUPPORTED), as in the reference. */
+int lep_compress_slice(lep_gpu *g, const uint8_t *jpg, size_t len, size_t start_byte, size_t trunc, lep_bytes *out);
 int lep_decompress(lep_gpu *g, const uint8_t *lepdata, size_t len, lep_bytes *out);
 
 /* Whole batches of files as a pipeline (what `lepton -socket` workers / src/lepton/socket_serve.cc:312-390 would hand to

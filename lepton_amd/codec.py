@@ -28,11 +28,15 @@ def _check(rc, what):
 class JpegImage:
     """A parsed JPEG: coefficient frame + hand-offs (host memory owned by the library)."""
 
-    def __init__(self, data, allow_progressive=True):
+    def __init__(self, data, allow_progressive=True, start_byte=0, trunc=0):
+        """start_byte / trunc: `lepton -startbyte= -trunc=`: the .lep written from this object restores bytes [start_byte, trunc)"""
         self._L = abi.lib()
-        self.data = bytes(data)
+        self.data = bytes(data[:trunc] if trunc else data)
         self.handle = C.c_void_p()
-        _check(self._L.lep_jpeg_open(self.data, len(self.data), 1 if allow_progressive else 0, C.byref(self.handle)), "lep_jpeg_open")
+        if start_byte:
+            _check(self._L.lep_jpeg_open_slice(self.data, len(self.data), start_byte, C.byref(self.handle)), "lep_jpeg_open_slice")
+        else:
+            _check(self._L.lep_jpeg_open(self.data, len(self.data), 1 if allow_progressive else 0, C.byref(self.handle)), "lep_jpeg_open")
         self.desc = abi.ImageDesc()
         _check(self._L.lep_jpeg_describe(self.handle, C.byref(self.desc)), "lep_jpeg_describe")
 
@@ -173,6 +177,13 @@ class GpuCodec:
         rc = self._L.lep_compress(self.handle, bytes(jpg), len(jpg), C.byref(out))
         if rc:
             raise LeptonError(rc, "lep_compress [%s]" % self.last_error())
+        data = out.tobytes()
+        self._L.lep_free(out.data)
+        return data
+
+    def compress_slice(self, jpg, start_byte, trunc=0):
+        out = abi.Bytes()
+        _check(self._L.lep_compress_slice(self.handle, jpg, len(jpg), start_byte, trunc, C.byref(out)), "lep_compress_slice")
         data = out.tobytes()
         self._L.lep_free(out.data)
         return data

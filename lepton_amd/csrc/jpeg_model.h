@@ -67,6 +67,10 @@ struct JpegFile {
     std::vector<uint8_t> rst_err;   // wrongly placed RST markers at scan end, per scan
     bool early_eof = false;
     int padbit = -1;
+    // -startbyte=<n> (jpgcoder.cc:364, 1132-1133, 3801-3843): the .lep restores only the bytes from start_byte on; set before
+    // parse_jpeg.  prefix_garbage = the raw bytes from start_byte up to the first MCU row that starts at or after it.
+    uint32_t start_byte = 0;
+    std::vector<uint8_t> prefix_garbage;
     uint32_t file_size = 0;
     // --- frame
     int width = 0, height = 0, ncomp = 0;

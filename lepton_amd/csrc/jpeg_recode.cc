@@ -231,7 +231,9 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result);   // jpeg_pro
 
 int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
     JpegFile& jf = lf->jpeg;
-    if (lf->flag != 'Z') return recode_progressive(lf, result);
+    // 'Z' and 'Y' (a -startbyte slice) take the baseline re-coder, 'X' the general one: read_fixed_ujpg_header tests
+    // header[1] == 'Z' || (header[1] & 1) == ('Y' & 1), jpgcoder.cc:2162-2166
+    if (lf->flag != 'Z' && lf->flag != 'Y') return recode_progressive(lf, result);
     const size_t max_file_size = lf->jpeg_size;
     if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
     BoundedOut out;

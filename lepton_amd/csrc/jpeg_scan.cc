@@ -290,7 +290,9 @@ static int split_file(const uint8_t* d, size_t n, JpegFile* jf) {
         if (len < 4) break;
         if (seg.size() < len) seg.resize(len);
         if (rdn(seg.data() + 4, len - 4) != (uint16_t)(len - 4)) break;
-        jf->hdr.insert(jf->hdr.end(), seg.begin(), seg.begin() + len);
+        // a slice keeps only the segments needed to decode the scan (is_needed_for_second_block, jpgcoder.cc:2242-2264, :2414)
+        const bool needed = type == 0xC4 || type == 0xDB || type == 0xDD || type == 0xDA || type == 0xC0 || type == 0xC1 || type == 0xC2;
+        if (jf->start_byte == 0 || needed) jf->hdr.insert(jf->hdr.end(), seg.begin(), seg.begin() + len);
     }
     if (!have_hdr || jf->hdr.empty()) { jf->error = "unexpected end of data encountered in header"; return EX_UNSUPPORTED_JPEG; }
     if (jf->scan.empty()) { jf->error = "unexpected end of data encountered in huffman"; return EX_UNSUPPORTED_JPEG; }
@@ -645,7 +647,23 @@ int parse_jpeg(const uint8_t* data, size_t size, bool allow_progressive, JpegFil
     if (rc) return rc;
     if (!setup_frame(jf)) return jf->warn < 0 ? -jf->warn : EX_UNSUPPORTED_JPEG;
     if (jf->ncomp > 3) return EX_UNSUPPORTED_4_COLORS;
-    return decode_scans(jf, allow_progressive);
+    if (jf->start_byte) allow_progressive = false;   // "Encode of partial progressive images not allowed" (jpgcoder.cc:1205-1208)
+    rc = decode_scans(jf, allow_progressive);
+    if (rc || !jf->start_byte) return rc;
+    // -startbyte: drop the hand-off rows that lie in front of start_byte (the last record always stays) and keep the raw
+    // bytes between start_byte and the first remaining row as prefix garbage (write_ujpg, jpgcoder.cc:3801-3843)
+    std::vector<Handoff> kept;
+    for (size_t i = 0; i < jf->rows.size(); ++i)
+        if (i + 1 == jf->rows.size() || jf->rows[i].segment_size >= jf->start_byte) kept.push_back(jf->rows[i]);
+    jf->rows.swap(kept);
+    if (jf->rows.empty() || jf->rows[0].segment_size < jf->start_byte) return EX_ONLY_GARBAGE_NO_JPEG;
+    uint32_t prefix = jf->rows[0].segment_size - jf->start_byte;
+    if (jf->rows.size() > 1 && prefix) --prefix;   // the reference's own "FIXME why is this ?!" (jpgcoder.cc:3823-3827)
+    jf->prefix_garbage.clear();
+    if (prefix && jf->start_byte < size)
+        jf->prefix_garbage.assign(data + jf->start_byte, data + jf->start_byte + std::min<size_t>(prefix, size - jf->start_byte));
+    jf->prefix_garbage.resize(prefix, 0);
+    return 0;
 }
 
 }  // namespace lep

@@ -97,6 +97,16 @@ int lep_jpeg_open_into(const uint8_t* jpg, size_t len, int allow_progressive, vo
     *out = j.release();
     return 0;
 }
+int lep_jpeg_open_slice(const uint8_t* jpg, size_t len, size_t start_byte, lep_jpeg** out) {
+    if (start_byte > 0xffffffffu) return LEP_ASSERTION_FAILURE;
+    std::unique_ptr<lep_jpeg> j(new lep_jpeg);
+    j->jf.start_byte = (uint32_t)start_byte;
+    j->opt.allow_progressive = start_byte == 0;
+    int rc = lep::parse_jpeg(jpg, len, start_byte == 0, &j->jf);
+    if (rc) return rc;
+    *out = j.release();
+    return 0;
+}
 int lep_jpeg_open_gpu(const uint8_t* jpg, size_t len, lep_jpeg** out, lep_huffdec_image* image, int* eligible) {
     std::unique_ptr<lep_jpeg> j(new lep_jpeg);
     j->opt.allow_progressive = true;
@@ -252,10 +262,13 @@ int lep_file_recode_finish(lep_file* f, const lep_bytes* seg_bytes, int nseg, le
 // ---- layer 3: whole files (JPEG -> .lep -> JPEG) through the GPU hot path ---------------------------
 extern "C" {
 
-int lep_compress(lep_gpu* g, const uint8_t* jpg, size_t len, lep_bytes* out) {
+int lep_compress(lep_gpu* g, const uint8_t* jpg, size_t len, lep_bytes* out) { return lep_compress_slice(g, jpg, len, 0, 0, out); }
+
+int lep_compress_slice(lep_gpu* g, const uint8_t* jpg, size_t len, size_t start_byte, size_t trunc, lep_bytes* out) {
     if (!g) return LEP_GPU_ERROR;
+    if (trunc && trunc < len) len = trunc;   // -trunc bounds the reader (check_file -> BindFdToReader, jpgcoder.cc:2181)
     lep_jpeg* j = nullptr;
-    int rc = lep_jpeg_open(jpg, len, 1, &j);
+    int rc = lep_jpeg_open_slice(jpg, len, start_byte, &j);
     if (rc) return rc;
     std::unique_ptr<lep_jpeg> hold(j);
     lep_image_desc d;

@@ -131,6 +131,11 @@ static std::vector<uint8_t> build_header_payload(const JpegFile& jf, const std::
         put_le32(p, (uint32_t)jf.max_sah);
         for (int i = 0; i < 4; ++i) put_le32(p, (uint32_t)jf.max_dpos[i]);
     }
+    if (jf.start_byte) {   // written even when empty (prefix_grbgdata != NULL, jpgcoder.cc:4009-4017)
+        p.insert(p.end(), {'P', 'G', 'R'});
+        put_le32(p, (uint32_t)jf.prefix_garbage.size());
+        p.insert(p.end(), jf.prefix_garbage.begin(), jf.prefix_garbage.end());
+    }
     if (!jf.garbage.empty()) {
         p.insert(p.end(), {'G', 'R', 'B'});
         put_le32(p, (uint32_t)jf.garbage.size());
@@ -267,11 +272,11 @@ int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::v
     out->reserve(z.size() + 64);
     out->push_back(0xCF); out->push_back(0x84);
     out->push_back(1);                                     // format version
-    out->push_back(jf.progressive_needed ? 'X' : 'Z');
+    out->push_back(jf.start_byte ? 'Y' : (jf.progressive_needed ? 'X' : 'Z'));   // jpgcoder.cc:4046-4052
     out->push_back((uint8_t)segs.size());
     out->insert(out->end(), 3, 0);
     out->insert(out->end(), 12, 0);                        // git revision: zeros, as an out-of-git reference build writes
-    put_le32(*out, jf.file_size);
+    put_le32(*out, jf.file_size - jf.start_byte);
     put_le32(*out, (uint32_t)z.size());
     out->insert(out->end(), z.begin(), z.end());
     out->insert(out->end(), {'C', 'M', 'P'});

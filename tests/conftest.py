@@ -25,7 +25,13 @@ def _built():
 
 def golden_cases():
     man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
-    return sorted(k for k, v in man.items() if v.get("encode_exit") == 0)
+    return sorted(k for k, v in man.items() if v.get("encode_exit") == 0 and "slice" not in v)
+
+
+def slice_cases():
+    """`lepton -startbyte -trunc` fixtures: [(name, start_byte, trunc)]; the .jpg is the whole input, the .lep restores [start, trunc)"""
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    return sorted((k, v["slice"][0], v["slice"][1]) for k, v in man.items() if v.get("encode_exit") == 0 and "slice" in v and v.get("restored_equals_input"))
 
 
 def golden(name):

@@ -61,6 +61,17 @@ CASES = {
     "prog_truncated_q97_800x600": lambda: (lambda b: b[:len(b) * 2 // 3])(corpus.synth_jpeg(800, 600, 134, quality=97, progressive=True)),
 }
 
+# `lepton -startbyte=<s> -trunc=<t>` slices (format flag 'Y'): name -> (input case above, start_byte, trunc; 0 = to the end).
+# The .jpg of a slice fixture is the WHOLE input file; the .lep restores bytes [start_byte, trunc) of it.
+SLICES = {
+    "slice_mid_q97": ("q30_256x256_4seg", 60000, 140000),      # several thread segments, starts and ends inside the scan
+    "slice_tail_q97": ("q30_256x256_4seg", 150000, 0),          # to the end of the file: EOI included
+    "slice_head_cut": ("c420_160x120", 700, 4000),               # start inside the header area... the first rows, cut short
+    "slice_rst": ("rst_c420_176x112", 2000, 0),                  # restart markers inside the slice
+    "slice_4seg_q97": ("_q97_960x720", 90000, 400000),          # 310 kB of scan: four thread segments, the first starts mid-image
+}
+SLICE_ONLY_INPUTS = {"_q97_960x720": lambda: corpus.synth_jpeg(960, 720, 140, quality=97)}
+
 
 def main():
     only = set(sys.argv[1:])   # names to (re)generate; default: all
@@ -85,6 +96,26 @@ def main():
                          restored_md5=hashlib.md5(restored).hexdigest(), restored_equals_input=restored == jpg)
         elif os.path.exists(lp):
             os.unlink(lp)
+        manifest[name] = entry
+        print(name, entry)
+    for name, (src, start, trunc) in SLICES.items():
+        if only and name not in only:
+            continue
+        jpg = (CASES.get(src) or SLICE_ONLY_INPUTS[src])()
+        jp = os.path.join(HERE, name + ".jpg")
+        lp = os.path.join(HERE, name + ".lep")
+        open(jp, "wb").write(jpg)
+        if os.path.exists(lp):
+            os.unlink(lp)
+        flags = ["-startbyte=%d" % start] + (["-trunc=%d" % trunc] if trunc else [])
+        r = subprocess.run([REF, "-unjailed", "-skipverify"] + flags + [jp, lp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        entry = {"jpg_md5": hashlib.md5(jpg).hexdigest(), "jpg_size": len(jpg), "encode_exit": r.returncode, "slice": [start, trunc]}
+        if r.returncode == 0:
+            lep = open(lp, "rb").read()
+            back = subprocess.run([REF, "-unjailed", lp, "/tmp/_golden_back.jpg"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            restored = open("/tmp/_golden_back.jpg", "rb").read() if back.returncode == 0 else b""
+            entry.update(lep_md5=hashlib.md5(lep).hexdigest(), lep_size=len(lep), segments=lep[4], flag=chr(lep[3]),
+                         restored_md5=hashlib.md5(restored).hexdigest(), restored_equals_input=restored == jpg[start:(trunc or len(jpg))])
         manifest[name] = entry
         print(name, entry)
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
