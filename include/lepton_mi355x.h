@@ -175,6 +175,10 @@ int lep_jpeg_peek_frame_bytes(const uint8_t *jpg, size_t len, size_t *bytes);
 int lep_jpeg_open_gpu(const uint8_t *jpg, size_t len, lep_jpeg **out, lep_huffdec_image *image, int *eligible);
 /* the parse behind lep_compress_slice: len already bounded by -trunc; lep_jpeg_plan / lep_jpeg_write_lep then produce the 'Y' file */
 int lep_jpeg_open_slice(const uint8_t *jpg, size_t len, size_t start_byte, lep_jpeg **out);
+/* `lepton -embedding=<offset>` (jpgcoder.cc:1135-1137, 2275-2282; test_suite/test_embedded.sh): a JPEG that sits `offset` bytes
+ * into a larger blob; the .lep ('PGE' section + ordinary garbage) restores the whole blob */
+int lep_jpeg_open_embedded(const uint8_t *blob, size_t len, size_t offset, lep_jpeg **out);
+int lep_compress_embedded(lep_gpu *g, const uint8_t *blob, size_t len, size_t offset, lep_bytes *out);
 int lep_jpeg_scan_bytes(const lep_jpeg *j, const uint8_t **data, size_t *len);
 int lep_jpeg_finish_gpu(lep_jpeg *j, const lep_huffdec_row *rows);
 void lep_jpeg_close(lep_jpeg *j);

@@ -28,12 +28,15 @@ def _check(rc, what):
 class JpegImage:
     """A parsed JPEG: coefficient frame + hand-offs (host memory owned by the library)."""
 
-    def __init__(self, data, allow_progressive=True, start_byte=0, trunc=0):
-        """start_byte / trunc: `lepton -startbyte= -trunc=`: the .lep written from this object restores bytes [start_byte, trunc)"""
+    def __init__(self, data, allow_progressive=True, start_byte=0, trunc=0, embedding=0):
+        """start_byte / trunc: `lepton -startbyte= -trunc=`: the .lep written from this object restores bytes [start_byte, trunc);
+        embedding: `lepton -embedding=`: the JPEG starts that many bytes into `data`, the .lep restores all of `data`"""
         self._L = abi.lib()
         self.data = bytes(data[:trunc] if trunc else data)
         self.handle = C.c_void_p()
-        if start_byte:
+        if embedding:
+            _check(self._L.lep_jpeg_open_embedded(self.data, len(self.data), embedding, C.byref(self.handle)), "lep_jpeg_open_embedded")
+        elif start_byte:
             _check(self._L.lep_jpeg_open_slice(self.data, len(self.data), start_byte, C.byref(self.handle)), "lep_jpeg_open_slice")
         else:
             _check(self._L.lep_jpeg_open(self.data, len(self.data), 1 if allow_progressive else 0, C.byref(self.handle)), "lep_jpeg_open")
@@ -184,6 +187,13 @@ class GpuCodec:
     def compress_slice(self, jpg, start_byte, trunc=0):
         out = abi.Bytes()
         _check(self._L.lep_compress_slice(self.handle, jpg, len(jpg), start_byte, trunc, C.byref(out)), "lep_compress_slice")
+        data = out.tobytes()
+        self._L.lep_free(out.data)
+        return data
+
+    def compress_embedded(self, blob, offset):
+        out = abi.Bytes()
+        _check(self._L.lep_compress_embedded(self.handle, blob, len(blob), offset, C.byref(out)), "lep_compress_embedded")
         data = out.tobytes()
         self._L.lep_free(out.data)
         return data

@@ -71,6 +71,9 @@ struct JpegFile {
     // parse_jpeg.  prefix_garbage = the raw bytes from start_byte up to the first MCU row that starts at or after it.
     uint32_t start_byte = 0;
     std::vector<uint8_t> prefix_garbage;
+    // -embedding=<n> (jpgcoder.cc:365, 1135-1137, 2275-2282): the JPEG sits n bytes into a larger blob; those n bytes are kept as
+    // prefix garbage ('PGE' section), what follows EOI as ordinary garbage, and the .lep restores the whole blob
+    bool embedded = false;
     uint32_t file_size = 0;
     // --- frame
     int width = 0, height = 0, ncomp = 0;

@@ -107,6 +107,20 @@ int lep_jpeg_open_slice(const uint8_t* jpg, size_t len, size_t start_byte, lep_j
     *out = j.release();
     return 0;
 }
+int lep_jpeg_open_embedded(const uint8_t* blob, size_t len, size_t offset, lep_jpeg** out) {
+    if (offset + 4 > len || len > 0xffffffffu) return LEP_UNSUPPORTED_JPEG;
+    std::unique_ptr<lep_jpeg> j(new lep_jpeg);
+    j->opt.allow_progressive = true;
+    int rc = lep::parse_jpeg(blob + offset, len - offset, true, &j->jf);
+    if (rc) return rc;
+    // hand-off byte positions are only ever used as differences (plan_segments), so they may stay relative to the JPEG;
+    // the file size and the prefix are the blob's
+    j->jf.embedded = true;
+    j->jf.prefix_garbage.assign(blob, blob + offset);
+    j->jf.file_size = (uint32_t)len;
+    *out = j.release();
+    return 0;
+}
 int lep_jpeg_open_gpu(const uint8_t* jpg, size_t len, lep_jpeg** out, lep_huffdec_image* image, int* eligible) {
     std::unique_ptr<lep_jpeg> j(new lep_jpeg);
     j->opt.allow_progressive = true;
@@ -264,12 +278,7 @@ extern "C" {
 
 int lep_compress(lep_gpu* g, const uint8_t* jpg, size_t len, lep_bytes* out) { return lep_compress_slice(g, jpg, len, 0, 0, out); }
 
-int lep_compress_slice(lep_gpu* g, const uint8_t* jpg, size_t len, size_t start_byte, size_t trunc, lep_bytes* out) {
-    if (!g) return LEP_GPU_ERROR;
-    if (trunc && trunc < len) len = trunc;   // -trunc bounds the reader (check_file -> BindFdToReader, jpgcoder.cc:2181)
-    lep_jpeg* j = nullptr;
-    int rc = lep_jpeg_open_slice(jpg, len, start_byte, &j);
-    if (rc) return rc;
+static int compress_parsed(lep_gpu* g, lep_jpeg* j, lep_bytes* out) {
     std::unique_ptr<lep_jpeg> hold(j);
     lep_image_desc d;
     lep_jpeg_describe(j, &d);
@@ -284,9 +293,26 @@ int lep_compress_slice(lep_gpu* g, const uint8_t* jpg, size_t len, size_t start_
         bufs[i].resize(blocks * 160 / n + blocks * 16 + 65536);   // worst case is far below 2 bytes per coefficient
         streams[i].data = bufs[i].data(); streams[i].cap = bufs[i].size(); streams[i].len = 0;
     }
-    rc = lep_gpu_encode_host(g, &d, 1, segs, n, streams, status);
+    int rc = lep_gpu_encode_host(g, &d, 1, segs, n, streams, status);
     if (rc) return rc;
     return lep_jpeg_write_lep(j, 0, streams, n, out);
+}
+
+int lep_compress_slice(lep_gpu* g, const uint8_t* jpg, size_t len, size_t start_byte, size_t trunc, lep_bytes* out) {
+    if (!g) return LEP_GPU_ERROR;
+    if (trunc && trunc < len) len = trunc;   // -trunc bounds the reader (check_file -> BindFdToReader, jpgcoder.cc:2181)
+    lep_jpeg* j = nullptr;
+    int rc = lep_jpeg_open_slice(jpg, len, start_byte, &j);
+    if (rc) return rc;
+    return compress_parsed(g, j, out);
+}
+
+int lep_compress_embedded(lep_gpu* g, const uint8_t* blob, size_t len, size_t offset, lep_bytes* out) {
+    if (!g) return LEP_GPU_ERROR;
+    lep_jpeg* j = nullptr;
+    int rc = lep_jpeg_open_embedded(blob, len, offset, &j);
+    if (rc) return rc;
+    return compress_parsed(g, j, out);
 }
 
 int lep_decompress(lep_gpu* g, const uint8_t* lepdata, size_t len, lep_bytes* out) {

@@ -131,8 +131,8 @@ static std::vector<uint8_t> build_header_payload(const JpegFile& jf, const std::
         put_le32(p, (uint32_t)jf.max_sah);
         for (int i = 0; i < 4; ++i) put_le32(p, (uint32_t)jf.max_dpos[i]);
     }
-    if (jf.start_byte) {   // written even when empty (prefix_grbgdata != NULL, jpgcoder.cc:4009-4017)
-        p.insert(p.end(), {'P', 'G', 'R'});
+    if (jf.start_byte || jf.embedded) {   // written even when empty (prefix_grbgdata != NULL, jpgcoder.cc:4009-4017)
+        p.insert(p.end(), {(uint8_t)'P', (uint8_t)'G', (uint8_t)(jf.embedded ? 'E' : 'R')});
         put_le32(p, (uint32_t)jf.prefix_garbage.size());
         p.insert(p.end(), jf.prefix_garbage.begin(), jf.prefix_garbage.end());
     }

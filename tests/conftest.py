@@ -25,7 +25,13 @@ def _built():
 
 def golden_cases():
     man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
-    return sorted(k for k, v in man.items() if v.get("encode_exit") == 0 and "slice" not in v)
+    return sorted(k for k, v in man.items() if v.get("encode_exit") == 0 and "slice" not in v and "embedding" not in v)
+
+
+def embedded_cases():
+    """`lepton -embedding=<n>` fixtures: [(name, n)]; the .jpg is the whole blob, which the .lep restores"""
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    return sorted((k, v["embedding"]) for k, v in man.items() if v.get("encode_exit") == 0 and "embedding" in v)
 
 
 def slice_cases():

@@ -70,6 +70,9 @@ SLICES = {
     "slice_rst": ("rst_c420_176x112", 2000, 0),                  # restart markers inside the slice
     "slice_4seg_q97": ("_q97_960x720", 90000, 400000),          # 310 kB of scan: four thread segments, the first starts mid-image
 }
+# `lepton -embedding=<n>`: a JPEG n bytes into a larger blob (name -> (input case, prefix bytes, trailer bytes)); the .jpg of the
+# fixture is the whole blob, which the .lep restores
+EMBEDDED = {"embedded_c422": ("c422_128x72", 1001, 2003)}
 SLICE_ONLY_INPUTS = {"_q97_960x720": lambda: corpus.synth_jpeg(960, 720, 140, quality=97)}
 
 
@@ -116,6 +119,25 @@ def main():
             restored = open("/tmp/_golden_back.jpg", "rb").read() if back.returncode == 0 else b""
             entry.update(lep_md5=hashlib.md5(lep).hexdigest(), lep_size=len(lep), segments=lep[4], flag=chr(lep[3]),
                          restored_md5=hashlib.md5(restored).hexdigest(), restored_equals_input=restored == jpg[start:(trunc or len(jpg))])
+        manifest[name] = entry
+        print(name, entry)
+    for name, (src, npre, npost) in EMBEDDED.items():
+        if only and name not in only:
+            continue
+        blob = bytes((i * 7 + 3) & 255 for i in range(npre)) + CASES[src]() + bytes((i * 13 + 5) & 255 for i in range(npost))
+        jp = os.path.join(HERE, name + ".jpg")
+        lp = os.path.join(HERE, name + ".lep")
+        open(jp, "wb").write(blob)
+        if os.path.exists(lp):
+            os.unlink(lp)
+        r = subprocess.run([REF, "-unjailed", "-skipverify", "-embedding=%d" % npre, jp, lp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        entry = {"jpg_md5": hashlib.md5(blob).hexdigest(), "jpg_size": len(blob), "encode_exit": r.returncode, "embedding": npre}
+        if r.returncode == 0:
+            lep = open(lp, "rb").read()
+            back = subprocess.run([REF, "-unjailed", lp, "/tmp/_golden_back.jpg"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            restored = open("/tmp/_golden_back.jpg", "rb").read() if back.returncode == 0 else b""
+            entry.update(lep_md5=hashlib.md5(lep).hexdigest(), lep_size=len(lep), segments=lep[4],
+                         restored_md5=hashlib.md5(restored).hexdigest(), restored_equals_input=restored == blob)
         manifest[name] = entry
         print(name, entry)
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)

@@ -7,7 +7,7 @@ import ctypes as C
 import pytest
 
 import oracle_binding as ob
-from conftest import golden, slice_cases
+from conftest import embedded_cases, golden, slice_cases
 from lepton_amd.codec import JpegImage, LepFile, LeptonError
 
 CASES = slice_cases()
@@ -75,6 +75,22 @@ def test_kernel_sources_code_slices_like_the_oracle(emu, name, start, trunc):
         assert C.string_at(d.blocks[c], d.nblocks(c) * 128) == C.string_at(f.desc.blocks[c], f.desc.nblocks(c) * 128)
 
 
+@pytest.mark.parametrize("name,offset", embedded_cases())
+def test_embedded_jpeg_equals_the_reference(name, offset):
+    """`lepton -embedding=<n>` (jpgcoder.cc:1135-1137, 2275-2282; test_suite/test_embedded.sh): a JPEG inside a larger blob --
+    the bytes in front travel in a 'PGE' section, the bytes behind EOI as ordinary garbage, the .lep restores the blob"""
+    blob, lep = golden(name)
+    img = JpegImage(blob, embedding=offset)
+    segs = img.plan()
+    streams, _ = ob.oracle_encode(img.desc, segs)
+    assert img.write_lep(streams) == lep
+    f = LepFile(lep)
+    ob.oracle_decode(f.desc, f.segments, f.streams)
+    assert f.recode() == blob
+    with pytest.raises(LeptonError):
+        JpegImage(blob, embedding=offset + 1)     # no SOI there
+
+
 # ---- on the GPU -----------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,start,trunc", CASES)
@@ -82,6 +98,14 @@ def test_gpu_slices(gpu_codec, name, start, trunc):
     jpg, lep = golden(name)
     assert gpu_codec.compress_slice(jpg, start, trunc) == lep
     assert gpu_codec.decompress(lep) == jpg[start:(trunc or len(jpg))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,offset", embedded_cases())
+def test_gpu_embedded(gpu_codec, name, offset):
+    blob, lep = golden(name)
+    assert gpu_codec.compress_embedded(blob, offset) == lep
+    assert gpu_codec.decompress(lep) == blob
 
 
 @pytest.mark.gpu
