@@ -189,7 +189,10 @@ void lep_server::io_loop() {
                 for (;;) {
                     if (opt.max_connections > 0 && (int)conns.size() >= opt.max_connections) break;
                     const int fd = accept(l.fd, nullptr, nullptr);
-                    if (fd < 0) break;
+                    if (fd < 0) {
+                        if (errno == EMFILE || errno == ENFILE) usleep(1000);   // out of descriptors: do not spin on a readable listener
+                        break;
+                    }
                     set_nonblock(fd);
                     auto c = std::make_shared<Conn>();
                     c->fd = fd; c->zlib = l.zlib;
