@@ -73,7 +73,7 @@ def test_serve_round_trips_and_batches():
     name = _name()
     tab = Table()
     cases = golden_cases()
-    with Server(name, process=tab, batch_window_us=100000, max_batch=64) as srv:
+    with Server(name, process=tab, batch_window_us=300000, max_batch=64) as srv:
         assert os.path.exists(name) and os.path.exists(name + ".z0") and os.path.exists(name + ".lock")
         jpgs = [golden(c)[0] for c in cases]
         leps = [golden(c)[1] for c in cases]
@@ -131,11 +131,11 @@ def test_serve_time_bound():
     # -timebound counts from the first byte received and closes the connection whatever state the request is in
     name = _name()
     j, l = golden("c420_160x120")
-    with Server(name, process=Table(delay=0.6), time_bound_ms=150, batch_window_us=1000) as srv:
+    with Server(name, process=Table(delay=2.0), time_bound_ms=150, batch_window_us=1000) as srv:
         t0 = time.time()
         assert request(name, j) == b""
-        assert time.time() - t0 < 0.5           # closed at the bound, not when the batch came back
-        time.sleep(0.7)
+        assert time.time() - t0 < 1.5           # closed at the bound, not when the batch came back (generous: loaded CI hosts)
+        time.sleep(2.2)
         assert srv.stats()["timed_out"] == 1 and srv.stats()["answered"] == 0
     with Server(name, process=Table(), time_bound_ms=5000) as srv:
         assert request(name, j) == l
