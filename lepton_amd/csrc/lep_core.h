@@ -65,7 +65,7 @@ struct SegDev {
     int32_t image, y0, y1, is_last;
     uint64_t stream_off;     // into the stream arena
     uint32_t stream_cap;
-    uint32_t pad;
+    uint32_t slot;           // index of this segment in the caller's arrays (status / stream_len / bins): the launch order may differ
 };
 
 // ---- constant tables -----------------------------------------------------------------------------

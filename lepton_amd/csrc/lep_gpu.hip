@@ -116,9 +116,9 @@ __global__ __launch_bounds__(64, WAVES) void lep_encode_v3_kernel(const ImageDev
     uint32_t n = rc ? 0 : w.bc.finish();
     if (lane != 0) return;
     if (!rc && w.bc.overflow) rc = LEP_BUFFER_TOO_SMALL;
-    stream_len[s] = n;
-    status[s] = rc;
-    bins[s] = w.nbins;
+    stream_len[seg.slot] = n;
+    status[seg.slot] = rc;
+    bins[seg.slot] = w.nbins;
 }
 
 // v2 decoder: wave-cooperative with prefetch rounds (lep_dec2.h)
@@ -210,13 +210,13 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
 #ifdef LEP_PROF
     w.prof_begin(&g_prof4[s & 8191][0]);
 #endif
-    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, stream_len[s]);
+    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, stream_len[seg.slot]);
 #ifdef LEP_PROF
     w.prof_end();
 #endif
     if (lane != 0) return;
-    status[s] = rc;
-    bins[s] = w.nbins;
+    status[seg.slot] = rc;
+    bins[seg.slot] = w.nbins;
 }
 
 // JPEG Huffman re-encode of decoded frames: one wavefront per thread segment (lep_huff.h)
@@ -304,14 +304,40 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     std::vector<SegDev> hseg(nseg);
     std::vector<uint64_t> hns(nseg);
     uint64_t ns_total = 0;
-    for (int s = 0; s < nseg; ++s) {
+    for (int s = 0; s < nseg; ++s)
         if (segs[s].image < 0 || segs[s].image >= nimg) return LEP_ASSERTION_FAILURE;
-        hseg[s].image = segs[s].image; hseg[s].y0 = segs[s].luma_y_start; hseg[s].y1 = segs[s].luma_y_end;
-        hseg[s].is_last = segs[s].is_last;
-        hseg[s].stream_off = stream_offsets[s];
+    // Launch order.  Workgroups are observed to go to the 8 XCDs round-robin (block b -> XCD b % 8, MI355X_MICROARCH.md
+    // "Workgroup dispatch, XCD placement": a speed matter only, nothing here depends on it), and the caller's order is
+    // image-major: with 8 thread segments per image, segment k of EVERY image would land on XCD k -- and photographs are not
+    // uniform top to bottom (sky above, detail below: up to 2x the bins per row), so one XCD would be the straggler of every
+    // launch.  Segment r of image m is therefore queued for XCD (r + m) % 8 and the queues are interleaved; SegDev.slot
+    // carries the caller's index for the results.  (Only the current kernel generations read slot; the older ones index by
+    // workgroup and keep the caller's order.)
+    const bool permute = (DEC ? g->decode_kernel == 4 : g->encode_kernel == 3) && nseg > 8;
+    std::vector<int> order(nseg);
+    if (permute) {
+        std::vector<int> q[8];
+        int rank = 0;
+        for (int s = 0; s < nseg; ++s) {
+            rank = (s > 0 && segs[s].image == segs[s - 1].image) ? rank + 1 : 0;
+            q[(rank + segs[s].image) & 7].push_back(s);
+        }
+        size_t at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < nseg;)
+            for (int x = 0; x < 8 && i < nseg; ++x)
+                if (at[x] < q[x].size()) order[i++] = q[x][at[x]++];
+    } else {
+        for (int s = 0; s < nseg; ++s) order[s] = s;
+    }
+    for (int i = 0; i < nseg; ++i) {
+        const int s = order[i];
+        hseg[i].image = segs[s].image; hseg[i].y0 = segs[s].luma_y_start; hseg[i].y1 = segs[s].luma_y_end;
+        hseg[i].is_last = segs[s].is_last;
+        hseg[i].stream_off = stream_offsets[s];
         uint64_t cap = stream_offsets[s + 1] - stream_offsets[s];
-        hseg[s].stream_cap = (uint32_t)(cap > 0xffffffffu ? 0xffffffffu : cap);
-        hns[s] = ns_total;
+        hseg[i].stream_cap = (uint32_t)(cap > 0xffffffffu ? 0xffffffffu : cap);
+        hseg[i].slot = (uint32_t)s;
+        hns[i] = ns_total;
         ns_total += (uint64_t)himg[segs[s].image].ns_total;
     }
     HIPCHK(g, hipSetDevice(g->device));
