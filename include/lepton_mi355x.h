@@ -95,6 +95,10 @@ int lep_gpu_encode_device(lep_gpu *g, const lep_image_desc *images, int nimg, co
 int lep_gpu_decode_device(lep_gpu *g, const lep_image_desc *images, int nimg, const lep_segment *segs, int nseg,
                           const uint8_t *d_streams, const uint64_t *stream_offsets, const uint32_t *d_stream_len,
                           int32_t *d_status, void *hip_stream);
+/* Workspace set (0 or 1) the next lep_gpu_*_device launches use.  Two launches that overlap in time (different hip streams) must
+ * use different sets; a set may be reused once the launch that used it has finished (stream order does that when the same
+ * stream always goes with the same set).  Default 0. */
+int lep_gpu_use_arena(lep_gpu *g, int k);
 int lep_gpu_sync(lep_gpu *g);
 double lep_gpu_last_kernel_ms(lep_gpu *g);
 const char *lep_gpu_last_kernel_name(lep_gpu *g);   /* which kernel generation / register-budget variant that launch used */   /* HIP-event duration of the most recent encode/decode kernel */
@@ -248,6 +252,8 @@ typedef struct lep_batch_options {
                                     GPU Huffman decoder at most 7168 thread segments (7 coder wavefronts per SIMD; the eighth
                                     slot decodes the next chunk's scans meanwhile).  A coder kernel takes as long for 100
                                     segments as for 8192, so chunks must be this big */
+    int32_t overlap_launches;    /* compress: consecutive chunks' coder kernels on two streams / two workspace sets (experimental; also
+                                    LEP_BATCH_OVERLAP=1) */
 } lep_batch_options;
 typedef struct lep_batch_stats {
     double wall_s;               /* whole call */

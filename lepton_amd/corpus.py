@@ -9,7 +9,7 @@ from concurrent.futures import ProcessPoolExecutor
 import numpy as np
 
 
-def synth_jpeg(w, h, seed, quality=90, progressive=False, subsampling="4:2:0"):
+def synth_jpeg(w, h, seed, quality=90, progressive=False, subsampling="4:2:0", skew=0.0):
     from PIL import Image
 
     rng = np.random.default_rng(seed)
@@ -21,7 +21,12 @@ def synth_jpeg(w, h, seed, quality=90, progressive=False, subsampling="4:2:0"):
     tex_img = np.stack(
         [np.asarray(Image.fromarray(tex[:, :, c], "F").resize((w, h), Image.BILINEAR)) for c in range(3)], axis=2
     )
-    img = img + tex_img + rng.normal(0.0, 4.0, (h, w, 3)).astype(np.float32)
+    detail = tex_img + rng.normal(0.0, 4.0, (h, w, 3)).astype(np.float32)
+    if skew:   # photograph-like: smooth at the top ("sky"), detail growing towards the bottom -> thread segments of equal
+        #        compressed size then differ several-fold in blocks, as they do for real pictures
+        ramp = ((np.arange(h, dtype=np.float32) + 0.5) / h) ** float(skew)
+        detail *= ramp[:, None, None]
+    img = img + detail
     out = Image.fromarray(np.clip(img, 0, 255).astype(np.uint8), "RGB")
     buf = io.BytesIO()
     out.save(buf, format="JPEG", quality=quality, subsampling=subsampling, optimize=False, progressive=progressive)
@@ -34,7 +39,7 @@ def _job(args):
 
 def make_corpus(n, w, h, seed0, workers=None, **kw):
     """n distinct images, seeds seed0..seed0+n-1, generated with a process pool."""
-    jobs = [(w, h, seed0 + i, kw.get("quality", 90), kw.get("progressive", False)) for i in range(n)]
+    jobs = [(w, h, seed0 + i, kw.get("quality", 90), kw.get("progressive", False), kw.get("subsampling", "4:2:0"), kw.get("skew", 0.0)) for i in range(n)]
     workers = workers or min(len(jobs), max(1, (os.cpu_count() or 2) - 1), 32)
     if workers <= 1 or n <= 2:
         return [_job(j) for j in jobs]

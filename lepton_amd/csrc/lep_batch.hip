@@ -286,9 +286,14 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         c->frame_bytes = bytes;
         chunks.push_back(std::move(c));
     }
-    hipStream_t s_copy = nullptr, s_compute = nullptr, s_down = nullptr, s_huff = nullptr;
+    hipStream_t s_copy = nullptr, s_compute = nullptr, s_compute2 = nullptr, s_down = nullptr, s_huff = nullptr;
+    // overlap_launches: chunk k+1's coder kernel goes to a second stream (and the library's second workspace set), so its
+    // wavefronts start in the slots that chunk k's long thread segments leave free instead of waiting for the last of them
+    // (real photographs: segments of equal compressed size differ several-fold in blocks).  Off by default until measured.
+    const bool overlap = (o && o->overlap_launches) || (getenv("LEP_BATCH_OVERLAP") && atoi(getenv("LEP_BATCH_OVERLAP")) != 0);
     HIPOK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
     HIPOK(hipStreamCreateWithFlags(&s_compute, hipStreamNonBlocking));
+    if (overlap) HIPOK(hipStreamCreateWithFlags(&s_compute2, hipStreamNonBlocking));
     HIPOK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
     {   // Huffman decode of chunk k+1 beside the coder kernels of chunk k: its workgroups go first whenever a slot is free
         int lo = 0, hi = 0;
@@ -470,9 +475,13 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
 
     // coder kernels of one chunk, stream-ordered behind the previous chunk's (the call returns once they are enqueued, i.e.
     // after the previous chunk's kernels have finished: the descriptor upload inside lep_gpu_encode_device is synchronous)
+    hipStream_t s_compute_first = s_compute;
     auto launch_chunk = [&](Chunk* c, Slot* s) -> int {
         const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
         if (!nimg) return 0;
+        const int set = overlap ? (int)(s - slots) : 0;            // slot 0 / 1 <-> stream and workspace set 0 / 1
+        hipStream_t s_compute = set ? s_compute2 : s_compute_first;
+        if (int rc0 = lep_gpu_use_arena(g, set)) return rc0;
         HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
         int rc = lep_gpu_encode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
         if (rc) return rc;
@@ -488,6 +497,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             }
         }
         HIPOK(hipEventRecord(s->done, s_compute));
+        (void)lep_gpu_use_arena(g, 0);
         return 0;
     };
 
@@ -564,6 +574,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     for (int i = 0; i < n; ++i) if (parsed[i]) lep_jpeg_close(parsed[i]);
     st.alloc_s = g_alloc_s;
     (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_compute); (void)hipStreamDestroy(s_down); (void)hipStreamDestroy(s_huff);
+    if (s_compute2) (void)hipStreamDestroy(s_compute2);
     st.wall_s = now_s() - t_begin;
     if (stats) *stats = st;
     return rc_all;

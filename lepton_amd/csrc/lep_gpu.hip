@@ -255,10 +255,15 @@ struct lep_gpu {
     int encode_kernel = 3;   // 3 = v3 (default), 2 = v2 wave-cooperative, 1 = single-lane reference kernel (LEP_ENCODE_KERNEL)
     std::string err;
     const char* last_kernel = "";   // name of the kernel the most recent launch used
-    // grow-only device workspace
-    void* d_models = nullptr; size_t models_bytes = 0;
-    void* d_ns = nullptr; size_t ns_bytes = 0;
-    void* d_meta = nullptr; size_t meta_bytes = 0;      // ImageDev[] | SegDev[] | ns_offsets[] | bins[]
+    // grow-only device workspace of a coder launch (models, neighbour summaries, descriptors).  There are two sets so that two
+    // launches may be in flight at once on different streams (lep_gpu_use_arena: the next chunk's coder kernel starts in the
+    // wave slots that the long segments of the current one leave free); everything else uses set 0.
+    struct Arena {
+        void* d_models = nullptr; size_t models_bytes = 0;
+        void* d_ns = nullptr; size_t ns_bytes = 0;
+        void* d_meta = nullptr; size_t meta_bytes = 0;      // ImageDev[] | SegDev[] | ns_offsets[] | bins[]
+    } arena[2];
+    int cur = 0;
     uint32_t* d_bins = nullptr;
     std::vector<uint32_t> h_bins;
     // host-variant staging
@@ -341,13 +346,13 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         ns_total += (uint64_t)himg[segs[s].image].ns_total;
     }
     HIPCHK(g, hipSetDevice(g->device));
-    if (int rc = ensure(g, &g->d_models, &g->models_bytes, (size_t)nseg * kModelStride * 4)) return rc;
-    if (int rc = ensure(g, &g->d_ns, &g->ns_bytes, (size_t)ns_total * sizeof(NSum) + 16)) return rc;
+    if (int rc = ensure(g, &g->arena[g->cur].d_models, &g->arena[g->cur].models_bytes, (size_t)nseg * kModelStride * 4)) return rc;
+    if (int rc = ensure(g, &g->arena[g->cur].d_ns, &g->arena[g->cur].ns_bytes, (size_t)ns_total * sizeof(NSum) + 16)) return rc;
     const size_t o_img = 0, o_seg = o_img + ((nimg * sizeof(ImageDev) + 255) & ~(size_t)255),
                  o_ns = o_seg + ((nseg * sizeof(SegDev) + 255) & ~(size_t)255),
                  o_bins = o_ns + ((nseg * sizeof(uint64_t) + 255) & ~(size_t)255), total = o_bins + nseg * sizeof(uint32_t);
-    if (int rc = ensure(g, &g->d_meta, &g->meta_bytes, total)) return rc;
-    char* meta = (char*)g->d_meta;
+    if (int rc = ensure(g, &g->arena[g->cur].d_meta, &g->arena[g->cur].meta_bytes, total)) return rc;
+    char* meta = (char*)g->arena[g->cur].d_meta;
     HIPCHK(g, hipMemcpyAsync(meta + o_img, himg.data(), nimg * sizeof(ImageDev), hipMemcpyHostToDevice, st));
     HIPCHK(g, hipMemcpyAsync(meta + o_seg, hseg.data(), nseg * sizeof(SegDev), hipMemcpyHostToDevice, st));
     HIPCHK(g, hipMemcpyAsync(meta + o_ns, hns.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -361,7 +366,7 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
 #endif
 #define LEP_LAUNCH_DEC4(W)                                                                                                     \
     hipLaunchKernelGGL((lep_decode_v4_kernel<W>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),                  \
-                       (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns), \
+                       (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns), \
                        d_streams, d_stream_len, d_status, g->d_bins)
         int waves = g->dec3_waves;
         if (!waves) waves = nseg > 4608 ? 8 : 4;
@@ -374,7 +379,7 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     else if (DEC && g->decode_kernel == 3) {
 #define LEP_LAUNCH_DEC3(W)                                                                                                     \
     hipLaunchKernelGGL((lep_decode_v3_kernel<W>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),                  \
-                       (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns), \
+                       (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns), \
                        d_streams, d_stream_len, d_status, g->d_bins)
         // register-budget variant: more resident waves only pay once the batch can fill them (measured, MI355X, 4K
         // corpus: 4096 segments 822 MB/s with the 4-wave build vs 742 with the 5-wave build; 8192 segments 867 vs 947
@@ -393,27 +398,27 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     else if (DEC && g->decode_kernel == 2) {
         g->last_kernel = "lep_decode_v2_kernel";
         hipLaunchKernelGGL(lep_decode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                           (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                           (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
     } else if (!DEC && g->encode_kernel == 3) {
         g->last_kernel = g->enc_waves == 7 ? "lep_encode_v3_kernel<7>" : "lep_encode_v3_kernel";
         if (g->enc_waves == 7)
             hipLaunchKernelGGL((lep_encode_v3_kernel<7>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                               (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                               (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
                                d_streams, d_stream_len, d_status, g->d_bins);
         else
             hipLaunchKernelGGL((lep_encode_v3_kernel<8>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                               (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                               (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
                                d_streams, d_stream_len, d_status, g->d_bins);
     } else if (!DEC && g->encode_kernel == 2) {
         g->last_kernel = "lep_encode_v2_kernel";
         hipLaunchKernelGGL(lep_encode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                           (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                           (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
     } else {
         g->last_kernel = DEC ? "lep_segment_kernel<decode>" : "lep_segment_kernel<encode>";
         hipLaunchKernelGGL(lep_segment_kernel<DEC>, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                           (const SegDev*)(meta + o_seg), (uint32_t*)g->d_models, (NSum*)g->d_ns, (const uint64_t*)(meta + o_ns),
+                           (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
     }
     HIPCHK(g, hipGetLastError());
@@ -443,7 +448,7 @@ void lep_gpu_destroy(lep_gpu* g) {
     if (!g) return;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    for (void* p : {g->d_models, g->d_ns, g->d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffdec, g->d_scan, g->d_scanlen})
+    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffdec, g->d_scan, g->d_scanlen})
         if (p) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -507,6 +512,12 @@ int lep_gpu_huffman_decode_device(lep_gpu* g, const lep_huffdec_image* images, i
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
     g->last_kernel = "lep_huffman_decode_kernel";
+    return 0;
+}
+
+int lep_gpu_use_arena(lep_gpu* g, int k) {
+    if (!g || k < 0 || k > 1) return LEP_ASSERTION_FAILURE;
+    g->cur = k;
     return 0;
 }
 

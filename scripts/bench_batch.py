@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--chunk-mb", type=int, default=0)
     ap.add_argument("--chunk-images", type=int, default=0)
     ap.add_argument("--verify", action="store_true")
+    ap.add_argument("--skew", type=float, default=0.0, help="photograph-like corpus: detail grows from top to bottom (exponent of the ramp), unequal thread segments")
     ap.add_argument("--host-huffman", action="store_true", help="decompress: JPEG Huffman re-encode on the host pool instead of the GPU")
     args = ap.parse_args()
     import __graft_entry__ as ge
@@ -32,7 +33,7 @@ def main():
 
     codec = GpuCodec(0)
     nu = max(1, min(args.unique, args.images))
-    uniq = corpus.make_corpus(nu, args.width, args.height, 10000)
+    uniq = corpus.make_corpus(nu, args.width, args.height, 10000, skew=args.skew)
     jpgs = [uniq[i % nu] for i in range(args.images)]
     mb = sum(map(len, jpgs)) / 1e6
     kw = dict(threads=args.threads, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images, host_huffman=args.host_huffman)
@@ -63,6 +64,7 @@ def main():
                        "d2h_GBps": round(ds["d2h_bytes"] / ds["pipeline_s"] / 1e9, 2), **{k: round(v, 3) for k, v in ds.items()}},
         "cold_first_call": {"compress_MBps_wall": round(mb / cold_c["wall_s"], 1), "compress_alloc_s": round(cold_c["alloc_s"], 3),
                             "decompress_MBps_wall": round(mb / cold_d["wall_s"], 1), "decompress_alloc_s": round(cold_d["alloc_s"], 3)},
+        "skew": args.skew, "overlap_launches": os.environ.get("LEP_BATCH_OVERLAP", "0"),
         "roundtrip": "bit exact (%d files)" % args.images, "huffman": "host pool" if args.host_huffman else "GPU (lep_huffman_decode_kernel / lep_huffman_encode_kernel)", "last_kernel_of_last_chunk_ms": last_kernel,
     }
     print(json.dumps(out), flush=True)

@@ -233,6 +233,18 @@ def test_gpu_batch_pipeline_equals_per_file_and_reference(gpu_codec):
     assert status2[-1] != 0 and back[-1] is None
 
 
+def test_gpu_batch_pipeline_with_overlapped_launches(gpu_codec, monkeypatch):
+    """LEP_BATCH_OVERLAP=1: consecutive chunks' coder kernels on two streams / two workspace sets of the library (the next
+    chunk starts in the wave slots the current one's long segments leave free) -- same bytes, with and without verification"""
+    monkeypatch.setenv("LEP_BATCH_OVERLAP", "1")
+    names = golden_cases()
+    jpgs = [golden(n)[0] for n in names] * 3
+    leps = [golden(n)[1] for n in names] * 3
+    for verify in (False, True):
+        got, status, _ = gpu_codec.compress_batch(jpgs, chunk_bytes=300000, verify=verify)
+        assert status == [0] * len(jpgs) and got == leps
+
+
 def test_gpu_batch_pipeline_verifies_on_the_gpu(gpu_codec):
     """verify=1: every file is decoded again on the GPU and compared with its input frame before its .lep is released"""
     jpgs = [corpus.synth_jpeg(640, 480, 51), corpus.synth_jpeg(320, 200, 52, quality=75), golden("c420_odd_203x149")[0]]
