@@ -266,6 +266,9 @@ int lep_compress_batch(lep_gpu *g, const lep_bytes *jpgs, int n, lep_bytes *outs
                        const lep_batch_options *opt, lep_batch_stats *stats);
 int lep_decompress_batch(lep_gpu *g, const lep_bytes *leps, int n, lep_bytes *outs, int32_t *status,
                          const lep_batch_options *opt, lep_batch_stats *stats);
+/* the chunking lep_compress_batch will apply: file_bytes[i] / frame_bytes[i] (lep_jpeg_peek_frame_bytes; 0 = not a usable file)
+ * -> chunk k holds files [chunk_first[k], chunk_first[k + 1]); returns the number of chunks (cap = entries of chunk_first) */
+int lep_batch_plan(const size_t *file_bytes, const size_t *frame_bytes, int n, const lep_batch_options *opt, int *chunk_first, int cap);
 void lep_batch_release(void);   /* frees the staging buffers the two calls above keep between invocations (not re-entrant) */
 
 /* ---- serving surface ------------------------------------------------------------------------------

@@ -315,6 +315,46 @@ int lep_compress_embedded(lep_gpu* g, const uint8_t* blob, size_t len, size_t of
     return compress_parsed(g, j, out);
 }
 
+// How lep_compress_batch cuts a batch into pipeline chunks (pure host logic, unit-tested on the CPU).  A chunk's thread
+// segments are one coder wavefront each and the next chunk's Huffman decode needs the eighth wave slot of every SIMD
+// (lep_batch.hip), so an automatic chunk holds at most 7168 segments and 1024 images; a kernel takes as long for a small
+// chunk as for a full one, so the chunks are balanced (k equal chunks, not k - 1 full ones and a remainder), and a batch
+// that fits one launch (<= 1024 images, <= 8192 segments) is not split at all.
+int lep_batch_plan(const size_t* file_bytes, const size_t* frame_bytes, int n, const lep_batch_options* o, int* chunk_first, int cap) {
+    if (n < 0 || cap < 2) return -1;
+    const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
+    size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
+    const bool auto_chunks = !(o && o->chunk_images > 0) && !(o && o->host_huffman);
+    size_t chunk_segments = auto_chunks ? 7168 : (size_t)1 << 30;
+    // thread segments a file will get, from its size (write_ujpg's rule on the scan size, jpgcoder.cc:3856-3871; the file
+    // size over-estimates the scan a little, which only makes a chunk slightly smaller)
+    auto segments_guess = [&](int i) -> size_t { const size_t b = file_bytes[i]; return b < 125000 ? 1 : b < 250000 ? 2 : b < 500000 ? 4 : 8; };
+    if (auto_chunks) {
+        size_t live = 0, segs = 0;
+        for (int i = 0; i < n; ++i) if (frame_bytes[i]) { ++live; segs += segments_guess(i); }
+        if (live <= 1024 && segs <= 8192) chunk_segments = 8192;
+        else {
+            const size_t k = std::max({(segs + 7167) / 7168, (live + 1023) / 1024, (size_t)1});
+            chunk_segments = std::min<size_t>(7168, (segs + k - 1) / k + 8);
+            chunk_images = std::min<size_t>(1024, (live + k - 1) / k + 1);
+        }
+    }
+    int nchunks = 0;
+    for (int i = 0; i < n;) {
+        if (nchunks + 1 >= cap) return -1;
+        chunk_first[nchunks++] = i;
+        size_t bytes = 0, nsegs = 0, count = 0;
+        for (; i < n; ++i) {
+            if (!frame_bytes[i]) continue;
+            const size_t fb = (frame_bytes[i] + 255) & ~(size_t)255, sg = segments_guess(i);
+            if (count && (bytes + fb > chunk_budget || count >= chunk_images || nsegs + sg > chunk_segments)) break;
+            bytes += fb; nsegs += sg; ++count;
+        }
+    }
+    chunk_first[nchunks] = n;
+    return nchunks;
+}
+
 int lep_decompress(lep_gpu* g, const uint8_t* lepdata, size_t len, lep_bytes* out) {
     if (!g) return LEP_GPU_ERROR;
     lep_file* f = nullptr;

@@ -231,18 +231,10 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                        lep_batch_stats* stats) {
     if (!g || n < 0) return LEP_GPU_ERROR;
     const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
-    const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
-    const size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
     // With the Huffman decode on the GPU, chunk k+1 is decoded WHILE the arithmetic coder of chunk k runs: a chunk's thread
     // segments (one coder wavefront each) fill 7 of the 8 wave slots of every SIMD (7 x 4 x 256 = 7168), the eighth holds
-    // the next chunk's Huffman wavefronts (one per image, raised priority, sized to fit: lep_gpu.hip).  Explicit
-    // chunk_images overrides the segment budget.
-    // chunk_images overrides the segment budget.  A kernel takes as long for a small chunk as for a full one, so the
-    // chunks are balanced (k equal chunks rather than k - 1 full ones and a remainder), and a batch that fits one launch
-    // (<= 1024 images, <= 8192 segments) is not split at all: there is nothing to overlap with.
-    const bool auto_chunks = !(o && o->chunk_images > 0) && !(o && o->host_huffman);
-    size_t chunk_segments = auto_chunks ? 7168 : (size_t)1 << 30;
-    size_t chunk_images_eff = chunk_images;
+    // the next chunk's Huffman wavefronts (one per image, raised priority, sized to fit: lep_gpu.hip).  The chunking itself
+    // is lep_batch_plan (lep_api.cc).
     const bool verify = o && o->verify;
     HIPOK(hipSetDevice(lep_gpu_device(g)));
     tune_malloc_for_pool();
@@ -250,39 +242,24 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     lep_batch_stats st;
     memset(&st, 0, sizeof st);
     for (int i = 0; i < n; ++i) { outs[i].data = nullptr; outs[i].len = outs[i].cap = 0; status[i] = 0; }
-    // thread segments a file will get, from its size (write_ujpg's rule on the scan size, jpgcoder.cc:3856-3871; the file
-    // size over-estimates the scan a little, which only makes a chunk slightly smaller)
-    auto segments_guess = [&](int i) -> size_t { const size_t b = jpgs[i].len; return b < 125000 ? 1 : b < 250000 ? 2 : b < 500000 ? 4 : 8; };
-
-    // 1. frame sizes from the SOF markers -> the whole batch is cut into chunks before anything is decoded, so that every
-    //    image can be Huffman-decoded straight into its place in a pinned staging buffer (no page faults, no second copy)
-    std::vector<size_t> fbytes(n, 0);
-    parallel_for(n, threads, [&](int i) { if (int rc = lep_jpeg_peek_frame_bytes(jpgs[i].data, jpgs[i].len, &fbytes[i])) status[i] = rc; });
+    // 1. frame sizes from the SOF markers -> the whole batch is cut into chunks before anything is decoded (lep_batch_plan),
+    //    so that every image can be Huffman-decoded straight into its place in a staging buffer (no page faults, no second copy)
+    std::vector<size_t> fbytes(n, 0), jbytes(n, 0);
+    parallel_for(n, threads, [&](int i) { jbytes[i] = jpgs[i].len; if (int rc = lep_jpeg_peek_frame_bytes(jpgs[i].data, jpgs[i].len, &fbytes[i])) { status[i] = rc; fbytes[i] = 0; } });
+    std::vector<int> first((size_t)n + 2, 0);
+    const int nchunks = lep_batch_plan(jbytes.data(), fbytes.data(), n, o, first.data(), n + 2);
+    if (nchunks < 0) return LEP_ASSERTION_FAILURE;
     std::vector<std::unique_ptr<Chunk>> chunks;
-    if (auto_chunks) {
-        size_t live = 0, segs = 0, bytes = 0;
-        for (int i = 0; i < n; ++i) if (!status[i]) { ++live; segs += segments_guess(i); bytes += (fbytes[i] + 255) & ~(size_t)255; }
-        if (live <= 1024 && segs <= 8192) chunk_segments = 8192;
-        else {
-            const size_t k = std::max({(segs + 7167) / 7168, (live + 1023) / 1024, (size_t)1});
-            chunk_segments = std::min<size_t>(7168, (segs + k - 1) / k + 8);
-            chunk_images_eff = std::min<size_t>(1024, (live + k - 1) / k + 1);
-        }
-        (void)bytes;
-    }
-    for (int i = 0; i < n;) {
+    for (int k = 0; k < nchunks; ++k) {
         std::unique_ptr<Chunk> c(new Chunk);
-        c->first = i;
-        size_t bytes = 0, nsegs = 0;
-        for (; i < n; ++i) {
+        c->first = first[k];
+        size_t bytes = 0;
+        for (int i = first[k]; i < first[k + 1]; ++i) {
             if (status[i]) continue;
-            const size_t fb = (fbytes[i] + 255) & ~(size_t)255;
-            const size_t sg = segments_guess(i);
-            if (!c->live.empty() && (bytes + fb > chunk_budget || c->live.size() >= chunk_images_eff || nsegs + sg > chunk_segments)) break;
             c->live.push_back(i); c->frame_off.push_back(bytes);
-            bytes += fb; nsegs += sg;
+            bytes += (fbytes[i] + 255) & ~(size_t)255;
         }
-        c->count = i - c->first;
+        c->count = first[k + 1] - first[k];
         c->frame_bytes = bytes;
         chunks.push_back(std::move(c));
     }

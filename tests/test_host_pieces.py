@@ -138,3 +138,41 @@ def test_bytes_after_a_lep_file_are_ignored_like_the_reference():
         f = LepFile(lep + tail)
         ob.oracle_decode(f.desc, f.segments, f.streams)
         assert f.recode() == jpg
+
+
+def test_batch_chunk_plan():
+    """lep_batch_plan: how lep_compress_batch cuts a batch (the GPU pipeline itself needs a device; its chunking does not)"""
+    import ctypes as C
+
+    L = abi.lib()
+
+    def plan(file_bytes, frame_bytes=None, **opt):
+        n = len(file_bytes)
+        fb = (C.c_size_t * n)(*file_bytes)
+        fr = (C.c_size_t * n)(*(frame_bytes or [25_000_000 if b >= 500_000 else 6_000_000 for b in file_bytes]))
+        o = abi.BatchOptions()
+        for k, v in opt.items():
+            setattr(o, k, v)
+        first = (C.c_int * (n + 2))()
+        k = L.lep_batch_plan(fb, fr, n, C.byref(o), first, n + 2)
+        assert k >= 0 and first[k] == n and list(first[: k + 1]) == sorted(first[: k + 1])
+        return [first[i + 1] - first[i] for i in range(k)]
+
+    big, small = 2_200_000, 60_000                     # 8 thread segments / 1 thread segment
+    assert plan([big] * 1024) == [1024]                # fits one launch: nothing to overlap with, not split
+    assert plan([big] * 2688) == [896, 896, 896]       # 7168 segments per chunk: the eighth wave slot decodes the next chunk
+    assert plan([big] * 2048) == [683, 683, 682]       # balanced, not 896 + 896 + 256
+    sizes = plan([big] * 1025)
+    assert len(sizes) == 2 and abs(sizes[0] - sizes[1]) <= 2
+    assert plan([small] * 5000) == [1001, 1001, 1001, 1001, 996]   # images, not segments, bound chunks of small files
+    assert all(s * 8 <= 7168 + 8 for s in plan([big] * 10000))
+    mixed = plan([big, small] * 3000)
+    assert sum(mixed) == 6000 and max(mixed) <= 1024
+    # unusable files (frame_bytes 0) ride along in whatever chunk they fall into and do not count
+    assert sum(plan([big] * 10, frame_bytes=[0, 25_000_000] * 5)) == 10
+    # explicit settings override the automatic budget
+    assert plan([big] * 2048, chunk_images=1024) == [1024, 1024]
+    assert plan([big] * 100, chunk_images=7) == [7] * 14 + [2]
+    assert len(plan([big] * 64, chunk_frame_bytes=101_000_000)) == 16   # 4 x 25 MB frames per chunk
+    assert plan([big] * 2048, host_huffman=1) == [1024, 1024]
+    assert plan([]) == []
