@@ -32,6 +32,26 @@ static void run_jpeg(const uint8_t* d, size_t n) {
         }
         lep_jpeg_close(j);
     }
+    // -startbyte slices and -embedding blobs: the same parser behind two more front doors
+    const size_t starts[] = {1, 17, n / 3, n / 2, n - 1, n, n + 5};
+    for (size_t sb : starts) {
+        lep_jpeg* j = nullptr;
+        if (lep_jpeg_open_slice(d, n, sb, &j) != 0 || !j) continue;
+        lep_segment segs[LEP_MAX_SEGMENTS];
+        const int ns = lep_jpeg_plan(j, 0, segs, 0);
+        if (ns > 0 && ns <= LEP_MAX_SEGMENTS) {
+            uint8_t fake[16] = {0};
+            lep_bytes st[LEP_MAX_SEGMENTS];
+            for (int i = 0; i < ns; ++i) { st[i].data = fake; st[i].len = st[i].cap = sizeof fake; }
+            lep_bytes out = {nullptr, 0, 0};
+            if (lep_jpeg_write_lep(j, 0, st, ns, &out) == 0) lep_free(out.data);
+        }
+        lep_jpeg_close(j);
+    }
+    for (size_t off : {(size_t)0, (size_t)2, n / 4}) {
+        lep_jpeg* j = nullptr;
+        if (lep_jpeg_open_embedded(d, n, off, &j) == 0 && j) lep_jpeg_close(j);
+    }
     // the GPU-assisted front end: split + table set-up only (the scan decode itself runs on the device)
     lep_jpeg* j = nullptr;
     lep_huffdec_image img;
