@@ -190,6 +190,9 @@ int lep_jpeg_describe(const lep_jpeg *j, lep_image_desc *desc);          /* host
 int lep_jpeg_is_progressive(const lep_jpeg *j);   /* 1: not a single interleaved sequential scan (needs the progressive re-coder) */
 /* segment choice of write_ujpg (src/lepton/jpgcoder.cc:3856-3934); returns count, fills segs */
 int lep_jpeg_plan(const lep_jpeg *j, int max_threads, lep_segment *segs, int image_index);
+/* -maxencodethreads / -minencodethreads / -evensplit (jpgcoder.cc:1064-1095): they change how many thread segments a file gets
+ * and where they are cut, i.e. the .lep bytes; 0 / 0 / 0 leaves the reference's defaults (8, 1, by compressed size) */
+int lep_jpeg_set_encode_options(lep_jpeg *j, int max_threads, int min_threads, int even_split);
 /* whole .lep file from the per-segment streams (header + mux + trailer) */
 int lep_jpeg_write_lep(const lep_jpeg *j, int max_threads, const lep_bytes *streams, int nstreams, lep_bytes *out);
 

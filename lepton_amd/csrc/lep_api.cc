@@ -147,6 +147,14 @@ int lep_jpeg_describe(const lep_jpeg* j, lep_image_desc* d) {
     return 0;
 }
 
+int lep_jpeg_set_encode_options(lep_jpeg* j, int max_threads, int min_threads, int even_split) {
+    if (!j) return LEP_ASSERTION_FAILURE;
+    if (max_threads > 0) j->opt.max_threads = (unsigned)std::min(max_threads, LEP_MAX_SEGMENTS);
+    if (min_threads > 0) j->opt.min_threads = (unsigned)std::min(min_threads, LEP_MAX_SEGMENTS);
+    j->opt.even_split = even_split != 0;
+    return 0;
+}
+
 int lep_jpeg_is_progressive(const lep_jpeg* j) { return j->jf.progressive_needed ? 1 : 0; }
 
 int lep_jpeg_plan(const lep_jpeg* j, int max_threads, lep_segment* segs, int image_index) {

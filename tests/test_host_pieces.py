@@ -176,3 +176,26 @@ def test_batch_chunk_plan():
     assert len(plan([big] * 64, chunk_frame_bytes=101_000_000)) == 16   # 4 x 25 MB frames per chunk
     assert plan([big] * 2048, host_huffman=1) == [1024, 1024]
     assert plan([]) == []
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "lepton")),
+                    reason="needs the reference binary (built where /root/reference exists)")
+def test_encode_thread_options_match_the_reference_flags(tmp_path):
+    """-maxencodethreads / -minencodethreads / -evensplit change the segment count and cut points, i.e. the .lep bytes"""
+    import subprocess
+    import oracle_binding as ob
+    from conftest import ROOT
+
+    ref = os.path.join(ROOT, "oracle", "_ref", "lepton")
+    jp = os.path.join(ROOT, "tests", "golden", "slice_4seg_q97.jpg")   # a 400 kB baseline file (the fixture's whole input)
+    jpg = open(jp, "rb").read()
+    for flags, (mx, mn, ev) in ((["-maxencodethreads=2"], (2, 0, 0)), (["-minencodethreads=8"], (0, 8, 0)), (["-evensplit"], (0, 0, 1)),
+                                (["-maxencodethreads=4", "-minencodethreads=4", "-evensplit"], (4, 4, 1))):
+        out = str(tmp_path / "o.lep")
+        assert subprocess.run([ref, "-unjailed", "-skipverify"] + flags + [jp, out], capture_output=True).returncode == 0
+        want = open(out, "rb").read()
+        img = JpegImage(jpg)
+        assert abi.lib().lep_jpeg_set_encode_options(img.handle, mx, mn, ev) == 0
+        segs = img.plan(max_threads=0)
+        streams, _ = ob.oracle_encode(img.desc, segs)
+        assert len(segs) == want[4] and img.write_lep(streams, max_threads=0) == want
