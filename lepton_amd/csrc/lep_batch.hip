@@ -387,6 +387,15 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 launch.push_back(hi); which.push_back(k);
             }
             HIPOK(hipStreamWaitEvent(s_huff, s->up, 0));
+            // LEP_HUFFDEC_PAR=<n> (experimental): n wavefronts per image for the scans without restart intervals
+            // (lep_huffdec_par.h); the others, and by default all, take the single-wave kernel
+            const int par = getenv("LEP_HUFFDEC_PAR") ? atoi(getenv("LEP_HUFFDEC_PAR")) : 0;
+            if (par >= 2) {
+                std::vector<lep_huffdec_image> many, one;
+                for (const lep_huffdec_image& hi : launch) (hi.rsti ? one : many).push_back(hi);
+                if (!many.empty()) { if (int rc = lep_gpu_huffman_decode_parallel_device(g, many.data(), (int)many.size(), par > 64 ? 64 : par, (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
+                if (!one.empty()) { if (int rc = lep_gpu_huffman_decode_device(g, one.data(), (int)one.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
+            } else
             if (int rc = lep_gpu_huffman_decode_device(g, launch.data(), (int)launch.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc;
             HIPOK(hipMemcpyAsync(rows.data(), s->d_rows, rows_total * sizeof(lep_huffdec_row), hipMemcpyDeviceToHost, s_huff));
             HIPOK(hipStreamSynchronize(s_huff));

@@ -22,6 +22,7 @@
 #include "lep_dec4.h"
 #include "lep_huff.h"
 #include "lep_huffdec.h"
+#include "lep_huffdec_par.h"
 
 using namespace lepdev;
 
@@ -241,6 +242,35 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_decode_kernel(const lephuff
     w.run(images + blockIdx.x, &sh, rows);
 }
 
+// Several wavefronts per image (lep_huffdec_par.h; experimental, opt-in): sync / count / write passes over nsub subsequences
+// of every scan, then one thread per image folds the passes' verdicts into the final row record's status.
+__global__ __launch_bounds__(64, 8) void lep_huffman_par_sync_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffParState* st, int nsub) {
+    __shared__ lephuff::HuffParShared sh;
+    const int img = (int)blockIdx.x / nsub, sub = (int)blockIdx.x % nsub;
+    lephuff::HuffParWave w;
+    w.run_sync(images + img, &sh, st + (size_t)img * nsub, sub, nsub);
+}
+__global__ __launch_bounds__(64, 8) void lep_huffman_par_count_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffParState* st, int nsub) {
+    __shared__ lephuff::HuffParShared sh;
+    const int img = (int)blockIdx.x / nsub, sub = (int)blockIdx.x % nsub;
+    lephuff::HuffParWave w;
+    w.run_count(images + img, &sh, st + (size_t)img * nsub, sub, nsub);
+}
+__global__ __launch_bounds__(64, 8) void lep_huffman_par_write_kernel(const lephuff::HuffDecImage* __restrict__ images, const lephuff::HuffParState* st, int nsub,
+                                                                     lephuff::HuffDecRow* rows, int* img_status) {
+    __shared__ lephuff::HuffParShared sh;
+    const int img = (int)blockIdx.x / nsub, sub = (int)blockIdx.x % nsub;
+    lephuff::HuffParWave w;
+    const int rc = w.run_write(images + img, &sh, st + (size_t)img * nsub, rows, sub, nsub);
+    if (rc && threadIdx.x == 0) atomicOr(img_status + img, rc);
+}
+__global__ void lep_huffman_par_finish_kernel(const lephuff::HuffDecImage* __restrict__ images, int nimg, lephuff::HuffDecRow* rows, const int* img_status) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= nimg) return;
+    lephuff::HuffDecRow* last = rows + images[i].rows_off + images[i].mcuv;
+    last->aux = (last->aux & 255) | (img_status[i] << 8);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -272,6 +302,7 @@ struct lep_gpu {
     void* d_lens = nullptr; size_t lens_bytes = 0;
     void* d_huff = nullptr; size_t huff_bytes = 0;      // HuffImage[] | HuffSegment[]
     void* d_huffdec = nullptr; size_t huffdec_bytes = 0;   // HuffDecImage[]
+    void* d_huffpar = nullptr; size_t huffpar_bytes = 0;   // HuffParState[nimg][nsub] | int status[nimg] (parallel Huffman decode)
     void* d_scan = nullptr; size_t scan_bytes = 0;      // scan bytes of the Huffman encoder (host variant)
     void* d_scanlen = nullptr; size_t scanlen_bytes = 0;
 };
@@ -448,7 +479,7 @@ void lep_gpu_destroy(lep_gpu* g) {
     if (!g) return;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffdec, g->d_scan, g->d_scanlen})
+    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
         if (p) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -512,6 +543,33 @@ int lep_gpu_huffman_decode_device(lep_gpu* g, const lep_huffdec_image* images, i
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
     g->last_kernel = "lep_huffman_decode_kernel";
+    return 0;
+}
+
+int lep_gpu_huffman_decode_parallel_device(lep_gpu* g, const lep_huffdec_image* images, int nimg, int nsub, lep_huffdec_row* d_rows, void* hip_stream) {
+    if (!g || nsub < 2 || nsub > lephuff::kHuffParMaxSub) return LEP_ASSERTION_FAILURE;
+    if (nimg <= 0) return 0;
+    for (int i = 0; i < nimg; ++i) if (images[i].rsti) return LEP_ASSERTION_FAILURE;   // restart intervals: the single-wave kernel's
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
+    HIPCHK(g, hipSetDevice(g->device));
+    if (int rc = ensure(g, &g->d_huffdec, &g->huffdec_bytes, (size_t)nimg * sizeof(lep_huffdec_image))) return rc;
+    const size_t o_status = ((size_t)nimg * nsub * sizeof(lephuff::HuffParState) + 255) & ~(size_t)255, total = o_status + (size_t)nimg * sizeof(int);
+    if (int rc = ensure(g, &g->d_huffpar, &g->huffpar_bytes, total)) return rc;
+    HIPCHK(g, hipMemcpyAsync(g->d_huffdec, images, (size_t)nimg * sizeof(lep_huffdec_image), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipMemsetAsync(g->d_huffpar, 0, total, st));
+    HIPCHK(g, hipStreamSynchronize(st));   // the caller's array may go away
+    lephuff::HuffParState* ps = (lephuff::HuffParState*)g->d_huffpar;
+    int* status = (int*)((char*)g->d_huffpar + o_status);
+    const lephuff::HuffDecImage* di = (const lephuff::HuffDecImage*)g->d_huffdec;
+    HIPCHK(g, hipEventRecord(g->ev0, st));
+    hipLaunchKernelGGL(lep_huffman_par_sync_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, ps, nsub);
+    hipLaunchKernelGGL(lep_huffman_par_count_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, ps, nsub);
+    hipLaunchKernelGGL(lep_huffman_par_write_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, (const lephuff::HuffParState*)ps, nsub, (lephuff::HuffDecRow*)d_rows, status);
+    hipLaunchKernelGGL(lep_huffman_par_finish_kernel, dim3((nimg + 255) / 256), dim3(256), 0, st, di, nimg, (lephuff::HuffDecRow*)d_rows, (const int*)status);
+    HIPCHK(g, hipGetLastError());
+    HIPCHK(g, hipEventRecord(g->ev1, st));
+    g->timed = true;
+    g->last_kernel = "lep_huffman_par_{sync,count,write}_kernel";
     return 0;
 }
 

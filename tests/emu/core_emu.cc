@@ -185,3 +185,22 @@ extern "C" int emu_huffman_decode_image(const lep_huffdec_image* img, lep_huffde
     w.run(&im, &sh, reinterpret_cast<lephuff::HuffDecRow*>(rows));
     return 0;
 }
+
+// several wavefronts per image (lep_huffdec_par.h): the three passes run one wave after the other
+#include "../../lepton_amd/csrc/lep_huffdec_par.h"
+extern "C" int emu_huffman_decode_image_parallel(const lep_huffdec_image* img, lep_huffdec_row* rows, int nsub, uint32_t* sync_blocks) {
+    static lephuff::HuffParShared sh;
+    if (nsub < 1 || nsub > lephuff::kHuffParMaxSub) return -1;
+    lephuff::HuffDecImage im;
+    memcpy(&im, img, sizeof im);
+    im.rows_off = 0;
+    std::vector<lephuff::HuffParState> st((size_t)nsub);
+    memset(st.data(), 0, st.size() * sizeof(lephuff::HuffParState));
+    for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; w.run_sync(&im, &sh, st.data(), s, nsub); }
+    for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; w.run_count(&im, &sh, st.data(), s, nsub); }
+    int status = 0;
+    for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; status |= w.run_write(&im, &sh, st.data(), reinterpret_cast<lephuff::HuffDecRow*>(rows), s, nsub); }
+    rows[im.mcuv].aux = (rows[im.mcuv].aux & 255) | (status << 8);
+    if (sync_blocks) for (int s = 0; s < nsub; ++s) sync_blocks[s] = st[(size_t)s].nblocks;
+    return 0;
+}

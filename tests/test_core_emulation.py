@@ -418,3 +418,96 @@ def test_gpu_huffman_decoder_survives_garbage_scans(emu, seed):
     if rows[img.mcuv].aux >> 8 == 0:
         assert L.lep_jpeg_finish_gpu(h, rows) in (0, 42)
     L.lep_jpeg_close(h)
+
+
+def _huffdec_setup(jpg):
+    """lep_jpeg_open_gpu + a zero padded copy of the scan + zeroed planes for the Huffman decode kernels' emulation"""
+    from lepton_amd import abi
+
+    L = abi.lib()
+    h = C.c_void_p()
+    img = abi.HuffDecImage()
+    ok = C.c_int(0)
+    assert L.lep_jpeg_open_gpu(jpg, len(jpg), C.byref(h), C.byref(img), C.byref(ok)) == 0
+    if not ok.value:
+        L.lep_jpeg_close(h)
+        return None
+    p, n = C.c_void_p(), C.c_size_t(0)
+    L.lep_jpeg_scan_bytes(h, C.byref(p), C.byref(n))
+    scan = C.create_string_buffer(C.string_at(p, n.value) + bytes(64), n.value + 64)
+    img.scan = C.addressof(scan)
+    d = JpegImage(jpg).desc
+    planes = [C.create_string_buffer(d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        img.blocks[c] = C.cast(planes[c], C.c_void_p).value
+    L.lep_jpeg_close(h)
+    return img, scan, planes, d
+
+
+@pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "optimized_q30"])
+@pytest.mark.parametrize("nsub", [2, 5, 16])
+def test_parallel_huffman_decoder_equals_the_single_wave_one(emu, name, nsub):
+    """lep_huffdec_par.h (several wavefronts per image: speculative sync pass, checked count pass, write pass) must leave
+    exactly what lep_huffdec.h leaves -- frame, hand-off records, pad bit -- or report a non-zero status (fallback), never
+    a different result"""
+    import io
+    from lepton_amd import abi, corpus
+
+    if name == "synth_640x360":
+        jpg = corpus.synth_jpeg(640, 360, 71, quality=88)
+    elif name == "optimized_q30":
+        from PIL import Image
+        import numpy as np
+        rng = np.random.default_rng(31)
+        a = np.asarray(Image.fromarray(rng.integers(0, 256, (30, 40, 3), dtype=np.uint8), "RGB").resize((320, 240), Image.BICUBIC)).astype(np.int16)
+        a = np.clip(a + rng.normal(0, 12, a.shape), 0, 255).astype(np.uint8)
+        buf = io.BytesIO(); Image.fromarray(a, "RGB").save(buf, format="JPEG", quality=30, subsampling="4:2:2", optimize=True)
+        jpg = buf.getvalue()
+    else:
+        jpg, _ = golden(name)
+    one = _huffdec_setup(jpg)
+    if one is None:
+        pytest.skip("not eligible for the GPU Huffman decoder")
+    img1, scan1, planes1, d = one
+    rows1 = (abi.HuffDecRow * (img1.mcuv + 1))()
+    assert emu.emu_huffman_decode_image(C.byref(img1), rows1) == 0 and rows1[img1.mcuv].aux >> 8 == 0
+    img2, scan2, planes2, _ = _huffdec_setup(jpg)
+    rows2 = (abi.HuffDecRow * (img2.mcuv + 1))()
+    assert emu.emu_huffman_decode_image_parallel(C.byref(img2), rows2, nsub, None) == 0
+    status = rows2[img2.mcuv].aux >> 8
+    if img2.rsti:
+        pytest.skip("restart intervals: the single-wave kernel keeps these files")
+    if status:
+        # allowed only when a subsequence is too short to synchronise in (tiny fixtures cut into many pieces)
+        assert img2.scan_len * 8 // nsub < 4096, "parallel decode gave up on a scan with %d bits per subsequence" % (img2.scan_len * 8 // nsub)
+        return
+    for c in range(d.ncomp):
+        assert planes2[c].raw == planes1[c].raw
+    for r in range(img1.mcuv + 1):
+        assert (rows2[r].bitpos, list(rows2[r].last_dc), rows2[r].aux) == (rows1[r].bitpos, list(rows1[r].last_dc), rows1[r].aux), r
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_parallel_huffman_decoder_survives_garbage(emu, seed):
+    """random bytes instead of a scan: every pass terminates, nothing is written outside the frame, and the outcome is a
+    status or (if the garbage happens to decode) the same as the single-wave kernel's"""
+    import numpy as np
+    from lepton_amd import abi, corpus
+
+    jpg = corpus.synth_jpeg(96, 64, 78)
+    rng = np.random.default_rng(seed)
+    outs = []
+    for par in (0, 4):
+        img, scan, planes, d = _huffdec_setup(jpg)
+        n = img.scan_len
+        junk = C.create_string_buffer(bytes(np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)) + bytes(64), n + 72)
+        img.scan = C.addressof(junk)
+        rows = (abi.HuffDecRow * (img.mcuv + 1))()
+        if par:
+            assert emu.emu_huffman_decode_image_parallel(C.byref(img), rows, par, None) == 0
+        else:
+            assert emu.emu_huffman_decode_image(C.byref(img), rows) == 0
+        outs.append((rows[img.mcuv].aux >> 8, [p.raw for p in planes]))
+    if outs[0][0] == 0 and outs[1][0] == 0:
+        assert outs[0][1] == outs[1][1]
+    del rng
