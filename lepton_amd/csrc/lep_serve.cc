@@ -272,7 +272,9 @@ void lep_server::batch_loop() {
             cv.wait(lk, [&] { return stop.load() || !ready.empty(); });
             if (stop.load()) return;
             // a request is complete: give the others that are in flight a moment to join its launch
-            cv.wait_for(lk, window, [&] { return stop.load() || ready.size() >= max_batch; });
+            // (system_clock: pthread_cond_timedwait, which ThreadSanitizer models -- the steady-clock wait is pthread_cond_clockwait,
+            //  which the gcc 11 runtime does not, and every lock after it would be reported)
+            cv.wait_until(lk, std::chrono::system_clock::now() + window, [&] { return stop.load() || ready.size() >= max_batch; });
             if (stop.load()) return;
             while (!ready.empty() && batch.size() < max_batch) { batch.push_back(ready.front()); ready.pop_front(); }
         }

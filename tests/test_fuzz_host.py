@@ -70,3 +70,20 @@ def test_frame_budget_is_the_references():
     ok = bytearray(j); ok[sof + 5:sof + 7] = (9000).to_bytes(2, "big"); ok[sof + 7:sof + 9] = (12000).to_bytes(2, "big")
     img = JpegImage(bytes(ok))    # 2.5 M blocks: inside the budget; the short scan simply ends early, like in the reference
     assert img.desc.width_blocks[0] == 1500
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_server_is_thread_and_memory_safe_under_load(sanitizer, tmp_path):
+    """lep_serve.cc (IO thread + batcher thread + client-facing sockets) under ThreadSanitizer and AddressSanitizer: 24 client
+    threads for a few seconds -- good requests, hang-ups mid-upload, answers never read, oversized and unknown files, failing
+    files, a time bound and a connection cap in force (tests/fuzz/serve_stress.cc)"""
+    exe = str(tmp_path / "serve_stress")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-o", exe,
+           os.path.join(FUZZ, "serve_stress.cc"), os.path.join(CSRC, "lep_serve.cc"), "-lz", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no %s sanitizer runtime for g++ here: %s" % (sanitizer, r.stderr[-200:]))
+    sock = "/tmp/lep-stress-%d-%s" % (os.getpid(), sanitizer[:4])
+    r = subprocess.run([exe, sock, "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert "good answers" in r.stderr
