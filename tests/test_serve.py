@@ -225,3 +225,26 @@ def test_daemon_batches_a_burst():
     finally:
         proc.terminate()
         proc.wait()
+
+
+def test_daemon_command_line():
+    """lepton_served's option handling (no GPU needed: every case ends before or at device creation)"""
+    def run(*args):
+        r = subprocess.run([SERVED] + list(args), capture_output=True, text=True, timeout=60)
+        return r.returncode, r.stdout, r.stderr
+
+    assert os.path.exists(SERVED), "lepton_served is built by __graft_entry__.build()"
+    rc, out, err = run()
+    assert rc == 1 and "usage" in err and out == ""
+    rc, out, err = run("-socket=/tmp/lep-x", "-bogus")
+    assert rc == 1 and "unknown option -bogus" in err
+    rc, out, err = run("-listen=2402", "-timebound=5s")          # jpgcoder.cc:1209-1212
+    assert rc == 1 and "Time bound action only supported with UNIX domain sockets" in err
+    rc, out, err = run("-devices=0,1", "-socket")                 # children need a name to derive theirs from
+    assert rc == 1 and "-devices needs -socket=<name>" in err
+    import torch
+    if not torch.cuda.is_available():
+        name = _name()
+        rc, out, err = run("-socket=" + name, "-timebound=10000ms", "-maxchildren=8", "-listenbacklog=64", "-skipverify", "-preload")
+        assert rc == 120 and "no usable gfx950 device" in err and out == ""     # no CPU fallback: nothing is served without a GPU
+        assert not os.path.exists(name)
