@@ -73,6 +73,9 @@ SLICES = {
 # `lepton -embedding=<n>`: a JPEG n bytes into a larger blob (name -> (input case, prefix bytes, trailer bytes)); the .jpg of the
 # fixture is the whole blob, which the .lep restores
 EMBEDDED = {"embedded_c422": ("c422_128x72", 1001, 2003)}
+# `lepton -permissive` on something that is not a JPEG: the bytes travel verbatim in a 'PGE' section behind a stock header
+# (generic_compress.cc:60-215); only the decode direction is supported here.  name -> number of bytes
+PERMISSIVE = {"permissive_5000": 5000}
 SLICE_ONLY_INPUTS = {"_q97_960x720": lambda: corpus.synth_jpeg(960, 720, 140, quality=97)}
 
 
@@ -138,6 +141,24 @@ def main():
             restored = open("/tmp/_golden_back.jpg", "rb").read() if back.returncode == 0 else b""
             entry.update(lep_md5=hashlib.md5(lep).hexdigest(), lep_size=len(lep), segments=lep[4],
                          restored_md5=hashlib.md5(restored).hexdigest(), restored_equals_input=restored == blob)
+        manifest[name] = entry
+        print(name, entry)
+    for name, nbytes in PERMISSIVE.items():
+        if only and name not in only:
+            continue
+        blob = bytes(((i * 2654435761) >> 13) & 255 for i in range(nbytes))
+        jp = os.path.join(HERE, name + ".jpg")       # (not a JPEG: the fixture's input)
+        lp = os.path.join(HERE, name + ".lep")
+        open(jp, "wb").write(blob)
+        if os.path.exists(lp):
+            os.unlink(lp)
+        r = subprocess.run([REF, "-unjailed", "-permissive", jp, lp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        entry = {"jpg_md5": hashlib.md5(blob).hexdigest(), "jpg_size": len(blob), "encode_exit": r.returncode, "permissive": True}
+        if r.returncode == 0:
+            lep = open(lp, "rb").read()
+            back = subprocess.run([REF, "-unjailed", lp, "/tmp/_golden_back.jpg"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            restored = open("/tmp/_golden_back.jpg", "rb").read() if back.returncode == 0 else b""
+            entry.update(lep_md5=hashlib.md5(lep).hexdigest(), lep_size=len(lep), segments=lep[4], restored_equals_input=restored == blob)
         manifest[name] = entry
         print(name, entry)
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)

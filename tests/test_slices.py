@@ -118,3 +118,13 @@ def test_gpu_batch_decompress_takes_slices():
     want = [golden(n)[0][s:(t or None)] for n, s, t in CASES] + [golden("c420_160x120")[0]]
     out, status, _ = codec.decompress_batch(leps)
     assert status == [0] * len(leps) and out == want
+
+
+def test_permissive_files_decode():
+    """`lepton -permissive` wraps bytes that are not a JPEG at all: a stock header, every byte in a 'PGE' section, empty coder
+    streams (generic_compress.cc:60-215).  Such files exist in stores written by the reference, so they must come back."""
+    blob, lep = golden("permissive_5000")
+    assert lep[3:4] == b"Y" and blob[:2] != b"\\xff\\xd8"
+    f = LepFile(lep)
+    ob.oracle_decode(f.desc, f.segments, f.streams)
+    assert f.recode() == blob
