@@ -37,6 +37,23 @@ extern "C" int emu_decode_segment(const lep_image_desc* d, int y0, int y1, int i
     return run<true>(d, y0, y1, is_last, const_cast<uint8_t*>(in), &len, 0, bins);
 }
 
+
+// The v3 / v4 decoders read the stream as ALIGNED dwords (the dword that holds the first and the one that holds the last byte
+// are loaded whole, the bytes outside the stream masked off) -- on the device every stream sits in an arena that is padded to
+// 256 bytes.  Give the emulation the same guarantee (and keep the caller's alignment phase), so that an address sanitizer
+// run of these tests only reports real out-of-bounds accesses.
+struct PaddedStream {
+    std::vector<uint8_t> arena;
+    const uint8_t* p;
+    PaddedStream(const uint8_t* in, uint32_t len) : arena((size_t)len + 24, 0) {
+        uint8_t* base = arena.data() + 8;
+        base -= (uintptr_t)base & 3;                 // 4-byte aligned, at least 4 bytes into the arena
+        uint8_t* q = base + ((uintptr_t)in & 3);     // same phase as the caller's pointer
+        if (len) memcpy(q, in, len);
+        p = q;
+    }
+};
+
 // v2 (wave-cooperative) encoder run as a 64-lane loop emulation
 extern "C" int emu_encode_segment_v2(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins) {
     ImageDev img;
@@ -100,7 +117,8 @@ extern "C" int emu_decode_segment_v3(const lep_image_desc* d, int y0, int y1, in
     seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = 0;
     static lep3::Dec3Shared sh;
     lep3::Dec3Wave w;
-    rc = w.run(&img, seg, reinterpret_cast<uint32_t*>(model.data()), ns.data(), &sh, in, len);
+    PaddedStream ps(in, len);
+    rc = w.run(&img, seg, reinterpret_cast<uint32_t*>(model.data()), ns.data(), &sh, ps.p, len);
     if (bins) *bins = w.nbins;
     return rc;
 }
@@ -139,7 +157,8 @@ extern "C" int emu_decode_segment_v4(const lep_image_desc* d, int y0, int y1, in
     seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = 0;
     static lep4::Dec4Shared sh;
     lep4::Dec4Wave w;
-    rc = w.run(&img, seg, reinterpret_cast<uint32_t*>(model.data()), ns.data(), &sh, in, len);
+    PaddedStream ps(in, len);
+    rc = w.run(&img, seg, reinterpret_cast<uint32_t*>(model.data()), ns.data(), &sh, ps.p, len);
     if (bins) *bins = w.nbins;
     return rc;
 }

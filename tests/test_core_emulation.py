@@ -11,7 +11,7 @@ import oracle_binding as ob
 from conftest import ROOT, golden, golden_cases
 from lepton_amd.codec import JpegImage
 
-EMU_SO = os.path.join(ROOT, "tests", "emu", "libcore_emu.so")
+EMU_SO = os.environ.get("LEP_EMU_SO") or os.path.join(ROOT, "tests", "emu", "libcore_emu.so")   # LEP_EMU_SO: sanitizer builds go elsewhere
 
 
 @pytest.fixture(scope="module")

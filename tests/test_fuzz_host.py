@@ -87,3 +87,13 @@ def test_server_is_thread_and_memory_safe_under_load(sanitizer, tmp_path):
     r = subprocess.run([exe, sock, "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert "good answers" in r.stderr
+
+
+
+# The kernel headers themselves (coders, Huffman kernels, the parallel Huffman decoder) have been through their parity tests
+# compiled with -fsanitize=address,undefined (257 tests, no finding; an out-of-bounds LDS / model / frame index is silent on
+# the GPU, not there).  By hand, because a preloaded sanitizer runtime inside pytest-in-pytest proved fragile:
+#   ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.so)
+#   LEP_EMU_SO=/tmp/libcore_emu_san.so LEP_EMU_DEFINES="-fsanitize=address,undefined -fno-omit-frame-pointer -g" \
+#   LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:log_path=/tmp/asanlog \
+#   python -m pytest tests/test_core_emulation.py tests/test_slices.py -x -q -m "not gpu" -p no:cacheprovider
