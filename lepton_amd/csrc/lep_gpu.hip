@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_decode_kernel(const lephuff
     w.run(images + blockIdx.x, &sh, rows);
 }
 
-// Several wavefronts per image (lep_huffdec_par.h; experimental, opt-in): sync / count / write passes over nsub subsequences
+// Several wavefronts per image (lep_huffdec_par.h; experimental, opt-in): sync / stitch / write passes over nsub subsequences
 // of every scan, then one thread per image folds the passes' verdicts into the final row record's status.
 __global__ __launch_bounds__(64, 8) void lep_huffman_par_sync_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffParState* st, int nsub) {
     __shared__ lephuff::HuffParShared sh;
@@ -250,11 +250,11 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_par_sync_kernel(const lephu
     lephuff::HuffParWave w;
     w.run_sync(images + img, &sh, st + (size_t)img * nsub, sub, nsub);
 }
-__global__ __launch_bounds__(64, 8) void lep_huffman_par_count_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffParState* st, int nsub) {
+__global__ __launch_bounds__(64, 8) void lep_huffman_par_stitch_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffParState* st, int nsub) {
     __shared__ lephuff::HuffParShared sh;
     const int img = (int)blockIdx.x / nsub, sub = (int)blockIdx.x % nsub;
     lephuff::HuffParWave w;
-    w.run_count(images + img, &sh, st + (size_t)img * nsub, sub, nsub);
+    w.run_stitch(images + img, &sh, st + (size_t)img * nsub, sub, nsub);
 }
 __global__ __launch_bounds__(64, 8) void lep_huffman_par_write_kernel(const lephuff::HuffDecImage* __restrict__ images, const lephuff::HuffParState* st, int nsub,
                                                                      lephuff::HuffDecRow* rows, int* img_status) {
@@ -563,13 +563,13 @@ int lep_gpu_huffman_decode_parallel_device(lep_gpu* g, const lep_huffdec_image* 
     const lephuff::HuffDecImage* di = (const lephuff::HuffDecImage*)g->d_huffdec;
     HIPCHK(g, hipEventRecord(g->ev0, st));
     hipLaunchKernelGGL(lep_huffman_par_sync_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, ps, nsub);
-    hipLaunchKernelGGL(lep_huffman_par_count_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, ps, nsub);
+    hipLaunchKernelGGL(lep_huffman_par_stitch_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, ps, nsub);
     hipLaunchKernelGGL(lep_huffman_par_write_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, (const lephuff::HuffParState*)ps, nsub, (lephuff::HuffDecRow*)d_rows, status);
     hipLaunchKernelGGL(lep_huffman_par_finish_kernel, dim3((nimg + 255) / 256), dim3(256), 0, st, di, nimg, (lephuff::HuffDecRow*)d_rows, (const int*)status);
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
-    g->last_kernel = "lep_huffman_par_{sync,count,write}_kernel";
+    g->last_kernel = "lep_huffman_par_{sync,stitch,write}_kernel";
     return 0;
 }
 

@@ -6,28 +6,39 @@
 // at an arbitrary bit with an arbitrary guess of its position inside the MCU falls into step with the true decoder -- same
 // bit position AND same block-within-MCU -- after a few blocks (measured on the bench corpus: 1..49 blocks, <= 2.5 kbit, in
 // 24 of 24 random starts; Klein & Wiseman 2003, Weissenberger & Schmidt 2018 for the GPU formulation).  So the scan is cut
-// into n subsequences of equal length and decoded in three passes of n wavefronts per image:
-//   A  sync   wave i decodes subsequence i from its first bit, speculatively (nothing stored, errors ignored), and records
-//             where its first block boundary at or behind the subsequence's end lies: E_i = (bit position, block phase);
-//   B  count  wave i decodes again from E_(i-1) -- the TRUE state if wave i-1 had synchronised -- to E_i, counting blocks and
-//             summing DC differences per component, and CHECKS that it arrives exactly at E_i.  By induction from wave 0
-//             (whose start is the start of the scan) a passed check proves E_i true; a failed one sends the image to the
-//             single-wave kernel / host parser (status != 0), so speculation can cost time but never correctness;
-//   C  write  prefix sums of the counts give every wave its first block's position in the frame and its DC predictors; it
-//             decodes a third time, now storing blocks and the per-MCU-row hand-off records exactly as lep_huffdec.h does.
-// Three passes of 1/n of the chain each.  Files with restart intervals keep the single-wave kernel (a restart resets state
-// at an MCU count that a speculative wave does not know).
+// into n subsequences of equal length and decoded in two full passes and a short one, n wavefronts per image each:
+//   A  sync    wave i decodes subsequence i from its first bit, speculatively (nothing stored, errors ignored), counting
+//              blocks and summing DC differences per component; it LOGS its first kHuffParLog block boundaries (bit position,
+//              block phase, running count / sums) and records where its first boundary at or behind the subsequence's end
+//              lies: E_i = (bit position, block phase);
+//   S  stitch  wave i (i >= 1) starts at E_(i-1) -- the TRUE state if wave i-1 was in step by its end -- and decodes until
+//              it stands on a boundary of wave i's log: from there on wave i's pass-A trajectory, and with it E_i, is the true
+//              decode.  By induction from wave 0 (whose start is the start of the scan) a found match is a proof; no match
+//              within the log sends the image to the single-wave kernel / host parser (status != 0): speculation can cost
+//              time, never correctness.  The true content of region i = [E_(i-1), E_i) is then (stitched blocks) + (wave i's
+//              totals - its log entry at the match);
+//   C  write   prefix sums of the region counts / DC sums give every wave its first block's position in the frame and its DC
+//              predictors; it decodes its region again, now storing blocks and the per-MCU-row hand-off records exactly as
+//              lep_huffdec.h does.
+// Two passes of 1/n of the chain each plus a few dozen blocks of stitching.  Files with restart intervals keep the
+// single-wave kernel (a restart resets state at an MCU count that a speculative wave does not know).
 #pragma once
 #include "lep_huffdec.h"
 
 namespace lephuff {
 
+constexpr int kHuffParLog = 96;   // boundaries a wave logs at its start (synchronisation was observed within 49 blocks)
+
 struct HuffParState {       // one per (image, subsequence), device memory, zeroed before pass A
     uint32_t end_bitpos;    // A: first block boundary at or behind the end of the subsequence
     uint32_t end_phase;     //    and the block-within-MCU there
-    uint32_t nblocks;       // B: blocks between the true start and E_i
-    int32_t status;         // B / C: non-zero = irregular or not synchronised: the image takes the fallback
-    int16_t dcsum[4];       // B: sum of the DC differences per component (int16 wrap, like the predictor itself)
+    uint32_t nblocks;       // A: blocks this wave decoded (speculative);  S: blocks of the true region [E_(i-1), E_i)
+    int32_t status;         // S / C: non-zero = irregular or not synchronised: the image takes the fallback
+    int16_t dcsum[4];       // A / S: sum of the DC differences per component, like nblocks (int16 wrap, like the predictor)
+    uint32_t nlog;          // A: entries of the log
+    uint32_t log_bitpos[kHuffParLog];      // boundary BEFORE block k of this wave's pass-A decode
+    uint8_t log_phase[kHuffParLog];
+    int16_t log_dcsum[kHuffParLog][4];     // sums over the blocks before that boundary
 };
 
 struct HuffParShared : HuffDecShared {
@@ -102,23 +113,36 @@ struct HuffParWave : HuffDecWave {
     // ---- pass A -----------------------------------------------------------------------------------------------------------
     WDEV void run_sync(const HuffDecImage* image, HuffParShared* shared, HuffParState* st, int sub, int nsub) {
         setup(image, shared);
-        if (sub + 1 >= nsub) return;                       // the last subsequence ends where the scan ends
         const uint32_t cb = chunk_bits_of(scan_bits, nsub);
         const uint32_t start = (uint32_t)sub * cb, end = (uint32_t)(sub + 1) * cb;
-        uint32_t eb = 0xffffffffu, ep = 0;
-        if (start < scan_bits) {
+        uint32_t eb = 0xffffffffu, ep = 0, count = 0, nlog = 0;
+        int sum[4] = {0, 0, 0, 0};
+        if (start < scan_bits && sub + 1 < nsub) {           // the last region ends where the image ends: pass C counts it down
             seek(start);
             int phase = 0;
             const uint32_t stop = end < scan_bits ? end : scan_bits;
             while (uni(bitpos) < stop) {
+                if (nlog < (uint32_t)kHuffParLog) {
+                    const uint32_t b = uni(bitpos);
+                    LANES(l) if (l == 0) {
+                        st[sub].log_bitpos[nlog] = b; st[sub].log_phase[nlog] = (uint8_t)phase;
+                        for (int c = 0; c < 4; ++c) st[sub].log_dcsum[nlog][c] = (int16_t)sum[c];
+                    }
+                    ++nlog;
+                }
                 int diff = 0;
                 const int cmp = psh->ph_cmp[phase];
                 skip_block(img->dc_tbl[cmp], 2 + img->ac_tbl[cmp], &diff, true);
+                sum[cmp] = (int16_t)(sum[cmp] + diff);
+                ++count;
                 phase = phase + 1 == nphase ? 0 : phase + 1;
             }
             eb = uni(bitpos); ep = (uint32_t)phase;
         }
-        LANES(l) if (l == 0) { st[sub].end_bitpos = eb; st[sub].end_phase = ep; }
+        LANES(l) if (l == 0) {
+            st[sub].end_bitpos = eb; st[sub].end_phase = ep; st[sub].nblocks = count; st[sub].nlog = nlog;
+            for (int c = 0; c < 4; ++c) st[sub].dcsum[c] = (int16_t)sum[c];
+        }
     }
 
     // true start of subsequence `sub`: the start of the scan, or where the wave in front said its last block ended
@@ -127,32 +151,41 @@ struct HuffParWave : HuffDecWave {
         else { *bp = st[sub - 1].end_bitpos; *phase = (int)st[sub - 1].end_phase; }
     }
 
-    // ---- pass B -----------------------------------------------------------------------------------------------------------
-    WDEV void run_count(const HuffDecImage* image, HuffParShared* shared, HuffParState* st, int sub, int nsub) {
+    // ---- pass S -----------------------------------------------------------------------------------------------------------
+    // Region i = [E_(i-1), E_i).  Wave 0's region is its own pass-A decode (its start was the true start).  Wave i >= 1 walks
+    // from E_(i-1) until it stands on a logged boundary of wave i; what wave i decoded BEFORE that boundary was out of step and
+    // is replaced by what was walked here.  Runs after pass A of the whole image; rewrites nblocks / dcsum of its own entry only.
+    WDEV void run_stitch(const HuffDecImage* image, HuffParShared* shared, HuffParState* st, int sub, int nsub) {
         setup(image, shared);
-        if (sub + 1 >= nsub) return;                       // the last wave's count is what is left of the image (pass C)
+        if (sub == 0 || sub + 1 >= nsub) return;           // wave 0: nothing to replace; the last region is counted down in pass C
         uint32_t bp; int phase;
         true_start(st, sub, &bp, &phase);
-        const uint32_t endpos = st[sub].end_bitpos;
-        uint32_t count = 0;
-        int sum[4] = {0, 0, 0, 0};
+        const uint32_t nlog = st[sub].nlog;
         int bad = 0;
-        if (bp > scan_bits || endpos == 0xffffffffu || bp > endpos || phase >= nphase) bad = 3;
+        uint32_t walked = 0, k = 0;
+        int sum[4] = {0, 0, 0, 0};
+        if (bp > scan_bits || st[sub].end_bitpos == 0xffffffffu || phase >= nphase || nlog == 0) bad = 3;
         if (!bad) {
             seek(bp);
-            while (uni(bitpos) < endpos) {
+            for (;;) {
+                const uint32_t b = uni(bitpos);
+                while (k < nlog && st[sub].log_bitpos[k] < b) ++k;            // both sequences only move forward
+                if (k < nlog && st[sub].log_bitpos[k] == b && st[sub].log_phase[k] == (uint8_t)phase) break;   // in step
+                if (k >= nlog || b >= st[sub].end_bitpos) { bad = 3; break; }   // not synchronised inside the log
                 int diff = 0;
                 const int cmp = psh->ph_cmp[phase];
                 if (!skip_block(img->dc_tbl[cmp], 2 + img->ac_tbl[cmp], &diff, false)) { bad = 1; break; }
                 sum[cmp] = (int16_t)(sum[cmp] + diff);
-                ++count;
+                ++walked;
                 phase = phase + 1 == nphase ? 0 : phase + 1;
             }
-            if (!bad && (uni(bitpos) != endpos || (uint32_t)phase != st[sub].end_phase)) bad = 3;   // the wave in front was not in step
         }
         LANES(l) if (l == 0) {
-            st[sub].nblocks = count; st[sub].status = bad;
-            for (int c = 0; c < 4; ++c) st[sub].dcsum[c] = (int16_t)sum[c];
+            if (!bad) {
+                st[sub].nblocks = walked + (st[sub].nblocks - k);
+                for (int c = 0; c < 4; ++c) st[sub].dcsum[c] = (int16_t)(sum[c] + st[sub].dcsum[c] - st[sub].log_dcsum[k][c]);
+            }
+            st[sub].status = bad;
         }
     }
 
@@ -203,6 +236,7 @@ struct HuffParWave : HuffDecWave {
             if (uni(bitpos) > scan_bits) return 2;          // ran out of data inside a block
             if (++phase == nphase) { phase = 0; ++mcu; }
         }
+        if (!last && (uni(bitpos) != st[sub].end_bitpos || (uint32_t)phase != st[sub].end_phase)) return 3;   // must stand where the next region starts
         if (last) {
             if (phase != 0 || mcu != img->mcuc) return 3;
             const int padbit = (int8_t)unpad(255);

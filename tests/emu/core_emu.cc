@@ -216,7 +216,7 @@ extern "C" int emu_huffman_decode_image_parallel(const lep_huffdec_image* img, l
     std::vector<lephuff::HuffParState> st((size_t)nsub);
     memset(st.data(), 0, st.size() * sizeof(lephuff::HuffParState));
     for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; w.run_sync(&im, &sh, st.data(), s, nsub); }
-    for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; w.run_count(&im, &sh, st.data(), s, nsub); }
+    for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; w.run_stitch(&im, &sh, st.data(), s, nsub); }
     int status = 0;
     for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; status |= w.run_write(&im, &sh, st.data(), reinterpret_cast<lephuff::HuffDecRow*>(rows), s, nsub); }
     rows[im.mcuv].aux = (rows[im.mcuv].aux & 255) | (status << 8);
