@@ -8,7 +8,7 @@
 // 24 of 24 random starts; Klein & Wiseman 2003, Weissenberger & Schmidt 2018 for the GPU formulation).  So the scan is cut
 // into n subsequences of equal length and decoded in two full passes and a short one, n wavefronts per image each:
 //   A  sync    wave i decodes subsequence i from its first bit, speculatively (nothing stored, errors ignored), counting
-//              blocks and summing DC differences per component; it LOGS its first kHuffParLog block boundaries (bit position,
+//              blocks and summing DC differences per component; it LOGS its first kHuffParLog (192) block boundaries (bit position,
 //              block phase, running count / sums) and records where its first boundary at or behind the subsequence's end
 //              lies: E_i = (bit position, block phase);
 //   S  stitch  wave i (i >= 1) starts at E_(i-1) -- the TRUE state if wave i-1 was in step by its end -- and decodes until
@@ -27,7 +27,7 @@
 
 namespace lephuff {
 
-constexpr int kHuffParLog = 96;   // boundaries a wave logs at its start (synchronisation was observed within 49 blocks)
+constexpr int kHuffParLog = 192;  // boundaries a wave logs at its start (synchronisation is usually there within 50 blocks, rarely beyond 100)
 
 struct HuffParState {       // one per (image, subsequence), device memory, zeroed before pass A
     uint32_t end_bitpos;    // A: first block boundary at or behind the end of the subsequence
