@@ -400,6 +400,22 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             HIPOK(hipMemcpyAsync(rows.data(), s->d_rows, rows_total * sizeof(lep_huffdec_row), hipMemcpyDeviceToHost, s_huff));
             HIPOK(hipStreamSynchronize(s_huff));
             st.d2h_bytes += (double)(rows_total * sizeof(lep_huffdec_row));
+            if (par >= 2) {
+                // a scan whose subsequences did not synchronise (or that is irregular) gets a second chance with the single-wave
+                // kernel before the host parser is bothered: its frame is wiped first (pass C may have written part of it)
+                std::vector<lep_huffdec_image> again;
+                for (const lep_huffdec_image& hi : launch) {
+                    if (hi.rsti || (rows[hi.rows_off + (size_t)hi.mcuv].aux >> 8) == 0) continue;
+                    for (int cc = 0; cc < hi.ncomp; ++cc)
+                        HIPOK(hipMemsetAsync(hi.blocks[cc], 0, (size_t)hi.bch[cc] * hi.vs[cc] * hi.mcuv * 128, s_huff));
+                    again.push_back(hi);
+                }
+                if (!again.empty()) {
+                    if (int rc = lep_gpu_huffman_decode_device(g, again.data(), (int)again.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc;
+                    HIPOK(hipMemcpyAsync(rows.data(), s->d_rows, rows_total * sizeof(lep_huffdec_row), hipMemcpyDeviceToHost, s_huff));
+                    HIPOK(hipStreamSynchronize(s_huff));
+                }
+            }
             // hand-offs from the row records; irregular scans go back to the host parser (and their frames up again)
             t0 = now_s();
             std::vector<char> redo(nl, 0);
