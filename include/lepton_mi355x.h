@@ -149,7 +149,7 @@ typedef struct lep_huffdec_row {
 } lep_huffdec_row;
 int lep_gpu_huffman_decode_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, lep_huffdec_row *d_rows, void *hip_stream);
 /* EXPERIMENTAL (opt-in, not yet measured on hardware): the same result with nsub (2..64) wavefronts per image -- speculative
- * synchronisation pass, checked count pass, write pass (lep_huffdec_par.h; bit-exact against the single-wave kernel in the
+ * synchronisation pass, stitching walk that proves each region, write pass (lep_huffdec_par.h; bit-exact against the single-wave kernel in the
  * lane-loop emulation).  Images with restart intervals are not accepted.  A subsequence that fails to synchronise gives its
  * image a non-zero status, exactly like an irregular scan. */
 int lep_gpu_huffman_decode_parallel_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, int nsub, lep_huffdec_row *d_rows, void *hip_stream);

@@ -447,7 +447,7 @@ def _huffdec_setup(jpg):
 @pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "optimized_q30"])
 @pytest.mark.parametrize("nsub", [2, 5, 16])
 def test_parallel_huffman_decoder_equals_the_single_wave_one(emu, name, nsub):
-    """lep_huffdec_par.h (several wavefronts per image: speculative sync pass, checked count pass, write pass) must leave
+    """lep_huffdec_par.h (several wavefronts per image: speculative sync pass, stitching walk, write pass) must leave
     exactly what lep_huffdec.h leaves -- frame, hand-off records, pad bit -- or report a non-zero status (fallback), never
     a different result"""
     import io
