@@ -200,6 +200,14 @@ int lep_jpeg_plan(const lep_jpeg *j, int max_threads, lep_segment *segs, int ima
 int lep_jpeg_set_encode_options(lep_jpeg *j, int max_threads, int min_threads, int even_split);
 /* whole .lep file from the per-segment streams (header + mux + trailer) */
 int lep_jpeg_write_lep(const lep_jpeg *j, int max_threads, const lep_bytes *streams, int nstreams, lep_bytes *out);
+/* The Huffman half of the reference's default round-trip check (src/lepton/validation.cc:97-218; `lepton` without
+ * -skipverify exits with ROUNDTRIP_FAILURE when the file it would restore differs from its input): parses `lepdata` (what
+ * lep_jpeg_write_lep just produced), re-codes j's own coefficient frame with the .lep's header, and compares the result
+ * with `want` (the whole input; for a slice the bytes [start_byte, trunc); for an embedded JPEG the whole blob).  Host
+ * only.  The arithmetic-coder half (streams -> the same coefficients) is lep_batch_options.verify's on-GPU comparison.
+ * Returns 0, LEP_ROUNDTRIP_FAILURE, or the exit code of a .lep that does not parse.  Files the reference itself cannot
+ * restore -- e.g. a one-component frame with sampling factors 2x2, restart markers and more than one MCU row -- end here. */
+int lep_jpeg_check_restores(const lep_jpeg *j, const uint8_t *lepdata, size_t lep_len, const uint8_t *want, size_t want_len);
 
 /* .lep -> streams + frame geometry (read_ujpg, src/lepton/jpgcoder.cc:4117-4362) */
 int lep_file_open(const uint8_t *lepdata, size_t len, lep_file **out);

@@ -649,6 +649,11 @@ int parse_jpeg(const uint8_t* data, size_t size, bool allow_progressive, JpegFil
     if (jf->ncomp > 3) return EX_UNSUPPORTED_4_COLORS;
     if (jf->start_byte) allow_progressive = false;   // "Encode of partial progressive images not allowed" (jpgcoder.cc:1205-1208)
     rc = decode_scans(jf, allow_progressive);
+    // the reference's errorlevel 1 ("warnings": an unknown marker, a block ending in a coded zero, inconsistent pad bits,
+    // non-optimal end-of-band runs, data left over in the scan) stops it before write_ujpg (err_tresh = 1,
+    // jpgcoder.cc:528, 2047) and exits with UNSUPPORTED_JPEG (jpgcoder.cc:2024): none of those files can be restored
+    // byte for byte by a canonical re-encoder
+    if (!rc && jf->warn > 0) { if (jf->error.empty()) jf->error = "non-canonical JPEG (reference errorlevel 1)"; return EX_UNSUPPORTED_JPEG; }
     if (rc || !jf->start_byte) return rc;
     // -startbyte: drop the hand-off rows that lie in front of start_byte (the last record always stays) and keep the raw
     // bytes between start_byte and the first remaining row as prefix garbage (write_ujpg, jpgcoder.cc:3801-3843)

@@ -254,6 +254,23 @@ int lep_file_recode(lep_file* f, lep_bytes* out) {
     return to_bytes(jpg, out);
 }
 
+int lep_jpeg_check_restores(const lep_jpeg* j, const uint8_t* lepdata, size_t lep_len, const uint8_t* want, size_t want_len) {
+    lep_file* f = nullptr;
+    if (int rc = lep_file_open(lepdata, lep_len, &f)) return rc;
+    std::unique_ptr<lep_file> hold(f);
+    const lep::JpegFile& src = j->jf;
+    lep::JpegFile& dst = f->lf.jpeg;
+    if (dst.ncomp != src.ncomp) return LEP_ROUNDTRIP_FAILURE;
+    for (int c = 0; c < src.ncomp; ++c)
+        if (dst.comp[c].bch != src.comp[c].bch || dst.comp[c].bcv != src.comp[c].bcv || !src.plane[c]) return LEP_ROUNDTRIP_FAILURE;
+    // the re-coder only reads coefficients: lend it the parsed frame (what the arithmetic decoder would have produced)
+    for (int c = 0; c < src.ncomp; ++c) dst.plane[c] = src.plane[c];
+    f->frame_ready = true;
+    std::vector<uint8_t> jpg;
+    if (lep::recode_jpeg(&f->lf, &jpg)) return LEP_ROUNDTRIP_FAILURE;
+    return jpg.size() == want_len && (want_len == 0 || memcmp(jpg.data(), want, want_len) == 0) ? 0 : LEP_ROUNDTRIP_FAILURE;
+}
+
 int lep_file_recode_plan(lep_file* f, lep_huff_image* image, lep_huff_segment* segs, int* nseg, int* gpu_ok) {
     int rc = lep::recode_prepare(&f->lf, &f->plan);
     if (rc) return rc;
@@ -286,7 +303,8 @@ extern "C" {
 
 int lep_compress(lep_gpu* g, const uint8_t* jpg, size_t len, lep_bytes* out) { return lep_compress_slice(g, jpg, len, 0, 0, out); }
 
-static int compress_parsed(lep_gpu* g, lep_jpeg* j, lep_bytes* out) {
+// want: the bytes the .lep has to restore (the reference's default validation; a file that fails it is refused, not written)
+static int compress_parsed(lep_gpu* g, lep_jpeg* j, const uint8_t* want, size_t want_len, lep_bytes* out) {
     std::unique_ptr<lep_jpeg> hold(j);
     lep_image_desc d;
     lep_jpeg_describe(j, &d);
@@ -303,7 +321,11 @@ static int compress_parsed(lep_gpu* g, lep_jpeg* j, lep_bytes* out) {
     }
     int rc = lep_gpu_encode_host(g, &d, 1, segs, n, streams, status);
     if (rc) return rc;
-    return lep_jpeg_write_lep(j, 0, streams, n, out);
+    rc = lep_jpeg_write_lep(j, 0, streams, n, out);
+    if (rc) return rc;
+    rc = lep_jpeg_check_restores(j, out->data, out->len, want, want_len);
+    if (rc) { lep_free(out->data); out->data = nullptr; out->len = out->cap = 0; }
+    return rc;
 }
 
 int lep_compress_slice(lep_gpu* g, const uint8_t* jpg, size_t len, size_t start_byte, size_t trunc, lep_bytes* out) {
@@ -312,7 +334,7 @@ int lep_compress_slice(lep_gpu* g, const uint8_t* jpg, size_t len, size_t start_
     lep_jpeg* j = nullptr;
     int rc = lep_jpeg_open_slice(jpg, len, start_byte, &j);
     if (rc) return rc;
-    return compress_parsed(g, j, out);
+    return compress_parsed(g, j, jpg + start_byte, len - start_byte, out);
 }
 
 int lep_compress_embedded(lep_gpu* g, const uint8_t* blob, size_t len, size_t offset, lep_bytes* out) {
@@ -320,7 +342,7 @@ int lep_compress_embedded(lep_gpu* g, const uint8_t* blob, size_t len, size_t of
     lep_jpeg* j = nullptr;
     int rc = lep_jpeg_open_embedded(blob, len, offset, &j);
     if (rc) return rc;
-    return compress_parsed(g, j, out);
+    return compress_parsed(g, j, blob, len, out);
 }
 
 // How lep_compress_batch cuts a batch into pipeline chunks (pure host logic, unit-tested on the CPU).  A chunk's thread

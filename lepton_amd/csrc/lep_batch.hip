@@ -281,6 +281,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     g_alloc_s = 0;
     int rc_all = 0;
     std::vector<lep_jpeg*> parsed(n, nullptr);
+    std::vector<char> host_parsed(n, 0);   // files the host parser took (irregular scans): verify also re-codes them on the host
 
     // 2. per chunk: split the files on the host pool; eligible scans are Huffman-decoded ON THE GPU straight into the device
     //    frame (only the 2 MB of scan bytes cross PCIe), the others by the host parser into the slot's pinned frames; then the
@@ -291,6 +292,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         const size_t room = (k + 1 < (int)c->live.size() ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
         if (parsed[i]) { lep_jpeg_close(parsed[i]); parsed[i] = nullptr; }
         int rc = lep_jpeg_open_into(jpgs[i].data, jpgs[i].len, 1, s->h_frames + c->frame_off[k], room, &parsed[i]);
+        host_parsed[i] = 1;
         if (!rc) {
             lep_jpeg_describe(parsed[i], &c->host_desc[k]);
             const lep_image_desc& d = c->host_desc[k];
@@ -564,6 +566,13 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                     if (flags[k]) rc = LEP_ROUNDTRIP_FAILURE;
                 }
                 if (!rc) rc = lep_jpeg_write_lep(parsed[i], 0, strs, s1 - s0, &outs[i]);
+                // the Huffman half of the reference's round-trip check for the files whose scans the host parser took (their
+                // frame is still in this slot's pinned staging): a scan the GPU decoder accepted is canonical by construction
+                // -- every code valid, no block ending in a coded zero, one pad-bit pattern, restart markers in step
+                if (!rc && verify && host_parsed[i]) {
+                    rc = lep_jpeg_check_restores(parsed[i], outs[i].data, outs[i].len, jpgs[i].data, jpgs[i].len);
+                    if (rc) { lep_free(outs[i].data); outs[i].data = nullptr; outs[i].len = outs[i].cap = 0; }
+                }
                 status[i] = rc;
                 lep_jpeg_close(parsed[i]);
                 parsed[i] = nullptr;

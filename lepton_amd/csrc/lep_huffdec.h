@@ -139,6 +139,7 @@ struct HuffDecWave {
         if (ucond(hc < 0)) return false;
         *diff = devli((uint32_t)hc & 255u, n);
         uint32_t bpos = vec(1);
+        uint32_t last_s = vec(1);                     // magnitude category of the last coefficient written (0 = a coded zero)
 #pragma nounroll
         while (ucond(bpos < 64)) {
             hc = symbol_and_bits(act, false, &n);
@@ -149,8 +150,11 @@ struct HuffDecWave {
             bpos += z;
             sh->blk[sh->z2a[bpos]] = (int16_t)devli(s, n);
             ++bpos;
+            last_s = s;
         }
-        return true;
+        // a block whose last coded coefficient is zero (ZRL + EOB, a run/size symbol with size 0): the re-encoder would write
+        // it differently, and the reference refuses the file ("cannot encode image with eob after last 0", jpgcoder.cc:2950)
+        return !ucond(last_s == 0);
     }
 
     // BitReader::unpad (bitops.hh): the pad-bit pattern of the current partial byte, consuming it
@@ -221,7 +225,7 @@ struct HuffDecWave {
                 if (sta) {
                     const int got = unpad(padbit == -1 ? 255 : padbit);
                     if (padbit == -1) padbit = (int8_t)got;
-                    else if (padbit != got) padbit = 1;
+                    else if (padbit != got) { padbit = 1; status = 3; }   // "inconsistent use of padbits" (jpgcoder.cc:3255): refused by the host parser
                     if (sta == 1) { rstw = rsti; lastdc[0] = lastdc[1] = lastdc[2] = lastdc[3] = 0; }
                 }
             }

@@ -37,7 +37,13 @@ def _built():
 
 def golden_cases():
     man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
-    return sorted(k for k, v in man.items() if v.get("encode_exit") == 0 and "slice" not in v and "embedding" not in v and "permissive" not in v)
+    return sorted(k for k, v in man.items() if v.get("encode_exit") == 0 and "slice" not in v and "embedding" not in v and "permissive" not in v and "roundtrip_failure" not in v)
+
+
+def roundtrip_failure_cases():
+    """files the reference only compresses with -skipverify (its default run: ROUNDTRIP_FAILURE): [(name, md5 of what the reference restores)]"""
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    return sorted((k, v["restored_md5"]) for k, v in man.items() if v.get("roundtrip_failure"))
 
 
 def embedded_cases():

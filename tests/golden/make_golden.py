@@ -15,7 +15,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from lepton_amd import corpus  # noqa: E402
+import jpeg_writer  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref", "lepton")
 
@@ -30,6 +32,15 @@ def pil_jpeg(w, h, seed, mode="RGB", **save):
     img.save(buf, format="JPEG", **save)
     return buf.getvalue()
 
+
+def layout(w, h, comps, seed, **kw):
+    """frames PIL cannot write (tests/jpeg_writer.py): comps = [(id, h, v, quant table, dc table, ac table)]"""
+    import numpy as np
+
+    return jpeg_writer.write_baseline(w, h, comps, np.random.default_rng(seed), **kw)[0]
+
+
+Y, CB, CR = (lambda h, v, i=1: (i, h, v, 0, 0, 0)), (lambda h, v, i=2: (i, h, v, 1, 1, 1)), (lambda h, v, i=3: (i, h, v, 1, 1, 1))
 
 CASES = {
     "c420_160x120": lambda: corpus.synth_jpeg(160, 120, 101),
@@ -59,6 +70,22 @@ CASES = {
     "prog_truncated_mid": lambda: (lambda b: b[:len(b) // 2])(corpus.synth_jpeg(320, 240, 132, progressive=True)),
     "prog_truncated_dc": lambda: corpus.synth_jpeg(320, 240, 133, progressive=True)[:1100],
     "prog_truncated_q97_800x600": lambda: (lambda b: b[:len(b) * 2 // 3])(corpus.synth_jpeg(800, 600, 134, quality=97, progressive=True)),
+    # sampling layouts beyond libjpeg's front end (coefficient-domain writer, tests/jpeg_writer.py)
+    "lay_440_97x50": lambda: layout(97, 50, [Y(1, 2), CB(1, 1), CR(1, 1)], 201),                         # 4:4:0
+    "lay_mixed_200x120": lambda: layout(200, 120, [Y(2, 2), CB(2, 1), CR(1, 1)], 202),                   # every component its own factors
+    "lay_mixed_rst_104x72": lambda: layout(104, 72, [Y(2, 2), CB(1, 2), CR(2, 1)], 203, restart_interval=3),
+    "lay_chromafine_96x64": lambda: layout(96, 64, [Y(1, 1), CB(2, 2), CR(1, 1)], 204),                  # chroma sampled finer than luma
+    "lay_all22_64x48": lambda: layout(64, 48, [Y(2, 2), CB(2, 2), CR(2, 2)], 205),                       # four blocks of each per MCU
+    "lay_two_components_120x40": lambda: layout(120, 40, [Y(2, 1), CB(1, 1)], 206),
+    "lay_gray22_80x56": lambda: layout(80, 56, [Y(2, 2)], 207),                                          # one component, factors 2x2 (images/gray2sf.jpg)
+    "lay_ids_pad0_64x64": lambda: layout(64, 64, [Y(2, 2, 0), CB(1, 1, 200), CR(1, 1, 7)], 208, pad_bit=0, restart_interval=4),
+    "lay_440_640x480_2seg": lambda: layout(640, 480, [Y(1, 2), CB(1, 1), CR(1, 1)], 209, restart_interval=7),   # 170 kB of scan: two thread segments
+}
+# Files the reference compresses with -skipverify but cannot restore (its default run ends in ROUNDTRIP_FAILURE, exit 41;
+# test_suite/test_roundtrip.sh does the same with images/roundtripfail.jpg): the .lep is the -skipverify one, restored_md5 what
+# the reference makes of it.  We must refuse the compression with 41 and decode the .lep to the same wrong bytes.
+ROUNDTRIP_FAILURES = {
+    "rtfail_gray22_rst_64x64": lambda: layout(64, 64, [Y(2, 2)], 210, restart_interval=7),   # one component, factors 2x2, restart markers, > 1 MCU row
 }
 
 # `lepton -startbyte=<s> -trunc=<t>` slices (format flag 'Y'): name -> (input case above, start_byte, trunc; 0 = to the end).
@@ -83,7 +110,7 @@ def main():
     only = set(sys.argv[1:])   # names to (re)generate; default: all
     mpath = os.path.join(HERE, "manifest.json")
     manifest = json.load(open(mpath)) if only and os.path.exists(mpath) else {}
-    for name, make in CASES.items():
+    for name, make in list(CASES.items()) + list(ROUNDTRIP_FAILURES.items()):
         if only and name not in only:
             continue
         jpg = make()
@@ -100,6 +127,11 @@ def main():
             restored = open("/tmp/_golden_back.jpg", "rb").read() if back.returncode == 0 else b""
             entry.update(lep_md5=hashlib.md5(lep).hexdigest(), lep_size=len(lep), segments=lep[4],
                          restored_md5=hashlib.md5(restored).hexdigest(), restored_equals_input=restored == jpg)
+            if name in ROUNDTRIP_FAILURES:
+                assert restored != jpg and back.returncode == 0
+                dflt = subprocess.run([REF, "-unjailed", jp, "/tmp/_golden_default.lep"], capture_output=True)
+                assert b"ROUNDTRIP_FAILURE" in dflt.stderr, dflt.stderr[-200:]
+                entry["roundtrip_failure"] = True
         elif os.path.exists(lp):
             os.unlink(lp)
         manifest[name] = entry

@@ -1,5 +1,5 @@
 """Randomised parity sweep of the host side against the real reference binary (where it exists: the build container): seeded
-PIL-written JPEGs over sizes, qualities, chroma layouts (4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 / 4:1:1), grey, CMYK, progressive,
+PIL-written JPEGs over sizes, qualities, chroma layouts (4:4:4 / 4:2:2 / 4:2:0; other sampling factors: test_sampling_layouts.py), grey, CMYK, progressive,
 restart intervals, optimised tables, comments, multi-segment ICC profiles, EXIF, trailing garbage and truncation.  For each
 file either both sides reject it with the same exit code, or the .lep written here (JPEG parse, segment plan, container;
 arithmetic-coded streams from the oracle, which the GPU tests pin the kernels to) equals the reference's byte for byte and the
@@ -27,7 +27,8 @@ def _random_jpeg(rnd, trial):
     w = rnd.choice([8, 16, 17, 64, 97, 160, 333, 640])
     h = rnd.choice([8, 16, 23, 48, 99, 240, 480])
     mode = rnd.choice(["RGB", "RGB", "RGB", "L", "CMYK"])
-    sub = rnd.choice(["4:4:4", "4:2:2", "4:2:0", "4:4:0", "4:1:1"])
+    sub = rnd.choice(["4:4:4", "4:2:2", "4:2:0", "4:4:0", "4:1:1"])   # PIL refuses "4:4:0" (skipped below) and writes 4:2:0 for "4:1:1";
+    #                                                                      real 4:4:0 / 4:1:1 frames: tests/test_sampling_layouts.py
     kw = dict(format="JPEG", quality=rnd.choice([5, 20, 50, 75, 90, 97, 100]), optimize=rnd.random() < 0.4, progressive=rnd.random() < 0.3)
     rng = np.random.default_rng(1000 + trial)
     base = rng.integers(0, 256, (max(2, h // 16), max(2, w // 16), 3), dtype=np.uint8)

@@ -1,0 +1,252 @@
+"""Frames and Huffman layers that libjpeg's front end (PIL) cannot be asked for, written in the coefficient domain by
+tests/jpeg_writer.py:
+
+ * sampling layouts -- 4:4:0, true 4:1:1 (factor 4: refused), every component with its own factors, chroma sampled finer
+   than luma, all components 2x2, one and two components, four components -- against the real reference binary (decision,
+   exit code, .lep bytes, restored bytes) and through the current kernel sources in the lane-loop emulation;
+ * legal-to-decode but non-canonical Huffman layers (ZRL + EOB, fill bytes before restart markers, mixed pad bits, a symbol
+   coded twice, restart markers out of step): the reference stops at errorlevel 1 / fails its round trip; here the host
+   parser must refuse them (UNSUPPORTED_JPEG) and the GPU scan decoder must hand them to the host parser;
+ * the Huffman half of the round-trip check (lep_jpeg_check_restores): 0 on every fixture, ROUNDTRIP_FAILURE where the
+   reference's own default run fails (images/roundtripfail.jpg, test_suite/test_roundtrip.sh; one component with factors
+   2x2 + restart markers), with the decode direction staying bug-compatible."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import jpeg_writer as jw
+import oracle_binding as ob
+from conftest import REF_IMAGES, ROOT, embedded_cases, golden, golden_cases, roundtrip_failure_cases, slice_cases
+from lepton_amd import abi
+from lepton_amd.codec import JpegImage, LepFile, LeptonError
+
+REF = os.path.join(ROOT, "oracle", "_ref", "lepton")
+needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="needs the reference binary (built where /root/reference exists)")
+
+
+def Y(h, v, i=1):
+    return (i, h, v, 0, 0, 0)
+
+
+def Cx(h, v, i):
+    return (i, h, v, 1, 1, 1)
+
+
+LAYOUTS = {
+    "440": [Y(1, 2), Cx(1, 1, 2), Cx(1, 1, 3)],
+    "411": [Y(4, 1), Cx(1, 1, 2), Cx(1, 1, 3)],            # SAMPLING_BEYOND_TWO_UNSUPPORTED
+    "v4": [Y(1, 4), Cx(1, 1, 2), Cx(1, 1, 3)],
+    "h3": [Y(3, 1), Cx(1, 1, 2), Cx(1, 1, 3)],
+    "mixed": [Y(2, 2), Cx(2, 1, 2), Cx(1, 1, 3)],
+    "mixed2": [Y(2, 2), Cx(1, 2, 2), Cx(2, 1, 3)],
+    "chromafine": [Y(1, 1), Cx(2, 2, 2), Cx(1, 1, 3)],
+    "chromafine2": [Y(1, 1), Cx(1, 2, 2), Cx(2, 1, 3)],
+    "all22": [Y(2, 2), Cx(2, 2, 2), Cx(2, 2, 3)],
+    "gray22": [Y(2, 2)],
+    "gray21": [Y(2, 1)],
+    "two": [Y(2, 1), Cx(1, 1, 2)],
+    "two22": [Y(2, 2), Cx(1, 1, 2)],
+    "cmyk": [Y(1, 1, 1), Y(1, 1, 2), Y(1, 1, 3), Y(1, 1, 4)],            # UNSUPPORTED_4_COLORS
+    "cmykmixed": [Y(2, 2, 1), Cx(1, 1, 2), Cx(1, 1, 3), Y(2, 2, 4)],
+    "ids": [Y(2, 2, 0), Cx(1, 1, 200), Cx(1, 1, 7)],
+}
+SAID = {b"UNSUPPORTED_4_COLORS": 4, b"SAMPLING_BEYOND_TWO_UNSUPPORTED": 10, b"SAMPLING_BEYOND_FOUR_UNSUPPORTED": 11}
+
+
+def oracle_compress(jpg):
+    img = JpegImage(jpg)
+    segs = img.plan()
+    streams, _ = ob.oracle_encode(img.desc, segs)
+    return img, img.write_lep(streams)
+
+
+@needs_ref
+@pytest.mark.parametrize("name", sorted(LAYOUTS))
+def test_layout_against_the_reference_binary(name, tmp_path):
+    comps = LAYOUTS[name]
+    jp, lp, bp = (str(tmp_path / n) for n in ("s.jpg", "s.lep", "s.back"))
+    # restart markers only where the reference can restore them (one component with factors > 1: see the round-trip test)
+    grey_sampled = len(comps) == 1 and comps[0][1] * comps[0][2] > 1
+    for w, h, ri in [(97, 50, 0), (33, 70, 0 if grey_sampled else 3), (8, 8, 0), (200, 333, 0), (640, 480, 0 if grey_sampled else 7)]:
+        jpg, _ = jw.write_baseline(w, h, comps, np.random.default_rng(zlib.crc32(("%s %d" % (name, w)).encode())), restart_interval=ri)
+        open(jp, "wb").write(jpg)
+        for f in (lp, bp):
+            if os.path.exists(f):
+                os.unlink(f)
+        r = subprocess.run([REF, "-unjailed", "-skipverify", jp, lp], capture_output=True)
+        said = [v for k, v in SAID.items() if k + b"\n" in r.stderr]   # the exit code itself is not reliable on error paths
+        ref_ok = r.returncode == 0 and os.path.exists(lp) and os.path.getsize(lp) > 0 and not said
+        try:
+            _, got = oracle_compress(jpg)
+            code = 0
+        except LeptonError as e:
+            got, code = None, e.code
+        assert (got is not None) == ref_ok, (name, w, h, code, r.returncode, said)
+        if not ref_ok:
+            assert said and code == said[0], (name, w, h, code, said)
+            continue
+        assert got == open(lp, "rb").read(), "%s %dx%d: .lep differs from the reference's" % (name, w, h)
+        assert subprocess.run([REF, "-unjailed", lp, bp], capture_output=True).returncode == 0
+        f = LepFile(got)
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        back = f.recode()
+        assert back == open(bp, "rb").read() and back == jpg, "%s %dx%d: restored file" % (name, w, h)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(ROOT, "tests", "emu", "libcore_emu_layouts.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "emu", "core_emu.cc")])
+    return C.CDLL(so)
+
+
+def gpu_scan_decode(emu, jpg):
+    """lep_jpeg_open_gpu + the scan decode kernel source in the emulation: 'host' (not eligible), ('irregular', status) or
+    ('ok', planes)"""
+    L = abi.lib()
+    h, img, ok = C.c_void_p(), abi.HuffDecImage(), C.c_int(0)
+    rc = L.lep_jpeg_open_gpu(jpg, len(jpg), C.byref(h), C.byref(img), C.byref(ok))
+    if rc:
+        return ("refused", rc)
+    try:
+        if not ok.value:
+            return ("host", 0)
+        p, n = C.c_void_p(), C.c_size_t(0)
+        L.lep_jpeg_scan_bytes(h, C.byref(p), C.byref(n))
+        scan = C.create_string_buffer(C.string_at(p, n.value) + b"\0" * 64, n.value + 64)
+        img.scan = C.addressof(scan)
+        d = abi.ImageDesc()
+        L.lep_jpeg_describe(h, C.byref(d))
+        planes = []
+        for c in range(d.ncomp):
+            b = C.create_string_buffer(d.nblocks(c) * 128)
+            planes.append(b)
+            img.blocks[c] = C.cast(b, C.c_void_p).value
+        rows = (abi.HuffDecRow * (img.mcuv + 1))()
+        assert emu.emu_huffman_decode_image(C.byref(img), rows) == 0
+        status = rows[img.mcuv].aux >> 8
+        if status:
+            return ("irregular", status)
+        assert L.lep_jpeg_finish_gpu(h, rows) == 0
+        return ("ok", [p.raw for p in planes])
+    finally:
+        L.lep_jpeg_close(h)
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(LAYOUTS) if n not in ("411", "v4", "h3", "cmyk", "cmykmixed")])
+def test_layout_through_the_kernel_sources(emu, name):
+    """coder kernels (v3 encoder, v4 decoder) and the Huffman scan decoder, lane-loop emulation, against the oracle / host parser"""
+    for w, h, ri in [(97, 50, 0), (33, 70, 0), (160, 120, 5)]:
+        if ri and len(LAYOUTS[name]) == 1:
+            ri = 0
+        jpg, _ = jw.write_baseline(w, h, LAYOUTS[name], np.random.default_rng(77 + w), restart_interval=ri, density=0.4)
+        img = JpegImage(jpg)
+        d, segs = img.desc, img.plan()
+        want, _ = ob.oracle_encode(d, segs)
+        orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+        for s, wv in zip(segs, want):
+            cap = len(wv) + 4096
+            b = C.create_string_buffer(cap)
+            n = C.c_uint32(0)
+            assert emu.emu_encode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, b, cap, C.byref(n), None) == 0
+            assert b.raw[: n.value] == wv, (name, w, h)
+        for c in range(d.ncomp):
+            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+        for s, wv in zip(segs, want):
+            assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
+        assert [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == orig, (name, w, h)
+        kind, planes = gpu_scan_decode(emu, jpg)
+        assert kind in ("ok", "host")
+        if len(LAYOUTS[name]) > 1:
+            assert kind == "ok", "an interleaved sequential scan must be eligible for the GPU decoder"
+            assert planes == orig, (name, w, h)
+
+
+QUIRKS = ["trailing_zrl", "rst_fill", "mixed_pad", "dup_symbol", "rst_order"]
+
+
+@pytest.mark.parametrize("quirk", QUIRKS)
+@pytest.mark.parametrize("pad", [0, 1])
+def test_non_canonical_huffman_layers_are_refused(emu, quirk, pad):
+    c420 = LAYOUTS["ids"]
+    clean, _ = jw.write_baseline(160, 96, c420, np.random.default_rng(4), restart_interval=4, pad_bit=pad)
+    JpegImage(clean)
+    assert gpu_scan_decode(emu, clean)[0] == "ok"
+    jpg, _ = jw.write_baseline(160, 96, c420, np.random.default_rng(4), restart_interval=4, pad_bit=pad, quirks=(quirk,))
+    assert jpg != clean
+    from PIL import Image
+    import io
+    Image.open(io.BytesIO(jpg)).load()                       # a decoder has no complaint
+    with pytest.raises(LeptonError) as e:
+        JpegImage(jpg)
+    assert e.value.code == 42                                # UNSUPPORTED_JPEG (errorlevel 1 -> jpgcoder.cc:2024)
+    kind, what = gpu_scan_decode(emu, jpg)
+    assert kind in ("host", "irregular", "refused"), "the GPU scan decoder accepted a scan the re-encoder cannot reproduce"
+
+
+@needs_ref
+@pytest.mark.parametrize("quirk", QUIRKS)
+def test_reference_writes_nothing_for_non_canonical_layers(quirk, tmp_path):
+    jp, lp = str(tmp_path / "q.jpg"), str(tmp_path / "q.lep")
+    jpg, _ = jw.write_baseline(160, 96, LAYOUTS["ids"], np.random.default_rng(4), restart_interval=4, quirks=(quirk,))
+    open(jp, "wb").write(jpg)
+    subprocess.run([REF, "-unjailed", jp, lp], capture_output=True)   # default run (verification on)
+    assert not os.path.exists(lp) or os.path.getsize(lp) == 0
+
+
+def check_restores(jpg, **kw):
+    img = JpegImage(jpg, **kw)
+    segs = img.plan()
+    streams, _ = ob.oracle_encode(img.desc, segs)
+    lep = img.write_lep(streams)
+    want = img.data if kw.get("embedding") else img.data[kw.get("start_byte", 0):]
+    return abi.lib().lep_jpeg_check_restores(img.handle, lep, len(lep), want, len(want))
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_round_trip_check_passes_every_fixture(name):
+    assert check_restores(golden(name)[0]) == 0
+
+
+def test_round_trip_check_passes_slices_and_embedded_files():
+    for name, start, trunc in slice_cases():
+        assert check_restores(golden(name)[0], start_byte=start, trunc=trunc) == 0, name
+    for name, off in embedded_cases():
+        assert check_restores(golden(name)[0], embedding=off) == 0, name
+
+
+@pytest.mark.parametrize("name,restored_md5", roundtrip_failure_cases())
+def test_round_trip_failure_is_reported_and_decode_stays_compatible(name, restored_md5):
+    """what `lepton` (verification on) answers with exit 41: compression refused; the -skipverify .lep of the reference is
+    still equal to ours and decodes to the bytes the reference makes of it"""
+    jpg, lep = golden(name)
+    img, got = oracle_compress(jpg)
+    assert got == lep
+    assert abi.lib().lep_jpeg_check_restores(img.handle, got, len(got), jpg, len(jpg)) == 41
+    f = LepFile(lep)
+    ob.oracle_decode(f.desc, f.segments, f.streams)
+    back = f.recode()
+    assert back != jpg and hashlib.md5(back).hexdigest() == restored_md5
+    # a corrupted expectation is a failure too, a foreign .lep is reported with its own code
+    ok, _ = golden("c420_160x120")
+    assert check_restores(ok) == 0
+    img2 = JpegImage(ok)
+    assert abi.lib().lep_jpeg_check_restores(img2.handle, lep, len(lep), ok, len(ok)) == 41
+    assert abi.lib().lep_jpeg_check_restores(img2.handle, b"junk", 4, ok, len(ok)) != 0
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_IMAGES), reason="reference checkout not present (GPU box)")
+def test_reference_roundtripfail_image():
+    """test_suite/test_roundtrip.sh: `lepton -verify` must fail on images/roundtripfail.jpg, `-skipverify` must succeed"""
+    jpg = open(os.path.join(REF_IMAGES, "roundtripfail.jpg"), "rb").read()
+    assert check_restores(jpg) == 41
+    _, lep = oracle_compress(jpg)                           # -skipverify: a .lep is written ...
+    if os.path.exists(REF):
+        out = "/tmp/_rtf.lep"
+        subprocess.run([REF, "-unjailed", "-skipverify", os.path.join(REF_IMAGES, "roundtripfail.jpg"), out], capture_output=True)
+        assert lep == open(out, "rb").read()                # ... the reference's
