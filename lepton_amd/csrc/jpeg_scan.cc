@@ -630,6 +630,9 @@ int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows) {
     }
     for (size_t i = 1; i < jf->rows.size(); ++i)
         if (jf->rows[i].luma_y_start < jf->rows[i - 1].luma_y_end) jf->rows[i].luma_y_start = jf->rows[i - 1].luma_y_end;
+    // entropy-coded bytes left over behind the last MCU and its padding ("unneeded data found after coded image data",
+    // jpgcoder.cc:3290): the host parser refuses the file as the reference does
+    if (rows[mcuv].bitpos != total_bits) return -1;
     jf->padbit = (int8_t)(rows[mcuv].aux & 255);
     jf->scan_count = 1;
     jf->max_bpos = std::max(jf->max_bpos, jf->cs_to);

@@ -124,7 +124,8 @@ def write_baseline(width, height, comps, rng, restart_interval=0, quality=85, de
       "rst_fill"      an extra 0xFF fill byte in front of every restart marker (T.81 B.1.1.2)
       "mixed_pad"     pad bits alternate between all-ones and all-zeros from one restart interval to the next
       "dup_symbol"    the AC tables code symbol 0x01 twice (the unused 0xFA's code is reassigned); every other use takes the long one
-      "rst_order"     restart markers count 0, 2, 4 ... instead of 0, 1, 2 ..."""
+      "rst_order"     restart markers count 0, 2, 4 ... instead of 0, 1, 2 ...
+      "scan_tail"     two more entropy-coded bytes after the last MCU ("unneeded data found after coded image data")"""
     dqt, dht = annex_k_tables(quality)
     if "dup_symbol" in quirks:
         dht = dict(dht)
@@ -229,5 +230,7 @@ def write_baseline(width, height, comps, rng, restart_interval=0, quality=85, de
             rst += 1
             pred = [0] * len(comps)
     bw_.flush(pad_bit)
+    if "scan_tail" in quirks:
+        bw_.out += b"\x12\x34"
     out += bw_.out + b"\xff\xd9"
     return bytes(out), blocks

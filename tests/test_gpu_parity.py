@@ -256,7 +256,7 @@ def test_gpu_batch_pipeline_verifies_on_the_gpu(gpu_codec):
 def test_gpu_round_trip_failures_and_non_canonical_scans_are_refused(gpu_codec):
     """the reference's default run (verification on) on files it cannot restore: exit 41 -- here lep_compress refuses them, and
     lep_compress_batch with verify=1 does (without verification the .lep is the reference's -skipverify one, and decodes to
-    the same wrong bytes); legal but non-canonical Huffman layers (ZRL + EOB, mixed pad bits: given up by the GPU scan
+    the same wrong bytes); legal but non-canonical Huffman layers (ZRL + EOB, mixed pad bits, bytes left over behind the last MCU: given up by the GPU scan
     decoder, refused by the host parser it falls back to) end in UNSUPPORTED_JPEG; their neighbours in the batch are untouched"""
     import hashlib
     import numpy as np
@@ -271,7 +271,7 @@ def test_gpu_round_trip_failures_and_non_canonical_scans_are_refused(gpu_codec):
     assert e.value.code == 41
     assert hashlib.md5(gpu_codec.decompress(bad_lep)).hexdigest() == restored_md5
     comps = [(0, 2, 2, 0, 0, 0), (200, 1, 1, 1, 1, 1), (7, 1, 1, 1, 1, 1)]
-    quirky = [jw.write_baseline(160, 96, comps, np.random.default_rng(4), restart_interval=4, quirks=(q,))[0] for q in ("trailing_zrl", "mixed_pad", "rst_fill")]
+    quirky = [jw.write_baseline(160, 96, comps, np.random.default_rng(4), restart_interval=4, quirks=(q,))[0] for q in ("trailing_zrl", "mixed_pad", "scan_tail")]
     good = [golden("lay_mixed_200x120"), golden("c420_160x120"), golden("lay_gray22_80x56")]
     jpgs = [good[0][0], bad, quirky[0], good[1][0], quirky[1], quirky[2], good[2][0]]
     for verify in (True, False):
