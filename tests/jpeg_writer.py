@@ -115,7 +115,7 @@ def random_blocks(rng, n, density=0.25, amp=40.0, dc_step=30.0, max_ac=1023):
 
 
 def write_baseline(width, height, comps, rng, restart_interval=0, quality=85, density=0.25, amp=40.0, pad_bit=1, blocks=None,
-                   extra_segments=(), quirks=()):
+                   extra_segments=(), quirks=(), sof=0xC0, precision=8, dqt16=False):
     """comps: [(component id, h, v, quant table id, dc table id, ac table id)], one interleaved scan (one component: the
     non-interleaved geometry of T.81 A.2.2).  Returns (jpeg bytes, per-component [rows][cols] zig-zag block arrays).
 
@@ -170,8 +170,11 @@ def write_baseline(width, height, comps, rng, restart_interval=0, quality=85, de
     for marker, payload in extra_segments:
         out += bytes([0xFF, marker]) + struct.pack(">H", len(payload) + 2) + payload
     for tq in sorted({c[3] for c in comps}):
-        out += b"\xff\xdb" + struct.pack(">H", 67) + bytes([tq]) + dqt[tq]
-    out += b"\xff\xc0" + struct.pack(">HBHHB", 8 + 3 * len(comps), 8, height, width, len(comps))
+        if dqt16:   # Pq = 1: sixteen-bit entries (some above 255)
+            out += b"\xff\xdb" + struct.pack(">H", 131) + bytes([0x10 | tq]) + b"".join(struct.pack(">H", q * (3 if i > 40 else 1)) for i, q in enumerate(dqt[tq]))
+        else:
+            out += b"\xff\xdb" + struct.pack(">H", 67) + bytes([tq]) + dqt[tq]
+    out += bytes([0xFF, sof]) + struct.pack(">HBHHB", 8 + 3 * len(comps), precision, height, width, len(comps))
     for c in comps:
         out += bytes([c[0], (c[1] << 4) | c[2], c[3]])
     for key in sorted({(0, c[4]) for c in comps} | {(1, c[5]) for c in comps}):

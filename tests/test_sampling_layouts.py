@@ -251,3 +251,182 @@ def test_reference_roundtripfail_image():
         out = "/tmp/_rtf.lep"
         subprocess.run([REF, "-unjailed", "-skipverify", os.path.join(REF_IMAGES, "roundtripfail.jpg"), out], capture_output=True)
         assert lep == open(out, "rb").read()                # ... the reference's
+
+
+@needs_ref
+@pytest.mark.parametrize("kw", [dict(dqt16=True), dict(sof=0xC1), dict(sof=0xC1, dqt16=True), dict(precision=12), dict(sof=0xC1, precision=12),
+                                dict(sof=0xC3), dict(sof=0xC5), dict(sof=0xC9)], ids=lambda k: "-".join("%s=%s" % i for i in sorted(k.items())))
+def test_frame_header_variants_against_the_reference_binary(kw, tmp_path):
+    """sixteen-bit quantisation tables and SOF1 (extended sequential) frames are coded like baseline ones; twelve-bit
+    precision, lossless, differential and arithmetic frames are UNSUPPORTED_JPEG -- as in the reference"""
+    jp, lp = str(tmp_path / "v.jpg"), str(tmp_path / "v.lep")
+    jpg, _ = jw.write_baseline(160, 96, LAYOUTS["ids"], np.random.default_rng(4), **kw)
+    open(jp, "wb").write(jpg)
+    r = subprocess.run([REF, "-unjailed", "-skipverify", jp, lp], capture_output=True)
+    ref_ok = os.path.exists(lp) and os.path.getsize(lp) > 0
+    try:
+        img, got = oracle_compress(jpg)
+    except LeptonError as e:
+        assert not ref_ok and e.code == 42 and b"UNSUPPORTED_JPEG\n" in r.stderr
+        return
+    assert ref_ok and got == open(lp, "rb").read()
+    assert abi.lib().lep_jpeg_check_restores(img.handle, got, len(got), jpg, len(jpg)) == 0
+
+
+def _random_layout_jpeg(rnd, trial):
+    ncomp = rnd.choice([1, 2, 3, 3, 3, 3])
+    f = lambda: rnd.choice([1, 1, 2, 2, 2, 3, 4]) if rnd.random() < 0.08 else rnd.choice([1, 2])
+    comps = [((i + 1) if rnd.random() < 0.8 else rnd.randrange(256), f(), f(), min(i, 1), min(i, 1), min(i, 1)) for i in range(ncomp)]
+    if len({c[0] for c in comps}) < ncomp:
+        comps = [(i + 1,) + c[1:] for i, c in enumerate(comps)]
+    w, h = rnd.choice([8, 15, 16, 17, 31, 64, 97, 160, 333, 640]), rnd.choice([8, 9, 16, 23, 48, 99, 240, 480])
+    ri = rnd.choice([0, 0, 0, 1, 2, 3, 7, 50])
+    if ncomp == 1 and comps[0][1] * comps[0][2] > 1:
+        ri = 0                                                                        # see the round-trip-failure fixture
+    jpg, _ = jw.write_baseline(w, h, comps, np.random.default_rng(3000 + trial), restart_interval=ri, quality=rnd.choice([30, 75, 95]),
+                               density=rnd.choice([0.02, 0.1, 0.25, 0.6, 1.0]), amp=rnd.choice([2.0, 10.0, 40.0, 200.0]), pad_bit=rnd.choice([0, 1, 1]),
+                               dqt16=rnd.random() < 0.1, sof=0xC1 if rnd.random() < 0.1 else 0xC0)
+    tail = rnd.random()
+    if tail < 0.1:
+        jpg += bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 300)))
+    elif tail < 0.25:
+        jpg = jpg[: rnd.randint(len(jpg) // 3, len(jpg) - 1)]
+    return jpg
+
+
+def sweep_against_the_reference(trials, seed, tmp):
+    import random
+
+    rnd = random.Random(seed)
+    jp, lp, bp = (os.path.join(tmp, n) for n in ("s.jpg", "s.lep", "s.back"))
+    accepted = rejected = 0
+    codes = dict(SAID)
+    codes.update({b"THREADING_PARTIAL_MCU": 12, b"ONLY_GARBAGE_NO_JPEG": 14, b"UNSUPPORTED_JPEG": 42, b"COEFFICIENT_OUT_OF_RANGE": 6,
+                  b"UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0": 43})
+    for trial in range(trials):
+        jpg = _random_layout_jpeg(rnd, trial)
+        open(jp, "wb").write(jpg)
+        for f in (lp, bp):
+            if os.path.exists(f):
+                os.unlink(f)
+        r = subprocess.run([REF, "-unjailed", "-skipverify", jp, lp], capture_output=True)
+        said = [v for k, v in codes.items() if k + b"\n" in r.stderr]
+        ref_ok = r.returncode == 0 and os.path.exists(lp) and os.path.getsize(lp) > 0 and not said
+        try:
+            img, got = oracle_compress(jpg)
+            code = 0
+        except LeptonError as e:
+            got, code = None, e.code
+        except RuntimeError as e:                                  # the coder itself: "oracle encode exit code 6"
+            got, code = None, int(str(e).split()[-1])
+        assert (got is not None) == ref_ok, (trial, code, r.returncode, said)
+        if not ref_ok:
+            rejected += 1
+            if said:
+                assert code == said[0], (trial, code, said)
+            continue
+        accepted += 1
+        assert got == open(lp, "rb").read(), "trial %d: .lep differs from the reference's" % trial
+        assert subprocess.run([REF, "-unjailed", lp, bp], capture_output=True).returncode == 0
+        f = LepFile(got)
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        back = f.recode()
+        assert back == open(bp, "rb").read(), "trial %d: restored file differs from the reference's" % trial
+        # the round-trip check says exactly whether the reference restored its input
+        assert (abi.lib().lep_jpeg_check_restores(img.handle, got, len(got), jpg, len(jpg)) == 0) == (back == jpg), trial
+    return accepted, rejected
+
+
+@needs_ref
+def test_random_layouts_against_the_reference_binary(tmp_path):
+    """seeded random frames from the coefficient-domain writer -- 1..3 components, factors 1..2 (now and then 3 or 4: refused),
+    random component ids, one block up to 640x480, restart intervals, sparse to dense blocks, small to large amplitudes, both
+    pad bits, sixteen-bit tables, SOF1, trailing garbage, truncation: same decision and exit code, same .lep bytes, same
+    restored bytes as the reference binary (600 cases by hand, 40 here)"""
+    accepted, rejected = sweep_against_the_reference(40, 20260924, str(tmp_path))
+    assert accepted >= 20 and rejected >= 2
+
+
+def sweep_through_the_kernel_sources(emu, trials, seed):
+    """the same random frames through the device code in the lane-loop emulation: coder kernels (v3 encoder / v4 decoder) against
+    the oracle, the Huffman scan decoder against the host parser, the Huffman re-encoder against the input bytes"""
+    import random
+
+    rnd = random.Random(seed)
+    L = abi.lib()
+    stats = dict(coded=0, scan_decoded=0, reencoded=0)
+    for trial in range(trials):
+        jpg = _random_layout_jpeg(rnd, trial)
+        try:
+            img = JpegImage(jpg)
+            d, segs = img.desc, img.plan()
+            want, _ = ob.oracle_encode(d, segs)
+        except (LeptonError, RuntimeError):
+            continue
+        orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+        for s_, wv in zip(segs, want):
+            cap = len(wv) + 4096
+            b = C.create_string_buffer(cap)
+            n = C.c_uint32(0)
+            assert emu.emu_encode_segment_v3(C.byref(d), s_.luma_y_start, s_.luma_y_end, s_.is_last, b, cap, C.byref(n), None) == 0
+            assert b.raw[: n.value] == wv, trial
+        for c in range(d.ncomp):
+            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+        for s_, wv in zip(segs, want):
+            assert emu.emu_decode_segment_v4(C.byref(d), s_.luma_y_start, s_.luma_y_end, s_.is_last, wv, len(wv), None) == 0
+        got = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+        for c in range(d.ncomp):                                  # what the oracle's decoder leaves (truncated files: coded blocks only)
+            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+        ob.oracle_decode(d, segs, want)
+        assert got == [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)], trial
+        stats["coded"] += 1
+        kind, planes = gpu_scan_decode(emu, jpg)
+        assert kind in ("ok", "host", "irregular"), (trial, kind, planes)
+        if kind == "ok":
+            assert planes == orig, trial
+            stats["scan_decoded"] += 1
+        # re-encode: the frame the JPEG itself holds, the header of the .lep
+        lep = img.write_lep(want)
+        f = LepFile(lep)
+        for c in range(f.desc.ncomp):
+            C.memmove(f.desc.blocks[c], orig[c], f.desc.nblocks(c) * 128)
+        host = f.recode()
+        himg = abi.HuffImage()
+        hsegs = (abi.HuffSegment * abi.MAX_SEGMENTS)()
+        nseg, ok = C.c_int(0), C.c_int(0)
+        assert L.lep_file_recode_plan(f.handle, C.byref(himg), hsegs, C.byref(nseg), C.byref(ok)) == 0
+        if not ok.value:
+            continue
+        outs = (abi.Bytes * nseg.value)()
+        keep = []
+        for i in range(nseg.value):
+            cap = min(hsegs[i].out_cap, len(jpg) + 1024)
+            hsegs[i].out_cap = cap
+            buf = C.create_string_buffer(cap + 8)
+            keep.append(buf)
+            n = C.c_uint32(0)
+            assert emu.emu_huffman_encode_segment(C.byref(himg), C.byref(hsegs[i]), buf, C.byref(n)) == 0
+            outs[i].data = C.cast(buf, C.c_void_p).value
+            outs[i].len = outs[i].cap = n.value
+        out = abi.Bytes()
+        assert L.lep_file_recode_finish(f.handle, outs, nseg.value, C.byref(out)) == 0
+        assert out.tobytes() == host, trial
+        L.lep_free(out.data)
+        stats["reencoded"] += 1
+    return stats
+
+
+def test_random_layouts_through_the_kernel_sources(emu):
+    """(400 cases by hand, 40 here)"""
+    st = sweep_through_the_kernel_sources(emu, 40, 20260925)
+    assert st["coded"] >= 25 and st["scan_decoded"] >= 12 and st["reencoded"] >= 12, st
+
+
+if __name__ == "__main__":   # python tests/test_sampling_layouts.py <trials> <seed>: the sweep by hand
+    import sys
+    import tempfile
+
+    if len(sys.argv) > 3 and sys.argv[3] == "kernels":
+        print(sweep_through_the_kernel_sources(C.CDLL(os.path.join(ROOT, "tests", "emu", "libcore_emu_layouts.so")), int(sys.argv[1]), int(sys.argv[2])))
+    else:
+        print(sweep_against_the_reference(int(sys.argv[1]), int(sys.argv[2]), tempfile.mkdtemp()))
