@@ -345,8 +345,38 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
             int sta = 0, rstw = jf.rsti;
             unsigned eobrun = 0;
             auto dc_of = [&](int c, int d) -> int { return jf.plane[c][(size_t)d * 64 + kZigzagToAligned[0]]; };
-            if (jf.cs_cmpc > 1) {
-                if (jf.jpegtype == 1) return EX_CODING_ERROR;   // 'X' files with interleaved sequential scans of a component subset: not handled
+            // one whole block of component cmp at dpos, sequential coding (encode_block_seq, jpgcoder.cc:5009-5066)
+            auto sequential_block = [&]() {
+                const int16_t* src = jf.plane[cmp] + (size_t)dpos * 64;
+                for (int b = 0; b < 64; ++b) blk[b] = src[kZigzagToAligned[b]];
+                const int16_t dc = blk[0];
+                blk[0] = (int16_t)(blk[0] - lastdc[cmp]);
+                lastdc[cmp] = dc;
+                const HuffTable& dct = jf.htab[0][jf.comp[cmp].dc_tbl];
+                const HuffTable& act = jf.htab[1][jf.comp[cmp].ac_tbl];
+                int t = blk[0], s = blen16((unsigned)(t > 0 ? t : -t) & 0xffff);
+                sw.code(dct, s); sw.put(envli(s, t), s);
+                int end = 63, z = 0;
+                while (end && !blk[end]) --end;
+                for (int b = 1; b <= end; ++b) {
+                    t = blk[b];
+                    if (!t) { ++z; continue; }
+                    s = blen16((unsigned)(t > 0 ? t : -t) & 0xffff);
+                    while (z & 0xf0) { sw.code(act, 0xF0); z -= 16; }
+                    sw.code(act, ((z & 0xf) << 4) + s);
+                    sw.put(envli(s, t), s);
+                    z = 0;
+                }
+                if (end != 63) sw.code(act, 0);
+            };
+            if (jf.cs_cmpc > 1 && jf.jpegtype == 1) {
+                // sequential multi-scan file, this scan interleaves several components (e.g. luma alone, then Cb + Cr together;
+                // recode_jpeg's sequential MCU loop, jpgcoder.cc:3461-3486)
+                while (sta == 0) {
+                    sequential_block();
+                    sta = next_mcupos(jf, &mcu, &cmp, &csc, &sub, &dpos, &rstw, jf.cs_cmpc);
+                }
+            } else if (jf.cs_cmpc > 1) {
                 if (jf.cs_sah == 0) {
                     while (sta == 0) {
                         const int tmp = dc_of(cmp, dpos) >> sal;
@@ -365,27 +395,7 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
                 }
             } else if (jf.jpegtype == 1) {
                 while (sta == 0) {   // sequential, one component per scan
-                    const int16_t* src = jf.plane[cmp] + (size_t)dpos * 64;
-                    for (int b = 0; b < 64; ++b) blk[b] = src[kZigzagToAligned[b]];
-                    const int16_t dc = blk[0];
-                    blk[0] = (int16_t)(blk[0] - lastdc[cmp]);
-                    lastdc[cmp] = dc;
-                    const HuffTable& dct = jf.htab[0][jf.comp[cmp].dc_tbl];
-                    const HuffTable& act = jf.htab[1][jf.comp[cmp].ac_tbl];
-                    int t = blk[0], s = blen16((unsigned)(t > 0 ? t : -t) & 0xffff);
-                    sw.code(dct, s); sw.put(envli(s, t), s);
-                    int end = 63, z = 0;
-                    while (end && !blk[end]) --end;
-                    for (int b = 1; b <= end; ++b) {
-                        t = blk[b];
-                        if (!t) { ++z; continue; }
-                        s = blen16((unsigned)(t > 0 ? t : -t) & 0xffff);
-                        while (z & 0xf0) { sw.code(act, 0xF0); z -= 16; }
-                        sw.code(act, ((z & 0xf) << 4) + s);
-                        sw.put(envli(s, t), s);
-                        z = 0;
-                    }
-                    if (end != 63) sw.code(act, 0);
+                    sequential_block();
                     sta = next_mcuposn(jf, cmp, &dpos, &rstw);
                 }
             } else if (to == 0) {

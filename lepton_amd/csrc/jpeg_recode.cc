@@ -233,7 +233,7 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
     JpegFile& jf = lf->jpeg;
     // 'Z' and 'Y' (a -startbyte slice) take the baseline re-coder, 'X' the general one: read_fixed_ujpg_header tests
     // header[1] == 'Z' || (header[1] & 1) == ('Y' & 1), jpgcoder.cc:2162-2166
-    if (lf->flag != 'Z' && lf->flag != 'Y') return recode_progressive(lf, result);
+    if (!(lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1))) return recode_progressive(lf, result);
     const size_t max_file_size = lf->jpeg_size;
     if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
     BoundedOut out;

@@ -307,8 +307,10 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
     lf->flag = d[3];
     lf->nthreads = d[4];
     if (lf->version != 1) return EX_VERSION_UNSUPPORTED;   // v2+ (brotli header) is not produced by the default encoder
+    if (lf->nthreads == 0) return EX_ASSERTION_FAILURE;    // always_assert(num_threads_hint != 0), jpgcoder.cc:2168
     lf->jpeg_size = get_le32(d + 20);
     uint32_t zsize = get_le32(d + 24);
+    if (zsize > (128u << 20) || lf->jpeg_size > (128u << 20)) return EX_ASSERTION_FAILURE;   // "Only support images < 128 megs" (jpgcoder.cc:4133-4136)
     if (28 + (uint64_t)zsize + 3 > n) return EX_SHORT_READ;
     std::vector<uint8_t> p;
     if (!unzlib(d + 28, zsize, &p)) return EX_STREAM_INCONSISTENT;
@@ -390,6 +392,10 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
         for (unsigned i = 0; i + 1 < mark; ++i, at += 2) lf->segs[i].luma_y_end = (uint16_t)(d[at] | (d[at + 1] << 8));
         for (unsigned i = 1; i < mark; ++i) lf->segs[i].luma_y_start = lf->segs[i - 1].luma_y_end;
     }
+    // the decoder runs min(thread hint, MAX_NUM_THREADS = 8) physical threads (one, for a pre-hand-off file: recoder.cc:731-733);
+    // one without a hand-off of its own trips always_assert(logical_thread_start < thread_handoffs.size()) (recoder.cc:547-578)
+    const bool baseline_recoder = lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1);   // jpgcoder.cc:2162; the general re-coder is single-threaded
+    if (baseline_recoder && lf->segs[0].num_overhang_bits != 0xff && (size_t)std::min(lf->nthreads, 8) > lf->segs.size()) return EX_ASSERTION_FAILURE;
     demux_packets(d, n, at, &lf->streams);
     return 0;
 }

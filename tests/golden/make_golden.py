@@ -81,6 +81,11 @@ CASES = {
     "lay_ids_pad0_64x64": lambda: layout(64, 64, [Y(2, 2, 0), CB(1, 1, 200), CR(1, 1, 7)], 208, pad_bit=0, restart_interval=4),
     "lay_440_640x480_2seg": lambda: layout(640, 480, [Y(1, 2), CB(1, 1), CR(1, 1)], 209, restart_interval=7),   # 170 kB of scan: two thread segments
 }
+# sequential frames coded in several scans, one of them interleaving a subset of the components ('X' files, general re-coder)
+CASES.update({
+    "seq_y_cbcr_420_rst_97x50": lambda: jpeg_writer.write_sequential_scans(97, 50, [Y(2, 2), CB(1, 1), CR(1, 1)], __import__("numpy").random.default_rng(211), [[0], [1, 2]], restart_interval=5)[0],
+    "seq_ycb_cr_422_640x480_2seg": lambda: jpeg_writer.write_sequential_scans(640, 480, [Y(2, 1), CB(1, 1), CR(1, 1)], __import__("numpy").random.default_rng(212), [[0, 1], [2]])[0],
+})
 # Files the reference compresses with -skipverify but cannot restore (its default run ends in ROUNDTRIP_FAILURE, exit 41;
 # test_suite/test_roundtrip.sh does the same with images/roundtripfail.jpg): the .lep is the -skipverify one, restored_md5 what
 # the reference makes of it.  We must refuse the compression with 41 and decode the .lep to the same wrong bytes.

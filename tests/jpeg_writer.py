@@ -115,9 +115,13 @@ def random_blocks(rng, n, density=0.25, amp=40.0, dc_step=30.0, max_ac=1023):
 
 
 def write_baseline(width, height, comps, rng, restart_interval=0, quality=85, density=0.25, amp=40.0, pad_bit=1, blocks=None,
-                   extra_segments=(), quirks=(), sof=0xC0, precision=8, dqt16=False):
+                   extra_segments=(), quirks=(), sof=0xC0, precision=8, dqt16=False, scans=None):
     """comps: [(component id, h, v, quant table id, dc table id, ac table id)], one interleaved scan (one component: the
     non-interleaved geometry of T.81 A.2.2).  Returns (jpeg bytes, per-component [rows][cols] zig-zag block arrays).
+
+    scans: None = one scan of all components; else a list of component-index lists, e.g. [[0], [1, 2]] -- a sequential
+    multi-scan file (a one-component scan is non-interleaved, T.81 A.2.2: only the blocks that cover the image are coded; the
+    frame needs more than one component).
 
     quirks: legal-to-decode but non-canonical Huffman layers, which a decode -> re-encode cannot reproduce unless it notices:
       "trailing_zrl"  every third block that ends before coefficient 47 codes ZRL + EOB instead of EOB
@@ -236,4 +240,84 @@ def write_baseline(width, height, comps, rng, restart_interval=0, quality=85, de
     if "scan_tail" in quirks:
         bw_.out += b"\x12\x34"
     out += bw_.out + b"\xff\xd9"
+    return bytes(out), blocks
+
+
+def _put_block(bw, blk, pred, dc, ac):
+    """one block, sequential Huffman coding (T.81 F.1.2); returns the new DC predictor"""
+    s, extra = _magnitude(int(blk[0]) - pred)
+    bw.put(*dc[s])
+    if s:
+        bw.put(extra, s)
+    run = 0
+    last = max([k for k in range(1, 64) if blk[k]], default=0)
+    for k in range(1, last + 1):
+        v = int(blk[k])
+        if not v:
+            run += 1
+            continue
+        while run > 15:
+            bw.put(*ac[0xF0])
+            run -= 16
+        s, extra = _magnitude(v)
+        bw.put(*ac[(run << 4) | s])
+        bw.put(extra, s)
+        run = 0
+    if last < 63:
+        bw.put(*ac[0x00])
+    return int(blk[0])
+
+
+def write_sequential_scans(width, height, comps, rng, scans, restart_interval=0, quality=85, density=0.25, amp=40.0):
+    """A sequential (SOF0) frame coded in SEVERAL scans, e.g. scans=[[0], [1, 2]]: luma alone, then the chroma components
+    interleaved -- what `jpegtran -scans` writes for non-progressive multi-scan files.  A one-component scan is
+    non-interleaved (T.81 A.2.2: only the blocks covering the image are coded, MCU = one block, the restart interval counts
+    blocks); the frame geometry is the interleaved one.  Returns (jpeg bytes, per-component block arrays)."""
+    dqt, dht = annex_k_tables(quality)
+    hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
+    mcux, mcuy = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    dims = [(mcux * c[1], mcuy * c[2]) for c in comps]
+    blocks = [random_blocks(rng, bw * bh, density, amp).reshape(bh, bw, 64) for bw, bh in dims]
+    out = bytearray(b"\xff\xd8")
+    for tq in sorted({c[3] for c in comps}):
+        out += b"\xff\xdb" + struct.pack(">H", 67) + bytes([tq]) + dqt[tq]
+    out += b"\xff\xc0" + struct.pack(">HBHHB", 8 + 3 * len(comps), 8, height, width, len(comps))
+    for c in comps:
+        out += bytes([c[0], (c[1] << 4) | c[2], c[3]])
+    for key in sorted({(0, c[4]) for c in comps} | {(1, c[5]) for c in comps}):
+        bits, vals = dht[key]
+        out += b"\xff\xc4" + struct.pack(">H", 19 + len(vals)) + bytes([(key[0] << 4) | key[1]]) + bytes(bits) + bytes(vals)
+    if restart_interval:
+        out += b"\xff\xdd" + struct.pack(">HH", 4, restart_interval)
+    for scan in scans:
+        out += b"\xff\xda" + struct.pack(">HB", 6 + 2 * len(scan), len(scan))
+        for ci in scan:
+            out += bytes([comps[ci][0], (comps[ci][4] << 4) | comps[ci][5]])
+        out += b"\x00\x3f\x00"
+        bw = _Bits()
+        pred = {ci: 0 for ci in scan}
+        enc = {ci: (_codes(*dht[(0, comps[ci][4])]), _codes(*dht[(1, comps[ci][5])])) for ci in scan}
+        units = []   # one entry per MCU: [(ci, row, col)]
+        if len(scan) == 1:
+            ci = scan[0]
+            bw_c = -(-(-(-width * comps[ci][1] // hmax)) // 8)
+            bh_c = -(-(-(-height * comps[ci][2] // vmax)) // 8)
+            units = [[(ci, r, c)] for r in range(bh_c) for c in range(bw_c)]
+        else:
+            for my in range(mcuy):
+                for mx in range(mcux):
+                    units.append([(ci, my * comps[ci][2] + by, mx * comps[ci][1] + bx)
+                                  for ci in scan for by in range(comps[ci][2]) for bx in range(comps[ci][1])])
+        rst = 0
+        for m, unit in enumerate(units):
+            for ci, r, c in unit:
+                pred[ci] = _put_block(bw, blocks[ci][r][c], pred[ci], *enc[ci])
+            if restart_interval and (m + 1) % restart_interval == 0 and m + 1 < len(units):
+                bw.flush(1)
+                bw.marker(0xD0 + (rst & 7))
+                rst += 1
+                pred = {ci: 0 for ci in scan}
+        bw.flush(1)
+        out += bw.out
+    out += b"\xff\xd9"
     return bytes(out), blocks

@@ -430,3 +430,36 @@ if __name__ == "__main__":   # python tests/test_sampling_layouts.py <trials> <s
         print(sweep_through_the_kernel_sources(C.CDLL(os.path.join(ROOT, "tests", "emu", "libcore_emu_layouts.so")), int(sys.argv[1]), int(sys.argv[2])))
     else:
         print(sweep_against_the_reference(int(sys.argv[1]), int(sys.argv[2]), tempfile.mkdtemp()))
+
+
+SCAN_SCRIPTS = {
+    "y_cbcr_420": ([Y(2, 2), Cx(1, 1, 2), Cx(1, 1, 3)], [[0], [1, 2]]),
+    "y_cb_cr_444": ([Y(1, 1), Cx(1, 1, 2), Cx(1, 1, 3)], [[0], [1], [2]]),
+    "ycb_cr_422": ([Y(2, 1), Cx(1, 1, 2), Cx(1, 1, 3)], [[0, 1], [2]]),
+    "cbcr_y_420": ([Y(2, 2), Cx(1, 1, 2), Cx(1, 1, 3)], [[1, 2], [0]]),
+    "y_cbcr_440": ([Y(1, 2), Cx(1, 1, 2), Cx(1, 1, 3)], [[0], [1, 2]]),
+    "y_cbcr_mixed": ([Y(2, 2), Cx(2, 1, 2), Cx(1, 2, 3)], [[0], [1, 2]]),
+}
+
+
+@needs_ref
+@pytest.mark.parametrize("name", sorted(SCAN_SCRIPTS))
+def test_sequential_multi_scan_files_against_the_reference_binary(name, tmp_path):
+    """non-progressive frames coded in several scans (luma alone, then Cb + Cr interleaved, ...): format flag 'X', the general
+    re-coder with a sequential MCU loop over the scan's component subset -- same .lep as the reference, which restores its input from it, and so do we, several thread segments included"""
+    comps, scans = SCAN_SCRIPTS[name]
+    jp, lp = str(tmp_path / "m.jpg"), str(tmp_path / "m.lep")
+    for w, h, ri in [(97, 50, 0), (96, 64, 5), (640, 480, 0), (640, 480, 5)]:
+        jpg, _ = jw.write_sequential_scans(w, h, comps, np.random.default_rng(8), scans, restart_interval=ri)
+        open(jp, "wb").write(jpg)
+        if os.path.exists(lp):
+            os.unlink(lp)
+        bp = jp + ".back"
+        assert subprocess.run([REF, "-unjailed", "-skipverify", jp, lp], capture_output=True).returncode == 0
+        assert subprocess.run([REF, "-unjailed", lp, bp], capture_output=True).returncode == 0 and open(bp, "rb").read() == jpg
+        img, got = oracle_compress(jpg)
+        assert got[3:4] == b"X" and got == open(lp, "rb").read(), (name, w, h, ri)
+        assert abi.lib().lep_jpeg_check_restores(img.handle, got, len(got), jpg, len(jpg)) == 0
+        f = LepFile(got)
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        assert f.recode() == jpg, (name, w, h, ri)
