@@ -236,6 +236,9 @@ typedef struct lep_handoff {           /* ThreadHandoff, src/lepton/thread_hando
 /* 'H', n, then n 16-byte records (ThreadHandoff::serialize / deserialize, thread_handoff.cc:4-76) */
 int lep_handoffs_serialize(const lep_handoff *h, int n, uint8_t *out, size_t out_cap);
 int lep_handoffs_parse(const uint8_t *data, size_t len, lep_handoff *out, int out_cap);
+/* lep_jpeg_plan's choice as hand-off records (what write_ujpg serialises into the header, jpgcoder.cc:3873-3934):
+ * segment_size = the JPEG scan bytes each thread segment covers.  Returns the count, or -LEP_BUFFER_TOO_SMALL. */
+int lep_jpeg_plan_handoffs(const lep_jpeg *j, int max_threads, lep_handoff *out, int cap);
 /* MuxWriter policy (src/io/MuxReader.hh:336-522) fed in the encoder's slice order (vp8_encoder.cc:575-594) */
 int lep_mux(const lep_bytes *streams, int nstreams, int version, lep_bytes *out);
 /* MuxReader (src/io/MuxReader.hh:230-283): packets until the data runs out; streams[16] are malloc'd */
@@ -277,6 +280,7 @@ typedef struct lep_batch_stats {
     double parse_s, stage_s, write_s;   /* host pool: parse, copies into pinned staging, container / Huffman re-code (summed) */
     double h2d_bytes, d2h_bytes; /* PCIe traffic */
     double alloc_s;              /* inside pipeline_s: (re)allocation of the pinned / device staging buffers (kept between calls) */
+    double redone_files;         /* compress: files whose streams outgrew the space reserved from their JPEG size and went through lep_compress */
 } lep_batch_stats;
 int lep_compress_batch(lep_gpu *g, const lep_bytes *jpgs, int n, lep_bytes *outs, int32_t *status,
                        const lep_batch_options *opt, lep_batch_stats *stats);
@@ -286,6 +290,8 @@ int lep_decompress_batch(lep_gpu *g, const lep_bytes *leps, int n, lep_bytes *ou
  * -> chunk k holds files [chunk_first[k], chunk_first[k + 1]); returns the number of chunks (cap = entries of chunk_first) */
 int lep_batch_plan(const size_t *file_bytes, const size_t *frame_bytes, int n, const lep_batch_options *opt, int *chunk_first, int cap);
 void lep_batch_release(void);   /* frees the staging buffers the two calls above keep between invocations (not re-entrant) */
+/* test hook: overwrite the pinned staging buffers kept between batch calls with `value` (stale-staging regression tests) */
+void lep_batch_debug_poison(int value);
 
 /* ---- serving surface ------------------------------------------------------------------------------
  * The `lepton -socket[=name] / -listen[=port]` protocol (src/lepton/socket_serve.cc:312-390, jpgcoder.cc:1162-1186):

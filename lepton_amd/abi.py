@@ -79,7 +79,7 @@ class BatchOptions(C.Structure):
 
 class BatchStats(C.Structure):
     _fields_ = [("wall_s", C.c_double), ("pipeline_s", C.c_double), ("parse_s", C.c_double), ("stage_s", C.c_double),
-                ("write_s", C.c_double), ("h2d_bytes", C.c_double), ("d2h_bytes", C.c_double), ("alloc_s", C.c_double)]
+                ("write_s", C.c_double), ("h2d_bytes", C.c_double), ("d2h_bytes", C.c_double), ("alloc_s", C.c_double), ("redone_files", C.c_double)]
 
 
 SERVE_PROCESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Bytes), C.c_int, C.POINTER(Bytes), C.POINTER(C.c_int32))
@@ -179,6 +179,9 @@ def lib():
         L.lep_gpu_huffman_encode_device.argtypes = [vp, P(HuffImage), C.c_int, P(HuffSegment), C.c_int, vp, vp, vp]
         L.lep_batch_release.argtypes = []
         L.lep_batch_release.restype = None
+        L.lep_batch_debug_poison.argtypes = [C.c_int]
+        L.lep_batch_debug_poison.restype = None
+        L.lep_jpeg_plan_handoffs.argtypes = [vp, C.c_int, P(Handoff), C.c_int]
         L.lep_handoffs_serialize.argtypes = [P(Handoff), C.c_int, vp, C.c_size_t]
         L.lep_handoffs_parse.argtypes = [vp, C.c_size_t, P(Handoff), C.c_int]
         L.lep_mux.argtypes = [P(Bytes), C.c_int, C.c_int, P(Bytes)]
@@ -196,5 +199,5 @@ EXPORTS = [
     "lep_file_segments", "lep_file_jpeg_size", "lep_file_recode", "lep_compress", "lep_decompress", "lep_free",
     "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_file_recode_plan", "lep_file_recode_finish", "lep_gpu_huffman_encode_device", "lep_jpeg_open_gpu", "lep_jpeg_scan_bytes", "lep_jpeg_finish_gpu", "lep_gpu_huffman_decode_device", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
     "lep_serve_start", "lep_serve_get_stats", "lep_serve_stop", "lep_zlib0_wrap", "lep_jpeg_open_slice", "lep_compress_slice", "lep_jpeg_open_embedded", "lep_compress_embedded", "lep_gpu_use_arena", "lep_batch_plan", "lep_jpeg_set_encode_options", "lep_gpu_huffman_decode_parallel_device",
-    "lep_jpeg_check_restores",
+    "lep_jpeg_check_restores", "lep_batch_debug_poison", "lep_jpeg_plan_handoffs",
 ]

@@ -177,6 +177,8 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
             im.code[2 + t][i] = jf.htab[1][t].set ? ((uint32_t)jf.htab[1][t].clen[i] << 16) | jf.htab[1][t].cval[i] : 0u;
         }
     const int luma_mul = jf.comp[0].bcv / jf.mcuv;
+    size_t blocks_per_mcu = 0, total_cap = 0;
+    for (int c = 0; c < jf.ncomp; ++c) blocks_per_mcu += jf.ncomp > 1 ? (size_t)jf.comp[c].hs * jf.comp[c].vs : 1;
     for (size_t s = 0; s < lf->segs.size(); ++s) {
         const Handoff& th = lf->segs[s];
         RecodeSegment g;
@@ -195,11 +197,20 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
         memcpy(g.last_dc, th.last_dc, sizeof g.last_dc);
         const size_t room = plan->scan_bound - plan->head.size();
         size_t cap = s == 0 ? room : (th.segment_size ? (size_t)th.segment_size : max_file_size);
-        // natural upper bound of a segment's bytes: 2 bytes per coefficient bit-wise worst case is far above real data;
-        // the arena slot is sized by the caller from this cap
+        // segment_size comes from an untrusted header (up to 4 GB per hand-off) and sizes a pinned + device arena slot in
+        // the batch pipeline: never reserve more than the file may hold, nor more than the segment's blocks can possibly
+        // code to -- 64 coefficients x (16-bit code + 11 magnitude bits) = 216 bytes, every one of them 0xFF and stuffed,
+        // plus a restart marker per MCU at worst
+        const size_t seg_blocks = (size_t)(r1 - r0) * (size_t)jf.mcuh * std::max<size_t>(1, blocks_per_mcu);
+        const size_t geo = seg_blocks * 432 + (size_t)(r1 - r0) * (size_t)jf.mcuh * 2 + 64;
+        cap = std::min(std::min(cap, room), geo);
+        if (s > 0) total_cap += cap;   // segment 0 is only bounded by the file; the caller gives it what the others leave
         g.out_cap = (uint32_t)std::min<size_t>(cap, 0xffffffffu);
         plan->segs.push_back(g);
     }
+    // later segments that together claim more than the file can hold are not what an encoder writes: the host re-coder
+    // (whose buffers grow with what is really written) takes such files
+    if (total_cap > (plan->scan_bound - plan->head.size()) + lf->segs.size() * 8192) { plan->segs.clear(); return 0; }
     plan->gpu_ok = true;
     return 0;
 }

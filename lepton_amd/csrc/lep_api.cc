@@ -170,6 +170,20 @@ int lep_jpeg_plan(const lep_jpeg* j, int max_threads, lep_segment* segs, int ima
     return (int)s.size();
 }
 
+// the same choice as lep_jpeg_plan, as hand-off records: segment_size = the JPEG scan bytes the segment covers
+int lep_jpeg_plan_handoffs(const lep_jpeg* j, int max_threads, lep_handoff* out, int cap) {
+    lep::EncodeOptions o = j->opt;
+    if (max_threads > 0) o.max_threads = (unsigned)max_threads;
+    std::vector<lep::Handoff> s = lep::plan_segments(j->jf, o);
+    if ((int)s.size() > cap) return -LEP_BUFFER_TOO_SMALL;
+    for (size_t i = 0; i < s.size(); ++i) {
+        out[i].luma_y_start = s[i].luma_y_start; out[i].luma_y_end = s[i].luma_y_end; out[i].segment_size = s[i].segment_size;
+        out[i].overhang_byte = s[i].overhang_byte; out[i].num_overhang_bits = s[i].num_overhang_bits;
+        memcpy(out[i].last_dc, s[i].last_dc, sizeof out[i].last_dc);
+    }
+    return (int)s.size();
+}
+
 int lep_jpeg_write_lep(const lep_jpeg* j, int max_threads, const lep_bytes* streams, int nstreams, lep_bytes* out) {
     lep::EncodeOptions o = j->opt;
     if (max_threads > 0) o.max_threads = (unsigned)max_threads;
@@ -201,6 +215,13 @@ int lep_file_open(const uint8_t* d, size_t len, lep_file** out) {
             jf.trunc_bcv[c] = lines;
             jf.trunc_bc[c] = tbc;
         }
+    }
+    // pre-hand-off split tables must cut on MCU rows: luma_y_end % (luma block rows per MCU row) -> THREADING_PARTIAL_MCU
+    // (vp8_decoder.cc:353-360; the last entry is not read from the file and not checked)
+    if (!f->lf.segs.empty() && f->lf.segs[0].num_overhang_bits == 0xff && jf.mcuv > 0) {
+        const int lcm = std::max(jf.comp[0].bcv / jf.mcuv, 1);
+        for (size_t i = 0; i + 1 < f->lf.segs.size(); ++i)
+            if (f->lf.segs[i].luma_y_end % lcm) return LEP_THREADING_PARTIAL_MCU;
     }
     if (!f->lf.segs.empty()) f->lf.segs.back().luma_y_end = (uint16_t)jf.trunc_bcv[0];   // vp8_decoder.cc:366-368
     *out = f.release();
@@ -235,7 +256,7 @@ int lep_file_describe_into(lep_file* f, void* frame_mem, size_t frame_cap, lep_i
 }
 
 int lep_file_segments(const lep_file* f, lep_segment* segs, lep_bytes* streams, int image_index) {
-    const auto& s = f->lf.segs;
+    const auto& s = f->lf.segs;   // <= LEP_MAX_SEGMENTS: parse_lep refuses files with more
     for (size_t i = 0; i < s.size(); ++i) {
         segs[i].image = image_index;
         segs[i].luma_y_start = s[i].luma_y_start;

@@ -112,6 +112,24 @@ struct Joiner {   // a background thread that is joined on every way out of the 
     ~Joiner() { if (t.joinable()) t.join(); }
 };
 
+struct StreamSet {   // HIP streams of one batch call, destroyed on every way out
+    std::vector<hipStream_t> all;
+    int make(hipStream_t* s, int priority = 0, bool with_priority = false) {
+        const hipError_t e = with_priority ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        if (e != hipSuccess) return LEP_GPU_ERROR;
+        all.push_back(*s);
+        return 0;
+    }
+    ~StreamSet() { for (hipStream_t s : all) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } }
+};
+template <class T, void (*CLOSE)(T*)>
+struct HandleVector {   // parsed files of a batch: whatever is still open when the call returns is closed
+    std::vector<T*> v;
+    explicit HandleVector(size_t n) : v(n, nullptr) {}
+    ~HandleVector() { for (T* p : v) if (p) CLOSE(p); }
+    T*& operator[](size_t i) { return v[i]; }
+};
+
 double g_alloc_s = 0;   // time spent in (re)allocating staging buffers during the current call (single orchestrator thread)
 
 int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_t nimg, bool scratch, size_t host_streams);
@@ -213,11 +231,13 @@ struct Chunk {
 
 Slot g_slots[2];         // one batch call at a time (the calls are not re-entrant)
 
-size_t frame_bytes_of(const lep_image_desc& d) {
+// exact bytes of a coefficient frame (a multiple of 128); a frame's ROOM in a slot is this rounded up to 256
+size_t frame_exact_bytes(const lep_image_desc& d) {
     size_t b = 0;
     for (int c = 0; c < d.ncomp; ++c) b += (size_t)d.width_blocks[c] * d.height_blocks[c] * 128;
-    return (b + 255) & ~(size_t)255;
+    return b;
 }
+size_t frame_bytes_of(const lep_image_desc& d) { return (frame_exact_bytes(d) + 255) & ~(size_t)255; }
 
 }  // namespace
 
@@ -225,6 +245,16 @@ extern "C" {
 
 // frees the pinned / device staging buffers the batch calls keep between invocations
 void lep_batch_release(void) { for (Slot& s : g_slots) s.release(); }
+
+// test hook: fills every pinned staging buffer the batch calls keep between invocations with `value`, so that a test can
+// show that nothing stale from an earlier batch (the padding between frames, the tails of streams) reaches a result
+void lep_batch_debug_poison(int value) {
+    for (Slot& s : g_slots) {
+        if (s.h_frames) memset(s.h_frames, value, s.hframes_cap);
+        if (s.h_streams) memset(s.h_streams, value, s.hstreams_cap);
+        if (s.h_scan) memset(s.h_scan, value, s.scan_cap);
+    }
+}
 
 // ---- JPEG -> .lep, batch ---------------------------------------------------------------------------------------------
 int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs, int32_t* status, const lep_batch_options* o,
@@ -268,19 +298,17 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     // wavefronts start in the slots that chunk k's long thread segments leave free instead of waiting for the last of them
     // (real photographs: segments of equal compressed size differ several-fold in blocks).  Off by default until measured.
     const bool overlap = (o && o->overlap_launches) || (getenv("LEP_BATCH_OVERLAP") && atoi(getenv("LEP_BATCH_OVERLAP")) != 0);
-    HIPOK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
-    HIPOK(hipStreamCreateWithFlags(&s_compute, hipStreamNonBlocking));
-    if (overlap) HIPOK(hipStreamCreateWithFlags(&s_compute2, hipStreamNonBlocking));
-    HIPOK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+    StreamSet stream_set;
+    if (stream_set.make(&s_copy) || stream_set.make(&s_compute) || (overlap && stream_set.make(&s_compute2)) || stream_set.make(&s_down)) return LEP_GPU_ERROR;
     {   // Huffman decode of chunk k+1 beside the coder kernels of chunk k: its workgroups go first whenever a slot is free
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIPOK(hipStreamCreateWithPriority(&s_huff, hipStreamNonBlocking, hi));
+        if (stream_set.make(&s_huff, hi, true)) return LEP_GPU_ERROR;
     }
     Slot* slots = g_slots;   // grow-only staging cache shared by the batch calls (lep_batch_release frees it)
     g_alloc_s = 0;
-    int rc_all = 0;
-    std::vector<lep_jpeg*> parsed(n, nullptr);
+    int rc_all = 0, st_redone = 0;
+    HandleVector<lep_jpeg, lep_jpeg_close> parsed(n);
     std::vector<char> host_parsed(n, 0);   // files the host parser took (irregular scans): verify also re-codes them on the host
 
     // 2. per chunk: split the files on the host pool; eligible scans are Huffman-decoded ON THE GPU straight into the device
@@ -365,8 +393,10 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         st.parse_s += now_s() - t0;
         // uploads: zero frames for the GPU-decoded images, host-decoded frames as they are
         HIPOK(hipMemsetAsync(s->d_frames, 0, c->frame_bytes, s_copy));
+        // (exactly the frame: the parser zeroes and fills frame_exact_bytes only, the rest of the 256-byte-rounded room in the
+        // pinned staging is whatever an earlier batch left there and must not reach the device, where the padding stays zero)
         for (int k = 0; k < nl; ++k) if (!on_gpu[k] && parsed[c->live[k]]) {
-            const size_t fb = (k + 1 < nl ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
+            const size_t fb = frame_exact_bytes(c->host_desc[k]);
             HIPOK(hipMemcpyAsync(s->d_frames + c->frame_off[k], s->h_frames + c->frame_off[k], fb, hipMemcpyHostToDevice, s_copy));
             st.h2d_bytes += (double)fb;
         }
@@ -451,14 +481,20 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         c->segs.clear(); c->offs.assign(1, 0); c->seg_first.clear();
         for (size_t k = 0; k < c->live.size(); ++k) {
             lep_segment sg[LEP_MAX_SEGMENTS];
+            lep_handoff ho[LEP_MAX_SEGMENTS];
             const int ns = lep_jpeg_plan(parsed[c->live[k]], 0, sg, (int)k);
+            (void)lep_jpeg_plan_handoffs(parsed[c->live[k]], 0, ho, LEP_MAX_SEGMENTS);
             c->seg_first.push_back((int)c->segs.size());
             const lep_image_desc& d = c->host_desc[k];
             size_t blocks = 0;
             for (int cc = 0; cc < d.ncomp; ++cc) blocks += (size_t)d.width_blocks[cc] * d.height_blocks[cc];
             for (int q = 0; q < ns; ++q) {
+                // stream space: segments are cut by equal JPEG bytes, not blocks, so the segment's own scan bytes (+ 25 %)
+                // are the measure; the per-block term covers progressive files, whose hand-offs only count the first scan.
+                // What still overflows is redone per file (end of this function).
+                const size_t by_bytes = (size_t)ho[q].segment_size + ho[q].segment_size / 4, by_blocks = blocks * 40 / ns;
                 c->segs.push_back(sg[q]);
-                c->offs.push_back(c->offs.back() + ((blocks * 40 / ns + 65536 + 255) & ~(size_t)255));
+                c->offs.push_back(c->offs.back() + ((std::max(by_bytes, by_blocks) + 65536 + 255) & ~(size_t)255));
             }
         }
         c->seg_first.push_back((int)c->segs.size());
@@ -495,7 +531,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             rc = lep_gpu_decode_device(g, c->scratch_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status + nseg, s_compute);
             if (rc) return rc;
             for (int k = 0; k < nimg; ++k) {
-                const size_t fb = frame_bytes_of(c->host_desc[k]);
+                const size_t fb = frame_exact_bytes(c->host_desc[k]);   // the frame itself, not its rounded room in the slot
                 hipLaunchKernelGGL(lep_compare_kernel, dim3(256), dim3(256), 0, s_compute, (const uint4*)(s->d_frames + c->frame_off[k]),
                                    (const uint4*)(s->d_scratch + c->frame_off[k]), fb / 16, s->d_flags + k, 1u);
             }
@@ -582,10 +618,28 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     }
     if (writer.joinable()) writer.join();
     st.pipeline_s = now_s() - t_pipe;
-    for (int i = 0; i < n; ++i) if (parsed[i]) lep_jpeg_close(parsed[i]);
+    for (int i = 0; i < n; ++i) if (parsed[i]) { lep_jpeg_close(parsed[i]); parsed[i] = nullptr; }
+    // A thread segment that did not fit the stream space reserved for it (sized from its JPEG bytes: the arithmetic coder
+    // almost never writes more than the Huffman coder did) is not a refusal the reference would make: such files go
+    // through the per-file path, which reserves the worst case, once the pipeline has drained.
+    if (!rc_all)
+        for (int i = 0; i < n; ++i) {
+            if (status[i] != LEP_BUFFER_TOO_SMALL) continue;
+            lep_bytes o; o.data = nullptr; o.len = o.cap = 0;
+            int rc = lep_compress(g, jpgs[i].data, jpgs[i].len, &o);
+            if (!rc && verify) {   // the arithmetic-coder half of the round-trip check, through the per-file decoder
+                lep_bytes back; back.data = nullptr; back.len = back.cap = 0;
+                rc = lep_decompress(g, o.data, o.len, &back);
+                if (!rc && (back.len != jpgs[i].len || memcmp(back.data, jpgs[i].data, back.len))) rc = LEP_ROUNDTRIP_FAILURE;
+                lep_free(back.data);
+                if (rc) { lep_free(o.data); o.data = nullptr; o.len = o.cap = 0; }
+            }
+            outs[i] = o;
+            status[i] = rc;
+            ++st_redone;
+        }
     st.alloc_s = g_alloc_s;
-    (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_compute); (void)hipStreamDestroy(s_down); (void)hipStreamDestroy(s_huff);
-    if (s_compute2) (void)hipStreamDestroy(s_compute2);
+    st.redone_files = st_redone;
     st.wall_s = now_s() - t_begin;
     if (stats) *stats = st;
     return rc_all;
@@ -605,7 +659,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     lep_batch_stats st;
     memset(&st, 0, sizeof st);
     for (int i = 0; i < n; ++i) { outs[i].data = nullptr; outs[i].len = outs[i].cap = 0; status[i] = 0; }
-    std::vector<lep_file*> files(n, nullptr);
+    HandleVector<lep_file, lep_file_close> files(n);
     std::vector<size_t> fbytes(n, 0);
     {
         const double t0 = now_s();
@@ -617,9 +671,8 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         st.parse_s += now_s() - t0;
     }
     hipStream_t s_copy = nullptr, s_compute = nullptr, s_down = nullptr;
-    HIPOK(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking));
-    HIPOK(hipStreamCreateWithFlags(&s_compute, hipStreamNonBlocking));
-    HIPOK(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+    StreamSet stream_set;
+    if (stream_set.make(&s_copy) || stream_set.make(&s_compute) || stream_set.make(&s_down)) return LEP_GPU_ERROR;
     Slot* slots = g_slots;
     g_alloc_s = 0;
     int rc_all = 0;
@@ -703,7 +756,11 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                 }
                 c->himg.push_back(hi);
             }
-            if (!c->hseg.empty()) { if (int rc = scan_reserve(s, c->scan_bytes + 256, c->hseg.size())) return rc; }
+            // no room for the scan arena (hostile hand-off sizes are clamped by recode_prepare, so this is a real shortage):
+            // the chunk's files take the host re-coder instead of failing everybody's request
+            if (!c->hseg.empty() && scan_reserve(s, c->scan_bytes + 256, c->hseg.size())) {
+                c->himg.clear(); c->hseg.clear(); c->hfirst.assign(c->live.size(), -1); c->hslot.clear(); c->hbound.clear(); c->scan_bytes = 0;
+            }
         }
         // files the host re-coder handles read their frame where the D2H copy puts it: the slot's pinned buffer
         bool any_host = false;
@@ -807,9 +864,8 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     }
     if (writer.joinable()) writer.join();
     st.pipeline_s = now_s() - t_pipe;
-    for (int i = 0; i < n; ++i) if (files[i]) lep_file_close(files[i]);
+    for (int i = 0; i < n; ++i) if (files[i]) { lep_file_close(files[i]); files[i] = nullptr; }
     st.alloc_s = g_alloc_s;
-    (void)hipStreamDestroy(s_copy); (void)hipStreamDestroy(s_compute); (void)hipStreamDestroy(s_down);
     st.wall_s = now_s() - t_begin;
     if (stats) *stats = st;
     return rc_all;

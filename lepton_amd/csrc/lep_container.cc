@@ -162,7 +162,10 @@ static bool zlib9(const std::vector<uint8_t>& in, std::vector<uint8_t>* out) {
     return true;
 }
 
-static bool unzlib(const uint8_t* d, size_t n, std::vector<uint8_t>* out) {
+// limit: the reference inflates at most max_file_size + 2048 bytes of header and treats a longer one like a corrupt one
+// (ZlibDecoderDecompressionReader::Decompress(..., max_file_size + 2048), jpgcoder.cc:4158-4166) -- which also keeps a
+// zlib bomb in a request from blowing up a shared serving process
+static bool unzlib(const uint8_t* d, size_t n, size_t limit, std::vector<uint8_t>* out) {
     z_stream s;
     memset(&s, 0, sizeof s);
     if (inflateInit(&s) != Z_OK) return false;
@@ -175,6 +178,7 @@ static bool unzlib(const uint8_t* d, size_t n, std::vector<uint8_t>* out) {
         r = inflate(&s, Z_NO_FLUSH);
         if (r != Z_OK && r != Z_STREAM_END) { inflateEnd(&s); return false; }
         out->insert(out->end(), buf, buf + (sizeof buf - s.avail_out));
+        if (out->size() > limit) { inflateEnd(&s); return false; }
     } while (r != Z_STREAM_END);
     inflateEnd(&s);
     return true;
@@ -313,7 +317,7 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
     if (zsize > (128u << 20) || lf->jpeg_size > (128u << 20)) return EX_ASSERTION_FAILURE;   // "Only support images < 128 megs" (jpgcoder.cc:4133-4136)
     if (28 + (uint64_t)zsize + 3 > n) return EX_SHORT_READ;
     std::vector<uint8_t> p;
-    if (!unzlib(d + 28, zsize, &p)) return EX_STREAM_INCONSISTENT;
+    if (!unzlib(d + 28, zsize, (size_t)lf->jpeg_size + 2048, &p)) return EX_STREAM_INCONSISTENT;
     size_t pos = 0;
     auto need = [&](size_t k) { return pos + k <= p.size(); };
     JpegFile& jf = lf->jpeg;
@@ -342,6 +346,7 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
         } else if (m[0] == 'H' && m[1] == 'H') {
             size_t bytes = (size_t)m[2] * 16 + 2;
             if (!need(1 + bytes)) return EX_STREAM_INCONSISTENT;
+            lf->segs.clear();   // a later section replaces an earlier one (thread_handoff = ThreadHandoff::deserialize(...), jpgcoder.cc:4266)
             if (!deserialize_handoffs(m + 1, bytes, &lf->segs)) return EX_VERSION_UNSUPPORTED;
             pos += 1 + bytes;
         } else if (!memcmp(m, "FRS", 3)) {
@@ -371,7 +376,11 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
             for (int i = 0; i < 4; ++i) jf.max_dpos[i] = (int)get_le32(m + 15 + 4 * i);
             jf.early_eof = true;
             pos += 31;
-        } else break;
+        } else if (!memcmp(m, "CMP", 3) || !memcmp(m, "CNT", 3)) {
+            break;
+        } else {
+            return EX_UNSUPPORTED_JPEG;   // "unknown data found": errorlevel 2 (jpgcoder.cc:4326-4337)
+        }
     }
     if (lf->garbage_default_eoi) jf.garbage = {0xFF, 0xD9};
     const uint8_t* q = d + 28 + zsize;
@@ -394,8 +403,16 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
     }
     // the decoder runs min(thread hint, MAX_NUM_THREADS = 8) physical threads (one, for a pre-hand-off file: recoder.cc:731-733);
     // one without a hand-off of its own trips always_assert(logical_thread_start < thread_handoffs.size()) (recoder.cc:547-578)
+    // more logical threads than stream ids (MuxReader::MAX_STREAM_ID = 16, MuxReader.hh:201): the reference dies in an
+    // always_assert / out-of-bounds access (probed: abort with 17 and 32 hand-offs, SIGSEGV with 200); every caller of
+    // lep_file_segments sizes its arrays LEP_MAX_SEGMENTS
+    if (lf->segs.size() > 16) return EX_ASSERTION_FAILURE;
     const bool baseline_recoder = lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1);   // jpgcoder.cc:2162; the general re-coder is single-threaded
     if (baseline_recoder && lf->segs[0].num_overhang_bits != 0xff && (size_t)std::min(lf->nthreads, 8) > lf->segs.size()) return EX_ASSERTION_FAILURE;
+    // the general re-coder decodes through decode_chunk, which gives up when the file has more logical threads than the
+    // decoder was started with: `num_threads_needed > NUM_THREADS` -> CODING_ERROR (vp8_decoder.cc:415-417), NUM_THREADS =
+    // min(8, thread hint) (read_fixed_ujpg_header, jpgcoder.cc:2167-2171)
+    if (!baseline_recoder && lf->segs.size() > (size_t)std::min(lf->nthreads, 8)) return EX_CODING_ERROR;
     demux_packets(d, n, at, &lf->streams);
     return 0;
 }

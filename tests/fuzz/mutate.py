@@ -1,10 +1,92 @@
 #!/usr/bin/env python3
-"""Seeded structure-blind mutations of the golden JPEG / .lep files for tests/fuzz/host_fuzz.cc: bit flips, byte stomps,
-truncations, insertions, block duplications, 16-bit length-field edits near markers.  usage: mutate.py <outdir> <count> <seed>"""
+"""Seeded mutations of the golden JPEG / .lep files for tests/fuzz/host_fuzz.cc.  Structure-blind: bit flips, byte stomps,
+truncations, insertions, block duplications, 16-bit length-field edits near markers.  Structure-aware (.lep only, every
+third mutant): the zlib-compressed header is inflated, mutated and deflated again -- a blind mutation of it dies in inflate /
+Adler-32 and never reaches the section parser (HH / CRS / FRS / EEE / GRB / PGR, the embedded JPEG header) or the re-coder --
+and the flag / thread-count bytes and the hand-off section are edited by field (count > 16, several HH sections, huge
+segment sizes).  usage: mutate.py <outdir> <count> <seed>"""
 import glob
 import os
 import random
+import struct
 import sys
+import zlib
+
+
+def lep_split(lep):
+    """(28-byte fixed prefix, inflated header payload, everything from "CMP" on) of a format-1 .lep, or None"""
+    if len(lep) < 32 or lep[:2] != b"\xcf\x84":
+        return None
+    zs = struct.unpack("<I", lep[24:28])[0]
+    try:
+        payload = zlib.decompress(lep[28:28 + zs])
+    except zlib.error:
+        return None
+    return lep[:28], payload, lep[28 + zs:]
+
+
+def lep_join(fixed, payload, rest):
+    z = zlib.compress(payload, 9)
+    out = bytearray(fixed[:24]) + struct.pack("<I", len(z)) + z + rest
+    if len(out) >= 4:
+        out[-4:] = struct.pack("<I", len(out))   # the size trailer (vp8_encoder.cc:602-614)
+    return bytes(out)
+
+
+def find_handoffs(payload):
+    """offset of the "HH" section in an inflated header (behind HDR + P0D), or -1"""
+    if payload[:3] != b"HDR" or len(payload) < 7:
+        return -1
+    pos = 7 + struct.unpack("<I", payload[3:7])[0] + 4
+    return pos if payload[pos:pos + 2] == b"HH" else -1
+
+
+def with_handoffs(lep, count=None, repeat=1, segment_size=None, thread_byte=None):
+    """re-packs a .lep with `count` hand-off records (the last one repeated), the HH section `repeat` times, every
+    segment_size overwritten, byte 4 (thread hint) replaced"""
+    parts = lep_split(lep)
+    if not parts:
+        return lep
+    fixed, p, rest = parts
+    pos = find_handoffs(p)
+    if pos < 0:
+        return lep
+    n = p[pos + 2]
+    recs = [bytearray(p[pos + 3 + 16 * i:pos + 19 + 16 * i]) for i in range(n)]
+    if count is not None and recs:
+        recs = (recs + [bytearray(recs[-1]) for _ in range(max(0, count - n))])[:count]
+    if segment_size is not None:
+        for r in recs:
+            r[2:6] = struct.pack("<I", segment_size)
+    sect = b"HH" + bytes([len(recs) & 255]) + b"".join(bytes(r) for r in recs)
+    p2 = p[:pos] + sect * repeat + p[pos + 3 + 16 * n:]
+    fixed = bytearray(fixed)
+    if thread_byte is not None:
+        fixed[4] = thread_byte
+    return lep_join(bytes(fixed), p2, rest)
+
+
+def mutate_lep_structured(rng, lep):
+    parts = lep_split(lep)
+    if not parts:
+        return mutate(rng, lep)
+    k = rng.randrange(6)
+    if k == 0:
+        return with_handoffs(lep, count=rng.choice([0, 1, 9, 16, 17, 32, 200, 255]))
+    if k == 1:
+        return with_handoffs(lep, repeat=rng.choice([2, 3, 20]), count=rng.choice([None, 16, 255]))
+    if k == 2:
+        return with_handoffs(lep, segment_size=rng.choice([0, 1, 0x7fffffff, 0xffffffff, rng.randrange(1 << 32)]))
+    if k == 3:
+        return with_handoffs(lep, thread_byte=rng.choice([0, 1, 8, 9, 16, 17, 255]))
+    fixed, p, rest = parts
+    p = mutate(rng, p)
+    fixed = bytearray(fixed)
+    if rng.random() < 0.3:
+        fixed[3] = rng.choice([ord("Z"), ord("X"), ord("Y"), rng.randrange(256)])
+    if rng.random() < 0.2:
+        fixed[20:24] = struct.pack("<I", rng.choice([0, 1, len(p), 1 << 20, (128 << 20) + 1, rng.randrange(1 << 32)]))
+    return lep_join(bytes(fixed), p, rest if rng.random() < 0.7 else mutate(rng, rest))
 
 
 def mutate(rng, d):
@@ -56,7 +138,8 @@ def main():
     for i in range(count):
         k = rng.randrange(len(blobs))
         ext = os.path.splitext(seeds[k])[1]
-        open(os.path.join(out, "m%06d%s" % (i, ext)), "wb").write(mutate(rng, blobs[k]))
+        m = mutate_lep_structured(rng, blobs[k]) if ext == ".lep" and i % 3 == 0 else mutate(rng, blobs[k])
+        open(os.path.join(out, "m%06d%s" % (i, ext)), "wb").write(m)
 
 
 if __name__ == "__main__":

@@ -52,6 +52,18 @@ def test_host_parsers_survive_hand_made_killers(harness, tmp_path):
     cases["magic_only.lep"] = l[:4]
     cases["header_cut.lep"] = l[:40]
     cases["huge_sizes.lep"] = l[:20] + b"\xff\xff\xff\x7f" * 4 + l[36:]
+    # more hand-off records than stream ids (a stack overflow in the callers' 16-entry arrays before parse_lep capped it),
+    # the section several times over, segment sizes of 4 GB, and a zlib bomb for a header
+    sys.path.insert(0, FUZZ)
+    import mutate as mu
+    l4 = golden("q30_256x256_4seg")[1]
+    for n in (17, 200, 255):
+        cases["handoffs_%d.lep" % n] = mu.with_handoffs(l4, count=n)
+    cases["handoffs_twice.lep"] = mu.with_handoffs(l4, repeat=2)
+    cases["handoffs_20x255.lep"] = mu.with_handoffs(l4, count=255, repeat=20)
+    cases["handoffs_4gb.lep"] = mu.with_handoffs(l4, segment_size=0xffffffff)
+    fixed, payload, rest = mu.lep_split(l4)
+    cases["header_bomb.lep"] = mu.lep_join(fixed, payload + bytes(64 << 20), rest)
     for name, data in cases.items():
         (tmp_path / name).write_bytes(data)
     _run(harness, sorted(cases), str(tmp_path))
@@ -97,3 +109,25 @@ def test_server_is_thread_and_memory_safe_under_load(sanitizer, tmp_path):
 #   LEP_EMU_SO=/tmp/libcore_emu_san.so LEP_EMU_DEFINES="-fsanitize=address,undefined -fno-omit-frame-pointer -g" \
 #   LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:log_path=/tmp/asanlog \
 #   python -m pytest tests/test_core_emulation.py tests/test_slices.py -x -q -m "not gpu" -p no:cacheprovider
+
+
+def test_lep_container_rules_found_by_the_structure_aware_fuzz():
+    """what the hand-off section may hold, as the reference behaves (probed with the reference binary: 17 and 32 records abort
+    in always_assert, 200 die with SIGSEGV; a second HH section replaces the first; the header may inflate to the announced
+    JPEG size + 2048 bytes and no further, jpgcoder.cc:4158-4166)"""
+    sys.path.insert(0, FUZZ)
+    import mutate as mu
+    from lepton_amd.codec import LepFile, LeptonError
+
+    l4 = golden("q30_256x256_4seg")[1]
+    for n in (17, 32, 200, 255):
+        with pytest.raises(LeptonError) as e:
+            LepFile(mu.with_handoffs(l4, count=n))
+        assert e.value.code == 1
+    f = LepFile(mu.with_handoffs(l4, repeat=3))
+    assert len(f.segments) == len(LepFile(l4).segments) and [s.luma_y_start for s in f.segments] == [s.luma_y_start for s in LepFile(l4).segments]
+    assert len(LepFile(mu.with_handoffs(l4, count=16, thread_byte=2)).segments) == 16
+    fixed, payload, rest = mu.lep_split(l4)
+    with pytest.raises(LeptonError):
+        LepFile(mu.lep_join(fixed, payload + bytes(1 << 20), rest))     # header inflates far beyond jpeg_size + 2048
+    LepFile(mu.lep_join(fixed, payload + bytes(1000), rest))            # trailing bytes inside the bound: ignored, as in the reference

@@ -309,3 +309,68 @@ def test_gpu_huffman_decode_matches_host_and_reference(gpu_codec):
     assert stats_gpu["h2d_bytes"] < stats_host["h2d_bytes"] / 2
     back, st, _ = gpu_codec.decompress_batch(a)
     assert st == [0] * len(jpgs) and back == jpgs
+
+
+def test_gpu_verify_is_blind_to_stale_staging(gpu_codec):
+    """Round-1 driver failure: `verify` compared a frame's 256-byte-rounded ROOM in the slot, and host-parsed frames were
+    uploaded with that room -- so whatever an earlier batch had left in the pinned staging behind a frame with an odd
+    block count (prog_gray_120x88: 165 blocks) surfaced as a false ROUNDTRIP_FAILURE in a re-used slot.  The staging is
+    poisoned on purpose here; files that take the host parser (progressive, truncated, grey) with odd block counts must
+    verify, batch after batch, in both slots."""
+    from lepton_amd import abi
+
+    L = abi.lib()
+    names = ["prog_gray_120x88", "prog_c444_203x149", "prog_truncated_mid", "gray_120x88", "one_block_8x8", "c420_odd_203x149", "prog_truncated_dc"]
+    jpgs = [golden(n)[0] for n in names]
+    leps = [golden(n)[1] for n in names]
+    filler = [corpus.synth_jpeg(640, 480, 60 + i) for i in range(6)]
+    # grow the pinned staging (host Huffman path stages whole frames) and leave it dirty
+    _, st, _ = gpu_codec.compress_batch(filler * 4, host_huffman=True, chunk_images=8, verify=True)
+    assert st == [0] * len(st)
+    for it in range(6):
+        L.lep_batch_debug_poison(0xA5 if it % 2 == 0 else 0xFF)
+        batch = (jpgs * 3)[it % 3:] + filler[:2]
+        got, st, _ = gpu_codec.compress_batch(batch, verify=True, chunk_images=5)   # several chunks: both slots are re-used
+        assert st == [0] * len(batch), (it, st)
+        want = (leps * 3)[it % 3:]
+        assert got[: len(want)] == want
+    L.lep_batch_debug_poison(0x5A)
+    back, st2, _ = gpu_codec.decompress_batch(leps * 2, chunk_images=3)
+    assert st2 == [0] * (2 * len(leps)) and back == jpgs * 2
+
+
+def test_gpu_batch_redoes_files_whose_streams_outgrow_their_reservation(gpu_codec):
+    """the batch pipeline reserves stream space from a segment's JPEG bytes; a file that needs more (dense noise at q100,
+    where the arithmetic coder gains nothing) must come out exactly like the per-file path, not as BUFFER_TOO_SMALL"""
+    import io
+    import numpy as np
+    from PIL import Image
+
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(a, "RGB").save(buf, format="JPEG", quality=100, subsampling=0)
+    noisy = buf.getvalue()
+    jpgs = [noisy, golden("c420_160x120")[0], noisy]
+    got, st, stats = gpu_codec.compress_batch(jpgs, verify=True)
+    assert st == [0, 0, 0]
+    assert got[0] == gpu_codec.compress(noisy) and got[2] == got[0] and got[1] == golden("c420_160x120")[1]
+    assert gpu_codec.decompress(got[0]) == noisy
+
+
+def test_gpu_hostile_handoff_sizes_do_not_size_the_arena(gpu_codec):
+    """a .lep whose hand-offs claim 4 GB segments (or 200 of them) is one request among many: it must fail or fall back
+    alone, without a multi-GB reservation and without taking the batch down"""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
+    import mutate as mu
+
+    jpg, lep = golden("q30_256x256_4seg")
+    hostile = [mu.with_handoffs(lep, segment_size=0xffffffff), mu.with_handoffs(lep, count=200), mu.with_handoffs(lep, count=17)]
+    good = [golden(n)[1] for n in ("c420_160x120", "c444_96x80")]
+    back, st, stats = gpu_codec.decompress_batch([good[0]] + hostile + [good[1]])
+    assert st[0] == 0 and st[-1] == 0 and back[0] == golden("c420_160x120")[0] and back[-1] == golden("c444_96x80")[0]
+    assert st[2] == 1 and st[3] == 1              # more hand-offs than stream ids: the reference dies in an assertion
+    assert st[1] != 0 or back[1] == jpg            # absurd sizes (the reference segfaults on them): refused, or restored right
