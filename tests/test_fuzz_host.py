@@ -130,4 +130,7 @@ def test_lep_container_rules_found_by_the_structure_aware_fuzz():
     fixed, payload, rest = mu.lep_split(l4)
     with pytest.raises(LeptonError):
         LepFile(mu.lep_join(fixed, payload + bytes(1 << 20), rest))     # header inflates far beyond jpeg_size + 2048
-    LepFile(mu.lep_join(fixed, payload + bytes(1000), rest))            # trailing bytes inside the bound: ignored, as in the reference
+    with pytest.raises(LeptonError) as e:
+        LepFile(mu.lep_join(fixed, payload + bytes(1000), rest))        # "unknown data found" -> errorlevel 2 (jpgcoder.cc:4326-4337)
+    assert e.value.code == 42
+    LepFile(mu.lep_join(fixed, payload + b"CMP" + bytes(50), rest))     # an explicit end mark stops the section loop
