@@ -4,11 +4,12 @@
 // tests/test_integration_adapter.py can type-check it against the reference's own headers wherever a reference checkout is
 // present (g++ -fsyntax-only, the reference's include paths and default defines).  The three factories of jpgcoder.cc:440-471
 // then become:
-//     BaseEncoder *makeEncoder(bool, bool)       { return new MI355XEncoder; }
-//     BaseDecoder *makeDecoder(bool, bool, bool) { return new MI355XDecoder; }
-//     makeBoth<>                                  -> the two above
-// and nothing else in jpgcoder.cc / recoder.cc changes.  The process must be able to reach /dev/kfd, i.e. run -unjailed or
+//     g_encoder.reset(make_mi355x_encoder(g_threaded, g_threaded));      (jpgcoder.cc:1710)
+//     g_decoder = make_mi355x_decoder(g_threaded, g_threaded);           (jpgcoder.cc:1727)
+// (oracle/mi355x_factories.sed is exactly that patch; oracle/Makefile.ref applies it to a copy of jpgcoder.cc and links
+// oracle/_ref/lepton-mi355x, which tests/test_integration_adapter.py runs) and nothing else in jpgcoder.cc / recoder.cc changes.  The process must be able to reach /dev/kfd, i.e. run -unjailed or
 // create the lep_gpu before installStrictSyscallFilter (jpgcoder.cc:1765) with a filter that admits the HIP runtime's calls.
+#include <pthread.h>
 #include <string.h>
 
 #include <algorithm>
@@ -28,19 +29,24 @@ namespace {
 
 // what encode_chunk consumes of UncompressedComponents (vp8_encoder.cc:521-548): geometry, truncation bounds, zig-zag
 // quantisation tables, the dense AlignedBlock arrays
-void fill_desc(const UncompressedComponents *in, lep_image_desc *d) {
+// with_frame = false: geometry only.  The baseline decode path never allocates the full components of `in` (the reference
+// decodes through two-row framebuffers there, uncompressed_components.hh:155-167), so neither their dimensions nor their
+// blocks may be asked of the BlockBasedImage objects -- raster(0) of an unallocated image is an OOM exit
+// (block_based_image.hh:216-224); the header's own block counts are always there.
+void fill_desc(const UncompressedComponents *in, lep_image_desc *d, bool with_frame) {
     memset(d, 0, sizeof *d);
     d->ncomp = in->get_num_components();
     d->mcu_rows = in->get_mcu_count_vertical();
     Sirikata::Array1d<uint32_t, (uint32_t)ColorChannel::NumBlockTypes> coded_h = in->get_max_coded_heights();
     for (int c = 0; c < d->ncomp && c < LEP_MAX_COMPONENTS; ++c) {
-        const BlockBasedImage &img = in->full_component_nosync(c);
-        d->width_blocks[c] = (int32_t)img.block_width();
-        d->height_blocks[c] = (int32_t)img.original_height();
+        d->width_blocks[c] = (int32_t)in->block_width(c);
+        // the frame's theoretical height (bcv); block_height() is the TRUNCATED height.  Without a full component the caller
+        // takes it from the row framebuffers it was handed (initialize_baseline_decoder)
+        d->height_blocks[c] = with_frame ? (int32_t)in->full_component_nosync(c).original_height() : 0;
         d->coded_blocks[c] = (int32_t)in->component_size_in_blocks(c);
         d->coded_height[c] = (int32_t)coded_h[c];
         memcpy(d->qtable_zigzag[c], in->get_quantization_tables((BlockType)c), 64 * sizeof(uint16_t));
-        d->blocks[c] = const_cast<int16_t *>(in->block_nosync((BlockType)c, 0).raw_data());
+        d->blocks[c] = with_frame ? const_cast<int16_t *>(in->block_nosync((BlockType)c, 0).raw_data()) : NULL;
     }
 }
 
@@ -64,7 +70,7 @@ public:
     CodingReturnValue encode_chunk(const UncompressedComponents *in, IOUtil::FileWriter *out, const ThreadHandoff *splits,
                                    unsigned int n) {
         lep_image_desc d;
-        fill_desc(in, &d);
+        fill_desc(in, &d, true);
         lep_segment seg[LEP_MAX_SEGMENTS];
         lep_bytes st[LEP_MAX_SEGMENTS];
         int32_t status[LEP_MAX_SEGMENTS];
@@ -113,7 +119,9 @@ class MI355XDecoder : public BaseDecoder {
     std::vector<ThreadHandoff> handoff_;
     GenericWorker *workers_;
     unsigned int num_workers_;
-    // baseline path: the adapter's own frame
+    // baseline path: the adapter's own frame, decoded once by whichever of the re-coder's threads asks first (recoder.cc
+    // runs recode_physical_thread on up to NUM_THREADS workers, each calling decode_row for its own segments)
+    pthread_mutex_t once_;
     bool decoded_;
     lep_image_desc desc_;
     std::vector<int16_t> frame_[LEP_MAX_COMPONENTS];
@@ -151,10 +159,11 @@ class MI355XDecoder : public BaseDecoder {
 
 public:
     MI355XDecoder() : gpu_(NULL), in_(NULL), mux_(Sirikata::JpegAllocator<uint8_t>()), workers_(NULL), num_workers_(0), decoded_(false) {
+        pthread_mutex_init(&once_, NULL);
         memset(&desc_, 0, sizeof desc_);
         die_on(lep_gpu_create(0, &gpu_));
     }
-    ~MI355XDecoder() { lep_gpu_destroy(gpu_); }
+    ~MI355XDecoder() { lep_gpu_destroy(gpu_); pthread_mutex_destroy(&once_); }
 
     void initialize(Sirikata::DecoderReader *input, const std::vector<ThreadHandoff> &thread_transition_info) {
         in_ = input;
@@ -165,9 +174,12 @@ public:
     // frame-pull path (progressive files, uncompressed_components.hh:106-108): the whole frame in one call
     CodingReturnValue decode_chunk(UncompressedComponents *dst) {
         lep_image_desc d;
-        fill_desc(dst, &d);
+        fill_desc(dst, &d, true);
         if (!handoff_.empty()) handoff_.back().luma_y_end = (uint16_t)dst->block_height(0);   // vp8_decoder.cc:366-368
         decode_into(&d);
+        // what the reference's decode_chunk signals when it returns CODING_DONE (vp8_decoder.cc:483-487): the callers spin in
+        // wait_for_worker_on_dpos / _bpos / _bit on these counters, calling decode_chunk again until they move
+        for (int c = 0; c < d.ncomp; ++c) dst->worker_mark_cmp_finished((BlockType)c);
         dst->worker_update_coefficient_position_progress(64);   // every coefficient of every block is there
         dst->worker_update_bit_progress(16);
         return CODING_DONE;
@@ -179,9 +191,10 @@ public:
     // row-pull path (baseline files, recoder.cc:694-889): geometry now, the frame on the first decode_row
     std::vector<ThreadHandoff> initialize_baseline_decoder(
         const UncompressedComponents *const colldata,
-        Sirikata::Array1d<BlockBasedImagePerChannel<true>, MAX_NUM_THREADS> &) {
-        fill_desc(colldata, &desc_);
+        Sirikata::Array1d<BlockBasedImagePerChannel<true>, MAX_NUM_THREADS> &framebuffer) {
+        fill_desc(colldata, &desc_, false);
         for (int c = 0; c < desc_.ncomp; ++c) {
+            desc_.height_blocks[c] = (int32_t)framebuffer[0][c]->original_height();   // allocate_channel_framebuffer: init(bch, bcv, ...)
             frame_[c].assign((size_t)desc_.width_blocks[c] * desc_.height_blocks[c] * 64, 0);
             desc_.blocks[c] = frame_[c].empty() ? NULL : &frame_[c][0];
         }
@@ -192,7 +205,9 @@ public:
     void decode_row(int, BlockBasedImagePerChannel<true> &image_data,
                     Sirikata::Array1d<uint32_t, (uint32_t)ColorChannel::NumBlockTypes> component_size_in_blocks, int component,
                     int curr_y) {
+        pthread_mutex_lock(&once_);
         if (!decoded_) { decode_into(&desc_); decoded_ = true; }
+        pthread_mutex_unlock(&once_);
         const uint32_t w = (uint32_t)desc_.width_blocks[component];
         const int16_t *row = &frame_[component][(size_t)curr_y * w * 64];
         for (uint32_t x = 0; x < w && (uint32_t)curr_y * w + x < component_size_in_blocks[component]; ++x)
@@ -206,5 +221,13 @@ public:
     void reset_all_comm_buffers() {}
 };
 
-BaseEncoder *make_mi355x_encoder() { return new MI355XEncoder; }
-BaseDecoder *make_mi355x_decoder() { return new MI355XDecoder; }
+// The factories, with the signatures and the worker-thread registration of the ones they replace (makeEncoder / makeDecoder /
+// makeBoth, jpgcoder.cc:440-471).  The decoder needs the reference's worker threads: the baseline re-coder runs its Huffman
+// half on them (recoder.cc:740-790 reaches them through g_decoder->getWorker); the encoder's segments are wavefronts.
+GenericWorker *get_worker_threads(unsigned int num_workers);   // jpgcoder.cc:429
+BaseEncoder *make_mi355x_encoder(bool /*threaded*/, bool /*start_workers*/) { return new MI355XEncoder; }
+BaseDecoder *make_mi355x_decoder(bool /*threaded*/, bool start_workers) {
+    MI355XDecoder *d = new MI355XDecoder;
+    if (start_workers) d->registerWorkers(get_worker_threads(NUM_THREADS), NUM_THREADS);
+    return d;
+}

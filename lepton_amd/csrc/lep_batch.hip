@@ -419,9 +419,12 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 launch.push_back(hi); which.push_back(k);
             }
             HIPOK(hipStreamWaitEvent(s_huff, s->up, 0));
-            // LEP_HUFFDEC_PAR=<n> (experimental): n wavefronts per image for the scans without restart intervals
-            // (lep_huffdec_par.h); the others, and by default all, take the single-wave kernel
-            const int par = getenv("LEP_HUFFDEC_PAR") ? atoi(getenv("LEP_HUFFDEC_PAR")) : 0;
+            // Several wavefronts per image (lep_huffdec_par.h) for the scans without restart intervals when the decode is
+            // EXPOSED -- the first chunk of a call has no coder kernel to hide behind: 1024 4K images, one chunk, compress
+            // 2.39 s -> 1.84 s at 16 wavefronts per image (MI355X, profiles/r02a_huffpar_*).  Later chunks keep the single-wave
+            // kernel, which is built to sit in the eighth wave slot beside the previous chunk's coder waves.
+            // LEP_HUFFDEC_PAR=<n> forces n (0 = single wave) for every chunk.
+            const int par = getenv("LEP_HUFFDEC_PAR") ? atoi(getenv("LEP_HUFFDEC_PAR")) : (c == chunks[0].get() ? 16 : 0);
             if (par >= 2) {
                 std::vector<lep_huffdec_image> many, one;
                 for (const lep_huffdec_image& hi : launch) (hi.rsti ? one : many).push_back(hi);

@@ -76,40 +76,6 @@ __global__ __launch_bounds__(64) void lep_segment_kernel(const ImageDev* __restr
     bins[s] = sc.nbins;
 }
 
-// EXPERIMENT (LEP_ENCODE_KERNEL=5 / LEP_DECODE_KERNEL=5): the same single-lane coder, but every LANE of a wavefront codes its own
-// thread segment (SIMT: 64 segments per wavefront).  The serial chain of a segment keeps one lane busy instead of one
-// wavefront, so a launch needs 64x the segments to fill the chip; measures what lane-per-segment costs in divergence.
-__global__ void lep_reset_models_kernel(uint32_t* models, size_t words_per_model, size_t stride, int nseg, NSum* ns_area, size_t ns_words) {
-    const uint4 init = make_uint4(kBranchInit, kBranchInit, kBranchInit, kBranchInit);
-    const size_t per = words_per_model / 4, total = per * (size_t)nseg;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t sgm = i / per, k = i - sgm * per;
-        reinterpret_cast<uint4*>(models + sgm * stride)[k] = init;
-    }
-    uint32_t* n32 = reinterpret_cast<uint32_t*>(ns_area);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns_words; i += (size_t)gridDim.x * blockDim.x) n32[i] = 0;
-}
-template <bool DEC>
-__global__ __launch_bounds__(64) void lep_segment_simt_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs, int nseg,
-                                                              uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
-                                                              uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
-    const int s = (int)blockIdx.x * 64 + (int)threadIdx.x;
-    if (s >= nseg) return;
-    const SegDev seg = segs[s];
-    const ImageDev* img = images + seg.image;
-    SegmentCoder<DEC> sc;
-    if (DEC) sc.bc.init_stream(streams + seg.stream_off, stream_len[s]);
-    else sc.bc.init_stream(streams + seg.stream_off, seg.stream_cap);
-    int rc = sc.run(img, seg, models + (size_t)s * kModelStride, ns_area + ns_offsets[s]);
-    if (!DEC) {
-        uint32_t n = finish_stream(sc.bc);
-        if (stream_overflow(sc.bc)) rc = LEP_BUFFER_TOO_SMALL;
-        stream_len[s] = n;
-    }
-    status[s] = rc;
-    bins[s] = sc.nbins;
-}
-
 // v2 encoder: wave-cooperative (lep_enc2.h); same arguments as lep_segment_kernel<false>
 __global__ __launch_bounds__(64) void lep_encode_v2_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
                                                            uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
@@ -480,13 +446,6 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         hipLaunchKernelGGL(lep_encode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
                            (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
-    } else if ((DEC ? g->decode_kernel : g->encode_kernel) == 5) {
-        g->last_kernel = DEC ? "lep_segment_simt_kernel<decode>" : "lep_segment_simt_kernel<encode>";
-        hipLaunchKernelGGL(lep_reset_models_kernel, dim3(4096), dim3(256), 0, st, (uint32_t*)g->arena[g->cur].d_models, (size_t)kModelBranches, (size_t)kModelStride, nseg,
-                           (NSum*)g->arena[g->cur].d_ns, (size_t)ns_total * (sizeof(NSum) / 4));
-        hipLaunchKernelGGL(lep_segment_simt_kernel<DEC>, dim3((nseg + 63) / 64), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                           (const SegDev*)(meta + o_seg), nseg, (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
-                           d_streams, d_stream_len, d_status, g->d_bins);
     } else {
         g->last_kernel = DEC ? "lep_segment_kernel<decode>" : "lep_segment_kernel<encode>";
         hipLaunchKernelGGL(lep_segment_kernel<DEC>, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
@@ -504,8 +463,8 @@ extern "C" {
 int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
-    if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = (atoi(e) >= 1 && atoi(e) <= 3) || atoi(e) == 5 ? atoi(e) : 3;
-    if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) >= 1 && atoi(e) <= 5 ? atoi(e) : 4;
+    if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3;
+    if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 4;
     if (const char* e = getenv("LEP_DEC3_WAVES")) g->dec3_waves = atoi(e);
     if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 7 ? 7 : 8;
     int n = 0;

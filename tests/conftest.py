@@ -14,18 +14,6 @@ REF_IMAGES = "/root/reference/images"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs an MI355X (run by the driver with -m gpu)")
-    config.addinivalue_line("markers", "gpu_experimental: opt-in kernels that have not been through a GPU visit yet; run by hand under `timeout` (scripts/gpu_huffpar.sh), never by -m gpu")
-
-
-def pytest_collection_modifyitems(config, items):
-    # gpu_experimental tests only run when asked for by name (-m gpu_experimental): neither the CPU run (-m "not gpu") nor the
-    # GPU run (-m gpu) may pick up a kernel that has not been through a supervised hardware visit
-    if "gpu_experimental" in (config.option.markexpr or ""):
-        return
-    skip = pytest.mark.skip(reason="opt-in: -m gpu_experimental (scripts/gpu_huffpar.sh)")
-    for item in items:
-        if "gpu_experimental" in item.keywords:
-            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session", autouse=True)

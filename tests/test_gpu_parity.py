@@ -374,3 +374,16 @@ def test_gpu_hostile_handoff_sizes_do_not_size_the_arena(gpu_codec):
     assert st[0] == 0 and st[-1] == 0 and back[0] == golden("c420_160x120")[0] and back[-1] == golden("c444_96x80")[0]
     assert st[2] == 1 and st[3] == 1              # more hand-offs than stream ids: the reference dies in an assertion
     assert st[1] != 0 or back[1] == jpg            # absurd sizes (the reference segfaults on them): refused, or restored right
+
+
+@pytest.mark.parametrize("nsub", ["0", "4", "16", "32"])
+def test_gpu_parallel_huffman_decode_in_the_compress_pipeline(gpu_codec, monkeypatch, nsub):
+    """n wavefronts per image decode the JPEG scan (lep_huffdec_par.h; the default for a call's first chunk is 16,
+    LEP_HUFFDEC_PAR forces n for every chunk, 0 = the single-wave kernel) -- same .lep bytes as the reference's"""
+    names = golden_cases()
+    jpgs = [golden(n)[0] for n in names] + [corpus.synth_jpeg(1280, 720, 61), corpus.synth_jpeg(640, 480, 62, quality=97)]
+    monkeypatch.setenv("LEP_HUFFDEC_PAR", nsub)
+    got, st, _ = gpu_codec.compress_batch(jpgs, chunk_images=12)
+    assert st == [0] * len(jpgs)
+    assert got[: len(names)] == [golden(n)[1] for n in names]
+    assert got[len(names):] == [gpu_codec.compress(j) for j in jpgs[len(names):]]
