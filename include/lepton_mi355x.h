@@ -212,6 +212,14 @@ int lep_jpeg_check_restores(const lep_jpeg *j, const uint8_t *lepdata, size_t le
 
 /* .lep -> streams + frame geometry (read_ujpg, src/lepton/jpgcoder.cc:4117-4362) */
 int lep_file_open(const uint8_t *lepdata, size_t len, lep_file **out);
+/* Format versions >= 2 (brotli header, `lepton -brotliheader`) mark the end of their packets, so several files may follow
+ * each other in one stream and restore the concatenation of their JPEGs (jpgcoder.cc:1868-1897): lep_file_consumed = bytes
+ * the parsed file occupies; lep_chained_file_follows = another file's magic stands behind them; lep_file_open_next parses
+ * it, handing over what `prev` left in the shared header reader (the "CNT" sections `lepton -lepcat` writes,
+ * concat.cc:84-95).  lep_decompress walks such streams itself. */
+size_t lep_file_consumed(const lep_file *f);
+int lep_chained_file_follows(const uint8_t *lepdata, size_t len, size_t consumed);
+int lep_file_open_next(const uint8_t *lepdata, size_t len, const lep_file *prev, lep_file **out);
 void lep_file_close(lep_file *f);
 int lep_file_describe(lep_file *f, lep_image_desc *desc);                /* allocates zeroed host frame */
 int lep_file_describe_into(lep_file *f, void *frame_mem, size_t frame_cap, lep_image_desc *desc);   /* frame in caller memory; (NULL, (size_t)-1) = geometry only */

@@ -78,11 +78,15 @@ class JpegImage:
 class LepFile:
     """A parsed .lep: streams + frame geometry; the frame is filled by GpuCodec.decode."""
 
-    def __init__(self, data):
+    def __init__(self, data, prev=None):
+        """prev: the previous file of a chained stream of format-version >= 2 files (see lep_stream); it hands over the header
+        bytes a `lepton -lepcat` file keeps for its successors"""
         self._L = abi.lib()
         self.data = bytes(data)
         self.handle = C.c_void_p()
-        _check(self._L.lep_file_open(self.data, len(self.data), C.byref(self.handle)), "lep_file_open")
+        _check(self._L.lep_file_open_next(self.data, len(self.data), prev.handle if prev else None, C.byref(self.handle)), "lep_file_open")
+        self.consumed = self._L.lep_file_consumed(self.handle)
+        self.more = bool(self._L.lep_chained_file_follows(self.data, len(self.data), self.consumed))
         self.desc = abi.ImageDesc()
         _check(self._L.lep_file_describe(self.handle, C.byref(self.desc)), "lep_file_describe")
         segs = (abi.Segment * abi.MAX_SEGMENTS)()
@@ -108,6 +112,19 @@ class LepFile:
             self.close()
         except Exception:
             pass
+
+
+def lep_stream(data):
+    """the files of a stream of .lep files written back to back (`cat a.lep b.lep | lepton -`, jpgcoder.cc:1868-1897)"""
+    data = bytes(data)
+    off, prev, out = 0, None, []
+    while True:
+        f = LepFile(data[off:], prev)
+        out.append(f)
+        if not f.more:
+            return out
+        off += f.consumed
+        prev = f
 
 
 class GpuCodec:

@@ -196,7 +196,9 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
         g.overhang = (uint32_t)th.overhang_byte | ((uint32_t)th.num_overhang_bits << 8);
         memcpy(g.last_dc, th.last_dc, sizeof g.last_dc);
         const size_t room = plan->scan_bound - plan->head.size();
-        size_t cap = s == 0 ? room : (th.segment_size ? (size_t)th.segment_size : max_file_size);
+        // format version 1 leaves the first thread's output unbounded; from version 2 on every thread is bound by its
+        // segment size (recode_physical_thread, recoder.cc:598-613)
+        size_t cap = (s == 0 && lf->version == 1) ? room : (th.segment_size ? (size_t)th.segment_size : max_file_size);
         // segment_size comes from an untrusted header (up to 4 GB per hand-off) and sizes a pinned + device arena slot in
         // the batch pipeline: never reserve more than the file may hold, nor more than the segment's blocks can possibly
         // code to -- 64 coefficients x (16-bit code + 11 magnitude bits) = 216 bytes, every one of them 0xFF and stuffed,
@@ -286,6 +288,10 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
         BoundedOut seg;
         BoundedOut* o = &out;
         if (s > 0 && !legacy) { seg.bound = th.segment_size ? th.segment_size : max_file_size; o = &seg; }
+        // version >= 2: the first thread is bound by its segment size too (recoder.cc:598-613: new_bound = bytes_written +
+        // segment_size, applied when it is tighter than the file's)
+        const size_t file_bound = out.bound;
+        if (s == 0 && !legacy && lf->version > 1 && out.buf.size() + (size_t)th.segment_size < file_bound) out.bound = out.buf.size() + th.segment_size;
         BitWriter w;
         w.fillbit = (uint8_t)jf.padbit;
         w.seed(th.overhang_byte, th.num_overhang_bits);
@@ -303,6 +309,7 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
         carry.num_overhang_bits = (uint8_t)w.overhang_bits();
         memcpy(carry.last_dc, lastdc, sizeof lastdc);
         if (o == &seg) out.write(seg.buf.data(), seg.buf.size());
+        else if (out.bound != file_bound) { out.bound = file_bound; out.attempted = out.buf.size(); }
     }
 
     // 3. wrongly placed RST markers at the end of the scan, then the rest of the header, then garbage

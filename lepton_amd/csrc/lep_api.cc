@@ -197,9 +197,13 @@ int lep_jpeg_write_lep(const lep_jpeg* j, int max_threads, const lep_bytes* stre
     return to_bytes(file, out);
 }
 
-int lep_file_open(const uint8_t* d, size_t len, lep_file** out) {
+int lep_file_open(const uint8_t* d, size_t len, lep_file** out) { return lep_file_open_next(d, len, nullptr, out); }
+
+size_t lep_file_consumed(const lep_file* f) { return f->lf.consumed; }
+
+int lep_file_open_next(const uint8_t* d, size_t len, const lep_file* prev, lep_file** out) {
     std::unique_ptr<lep_file> f(new lep_file);
-    int rc = lep::parse_lep(d, len, &f->lf);
+    int rc = lep::parse_lep(d, len, &f->lf, prev ? &prev->lf.pending_header : nullptr);
     if (rc) return rc;
     lep::JpegFile& jf = f->lf.jpeg;
     memset(jf.qtables, 0, sizeof jf.qtables);
@@ -406,21 +410,46 @@ int lep_batch_plan(const size_t* file_bytes, const size_t* frame_bytes, int n, c
     return nchunks;
 }
 
+// A stream of format-version >= 2 files back to back restores the concatenation of their JPEGs (`cat a.lep b.lep | lepton -`,
+// jpgcoder.cc:1868-1897, test_suite/test_concat.sh): after each file the reader looks for another header behind the size
+// trailer.  A version-1 file runs to the end of the input, so nothing can follow it.
 int lep_decompress(lep_gpu* g, const uint8_t* lepdata, size_t len, lep_bytes* out) {
     if (!g) return LEP_GPU_ERROR;
-    lep_file* f = nullptr;
-    int rc = lep_file_open(lepdata, len, &f);
-    if (rc) return rc;
-    std::unique_ptr<lep_file> hold(f);
-    lep_image_desc d;
-    lep_file_describe(f, &d);
-    lep_segment segs[LEP_MAX_SEGMENTS];
-    lep_bytes streams[LEP_MAX_SEGMENTS];
-    int32_t status[LEP_MAX_SEGMENTS];
-    int n = lep_file_segments(f, segs, streams, 0);
-    rc = lep_gpu_decode_host(g, &d, 1, segs, n, streams, status);
-    if (rc) return rc;
-    return lep_file_recode(f, out);
+    std::vector<uint8_t> all;
+    std::unique_ptr<lep_file> prev;
+    size_t off = 0;
+    int files = 0;
+    for (;;) {
+        lep_file* f = nullptr;
+        int rc = lep_file_open_next(lepdata + off, len - off, prev.get(), &f);
+        if (rc) return rc;
+        std::unique_ptr<lep_file> hold(f);
+        lep_image_desc d;
+        lep_file_describe(f, &d);
+        lep_segment segs[LEP_MAX_SEGMENTS];
+        lep_bytes streams[LEP_MAX_SEGMENTS];
+        int32_t status[LEP_MAX_SEGMENTS];
+        int n = lep_file_segments(f, segs, streams, 0);
+        rc = lep_gpu_decode_host(g, &d, 1, segs, n, streams, status);
+        if (rc) return rc;
+        const size_t used = lep_file_consumed(f);
+        const bool more = lep_chained_file_follows(lepdata + off, len - off, used);
+        if (!files && !more) return lep_file_recode(f, out);   // the usual case: one file, no copy
+        lep_bytes one = {nullptr, 0, 0};
+        rc = lep_file_recode(f, &one);
+        if (rc) return rc;
+        all.insert(all.end(), one.data, one.data + one.len);
+        lep_free(one.data);
+        ++files;
+        if (!more) break;
+        off += used;
+        prev = std::move(hold);
+    }
+    return to_bytes(all, out);
+}
+
+int lep_chained_file_follows(const uint8_t* lepdata, size_t len, size_t consumed) {
+    return consumed + 2 <= len && lepdata[consumed] == 0xCF && lepdata[consumed + 1] == 0x84 ? 1 : 0;
 }
 
 }  // extern "C"

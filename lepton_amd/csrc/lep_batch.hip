@@ -664,10 +664,16 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     for (int i = 0; i < n; ++i) { outs[i].data = nullptr; outs[i].len = outs[i].cap = 0; status[i] = 0; }
     HandleVector<lep_file, lep_file_close> files(n);
     std::vector<size_t> fbytes(n, 0);
+    std::vector<char> chained(n, 0);
     {
         const double t0 = now_s();
         parallel_for(n, threads, [&](int i) {
             int rc = lep_file_open(leps[i].data, leps[i].len, &files[i]);
+            if (!rc && lep_chained_file_follows(leps[i].data, leps[i].len, lep_file_consumed(files[i]))) {
+                chained[i] = 1;   // a stream of several v2+ files: the per-file path walks it once the pipeline has drained
+                lep_file_close(files[i]); files[i] = nullptr;
+                return;
+            }
             if (!rc) fbytes[i] = (lep_file_frame_bytes(files[i]) + 255) & ~(size_t)255;
             if (rc) { status[i] = rc; if (files[i]) { lep_file_close(files[i]); files[i] = nullptr; } }
         });
@@ -868,6 +874,9 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     if (writer.joinable()) writer.join();
     st.pipeline_s = now_s() - t_pipe;
     for (int i = 0; i < n; ++i) if (files[i]) { lep_file_close(files[i]); files[i] = nullptr; }
+    if (!rc_all)
+        for (int i = 0; i < n; ++i)
+            if (chained[i]) status[i] = lep_decompress(g, leps[i].data, leps[i].len, &outs[i]);
     st.alloc_s = g_alloc_s;
     st.wall_s = now_s() - t_begin;
     if (stats) *stats = st;

@@ -7,10 +7,12 @@
 //                         slice order src/lepton/vp8_encoder.cc:575-594; size trailer :602-614
 #include "lep_container.h"
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 namespace lep {
 
@@ -184,6 +186,62 @@ static bool unzlib(const uint8_t* d, size_t n, size_t limit, std::vector<uint8_t
     return true;
 }
 
+// Headers of format versions >= 2 are brotli streams (`lepton -brotliheader`, jpgcoder.cc:1116-1119, 4038, 4172;
+// src/io/BrotliCompression.cc:100-150).  The reference vendors brotli 1.0.0; decoding is version-independent (RFC 7932), so
+// the system's libbrotlidec is bound at first use.  Without it such files are refused with VERSION_UNSUPPORTED, loudly.
+namespace {
+struct BrotliDec {
+    void* lib = nullptr;
+    void* (*create)(void*, void*, void*) = nullptr;
+    int (*stream)(void*, size_t*, const uint8_t**, size_t*, uint8_t**, size_t*) = nullptr;
+    void (*destroy)(void*) = nullptr;
+    bool ok = false;
+};
+const BrotliDec& brotli_dec() {
+    static BrotliDec b;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        for (const char* name : {"libbrotlidec.so.1", "libbrotlidec.so"}) {
+            b.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (b.lib) break;
+        }
+        if (!b.lib) return;
+        b.create = (void* (*)(void*, void*, void*))dlsym(b.lib, "BrotliDecoderCreateInstance");
+        b.stream = (int (*)(void*, size_t*, const uint8_t**, size_t*, uint8_t**, size_t*))dlsym(b.lib, "BrotliDecoderDecompressStream");
+        b.destroy = (void (*)(void*))dlsym(b.lib, "BrotliDecoderDestroyInstance");
+        b.ok = b.create && b.stream && b.destroy;
+    });
+    return b;
+}
+}  // namespace
+
+bool brotli_available() { return brotli_dec().ok; }
+
+// BrotliCodec::Decompress: the whole input must be one complete stream (left-over input is an error), output bounded
+static bool unbrotli(const uint8_t* d, size_t n, size_t limit, std::vector<uint8_t>* out) {
+    const BrotliDec& b = brotli_dec();
+    if (!b.ok) return false;
+    void* st = b.create(nullptr, nullptr, nullptr);
+    if (!st) return false;
+    out->clear();
+    uint8_t buf[65536];
+    size_t avail_in = n, total = 0;
+    const uint8_t* next_in = d;
+    bool good = false;
+    for (;;) {
+        size_t avail_out = sizeof buf;
+        uint8_t* next_out = buf;
+        const int r = b.stream(st, &avail_in, &next_in, &avail_out, &next_out, &total);   // 0 error, 1 success, 2 more input, 3 more output
+        out->insert(out->end(), buf, buf + (sizeof buf - avail_out));
+        if (out->size() > limit) break;
+        if (r == 1) { good = avail_in == 0; break; }
+        if (r == 3) continue;
+        break;   // error, or the input ended inside the stream
+    }
+    b.destroy(st);
+    return good;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Multiplexer: same packetisation policy as MuxWriter, expressed over per-stream pending queues.
 namespace {
@@ -290,11 +348,14 @@ int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::v
 }
 
 // ------------------------------------------------------------------------------------------------
-void demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vector<uint8_t>>* streams) {
+// returns the offset behind the last packet taken; *saw_eof: stopped on the end marker FF FE FF that format versions >= 2
+// write behind the packets (MuxWriter::Close, MuxReader.hh:507-517) -- the marker itself is not consumed
+size_t demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vector<uint8_t>>* streams, bool* saw_eof) {
     streams->assign(16, {});
+    if (saw_eof) *saw_eof = false;
     while (at + 3 <= n) {
         uint8_t h = d[at];
-        if (d[at] == 0xFF && d[at + 1] == 0xFE && d[at + 2] == 0xFF) break;
+        if (d[at] == 0xFF && d[at + 1] == 0xFE && d[at + 2] == 0xFF) { if (saw_eof) *saw_eof = true; break; }
         int id = h & 15, fl = (h >> 4) & 3;
         size_t len, hl;
         if (fl == 0) { len = (size_t)d[at + 1] + ((size_t)d[at + 2] << 8) + 1; hl = 3; }
@@ -303,21 +364,35 @@ void demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vecto
         (*streams)[id].insert((*streams)[id].end(), d + at + hl, d + at + hl + len);
         at += hl + len;
     }
+    return at;
 }
 
-int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
+// carried: what a previous file of the same stream left in the header reader behind a "CNT" section (`lepton -lepcat`
+// merges the headers of all its inputs into the first file's, concat.cc:67-108); this file then has no header of its own
+int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t>* carried) {
+    if (n >= 2 && n < 28 && d[0] == 0xCF && d[1] == 0x84) return EX_SHORT_READ;   // read_fixed_ujpg_header: ReadFull(22) != 22
     if (n < 28 || d[0] != 0xCF || d[1] != 0x84) return EX_VERSION_UNSUPPORTED;
     lf->version = d[2];
     lf->flag = d[3];
     lf->nthreads = d[4];
-    if (lf->version != 1) return EX_VERSION_UNSUPPORTED;   // v2+ (brotli header) is not produced by the default encoder
+    lf->consumed = n;
+    if (lf->version < 1 || lf->version > 4) return EX_VERSION_UNSUPPORTED;   // read_fixed_ujpg_header, jpgcoder.cc:2148-2153
     if (lf->nthreads == 0) return EX_ASSERTION_FAILURE;    // always_assert(num_threads_hint != 0), jpgcoder.cc:2168
+    if (lf->version == 3) return EX_ASSERTION_FAILURE;     // ANS-coded streams: "ANS compile flag not selected" (jpgcoder.cc:461-468)
     lf->jpeg_size = get_le32(d + 20);
     uint32_t zsize = get_le32(d + 24);
     if (zsize > (128u << 20) || lf->jpeg_size > (128u << 20)) return EX_ASSERTION_FAILURE;   // "Only support images < 128 megs" (jpgcoder.cc:4133-4136)
     if (28 + (uint64_t)zsize + 3 > n) return EX_SHORT_READ;
     std::vector<uint8_t> p;
-    if (!unzlib(d + 28, zsize, (size_t)lf->jpeg_size + 2048, &p)) return EX_STREAM_INCONSISTENT;
+    if (carried && !carried->empty()) {   // header_reader != NULL: the compressed header bytes are not even read (jpgcoder.cc:4139)
+        p = *carried;
+        zsize = 0;
+    } else if (lf->version == 1) {
+        if (!unzlib(d + 28, zsize, (size_t)lf->jpeg_size + 2048, &p)) return EX_STREAM_INCONSISTENT;
+    } else {
+        if (!brotli_available()) return EX_VERSION_UNSUPPORTED;   // no libbrotlidec on this host: said loudly, never guessed
+        if (!unbrotli(d + 28, zsize, (size_t)lf->jpeg_size * 2 + ((size_t)128 << 20), &p)) return EX_STREAM_INCONSISTENT;
+    }
     size_t pos = 0;
     auto need = [&](size_t k) { return pos + k <= p.size(); };
     JpegFile& jf = lf->jpeg;
@@ -376,7 +451,10 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
             for (int i = 0; i < 4; ++i) jf.max_dpos[i] = (int)get_le32(m + 15 + 4 * i);
             jf.early_eof = true;
             pos += 31;
-        } else if (!memcmp(m, "CMP", 3) || !memcmp(m, "CNT", 3)) {
+        } else if (!memcmp(m, "CNT", 3)) {   // the rest of this header belongs to the next file of the stream
+            lf->pending_header.assign(p.begin() + pos + 3, p.end());
+            break;
+        } else if (!memcmp(m, "CMP", 3)) {
             break;
         } else {
             return EX_UNSUPPORTED_JPEG;   // "unknown data found": errorlevel 2 (jpgcoder.cc:4326-4337)
@@ -413,7 +491,12 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf) {
     // decoder was started with: `num_threads_needed > NUM_THREADS` -> CODING_ERROR (vp8_decoder.cc:415-417), NUM_THREADS =
     // min(8, thread hint) (read_fixed_ujpg_header, jpgcoder.cc:2167-2171)
     if (!baseline_recoder && lf->segs.size() > (size_t)std::min(lf->nthreads, 8)) return EX_CODING_ERROR;
-    demux_packets(d, n, at, &lf->streams);
+    bool saw_eof = false;
+    const size_t end = demux_packets(d, n, at, &lf->streams, &saw_eof);
+    // Format versions >= 2 end their packets with a marker, so the reader knows where the file stops: 3 marker bytes, the
+    // 4-byte size trailer, and whatever follows is the next file of a chained stream (`cat a.lep b.lep | lepton -`,
+    // jpgcoder.cc:1881-1897, test_suite/test_concat.sh).  Version 1 has no marker: its reader runs to the end of the input.
+    if (lf->version > 1 && saw_eof && end + 7 <= n) lf->consumed = end + 7;
     return 0;
 }
 

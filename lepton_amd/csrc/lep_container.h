@@ -25,6 +25,8 @@ struct LepFile {
     bool has_prefix = false, embedded = false;
     std::vector<uint8_t> prefix_garbage;
     std::vector<std::vector<uint8_t>> streams;   // de-multiplexed, index = stream id = segment index
+    size_t consumed = 0;                         // bytes of the input this file occupies (less than the input for a chained stream of v2+ files)
+    std::vector<uint8_t> pending_header;         // header bytes behind a "CNT" section: they belong to the next file of the stream
 };
 
 std::vector<Handoff> plan_segments(const JpegFile& jf, const EncodeOptions& opt);
@@ -33,8 +35,9 @@ bool deserialize_handoffs(const uint8_t* d, size_t n, std::vector<Handoff>* out)
 void mux_streams(const std::vector<std::vector<uint8_t>>& streams, int version, std::vector<uint8_t>* out);
 int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::vector<std::vector<uint8_t>>& streams,
               std::vector<uint8_t>* out);
-int parse_lep(const uint8_t* d, size_t n, LepFile* lf);
-void demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vector<uint8_t>>* streams);
+int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t>* carried = nullptr);
+size_t demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vector<uint8_t>>* streams, bool* saw_eof = nullptr);
+bool brotli_available();
 
 // decode side (jpeg_recode.cc): coefficients -> JPEG bytes
 int recode_jpeg(LepFile* lf, std::vector<uint8_t>* out);

@@ -18,7 +18,7 @@ HOST_SOURCES = ["lep_api.cc", "jpeg_scan.cc", "jpeg_progressive.cc", "lep_contai
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("fuzz") / "host_fuzz")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
-           "-o", exe, os.path.join(FUZZ, "host_fuzz.cc")] + [os.path.join(CSRC, s) for s in HOST_SOURCES] + ["-lz"]
+           "-o", exe, os.path.join(FUZZ, "host_fuzz.cc")] + [os.path.join(CSRC, s) for s in HOST_SOURCES] + ["-lz", "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("no sanitizer runtime for g++ here: " + r.stderr[-200:])
