@@ -119,15 +119,41 @@ def cpu_baseline(jpgs, budget_s=20.0):
 
 
 def pmc_traffic(kernel, images):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes
-    (profiles/pmc_traffic.json, written by scripts/gpu_round.sh), scaled from that run's batch to this one; None when
-    the kernel has not been through a PMC pass."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 passes (profiles/pmc_traffic.json: memory-side request
+    counters TCC_EA0_RDREQ x 64 B + TCC_EA0_WRREQ by size, separate --pmc passes, scripts/gpu_r2_visit1.sh), scaled from that
+    run's batch to this one; None when the kernel has not been through a PMC pass.  A table lookup, not a measurement of this
+    run: the entry names the kernel build it was taken from."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
         per_image = table[kernel.split("<")[0]]["hbm_bytes_per_image"]
         return int(per_image * images)
     except Exception:
         return None
+
+
+def pmc_bound(kernel):
+    """what the counters say bounds `kernel` (profiles/pmc_traffic.json: L2 hit rate, wave time split)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"][kernel.split("<")[0]].get("bound")
+    except Exception:
+        return None
+
+
+def pipeline_figure(codec, jpgs, label, verify=False):
+    """JPEG files in host memory -> .lep files in host memory and back through the batch pipeline; one warm-up call (staging
+    buffers, kernel images), one timed call each way; every file must come back bit-exact"""
+    mb = sum(map(len, jpgs)) / 1e6
+    warm, st0, _ = codec.compress_batch(jpgs, verify=verify)
+    assert not any(st0), sorted(set(st0))
+    codec.decompress_batch(warm)
+    del warm
+    leps, st1, cs = codec.compress_batch(jpgs, verify=verify)
+    back, st2, ds = codec.decompress_batch(leps)
+    assert not any(st1) and not any(st2) and back == jpgs, label + ": round trip is not bit exact"
+    return {"workload": label, "jpeg_MB": round(mb, 1), "lep_MB": round(sum(map(len, leps)) / 1e6, 1), "files": len(jpgs),
+            "compress_MBps": round(mb / cs["wall_s"], 1), "decompress_MBps": round(mb / ds["wall_s"], 1),
+            "value": round(2 * mb / (cs["wall_s"] + ds["wall_s"]), 1), "files_per_s": round(2 * len(jpgs) / (cs["wall_s"] + ds["wall_s"]), 1),
+            "parity": "every file restored bit-exact", "_cs": cs, "_ds": ds}
 
 
 def main():
@@ -137,7 +163,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images", type=int, default=1024,
                     help="4K images per GPU per step (8 thread segments each; 1024 = 8192 segments = 8 wavefronts per SIMD)")
-    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic images per GPU (replicated up to --images)")
+    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic images per GPU (replicated up to --images)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary corpora (skewed, 1080p, progressive) and the latency table")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -269,25 +296,71 @@ def main():
     parity = "roundtrip-only"
     try:
         import oracle_binding as ob
-        want, bins = ob.oracle_encode(imgs[0].desc, plans[0])
+        from concurrent.futures import ThreadPoolExecutor
+
+        ob.oracle()
+        nchk = min(nimg, nuniq)
+        with ThreadPoolExecutor(min(16, len(os.sched_getaffinity(0)))) as ex:   # the oracle runs outside the GIL (ctypes)
+            wants = list(ex.map(lambda k: ob.oracle_encode(imgs[order[k]].desc, plans[order[k]]), range(nchk)))
         base = 0
-        for i, w in enumerate(want):
-            buf = C.create_string_buffer(lens[base + i])
-            L.lep_gpu_memcpy_d2h(g, buf, d_streams + offs[base + i], lens[base + i])
-            assert buf.raw == w, "GPU stream %d differs from the oracle" % i
-        parity = "streams==oracle(image 0) + exact round trip(all unique images)"
-        bins_per_image = bins
+        for k in range(nchk):            # every DISTINCT image: byte-equal streams, segment by segment
+            for i, w in enumerate(wants[k][0]):
+                buf = C.create_string_buffer(max(1, lens[base + i]))
+                L.lep_gpu_memcpy_d2h(g, buf, d_streams + offs[base + i], lens[base + i])
+                assert buf.raw[: lens[base + i]] == w, "GPU stream %d of image %d differs from the oracle" % (i, k)
+            base += len(plans[order[k]])
+        parity = "streams==oracle(all %d distinct images) + exact round trip(all distinct images)" % nchk
+        bins_per_image = sum(w[1] for w in wants) / nchk
     except ImportError:
         bins_per_image = None
+
+    # ---- latency (configs[1]: ONE 4K image, then small batches): a thread segment is one serial chain whatever the batch, so
+    # the chip is as slow for 1 image as for 1024 -- stated next to the reference's own per-image times (cpu_baseline below)
+    latency = None
+    if world == 1 and not args.no_extras:
+        latency = {"unit": "ms, device-resident frames, launch + kernel + sync (best of 3)", "encode": {}, "decode": {}}
+        for nb in (1, 8, 64):
+            if nb > nimg:
+                break
+            ns = sum(len(plans[order[k]]) for k in range(nb))
+            best_e = best_d = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                assert L.lep_gpu_encode_device(g, descs, nb, segs, ns, d_streams, offs, d_len, d_status, None) == 0
+                L.lep_gpu_sync(g)
+                t1 = time.perf_counter()
+                assert L.lep_gpu_decode_device(g, dec_descs, nb, segs, ns, d_streams, offs, d_len, d_status, None) == 0
+                L.lep_gpu_sync(g)
+                t2 = time.perf_counter()
+                best_e = min(best_e, t1 - t0); best_d = min(best_d, t2 - t1)
+            latency["encode"]["%d_image%s" % (nb, "" if nb == 1 else "s")] = round(best_e * 1e3, 1)
+            latency["decode"]["%d_image%s" % (nb, "" if nb == 1 else "s")] = round(best_d * 1e3, 1)
+        t0 = time.perf_counter(); one = codec.compress(uniq[0]); t1 = time.perf_counter(); assert codec.decompress(one) == uniq[0]; t2 = time.perf_counter()
+        latency["whole_file_host_to_host"] = {"compress_ms": round((t1 - t0) * 1e3, 1), "decompress_ms": round((t2 - t1) * 1e3, 1),
+                                              "note": "lep_compress / lep_decompress of one 4K JPEG: host Huffman + PCIe + kernels + container"}
 
     for k in range(nimg):   # the resident frames are no longer needed; the end-to-end measurement wants the memory
         for c in range(imgs[order[k]].desc.ncomp):
             L.lep_gpu_free(g, descs[k].blocks[c]); L.lep_gpu_free(g, dec_descs[k].blocks[c])
     L.lep_gpu_free(g, d_streams)
 
-    agg = shard.aggregate({"jpeg_bytes": jpeg_bytes, "images": nimg, "segments": nseg, "blocks": nblocks,
-                           "stream_bytes": stream_bytes, "elapsed_max": elapsed, "enc_ms_max": enc_ms, "dec_ms_max": dec_ms},
-                          backend_device=("cuda:%d" % local_rank) if dist else None)
+    # PCIe- and host-inclusive companion figure (never `value`): JPEG files in host memory -> .lep files in host memory and
+    # back through the batch pipeline (host split, GPU Huffman decode, GPU arithmetic coding, containers on the host pool; and
+    # the mirror image).  Every rank runs it on its own files; rank 0 reports the aggregate.
+    e2e = None
+    e2e_local = {"e2e_bytes": 0.0, "e2e_c_s_max": 0.0, "e2e_d_s_max": 0.0}
+    if not args.no_end_to_end:
+        try:
+            n_e2e = args.e2e_images if world == 1 else min(args.e2e_images, 1024)
+            e2e = pipeline_figure(codec, [uniq[i % nuniq] for i in range(n_e2e)],
+                                  "%d of the bench's 4K JPEGs per GPU, host memory -> host memory (lep_compress_batch / lep_decompress_batch), staging warm (second call)" % n_e2e)
+            e2e_local = {"e2e_bytes": e2e["jpeg_MB"] * 1e6, "e2e_c_s_max": e2e["_cs"]["wall_s"], "e2e_d_s_max": e2e["_ds"]["wall_s"]}
+        except Exception as e:   # the headline figure must not depend on it
+            e2e = {"error": repr(e)[:300]}
+    local = {"jpeg_bytes": jpeg_bytes, "images": nimg, "segments": nseg, "blocks": nblocks,
+             "stream_bytes": stream_bytes, "elapsed_max": elapsed, "enc_ms_max": enc_ms, "dec_ms_max": dec_ms}
+    local.update(e2e_local)
+    agg = shard.aggregate(local, backend_device=("cuda:%d" % local_rank) if dist else None)
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -302,6 +375,7 @@ def main():
     dominant = "decode" if dec_kernel_s >= enc_kernel_s else "encode"
     dom_s = max(enc_kernel_s, dec_kernel_s)
     achieved = b_alg / dom_s / 1e9
+    traffic = pmc_traffic(names.get(dominant, ""), args.images)
     out = {
         "metric": "encode+decode MB/s (JPEG bytes/sec), bit-exact round trip", "value": round(value, 3), "unit": "MB/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(t / K * 1e3, 3),
@@ -313,42 +387,50 @@ def main():
                    "parallelism": "image-sharded x%d, one wavefront per thread segment" % world, "parity": parity},
         "encode_MBps": round(mb / (agg["enc_ms_max"] / K / 1e3), 3), "decode_MBps": round(mb / (agg["dec_ms_max"] / K / 1e3), 3),
         "roofline": {"bound": "hbm", "kernel": names.get(dominant, dominant), "achieved": round(achieved, 4), "peak": 8000.0,
-                     "unit": "GB/s", "frac": round(achieved / 8000.0, 7), "traffic": pmc_traffic(names.get(dominant, ""), args.images),
+                     "unit": "GB/s", "frac": round(achieved / 8000.0, 7), "traffic": traffic,
+                     "traffic_frac": round(traffic / dom_s / 8e12, 4) if traffic else None,   # measured HBM bytes / kernel time / 8 TB/s
                      "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms": round(dom_s * 1e3, 3),
                      "encode_kernel_ms": round(enc_kernel_s * 1e3, 3), "decode_kernel_ms": round(dec_kernel_s * 1e3, 3),
-                     "kernels": names,
-                     "note": "instruction-issue / latency bound integer coder (19.4 M serially dependent bins per 4K image; one instruction per ~8 cycles per wavefront, ~1.4 instructions/cycle/CU), not bandwidth bound; traffic = PMC HBM bytes (profiles/pmc_traffic.json); see bins_per_s and DESIGN.md"},
+                     "kernels": names, "bound_by": pmc_bound(names.get(dominant, "")),
+                     "note": "frac = algorithmic bytes (128 B per block + stream bytes) / kernel time / 8 TB/s; traffic = HBM bytes from the memory-side request counters of the committed PMC passes (profiles/pmc_traffic.json), scaled to this batch; bound_by = what those passes say limits the kernel (instruction issue, not bandwidth: DESIGN.md 4)"},
     }
     if bins_per_image:
         bins_launch = bins_per_image * args.images
         out["bins_per_s"] = {"encode": round(bins_launch / enc_kernel_s / 1e6, 1), "decode": round(bins_launch / dec_kernel_s / 1e6, 1), "unit": "Mbins/s (per GPU, image 0's bin count x images)"}
-    if world == 1 and not args.no_end_to_end:
-        # PCIe- and host-inclusive companion figure (never `value`): JPEG files in host memory -> .lep files in host memory
-        # and back through the batch pipeline: host split, GPU Huffman decode, GPU arithmetic coding, containers on the host
-        # pool; and the mirror image with the GPU Huffman re-encode.  Same corpus, replicated.
-        try:
-            ejpgs = [uniq[i % nuniq] for i in range(args.e2e_images)]
-            emb = sum(map(len, ejpgs)) / 1e6
-            warm, _, _ = codec.compress_batch(ejpgs)             # first call: staging buffers, kernel images
-            codec.decompress_batch(warm)
-            t0 = time.perf_counter()
-            leps, st1, cs = codec.compress_batch(ejpgs)
-            t1 = time.perf_counter()
-            back, st2, ds = codec.decompress_batch(leps)
-            t2 = time.perf_counter()
-            assert not any(st1) and not any(st2) and back == ejpgs, "end-to-end round trip is not bit exact"
-            out["end_to_end"] = {
-                "workload": "%d of the bench's 4K JPEGs, host memory -> host memory (lep_compress_batch / lep_decompress_batch), staging buffers warm (second call)" % len(ejpgs),
-                "compress_MBps": round(emb / cs["wall_s"], 1), "decompress_MBps": round(emb / ds["wall_s"], 1),
-                "value": round(2 * emb / (cs["wall_s"] + ds["wall_s"]), 1), "unit": "MB/s (JPEG bytes, compress + decompress; wall clock of the two C-ABI calls)",
-                "through_the_python_binding_MBps": {"compress": round(emb / (t1 - t0), 1), "decompress": round(emb / (t2 - t1), 1)},
-                "h2d_GB": round((cs["h2d_bytes"] + ds["h2d_bytes"]) / 1e9, 2), "d2h_GB": round((cs["d2h_bytes"] + ds["d2h_bytes"]) / 1e9, 2),
-                "host_pool_seconds": {"compress_parse": round(cs["parse_s"], 3), "compress_write": round(cs["write_s"], 3),
-                                      "decompress_parse": round(ds["parse_s"], 3), "decompress_write": round(ds["write_s"], 3)},
-                "note": "JPEG Huffman decode / re-encode on the GPU, host only splits files and writes containers; lep_bytes == reference for the fixtures (tests)",
-            }
-        except Exception as e:   # the headline figure must not depend on it
-            out["end_to_end"] = {"error": repr(e)[:300]}
+    if e2e is not None:
+        if "error" in e2e:
+            out["end_to_end"] = e2e
+        else:
+            cs, ds = e2e.pop("_cs"), e2e.pop("_ds")
+            emb = agg["e2e_bytes"] / 1e6
+            out["end_to_end"] = dict(e2e, **{
+                "compress_MBps": round(emb / agg["e2e_c_s_max"], 1), "decompress_MBps": round(emb / agg["e2e_d_s_max"], 1),
+                "value": round(2 * emb / (agg["e2e_c_s_max"] + agg["e2e_d_s_max"]), 1), "n_gpus": world,
+                "unit": "MB/s (JPEG bytes, compress + decompress; wall clock of the two C-ABI calls, max over ranks, bytes summed over ranks)",
+                "rank0_h2d_GB": round((cs["h2d_bytes"] + ds["h2d_bytes"]) / 1e9, 2), "rank0_d2h_GB": round((cs["d2h_bytes"] + ds["d2h_bytes"]) / 1e9, 2),
+                "rank0_host_pool_seconds": {"compress_parse": round(cs["parse_s"], 3), "compress_write": round(cs["write_s"], 3),
+                                            "decompress_parse": round(ds["parse_s"], 3), "decompress_write": round(ds["write_s"], 3)},
+                "note": "JPEG Huffman decode / re-encode on the GPU, host only splits files and writes containers; lep bytes == reference for the fixtures (tests)"})
+    if latency:
+        out["latency"] = latency
+    if world == 1 and not args.no_extras:
+        # secondary corpora through the same host-to-host pipeline: a photograph-like one (detail growing from top to bottom:
+        # thread segments of equal compressed size then differ several-fold in blocks), BASELINE.json configs[2] (1024 x 1080p)
+        # and configs[4] (4K progressive: Huffman layer on the host pool today)
+        extras = {}
+        for key, label, n, nu, kw in (
+                ("skewed", "1024 x 4K 4:2:0 baseline, photograph-like (corpus.synth_jpeg skew=2), 16 distinct", 1024, 16, dict(width=3840, height=2160, skew=2.0)),
+                ("c1080p", "1024 x 1080p 4:2:0 baseline (BASELINE.json configs[2]), 32 distinct", 1024, 32, dict(width=1920, height=1080)),
+                ("progressive", "256 x 4K 4:2:0 progressive (BASELINE.json configs[4]; -allowprogressive), 8 distinct", 256, 8, dict(width=3840, height=2160, progressive=True))):
+            try:
+                w, h = kw.pop("width"), kw.pop("height")
+                u = corpus.make_corpus(nu, w, h, 30001 + 1000 * len(extras), **kw)
+                fig = pipeline_figure(codec, [u[i % nu] for i in range(n)], label)
+                fig.pop("_cs"); fig.pop("_ds")
+                extras[key] = fig
+            except Exception as e:
+                extras[key] = {"workload": label, "error": repr(e)[:300]}
+        out["extra"] = extras
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(uniq)
         if cb:
