@@ -9,6 +9,7 @@
 // SIGQUIT, removing its socket files on the way out (cleanup_socket, socket_serve.cc:71-84).
 #include <signal.h>
 #include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -60,39 +61,54 @@ int main(int argc, char** argv) {
     if (o.time_bound_ms && !want_uds) { fprintf(stderr, "Time bound action only supported with UNIX domain sockets\n"); return 1; }   // jpgcoder.cc:1209-1212
     if (devices.size() > 1) {   // one process per GPU, each with its own sockets; this process only supervises
         if (want_uds && uds.empty()) { fprintf(stderr, "lepton_served: -devices needs -socket=<name> (children listen on <name>.<device>)\n"); return 1; }
-        std::vector<pid_t> kids;
-        for (int dev : devices) {
+        // Supervision: a child that ends while the others serve is reported; one that had been serving (alive for 2 s or
+        // more, or killed by a signal) is started again -- a GPU that falls over must not take its socket away for good --
+        // at most 5 times per device; one that ends at once (no such device, socket name taken) stays down.
+        struct Kid { pid_t pid; int dev; double born; int restarts; };
+        std::vector<Kid> kids;
+        auto now_s = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + t.tv_nsec * 1e-9; };
+        bool is_child = false;
+        auto spawn = [&](int dev, int restarts) {
             const pid_t pid = fork();
             if (pid == 0) {
                 device = dev;
                 if (want_uds) uds += "." + std::to_string(dev);
                 if (o.tcp_port) o.tcp_port += dev;
                 if (o.zlib_tcp_port) o.zlib_tcp_port += dev;
-                devices.clear();
-                break;
-            }
-            if (pid > 0) kids.push_back(pid);
-        }
-        if (!devices.empty()) {
+                is_child = true;
+            } else if (pid > 0) kids.push_back(Kid{pid, dev, now_s(), restarts});
+            else fprintf(stderr, "lepton_served: fork for device %d failed\n", dev);
+        };
+        for (int dev : devices) { spawn(dev, 0); if (is_child) break; }
+        if (!is_child) {
             struct sigaction sa;
             memset(&sa, 0, sizeof sa);
             sa.sa_handler = on_signal;
             sigaction(SIGINT, &sa, nullptr); sigaction(SIGTERM, &sa, nullptr); sigaction(SIGQUIT, &sa, nullptr);
             int worst = 0;
-            size_t alive = kids.size();
-            while (alive && !g_quit) {   // a child that dies on its own (no such device, socket taken) is reported, the others keep serving
+            while (!kids.empty() && !g_quit && !is_child) {
                 int st = 0;
                 const pid_t r = waitpid(-1, &st, 0);
-                if (r > 0) {
-                    --alive;
+                if (r <= 0) continue;   // EINTR: a signal for us, g_quit says which
+                for (size_t k = 0; k < kids.size(); ++k) {
+                    if (kids[k].pid != r) continue;
+                    const Kid kid = kids[k];
+                    kids.erase(kids.begin() + k);
+                    const bool was_serving = now_s() - kid.born >= 2.0 || WIFSIGNALED(st);
                     if (WIFEXITED(st) && WEXITSTATUS(st)) worst = WEXITSTATUS(st);
-                    fprintf(stderr, "lepton_served: child %d ended (status %d)\n", (int)r, st);
+                    fprintf(stderr, "lepton_served: child %d (device %d) ended (%s %d)%s\n", (int)r, kid.dev, WIFSIGNALED(st) ? "signal" : "exit code",
+                            WIFSIGNALED(st) ? WTERMSIG(st) : WEXITSTATUS(st), was_serving && kid.restarts < 5 && !g_quit ? ", restarting" : "");
+                    if (was_serving && kid.restarts < 5 && !g_quit) { usleep(200000); spawn(kid.dev, kid.restarts + 1); }
+                    break;
                 }
             }
-            for (pid_t k : kids) kill(k, SIGTERM);
-            for (;;) { int st = 0; const pid_t r = waitpid(-1, &st, 0); if (r <= 0) break; if (WIFEXITED(st) && WEXITSTATUS(st)) worst = WEXITSTATUS(st); }
-            return worst;
+            if (!is_child) {
+                for (const Kid& k : kids) kill(k.pid, SIGTERM);
+                for (;;) { int st = 0; const pid_t r = waitpid(-1, &st, 0); if (r <= 0) break; if (WIFEXITED(st) && WEXITSTATUS(st)) worst = WEXITSTATUS(st); }
+                return worst;
+            }
         }
+        devices.clear();
     } else if (devices.size() == 1) device = devices[0];
     if (want_uds && uds.empty()) {   // /tmp/<random id>.uport and .z0 (name_socket, socket_serve.cc:40-69)
         unsigned char r[16] = {0};
@@ -110,7 +126,10 @@ int main(int argc, char** argv) {
     if (want_uds) { o.uds_path = uds.c_str(); if (!zuds.empty()) o.zlib_uds_path = zuds.c_str(); }
 
     lep_gpu* gpu = nullptr;
-    int rc = lep_gpu_create(device, &gpu);
+    // LEP_SERVED_NO_DEVICE=1 (supervision tests on machines without a GPU): listen and answer every request with a failure
+    // instead of exiting -- nothing is ever coded without a device
+    const bool no_device = getenv("LEP_SERVED_NO_DEVICE") && atoi(getenv("LEP_SERVED_NO_DEVICE")) != 0;
+    int rc = no_device ? 0 : lep_gpu_create(device, &gpu);
     if (rc) { fprintf(stderr, "lepton_served: no usable gfx950 device %d (code %d)\n", device, rc); return rc; }
     o.gpu = gpu;
     signal(SIGPIPE, SIG_IGN);
@@ -129,7 +148,7 @@ int main(int argc, char** argv) {
     lep_serve_get_stats(srv, &st);
     lep_serve_stop(srv);
     lep_batch_release();
-    lep_gpu_destroy(gpu);
+    if (gpu) lep_gpu_destroy(gpu);
     fprintf(stderr, "lepton_served: %llu accepted, %llu answered, %llu failed, %llu timed out, %llu batches (largest %llu)\n",
             (unsigned long long)st.accepted, (unsigned long long)st.answered, (unsigned long long)st.failed,
             (unsigned long long)st.timed_out, (unsigned long long)st.batches, (unsigned long long)st.largest_batch);

@@ -248,3 +248,60 @@ def test_daemon_command_line():
         rc, out, err = run("-socket=" + name, "-timebound=10000ms", "-maxchildren=8", "-listenbacklog=64", "-skipverify", "-preload")
         assert rc == 120 and "no usable gfx950 device" in err and out == ""     # no CPU fallback: nothing is served without a GPU
         assert not os.path.exists(name)
+
+
+def test_daemon_supervises_one_process_per_device():
+    """`lepton_served -devices=0,1`: one serving process per GPU under a supervisor (multi-GPU serving): a child
+    that is killed while serving is reported and started again on the same sockets; children that end at once (here: no
+    device) are reported and stay down; SIGTERM to the supervisor takes everything down and removes the socket files.
+    Runs without a GPU: LEP_SERVED_NO_DEVICE makes the children listen and answer every request with a failure."""
+    import signal
+
+    import psutil
+
+    name = _name()
+    env = dict(os.environ, LEP_SERVED_NO_DEVICE="1")
+    sup = subprocess.Popen([SERVED, "-devices=0,1", "-socket=" + name, "-skipverify"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    try:
+        socks = [name + ".0", name + ".1"]
+
+        def up(timeout=20.0):
+            t0 = time.time()
+            while time.time() - t0 < timeout:
+                if all(os.path.exists(s) for s in socks):
+                    return True
+                time.sleep(0.05)
+            return False
+
+        assert up()
+        assert request(socks[0], golden("c420_160x120")[0]) == b"" and request(socks[1], b"\xcf\x84junk") == b""   # no device: failures only
+        kids = psutil.Process(sup.pid).children()
+        assert len(kids) == 2
+        victim = kids[1]
+        time.sleep(0.3)
+        victim.send_signal(signal.SIGKILL)
+        t0 = time.time()
+        while time.time() - t0 < 20 and len([k for k in psutil.Process(sup.pid).children() if k.pid != victim.pid and k.is_running()]) < 2:
+            time.sleep(0.05)
+        now = psutil.Process(sup.pid).children()
+        assert len(now) == 2 and victim.pid not in [k.pid for k in now], "the killed child was not replaced"
+        t0 = time.time()
+        while time.time() - t0 < 20:   # the replacement owns the sockets again
+            try:
+                if request(socks[0], b"\xff\xd8x") == b"" and request(socks[1], b"\xff\xd8x") == b"":
+                    break
+            except OSError:
+                time.sleep(0.1)
+        else:
+            raise AssertionError("sockets did not come back")
+        assert sup.poll() is None
+    finally:
+        sup.terminate()
+        out, err = sup.communicate(timeout=30)
+    assert b"restarting" in err and b"signal 9" in err
+    assert not any(os.path.exists(s) for s in (name + ".0", name + ".1", name + ".0.z0", name + ".1.z0"))
+    # without the hook and without a GPU every child ends at once: reported, not restarted, and the supervisor gives up with their code
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([SERVED, "-devices=0,1", "-socket=" + _name()], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 120 and r.stderr.count("ended (exit code 120)") == 2 and "restarting" not in r.stderr
