@@ -156,9 +156,9 @@ int lep_gpu_huffman_decode_device(lep_gpu *g, const lep_huffdec_image *images, i
 int lep_gpu_huffman_decode_parallel_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, int nsub, lep_huffdec_row *d_rows, void *hip_stream);
 /* plain device memory helpers so non-torch callers need no HIP binding */
 /* Device self-test of kernel arithmetic that has no CPU twin (exhaustive: the float-reciprocal Branch probability of the
- * v3 kernels against integer division, src/vp8/model/branch.hh:82-125).  0 = exact everywhere. */
+ * kernels against integer division, src/vp8/model/branch.hh:82-125).  0 = exact everywhere. */
 int lep_gpu_selftest(lep_gpu *g);
-/* Profiling builds (-DLEP_PROF) only: per-phase shader-clock totals [64 segments][32 slots] of the last v3 launch. */
+/* Profiling builds (-DLEP_PROF) only: per-phase shader-clock totals [64 segments][32 slots] of the last decoder launch. */
 int lep_gpu_debug_prof(lep_gpu *g, uint64_t *out);
 int lep_gpu_malloc(lep_gpu *g, size_t bytes, void **dptr);
 int lep_gpu_free(lep_gpu *g, void *dptr);

@@ -393,68 +393,79 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
         if (!brotli_available()) return EX_VERSION_UNSUPPORTED;   // no libbrotlidec on this host: said loudly, never guessed
         if (!unbrotli(d + 28, zsize, (size_t)lf->jpeg_size * 2 + ((size_t)128 << 20), &p)) return EX_STREAM_INCONSISTENT;
     }
+    // The header sections, read the way the reference reads them (read_ujpg, jpgcoder.cc:4193-4339): every field goes through
+    // ReadFull into one 64-byte scratch buffer, and a header that ends early simply leaves that buffer -- or the zeroed
+    // destination -- as it was.  Reproduced literally (scratch buffer included), because which damaged headers are still
+    // accepted, and as what, is part of the decode direction's parity (tests/fuzz/diff_lep_structured.py).
     size_t pos = 0;
-    auto need = [&](size_t k) { return pos + k <= p.size(); };
+    uint8_t mrk[64] = {0};
+    auto read_full = [&](uint8_t* dst, size_t k) { const size_t got = std::min(k, p.size() - pos); if (got) memcpy(dst, p.data() + pos, got); pos += got; return got; };
+    auto left = [&]() { return p.size() - pos; };
     JpegFile& jf = lf->jpeg;
-    if (!need(7) || memcmp(&p[pos], "HDR", 3)) return EX_STREAM_INCONSISTENT;
-    uint32_t hdrs = get_le32(&p[pos + 3]); pos += 7;
-    if (!need(hdrs)) return EX_STREAM_INCONSISTENT;
-    jf.hdr.assign(p.begin() + pos, p.begin() + pos + hdrs); pos += hdrs;
-    if (!need(4)) return EX_STREAM_INCONSISTENT;
-    if (!memcmp(&p[pos], "P0D", 3)) jf.padbit = (int8_t)p[pos + 3];
-    else if (!memcmp(&p[pos], "PAD", 3)) {
-        int8_t pb = (int8_t)p[pos + 3];
+    read_full(mrk, 3);
+    if (memcmp(mrk, "HDR", 3)) return EX_UNSUPPORTED_JPEG;   // "HDR marker not found": errorlevel 2
+    read_full(mrk, 4);
+    const uint32_t hdrs = get_le32(mrk);
+    if (hdrs > (128u << 20)) return EX_STREAM_INCONSISTENT;   // (the reference's arena allocator gives up long before)
+    jf.hdr.assign(hdrs, 0);
+    read_full(jf.hdr.data(), hdrs);
+    read_full(mrk, 3);
+    if (!memcmp(mrk, "P0D", 3)) { uint8_t b = 0xff; read_full(&b, 1); jf.padbit = (int8_t)b; }
+    else if (!memcmp(mrk, "PAD", 3)) {
+        uint8_t b = 0xff; read_full(&b, 1);
+        const int8_t pb = (int8_t)b;
         if (!(pb == 0 || pb == 1 || pb == -1)) return EX_STREAM_INCONSISTENT;
         jf.padbit = pb == 1 ? 0x7f : pb;
-    } else return EX_STREAM_INCONSISTENT;
-    pos += 4;
+    } else return EX_UNSUPPORTED_JPEG;                         // "PAD marker not found": errorlevel 2
     lf->garbage_default_eoi = true;
-    while (need(3)) {
-        const uint8_t* m = &p[pos];
-        if (!memcmp(m, "CRS", 3)) {
-            if (!need(7)) return EX_STREAM_INCONSISTENT;
-            uint32_t c = get_le32(m + 3); pos += 7;
-            if (!need((size_t)c * 4)) return EX_STREAM_INCONSISTENT;
+    while (read_full(mrk, 3) == 3) {
+        if (!memcmp(mrk, "CRS", 3)) {
+            read_full(mrk, 4);
+            const uint32_t c = get_le32(mrk);
+            if (c > (1u << 22) && (uint64_t)c > left() / 4 + 16) return EX_STREAM_INCONSISTENT;   // a count the data cannot back: multi-GB vector in the reference
             lf->rst_cnt_set = true;
             jf.rst_cnt.resize(c);
-            for (uint32_t i = 0; i < c; ++i, pos += 4) jf.rst_cnt[i] = get_le32(&p[pos]);
-        } else if (m[0] == 'H' && m[1] == 'H') {
-            size_t bytes = (size_t)m[2] * 16 + 2;
-            if (!need(1 + bytes)) return EX_STREAM_INCONSISTENT;
+            for (uint32_t i = 0; i < c; ++i) { read_full(mrk, 4); jf.rst_cnt[i] = get_le32(mrk); }
+        } else if (mrk[0] == 'H' && mrk[1] == 'H') {   // only the first two bytes are looked at; the third is the count
+            const size_t bytes = (size_t)mrk[2] * 16 + 2;
+            std::vector<uint8_t> z(bytes, 0);
+            z[0] = mrk[1]; z[1] = mrk[2];
+            read_full(z.data() + 2, bytes - 2);
             lf->segs.clear();   // a later section replaces an earlier one (thread_handoff = ThreadHandoff::deserialize(...), jpgcoder.cc:4266)
-            if (!deserialize_handoffs(m + 1, bytes, &lf->segs)) return EX_VERSION_UNSUPPORTED;
-            pos += 1 + bytes;
-        } else if (!memcmp(m, "FRS", 3)) {
-            if (!need(7)) return EX_STREAM_INCONSISTENT;
-            uint32_t c = get_le32(m + 3); pos += 7;
-            if (!need(c)) return EX_STREAM_INCONSISTENT;
-            jf.rst_err.assign(p.begin() + pos, p.begin() + pos + c); pos += c;
-        } else if (!memcmp(m, "GRB", 3)) {
-            if (!need(7)) return EX_STREAM_INCONSISTENT;
-            uint32_t c = get_le32(m + 3); pos += 7;
-            if (!need(c)) return EX_STREAM_INCONSISTENT;
-            jf.garbage.assign(p.begin() + pos, p.begin() + pos + c); pos += c;
+            if (!deserialize_handoffs(z.data(), bytes, &lf->segs)) return EX_VERSION_UNSUPPORTED;
+        } else if (!memcmp(mrk, "FRS", 3)) {
+            read_full(mrk, 4);
+            const uint32_t c = get_le32(mrk);
+            if ((c > (1u << 24) && (uint64_t)c > left() + 16) || c < jf.rst_err.size()) return EX_STREAM_INCONSISTENT;
+            jf.rst_err.resize(c, 0);
+            read_full(jf.rst_err.data(), c);
+        } else if (!memcmp(mrk, "GRB", 3)) {
+            read_full(mrk, 4);
+            const uint32_t c = get_le32(mrk);
+            if (c > (128u << 20)) return EX_STREAM_INCONSISTENT;
+            jf.garbage.assign(c, 0);
+            read_full(jf.garbage.data(), c);
             lf->garbage_default_eoi = false;
-        } else if (!memcmp(m, "PGR", 3) || !memcmp(m, "PGE", 3)) {
-            if (!need(7)) return EX_STREAM_INCONSISTENT;
-            uint32_t c = get_le32(m + 3); pos += 7;
-            if (!need(c)) return EX_STREAM_INCONSISTENT;
-            lf->embedded = m[2] == 'E';
+        } else if (!memcmp(mrk, "PGR", 3) || !memcmp(mrk, "PGE", 3)) {
+            lf->embedded = lf->embedded || mrk[2] == 'E';
+            read_full(mrk, 4);
+            const uint32_t c = get_le32(mrk);
+            if (c > (128u << 20)) return EX_STREAM_INCONSISTENT;
             lf->has_prefix = true;
-            lf->prefix_garbage.assign(p.begin() + pos, p.begin() + pos + c); pos += c;
-        } else if (!memcmp(m, "SIZ", 3)) {
-            if (!need(7)) return EX_STREAM_INCONSISTENT;
-            lf->jpeg_size = get_le32(m + 3); pos += 7;
-        } else if (!memcmp(m, "EEE", 3)) {
-            if (!need(31)) return EX_STREAM_INCONSISTENT;
-            jf.max_cmp = (int)get_le32(m + 3); jf.max_bpos = (int)get_le32(m + 7); jf.max_sah = (int)get_le32(m + 11);
-            for (int i = 0; i < 4; ++i) jf.max_dpos[i] = (int)get_le32(m + 15 + 4 * i);
+            lf->prefix_garbage.assign(c, 0);
+            read_full(lf->prefix_garbage.data(), c);
+        } else if (!memcmp(mrk, "SIZ", 3)) {
+            read_full(mrk, 4);
+            lf->jpeg_size = get_le32(mrk);
+        } else if (!memcmp(mrk, "EEE", 3)) {
+            read_full(mrk, 28);
+            jf.max_cmp = (int)get_le32(mrk); jf.max_bpos = (int)get_le32(mrk + 4); jf.max_sah = (int)get_le32(mrk + 8);
+            for (int i = 0; i < 4; ++i) jf.max_dpos[i] = (int)get_le32(mrk + 12 + 4 * i);
             jf.early_eof = true;
-            pos += 31;
-        } else if (!memcmp(m, "CNT", 3)) {   // the rest of this header belongs to the next file of the stream
-            lf->pending_header.assign(p.begin() + pos + 3, p.end());
+        } else if (!memcmp(mrk, "CNT", 3)) {   // the rest of this header belongs to the next file of the stream
+            lf->pending_header.assign(p.begin() + pos, p.end());
             break;
-        } else if (!memcmp(m, "CMP", 3)) {
+        } else if (!memcmp(mrk, "CMP", 3)) {
             break;
         } else {
             return EX_UNSUPPORTED_JPEG;   // "unknown data found": errorlevel 2 (jpgcoder.cc:4326-4337)

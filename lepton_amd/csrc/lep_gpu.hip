@@ -15,9 +15,6 @@
 
 #define LEP_DEV __device__ __forceinline__
 #include "lep_core.h"
-#include "lep_enc2.h"
-#include "lep_dec2.h"
-#include "lep_dec3.h"
 #include "lep_enc3.h"
 #include "lep_dec4.h"
 #include "lep_huff.h"
@@ -26,17 +23,10 @@
 
 using namespace lepdev;
 
-// helpers so the kernel template compiles for both coder kinds
-namespace lepdev {
-__device__ inline uint32_t finish_stream(BoolCoder<false>& b) { return b.finish(); }
-__device__ inline uint32_t finish_stream(BoolCoder<true>&) { return 0; }
-__device__ inline bool stream_overflow(BoolCoder<false>& b) { return b.overflow; }
-__device__ inline bool stream_overflow(BoolCoder<true>&) { return false; }
-}  // namespace lepdev
-
 namespace {
 
-// every kernel generation has its own model layout; segments are spaced by the largest
+// the encoder uses the dense model layout (kModelBranches words), the decoder the group-aligned one (lep3::kModelWords);
+// segments are spaced by the larger so that one arena serves both
 constexpr size_t kModelStride = lep3::kModelWords > kModelBranches ? lep3::kModelWords : kModelBranches;
 
 template <uint32_t WORDS = kModelBranches>
@@ -50,56 +40,9 @@ __device__ void reset_segment_state(uint32_t* model, NSum* ns, int ns_count, int
     for (uint32_t i = lane; i < words; i += 64) n32[i] = 0;
 }
 
-template <bool DEC>
-__global__ __launch_bounds__(64) void lep_segment_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
-                                                         uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
-                                                         uint8_t* streams, uint32_t* stream_len, int32_t* status,
-                                                         uint32_t* bins) {
-    const int s = blockIdx.x, lane = threadIdx.x;
-    const SegDev seg = segs[s];
-    const ImageDev* img = images + seg.image;
-    uint32_t* model = models + (size_t)s * kModelStride;
-    NSum* ns = ns_area + ns_offsets[s];
-    reset_segment_state(model, ns, img->ns_total, lane);
-    __syncthreads();
-    if (lane != 0) return;
-    SegmentCoder<DEC> sc;
-    if (DEC) sc.bc.init_stream(streams + seg.stream_off, stream_len[s]);
-    else sc.bc.init_stream(streams + seg.stream_off, seg.stream_cap);
-    int rc = sc.run(img, seg, model, ns);
-    if (!DEC) {
-        uint32_t n = finish_stream(sc.bc);
-        if (stream_overflow(sc.bc)) rc = LEP_BUFFER_TOO_SMALL;
-        stream_len[s] = n;
-    }
-    status[s] = rc;
-    bins[s] = sc.nbins;
-}
-
-// v2 encoder: wave-cooperative (lep_enc2.h); same arguments as lep_segment_kernel<false>
-__global__ __launch_bounds__(64) void lep_encode_v2_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
-                                                           uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
-                                                           uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
-    __shared__ EncShared sh;
-    const int s = blockIdx.x, lane = threadIdx.x;
-    const SegDev seg = segs[s];
-    const ImageDev* img = images + seg.image;
-    uint32_t* model = models + (size_t)s * kModelStride;
-    NSum* ns = ns_area + ns_offsets[s];
-    reset_segment_state(model, ns, img->ns_total, lane);
-    __syncthreads();
-    EncWave w;
-    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, seg.stream_cap);
-    if (lane != 0) return;
-    uint32_t n = rc ? 0 : w.bc.finish();
-    if (!rc && w.bc.overflow) rc = LEP_BUFFER_TOO_SMALL;
-    stream_len[s] = n;
-    status[s] = rc;
-    bins[s] = w.nbins;
-}
-
-// v3 encoder: v2's phases at 8 wavefronts per SIMD, bool coder as uniform vector code (lep_enc3.h).  WAVES = waves per SIMD
-// the register allocation is held to (8 = 64 VGPRs, the default; 7 = 72 VGPRs, LEP_ENC_WAVES, an experiment)
+// The encoder (lep_enc3.h): lane-parallel context / bin-list phases, one model round trip per block, bool coder as uniform
+// vector code; 64 VGPRs -> 8 wavefronts per SIMD.  (Earlier generations -- single-lane, exec-masked lane 0, scalar-unit
+// serial part -- live on as CPU cross-checks under tests/emu/retired/.)
 template <int WAVES>
 __global__ __launch_bounds__(64, WAVES) void lep_encode_v3_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
                                                               uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
@@ -122,28 +65,8 @@ __global__ __launch_bounds__(64, WAVES) void lep_encode_v3_kernel(const ImageDev
     bins[seg.slot] = w.nbins;
 }
 
-// v2 decoder: wave-cooperative with prefetch rounds (lep_dec2.h)
-__global__ __launch_bounds__(64) void lep_decode_v2_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
-                                                           uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
-                                                           uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
-    __shared__ DecShared sh;
-    const int s = blockIdx.x, lane = threadIdx.x;
-    const SegDev seg = segs[s];
-    const ImageDev* img = images + seg.image;
-    uint32_t* model = models + (size_t)s * kModelStride;
-    NSum* ns = ns_area + ns_offsets[s];
-    reset_segment_state(model, ns, img->ns_total, lane);
-    __syncthreads();
-    DecWave w;
-    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, stream_len[s]);
-    if (lane != 0) return;
-    status[s] = rc;
-    bins[s] = w.nbins;
-}
-
 #ifdef LEP_PROF
-__device__ uint64_t g_prof[64][32];
-__device__ unsigned long long g_prof4[8192][32];   // v4: private accumulators per wave (no atomic contention)
+__device__ unsigned long long g_prof4[8192][32];   // private accumulators per wave (no atomic contention)
 #endif
 
 // exhaustive check of the float-reciprocal / table-reciprocal Branch probabilities against integer division (all 255 x 255 count pairs)
@@ -162,35 +85,6 @@ __global__ void lep_selftest_kernel(uint32_t* mismatches) {
         const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);
         if (lep3::bupd(w, obs) != branch_update(w, obs)) atomicAdd(mismatches, 1u);
     }
-}
-
-// v3 decoder: owner-lane model update, serial part on the scalar unit (lep_dec3.h).  WAVES = waves per SIMD the
-// register allocation is held to (4: 120 VGPRs, no spills; 5: 96; 6: 80; 8: 64 with spills to scratch).
-template <int WAVES>
-__global__ __launch_bounds__(64, WAVES) void lep_decode_v3_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
-                                                           uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
-                                                           uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
-    __shared__ lep3::Dec3Shared sh;
-    const int s = blockIdx.x, lane = threadIdx.x;
-    const SegDev seg = segs[s];
-    const ImageDev* img = images + seg.image;
-    uint32_t* model = models + (size_t)s * kModelStride;
-    NSum* ns = ns_area + ns_offsets[s];
-    reset_segment_state<lep3::kModelWords>(model, ns, img->ns_total, lane);
-    __syncthreads();
-    lep3::Dec3Wave w;
-#ifdef LEP_PROF
-    if (lane < 32) sh.prof[lane] = 0;
-    w.prof_last = __builtin_readcyclecounter();
-#endif
-    int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, stream_len[s]);
-#ifdef LEP_PROF
-    __syncthreads();
-    if (s < 64 && lane < 32) g_prof[s][lane] = sh.prof[lane];
-#endif
-    if (lane != 0) return;
-    status[s] = rc;
-    bins[s] = w.nbins;
 }
 
 // v4 decoder: serial part as uniform vector code, multi-bin interior windows, one merged edge round (lep_dec4.h).
@@ -279,10 +173,8 @@ struct lep_gpu {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    int decode_kernel = 4;   // 4 = v4 (default), 3 = v3 scalar-unit serial part, 2 = v2 prefetch rounds, 1 = single-lane reference kernel (LEP_DECODE_KERNEL)
-    int dec3_waves = 0;      // register budget variant of the v3 / v4 decoder: 0 = by batch size, LEP_DEC3_WAVES = 4 | 5 | 6 | 8
-    int enc_waves = 8;       // register budget variant of the v3 encoder (LEP_ENC_WAVES = 7 | 8)
-    int encode_kernel = 3;   // 3 = v3 (default), 2 = v2 wave-cooperative, 1 = single-lane reference kernel (LEP_ENCODE_KERNEL)
+    int dec_waves = 0;       // register-budget build of the decoder: 0 = by batch size (8 waves per SIMD / 64 VGPRs once a launch can
+                             // fill them, else 4 / 128 VGPRs, no spills); LEP_DEC_WAVES = 4 | 8 forces one
     std::string err;
     const char* last_kernel = "";   // name of the kernel the most recent launch used
     // grow-only device workspace of a coder launch (models, neighbour summaries, descriptors).  There are two sets so that two
@@ -347,9 +239,8 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     // image-major: with 8 thread segments per image, segment k of EVERY image would land on XCD k -- and photographs are not
     // uniform top to bottom (sky above, detail below: up to 2x the bins per row), so one XCD would be the straggler of every
     // launch.  Segment r of image m is therefore queued for XCD (r + m) % 8 and the queues are interleaved; SegDev.slot
-    // carries the caller's index for the results.  (Only the current kernel generations read slot; the older ones index by
-    // workgroup and keep the caller's order.)
-    const bool permute = (DEC ? g->decode_kernel == 4 : g->encode_kernel == 3) && nseg > 8;
+    // carries the caller's index for the results.
+    const bool permute = nseg > 8;
     std::vector<int> order(nseg);
     if (permute) {
         std::vector<int> q[8];
@@ -391,7 +282,7 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     g->d_bins = (uint32_t*)(meta + o_bins);
     g->h_bins.assign(nseg, 0);
     HIPCHK(g, hipEventRecord(g->ev0, st));
-    if (DEC && g->decode_kernel == 4) {
+    if (DEC) {
 #ifdef LEP_PROF
         { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_prof4)) == hipSuccess) (void)hipMemsetAsync(p, 0, sizeof(g_prof4), st); }
 #endif
@@ -399,56 +290,16 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     hipLaunchKernelGGL((lep_decode_v4_kernel<W>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),                  \
                        (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns), \
                        d_streams, d_stream_len, d_status, g->d_bins)
-        int waves = g->dec3_waves;
+        // more resident waves only pay once the batch can fill them (MI355X, 4K corpus: below ~4600 segments the 4-wave
+        // build, which does not spill, is faster)
+        int waves = g->dec_waves;
         if (!waves) waves = nseg > 4608 ? 8 : 4;
         if (waves >= 8) { g->last_kernel = "lep_decode_v4_kernel<8>"; LEP_LAUNCH_DEC4(8); }
-        else if (waves == 7) { g->last_kernel = "lep_decode_v4_kernel<7>"; LEP_LAUNCH_DEC4(7); }
-        else if (waves >= 6) { g->last_kernel = "lep_decode_v4_kernel<6>"; LEP_LAUNCH_DEC4(6); }
         else { g->last_kernel = "lep_decode_v4_kernel<4>"; LEP_LAUNCH_DEC4(4); }
 #undef LEP_LAUNCH_DEC4
-    }
-    else if (DEC && g->decode_kernel == 3) {
-#define LEP_LAUNCH_DEC3(W)                                                                                                     \
-    hipLaunchKernelGGL((lep_decode_v3_kernel<W>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),                  \
-                       (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns), \
-                       d_streams, d_stream_len, d_status, g->d_bins)
-        // register-budget variant: more resident waves only pay once the batch can fill them (measured, MI355X, 4K
-        // corpus: 4096 segments 822 MB/s with the 4-wave build vs 742 with the 5-wave build; 8192 segments 867 vs 947
-        // with the 8-wave build); LEP_DEC3_WAVES overrides
-        int waves = g->dec3_waves;
-        if (!waves) waves = nseg > 6144 ? 8 : (nseg > 4608 ? 6 : 4);
-        g->last_kernel = waves >= 8 ? "lep_decode_v3_kernel<8>" : waves == 6 ? "lep_decode_v3_kernel<6>" : waves == 5 ? "lep_decode_v3_kernel<5>" : "lep_decode_v3_kernel<4>";
-        switch (waves) {
-            case 8: LEP_LAUNCH_DEC3(8); break;
-            case 6: LEP_LAUNCH_DEC3(6); break;
-            case 5: LEP_LAUNCH_DEC3(5); break;
-            default: LEP_LAUNCH_DEC3(4); break;
-        }
-#undef LEP_LAUNCH_DEC3
-    }
-    else if (DEC && g->decode_kernel == 2) {
-        g->last_kernel = "lep_decode_v2_kernel";
-        hipLaunchKernelGGL(lep_decode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                           (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
-                           d_streams, d_stream_len, d_status, g->d_bins);
-    } else if (!DEC && g->encode_kernel == 3) {
-        g->last_kernel = g->enc_waves == 7 ? "lep_encode_v3_kernel<7>" : "lep_encode_v3_kernel";
-        if (g->enc_waves == 7)
-            hipLaunchKernelGGL((lep_encode_v3_kernel<7>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                               (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
-                               d_streams, d_stream_len, d_status, g->d_bins);
-        else
-            hipLaunchKernelGGL((lep_encode_v3_kernel<8>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                               (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
-                               d_streams, d_stream_len, d_status, g->d_bins);
-    } else if (!DEC && g->encode_kernel == 2) {
-        g->last_kernel = "lep_encode_v2_kernel";
-        hipLaunchKernelGGL(lep_encode_v2_kernel, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                           (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
-                           d_streams, d_stream_len, d_status, g->d_bins);
     } else {
-        g->last_kernel = DEC ? "lep_segment_kernel<decode>" : "lep_segment_kernel<encode>";
-        hipLaunchKernelGGL(lep_segment_kernel<DEC>, dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
+        g->last_kernel = "lep_encode_v3_kernel<8>";
+        hipLaunchKernelGGL((lep_encode_v3_kernel<8>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
                            (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
                            d_streams, d_stream_len, d_status, g->d_bins);
     }
@@ -463,10 +314,7 @@ extern "C" {
 int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
-    if (const char* e = getenv("LEP_ENCODE_KERNEL")) g->encode_kernel = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3;
-    if (const char* e = getenv("LEP_DECODE_KERNEL")) g->decode_kernel = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 4;
-    if (const char* e = getenv("LEP_DEC3_WAVES")) g->dec3_waves = atoi(e);
-    if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 7 ? 7 : 8;
+    if (const char* e = getenv("LEP_DEC_WAVES")) g->dec_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||
@@ -610,18 +458,14 @@ int lep_gpu_selftest(lep_gpu* g) {
     return h == 0 ? 0 : LEP_ASSERTION_FAILURE;
 }
 
-// profiling builds (-DLEP_PROF) only: per-phase shader-clock totals of the first 64 segments of the last v3 launch
+// profiling builds (-DLEP_PROF) only: per-phase shader-clock totals folded over the segments of the last decoder launch
 int lep_gpu_debug_prof(lep_gpu* g, uint64_t* out /* [64][32] */) {
 #ifdef LEP_PROF
-    if (g->decode_kernel == 4) {   // fold the per-wave accumulators into the 64 x 32 report
-        std::vector<unsigned long long> h(8192 * 32);
-        HIPCHK(g, hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_prof4), sizeof(unsigned long long) * 8192 * 32));
-        memset(out, 0, sizeof(uint64_t) * 64 * 32);
-        for (int s = 0; s < 8192; ++s)
-            for (int i = 0; i < 32; ++i) out[(s & 63) * 32 + i] += h[(size_t)s * 32 + i];
-        return 0;
-    }
-    HIPCHK(g, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(uint64_t) * 64 * 32));
+    std::vector<unsigned long long> h(8192 * 32);   // fold the per-wave accumulators into the 64 x 32 report
+    HIPCHK(g, hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_prof4), sizeof(unsigned long long) * 8192 * 32));
+    memset(out, 0, sizeof(uint64_t) * 64 * 32);
+    for (int s = 0; s < 8192; ++s)
+        for (int i = 0; i < 32; ++i) out[(s & 63) * 32 + i] += h[(size_t)s * 32 + i];
     return 0;
 #else
     (void)g; (void)out;

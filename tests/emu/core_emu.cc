@@ -7,8 +7,8 @@
 #include <vector>
 #define LEP_DEV inline
 #include "../../lepton_amd/csrc/lep_derive.h"
-#include "../../lepton_amd/csrc/lep_enc2.h"
-#include "../../lepton_amd/csrc/lep_dec2.h"
+#include "retired/lep_enc2.h"
+#include "retired/lep_dec2.h"
 
 using namespace lepdev;
 
@@ -105,7 +105,7 @@ extern "C" int emu_decode_segment_v2(const lep_image_desc* d, int y0, int y1, in
 }
 
 // v3 decoder (lep_dec3.h) as a 64-lane loop emulation
-#include "../../lepton_amd/csrc/lep_dec3.h"
+#include "retired/lep_dec3.h"
 extern "C" int emu_decode_segment_v3(const lep_image_desc* d, int y0, int y1, int is_last, const uint8_t* in, uint32_t len, uint32_t* bins) {
     ImageDev img;
     int rc = derive_image(*d, &img, false);

@@ -12,7 +12,7 @@
 // Syntax / contexts: src/vp8/decoder/decoder.cc:27-141,167-318; src/vp8/model/model.hh:463-485,852-871,
 // 1033-1122,674-832 (the same citations as lep_core.h, whose results this kernel reproduces bit for bit).
 #pragma once
-#include "lep_v3.h"
+#include "../../../lepton_amd/csrc/lep_v3.h"
 
 namespace lep3 {
 

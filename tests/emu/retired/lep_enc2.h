@@ -12,8 +12,8 @@
 //   P4  lane 0 runs the bool-coder state machine over (bit, probability) pairs read from LDS.
 // Syntax / contexts are those of lep_core.h (same reference citations); results are bit-identical.
 #pragma once
-#include "lep_core.h"
-#include "lep_wave.h"
+#include "../../../lepton_amd/csrc/lep_core.h"
+#include "../../../lepton_amd/csrc/lep_wave.h"
 
 namespace lepdev {
 

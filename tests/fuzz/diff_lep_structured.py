@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the decode direction with STRUCTURE-AWARE .lep mutants (mutate.mutate_lep_structured: the header is
+inflated, mutated, deflated again; hand-off counts / repeats / sizes, flag and thread bytes edited by field) against the real
+reference binary: either both sides refuse a file or both restore the same bytes.  A tool, run by hand where
+oracle/_ref/lepton exists:   python tests/fuzz/diff_lep_structured.py <seed> <trials> [outdir]
+Found and fixed so far (round 2): > 16 hand-offs, repeated HH sections, unknown sections ("unknown data found" -> 42),
+more logical threads than the thread hint on the general re-coder (CODING_ERROR), unaligned pre-hand-off split tables
+(THREADING_PARTIAL_MCU), a header that ends inside the hand-off records (zero-filled, accepted).  Known open, all of them
+mutations INSIDE the embedded JPEG header of a file whose flag byte was also changed (a progressive file forced through the
+baseline re-coder or vice versa, with a damaged DHT / DQT): both sides "succeed" with different garbage."""
+import os, sys, random, subprocess
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo/tests/fuzz')
+import mutate as mu
+from conftest import golden, golden_cases
+import oracle_binding as ob
+from lepton_amd.codec import LepFile, LeptonError
+REF='/root/repo/oracle/_ref/lepton'
+rnd=random.Random(int(sys.argv[1])); N=int(sys.argv[2])
+names=[n for n in golden_cases() if len(golden(n)[1])<40000]
+OUT=sys.argv[3] if len(sys.argv)>3 else '/tmp'
+lp,jp=os.path.join(OUT,'m.lep'),os.path.join(OUT,'m.jpg')
+bad=0; same=0; refused=0
+for t in range(N):
+    name=rnd.choice(names)
+    b=mu.mutate_lep_structured(rnd, golden(name)[1])
+    open(lp,'wb').write(b)
+    if os.path.exists(jp): os.unlink(jp)
+    try:
+        r=subprocess.run([REF,'-unjailed',lp,jp],capture_output=True,timeout=60)
+        want=open(jp,'rb').read() if r.returncode==0 and os.path.exists(jp) else None
+        rcode=r.returncode
+    except subprocess.TimeoutExpired:
+        want=None; rcode='timeout'
+    try:
+        f=LepFile(b); ob.oracle_decode(f.desc,f.segments,f.streams); got=f.recode(); code=0
+    except LeptonError as e: got=None; code=e.code
+    except RuntimeError as e: got=None; code=str(e)
+    if got!=want:
+        bad+=1; print('DIFF',t,name,'ref',rcode,None if want is None else len(want),'ours',code,None if got is None else len(got))
+        open(os.path.join(OUT,'diff_%d.lep'%t),'wb').write(b)
+    elif got is None: refused+=1
+    else: same+=1
+print('same',same,'refused',refused,'bad',bad)

@@ -8,6 +8,7 @@ import io
 import os
 import random
 import subprocess
+import sys
 
 import pytest
 
@@ -198,3 +199,48 @@ def test_mutated_lep_files_against_the_reference_binary(tmp_path):
         same += got is not None
         refused += got is None
     assert same >= 10 and refused >= 10
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="needs the reference binary (built where /root/reference exists)")
+def test_structured_lep_mutants_against_the_reference_binary(tmp_path):
+    """the container rules the structure-aware fuzz found (tests/fuzz/diff_lep_structured.py), replayed: hand-off sections
+    with 0..255 records, repeated sections, absurd segment sizes, every thread-hint byte, headers cut short at any point --
+    either both sides refuse the file or both restore the same bytes"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
+    import mutate as mu
+    from conftest import golden, golden_cases
+
+    rnd = random.Random(11)
+    names = [n for n in golden_cases() if len(golden(n)[1]) < 40000]
+    lp, jp = str(tmp_path / "m.lep"), str(tmp_path / "m.jpg")
+    same = refused = 0
+    for trial in range(70):
+        lep = golden(rnd.choice(names))[1]
+        kind = trial % 5
+        if kind == 0:
+            b = mu.with_handoffs(lep, count=rnd.choice([0, 1, 2, 8, 9, 16, 17, 32, 200, 255]))
+        elif kind == 1:
+            b = mu.with_handoffs(lep, repeat=rnd.choice([2, 3, 20]), count=rnd.choice([None, 16, 255]))
+        elif kind == 2:
+            b = mu.with_handoffs(lep, segment_size=rnd.choice([0, 1, 1000, 0x7fffffff]))
+        elif kind == 3:
+            b = mu.with_handoffs(lep, thread_byte=rnd.choice([0, 1, 2, 7, 8, 9, 16, 17, 255]))
+        else:
+            fixed, payload, rest = mu.lep_split(lep)
+            b = mu.lep_join(fixed, payload[: rnd.randrange(mu.find_handoffs(payload), len(payload))], rest)
+        open(lp, "wb").write(b)
+        if os.path.exists(jp):
+            os.unlink(jp)
+        r = subprocess.run([REF, "-unjailed", lp, jp], capture_output=True, timeout=60)
+        want = open(jp, "rb").read() if r.returncode == 0 and os.path.exists(jp) else None
+        try:
+            f = LepFile(b)
+            ob.oracle_decode(f.desc, f.segments, f.streams)
+            got = f.recode()
+        except (LeptonError, RuntimeError):
+            got = None
+        assert (got is None) == (want is None), (trial, kind, r.returncode)
+        assert got == want, (trial, kind)
+        same += got is not None
+        refused += got is None
+    assert same >= 15 and refused >= 15
