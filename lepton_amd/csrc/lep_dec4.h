@@ -42,6 +42,27 @@ constexpr int prof_slot(const char* n) {
     return 31;
 }
 
+// ---- model layout of this kernel ---------------------------------------------------------------------------------------
+// Same tables and sizes as lep_v3.h, but the three big families (interior exponents, edge exponents, residuals) are stored
+// [..][group 0..2]["non-zeros left" 0..9][4 words] instead of ["non-zeros left"][..][12 words]: the lanes of a round prefetch
+// the SAME position under several consecutive "non-zeros left" values (4 candidates in the interior, 1..7 at an edge
+// position), and in this order those 16-byte groups are neighbours -- one or two 64-byte sectors instead of one sector each.
+// Measured before the change (MI355X, profiles/r02a_pmc_bound_summary.json, r02b_fetch_calibration.txt): 257 sector reads per
+// block, 9 % L2 hit rate, 38 G requests/s -- the rate a pure random-gather kernel reaches on this chip.
+// Word i of a row: base + (i / 4) * kGS + (i % 4).
+#ifndef LEP_DEC4_ROW_MAJOR
+constexpr uint32_t kGS = 10 * 4;   // words from one group of a row to the next
+WDEV uint32_t ctx4_exp7(int ci, int nb, int zz, int bsr) { return lep3::kExp7 + (((((uint32_t)ci * 49 + zz) * 12 + bsr) * 3) * 10 + nb) * 4; }
+WDEV uint32_t ctx4_expx(int ci, int ne, int zig15, int bsr) { return lep3::kExpX + (((((uint32_t)ci * 15 + zig15) * 12 + bsr) * 3) * 10 + ne) * 4; }
+WDEV uint32_t ctx4_res(int ci, int coord, int nb) { return lep3::kRes + ((((uint32_t)ci * 64 + coord) * 3) * 10 + nb) * 4; }
+#else   // -DLEP_DEC4_ROW_MAJOR: round 1's layout (contiguous 12-word rows), kept for A/B measurements
+constexpr uint32_t kGS = 4;
+WDEV uint32_t ctx4_exp7(int ci, int nb, int zz, int bsr) { return lep3::ctx_exp7(ci, nb, zz, bsr); }
+WDEV uint32_t ctx4_expx(int ci, int ne, int zig15, int bsr) { return lep3::ctx_expx(ci, ne, zig15, bsr); }
+WDEV uint32_t ctx4_res(int ci, int coord, int nb) { return lep3::ctx_res(ci, coord, nb); }
+#endif
+WDEV uint32_t row_word(uint32_t base, int i) { return base + (uint32_t)(i >> 2) * kGS + (uint32_t)(i & 3); }
+
 struct Dec4Shared {
     uint32_t sign[kSignWords];    // resident Branches
     uint32_t resdc[kResDcWords];
@@ -269,7 +290,7 @@ struct Dec4Wave {
     WDEV int dec_unary_tail(uint32_t gbase) {   // exponent bins 8..10 straight from HBM (|v| >= 128: rare)
         int i = 8;
 #pragma nounroll
-        for (; i < 11; ++i) if (!ucond(dec_global(gbase + i) != 0)) break;
+        for (; i < 11; ++i) if (!ucond(dec_global(row_word(gbase, i)) != 0)) break;
         return i;
     }
     // residual bits b..0 (b <= 3) of |v| from the packed probabilities of the residual group (word i = bit i); unrolled, the
@@ -423,8 +444,8 @@ struct Dec4Wave {
             // candidate `cand` can only be in force at window position pi if enough non-zeros can have come before it
             const int valid = p < 49 && nb >= 1 && cand < LEP_DEC4_CANDS && pi >= left0 - nzhi_of(nb < 0 ? 0 : nb);
             if (valid) {
-                adr0 = ctx_exp7(ci, nb, p, S.bsr[p]);
-                adr1 = ctx_res(ci, S.a2r[p], nb);
+                adr0 = ctx4_exp7(ci, nb, p, S.bsr[p]);
+                adr1 = ctx4_res(ci, S.a2r[p], nb);
                 L(W0) = ld4(model + adr0);
                 pk0 = pack_probs(L(W0));
                 L(W1) = ld4(model + adr1); pk1 = pack_probs(L(W1));
@@ -447,8 +468,8 @@ struct Dec4Wave {
                 if (len == 4) {
                     // exponent words 4..7 (|v| >= 8: 5 % of the interior non-zeros) are not prefetched -- that third of the round's
                     // traffic was almost all waste; the serial code reads the group when it gets there, the owner re-reads it to adapt
-                    len += dec_unary4(pack_probs(vload4(model + ctx_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])) + 4)));
-                    if (len == 8) len = dec_unary_tail(ctx_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])));
+                    len += dec_unary4(pack_probs(vload4(model + ctx4_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])) + kGS)));
+                    if (len == 8) len = dec_unary_tail(ctx4_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])));
                 }
                 nbins += (uint32_t)(2 * len - (len == 11));
                 const uint32_t pos = bc.get(sgw >> 16);
@@ -458,9 +479,9 @@ struct Dec4Wave {
                 if (len > 1) {
                     int b = len - 2;
                     if (b >= 4) {
-                        const uint32_t rbase = ctx_res(ci, (int)uni(S.a2r[zz]), nb0 - cand);
+                        const uint32_t rbase = ctx4_res(ci, (int)uni(S.a2r[zz]), nb0 - cand);
 #pragma nounroll
-                        for (; b >= 4; --b) v |= dec_global(rbase + b) << b;
+                        for (; b >= 4; --b) v |= dec_global(row_word(rbase, b)) << b;
                     }
                     v = dec_residual(lepwave::wave_read(PK1, lane), b, v);
                 }
@@ -502,9 +523,9 @@ struct Dec4Wave {
         }
         if (lepwave::wave_ballot(u2)) {   // exponent words 4..7: re-read by the owner (rare in the interior)
             LV(U4, W2);
-            LANES(l) if (L(u2)) L(W2) = ld4(model + L(a0) + 4);
+            LANES(l) if (L(u2)) L(W2) = ld4(model + L(a0) + kGS);
             adapt_group(W2, u2, b2);
-            LANES(l) if (L(u2)) st4(model + L(a0) + 4, L(W2));
+            LANES(l) if (L(u2)) st4(model + L(a0) + kGS, L(W2));
         }
         LSYNC();
         zz_io = zz; left_io = left;
@@ -527,8 +548,8 @@ struct Dec4Wave {
                 const int32_t prior = S.eprior[e * 7 + j];
                 const uint32_t ap = prior < 0 ? 0u - (uint32_t)prior : (uint32_t)prior;
                 const int bsr = bitlen(ap > 1023 ? 1023 : ap);
-                adr0 = ctx_expx(ci, n, horizontal ? j : j + 7, bsr);
-                adr2 = ctx_res(ci, coord, n);
+                adr0 = ctx4_expx(ci, n, horizontal ? j : j + 7, bsr);
+                adr2 = ctx4_res(ci, coord, n);
                 L(W0) = ld4(model + adr0); L(W2) = ld4(model + adr2);
                 pk0 = pack_probs(L(W0)); pk2 = pack_probs(L(W2));
                 L(W1) = U4{0, 0, 0, 0};   // exponent words 4..7 (|v| >= 8) are read on demand, like the interior's
@@ -565,8 +586,8 @@ struct Dec4Wave {
                 if (len) {
                     const int coord = horizontal ? j + 1 : (j + 1) * 8;
                     if (len == 4) {
-                        len += dec_unary4(pack_probs(vload4(model + ctx_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)) + 4)));
-                        if (len == 8) len = dec_unary_tail(ctx_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)));
+                        len += dec_unary4(pack_probs(vload4(model + ctx4_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)) + kGS)));
+                        if (len == 8) len = dec_unary_tail(ctx4_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)));
                     }
                     nbins += (uint32_t)(2 * len - (len == 11));
                     const int sslot = (int)(info & 255);
@@ -588,9 +609,9 @@ struct Dec4Wave {
                             }
                         }
                         if (b >= 4) {
-                            const uint32_t rbase = ctx_res(ci, coord, left);
+                            const uint32_t rbase = ctx4_res(ci, coord, left);
 #pragma nounroll
-                            for (; b >= 4; --b) v |= dec_global(rbase + b) << b;
+                            for (; b >= 4; --b) v |= dec_global(row_word(rbase, b)) << b;
                         }
                         v = dec_residual(lepwave::wave_read(PK2, lane), b, v);
                     }
@@ -631,9 +652,9 @@ struct Dec4Wave {
         adapt_group(W0, u0, b0);
         LANES(l) if (L(u0)) st4(model + L(a0), L(W0));
         if (lepwave::wave_ballot(u1)) {
-            LANES(l) if (L(u1)) L(W1) = ld4(model + L(a0) + 4);   // read on demand by the serial code: the owner re-reads it
+            LANES(l) if (L(u1)) L(W1) = ld4(model + L(a0) + kGS);   // read on demand by the serial code: the owner re-reads it
             adapt_group(W1, u1, b1);
-            LANES(l) if (L(u1)) st4(model + L(a0) + 4, L(W1));
+            LANES(l) if (L(u1)) st4(model + L(a0) + kGS, L(W1));
         }
         if (lepwave::wave_ballot(u2)) {
             adapt_group(W2, u2, b2);

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -173,6 +174,8 @@ struct lep_gpu {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool released = false;   // device side already given back (by lep_gpu_destroy or by the exit handler)
+    int enc_waves = 0;       // the same choice for the encoder (LEP_ENC_WAVES = 4 | 8)
     int dec_waves = 0;       // register-budget build of the decoder: 0 = by batch size (8 waves per SIMD / 64 VGPRs once a launch can
                              // fill them, else 4 / 128 VGPRs, no spills); LEP_DEC_WAVES = 4 | 8 forces one
     std::string err;
@@ -298,10 +301,16 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         else { g->last_kernel = "lep_decode_v4_kernel<4>"; LEP_LAUNCH_DEC4(4); }
 #undef LEP_LAUNCH_DEC4
     } else {
-        g->last_kernel = "lep_encode_v3_kernel<8>";
-        hipLaunchKernelGGL((lep_encode_v3_kernel<8>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),
-                           (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
-                           d_streams, d_stream_len, d_status, g->d_bins);
+#define LEP_LAUNCH_ENC3(W)                                                                                                     \
+    hipLaunchKernelGGL((lep_encode_v3_kernel<W>), dim3(nseg), dim3(64), 0, st, (const ImageDev*)(meta + o_img),                  \
+                       (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns), \
+                       d_streams, d_stream_len, d_status, g->d_bins)
+        // like the decoder: a launch that cannot fill 8 wavefronts per SIMD takes the 4-wave build (128 VGPRs, no spills)
+        int waves = g->enc_waves;
+        if (!waves) waves = nseg > 4608 ? 8 : 4;
+        if (waves >= 8) { g->last_kernel = "lep_encode_v3_kernel<8>"; LEP_LAUNCH_ENC3(8); }
+        else { g->last_kernel = "lep_encode_v3_kernel<4>"; LEP_LAUNCH_ENC3(4); }
+#undef LEP_LAUNCH_ENC3
     }
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));
@@ -311,20 +320,44 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
 
 extern "C" {
 
+// Process exit.  The HIP runtime registers its own teardown with atexit() lazily, at the first HIP call -- i.e. AFTER the
+// static objects of a host program were constructed, so it runs BEFORE their destructors.  A host that keeps its coder in a
+// global (the reference does: g_encoder / g_decoder, jpgcoder.cc:428, 478) would call lep_gpu_destroy on a runtime that is
+// already gone and hang in hipStreamSynchronize (seen on MI355X with oracle/_ref/lepton-mi355x: work done in 0.1 s, process
+// never ended).  So the library registers its own atexit handler after the first successful create -- later than HIP's,
+// hence run earlier -- which releases every live object while the runtime still works; lep_gpu_destroy on such an object
+// afterwards only frees the host struct.
+static std::mutex g_live_mu;
+static std::vector<lep_gpu*> g_live;
+static bool g_exit_hook = false;
+static void release_device_side(lep_gpu* g);
+static void release_all_at_exit() {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (lep_gpu* g : g_live) release_device_side(g);
+    g_live.clear();
+}
+
 int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
     if (const char* e = getenv("LEP_DEC_WAVES")) g->dec_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
+    if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||
         hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess) { delete g; return LEP_GPU_ERROR; }
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.push_back(g);
+        if (!g_exit_hook) { g_exit_hook = true; atexit(release_all_at_exit); }
+    }
     *out = g;
     return 0;
 }
 
-void lep_gpu_destroy(lep_gpu* g) {
-    if (!g) return;
+static void release_device_side(lep_gpu* g) {
+    if (g->released) return;
+    g->released = true;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
     for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
@@ -332,6 +365,15 @@ void lep_gpu_destroy(lep_gpu* g) {
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);
+}
+
+void lep_gpu_destroy(lep_gpu* g) {
+    if (!g) return;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        for (size_t i = 0; i < g_live.size(); ++i) if (g_live[i] == g) { g_live.erase(g_live.begin() + i); break; }
+        release_device_side(g);   // a no-op when the exit handler got there first
+    }
     delete g;
 }
 

@@ -23,10 +23,10 @@ def _round_trip_through(binary, names, tmp_path, verify_flags=("-skipverify",)):
         jpg, lep = golden(n)
         jp, lp, bp = (str(tmp_path / (n + e)) for e in (".jpg", ".lep", ".back.jpg"))
         open(jp, "wb").write(jpg)
-        r = subprocess.run([binary, "-unjailed"] + list(verify_flags) + [jp, lp], capture_output=True, timeout=300)
+        r = subprocess.run([binary, "-unjailed"] + list(verify_flags) + [jp, lp], capture_output=True, timeout=120)
         assert r.returncode == 0, (n, r.returncode, r.stderr[-400:])
         assert open(lp, "rb").read() == lep, n + ": .lep differs from the reference's"
-        r = subprocess.run([binary, "-unjailed", lp, bp], capture_output=True, timeout=300)
+        r = subprocess.run([binary, "-unjailed", lp, bp], capture_output=True, timeout=120)
         assert r.returncode == 0, (n, r.returncode, r.stderr[-400:])
         assert open(bp, "rb").read() == jpg, n + ": restored JPEG differs"
 
