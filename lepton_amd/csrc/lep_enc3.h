@@ -43,6 +43,19 @@ struct Enc3Shared {
     NSum ns_left, ns_above, ns_here;
 };
 
+// Two wavefronts per thread segment (lep_encode_v3x2_kernel: launches too small to fill the chip with one wavefront per
+// segment -- a single image, a serving daemon's trickle).  In the encode direction nothing upstream of the bool coder
+// depends on it, so the block coder splits into a PRODUCER wavefront (P0-P3: staging, IDCT, contexts, bin list, model
+// round trip -> resolved (bit, probability) pairs in LDS) and a CONSUMER wavefront (P4: the bool coder and the sign
+// Branches), one bin-list chunk apart: while the consumer codes chunk i from one buffer the producer fills the other
+// with chunk i+1; one workgroup barrier per chunk hands a buffer over in each direction.
+struct Enc3Pipe {
+    alignas(16) uint32_t bins_b[kBinChunk];   // second bin-list buffer (the first is Enc3Shared::bins)
+    int count[2];                             // bins in buffer k; -1 = the producer is done (or gave up)
+    uint32_t out_len;                         // consumer -> producer at the very end
+    int out_overflow;
+};
+
 // on the GPU: true when the (wave-uniform) condition holds; written as a ballot so that a value the compiler cannot
 // prove uniform still yields a scalar branch instead of exec-mask control flow
 WDEV bool ucond(bool c) {
@@ -63,7 +76,7 @@ struct BoolEnc3 {
     bool overflow;
     WDEV void emit(uint8_t b) {
 #if LEP_ON_GPU
-        if (threadIdx.x == 0) out[pos] = b;
+        if ((threadIdx.x & 63) == 0) out[pos] = b;
 #else
         out[pos] = b;
 #endif
@@ -77,7 +90,7 @@ struct BoolEnc3 {
         int x = (int)pos - 1;
         while (x >= 0 && uload8(out + x) == 0xff) {
 #if LEP_ON_GPU
-            if (threadIdx.x == 0) out[x] = 0;
+            if ((threadIdx.x & 63) == 0) out[x] = 0;
 #else
             out[x] = 0;
 #endif
@@ -86,7 +99,7 @@ struct BoolEnc3 {
         if (x >= 0) {
             const uint8_t v = (uint8_t)(uload8(out + x) + 1);
 #if LEP_ON_GPU
-            if (threadIdx.x == 0) out[x] = v;
+            if ((threadIdx.x & 63) == 0) out[x] = v;
 #else
             out[x] = v;
 #endif
@@ -143,6 +156,55 @@ struct Enc3Wave {
     int comp, ci;
     BoolEnc3 bc;
     uint32_t nbins;
+    Enc3Pipe* pipe = nullptr;   // non-null: this wavefront is the producer half of a two-wave segment
+    int pcur = 0;               // buffer the producer fills next
+    WDEV uint32_t* bin_buffer(int k) const { return k ? pipe->bins_b : sh->bins; }
+    static WDEV void pair_barrier() {
+#if LEP_ON_GPU
+        __syncthreads();
+#endif
+    }
+    // P4 over one resolved chunk (consumer side; also the single-wave kernel's P4)
+    WDEV void code_chunk(const uint32_t* B, int n) {
+        // (entries are read back from LDS at a uniform address, four at a time, and everything derived from them stays
+        // on the vector ALU: a SALU instruction costs about two VALU ones here, profiles/r01_issue_microbench.txt)
+        int j = 0;
+#pragma nounroll
+        for (; j + 4 <= n; j += 4) {
+            const U4 q = ld4(B + j);   // one 16-byte LDS read
+            code_bin(vec(q.x)); code_bin(vec(q.y)); code_bin(vec(q.z)); code_bin(vec(q.w));
+        }
+#pragma nounroll
+        for (; j < n; ++j) code_bin(vec(B[j]));
+    }
+    // producer: hand the chunk in buffer pcur over, continue in the other buffer
+    WDEV void publish_chunk(int n) {
+        LANES(l) if (l == 0) pipe->count[pcur] = n;
+        LSYNC();
+#if LEP_ON_GPU
+        pair_barrier();
+#else
+        code_chunk(bin_buffer(pcur), n);   // lane-loop emulation: the consumer's step, run in place
+#endif
+        pcur ^= 1;
+    }
+    // consumer wavefront: codes chunk after chunk until the producer says -1; returns the stream length
+    WDEV uint32_t consume(Enc3Shared* shared, Enc3Pipe* p, uint8_t* stream, uint32_t cap) {
+        sh = shared; pipe = p;
+        bc.init_stream(stream, cap);
+        pair_barrier();   // tables (sign Branches) initialised by the producer
+        for (int k = 0;; k ^= 1) {
+            pair_barrier();
+            const int n = (int)uni((uint32_t)p->count[k]);
+            if (n < 0) break;
+            code_chunk(bin_buffer(k), n);
+        }
+        const uint32_t len = bc.finish();
+        LANES(l) if (l == 0) { p->out_len = len; p->out_overflow = bc.overflow ? 1 : 0; }
+        LSYNC();
+        pair_barrier();
+        return len;
+    }
 
     WDEV void init_tables() {
         LANES(l) {
@@ -402,6 +464,7 @@ struct Enc3Wave {
             const int n = (lane1 < 64 ? (int)lepwave::wave_read((const uint32_t*)off, lane1) : N) - base;
             const int dbase = (int)lepwave::wave_read((const uint32_t*)doff, lane0);
             const int D = (lane1 < 64 ? (int)lepwave::wave_read((const uint32_t*)doff, lane1) : dbase + 0x7fffffff) ;
+            uint32_t* const B = pipe ? bin_buffer(pcur) : S.bins;   // the bin list of this chunk
             // ---- P2: bin emission ---------------------------------------------------------------------
             LEP_EMARK("e_p2");
         LV(int, dcount);
@@ -412,19 +475,19 @@ struct Enc3Wave {
                     if (l == 0) {
                         const uint32_t T = lepdev::kNz7x7 + ((uint32_t)ci * 26 + S.nzbin[nzctx]) * 192;
                         int so_far = 0;
-                        for (int i = 5; i >= 0; --i) { int b = (nz >> i) & 1; S.bins[j++] = (T + i * 32 + so_far) | ((uint32_t)b << 31); so_far = (so_far << 1) | b; }
+                        for (int i = 5; i >= 0; --i) { int b = (nz >> i) & 1; B[j++] = (T + i * 32 + so_far) | ((uint32_t)b << 31); so_far = (so_far << 1) | b; }
                     }
                     if (l == 49 || l == 56) {
                         const bool horizontal = l == 49;
                         const uint32_t T = (horizontal ? lepdev::kNz8x1 : lepdev::kNz1x8) + (((uint32_t)ci * 8 + (horizontal ? eob_x : eob_y)) * 8 + (nz + 3) / 7) * 12;
                         const int ne = horizontal ? neh : nev;
                         int so_far = 0;
-                        for (int i = 2; i >= 0; --i) { int b = (ne >> i) & 1; S.bins[j++] = (T + i * 4 + so_far) | ((uint32_t)b << 31); so_far = (so_far << 1) | b; }
+                        for (int i = 2; i >= 0; --i) { int b = (ne >> i) & 1; B[j++] = (T + i * 4 + so_far) | ((uint32_t)b << 31); so_far = (so_far << 1) | b; }
                     }
                     if (L(coded_)) {
                         const int len = L(len_), v = L(val_), nexp = L(nexp_);
-                        for (int i = 0; i < nexp; ++i) S.bins[j++] = (L(expbase_) + i) | ((uint32_t)(len != i) << 31);
-                        if (len) S.bins[j++] = L(signidx_) | kResident3 | ((uint32_t)L(pos_) << 31);
+                        for (int i = 0; i < nexp; ++i) B[j++] = (L(expbase_) + i) | ((uint32_t)(len != i) << 31);
+                        if (len) B[j++] = L(signidx_) | kResident3 | ((uint32_t)L(pos_) << 31);
                         if (len > 1) {
                             int b = len - 2;
                             if (L(isedge_) && b >= L(thr_)) {
@@ -432,11 +495,11 @@ struct Enc3Wave {
                                 for (; b >= L(thr_); --b) {
                                     int bit = (v >> b) & 1;
                                     S.dup[dj++] = (uint16_t)j;
-                                    S.bins[j++] = (L(thrbase_) + s) | ((uint32_t)bit << 31);
+                                    B[j++] = (L(thrbase_) + s) | ((uint32_t)bit << 31);
                                     s = imin((s << 1) | bit, 127);
                                 }
                             }
-                            for (; b >= 0; --b) S.bins[j++] = (L(resbase_) + b) | ((uint32_t)((v >> b) & 1) << 31);
+                            for (; b >= 0; --b) B[j++] = (L(resbase_) + b) | ((uint32_t)((v >> b) & 1) << 31);
                         }
                     }
                 }
@@ -458,7 +521,7 @@ struct Enc3Wave {
                 int j = -1;
                 if (l < nn0) {
                     j = S.dup[l];
-                    const uint32_t e = S.bins[j];
+                    const uint32_t e = B[j];
                     idx = e & 0x3fffffffu; bit = e >> 31;
                     w = model[idx];
                 }
@@ -470,20 +533,20 @@ struct Enc3Wave {
                 LANES(l) {
                     const int j0 = b0 + l, j1 = b0 + 64 + l;
                     uint32_t a = 0, b = 0;
-                    if (j0 < n) { const uint32_t e = S.bins[j0]; if (!(e & kResident3) && (e & 0x3fffffffu) < lepdev::kThresh) a = model[e & 0x3fffffffu]; }
-                    if (j1 < n) { const uint32_t e = S.bins[j1]; if (!(e & kResident3) && (e & 0x3fffffffu) < lepdev::kThresh) b = model[e & 0x3fffffffu]; }
+                    if (j0 < n) { const uint32_t e = B[j0]; if (!(e & kResident3) && (e & 0x3fffffffu) < lepdev::kThresh) a = model[e & 0x3fffffffu]; }
+                    if (j1 < n) { const uint32_t e = B[j1]; if (!(e & kResident3) && (e & 0x3fffffffu) < lepdev::kThresh) b = model[e & 0x3fffffffu]; }
                     L(w0) = a; L(w1) = b;
                 }
                 LANES(l) {
                     for (int h = 0; h < 2; ++h) {
                         const int j = b0 + h * 64 + l;
                         if (j < n) {
-                            const uint32_t e = S.bins[j], idx = e & 0x3fffffffu;
+                            const uint32_t e = B[j], idx = e & 0x3fffffffu;
                             if (!(e & kResident3) && idx < lepdev::kThresh) {
                                 const uint32_t w = h ? L(w1) : L(w0);
                                 const int bit = (int)(e >> 31);
                                 model[idx] = bupd(w, bit);
-                                S.bins[j] = (w >> 16) | ((uint32_t)bit << 8);
+                                B[j] = (w >> 16) | ((uint32_t)bit << 8);
                             }
                         }
                     }
@@ -499,7 +562,7 @@ struct Enc3Wave {
                         int j = -1;
                         if (l < nn) {
                             j = S.dup[cb + l];
-                            const uint32_t e = S.bins[j];
+                            const uint32_t e = B[j];
                             idx = e & 0x3fffffffu; bit = e >> 31;
                             w = model[idx];
                         }
@@ -515,7 +578,7 @@ struct Enc3Wave {
                 }
                 if (!lepwave::wave_ballot(conf)) {
                     LANES(l) if (l < nn) {
-                        S.bins[L(djpos)] = (L(dw) >> 16) | (L(dbit) << 8);
+                        B[L(djpos)] = (L(dw) >> 16) | (L(dbit) << 8);
                         model[L(didx)] = bupd(L(dw), (int)L(dbit));
                     }
                 } else {
@@ -523,7 +586,7 @@ struct Enc3Wave {
                         const uint32_t ridx = lepwave::wave_read(didx, r), rw = lepwave::wave_read(dw, r), rbit = lepwave::wave_read(dbit, r);
                         const uint32_t nw = bupd_s(rw, (int)rbit);
                         LANES(l) {
-                            if (l == r) { S.bins[L(djpos)] = (rw >> 16) | (rbit << 8); L(dw) = nw; }
+                            if (l == r) { B[L(djpos)] = (rw >> 16) | (rbit << 8); L(dw) = nw; }
                             else if (L(didx) == ridx) { if (l > r) L(dw) = nw; else L(dlast) = 0; }
                         }
                     }
@@ -535,18 +598,8 @@ struct Enc3Wave {
 
             // ---- P4: bool coder over the resolved (bit, probability) pairs: uniform vector code ------------
             LEP_EMARK("e_p4");
-            // (entries are read back from LDS at a uniform address, four at a time, and everything derived from them stays
-            // on the vector ALU: a SALU instruction costs about two VALU ones here, profiles/r01_issue_microbench.txt)
-            {
-                int j = 0;
-#pragma nounroll
-                for (; j + 4 <= n; j += 4) {
-                    const U4 q = ld4(S.bins + j);   // one 16-byte LDS read
-                    code_bin(vec(q.x)); code_bin(vec(q.y)); code_bin(vec(q.z)); code_bin(vec(q.w));
-                }
-#pragma nounroll
-                for (; j < n; ++j) code_bin(vec(S.bins[j]));
-            }
+            if (pipe) publish_chunk(n);   // two-wave segment: the consumer wavefront codes it while this one goes on
+            else code_chunk(B, n);
             LSYNC();
             lane0 = lane1;
         }
@@ -568,11 +621,27 @@ struct Enc3Wave {
     }
 
     // whole segment; ns = this segment's NSum area (zeroed); returns exit code
+    // p != nullptr: this wavefront is the producer of a two-wave segment (the consumer runs consume() with the same p)
     WDEV int run(const ImageDev* image, const SegDev& seg, uint32_t* model_words, NSum* ns, Enc3Shared* shared, uint8_t* stream,
-                 uint32_t cap) {
-        img = image; model = model_words; sh = shared; nbins = 0;
+                 uint32_t cap, Enc3Pipe* p = nullptr) {
+        img = image; model = model_words; sh = shared; nbins = 0; pipe = p; pcur = 0;
         init_tables();
-        bc.init_stream(stream, cap);
+#if LEP_ON_GPU
+        if (pipe) pair_barrier(); else bc.init_stream(stream, cap);
+#else
+        bc.init_stream(stream, cap);   // lane-loop emulation: this instance also plays the consumer (publish_chunk)
+#endif
+        const int rc = run_rows(seg, ns);
+        if (pipe) {   // tell the consumer to finish, then wait for its verdict
+            LANES(l) if (l == 0) pipe->count[pcur] = -1;
+            LSYNC();
+            pair_barrier();
+            pair_barrier();
+        }
+        return rc;
+    }
+    WDEV int run_rows(const SegDev& seg, NSum* ns) {
+        const ImageDev* image = img;
         bool top[3] = {true, true, true};
         SegmentCoder<false> sched;   // only its row schedule is used
         sched.img = image;

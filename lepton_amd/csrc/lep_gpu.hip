@@ -66,6 +66,35 @@ __global__ __launch_bounds__(64, WAVES) void lep_encode_v3_kernel(const ImageDev
     bins[seg.slot] = w.nbins;
 }
 
+// Two wavefronts per thread segment (lep_enc3.h, Enc3Pipe): wavefront 0 produces resolved bin-list chunks, wavefront 1
+// runs the bool coder one chunk behind.  For launches that cannot fill the chip with one wavefront per segment (a single
+// image is 8 segments): the segment's serial chain is about half as long.
+__global__ __launch_bounds__(128, 2) void lep_encode_v3x2_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
+                                                                 uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
+                                                                 uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
+    __shared__ lep3::Enc3Shared sh;
+    __shared__ lep3::Enc3Pipe pipe;
+    const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const SegDev seg = segs[s];
+    const ImageDev* img = images + seg.image;
+    uint32_t* model = models + (size_t)s * kModelStride;
+    NSum* ns = ns_area + ns_offsets[s];
+    if (wave == 0) reset_segment_state(model, ns, img->ns_total, lane);
+    if (threadIdx.x == 0) { pipe.count[0] = 0; pipe.count[1] = 0; }
+    __syncthreads();
+    lep3::Enc3Wave w;
+    if (wave == 0) {
+        int rc = w.run(img, seg, model, ns, &sh, streams + seg.stream_off, seg.stream_cap, &pipe);
+        if (lane != 0) return;
+        if (!rc && pipe.out_overflow) rc = LEP_BUFFER_TOO_SMALL;
+        stream_len[seg.slot] = rc ? 0 : pipe.out_len;
+        status[seg.slot] = rc;
+        bins[seg.slot] = w.nbins;
+    } else {
+        w.consume(&sh, &pipe, streams + seg.stream_off, seg.stream_cap);
+    }
+}
+
 #ifdef LEP_PROF
 __device__ unsigned long long g_prof4[8192][32];   // private accumulators per wave (no atomic contention)
 #endif
@@ -175,7 +204,9 @@ struct lep_gpu {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     bool released = false;   // device side already given back (by lep_gpu_destroy or by the exit handler)
-    int enc_waves = 0;       // the same choice for the encoder (LEP_ENC_WAVES = 4 | 8)
+    int enc_waves = 0;       // the same choice for the encoder (LEP_ENC_WAVES = 4 | 8; 2 = the two-wavefronts-per-segment kernel)
+    int enc_pair_max = 2048; // launches of up to this many segments take the two-wave encoder (2048 workgroups x 2 waves still
+                             // leave every wavefront its own SIMD issue slot: 256 CUs x 4 SIMDs x ... ); LEP_ENC_PAIR_MAX
     int dec_waves = 0;       // register-budget build of the decoder: 0 = by batch size (8 waves per SIMD / 64 VGPRs once a launch can
                              // fill them, else 4 / 128 VGPRs, no spills); LEP_DEC_WAVES = 4 | 8 forces one
     std::string err;
@@ -307,8 +338,14 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
                        d_streams, d_stream_len, d_status, g->d_bins)
         // like the decoder: a launch that cannot fill 8 wavefronts per SIMD takes the 4-wave build (128 VGPRs, no spills)
         int waves = g->enc_waves;
-        if (!waves) waves = nseg > 4608 ? 8 : 4;
-        if (waves >= 8) { g->last_kernel = "lep_encode_v3_kernel<8>"; LEP_LAUNCH_ENC3(8); }
+        if (!waves) waves = nseg > 4608 ? 8 : (nseg <= g->enc_pair_max ? 2 : 4);
+        if (waves == 2) {   // few segments: two wavefronts per segment (producer / bool coder), half the serial chain
+            g->last_kernel = "lep_encode_v3x2_kernel";
+            hipLaunchKernelGGL(lep_encode_v3x2_kernel, dim3(nseg), dim3(128), 0, st, (const ImageDev*)(meta + o_img),
+                               (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
+                               d_streams, d_stream_len, d_status, g->d_bins);
+        }
+        else if (waves >= 8) { g->last_kernel = "lep_encode_v3_kernel<8>"; LEP_LAUNCH_ENC3(8); }
         else { g->last_kernel = "lep_encode_v3_kernel<4>"; LEP_LAUNCH_ENC3(4); }
 #undef LEP_LAUNCH_ENC3
     }
@@ -341,7 +378,8 @@ int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
     if (const char* e = getenv("LEP_DEC_WAVES")) g->dec_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
-    if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
+    if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 0));
+    if (const char* e = getenv("LEP_ENC_PAIR_MAX")) g->enc_pair_max = atoi(e);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||

@@ -135,8 +135,9 @@ extern "C" int emu_encode_segment_v3(const lep_image_desc* d, int y0, int y1, in
     SegDev seg;
     seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = cap;
     static lep3::Enc3Shared sh;
+    static lep3::Enc3Pipe pipe;   // LEP_EMU_ENC_PIPE=1: the producer half of the two-wave kernel; its hand-over runs the consumer's step in place
     lep3::Enc3Wave w;
-    rc = w.run(&img, seg, model.data(), ns.data(), &sh, out, cap);
+    rc = w.run(&img, seg, model.data(), ns.data(), &sh, out, cap, getenv("LEP_EMU_ENC_PIPE") ? &pipe : nullptr);
     if (rc) return rc;
     *len = w.bc.finish();
     if (w.bc.overflow) return LEP_BUFFER_TOO_SMALL;

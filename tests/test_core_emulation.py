@@ -152,8 +152,19 @@ def test_v3_decoder_unaligned_stream_start(emu, shift, gen):
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
 
 
+@pytest.fixture(params=["one wavefront", "producer + consumer"])
+def enc_mode(request, monkeypatch):
+    """the encoder's two forms: one wavefront per segment, or the producer half of the two-wave kernel handing its bin-list
+    chunks through the double buffer (the emulation runs the consumer's step in place)"""
+    if request.param != "one wavefront":
+        monkeypatch.setenv("LEP_EMU_ENC_PIPE", "1")
+    else:
+        monkeypatch.delenv("LEP_EMU_ENC_PIPE", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("name", golden_cases())
-def test_v3_encoder_on_cpu_matches_oracle(emu, name):
+def test_v3_encoder_on_cpu_matches_oracle(emu, name, enc_mode):
     """lep_enc3.h (lane-range bin list, uniform-vector bool coder) as a 64-lane loop emulation == oracle streams"""
     jpg, _ = golden(name)
     img = JpegImage(jpg)
@@ -171,7 +182,7 @@ def test_v3_encoder_on_cpu_matches_oracle(emu, name):
     assert total == bins
 
 
-def test_v3_encoder_many_bins_per_block(emu):
+def test_v3_encoder_many_bins_per_block(emu, enc_mode):
     """blocks whose bin list does not fit one 512-entry lane range (large coefficients everywhere) are coded in several
     ranges; streams must still equal the oracle's, and out-of-range coefficients are reported like the reference does"""
     import numpy as np

@@ -342,3 +342,43 @@ def test_gpu_parallel_huffman_decode_in_the_compress_pipeline(gpu_codec, monkeyp
     assert st == [0] * len(jpgs)
     assert got[: len(names)] == [golden(n)[1] for n in names]
     assert got[len(names):] == [gpu_codec.compress(j) for j in jpgs[len(names):]]
+
+
+@pytest.mark.parametrize("waves", ["2", "4", "8"])
+def test_gpu_encoder_builds_agree(waves, monkeypatch):
+    """the encoder's three launch forms -- two wavefronts per segment (producer / bool coder, small launches), one wavefront
+    with 128 VGPRs, one with 64 -- write the same streams: golden .lep bytes, oracle streams for blocks with more bins
+    than one chunk holds, and the same exit code for a coefficient the format cannot hold"""
+    import numpy as np
+
+    monkeypatch.setenv("LEP_ENC_WAVES", waves)
+    codec = GpuCodec(0)
+    try:
+        for name in ("c420_odd_203x149", "q30_256x256_4seg", "gray_120x88", "prog_c420_320x240", "truncated", "one_block_8x8"):
+            jpg, lep = golden(name)
+            assert codec.compress(jpg) == lep, name
+        assert abi.lib().lep_gpu_last_kernel_name(codec.handle).decode() == {"2": "lep_encode_v3x2_kernel", "4": "lep_encode_v3_kernel<4>", "8": "lep_encode_v3_kernel<8>"}[waves]
+        img = JpegImage(corpus.synth_jpeg(64, 48, 11, quality=100))
+        d = img.desc
+        rng = np.random.default_rng(5)
+        for c in range(d.ncomp):
+            n = d.nblocks(c) * 64
+            arr = (C.c_int16 * n).from_address(d.blocks[c])
+            vals = rng.integers(-255, 256, n)
+            vals[rng.random(n) < 0.1] = 0
+            for i in range(n):
+                arr[i] = int(vals[i])
+            for b in range(d.nblocks(c)):
+                arr[b * 64 + 49] = 0
+        plan = img.plan()
+        want, _ = ob.oracle_encode(d, plan)
+        assert codec.encode([img], [plan])[0] == want
+        arr = (C.c_int16 * 64).from_address(d.blocks[0])
+        arr[3] = 3000                                   # 12 bits: COEFFICIENT_OUT_OF_RANGE, and the launch must come back
+        with pytest.raises(LeptonError) as e:
+            codec.encode([img], [plan])
+        assert e.value.code == 6
+        jpg = corpus.synth_jpeg(1280, 720, 78, quality=92)
+        assert codec.decompress(codec.compress(jpg)) == jpg
+    finally:
+        codec.close()
