@@ -205,8 +205,9 @@ struct lep_gpu {
     bool timed = false;
     bool released = false;   // device side already given back (by lep_gpu_destroy or by the exit handler)
     int enc_waves = 0;       // the same choice for the encoder (LEP_ENC_WAVES = 4 | 8; 2 = the two-wavefronts-per-segment kernel)
-    int enc_pair_max = 2048; // launches of up to this many segments take the two-wave encoder (2048 workgroups x 2 waves still
-                             // leave every wavefront its own SIMD issue slot: 256 CUs x 4 SIMDs x ... ); LEP_ENC_PAIR_MAX
+    int enc_pair_max = 1280; // launches of up to this many segments take the two-wave encoder: its 128-thread workgroups are resident 6 per
+                             // CU (1536 on the chip), one pass; measured (profiles/r02d_latency_sweep.json, 4K images): 1 .. 128 images
+                             // 300-343 ms against 450-496 ms for one wavefront per segment, 256 images 650 against 510.  LEP_ENC_PAIR_MAX
     int dec_waves = 0;       // register-budget build of the decoder: 0 = by batch size (8 waves per SIMD / 64 VGPRs once a launch can
                              // fill them, else 4 / 128 VGPRs, no spills); LEP_DEC_WAVES = 4 | 8 forces one
     std::string err;
