@@ -127,6 +127,32 @@ typedef struct lep_huff_segment {
 } lep_huff_segment;
 int lep_gpu_huffman_encode_device(lep_gpu *g, const lep_huff_image *images, int nimg, const lep_huff_segment *segs, int nseg,
                                   uint8_t *d_out, uint32_t *d_out_len, void *hip_stream);
+/* The same for PROGRESSIVE files (BASELINE.json configs[4]; replaces the scan loop of recode_jpeg, src/lepton/jpgcoder.cc:3309-3716,
+ * with encode_dc_prg_*, encode_ac_prg_fs / _sa, encode_eobrun, encode_crbits :4991-5400): every scan of a progressive file is a
+ * function of the finished frame alone, so one wavefront per (image, scan) writes that scan's bytes (FF00-stuffed, restart
+ * markers included) to d_out + scans[i].out_off; d_out_len[i] = byte count, bit 31 set = the scan outgrew its slot or its
+ * scratch (let the host re-coder do that file).  d_corr: scratch for correction bits held back behind end-of-band runs
+ * (scans[i].corr_off / corr_cap dwords).  lep_file_recode_plan_progressive fills both structs. */
+typedef struct lep_huffprog_image {
+    int32_t ncomp, mcuh, mcuv, mcuc;
+    int32_t rsti, padbit;
+    int32_t hs[4], vs[4], bch[4], bcv[4], nch[4], ncv[4], mbs[4];
+    const int16_t *blocks[4];
+} lep_huffprog_image;
+typedef struct lep_huffprog_scan {
+    int32_t image;
+    int32_t cmpc, cmp[4];                /* components of the scan, in scan order */
+    int32_t from, to, sah, sal;          /* spectral band, successive approximation high / low */
+    int32_t max_eobrun;
+    int32_t tbl[4];                      /* DC scans: table slot (0 / 1) of each scan component */
+    uint64_t out_off;
+    uint32_t out_cap;
+    uint32_t corr_off, corr_cap;         /* dwords */
+    uint32_t pad;
+    uint32_t code[2][256];               /* DC scans: DC tables 0 / 1; AC scans: [0] = the component's AC table; length << 16 | code */
+} lep_huffprog_scan;
+int lep_gpu_huffman_progressive_encode_device(lep_gpu *g, const lep_huffprog_image *images, int nimg, const lep_huffprog_scan *scans,
+                                              int nscan, uint8_t *d_out, uint32_t *d_corr, uint32_t *d_out_len, void *hip_stream);
 /* JPEG Huffman scan decode on the GPU (replaces decode_jpeg / decode_block_seq, src/lepton/jpgcoder.cc:2799-3302,
  * 4893-4966, for whole single-scan interleaved sequential files): one wavefront per image decodes the un-stuffed scan into
  * the zero-filled device frame images[i].blocks and writes images[i].mcuv + 1 records (bit position + last DC per MCU row,
@@ -233,6 +259,11 @@ int lep_file_recode(lep_file *f, lep_bytes *out);
  * set; out_cap is the segment's byte bound); _finish glues header, the segments' scan bytes and the trailer together. */
 int lep_file_recode_plan(lep_file *f, lep_huff_image *image, lep_huff_segment *segs, int *nseg, int *gpu_ok);
 int lep_file_recode_finish(lep_file *f, const lep_bytes *seg_bytes, int nseg, lep_bytes *out);
+/* progressive files: _plan fills the image and up to `cap` scan descriptors (out_cap / corr_cap = what each scan may need;
+ * image index, out_off, corr_off and blocks[] are the caller's to set); *gpu_ok = 0: the file keeps the host re-coder
+ * (truncated, sequential multi-scan, withheld restart markers ...).  _finish glues header pieces, scans and trailer. */
+int lep_file_recode_plan_progressive(lep_file *f, lep_huffprog_image *image, lep_huffprog_scan *scans, int cap, int *nscan, int *gpu_ok);
+int lep_file_recode_finish_progressive(lep_file *f, const lep_bytes *scan_bytes, int nscan, lep_bytes *out);
 
 
 /* .lep framing pieces, exposed for callers that assemble containers themselves */

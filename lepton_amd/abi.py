@@ -62,6 +62,18 @@ class HuffSegment(C.Structure):
                 ("out_off", C.c_uint64), ("out_cap", C.c_uint32), ("pad", C.c_uint32)]
 
 
+class HuffProgImage(C.Structure):
+    _fields_ = [("ncomp", C.c_int32), ("mcuh", C.c_int32), ("mcuv", C.c_int32), ("mcuc", C.c_int32), ("rsti", C.c_int32), ("padbit", C.c_int32),
+                ("hs", C.c_int32 * 4), ("vs", C.c_int32 * 4), ("bch", C.c_int32 * 4), ("bcv", C.c_int32 * 4), ("nch", C.c_int32 * 4),
+                ("ncv", C.c_int32 * 4), ("mbs", C.c_int32 * 4), ("blocks", C.c_void_p * 4)]
+
+
+class HuffProgScan(C.Structure):
+    _fields_ = [("image", C.c_int32), ("cmpc", C.c_int32), ("cmp", C.c_int32 * 4), ("from_", C.c_int32), ("to", C.c_int32), ("sah", C.c_int32),
+                ("sal", C.c_int32), ("max_eobrun", C.c_int32), ("tbl", C.c_int32 * 4), ("out_off", C.c_uint64), ("out_cap", C.c_uint32),
+                ("corr_off", C.c_uint32), ("corr_cap", C.c_uint32), ("pad", C.c_uint32), ("code", (C.c_uint32 * 256) * 2)]
+
+
 class HuffDecImage(C.Structure):
     _fields_ = [("scan", C.c_void_p), ("scan_len", C.c_uint32), ("ncomp", C.c_int32), ("mcuh", C.c_int32), ("mcuv", C.c_int32), ("mcuc", C.c_int32),
                 ("rsti", C.c_int32), ("hs", C.c_int32 * 4), ("vs", C.c_int32 * 4), ("bch", C.c_int32 * 4), ("dc_tbl", C.c_int32 * 4),
@@ -179,6 +191,9 @@ def lib():
         L.lep_gpu_huffman_encode_device.argtypes = [vp, P(HuffImage), C.c_int, P(HuffSegment), C.c_int, vp, vp, vp]
         L.lep_batch_release.argtypes = []
         L.lep_batch_release.restype = None
+        L.lep_file_recode_plan_progressive.argtypes = [vp, P(HuffProgImage), P(HuffProgScan), C.c_int, P(C.c_int), P(C.c_int)]
+        L.lep_file_recode_finish_progressive.argtypes = [vp, P(Bytes), C.c_int, P(Bytes)]
+        L.lep_gpu_huffman_progressive_encode_device.argtypes = [vp, P(HuffProgImage), C.c_int, P(HuffProgScan), C.c_int, vp, vp, vp, vp]
         L.lep_file_consumed.argtypes = [vp]
         L.lep_file_consumed.restype = C.c_size_t
         L.lep_chained_file_follows.argtypes = [vp, C.c_size_t, C.c_size_t]
@@ -204,4 +219,5 @@ EXPORTS = [
     "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_file_recode_plan", "lep_file_recode_finish", "lep_gpu_huffman_encode_device", "lep_jpeg_open_gpu", "lep_jpeg_scan_bytes", "lep_jpeg_finish_gpu", "lep_gpu_huffman_decode_device", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
     "lep_serve_start", "lep_serve_get_stats", "lep_serve_stop", "lep_zlib0_wrap", "lep_jpeg_open_slice", "lep_compress_slice", "lep_jpeg_open_embedded", "lep_compress_embedded", "lep_gpu_use_arena", "lep_batch_plan", "lep_jpeg_set_encode_options", "lep_gpu_huffman_decode_parallel_device",
     "lep_jpeg_check_restores", "lep_batch_debug_poison", "lep_jpeg_plan_handoffs", "lep_file_consumed", "lep_chained_file_follows", "lep_file_open_next",
+    "lep_file_recode_plan_progressive", "lep_file_recode_finish_progressive", "lep_gpu_huffman_progressive_encode_device",
 ]

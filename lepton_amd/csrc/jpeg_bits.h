@@ -50,6 +50,14 @@ struct BitReader {
         }
         return out;
     }
+    // Fast path for the Huffman decoders: keep the window topped up and look at the next bits without consuming them.
+    // getpos / overhang / the end-of-data rule depend only on (next_byte, avail), not on how the window was filled.
+    inline void top_up() {
+        while (avail <= 56 && next_byte < size) { window = (window << 8) | data[next_byte++]; avail += 8; }
+    }
+    inline unsigned peek(int nbits) const { return (unsigned)(low_bits(window, avail) >> (avail - nbits)); }   // needs avail >= nbits
+    inline void skip(int nbits) { avail -= nbits; }
+
     // pad-bit pattern of the current partial byte (consumes it)
     uint8_t unpad(uint8_t fillbit) {
         if ((avail & 7) == 0 || eof) return fillbit;
@@ -77,6 +85,13 @@ struct BitReader {
 };
 
 inline int next_huffcode(BitReader& br, const HuffTable& t) {
+    if (!br.eof) {
+        br.top_up();
+        if (br.avail >= 10) {
+            const unsigned e = t.lut[br.peek(10)];
+            if (e) { br.skip((int)(e >> 8)); return (int)(e & 255); }
+        }
+    }
     int node = 0;
     while (node < 256) {
         node = br.read(1) == 1 ? t.r[node] : t.l[node];

@@ -55,6 +55,9 @@ struct HuffTable {
     uint16_t cval[256];
     uint16_t l[256], r[256];   // decoding tree, leaf = 256 + symbol
     int max_eobrun = 0;
+    // first-level lookup derived FROM the tree (so that odd tables decode exactly as the walk does): index = the next 10
+    // bits, entry = code length << 8 | symbol, 0 = longer than 10 bits or no such code (the bit-by-bit walk decides)
+    uint16_t lut[1024];
 };
 
 struct JpegFile {

@@ -466,4 +466,115 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
     return 0;
 }
 
+// ---- the same with the scans coded on the GPU (lep_huffprog.h) ---------------------------------------------------------------------
+int recode_progressive_prepare(LepFile* lf, ProgPlan* plan) {
+    JpegFile& jf = lf->jpeg;
+    plan->gpu_ok = false;
+    plan->scans.clear(); plan->scan_hdr_end.clear(); plan->markers.clear();
+    if (lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1)) return 0;   // the baseline re-coder's files
+    if (lf->jpeg_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
+    // eligibility: whole progressive frames of up to three components; everything else keeps the host coder
+    bool ok = jf.jpegtype == 2 && !jf.early_eof && jf.ncomp >= 1 && jf.ncomp <= 3 && jf.mcuh > 0 && jf.mcuv > 0;
+    for (int c = 0; c < jf.ncomp; ++c) ok = ok && jf.trunc_bcv[c] >= jf.comp[c].bcv && jf.comp[c].nch > 0 && jf.comp[c].ncv > 0;
+    if (!ok) return 0;
+    ProgImage& im = plan->image;
+    memset(&im, 0, sizeof im);
+    im.ncomp = jf.ncomp; im.mcuh = jf.mcuh; im.mcuv = jf.mcuv; im.mcuc = jf.mcuc; im.padbit = jf.padbit;
+    for (int c = 0; c < jf.ncomp; ++c) {
+        const Component& k = jf.comp[c];
+        im.hs[c] = k.hs; im.vs[c] = k.vs; im.bch[c] = k.bch; im.bcv[c] = k.bcv; im.nch[c] = k.nch; im.ncv[c] = k.ncv; im.mbs[c] = k.mbs;
+    }
+    const uint8_t* h = jf.hdr.data();
+    const size_t hdrs = jf.hdr.size();
+    size_t hpos = 0;
+    int rsti_seen = -1;
+    for (;;) {
+        uint8_t type = 0;
+        while (type != 0xDA) {
+            if (hpos >= hdrs) break;
+            type = hpos + 1 < hdrs ? h[hpos + 1] : 0;
+            const unsigned len = 2 + (((unsigned)(hpos + 2 < hdrs ? h[hpos + 2] : 0)) << 8) + (hpos + 3 < hdrs ? h[hpos + 3] : 0);
+            if (type == 0xC4 || type == 0xDA || type == 0xDD)
+                if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - hpos), h + hpos, false)) return EX_CODING_ERROR;
+            hpos += len;
+        }
+        if (type != 0xDA) break;
+        plan->scan_hdr_end.push_back(std::min(hpos, hdrs));
+        if (rsti_seen >= 0 && rsti_seen != jf.rsti) return 0;   // a restart interval that changes between scans: host
+        rsti_seen = jf.rsti;
+        ProgScan sc;
+        memset(&sc, 0, sizeof sc);
+        sc.cmpc = jf.cs_cmpc; sc.from = jf.cs_from; sc.to = jf.cs_to; sc.sah = jf.cs_sah; sc.sal = jf.cs_sal;
+        if (sc.cmpc < 1 || sc.cmpc > jf.ncomp || sc.sal < 0 || sc.sal > 13 || sc.from < 0 || sc.to > 63 || sc.from > sc.to) return 0;
+        const bool dc = sc.to == 0;
+        if (!dc && (sc.cmpc != 1 || sc.from < 1)) return 0;
+        if (dc && sc.from != 0) return 0;
+        size_t blocks = 0, units;
+        for (int i = 0; i < sc.cmpc; ++i) {
+            const int c = jf.cs_cmp[i];
+            if (c < 0 || c >= jf.ncomp) return 0;
+            sc.cmp[i] = c;
+        }
+        if (sc.cmpc == 1) { const Component& k = jf.comp[sc.cmp[0]]; blocks = units = (size_t)k.nch * k.ncv; }
+        else { units = (size_t)jf.mcuc; for (int i = 0; i < sc.cmpc; ++i) blocks += (size_t)jf.comp[sc.cmp[i]].mbs * jf.mcuc; }
+        if (dc) {
+            for (int i = 0; i < sc.cmpc; ++i) {
+                const int t = jf.comp[sc.cmp[i]].dc_tbl;
+                if (t < 0 || t > 1 || (sc.sah == 0 && !jf.htab[0][t].set)) return 0;
+                sc.tbl[i] = t;
+            }
+            for (int t = 0; t < 2; ++t)
+                for (int i = 0; i < 256; ++i) sc.code[t][i] = jf.htab[0][t].set ? ((uint32_t)jf.htab[0][t].clen[i] << 16) | jf.htab[0][t].cval[i] : 0u;
+        } else {
+            const int t = jf.comp[sc.cmp[0]].ac_tbl;
+            if (t < 0 || t > 3 || !jf.htab[1][t].set) return 0;
+            for (int i = 0; i < 256; ++i) sc.code[0][i] = ((uint32_t)jf.htab[1][t].clen[i] << 16) | jf.htab[1][t].cval[i];
+            sc.max_eobrun = jf.htab[1][t].max_eobrun;
+            if (sc.max_eobrun < 1) return 0;   // a table without any end-of-band code: the host coder's corner
+        }
+        const size_t nmark = jf.rsti > 0 ? (units + (size_t)jf.rsti - 1) / (size_t)jf.rsti - 1 : 0;
+        const size_t scan_index = plan->scans.size();
+        if (lf->rst_cnt_set && nmark > 0 && !(jf.rst_cnt.size() > scan_index && nmark <= jf.rst_cnt[scan_index])) return 0;   // markers withheld: host
+        plan->markers.push_back((uint32_t)nmark);
+        const size_t geo = blocks * (dc ? 8 : 432) + nmark * 2 + units / 4 + 64;
+        sc.out_cap = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)lf->jpeg_size + 16, geo), 0xfffffff0u);
+        sc.corr_cap = (!dc && sc.sah != 0) ? (uint32_t)std::min<size_t>(blocks * 2 + 8, 0x7fffffffu) : 0u;
+        plan->scans.push_back(sc);
+        if (plan->scans.size() > 256) return 0;
+    }
+    if (plan->scans.empty()) return 0;
+    im.rsti = jf.rsti;
+    plan->gpu_ok = true;
+    return 0;
+}
+
+int recode_progressive_finish(LepFile* lf, const ProgPlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& scan_bytes,
+                              std::vector<uint8_t>* result) {
+    JpegFile& jf = lf->jpeg;
+    const size_t max_file_size = lf->jpeg_size;
+    if (scan_bytes.size() != plan.scans.size()) return EX_ASSERTION_FAILURE;
+    const uint8_t* h = jf.hdr.data();
+    const size_t hdrs = jf.hdr.size();
+    std::vector<uint8_t> out;
+    out.reserve(max_file_size + 16);
+    const size_t bound = max_file_size - jf.garbage.size();
+    auto put = [&](uint8_t b) { if (out.size() < bound) out.push_back(b); };
+    if (lf->has_prefix) for (uint8_t b : lf->prefix_garbage) put(b);
+    if (lf->embedded || !lf->has_prefix) { put(0xFF); put(0xD8); }
+    size_t hp = 0;
+    for (size_t scan = 0; scan < plan.scans.size(); ++scan) {
+        for (size_t i = hp; i < plan.scan_hdr_end[scan]; ++i) put(h[i]);
+        hp = plan.scan_hdr_end[scan];
+        const size_t room = out.size() < bound ? bound - out.size() : 0, n = std::min(room, scan_bytes[scan].second);
+        out.insert(out.end(), scan_bytes[scan].first, scan_bytes[scan].first + n);
+        unsigned cpos = plan.markers[scan];
+        if (scan < jf.rst_err.size())
+            for (unsigned k = 0; k < jf.rst_err[scan]; ++k) { put(0xFF); put((uint8_t)(0xD0 + (cpos & 7))); ++cpos; }
+    }
+    for (size_t i = hp; i < hdrs; ++i) put(h[i]);
+    for (size_t i = 0; i < jf.garbage.size() && out.size() < max_file_size; ++i) out.push_back(jf.garbage[i]);
+    result->swap(out);
+    return 0;
+}
+
 }  // namespace lep

@@ -66,6 +66,17 @@ bool build_huff_table(const uint8_t* clen, size_t clen_avail, const uint8_t* cva
         if (node > 0xff) { if (strict) return false; continue; }
         if (t->clen[sym] > 0) ((t->cval[sym] & 1) ? t->r : t->l)[node] = (uint16_t)(sym + 256);
     }
+    for (unsigned pat = 0; pat < 1024; ++pat) {
+        unsigned node = 0, depth = 0;
+        uint16_t e = 0;
+        while (depth < 10) {
+            node = ((pat >> (9 - depth)) & 1) ? t->r[node] : t->l[node];
+            ++depth;
+            if (node == 0) break;                                            // no such code
+            if (node >= 256) { e = (uint16_t)((depth << 8) | (node - 256)); break; }
+        }
+        t->lut[pat] = e;
+    }
     t->set = true;
     return true;
 }

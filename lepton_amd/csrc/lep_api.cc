@@ -19,7 +19,10 @@ struct lep_file {
     bool frame_ready = false;
     lep::RecodePlan plan;
     bool planned = false;
+    lep::ProgPlan prog;
+    bool prog_planned = false;
 };
+static_assert(sizeof(lep_huffprog_image) == sizeof(lep::ProgImage) && sizeof(lep_huffprog_scan) == sizeof(lep::ProgScan), "C ABI mirrors");
 static_assert(sizeof(lep_huffdec_image) == sizeof(lep::ScanDecodePlan) && sizeof(lep_huffdec_row) == sizeof(lep::ScanDecodeRow), "C ABI mirrors");
 static_assert(sizeof(lep_huff_image) == sizeof(lep::RecodeImage) && sizeof(lep_huff_segment) == sizeof(lep::RecodeSegment), "C ABI mirrors");
 
@@ -309,6 +312,30 @@ int lep_file_recode_plan(lep_file* f, lep_huff_image* image, lep_huff_segment* s
         memcpy(segs, f->plan.segs.data(), sizeof(lep_huff_segment) * f->plan.segs.size());
     }
     return 0;
+}
+
+int lep_file_recode_plan_progressive(lep_file* f, lep_huffprog_image* image, lep_huffprog_scan* scans, int cap, int* nscan, int* gpu_ok) {
+    *gpu_ok = 0; *nscan = 0;
+    int rc = lep::recode_progressive_prepare(&f->lf, &f->prog);
+    if (rc) return rc;
+    f->prog_planned = true;
+    if (!f->prog.gpu_ok || (int)f->prog.scans.size() > cap) { f->prog.gpu_ok = false; return 0; }
+    memcpy(image, &f->prog.image, sizeof *image);
+    for (int c = 0; c < f->lf.jpeg.ncomp; ++c) image->blocks[c] = f->lf.jpeg.plane[c];
+    memcpy(scans, f->prog.scans.data(), sizeof(lep_huffprog_scan) * f->prog.scans.size());
+    *nscan = (int)f->prog.scans.size();
+    *gpu_ok = 1;
+    return 0;
+}
+
+int lep_file_recode_finish_progressive(lep_file* f, const lep_bytes* scan_bytes, int nscan, lep_bytes* out) {
+    if (!f->prog_planned || !f->prog.gpu_ok) return LEP_ASSERTION_FAILURE;
+    std::vector<std::pair<const uint8_t*, size_t>> sb;
+    for (int i = 0; i < nscan; ++i) sb.emplace_back(scan_bytes[i].data, scan_bytes[i].len);
+    std::vector<uint8_t> jpg;
+    int rc = lep::recode_progressive_finish(&f->lf, f->prog, sb, &jpg);
+    if (rc) return rc;
+    return to_bytes(jpg, out);
 }
 
 int lep_file_recode_finish(lep_file* f, const lep_bytes* seg_bytes, int nseg, lep_bytes* out) {

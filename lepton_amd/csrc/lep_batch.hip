@@ -92,12 +92,17 @@ struct Slot {   // one chunk's buffers (double-buffered)
     uint8_t* d_scan = nullptr; uint8_t* h_scan = nullptr; size_t scan_cap = 0;   // JPEG scan bytes of the GPU Huffman encoder
     uint32_t* d_scanlen = nullptr; size_t scanlen_cap = 0;
     char* d_rows = nullptr; size_t rows_cap = 0;   // row records of the GPU Huffman decoder
+    uint8_t* d_pscan = nullptr; size_t pscan_cap = 0;      // progressive files: the scans' device arena (sized for the worst case) ...
+    uint8_t* h_pscan = nullptr; size_t hpscan_cap = 0;     // ... and the pinned mirror, packed by the bytes actually written
+    uint32_t* d_corr = nullptr; size_t corr_cap = 0;       // held-back correction bits of the refinement scans (dwords)
+    uint32_t* d_pscanlen = nullptr; size_t pscanlen_cap = 0;
     hipEvent_t up = nullptr, done = nullptr;
     void release() {
         if (h_frames) (void)hipHostFree(h_frames);
         if (h_streams) (void)hipHostFree(h_streams);
         if (h_scan) (void)hipHostFree(h_scan);
-        for (void* p : {(void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags, (void*)d_scan, (void*)d_scanlen, (void*)d_rows})
+        if (h_pscan) (void)hipHostFree(h_pscan);
+        for (void* p : {(void*)d_pscan, (void*)d_corr, (void*)d_pscanlen, (void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags, (void*)d_scan, (void*)d_scanlen, (void*)d_rows})
             if (p) (void)hipFree(p);
         if (up) (void)hipEventDestroy(up);
         if (done) (void)hipEventDestroy(done);
@@ -199,6 +204,41 @@ int scan_reserve(Slot* s, size_t bytes, size_t nseg) {
     return 0;
 }
 
+int prog_reserve(Slot* s, size_t scan_bytes, size_t corr_words, size_t nscan) {
+    const double t0 = now_s();
+    if (scan_bytes > s->pscan_cap) {
+        if (s->d_pscan) (void)hipFree(s->d_pscan);
+        s->d_pscan = nullptr; s->pscan_cap = 0;
+        HIPOK(hipMalloc((void**)&s->d_pscan, scan_bytes));
+        s->pscan_cap = scan_bytes;
+    }
+    if (corr_words > s->corr_cap) {
+        if (s->d_corr) (void)hipFree(s->d_corr);
+        s->d_corr = nullptr; s->corr_cap = 0;
+        HIPOK(hipMalloc((void**)&s->d_corr, corr_words * 4));
+        s->corr_cap = corr_words;
+    }
+    if (nscan > s->pscanlen_cap) {
+        if (s->d_pscanlen) (void)hipFree(s->d_pscanlen);
+        s->d_pscanlen = nullptr; s->pscanlen_cap = 0;
+        HIPOK(hipMalloc((void**)&s->d_pscanlen, nscan * 4));
+        s->pscanlen_cap = nscan;
+    }
+    g_alloc_s += now_s() - t0;
+    return 0;
+}
+int prog_host_reserve(Slot* s, size_t bytes) {
+    if (bytes <= s->hpscan_cap) return 0;
+    const double t0 = now_s();
+    if (s->h_pscan) (void)hipHostFree(s->h_pscan);
+    s->h_pscan = nullptr; s->hpscan_cap = 0;
+    const size_t want = bytes + bytes / 4;
+    HIPOK(hipHostMalloc((void**)&s->h_pscan, want, hipHostMallocDefault));
+    s->hpscan_cap = want;
+    g_alloc_s += now_s() - t0;
+    return 0;
+}
+
 // pinned host staging for whole frames: only needed for files the host Huffman coder handles
 int host_frames_reserve(Slot* s, size_t frames) {
     if (frames <= s->hframes_cap) return 0;
@@ -227,6 +267,11 @@ struct Chunk {
     std::vector<uint32_t> hslot;           // per hseg: bytes reserved in the scan arena
     std::vector<uint32_t> hbound;          // per hseg: the segment's real byte bound (larger than the slot for segment 0)
     size_t scan_bytes = 0;
+    // decompression of progressive files: one GPU wavefront per (image, scan) (lep_huffprog.h)
+    std::vector<lep_huffprog_image> pimg;
+    std::vector<lep_huffprog_scan> pscan;
+    std::vector<int> pfirst, pcount;       // per live image: first entry of pscan / number of scans, -1 = not on this path
+    size_t pscan_bytes = 0, corr_words = 0;
 };
 
 Slot g_slots[2];         // one batch call at a time (the calls are not re-entrant)
@@ -771,13 +816,38 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                 c->himg.clear(); c->hseg.clear(); c->hfirst.assign(c->live.size(), -1); c->hslot.clear(); c->hbound.clear(); c->scan_bytes = 0;
             }
         }
+        // progressive files: every scan is a function of the finished frame -> one GPU wavefront per (image, scan)
+        c->pimg.clear(); c->pscan.clear(); c->pfirst.assign(c->live.size(), -1); c->pcount.assign(c->live.size(), 0); c->pscan_bytes = 0; c->corr_words = 0;
+        if (gpu_huffman) {
+            std::vector<lep_huffprog_scan> tmp(256);
+            for (size_t k = 0; k < c->live.size(); ++k) {
+                if (c->hfirst[k] >= 0) continue;
+                lep_huffprog_image pi;
+                int ns = 0, ok = 0;
+                if (lep_file_recode_plan_progressive(files[c->live[k]], &pi, tmp.data(), (int)tmp.size(), &ns, &ok) || !ok) continue;
+                for (int cc = 0; cc < 4; ++cc) pi.blocks[cc] = cc < c->dev_desc[k].ncomp ? c->dev_desc[k].blocks[cc] : nullptr;
+                c->pfirst[k] = (int)c->pscan.size(); c->pcount[k] = ns;
+                for (int q = 0; q < ns; ++q) {
+                    tmp[q].image = (int32_t)c->pimg.size();
+                    tmp[q].out_off = c->pscan_bytes;
+                    c->pscan_bytes += ((size_t)tmp[q].out_cap + 15) & ~(size_t)15;
+                    tmp[q].corr_off = (uint32_t)c->corr_words;
+                    c->corr_words += tmp[q].corr_cap;
+                    c->pscan.push_back(tmp[q]);
+                }
+                c->pimg.push_back(pi);
+            }
+            if (!c->pscan.empty() && (c->corr_words > 0xfffffff0u || prog_reserve(s, c->pscan_bytes + 256, c->corr_words + 16, c->pscan.size()))) {
+                c->pimg.clear(); c->pscan.clear(); c->pfirst.assign(c->live.size(), -1); c->pcount.assign(c->live.size(), 0);   // no room: host re-coder
+            }
+        }
         // files the host re-coder handles read their frame where the D2H copy puts it: the slot's pinned buffer
         bool any_host = false;
-        for (size_t k = 0; k < c->live.size(); ++k) any_host |= c->hfirst[k] < 0;
+        for (size_t k = 0; k < c->live.size(); ++k) any_host |= c->hfirst[k] < 0 && c->pfirst[k] < 0;
         if (any_host) {
             if (int rc = host_frames_reserve(s, c->frame_bytes)) return rc;
             for (size_t k = 0; k < c->live.size(); ++k)
-                if (c->hfirst[k] < 0) lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
+                if (c->hfirst[k] < 0 && c->pfirst[k] < 0) lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
         }
         HIPOK(hipMemcpyAsync(s->d_streams, s->h_streams, c->offs.back(), hipMemcpyHostToDevice, s_copy));
         HIPOK(hipMemcpyAsync(s->d_len, lens->data(), lens->size() * 4, hipMemcpyHostToDevice, s_copy));
@@ -797,6 +867,11 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         if (rc) return rc;
         if (!c->hseg.empty()) {
             rc = lep_gpu_huffman_encode_device(g, c->himg.data(), (int)c->himg.size(), c->hseg.data(), (int)c->hseg.size(), s->d_scan, s->d_scanlen, s_compute);
+            if (rc) return rc;
+        }
+        if (!c->pscan.empty()) {
+            rc = lep_gpu_huffman_progressive_encode_device(g, c->pimg.data(), (int)c->pimg.size(), c->pscan.data(), (int)c->pscan.size(), s->d_pscan, s->d_corr,
+                                                           s->d_pscanlen, s_compute);
             if (rc) return rc;
         }
         HIPOK(hipEventRecord(s->done, s_compute));
@@ -821,13 +896,38 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
             if (nxt->count > 0) { if (int rc = launch_chunk(nxt.get(), &slots[slot_i ^ 1])) { rc_all = rc; break; } }
         }
         std::vector<int32_t> sts(nseg);
-        std::vector<uint32_t> slens(c->hseg.size());
+        std::vector<uint32_t> slens(c->hseg.size()), plens(c->pscan.size());
+        std::vector<size_t> poff(c->pscan.size(), 0);   // packed offsets of the progressive scans in the pinned mirror
         if (nimg) {
             HIPOK(hipStreamWaitEvent(s_down, s->done, 0));
             HIPOK(hipMemcpyAsync(sts.data(), s->d_status, (size_t)nseg * 4, hipMemcpyDeviceToHost, s_down));
             if (!c->hseg.empty()) HIPOK(hipMemcpyAsync(slens.data(), s->d_scanlen, c->hseg.size() * 4, hipMemcpyDeviceToHost, s_down));
+            if (!c->pscan.empty()) HIPOK(hipMemcpyAsync(plens.data(), s->d_pscanlen, c->pscan.size() * 4, hipMemcpyDeviceToHost, s_down));
             HIPOK(hipStreamSynchronize(s_down));
+            if (!c->pscan.empty()) {
+                size_t total = 0;
+                for (int k = 0; k < nimg; ++k) {
+                    if (c->pfirst[k] < 0) continue;
+                    bool fits = true;
+                    for (int q = c->pfirst[k]; q < c->pfirst[k] + c->pcount[k]; ++q) fits = fits && !(plens[q] & 0x80000000u);
+                    if (!fits) {   // a scan outgrew its slot or its scratch: that file takes the host re-coder
+                        c->pfirst[k] = -1;
+                        if (int rc = host_frames_reserve(s, c->frame_bytes)) { rc_all = rc; break; }
+                        lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
+                        continue;
+                    }
+                    for (int q = c->pfirst[k]; q < c->pfirst[k] + c->pcount[k]; ++q) { poff[q] = total; total += ((size_t)plens[q] + 15) & ~(size_t)15; }
+                }
+                if (!rc_all) { if (int rc = prog_host_reserve(s, total + 256)) rc_all = rc; }
+                if (rc_all) break;
+                for (int k = 0; k < nimg; ++k) {
+                    if (c->pfirst[k] < 0) continue;
+                    for (int q = c->pfirst[k]; q < c->pfirst[k] + c->pcount[k]; ++q)
+                        if (plens[q]) { HIPOK(hipMemcpyAsync(s->h_pscan + poff[q], s->d_pscan + c->pscan[q].out_off, plens[q], hipMemcpyDeviceToHost, s_down)); st.d2h_bytes += plens[q]; }
+                }
+            }
             for (int k = 0; k < nimg; ++k) {
+                if (c->pfirst[k] >= 0) continue;
                 bool on_gpu = c->hfirst[k] >= 0;
                 if (on_gpu) {   // a segment that filled its reserved slot may have been cut short: let the host redo that file
                     const int h0 = c->hfirst[k], h1 = h0 + (c->seg_first[k + 1] - c->seg_first[k]);
@@ -850,7 +950,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
             if (rc_all) break;
         }
         std::shared_ptr<Chunk> keep(cur.release());
-        writer = std::thread([&, keep, s, sts, slens]() {
+        writer = std::thread([&, keep, s, sts, slens, plens, poff]() {
             const double t0 = now_s();
             parallel_for((int)keep->live.size(), threads, [&](int k) {
                 const int i = keep->live[k];
@@ -861,6 +961,11 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                     lep_bytes sb[LEP_MAX_SEGMENTS];
                     for (int q = 0; q < ns; ++q) { sb[q].data = s->h_scan + keep->hseg[h0 + q].out_off; sb[q].len = sb[q].cap = slens[h0 + q]; }
                     rc = lep_file_recode_finish(files[i], sb, ns, &outs[i]);
+                } else if (!rc && keep->pfirst[k] >= 0) {   // progressive file, scans coded on the GPU: glue header pieces and scans
+                    const int p0 = keep->pfirst[k], ns = keep->pcount[k];
+                    std::vector<lep_bytes> sb((size_t)ns);
+                    for (int q = 0; q < ns; ++q) { sb[q].data = s->h_pscan + poff[p0 + q]; sb[q].len = sb[q].cap = plens[p0 + q]; }
+                    rc = lep_file_recode_finish_progressive(files[i], sb.data(), ns, &outs[i]);
                 } else if (!rc) rc = lep_file_recode(files[i], &outs[i]);   // host re-coder reads the frame in place (pinned D2H buffer)
                 status[i] = rc;
                 lep_file_close(files[i]);

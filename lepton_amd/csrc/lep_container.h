@@ -72,6 +72,40 @@ struct RecodePlan {
     std::vector<RecodeSegment> segs;
 };
 int recode_prepare(LepFile* lf, RecodePlan* plan);
+
+// Progressive files with the Huffman coding of the scans done elsewhere (the GPU, lep_huffprog.h): _prepare walks the header
+// (one entry per SOS: band, successive approximation, tables) and decides eligibility; _finish glues header pieces, the scans'
+// bytes (already stuffed, restart markers in place), misplaced restart markers and garbage together.  ProgImage / ProgScan are
+// laid out exactly like lephuff::ProgImage / ProgScan and the C ABI's lep_huffprog_image / lep_huffprog_scan.
+struct ProgImage {
+    int32_t ncomp, mcuh, mcuv, mcuc;
+    int32_t rsti, padbit;
+    int32_t hs[4], vs[4], bch[4], bcv[4], nch[4], ncv[4], mbs[4];
+    const int16_t* blocks[4];
+};
+struct ProgScan {
+    int32_t image;
+    int32_t cmpc, cmp[4];
+    int32_t from, to, sah, sal;
+    int32_t max_eobrun;
+    int32_t tbl[4];
+    uint64_t out_off;
+    uint32_t out_cap;
+    uint32_t corr_off;
+    uint32_t corr_cap;
+    uint32_t pad;
+    uint32_t code[2][256];
+};
+struct ProgPlan {
+    bool gpu_ok = false;
+    ProgImage image;
+    std::vector<ProgScan> scans;          // out_cap / corr_cap = what the scan may need; offsets are the caller's
+    std::vector<size_t> scan_hdr_end;     // header position behind each SOS
+    std::vector<uint32_t> markers;        // restart markers each scan writes itself
+};
+int recode_progressive_prepare(LepFile* lf, ProgPlan* plan);
+int recode_progressive_finish(LepFile* lf, const ProgPlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& scan_bytes,
+                              std::vector<uint8_t>* out);
 int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& seg_bytes,
                   std::vector<uint8_t>* out);
 

@@ -21,6 +21,7 @@
 #include "lep_huff.h"
 #include "lep_huffdec.h"
 #include "lep_huffdec_par.h"
+#include "lep_huffprog.h"
 
 using namespace lepdev;
 
@@ -156,6 +157,17 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_encode_kernel(const lephuff
     if (threadIdx.x == 0) out_len[s] = n;
 }
 
+// progressive files: one wavefront per (image, scan) (lep_huffprog.h)
+__global__ __launch_bounds__(64, 8) void lep_huffman_progressive_encode_kernel(const lephuff::ProgImage* __restrict__ images,
+                                                                               const lephuff::ProgScan* __restrict__ scans, uint8_t* out,
+                                                                               uint32_t* corr, uint32_t* out_len) {
+    __shared__ lephuff::ProgShared sh;
+    const lephuff::ProgScan* sc = scans + blockIdx.x;
+    lephuff::ProgWave w;
+    const uint32_t n = w.run_scan(images + sc->image, sc, &sh, out, corr);
+    if (threadIdx.x == 0) out_len[blockIdx.x] = n;
+}
+
 // JPEG Huffman scan decode: one wavefront per image (lep_huffdec.h)
 // <= 64 VGPRs and 4.5 KB of LDS: one of these waves fits on a SIMD beside seven coder waves, and it runs at raised priority
 // there (it is one long dependency chain per image; the coder waves around it are the throughput work)
@@ -228,6 +240,7 @@ struct lep_gpu {
     void* d_streams = nullptr; size_t streams_bytes = 0;
     void* d_lens = nullptr; size_t lens_bytes = 0;
     void* d_huff = nullptr; size_t huff_bytes = 0;      // HuffImage[] | HuffSegment[]
+    void* d_huffprog = nullptr; size_t huffprog_bytes = 0;   // ProgImage[] | ProgScan[]
     void* d_huffdec = nullptr; size_t huffdec_bytes = 0;   // HuffDecImage[]
     void* d_huffpar = nullptr; size_t huffpar_bytes = 0;   // HuffParState[nimg][nsub] | int status[nimg] (parallel Huffman decode)
     void* d_scan = nullptr; size_t scan_bytes = 0;      // scan bytes of the Huffman encoder (host variant)
@@ -399,7 +412,7 @@ static void release_device_side(lep_gpu* g) {
     g->released = true;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
+    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffprog, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
         if (p) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -452,6 +465,29 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
     g->last_kernel = "lep_huffman_encode_kernel";
+    return 0;
+}
+
+static_assert(sizeof(lep_huffprog_image) == sizeof(lephuff::ProgImage) && sizeof(lep_huffprog_scan) == sizeof(lephuff::ProgScan), "C ABI mirrors");
+
+int lep_gpu_huffman_progressive_encode_device(lep_gpu* g, const lep_huffprog_image* images, int nimg, const lep_huffprog_scan* scans, int nscan,
+                                              uint8_t* d_out, uint32_t* d_corr, uint32_t* d_out_len, void* hip_stream) {
+    if (!g) return LEP_GPU_ERROR;
+    if (nscan <= 0) return 0;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
+    HIPCHK(g, hipSetDevice(g->device));
+    const size_t o_scan = (nimg * sizeof(lep_huffprog_image) + 255) & ~(size_t)255, total = o_scan + nscan * sizeof(lep_huffprog_scan);
+    if (int rc = ensure(g, &g->d_huffprog, &g->huffprog_bytes, total)) return rc;
+    HIPCHK(g, hipMemcpyAsync(g->d_huffprog, images, nimg * sizeof(lep_huffprog_image), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipMemcpyAsync((char*)g->d_huffprog + o_scan, scans, nscan * sizeof(lep_huffprog_scan), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipStreamSynchronize(st));   // the caller's arrays may go away
+    HIPCHK(g, hipEventRecord(g->ev0, st));
+    hipLaunchKernelGGL(lep_huffman_progressive_encode_kernel, dim3(nscan), dim3(64), 0, st, (const lephuff::ProgImage*)g->d_huffprog,
+                       (const lephuff::ProgScan*)((char*)g->d_huffprog + o_scan), d_out, d_corr, d_out_len);
+    HIPCHK(g, hipGetLastError());
+    HIPCHK(g, hipEventRecord(g->ev1, st));
+    g->timed = true;
+    g->last_kernel = "lep_huffman_progressive_encode_kernel";
     return 0;
 }
 

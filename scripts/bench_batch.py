@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--chunk-images", type=int, default=0)
     ap.add_argument("--verify", action="store_true")
     ap.add_argument("--skew", type=float, default=0.0, help="photograph-like corpus: detail grows from top to bottom (exponent of the ramp), unequal thread segments")
+    ap.add_argument("--progressive", action="store_true", help="progressive corpus (BASELINE.json configs[4])")
     ap.add_argument("--host-huffman", action="store_true", help="decompress: JPEG Huffman re-encode on the host pool instead of the GPU")
     args = ap.parse_args()
     import __graft_entry__ as ge
@@ -33,7 +34,7 @@ def main():
 
     codec = GpuCodec(0)
     nu = max(1, min(args.unique, args.images))
-    uniq = corpus.make_corpus(nu, args.width, args.height, 10000, skew=args.skew)
+    uniq = corpus.make_corpus(nu, args.width, args.height, 10000, skew=args.skew, progressive=args.progressive)
     jpgs = [uniq[i % nu] for i in range(args.images)]
     mb = sum(map(len, jpgs)) / 1e6
     kw = dict(threads=args.threads, chunk_bytes=args.chunk_mb << 20, chunk_images=args.chunk_images, host_huffman=args.host_huffman)

@@ -194,6 +194,17 @@ extern "C" int emu_huffman_encode_segment(const lep_huff_image* img, const lep_h
     return 0;
 }
 
+// progressive scans (lep_huffprog.h): every scan of one image, one emulated wavefront after the other
+#include "../../lepton_amd/csrc/lep_huffprog.h"
+extern "C" int emu_huffman_progressive_encode(const lep_huffprog_image* img, const lep_huffprog_scan* scans, int nscan, uint8_t* out, uint32_t* corr, uint32_t* out_len) {
+    static lephuff::ProgShared sh;
+    for (int i = 0; i < nscan; ++i) {
+        lephuff::ProgWave w;
+        out_len[i] = w.run_scan(reinterpret_cast<const lephuff::ProgImage*>(img), reinterpret_cast<const lephuff::ProgScan*>(scans + i), &sh, out, corr);
+    }
+    return 0;
+}
+
 // GPU Huffman scan decoder (lep_huffdec.h) as a 64-lane loop emulation: one image
 #include "../../lepton_amd/csrc/lep_huffdec.h"
 extern "C" int emu_huffman_decode_image(const lep_huffdec_image* img, lep_huffdec_row* rows) {

@@ -382,3 +382,24 @@ def test_gpu_encoder_builds_agree(waves, monkeypatch):
         assert codec.decompress(codec.compress(jpg)) == jpg
     finally:
         codec.close()
+
+
+def test_gpu_progressive_scans_are_recoded_on_the_gpu(gpu_codec):
+    """decode direction of progressive files (BASELINE.json configs[4]): arithmetic decode + lep_huffprog.h (one wavefront per
+    scan: DC / AC first-stage and refinement scans, end-of-band runs, held-back correction bits); the restored files equal the
+    reference's inputs, and only scan bytes cross PCIe (the frame of an eligible file stays on the device)"""
+    names = [n for n in golden_cases() if n.startswith("prog_")]
+    leps = [golden(n)[1] for n in names]
+    jpgs = [golden(n)[0] for n in names]
+    big = [corpus.synth_jpeg(1920, 1080, 91, progressive=True), corpus.synth_jpeg(640, 480, 92, progressive=True, subsampling="4:4:4", quality=97),
+           corpus.synth_jpeg(800, 600, 93, progressive=True, quality=35)]
+    big_lep = [gpu_codec.compress(j) for j in big]
+    back, st, stats = gpu_codec.decompress_batch(leps + big_lep + [golden("c420_160x120")[1]])
+    assert st == [0] * (len(names) + 4)
+    assert back[: len(names)] == jpgs and back[len(names): len(names) + 3] == big and back[-1] == golden("c420_160x120")[0]
+    # the three big files alone: frames 1080p = 6.2 MB + ... would cross PCIe on the host path; on the GPU path only their scans do
+    _, st2, stats2 = gpu_codec.decompress_batch(big_lep)
+    assert st2 == [0, 0, 0] and stats2["d2h_bytes"] < 1.2 * sum(map(len, big)) + 65536
+    # and the host path still agrees
+    back3, st3, _ = gpu_codec.decompress_batch(big_lep, host_huffman=True)
+    assert st3 == [0, 0, 0] and back3 == big
