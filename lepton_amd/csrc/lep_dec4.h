@@ -197,6 +197,13 @@ struct Dec4Wave {
     int comp, ci;
     BoolDec4 bc;
     uint32_t nbins;   // bins decoded, accounted per coefficient: a coefficient of bit length len costs 2*len+1 bins (22 at len 11)
+    // the count is a test aid (the emulation compares it with the oracle's); on the GPU nobody reads it, and kept in the serial
+    // loops it costs ~150 scalar instructions per block on a kernel that is bound by instruction issue
+#if LEP_ON_GPU && !defined(LEP_COUNT_BINS)
+#define LEP_BINS(expr) ((void)0)
+#else
+#define LEP_BINS(expr) (expr)
+#endif
 #if LEP_ON_GPU && defined(LEP_PROF)
     uint64_t prof_last;
     unsigned long long* prof_out;   // 32 accumulators of this wave in global memory, written once at the end
@@ -313,7 +320,7 @@ struct Dec4Wave {
             const uint32_t pk = lepwave::wave_read(PK, base + g + (n >> 2));
             n = (n << 1) | (int)uni(bc.get((pk >> ((n & 3) * 8)) & 255));
         }
-        nbins += (uint32_t)levels;
+        LEP_BINS(nbins += (uint32_t)levels);
         return n;
     }
 
@@ -463,7 +470,7 @@ struct Dec4Wave {
         for (;;) {   // runs while zz < zz_end && left > 0 && cand < 4 (true on entry: the caller checks zz < 49 && left > 0)
             const int lane = (zz - zz0) + 16 * cand;
             int len = dec_unary4(lepwave::wave_read(PK0, lane));
-            ++nbins;
+            LEP_BINS(++nbins);
             if (len) {
                 if (len == 4) {
                     // exponent words 4..7 (|v| >= 8: 5 % of the interior non-zeros) are not prefetched -- that third of the round's
@@ -471,7 +478,7 @@ struct Dec4Wave {
                     len += dec_unary4(pack_probs(vload4(model + ctx4_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])) + kGS)));
                     if (len == 8) len = dec_unary_tail(ctx4_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])));
                 }
-                nbins += (uint32_t)(2 * len - (len == 11));
+                LEP_BINS(nbins += (uint32_t)(2 * len - (len == 11)));
                 const uint32_t pos = bc.get(sgw >> 16);
                 sgw = bupd_u(sgw, pos, S.inv24);
                 --left;
@@ -582,14 +589,14 @@ struct Dec4Wave {
                 if (info >> 31) { rc = 43; break; }
                 const int lane = base + left - 1;
                 int len = dec_unary4(lepwave::wave_read(PK0, lane));
-                ++nbins;
+                LEP_BINS(++nbins);
                 if (len) {
                     const int coord = horizontal ? j + 1 : (j + 1) * 8;
                     if (len == 4) {
                         len += dec_unary4(pack_probs(vload4(model + ctx4_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)) + kGS)));
                         if (len == 8) len = dec_unary_tail(ctx4_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)));
                     }
-                    nbins += (uint32_t)(2 * len - (len == 11));
+                    LEP_BINS(nbins += (uint32_t)(2 * len - (len == 11)));
                     const int sslot = (int)(info & 255);
                     const uint32_t sgw = vec(S.sign[sslot]);
                     const uint32_t pos = bc.get(sgw >> 16);
@@ -686,7 +693,7 @@ struct Dec4Wave {
                 for (; len < 11; ++len) { if (!ucond(bc.get(pk & 255) != 0)) break; pk >>= 8; }
             }
         }
-        nbins += (uint32_t)(len ? 2 * len + 1 - (len == 11) : 1);
+        LEP_BINS(nbins += (uint32_t)(len ? 2 * len + 1 - (len == 11) : 1));
         uint32_t v = 0, pos = 1;
         if (len) {
             const uint32_t sgw = vec(S.sign[sslot]);
