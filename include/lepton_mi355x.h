@@ -174,6 +174,26 @@ typedef struct lep_huffdec_row {
     int32_t aux;
 } lep_huffdec_row;
 int lep_gpu_huffman_decode_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, lep_huffdec_row *d_rows, void *hip_stream);
+/* The same for PROGRESSIVE files (replaces the progressive branches of decode_jpeg's scan loop, src/lepton/jpgcoder.cc:2975-3260,
+ * with decode_dc_prg_*, decode_ac_prg_fs / _sa, decode_eobrun_sa, skip_eobrun :4968-5335, :5462-5500): one wavefront per
+ * (image, scan).  A refinement scan must see what the earlier scans of its band wrote, so every descriptor carries a
+ * dependency `level`; the call launches level after level on the stream.  Each scan writes its coefficients into the
+ * zero-filled frame t.blocks, the first scan of a file also one record per MCU row at d_rows + t.rows_off, and every scan a
+ * final record {bits consumed, last DC, pad bits | status << 8} at d_rows + result_off; a non-zero status anywhere sends the
+ * whole file to the host parser.  lep_jpeg_open_gpu_progressive fills the descriptors. */
+typedef struct lep_huffprogdec_scan {
+    lep_huffdec_image t;                 /* scan = this scan's bytes; lut[0..1] DC tables 0 / 1, lut[2] the scan's AC table */
+    int32_t cmpc, cmp[4];
+    int32_t from, to, sah, sal;
+    int32_t bcv[4], nch[4], ncv[4], mbs[4];
+    int32_t tbl[4];
+    int32_t max_eobrun;
+    int32_t want_rows;
+    int32_t level;
+    int32_t pad;
+    uint64_t result_off;
+} lep_huffprogdec_scan;
+int lep_gpu_huffman_progressive_decode_device(lep_gpu *g, const lep_huffprogdec_scan *scans, int nscan, lep_huffdec_row *d_rows, void *hip_stream);
 /* The same result with nsub (2..64) wavefronts per image -- speculative synchronisation pass, stitching walk that proves each
  * region, write pass (lep_huffdec_par.h; bit-exact against the single-wave kernel on MI355X and in the lane-loop emulation).
  * Used by lep_compress_batch for a call's first chunk, whose scan decode nothing hides: 1024 4K images 0.89 s -> ~0.3 s.
@@ -215,6 +235,12 @@ int lep_jpeg_open_slice(const uint8_t *jpg, size_t len, size_t start_byte, lep_j
  * into a larger blob; the .lep ('PGE' section + ordinary garbage) restores the whole blob */
 int lep_jpeg_open_embedded(const uint8_t *blob, size_t len, size_t offset, lep_jpeg **out);
 int lep_compress_embedded(lep_gpu *g, const uint8_t *blob, size_t len, size_t offset, lep_bytes *out);
+/* progressive files: after lep_jpeg_open_gpu answered *eligible = 0.  Fills up to `cap` scan descriptors (t.scan = byte offset of
+ * the scan inside lep_jpeg_scan_bytes, t.rows_off / result_off relative to the file's first record -- the caller adds its arena
+ * offsets and sets t.blocks); *rows_needed = records the file needs in the row arena.  _finish turns the kernels' records into
+ * the hand-offs and bookkeeping of the .lep header (non-zero: irregular, use the host parser). */
+int lep_jpeg_open_gpu_progressive(lep_jpeg *j, lep_huffprogdec_scan *scans, int cap, int *nscan, int *rows_needed, int *eligible);
+int lep_jpeg_finish_gpu_progressive(lep_jpeg *j, const lep_huffprogdec_scan *scans, int nscan, const lep_huffdec_row *rows);
 int lep_jpeg_scan_bytes(const lep_jpeg *j, const uint8_t **data, size_t *len);
 int lep_jpeg_finish_gpu(lep_jpeg *j, const lep_huffdec_row *rows);
 void lep_jpeg_close(lep_jpeg *j);

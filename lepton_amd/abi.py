@@ -81,6 +81,13 @@ class HuffDecImage(C.Structure):
                 ("lut", (C.c_uint16 * 512) * 4), ("maxcode", (C.c_int32 * 8) * 4), ("valoff", (C.c_int32 * 8) * 4), ("longsym", (C.c_uint8 * 256) * 4)]
 
 
+class HuffProgDecScan(C.Structure):
+    _fields_ = [("t", HuffDecImage), ("cmpc", C.c_int32), ("cmp", C.c_int32 * 4), ("from_", C.c_int32), ("to", C.c_int32), ("sah", C.c_int32),
+                ("sal", C.c_int32), ("bcv", C.c_int32 * 4), ("nch", C.c_int32 * 4), ("ncv", C.c_int32 * 4), ("mbs", C.c_int32 * 4),
+                ("tbl", C.c_int32 * 4), ("max_eobrun", C.c_int32), ("want_rows", C.c_int32), ("level", C.c_int32), ("pad", C.c_int32),
+                ("result_off", C.c_uint64)]
+
+
 class HuffDecRow(C.Structure):
     _fields_ = [("bitpos", C.c_uint32), ("last_dc", C.c_int16 * 4), ("aux", C.c_int32)]
 
@@ -194,6 +201,9 @@ def lib():
         L.lep_file_recode_plan_progressive.argtypes = [vp, P(HuffProgImage), P(HuffProgScan), C.c_int, P(C.c_int), P(C.c_int)]
         L.lep_file_recode_finish_progressive.argtypes = [vp, P(Bytes), C.c_int, P(Bytes)]
         L.lep_gpu_huffman_progressive_encode_device.argtypes = [vp, P(HuffProgImage), C.c_int, P(HuffProgScan), C.c_int, vp, vp, vp, vp]
+        L.lep_jpeg_open_gpu_progressive.argtypes = [vp, P(HuffProgDecScan), C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)]
+        L.lep_jpeg_finish_gpu_progressive.argtypes = [vp, P(HuffProgDecScan), C.c_int, P(HuffDecRow)]
+        L.lep_gpu_huffman_progressive_decode_device.argtypes = [vp, P(HuffProgDecScan), C.c_int, vp, vp]
         L.lep_file_consumed.argtypes = [vp]
         L.lep_file_consumed.restype = C.c_size_t
         L.lep_chained_file_follows.argtypes = [vp, C.c_size_t, C.c_size_t]
@@ -220,4 +230,5 @@ EXPORTS = [
     "lep_serve_start", "lep_serve_get_stats", "lep_serve_stop", "lep_zlib0_wrap", "lep_jpeg_open_slice", "lep_compress_slice", "lep_jpeg_open_embedded", "lep_compress_embedded", "lep_gpu_use_arena", "lep_batch_plan", "lep_jpeg_set_encode_options", "lep_gpu_huffman_decode_parallel_device",
     "lep_jpeg_check_restores", "lep_batch_debug_poison", "lep_jpeg_plan_handoffs", "lep_file_consumed", "lep_chained_file_follows", "lep_file_open_next",
     "lep_file_recode_plan_progressive", "lep_file_recode_finish_progressive", "lep_gpu_huffman_progressive_encode_device",
+    "lep_jpeg_open_gpu_progressive", "lep_jpeg_finish_gpu_progressive", "lep_gpu_huffman_progressive_decode_device",
 ]

@@ -89,7 +89,11 @@ inline int next_huffcode(BitReader& br, const HuffTable& t) {
         br.top_up();
         if (br.avail >= 10) {
             const unsigned e = t.lut[br.peek(10)];
-            if (e) { br.skip((int)(e >> 8)); return (int)(e & 255); }
+            if (e) {
+                br.skip((int)(e >> 8));
+                if (br.avail == 0 && br.next_byte == br.size) br.eof = true;   // the bit-by-bit walk sets eof with the read that takes the last bit of the data
+                return (int)(e & 255);
+            }
         }
     }
     int node = 0;

@@ -66,6 +66,7 @@ struct JpegFile {
     std::vector<uint8_t> scan;      // entropy-coded bytes, FF00 un-stuffed, RSTn removed (huffdata)
     std::vector<uint8_t> garbage;   // bytes from EOI on, empty if exactly FF D9 (grbgdata)
     std::vector<std::pair<uint32_t, uint32_t>> scan_to_file;   // huff_input_offsets
+    std::vector<uint32_t> scan_start;   // offset in `scan` where the entropy-coded bytes behind each SOS begin
     std::vector<uint32_t> rst_cnt;  // RST markers seen per scan
     std::vector<uint8_t> rst_err;   // wrongly placed RST markers at scan end, per scan
     bool early_eof = false;
@@ -141,6 +142,25 @@ struct ScanDecodeRow {
 };
 int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanDecodePlan* plan, bool* eligible);
 int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows);
+
+// Progressive files on the GPU scan decoder (lep_huffprogdec.h).  ProgScanDecodePlan is laid out exactly like
+// lephuff::ProgDecScan and the C ABI's lep_huffprogdec_scan.
+struct ProgScanDecodePlan {
+    ScanDecodePlan t;
+    int32_t cmpc, cmp[4];
+    int32_t from, to, sah, sal;
+    int32_t bcv[4], nch[4], ncv[4], mbs[4];
+    int32_t tbl[4];
+    int32_t max_eobrun;
+    int32_t want_rows;
+    int32_t level;
+    int32_t pad;
+    uint64_t result_off;
+};
+// after parse_jpeg_prepare_gpu said "not eligible" for a progressive file: one plan per scan (t.scan = offset into jf->scan as a
+// pointer-sized integer, t.scan_len, t.rows_off / result_off relative to the file's first record; rows_needed records in all)
+int parse_jpeg_prepare_gpu_progressive(JpegFile* jf, std::vector<ProgScanDecodePlan>* scans, int* rows_needed, bool* eligible);
+int parse_jpeg_finish_gpu_progressive(JpegFile* jf, const std::vector<ProgScanDecodePlan>& scans, const ScanDecodeRow* rows);
 
 bool build_huff_table(const uint8_t* clen, size_t clen_avail, const uint8_t* cval, size_t cval_avail,
                       HuffTable* t, bool strict);

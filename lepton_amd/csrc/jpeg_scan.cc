@@ -256,6 +256,7 @@ static int split_file(const uint8_t* d, size_t n, JpegFile* jf) {
     for (;;) {
         if (type == 0xDA) {
             unsigned cpos = 0, crst = 0;
+            jf->scan_start.push_back((uint32_t)jf->scan.size());
             for (;;) {
                 jf->scan_to_file.emplace_back((uint32_t)jf->scan.size(), (uint32_t)pos);
                 if (!rd1(&tmp)) { jf->early_eof = true; have_hdr = true; break; }
@@ -531,6 +532,39 @@ Handoff make_handoff_public(BitReader& br, const JpegFile& jf, int mcu_y, const 
     return make_handoff(br, jf, mcu_y, lastdc, luma_mul);
 }
 
+// the GPU decoders' view of one Huffman table: 9-bit first-level LUT + the one-step canonical test for codes of 9..16 bits.
+// That test equals the code tree only if the table IS canonical (Annex C: codes of one length consecutive, the next length
+// continues at (last + 1) << 1, no overflow); false = a DHT that breaks this: the file stays with the host parser.
+static bool fill_decode_tables(const HuffTable& t, uint16_t* lut, int32_t* maxcode, int32_t* valoff, uint8_t* longsym) {
+    for (int sym = 0; sym < 256; ++sym) {
+        const int len = t.clen[sym];
+        if (len < 1 || len > 9) continue;
+        const unsigned first = (unsigned)t.cval[sym] << (9 - len);
+        for (unsigned x = 0; x < (1u << (9 - len)); ++x) lut[first + x] = (uint16_t)((len << 8) | sym);
+    }
+    int order[256], no = 0;
+    for (int len = 1; len <= 16; ++len)
+        for (int sym = 0; sym < 256; ++sym)
+            if (t.clen[sym] == len) order[no++] = sym;
+    std::stable_sort(order, order + no, [&](int a, int b) { return t.clen[a] != t.clen[b] ? t.clen[a] < t.clen[b] : t.cval[a] < t.cval[b]; });
+    unsigned next = 0;
+    int prev_len = no ? t.clen[order[0]] : 0, nlong = 0;
+    for (int k = 0; k < 8; ++k) { maxcode[k] = -1; valoff[k] = 0; }
+    for (int q = 0; q < no; ++q) {
+        const int sym = order[q], len = t.clen[sym];
+        next <<= (len - prev_len);
+        prev_len = len;
+        if (t.cval[sym] != next || next >= (1u << len)) return false;
+        if (len >= 9) {
+            if (maxcode[len - 9] < 0) valoff[len - 9] = nlong - (int)next;
+            maxcode[len - 9] = (int32_t)next;
+            longsym[nlong++] = (uint8_t)sym;
+        }
+        ++next;
+    }
+    return true;
+}
+
 // ---- GPU Huffman decode (lep_huffdec.h): the host does everything except decoding the scan ---------------------------------------
 // parse_jpeg_prepare_gpu: split the file, set up the frame, read the tables of the first scan; *eligible when the scan is a
 // single MCU-interleaved sequential scan of all (2..3) components with at most two tables per class and the file is whole.
@@ -573,38 +607,7 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
         for (int id = 0; id < 2; ++id) {
             const HuffTable& t = jf->htab[cls][id];
             if (!t.set) continue;
-            uint16_t* lut = plan->lut[cls * 2 + id];
-            for (int sym = 0; sym < 256; ++sym) {
-                const int len = t.clen[sym];
-                if (len < 1 || len > 9) continue;
-                const unsigned first = (unsigned)t.cval[sym] << (9 - len);
-                for (unsigned x = 0; x < (1u << (9 - len)); ++x) lut[first + x] = (uint16_t)((len << 8) | sym);
-            }
-            // codes of 9..16 bits, for the kernel's one-step canonical test.  That test equals the code tree only if the
-            // table IS canonical (Annex C: codes of one length consecutive, the next length continues at (last + 1) << 1, no
-            // overflow); a DHT that breaks this stays with the host parser.
-            int order[256], no = 0;
-            for (int len = 1; len <= 16; ++len)
-                for (int sym = 0; sym < 256; ++sym)
-                    if (t.clen[sym] == len) order[no++] = sym;
-            std::stable_sort(order, order + no, [&](int a, int b) { return t.clen[a] != t.clen[b] ? t.clen[a] < t.clen[b] : t.cval[a] < t.cval[b]; });
-            unsigned next = 0;
-            int prev_len = no ? t.clen[order[0]] : 0, nlong = 0;
-            int32_t* maxcode = plan->maxcode[cls * 2 + id];
-            int32_t* valoff = plan->valoff[cls * 2 + id];
-            for (int k = 0; k < 8; ++k) { maxcode[k] = -1; valoff[k] = 0; }
-            for (int q = 0; q < no; ++q) {
-                const int sym = order[q], len = t.clen[sym];
-                next <<= (len - prev_len);
-                prev_len = len;
-                if (t.cval[sym] != next || next >= (1u << len)) return 0;   // not canonical: *eligible stays false
-                if (len >= 9) {
-                    if (maxcode[len - 9] < 0) valoff[len - 9] = nlong - (int)next;
-                    maxcode[len - 9] = (int32_t)next;
-                    plan->longsym[cls * 2 + id][nlong++] = (uint8_t)sym;
-                }
-                ++next;
-            }
+            if (!fill_decode_tables(t, plan->lut[cls * 2 + id], plan->maxcode[cls * 2 + id], plan->valoff[cls * 2 + id], plan->longsym[cls * 2 + id])) return 0;
         }
     *eligible = true;
     return 0;
@@ -651,6 +654,151 @@ int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows) {
     for (int i = 0; i < jf->cs_cmpc; ++i) jf->max_cmp = std::max(jf->max_cmp, jf->cs_cmp[i]);
     for (int c = 0; c < jf->ncomp; ++c) jf->max_dpos[c] = jf->comp[c].bc - 1;
     jf->progressive_needed = false;
+    return 0;
+}
+
+// ---- progressive files on the GPU scan decoder (lep_huffprogdec.h) ------------------------------------------------------------------
+// Called after parse_jpeg_prepare_gpu (which split the file and set up the frame) found the file not eligible for the
+// sequential kernel.  Eligible here: whole progressive frames whose FIRST scan is the one DC first-stage scan of all
+// components (what libjpeg writes), every other scan a DC refinement or a single-component AC scan, canonical tables, one
+// restart interval for the whole file.  Everything else -- and anything the kernels then find irregular -- is the host's.
+int parse_jpeg_prepare_gpu_progressive(JpegFile* jf, std::vector<ProgScanDecodePlan>* scans, int* rows_needed, bool* eligible) {
+    *eligible = false;
+    scans->clear();
+    if (jf->early_eof || jf->jpegtype != 2 || jf->ncomp < 1 || jf->ncomp > 3 || jf->scan.empty() || jf->start_byte) return 0;
+    const uint8_t* h = jf->hdr.data();
+    const size_t hdrs = jf->hdr.size();
+    size_t hpos = 0;
+    int rsti_seen = -1;
+    const int nrows = std::max(jf->mcuv, jf->comp[0].bcv);
+    while (3 + (uint64_t)hpos < hdrs) {
+        const uint8_t type = h[hpos + 1];
+        const unsigned len = 2 + be16(h[hpos + 2], h[hpos + 3]);
+        if ((uint64_t)hpos + len > hdrs) return 0;
+        if (type == 0xC4 || type == 0xDA || type == 0xDD)
+            if (!parse_segment(jf, type, len, len, h + hpos, true)) return 0;
+        hpos += len;
+        if (type != 0xDA) continue;
+        const size_t k = scans->size();
+        if (k >= jf->scan_start.size() || k >= 256) return 0;
+        if (rsti_seen >= 0 && rsti_seen != jf->rsti) return 0;
+        rsti_seen = jf->rsti;
+        ProgScanDecodePlan sc;
+        memset(&sc, 0, sizeof sc);
+        sc.cmpc = jf->cs_cmpc; sc.from = jf->cs_from; sc.to = jf->cs_to; sc.sah = jf->cs_sah; sc.sal = jf->cs_sal;
+        if (sc.cmpc < 1 || sc.cmpc > jf->ncomp || sc.sal < 0 || sc.sal > 13 || sc.sah < 0 || sc.sah > 13 || sc.from < 0 || sc.to > 63 || sc.from > sc.to) return 0;
+        const bool dc = sc.to == 0;
+        if (dc && sc.from != 0) return 0;
+        if (!dc && (sc.cmpc != 1 || sc.from < 1)) return 0;
+        if (k == 0 && !(dc && sc.sah == 0 && sc.cmpc == jf->ncomp)) return 0;   // the hand-off rows come from this scan
+        if (k > 0 && dc && sc.sah == 0) return 0;                               // a second DC first-stage scan: host
+        if (sc.sah != 0 && sc.sah != sc.sal + 1) return 0;
+        for (int i = 0; i < sc.cmpc; ++i) {
+            const int c = jf->cs_cmp[i];
+            if (c < 0 || c >= jf->ncomp) return 0;
+            for (int j = 0; j < i; ++j) if (sc.cmp[j] == c) return 0;
+            sc.cmp[i] = c;
+        }
+        if (sc.cmpc > 1) for (int i = 0; i < sc.cmpc; ++i) if (sc.cmp[i] != i) return 0;   // interleaved scans in frame order
+        ScanDecodePlan& t = sc.t;
+        t.scan = (const uint8_t*)(uintptr_t)jf->scan_start[k];
+        const size_t end = k + 1 < jf->scan_start.size() ? jf->scan_start[k + 1] : jf->scan.size();
+        if (end <= jf->scan_start[k]) return 0;
+        t.scan_len = (uint32_t)(end - jf->scan_start[k]);
+        t.ncomp = jf->ncomp; t.mcuh = jf->mcuh; t.mcuv = jf->mcuv; t.mcuc = jf->mcuc; t.rsti = jf->rsti;
+        for (int c = 0; c < jf->ncomp; ++c) {
+            const Component& q = jf->comp[c];
+            if (q.hs < 1 || q.vs < 1 || q.nch < 1 || q.ncv < 1 || q.bch != jf->mcuh * q.hs || q.bcv != jf->mcuv * q.vs) return 0;
+            if (jf->ncomp == 1 && (q.bch != q.nch || q.bcv != q.ncv)) return 0;
+            t.hs[c] = q.hs; t.vs[c] = q.vs; t.bch[c] = q.bch;
+            sc.bcv[c] = q.bcv; sc.nch[c] = q.nch; sc.ncv[c] = q.ncv; sc.mbs[c] = q.mbs;
+        }
+        if (dc) {
+            for (int i = 0; i < sc.cmpc; ++i) {
+                const int id = jf->comp[sc.cmp[i]].dc_tbl;
+                if (id < 0 || id > 1) return 0;
+                sc.tbl[i] = id;
+                if (sc.sah == 0) {
+                    if (!jf->htab[0][id].set) return 0;
+                    if (!fill_decode_tables(jf->htab[0][id], t.lut[id], t.maxcode[id], t.valoff[id], t.longsym[id])) return 0;
+                }
+            }
+        } else {
+            const int id = jf->comp[sc.cmp[0]].ac_tbl;
+            if (id < 0 || id > 3 || !jf->htab[1][id].set) return 0;
+            if (!fill_decode_tables(jf->htab[1][id], t.lut[2], t.maxcode[2], t.valoff[2], t.longsym[2])) return 0;
+            sc.max_eobrun = jf->htab[1][id].max_eobrun;
+        }
+        // dependency level: behind every earlier scan of the same component whose band overlaps
+        int level = 0;
+        for (const ProgScanDecodePlan& e : *scans) {
+            bool shares = false;
+            for (int i = 0; i < sc.cmpc; ++i) for (int j = 0; j < e.cmpc; ++j) shares |= sc.cmp[i] == e.cmp[j];
+            if (shares && e.from <= sc.to && sc.from <= e.to) level = std::max(level, e.level + 1);
+        }
+        sc.level = level;
+        sc.want_rows = k == 0 ? 1 : 0;
+        t.rows_off = 0;
+        sc.result_off = (uint64_t)(nrows + 1) + k;
+        scans->push_back(sc);
+    }
+    if (scans->empty() || scans->size() != jf->scan_start.size()) return 0;
+    *rows_needed = nrows + 1 + (int)scans->size();
+    *eligible = true;
+    return 0;
+}
+
+int parse_jpeg_finish_gpu_progressive(JpegFile* jf, const std::vector<ProgScanDecodePlan>& scans, const ScanDecodeRow* rows) {
+    const int nrows = std::max(jf->mcuv, jf->comp[0].bcv);
+    const int luma_mul = jf->comp[0].bcv / jf->mcuv;
+    int padbit = -1;
+    jf->max_bpos = 0; jf->max_sah = 0; jf->max_cmp = 0;
+    for (size_t k = 0; k < scans.size(); ++k) {
+        const ScanDecodeRow& fin = rows[scans[k].result_off];
+        if (fin.aux >> 8) return -1;                                       // irregular somewhere in this scan
+        if (fin.bitpos != scans[k].t.scan_len * 8u) return -1;
+        const int pb = (int8_t)(fin.aux & 255);
+        if (pb != -1) { if (padbit == -1) padbit = pb; else if (padbit != pb) return -1; }   // "inconsistent use of padbits"
+        jf->max_bpos = std::max(jf->max_bpos, scans[k].to);
+        jf->max_sah = std::max(jf->max_sah, std::max(scans[k].sal, scans[k].sah));
+        for (int i = 0; i < scans[k].cmpc; ++i) jf->max_cmp = std::max(jf->max_cmp, scans[k].cmp[i]);
+    }
+    const ProgScanDecodePlan& first = scans[0];
+    const int row_count = first.cmpc > 1 ? jf->mcuv : jf->comp[0].ncv;   // rows the first scan started
+    jf->rows.clear();
+    const auto& offs = jf->scan_to_file;
+    auto record = [&](uint32_t bit_in_all, const int16_t* last_dc, int mcu_y) {
+        const uint32_t p = (bit_in_all >> 3) + 1;   // BitReader::getpos
+        auto it = std::lower_bound(offs.begin(), offs.end(), std::pair<uint32_t, uint32_t>(p, p));
+        if (it != offs.begin()) --it;
+        uint32_t mapped = 0;
+        if (it != offs.end()) mapped = it->second + (p - it->first);
+        Handoff hnd;
+        hnd.segment_size = mapped;
+        for (int i = 0; i < 4; ++i) hnd.last_dc[i] = last_dc[i];
+        hnd.luma_y_start = (uint16_t)(luma_mul * mcu_y);
+        hnd.luma_y_end = (uint16_t)(luma_mul * (mcu_y + 1));
+        const int rem = (int)(bit_in_all & 7u);
+        hnd.num_overhang_bits = (uint8_t)rem;
+        hnd.overhang_byte = rem ? (uint8_t)(jf->scan[bit_in_all >> 3] & (uint8_t)(((1 << rem) - 1) << (8 - rem))) : 0;
+        jf->rows.push_back(hnd);
+    };
+    const uint32_t base0 = jf->scan_start.empty() ? 0u : jf->scan_start[0] * 8u;   // (the descriptors' scan pointers are the caller's device addresses by now)
+    for (int r = 0; r < row_count && r < nrows; ++r) {
+        if (rows[r].bitpos > first.t.scan_len * 8u) return -1;
+        record(base0 + rows[r].bitpos, rows[r].last_dc, r);
+    }
+    // the record after the last scan (decode_scans' final make_handoff): end of all data, the last scan's DC predictors, and
+    // the MCU row its MCU counter stood at -- which only interleaved scans advance
+    const ProgScanDecodePlan& last = scans.back();
+    const ScanDecodeRow& fin = rows[last.result_off];
+    record((uint32_t)jf->scan.size() * 8u, fin.last_dc, last.cmpc > 1 ? jf->mcuc / jf->mcuh : 0);
+    for (size_t i = 1; i < jf->rows.size(); ++i)
+        if (jf->rows[i].luma_y_start < jf->rows[i - 1].luma_y_end) jf->rows[i].luma_y_start = jf->rows[i - 1].luma_y_end;
+    jf->padbit = (int8_t)padbit;
+    jf->scan_count = (int)scans.size();
+    for (int c = 0; c < jf->ncomp; ++c) jf->max_dpos[c] = jf->comp[c].bc - 1;
+    jf->progressive_needed = true;
     return 0;
 }
 

@@ -24,6 +24,7 @@ struct lep_file {
 };
 static_assert(sizeof(lep_huffprog_image) == sizeof(lep::ProgImage) && sizeof(lep_huffprog_scan) == sizeof(lep::ProgScan), "C ABI mirrors");
 static_assert(sizeof(lep_huffdec_image) == sizeof(lep::ScanDecodePlan) && sizeof(lep_huffdec_row) == sizeof(lep::ScanDecodeRow), "C ABI mirrors");
+static_assert(sizeof(lep_huffprogdec_scan) == sizeof(lep::ProgScanDecodePlan), "C ABI mirrors");
 static_assert(sizeof(lep_huff_image) == sizeof(lep::RecodeImage) && sizeof(lep_huff_segment) == sizeof(lep::RecodeSegment), "C ABI mirrors");
 
 static void fill_desc(const lep::JpegFile& jf, lep_image_desc* d, int16_t* const* planes) {
@@ -133,6 +134,26 @@ int lep_jpeg_open_gpu(const uint8_t* jpg, size_t len, lep_jpeg** out, lep_huffde
     *eligible = ok ? 1 : 0;
     *out = j.release();
     return 0;
+}
+int lep_jpeg_open_gpu_progressive(lep_jpeg* j, lep_huffprogdec_scan* scans, int cap, int* nscan, int* rows_needed, int* eligible) {
+    *eligible = 0; *nscan = 0; *rows_needed = 0;
+    std::vector<lep::ProgScanDecodePlan> v;
+    bool ok = false;
+    int need = 0;
+    int rc = lep::parse_jpeg_prepare_gpu_progressive(&j->jf, &v, &need, &ok);
+    if (rc) return rc;
+    if (!ok || (int)v.size() > cap) return 0;
+    memcpy(scans, v.data(), v.size() * sizeof(lep_huffprogdec_scan));
+    *nscan = (int)v.size(); *rows_needed = need; *eligible = 1;
+    return 0;
+}
+int lep_jpeg_finish_gpu_progressive(lep_jpeg* j, const lep_huffprogdec_scan* scans, int nscan, const lep_huffdec_row* rows) {
+    std::vector<lep::ProgScanDecodePlan> v((size_t)nscan);
+    memcpy(v.data(), scans, (size_t)nscan * sizeof(lep_huffprogdec_scan));
+    // the descriptors as the caller launched them carry device addresses and arena offsets: rebase on the file's own
+    const uint64_t rows0 = v[0].t.rows_off;
+    for (auto& sc : v) { sc.result_off -= rows0; sc.t.rows_off -= rows0; }
+    return lep::parse_jpeg_finish_gpu_progressive(&j->jf, v, reinterpret_cast<const lep::ScanDecodeRow*>(rows) + rows0) ? LEP_UNSUPPORTED_JPEG : 0;
 }
 int lep_jpeg_scan_bytes(const lep_jpeg* j, const uint8_t** data, size_t* len) {
     *data = j->jf.scan.data(); *len = j->jf.scan.size();

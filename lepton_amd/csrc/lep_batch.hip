@@ -393,13 +393,26 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         std::vector<lep_huffdec_image> himg(nl);
         std::vector<char> on_gpu(nl, 0);
         std::vector<char> need_host(nl, gpu_huffman ? 0 : 1);
+        // progressive files: their scans go to the GPU scan decoder too (lep_huffprogdec.h) -- unless the caller wants the
+        // round trip verified: the Huffman half of that check needs the host parser's frame for files a canonical encoder
+        // might not reproduce, and the sequential kernel's "canonical by construction" argument has not been made for them
+        std::vector<std::vector<lep_huffprogdec_scan>> pscans(nl);
+        std::vector<int> prow_need(nl, 0);
+        std::vector<char> on_prog(nl, 0);
         if (gpu_huffman)
             parallel_for(nl, threads, [&](int k) {
                 const int i = c->live[k];
                 int ok = 0;
                 int rc = lep_jpeg_open_gpu(jpgs[i].data, jpgs[i].len, &parsed[i], &himg[k], &ok);
                 if (rc) { status[i] = rc; return; }      // not a JPEG the reference would take either
-                if (ok) on_gpu[k] = 1; else need_host[k] = 1;
+                if (ok) { on_gpu[k] = 1; return; }
+                if (!verify) {
+                    pscans[k].resize(64);
+                    int ns = 0, okp = 0;
+                    if (!lep_jpeg_open_gpu_progressive(parsed[i], pscans[k].data(), 64, &ns, &prow_need[k], &okp) && okp) { pscans[k].resize((size_t)ns); on_prog[k] = 1; return; }
+                    pscans[k].clear();
+                }
+                need_host[k] = 1;
             });
         bool any_host = false;
         for (int k = 0; k < nl; ++k) any_host |= need_host[k] != 0;
@@ -416,6 +429,14 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             row_off[k] = rows_total; rows_total += (size_t)himg[k].mcuv + 1;
             ++ngpu;
         }
+        std::vector<std::vector<size_t>> pscan_off(nl);   // progressive: every scan in its own aligned, zero-padded slot
+        int nprog = 0;
+        for (int k = 0; k < nl; ++k) if (on_prog[k]) {
+            for (const lep_huffprogdec_scan& sc : pscans[k]) { pscan_off[k].push_back(scan_total); scan_total += ((size_t)sc.t.scan_len + 80 + 15) & ~(size_t)15; }
+            row_off[k] = rows_total; rows_total += (size_t)prow_need[k];
+            ++nprog;
+        }
+        ngpu += nprog;
         std::vector<lep_huffdec_row> rows(rows_total);
         if (ngpu) {
             if (int rc = scan_reserve(s, scan_total + 256, 0)) return rc;
@@ -428,9 +449,17 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             }
             g_alloc_s += now_s() - ta;
             parallel_for(nl, threads, [&](int k) {
-                if (!on_gpu[k]) return;
+                if (!on_gpu[k] && !on_prog[k]) return;
                 const uint8_t* p = nullptr; size_t len = 0;
                 lep_jpeg_scan_bytes(parsed[c->live[k]], &p, &len);
+                if (on_prog[k]) {
+                    for (size_t q = 0; q < pscans[k].size(); ++q) {
+                        const size_t off = (size_t)(uintptr_t)pscans[k][q].t.scan, n = pscans[k][q].t.scan_len, room = ((n + 80 + 15) & ~(size_t)15);
+                        memcpy(s->h_scan + pscan_off[k][q], p + off, n);
+                        memset(s->h_scan + pscan_off[k][q] + n, 0, room - n);
+                    }
+                    return;
+                }
                 memcpy(s->h_scan + scan_off[k], p, len);
                 memset(s->h_scan + scan_off[k] + len, 0, (((size_t)himg[k].scan_len + 64 + 15) & ~(size_t)15) - len);
             });
@@ -440,7 +469,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         HIPOK(hipMemsetAsync(s->d_frames, 0, c->frame_bytes, s_copy));
         // (exactly the frame: the parser zeroes and fills frame_exact_bytes only, the rest of the 256-byte-rounded room in the
         // pinned staging is whatever an earlier batch left there and must not reach the device, where the padding stays zero)
-        for (int k = 0; k < nl; ++k) if (!on_gpu[k] && parsed[c->live[k]]) {
+        for (int k = 0; k < nl; ++k) if (!on_gpu[k] && !on_prog[k] && parsed[c->live[k]]) {
             const size_t fb = frame_exact_bytes(c->host_desc[k]);
             HIPOK(hipMemcpyAsync(s->d_frames + c->frame_off[k], s->h_frames + c->frame_off[k], fb, hipMemcpyHostToDevice, s_copy));
             st.h2d_bytes += (double)fb;
@@ -477,6 +506,25 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 if (!one.empty()) { if (int rc = lep_gpu_huffman_decode_device(g, one.data(), (int)one.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
             } else
             if (int rc = lep_gpu_huffman_decode_device(g, launch.data(), (int)launch.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc;
+            // progressive files: one wavefront per (image, scan), launched dependency level by dependency level
+            std::vector<lep_huffprogdec_scan> plaunch;
+            std::vector<size_t> pfirst_desc(nl, 0);
+            for (int k = 0; k < nl; ++k) if (on_prog[k]) {
+                pfirst_desc[k] = plaunch.size();
+                for (size_t q = 0; q < pscans[k].size(); ++q) {
+                    lep_huffprogdec_scan sc = pscans[k][q];
+                    sc.t.scan = s->d_scan + pscan_off[k][q];
+                    size_t off = c->frame_off[k];
+                    for (int cc = 0; cc < sc.t.ncomp; ++cc) {
+                        sc.t.blocks[cc] = (int16_t*)(s->d_frames + off);
+                        off += (size_t)sc.t.bch[cc] * sc.bcv[cc] * 128;
+                    }
+                    sc.t.rows_off += row_off[k];
+                    sc.result_off += row_off[k];
+                    plaunch.push_back(sc);
+                }
+            }
+            if (!plaunch.empty()) { if (int rc = lep_gpu_huffman_progressive_decode_device(g, plaunch.data(), (int)plaunch.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
             HIPOK(hipMemcpyAsync(rows.data(), s->d_rows, rows_total * sizeof(lep_huffdec_row), hipMemcpyDeviceToHost, s_huff));
             HIPOK(hipStreamSynchronize(s_huff));
             st.d2h_bytes += (double)(rows_total * sizeof(lep_huffdec_row));
@@ -500,8 +548,13 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             t0 = now_s();
             std::vector<char> redo(nl, 0);
             parallel_for(nl, threads, [&](int k) {
-                if (!on_gpu[k]) return;
                 const int i = c->live[k];
+                if (on_prog[k]) {
+                    if (lep_jpeg_finish_gpu_progressive(parsed[i], plaunch.data() + pfirst_desc[k], (int)pscans[k].size(), rows.data())) { redo[k] = 1; on_prog[k] = 0; return; }
+                    lep_jpeg_describe(parsed[i], &c->host_desc[k]);
+                    return;
+                }
+                if (!on_gpu[k]) return;
                 if (lep_jpeg_finish_gpu(parsed[i], rows.data() + row_off[k])) { redo[k] = 1; on_gpu[k] = 0; return; }
                 lep_jpeg_describe(parsed[i], &c->host_desc[k]);   // geometry; the frame itself only exists on the device
             });
@@ -513,7 +566,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             }
             st.parse_s += now_s() - t0;
             for (int k = 0; k < nl; ++k) if (redo[k] && parsed[c->live[k]]) {
-                const size_t fb = (k + 1 < nl ? c->frame_off[k + 1] : c->frame_bytes) - c->frame_off[k];
+                const size_t fb = frame_exact_bytes(c->host_desc[k]);   // the whole frame: the GPU decoder may have written part of it
                 HIPOK(hipMemcpyAsync(s->d_frames + c->frame_off[k], s->h_frames + c->frame_off[k], fb, hipMemcpyHostToDevice, s_copy));
                 st.h2d_bytes += (double)fb;
             }

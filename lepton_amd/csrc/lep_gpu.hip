@@ -5,6 +5,7 @@
 // point returns LEP_GPU_ERROR if HIP reports a failure.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +23,7 @@
 #include "lep_huffdec.h"
 #include "lep_huffdec_par.h"
 #include "lep_huffprog.h"
+#include "lep_huffprogdec.h"
 
 using namespace lepdev;
 
@@ -168,6 +170,13 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_progressive_encode_kernel(c
     if (threadIdx.x == 0) out_len[blockIdx.x] = n;
 }
 
+// progressive files, encode direction: one wavefront per (image, scan) of one dependency level (lep_huffprogdec.h)
+__global__ __launch_bounds__(64, 8) void lep_huffman_progressive_decode_kernel(const lephuff::ProgDecScan* __restrict__ scans, lephuff::HuffDecRow* rows) {
+    __shared__ lephuff::HuffDecShared sh;
+    lephuff::ProgDecWave w;
+    w.run_scan(scans + blockIdx.x, &sh, rows);
+}
+
 // JPEG Huffman scan decode: one wavefront per image (lep_huffdec.h)
 // <= 64 VGPRs and 4.5 KB of LDS: one of these waves fits on a SIMD beside seven coder waves, and it runs at raised priority
 // there (it is one long dependency chain per image; the coder waves around it are the throughput work)
@@ -241,6 +250,7 @@ struct lep_gpu {
     void* d_lens = nullptr; size_t lens_bytes = 0;
     void* d_huff = nullptr; size_t huff_bytes = 0;      // HuffImage[] | HuffSegment[]
     void* d_huffprog = nullptr; size_t huffprog_bytes = 0;   // ProgImage[] | ProgScan[]
+    void* d_huffprogdec = nullptr; size_t huffprogdec_bytes = 0;   // ProgDecScan[]
     void* d_huffdec = nullptr; size_t huffdec_bytes = 0;   // HuffDecImage[]
     void* d_huffpar = nullptr; size_t huffpar_bytes = 0;   // HuffParState[nimg][nsub] | int status[nimg] (parallel Huffman decode)
     void* d_scan = nullptr; size_t scan_bytes = 0;      // scan bytes of the Huffman encoder (host variant)
@@ -412,7 +422,7 @@ static void release_device_side(lep_gpu* g) {
     g->released = true;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffprog, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
+    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffprog, g->d_huffprogdec, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
         if (p) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -465,6 +475,41 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
     g->last_kernel = "lep_huffman_encode_kernel";
+    return 0;
+}
+
+static_assert(sizeof(lep_huffprogdec_scan) == sizeof(lephuff::ProgDecScan), "C ABI mirrors");
+
+int lep_gpu_huffman_progressive_decode_device(lep_gpu* g, const lep_huffprogdec_scan* scans, int nscan, lep_huffdec_row* d_rows, void* hip_stream) {
+    if (!g) return LEP_GPU_ERROR;
+    if (nscan <= 0) return 0;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
+    HIPCHK(g, hipSetDevice(g->device));
+    // scans ordered by dependency level (stable): one launch per level, stream order is the dependency
+    int maxlevel = 0;
+    for (int i = 0; i < nscan; ++i) { if (scans[i].level < 0 || scans[i].level > 63) return LEP_ASSERTION_FAILURE; maxlevel = std::max(maxlevel, (int)scans[i].level); }
+    std::vector<lep_huffprogdec_scan> sorted;
+    sorted.reserve((size_t)nscan);
+    std::vector<int> first((size_t)maxlevel + 2, 0);
+    for (int lv = 0; lv <= maxlevel; ++lv) {
+        first[(size_t)lv] = (int)sorted.size();
+        for (int i = 0; i < nscan; ++i) if (scans[i].level == lv) sorted.push_back(scans[i]);
+    }
+    first[(size_t)maxlevel + 1] = (int)sorted.size();
+    if (int rc = ensure(g, &g->d_huffprogdec, &g->huffprogdec_bytes, (size_t)nscan * sizeof(lep_huffprogdec_scan))) return rc;
+    HIPCHK(g, hipMemcpyAsync(g->d_huffprogdec, sorted.data(), (size_t)nscan * sizeof(lep_huffprogdec_scan), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipStreamSynchronize(st));
+    HIPCHK(g, hipEventRecord(g->ev0, st));
+    for (int lv = 0; lv <= maxlevel; ++lv) {
+        const int n = first[(size_t)lv + 1] - first[(size_t)lv];
+        if (n <= 0) continue;
+        hipLaunchKernelGGL(lep_huffman_progressive_decode_kernel, dim3(n), dim3(64), 0, st,
+                           (const lephuff::ProgDecScan*)g->d_huffprogdec + first[(size_t)lv], (lephuff::HuffDecRow*)d_rows);
+    }
+    HIPCHK(g, hipGetLastError());
+    HIPCHK(g, hipEventRecord(g->ev1, st));
+    g->timed = true;
+    g->last_kernel = "lep_huffman_progressive_decode_kernel";
     return 0;
 }
 

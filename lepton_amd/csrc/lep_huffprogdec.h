@@ -1,0 +1,300 @@
+// lep_huffprogdec.h -- PROGRESSIVE JPEG scans decoded into the coefficient frame ON THE GPU (BASELINE.json configs[4], encode
+// direction): the scan loop of the reference's decode_jpeg for progressive files (src/lepton/jpgcoder.cc:2975-3260) with
+// decode_dc_prg_fs / _sa, decode_ac_prg_fs / _sa, decode_eobrun_sa, skip_eobrun (:4968-5335, :5462-5500).
+//
+// One wavefront per (image, scan).  Unlike the re-encoder (lep_huffprog.h) the scans of an image are NOT independent here: a
+// refinement scan needs to know which coefficients of its band are already non-zero, and both DC scans write the same
+// coefficient.  The host sorts the scans of a batch into dependency levels (a scan's level = 1 + the highest level among the
+// earlier scans of the same component whose band overlaps its own); one launch per level, at most a handful.
+// Inside a scan decoding is serial, written as uniform vector code on lep_huffdec.h's window reader / one-step code
+// lookup.  Coefficients are written one 2-byte store at a time: scans of the same level write different positions of the same
+// blocks (libjpeg's script: luma 1..5 and luma 6..63 in parallel), so whole-block stores would race.
+// Anything irregular -- a code that does not exist, a zero run or an end-of-band run past its bounds, data left over or
+// missing, pad bits that change, end-of-band runs a canonical encoder would have merged, a block ending in a coded zero --
+// ends the scan with a status: the host parser then takes the whole file and answers as the reference does.
+// SPMD layer of lep_wave.h: tests/emu runs it on the CPU against the host parser (frame, hand-off rows, pad bit).
+#pragma once
+#include "lep_huffdec.h"
+
+namespace lephuff {
+
+struct ProgDecScan {
+    HuffDecImage t;         // scan = THIS scan's un-stuffed bytes; lut[0..1] DC tables 0 / 1, lut[2] = the scan's AC table; geometry; blocks;
+                            // rows_off = where this scan's per-MCU-row records go (want_rows)
+    int32_t cmpc, cmp[4];   // components of the scan, in scan order
+    int32_t from, to, sah, sal;
+    int32_t bcv[4], nch[4], ncv[4], mbs[4];
+    int32_t tbl[4];         // DC scans: table slot (0 / 1) of each scan component
+    int32_t max_eobrun;
+    int32_t want_rows;      // 1: the first (DC) scan of the file: one record per MCU row, the hand-offs of the .lep header
+    int32_t level;          // dependency level (host side; the kernel ignores it)
+    int32_t pad;
+    uint64_t result_off;    // this scan's final record {bit position, last DC, pad bits | status << 8} in the rows arena
+};
+
+struct ProgDecWave : HuffDecWave {
+    const ProgDecScan* sc;
+    uint32_t eobrun;
+    int peobrun;
+
+    WDEV void store_coef(int cmp, int dpos, int zz, int value) {   // one coefficient, aligned order
+        int16_t* dst = sc->t.blocks[cmp] + (int64_t)dpos * 64 + sh->z2a[zz];
+        LANES(l) if (l == 0) *dst = (int16_t)value;
+    }
+    // next_mcuposn (jpgcoder.cc:5432-5456): 0 go on, 1 restart interval over, 2 scan over
+    WDEV int next_noninterleaved(int cmp, int* dpos, int* rstw) const {
+        const int bch = sc->t.bch[cmp], nch = sc->nch[cmp], bcv = sc->bcv[cmp], ncv = sc->ncv[cmp];
+        ++*dpos;
+        if (bch != nch && *dpos % bch == nch) *dpos += bch - nch;
+        if (bcv != ncv && *dpos / bch == ncv) *dpos = bch * bcv;
+        if (*dpos >= bch * bcv) return 2;
+        if (sc->t.rsti > 0 && --*rstw == 0) return 1;
+        return 0;
+    }
+    // skip_eobrun (jpgcoder.cc:5462-5500): the blocks an end-of-band run covers are passed as a whole; -1 = irregular
+    WDEV int skip_run(int cmp, int* dpos, int* rstw) {
+        if (!eobrun) return 0;
+        const int bch = sc->t.bch[cmp], nch = sc->nch[cmp], bcv = sc->bcv[cmp], ncv = sc->ncv[cmp];
+        if (sc->t.rsti > 0) {
+            if ((int)eobrun > *rstw) return -1;
+            *rstw -= (int)eobrun;
+        }
+        if (bch != nch) *dpos += (int)((((uint32_t)(*dpos % bch) + eobrun) / (uint32_t)nch) * (uint32_t)(bch - nch));
+        if (bcv != ncv && *dpos / bch >= ncv) *dpos += (bcv - ncv) * bch;
+        *dpos += (int)eobrun;
+        eobrun = 0;
+        if (*dpos == bch * bcv) return 2;
+        if (*dpos > bch * bcv) return -1;
+        if (sc->t.rsti > 0 && *rstw == 0) return 1;
+        return 0;
+    }
+
+    // ---- AC first stage, one block (decode_ac_prg_fs): 0 ok, -1 irregular -------------------------------------------------------
+    WDEV int ac_first_block(int cmp, int dpos) {
+        const int from = sc->from, to = sc->to, sal = sc->sal;
+        if (eobrun > 0) { --eobrun; return 0; }   // inside a run: the band of this block is zero (the frame starts zeroed)
+        uint32_t bpos = vec((uint32_t)from);
+        uint32_t last_s = vec(1);
+#pragma nounroll
+        while (ucond(bpos <= (uint32_t)to)) {
+            uint32_t n = 0;
+            const int hc = symbol_and_bits(2, false, &n);
+            if (ucond(hc < 0)) return -1;
+            const uint32_t l = ((uint32_t)hc >> 4) & 15u, r = (uint32_t)hc & 15u;
+            if (ucond(l == 15u || r > 0u)) {
+                if (ucond(l + bpos > (uint32_t)to)) return -1;
+                bpos += l;
+                if (ucond(r > 0u)) store_coef(cmp, dpos, (int)uni(bpos), (int)(int16_t)((uint16_t)devli(r, n) << sal));
+                ++bpos;
+                last_s = r;
+            } else {
+                // end of band, and of 2^l + n - 1 further blocks.  A run that follows a run the encoder had not filled up is
+                // not what a canonical encoder writes (it would have written ONE longer run): host
+                const uint32_t extra = l ? read(l) : 0u;
+                if (ucond(last_s == 0u)) return -1;                   // coded zeros in front of the end of band
+                eobrun = uni(extra) + (1u << uni(l)) - 1u;
+                if (ucond(bpos == (uint32_t)from) && peobrun > 0 && peobrun < sc->max_eobrun) return -1;
+                peobrun = (int)eobrun + 1;
+                return 0;
+            }
+        }
+        if (ucond(last_s == 0u)) return -1;                           // the band ends in a coded zero
+        peobrun = 0;
+        return 0;
+    }
+
+    // ---- AC refinement, one block (decode_ac_prg_sa / decode_eobrun_sa) ---------------------------------------------------------------
+    // the band's coefficients as they are (sh->blk, zig-zag order here); every already non-zero position passed costs one
+    // correction bit; a code places one new +-1 behind `z` zero positions
+    WDEV int ac_refine_block(int cmp, int dpos) {
+        const int from = sc->from, to = sc->to, sal = sc->sal;
+        const int16_t* src = sc->t.blocks[cmp] + (int64_t)dpos * 64;
+        LV(int, nzf);
+        LANES(l) { const int v = (l >= from && l <= to) ? (int)src[sh->z2a[l]] : 0; sh->blk[l] = (int16_t)v; L(nzf) = v != 0; }
+        LSYNC();
+        const uint64_t nzm = lepwave::wave_ballot(nzf);   // already non-zero positions (zig-zag index = bit index)
+        uint32_t bpos = vec((uint32_t)from);
+        uint32_t last_kind = vec(1);                      // 0: the last code was a ZRL (sixteen zeros)
+        bool placed_any = false;
+        if (eobrun == 0) {
+#pragma nounroll
+            while (ucond(bpos <= (uint32_t)to)) {
+                uint32_t n = 0;
+                const int hc = symbol_and_bits(2, false, &n);
+                if (ucond(hc < 0)) return -1;
+                const uint32_t l = ((uint32_t)hc >> 4) & 15u, r = (uint32_t)hc & 15u;
+                if (ucond(l == 15u || r > 0u)) {
+                    if (ucond(r > 1u)) return -1;
+                    uint32_t z = l;
+                    const int v = r ? (uni(n) ? 1 : -1) : 0;
+                    // walk: non-zero positions take a correction bit, zero positions count the run down
+#pragma nounroll
+                    for (;;) {
+                        const uint32_t bp = uni(bpos);
+                        if (!((nzm >> bp) & 1ull)) {
+                            if (z > 0u) --z;
+                            else {
+                                if (v) store_coef(cmp, dpos, (int)bp, (int)(int16_t)((uint16_t)(int16_t)v << sal));
+                                ++bpos;
+                                break;
+                            }
+                        } else if (ucond(read(1) != 0u)) {
+                            const int old = sh->blk[bp];
+                            store_coef(cmp, dpos, (int)bp, (int)(int16_t)(old + (int16_t)((uint16_t)(int16_t)(old > 0 ? 1 : -1) << sal)));
+                        }
+                        ++bpos;
+                        if (ucond(bpos > (uint32_t)to)) return -1;   // (the reference: "if (bpos++ >= to) return -1")
+                    }
+                    last_kind = r;
+                    placed_any = placed_any || r != 0u;
+                } else {
+                    const uint32_t extra = l ? read(l) : 0u;
+                    if (ucond(last_kind == 0u)) return -1;           // ZRL in front of the end of band: not canonical
+                    eobrun = uni(extra) + (1u << uni(l));
+                    if (ucond(bpos == (uint32_t)from) && peobrun > 0 && peobrun < sc->max_eobrun - 1) return -1;   // jpgcoder.cc:3229-3236
+                    break;
+                }
+            }
+            if (eobrun == 0 && ucond(last_kind == 0u)) return -1;    // the band ends in a ZRL
+        }
+        if (eobrun > 0) {
+            // the rest of the band: correction bits only
+#pragma nounroll
+            while (ucond(bpos <= (uint32_t)to)) {
+                const uint32_t bp = uni(bpos);
+                if ((nzm >> bp) & 1ull) {
+                    if (ucond(read(1) != 0u)) {
+                        const int old = sh->blk[bp];
+                        store_coef(cmp, dpos, (int)bp, (int)(int16_t)(old + (int16_t)((uint16_t)(int16_t)(old > 0 ? 1 : -1) << sal)));
+                    }
+                }
+                ++bpos;
+            }
+            --eobrun;
+        }
+        peobrun = (int)eobrun;
+        (void)placed_any;
+        return 0;
+    }
+
+    WDEV void run_scan(const ProgDecScan* scan, HuffDecShared* shared, HuffDecRow* rows_arena) {
+        sc = scan; img = &scan->t; sh = shared; status = 0;
+        LANES(l) {
+            for (int i = l; i < 512; i += 64) sh->lut_ac[0][i] = img->lut[2][i];
+            for (int i = l; i < 2 * 256; i += 64) {
+                const uint16_t e = img->lut[i >> 8][(i & 255) * 2];
+                (&sh->lut_dc[0][0])[i] = (e >> 8) <= 8 ? e : (uint16_t)0;
+            }
+            if (l < 32) { (&sh->maxcode[0][0])[l] = (&img->maxcode[0][0])[l]; (&sh->valoff[0][0])[l] = (&img->valoff[0][0])[l]; }
+            for (int i = l; i < 4 * 256; i += 64) (&sh->longsym[0][0])[i] = (&img->longsym[0][0])[i];
+            sh->z2a[l] = kZ2A[l];
+            sh->blk[l] = 0;
+        }
+        LSYNC();
+        hi = vec(0); lo = vec(0); navail = 0; wi = 0; bitpos = vec(0);
+        refill(); refill();
+        HuffDecRow* rows = rows_arena + img->rows_off;
+        int lastdc[4] = {0, 0, 0, 0};
+        int padbit = -1;
+        const int rsti = img->rsti, mcuh = img->mcuh;
+        const bool dc = scan->to == 0;
+        const int sal = scan->sal;
+        int cmp = scan->cmp[0], csc = 0, sub = 0, dpos = 0, mcu = 0;
+        bool do_row = scan->want_rows != 0;
+        for (;;) {   // one restart interval per iteration
+            lastdc[0] = lastdc[1] = lastdc[2] = lastdc[3] = 0;
+            int sta = 0, rstw = rsti;
+            eobrun = 0; peobrun = 0;
+            if (dc && scan->cmpc > 1) {            // interleaved DC scan (the usual first scan)
+                while (sta == 0) {
+                    if (do_row) {
+                        const uint32_t bp = uni(bitpos);
+                        const int r = mcu / mcuh;
+                        LANES(l) if (l == 0) { rows[r].bitpos = bp; for (int c = 0; c < 4; ++c) rows[r].last_dc[c] = (int16_t)lastdc[c]; rows[r].aux = 0; }
+                        do_row = false;
+                    }
+                    int16_t* dst = img->blocks[cmp] + (int64_t)dpos * 64 + 49;
+                    if (scan->sah == 0) {
+                        uint32_t n = 0;
+                        const int hc = symbol_and_bits(scan->tbl[csc] & 1, true, &n);
+                        if (ucond(hc < 0)) { sta = -1; break; }
+                        const int v = (int16_t)(devli((uint32_t)hc & 255u, uni(n)) + lastdc[cmp]);
+                        lastdc[cmp] = v;
+                        LANES(l) if (l == 0) *dst = (int16_t)((uint16_t)v << sal);
+                    } else {
+                        const uint32_t bit = uni(read(1));
+                        LANES(l) if (l == 0) *dst = (int16_t)(*dst + (int16_t)(bit << sal));
+                    }
+                    // next_mcupos (jpgcoder.cc:5402-5430)
+                    const int old_mcu = mcu;
+                    if (++sub >= scan->mbs[cmp]) {
+                        sub = 0;
+                        if (++csc >= scan->cmpc) {
+                            csc = 0; cmp = scan->cmp[0]; ++mcu;
+                            if (mcu >= img->mcuc) sta = 2;
+                            else if (rsti > 0 && --rstw == 0) sta = 1;
+                        } else cmp = scan->cmp[csc];
+                    }
+                    {
+                        const uint32_t hs = (uint32_t)img->hs[cmp], vs = (uint32_t)img->vs[cmp], m = (uint32_t)mcu, sb = (uint32_t)sub, mh = (uint32_t)mcuh;
+                        if (vs > 1) dpos = (int)(((m / mh) * vs + sb / hs) * (uint32_t)img->bch[cmp] + (m % mh) * hs + sb % hs);
+                        else if (hs > 1) dpos = (int)(m * (uint32_t)scan->mbs[cmp] + sb);
+                        else dpos = mcu;
+                    }
+                    if (scan->want_rows && mcu % mcuh == 0 && old_mcu != mcu) do_row = true;
+                    if (ucond(bitpos > img->scan_len * 8u)) { sta = -1; break; }
+                }
+            } else if (dc) {                       // DC scan of one component
+                while (sta == 0) {
+                    if (do_row) {
+                        const uint32_t bp = uni(bitpos);
+                        const int r = dpos / img->bch[cmp];
+                        LANES(l) if (l == 0) { rows[r].bitpos = bp; for (int c = 0; c < 4; ++c) rows[r].last_dc[c] = (int16_t)lastdc[c]; rows[r].aux = 0; }
+                        do_row = false;
+                    }
+                    int16_t* dst = img->blocks[cmp] + (int64_t)dpos * 64 + 49;
+                    if (scan->sah == 0) {
+                        uint32_t n = 0;
+                        const int hc = symbol_and_bits(scan->tbl[0] & 1, true, &n);
+                        if (ucond(hc < 0)) { sta = -1; break; }
+                        const int v = (int16_t)(devli((uint32_t)hc & 255u, uni(n)) + lastdc[cmp]);
+                        lastdc[cmp] = v;
+                        LANES(l) if (l == 0) *dst = (int16_t)((uint16_t)v << sal);
+                    } else {
+                        const uint32_t bit = uni(read(1));
+                        LANES(l) if (l == 0) *dst = (int16_t)(*dst + (int16_t)(bit << sal));
+                    }
+                    sta = next_noninterleaved(cmp, &dpos, &rstw);
+                    if (scan->want_rows && cmp == 0 && dpos % img->bch[cmp] == 0) do_row = true;
+                    if (ucond(bitpos > img->scan_len * 8u)) { sta = -1; break; }
+                }
+            } else {                               // AC scan of one component
+                while (sta == 0) {
+                    const int rc = scan->sah == 0 ? ac_first_block(cmp, dpos) : ac_refine_block(cmp, dpos);
+                    if (rc < 0) { sta = -1; break; }
+                    if (scan->sah == 0) sta = skip_run(cmp, &dpos, &rstw);
+                    if (sta == 0) sta = next_noninterleaved(cmp, &dpos, &rstw);
+                    if (ucond(bitpos > img->scan_len * 8u)) { sta = -1; break; }
+                }
+                // a run that reaches past the end of its restart interval or scan (the reference tolerates it in the refinement
+                // stage and complains in the first): not canonical either way
+                if (sta > 0 && eobrun > 0) sta = -1;
+            }
+            if (sta == -1) { status = 1; break; }
+            const int got = unpad(padbit == -1 ? 255 : padbit);
+            if (padbit == -1) padbit = (int8_t)got;
+            else if (padbit != got) { status = 3; break; }
+            if (sta == 2) break;
+        }
+        if (!status && uni(bitpos) != img->scan_len * 8u) status = 2;   // bytes left over, or missing
+        const uint32_t bp = uni(bitpos);
+        HuffDecRow* fin = rows_arena + scan->result_off;
+        LANES(l) if (l == 0) {
+            fin->bitpos = bp;
+            for (int c = 0; c < 4; ++c) fin->last_dc[c] = (int16_t)lastdc[c];
+            fin->aux = (padbit & 255) | (status << 8);
+        }
+    }
+};
+
+}  // namespace lephuff

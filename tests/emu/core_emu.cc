@@ -217,6 +217,16 @@ extern "C" int emu_huffman_decode_image(const lep_huffdec_image* img, lep_huffde
     return 0;
 }
 
+// progressive scan decoder (lep_huffprogdec.h): the scans of one image, level by level, one emulated wavefront after the other
+#include "../../lepton_amd/csrc/lep_huffprogdec.h"
+extern "C" int emu_huffman_progressive_decode(const lep_huffprogdec_scan* scans, int nscan, lep_huffdec_row* rows) {
+    static lephuff::HuffDecShared sh;
+    for (int lv = 0; lv < 64; ++lv)
+        for (int i = 0; i < nscan; ++i)
+            if (scans[i].level == lv) { lephuff::ProgDecWave w; w.run_scan(reinterpret_cast<const lephuff::ProgDecScan*>(scans + i), &sh, reinterpret_cast<lephuff::HuffDecRow*>(rows)); }
+    return 0;
+}
+
 // several wavefronts per image (lep_huffdec_par.h): the three passes run one wave after the other
 #include "../../lepton_amd/csrc/lep_huffdec_par.h"
 extern "C" int emu_huffman_decode_image_parallel(const lep_huffdec_image* img, lep_huffdec_row* rows, int nsub, uint32_t* sync_blocks) {

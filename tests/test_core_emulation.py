@@ -669,3 +669,115 @@ def test_gpu_progressive_scan_encoder_on_random_files(emu):
         assert got is not None and got == jpg, (trial, w, h, mode, kw)
         done += 1
     assert done == 14
+
+
+def _progressive_decode_on_the_emulation(emu, jpg):
+    """progressive scans of `jpg` through lep_huffprogdec.h (lane-loop emulation).  Returns (handle, frame planes, status):
+    status None = not eligible, -1 = the kernels found it irregular, 0 = decoded and finished"""
+    from lepton_amd import abi
+
+    L = abi.lib()
+    h = C.c_void_p()
+    plan1 = abi.HuffDecImage()
+    ok = C.c_int(0)
+    rc = L.lep_jpeg_open_gpu(jpg, len(jpg), C.byref(h), C.byref(plan1), C.byref(ok))
+    assert rc == 0 and not ok.value, "a progressive file is not the sequential kernel's"
+    scans = (abi.HuffProgDecScan * 64)()
+    nscan, need, ok2 = C.c_int(0), C.c_int(0), C.c_int(0)
+    assert L.lep_jpeg_open_gpu_progressive(h, scans, 64, C.byref(nscan), C.byref(need), C.byref(ok2)) == 0
+    if not ok2.value:
+        L.lep_jpeg_close(h)
+        return None, None, None
+    d = abi.ImageDesc()
+    L.lep_jpeg_describe(h, C.byref(d))
+    planes = [C.create_string_buffer(d.nblocks(c) * 128) for c in range(d.ncomp)]
+    p, n = C.c_void_p(), C.c_size_t(0)
+    L.lep_jpeg_scan_bytes(h, C.byref(p), C.byref(n))
+    raw = C.string_at(p, n.value)
+    keep = []
+    for i in range(nscan.value):
+        off, ln = scans[i].t.scan or 0, scans[i].t.scan_len
+        buf = C.create_string_buffer(raw[off:off + ln] + bytes(80), ln + 80)   # every scan in its own aligned, zero-padded slot
+        keep.append(buf)
+        scans[i].t.scan = C.addressof(buf)
+        for c in range(d.ncomp):
+            scans[i].t.blocks[c] = C.addressof(planes[c])
+    rows = (abi.HuffDecRow * (need.value + 4))()
+    emu.emu_huffman_progressive_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    assert emu.emu_huffman_progressive_decode(scans, nscan.value, rows) == 0
+    rc = L.lep_jpeg_finish_gpu_progressive(h, scans, nscan.value, rows)
+    return h, planes, (0 if rc == 0 else -1)
+
+
+def _same_as_the_host_parser(jpg, h, planes):
+    from lepton_amd import abi
+
+    L = abi.lib()
+    host = JpegImage(jpg)
+    d = host.desc
+    for c in range(d.ncomp):
+        assert planes[c].raw == C.string_at(d.blocks[c], d.nblocks(c) * 128), "component %d differs" % c
+    # hand-offs, pad bit, restart bookkeeping: the .lep header written from either handle must be the same bytes
+    segs_h = (abi.Segment * abi.MAX_SEGMENTS)()
+    n_h = L.lep_jpeg_plan(h, 8, segs_h, 0)
+    segs = host.plan()
+    assert n_h == len(segs) and all((segs_h[i].luma_y_start, segs_h[i].luma_y_end) == (segs[i].luma_y_start, segs[i].luma_y_end) for i in range(n_h))
+    fake = [bytes([i + 1]) * 40 for i in range(n_h)]
+    arr = (abi.Bytes * n_h)()
+    bufs = []
+    for i, s in enumerate(fake):
+        b = C.create_string_buffer(s, len(s)); bufs.append(b)
+        arr[i].data = C.cast(b, C.c_void_p).value; arr[i].len = arr[i].cap = len(s)
+    out = abi.Bytes()
+    assert L.lep_jpeg_write_lep(h, 8, arr, n_h, C.byref(out)) == 0
+    got = out.tobytes(); L.lep_free(out.data)
+    assert got == host.write_lep(fake), "container (hand-offs / pad bit / restart counts) differs from the host parser's"
+
+
+@pytest.mark.parametrize("name", [n for n in golden_cases() if n.startswith("prog_")])
+def test_gpu_progressive_scan_decoder_on_cpu_equals_the_host_parser(emu, name):
+    """lep_huffprogdec.h (DC / AC first-stage and refinement scans, end-of-band runs, correction bits, dependency levels) as a
+    lane-loop emulation: the frame and the .lep header equal the host parser's; truncated files are left to the host"""
+    from lepton_amd import abi
+
+    jpg, _ = golden(name)
+    h, planes, st = _progressive_decode_on_the_emulation(emu, jpg)
+    if "truncated" in name:
+        assert st is None
+        return
+    assert st == 0, "eligible fixture was refused or found irregular"
+    _same_as_the_host_parser(jpg, h, planes)
+    abi.lib().lep_jpeg_close(h)
+
+
+def test_gpu_progressive_scan_decoder_on_random_files(emu):
+    import io
+    import random
+
+    import numpy as np
+    from PIL import Image
+    from lepton_amd import abi
+
+    rnd = random.Random(6)
+    done = 0
+    for trial in range(16):
+        w, h_ = rnd.choice([64, 97, 200, 333]), rnd.choice([48, 72, 150, 241])
+        mode = rnd.choice(["RGB", "RGB", "L"])
+        rng = np.random.default_rng(700 + trial)
+        base = rng.integers(0, 256, (max(2, h_ // 24), max(2, w // 24), 3), dtype=np.uint8)
+        a = np.asarray(Image.fromarray(base, "RGB").resize((w, h_), Image.BICUBIC)).astype(np.int16)
+        a = np.clip(a + rng.normal(0, rnd.choice([0, 2, 10, 40]), a.shape), 0, 255).astype(np.uint8)
+        kw = dict(format="JPEG", quality=rnd.choice([30, 75, 92, 100]), progressive=True)
+        if mode == "RGB":
+            kw["subsampling"] = rnd.choice([0, 1, 2])
+        if rnd.random() < 0.4:
+            kw["restart_marker_blocks"] = rnd.choice([1, 3, 7])
+        buf = io.BytesIO()
+        Image.fromarray(a, "RGB").convert(mode).save(buf, **kw)
+        jpg = buf.getvalue()
+        hdl, planes, st = _progressive_decode_on_the_emulation(emu, jpg)
+        assert st == 0, (trial, w, h_, mode, kw, st)
+        _same_as_the_host_parser(jpg, hdl, planes)
+        abi.lib().lep_jpeg_close(hdl)
+        done += 1
+    assert done == 16

@@ -403,3 +403,31 @@ def test_gpu_progressive_scans_are_recoded_on_the_gpu(gpu_codec):
     # and the host path still agrees
     back3, st3, _ = gpu_codec.decompress_batch(big_lep, host_huffman=True)
     assert st3 == [0, 0, 0] and back3 == big
+
+
+def test_gpu_progressive_scans_are_decoded_on_the_gpu(gpu_codec):
+    """encode direction of progressive files: lep_huffprogdec.h (one wavefront per scan, dependency levels) + the arithmetic
+    coder; the .lep files equal the reference's byte for byte, truncated progressive files still take the host parser, and
+    only scan bytes cross PCIe for the eligible ones.  With verify the host parser keeps these files (see lep_batch.hip)."""
+    names = [n for n in golden_cases() if n.startswith("prog_")]
+    jpgs = [golden(n)[0] for n in names]
+    leps = [golden(n)[1] for n in names]
+    big = [corpus.synth_jpeg(1920, 1080, 94, progressive=True), corpus.synth_jpeg(640, 480, 95, progressive=True, subsampling="4:4:4", quality=97),
+           corpus.synth_jpeg(800, 600, 96, progressive=True, quality=35), corpus.synth_jpeg(333, 241, 97, progressive=True, subsampling="4:2:2")]
+    want_big = [gpu_codec.compress(j) for j in big]          # per-file path: host parser
+    got, st, stats = gpu_codec.compress_batch(jpgs + big + [golden("c420_160x120")[0]], chunk_images=7)
+    assert st == [0] * (len(names) + 5)
+    assert got[: len(names)] == leps and got[len(names): len(names) + 4] == want_big and got[-1] == golden("c420_160x120")[1]
+    _, st2, stats2 = gpu_codec.compress_batch(big)
+    assert st2 == [0] * 4 and stats2["h2d_bytes"] < 1.3 * sum(map(len, big)) + 65536     # frames (6.2 MB for the 1080p one alone) never crossed
+    got3, st3, _ = gpu_codec.compress_batch(big, verify=True)
+    assert st3 == [0] * 4 and got3 == want_big
+    # a progressive file damaged inside a scan: whatever the GPU decoder makes of it, the answer is the host parser's
+    bad = bytearray(big[2]); bad[len(bad) // 2] ^= 0x10
+    try:
+        want_bad, code = gpu_codec.compress(bytes(bad)), 0
+    except LeptonError as e:
+        want_bad, code = None, e.code
+    got4, st4, _ = gpu_codec.compress_batch([bytes(bad), big[0]])
+    assert st4[1] == 0 and got4[1] == want_big[0]
+    assert (st4[0], got4[0]) == (code, want_bad) or (code == 41 and st4[0] == 0)   # per-file compress also runs the round-trip check
