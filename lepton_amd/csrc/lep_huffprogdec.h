@@ -7,8 +7,10 @@
 // coefficient.  The host sorts the scans of a batch into dependency levels (a scan's level = 1 + the highest level among the
 // earlier scans of the same component whose band overlaps its own); one launch per level, at most a handful.
 // Inside a scan decoding is serial, written as uniform vector code on lep_huffdec.h's window reader / one-step code
-// lookup.  Coefficients are written one 2-byte store at a time: scans of the same level write different positions of the same
-// blocks (libjpeg's script: luma 1..5 and luma 6..63 in parallel), so whole-block stores would race.
+// lookup, one step per CODE: what a code places goes into a block image in LDS, the correction bits of the positions it passes
+// are one read and a lane-parallel update, and the coefficients that changed leave with one masked lane-parallel store per
+// block (scans of the same level write different positions of the same blocks -- libjpeg's script: luma 1..5 and luma 6..63 in
+// parallel -- so whole-block stores would race).
 // Anything irregular -- a code that does not exist, a zero run or an end-of-band run past its bounds, data left over or
 // missing, pad bits that change, end-of-band runs a canonical encoder would have merged, a block ending in a coded zero --
 // ends the scan with a status: the host parser then takes the whole file and answers as the reference does.
@@ -37,10 +39,6 @@ struct ProgDecWave : HuffDecWave {
     uint32_t eobrun;
     int peobrun;
 
-    WDEV void store_coef(int cmp, int dpos, int zz, int value) {   // one coefficient, aligned order
-        int16_t* dst = sc->t.blocks[cmp] + (int64_t)dpos * 64 + sh->z2a[zz];
-        LANES(l) if (l == 0) *dst = (int16_t)value;
-    }
     // next_mcuposn (jpgcoder.cc:5432-5456): 0 go on, 1 restart interval over, 2 scan over
     WDEV int next_noninterleaved(int cmp, int* dpos, int* rstw) const {
         const int bch = sc->t.bch[cmp], nch = sc->nch[cmp], bcv = sc->bcv[cmp], ncv = sc->ncv[cmp];
@@ -69,112 +67,151 @@ struct ProgDecWave : HuffDecWave {
         return 0;
     }
 
+    // Both AC block decoders keep the serial part to one step per CODE: what a code places goes into the block image in LDS
+    // (zig-zag order) and a 64-bit "changed" mask; which already-non-zero positions it passes is a mask operation, their
+    // correction bits one read; the coefficients that changed leave with ONE lane-parallel store at the end of the block
+    // (lane = position; scans of the same level write different positions, so whole-block stores would race).
+    WDEV void flush_block(int cmp, int dpos, uint64_t changed) {
+        if (!changed) return;
+        int16_t* dst = sc->t.blocks[cmp] + (int64_t)dpos * 64;
+        LSYNC();
+        LANES(l) if ((changed >> l) & 1ull) dst[sh->z2a[l]] = sh->blk[l];
+        LSYNC();
+    }
+
     // ---- AC first stage, one block (decode_ac_prg_fs): 0 ok, -1 irregular -------------------------------------------------------
     WDEV int ac_first_block(int cmp, int dpos) {
         const int from = sc->from, to = sc->to, sal = sc->sal;
         if (eobrun > 0) { --eobrun; return 0; }   // inside a run: the band of this block is zero (the frame starts zeroed)
         uint32_t bpos = vec((uint32_t)from);
         uint32_t last_s = vec(1);
+        uint64_t changed = 0;
+        int rc = 0;
 #pragma nounroll
         while (ucond(bpos <= (uint32_t)to)) {
             uint32_t n = 0;
             const int hc = symbol_and_bits(2, false, &n);
-            if (ucond(hc < 0)) return -1;
+            if (ucond(hc < 0)) { rc = -1; break; }
             const uint32_t l = ((uint32_t)hc >> 4) & 15u, r = (uint32_t)hc & 15u;
             if (ucond(l == 15u || r > 0u)) {
-                if (ucond(l + bpos > (uint32_t)to)) return -1;
+                if (ucond(l + bpos > (uint32_t)to)) { rc = -1; break; }
                 bpos += l;
-                if (ucond(r > 0u)) store_coef(cmp, dpos, (int)uni(bpos), (int)(int16_t)((uint16_t)devli(r, n) << sal));
+                if (ucond(r > 0u)) {
+                    const uint32_t bp = uni(bpos);
+                    const int16_t v = (int16_t)((uint16_t)devli(r, uni(n)) << sal);
+                    LANES(ln) if (ln == 0) sh->blk[bp] = v;
+                    changed |= 1ull << bp;
+                }
                 ++bpos;
                 last_s = r;
             } else {
                 // end of band, and of 2^l + n - 1 further blocks.  A run that follows a run the encoder had not filled up is
                 // not what a canonical encoder writes (it would have written ONE longer run): host
                 const uint32_t extra = l ? read(l) : 0u;
-                if (ucond(last_s == 0u)) return -1;                   // coded zeros in front of the end of band
+                if (ucond(last_s == 0u)) { rc = -1; break; }          // coded zeros in front of the end of band
                 eobrun = uni(extra) + (1u << uni(l)) - 1u;
-                if (ucond(bpos == (uint32_t)from) && peobrun > 0 && peobrun < sc->max_eobrun) return -1;
+                if (ucond(bpos == (uint32_t)from) && peobrun > 0 && peobrun < sc->max_eobrun) { rc = -1; break; }
                 peobrun = (int)eobrun + 1;
+                flush_block(cmp, dpos, changed);
                 return 0;
             }
         }
-        if (ucond(last_s == 0u)) return -1;                           // the band ends in a coded zero
+        if (!rc && ucond(last_s == 0u)) rc = -1;                      // the band ends in a coded zero
+        flush_block(cmp, dpos, changed);
         peobrun = 0;
-        return 0;
+        return rc;
+    }
+
+    // the correction bits of the already-non-zero positions in `cm` (a mask of zig-zag positions, consumed in ascending order):
+    // one bit each from the stream; positions whose bit is 1 move one step away from zero.  Lane-parallel except for the read.
+    WDEV void correct(uint64_t cm, uint64_t* changed) {
+#pragma nounroll
+        while (cm) {
+            // up to 16 positions per read
+            uint64_t part = cm;
+            int k = lepwave::popc64(cm);
+            if (k > 16) {   // keep the 16 lowest set bits
+                uint64_t m = cm;
+                for (int i = 0; i < 16; ++i) m &= m - 1;
+                part = cm & ~m; k = 16;
+            }
+            const uint32_t bits = uni(read((uint32_t)k));   // first position = most significant of the k bits
+            uint64_t ones = 0;
+            LV(int, hit);
+            LANES(l) {
+                int h = 0;
+                if ((part >> l) & 1ull) {
+                    const int j = lepwave::popc64(part & ((1ull << l) - 1));
+                    h = (int)((bits >> (k - 1 - j)) & 1u);
+                    if (h) { const int old = sh->blk[l]; sh->blk[l] = (int16_t)(old + (int16_t)((uint16_t)(int16_t)(old > 0 ? 1 : -1) << sc->sal)); }
+                }
+                L(hit) = h;
+            }
+            ones = lepwave::wave_ballot(hit);
+            *changed |= ones;
+            cm &= ~part;
+        }
     }
 
     // ---- AC refinement, one block (decode_ac_prg_sa / decode_eobrun_sa) ---------------------------------------------------------------
-    // the band's coefficients as they are (sh->blk, zig-zag order here); every already non-zero position passed costs one
-    // correction bit; a code places one new +-1 behind `z` zero positions
+    // the band's coefficients as they are (sh->blk, zig-zag order); every already non-zero position passed costs one correction
+    // bit; a code places one new +-1 behind `z` zero positions
     WDEV int ac_refine_block(int cmp, int dpos) {
         const int from = sc->from, to = sc->to, sal = sc->sal;
         const int16_t* src = sc->t.blocks[cmp] + (int64_t)dpos * 64;
         LV(int, nzf);
         LANES(l) { const int v = (l >= from && l <= to) ? (int)src[sh->z2a[l]] : 0; sh->blk[l] = (int16_t)v; L(nzf) = v != 0; }
         LSYNC();
+        const uint64_t band = (to >= 63 ? ~0ull : ((1ull << (to + 1)) - 1)) & ~((1ull << from) - 1);
         const uint64_t nzm = lepwave::wave_ballot(nzf);   // already non-zero positions (zig-zag index = bit index)
-        uint32_t bpos = vec((uint32_t)from);
-        uint32_t last_kind = vec(1);                      // 0: the last code was a ZRL (sixteen zeros)
-        bool placed_any = false;
+        const uint64_t zm = band & ~nzm;                  // zero positions of the band
+        uint32_t bpos = (uint32_t)from;                   // scalar: everything it depends on is read through uni()
+        uint32_t last_kind = 1;                           // 0: the last code was a ZRL (sixteen zeros)
+        uint64_t changed = 0;
+        int rc = 0;
         if (eobrun == 0) {
 #pragma nounroll
-            while (ucond(bpos <= (uint32_t)to)) {
+            while (bpos <= (uint32_t)to) {
                 uint32_t n = 0;
                 const int hc = symbol_and_bits(2, false, &n);
-                if (ucond(hc < 0)) return -1;
+                if (ucond(hc < 0)) { rc = -1; break; }
                 const uint32_t l = ((uint32_t)hc >> 4) & 15u, r = (uint32_t)hc & 15u;
-                if (ucond(l == 15u || r > 0u)) {
-                    if (ucond(r > 1u)) return -1;
-                    uint32_t z = l;
+                if (l == 15u || r > 0u) {
+                    if (r > 1u) { rc = -1; break; }
+                    // the (l + 1)-th zero position at or after bpos takes the new coefficient (or, for a ZRL, nothing); the
+                    // non-zero positions in front of it take correction bits
+                    const uint64_t zrest = zm & ~((1ull << bpos) - 1);
+                    if ((uint32_t)lepwave::popc64(zrest) < l + 1u) { rc = -1; break; }   // the walk would leave the band
+                    uint64_t m = zrest;
+                    for (uint32_t i = 0; i < l; ++i) m &= m - 1;
+                    const uint32_t pos = (uint32_t)__builtin_ctzll(m);
+                    const uint64_t passed = nzm & ~((1ull << bpos) - 1) & ((1ull << pos) - 1);
                     const int v = r ? (uni(n) ? 1 : -1) : 0;
-                    // walk: non-zero positions take a correction bit, zero positions count the run down
-#pragma nounroll
-                    for (;;) {
-                        const uint32_t bp = uni(bpos);
-                        if (!((nzm >> bp) & 1ull)) {
-                            if (z > 0u) --z;
-                            else {
-                                if (v) store_coef(cmp, dpos, (int)bp, (int)(int16_t)((uint16_t)(int16_t)v << sal));
-                                ++bpos;
-                                break;
-                            }
-                        } else if (ucond(read(1) != 0u)) {
-                            const int old = sh->blk[bp];
-                            store_coef(cmp, dpos, (int)bp, (int)(int16_t)(old + (int16_t)((uint16_t)(int16_t)(old > 0 ? 1 : -1) << sal)));
-                        }
-                        ++bpos;
-                        if (ucond(bpos > (uint32_t)to)) return -1;   // (the reference: "if (bpos++ >= to) return -1")
+                    correct(passed, &changed);
+                    if (v) {
+                        const int16_t nv = (int16_t)((uint16_t)(int16_t)v << sal);
+                        LANES(ln) if (ln == 0) sh->blk[pos] = nv;
+                        changed |= 1ull << pos;
                     }
+                    bpos = pos + 1;
                     last_kind = r;
-                    placed_any = placed_any || r != 0u;
                 } else {
                     const uint32_t extra = l ? read(l) : 0u;
-                    if (ucond(last_kind == 0u)) return -1;           // ZRL in front of the end of band: not canonical
-                    eobrun = uni(extra) + (1u << uni(l));
-                    if (ucond(bpos == (uint32_t)from) && peobrun > 0 && peobrun < sc->max_eobrun - 1) return -1;   // jpgcoder.cc:3229-3236
+                    if (last_kind == 0u) { rc = -1; break; }         // ZRL in front of the end of band: not canonical
+                    eobrun = uni(extra) + (1u << l);
+                    if (bpos == (uint32_t)from && peobrun > 0 && peobrun < sc->max_eobrun - 1) { rc = -1; break; }   // jpgcoder.cc:3229-3236
                     break;
                 }
             }
-            if (eobrun == 0 && ucond(last_kind == 0u)) return -1;    // the band ends in a ZRL
+            if (!rc && eobrun == 0 && last_kind == 0u) rc = -1;      // the band ends in a ZRL
         }
-        if (eobrun > 0) {
-            // the rest of the band: correction bits only
-#pragma nounroll
-            while (ucond(bpos <= (uint32_t)to)) {
-                const uint32_t bp = uni(bpos);
-                if ((nzm >> bp) & 1ull) {
-                    if (ucond(read(1) != 0u)) {
-                        const int old = sh->blk[bp];
-                        store_coef(cmp, dpos, (int)bp, (int)(int16_t)(old + (int16_t)((uint16_t)(int16_t)(old > 0 ? 1 : -1) << sal)));
-                    }
-                }
-                ++bpos;
-            }
+        if (!rc && eobrun > 0) {
+            if (bpos <= (uint32_t)to) correct(nzm & ~((1ull << bpos) - 1) & band, &changed);   // the rest of the band: correction bits only
             --eobrun;
         }
+        flush_block(cmp, dpos, changed);
         peobrun = (int)eobrun;
-        (void)placed_any;
-        return 0;
+        return rc;
     }
 
     WDEV void run_scan(const ProgDecScan* scan, HuffDecShared* shared, HuffDecRow* rows_arena) {
