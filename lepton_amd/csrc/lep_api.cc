@@ -232,6 +232,7 @@ int lep_file_open_next(const uint8_t* d, size_t len, const lep_file* prev, lep_f
     lep::JpegFile& jf = f->lf.jpeg;
     memset(jf.qtables, 0, sizeof jf.qtables);
     if (!lep::setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : LEP_UNSUPPORTED_JPEG;
+    if (jf.warn > 0) return LEP_UNSUPPORTED_JPEG;   // errorlevel 1 in setup_imginfo_jpg (an unknown marker in the embedded header, jpgcoder.cc:4836-4840) stops the reference too
     if (jf.ncomp > 3) return LEP_UNSUPPORTED_4_COLORS;
     if (jf.early_eof) {
         for (int c = 0; c < jf.ncomp; ++c) {
