@@ -62,15 +62,22 @@ struct HuffDecWave {
     // bit reader (uniform vector): 64-bit top-aligned window, refilled with aligned big-endian dwords
     uint32_t hi, lo;
     int navail;
-    uint32_t wi;            // next dword to load (scalar)
+    uint32_t wi;            // index of the dword `ahead` holds (scalar)
+    uint32_t ahead;         // that dword, requested one refill before it is needed: the load's latency (a serial chain has nothing
+                            // else to hide it behind) passes while the window's current 32 bits are decoded
     uint32_t bitpos;        // bits consumed
     int status;
 
-    WDEV void refill() {
+    WDEV uint32_t fetch(uint32_t k) const {
         const uint32_t* words = reinterpret_cast<const uint32_t*>(img->scan);
         // data past the end reads as zero (the arena is zero padded); running past it is detected through bitpos
-        const uint32_t w = wi * 4 < img->scan_len + 16 ? __builtin_bswap32(lep3_vload(words + wi)) : 0u;
+        return k * 4 < img->scan_len + 16 ? lep3_vload(words + k) : 0u;
+    }
+    WDEV void start_reader(uint32_t first_word) { wi = first_word; ahead = fetch(first_word); }
+    WDEV void refill() {
+        const uint32_t w = __builtin_bswap32(ahead);
         ++wi;
+        ahead = fetch(wi);
         const uint64_t add = ((uint64_t)w << 32) >> navail;
         hi |= (uint32_t)(add >> 32); lo |= (uint32_t)add;
         navail += 32;
@@ -182,7 +189,8 @@ struct HuffDecWave {
             sh->blk[l] = 0;
         }
         LSYNC();
-        hi = vec(0); lo = vec(0); navail = 0; wi = 0; bitpos = vec(0);
+        hi = vec(0); lo = vec(0); navail = 0; bitpos = vec(0);
+        start_reader(0);
         refill(); refill();
         HuffDecRow* rows = rows_arena + img->rows_off;
         int lastdc[4] = {0, 0, 0, 0};

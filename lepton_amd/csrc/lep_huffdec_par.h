@@ -84,7 +84,7 @@ struct HuffParWave : HuffDecWave {
     // bit reader positioned at an arbitrary bit
     WDEV void seek(uint32_t bp) {
         hi = vec(0); lo = vec(0); navail = 0;
-        wi = bp >> 5;
+        start_reader(bp >> 5);
         bitpos = vec(bp & ~31u);
         refill(); refill();
         if (bp & 31u) consume(bp & 31u);

@@ -228,7 +228,8 @@ struct ProgDecWave : HuffDecWave {
             sh->blk[l] = 0;
         }
         LSYNC();
-        hi = vec(0); lo = vec(0); navail = 0; wi = 0; bitpos = vec(0);
+        hi = vec(0); lo = vec(0); navail = 0; bitpos = vec(0);
+        start_reader(0);
         refill(); refill();
         HuffDecRow* rows = rows_arena + img->rows_off;
         int lastdc[4] = {0, 0, 0, 0};
