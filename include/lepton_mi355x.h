@@ -241,6 +241,12 @@ int lep_compress_embedded(lep_gpu *g, const uint8_t *blob, size_t len, size_t of
  * the hand-offs and bookkeeping of the .lep header (non-zero: irregular, use the host parser). */
 int lep_jpeg_open_gpu_progressive(lep_jpeg *j, lep_huffprogdec_scan *scans, int cap, int *nscan, int *rows_needed, int *eligible);
 int lep_jpeg_finish_gpu_progressive(lep_jpeg *j, const lep_huffprogdec_scan *scans, int nscan, const lep_huffdec_row *rows);
+/* The Huffman half of the round-trip check (validation.cc:97-218) for a file whose scans lep_jpeg_open_gpu_progressive took:
+ * the plan that writes every scan of the parsed file again on the GPU (lep_gpu_huffman_progressive_encode_device; the caller
+ * sets image->blocks, out_off, corr_off) and where each scan's own bytes lie in the file (first byte, length -- up to the
+ * marker that ends the scan), to be compared with what the kernel wrote.  *eligible = 0: check on the host instead. */
+int lep_jpeg_plan_progressive_check(lep_jpeg *j, size_t jpeg_len, lep_huffprog_image *image, lep_huffprog_scan *scans,
+                                    uint32_t *file_first, uint32_t *file_len, int cap, int *nscan, int *eligible);
 int lep_jpeg_scan_bytes(const lep_jpeg *j, const uint8_t **data, size_t *len);
 int lep_jpeg_finish_gpu(lep_jpeg *j, const lep_huffdec_row *rows);
 void lep_jpeg_close(lep_jpeg *j);
@@ -347,6 +353,7 @@ typedef struct lep_batch_stats {
     double h2d_bytes, d2h_bytes; /* PCIe traffic */
     double alloc_s;              /* inside pipeline_s: (re)allocation of the pinned / device staging buffers (kept between calls) */
     double redone_files;         /* compress: files whose streams outgrew the space reserved from their JPEG size and went through lep_compress */
+    double gpu_huffman_files;    /* files whose Huffman scans the GPU decoded (compress) / wrote (decompress); the rest took the host coder */
 } lep_batch_stats;
 int lep_compress_batch(lep_gpu *g, const lep_bytes *jpgs, int n, lep_bytes *outs, int32_t *status,
                        const lep_batch_options *opt, lep_batch_stats *stats);

@@ -67,6 +67,7 @@ struct JpegFile {
     std::vector<uint8_t> garbage;   // bytes from EOI on, empty if exactly FF D9 (grbgdata)
     std::vector<std::pair<uint32_t, uint32_t>> scan_to_file;   // huff_input_offsets
     std::vector<uint32_t> scan_start;   // offset in `scan` where the entropy-coded bytes behind each SOS begin
+    std::vector<std::pair<uint32_t, uint32_t>> scan_file_range;   // the same scans in the FILE: [first entropy-coded byte, the marker that ends them)
     std::vector<uint32_t> rst_cnt;  // RST markers seen per scan
     std::vector<uint8_t> rst_err;   // wrongly placed RST markers at scan end, per scan
     bool early_eof = false;

@@ -468,11 +468,21 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
 
 // ---- the same with the scans coded on the GPU (lep_huffprog.h) ---------------------------------------------------------------------
 int recode_progressive_prepare(LepFile* lf, ProgPlan* plan) {
-    JpegFile& jf = lf->jpeg;
     plan->gpu_ok = false;
     plan->scans.clear(); plan->scan_hdr_end.clear(); plan->markers.clear();
     if (lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1)) return 0;   // the baseline re-coder's files
-    if (lf->jpeg_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
+    if (lf->jpeg_size <= lf->jpeg.garbage.size()) return EX_ASSERTION_FAILURE;
+    return progressive_plan(&lf->jpeg, lf->jpeg_size, lf->rst_cnt_set, plan);
+}
+
+// The plan itself, from a parsed JPEG: the decompressor's (above, the JpegFile rebuilt from a .lep header) and the
+// compressor's round-trip check (lep_batch.hip: the scans of the frame it has just coded are written again on the GPU and
+// compared with the file's own bytes).  Walks the header's DHT / DRI / SOS segments once more, leaving the tables in their
+// end-of-file state (what the parser left them in).
+int progressive_plan(JpegFile* jfp, size_t jpeg_size, bool rst_cnt_set, ProgPlan* plan) {
+    JpegFile& jf = *jfp;
+    plan->gpu_ok = false;
+    plan->scans.clear(); plan->scan_hdr_end.clear(); plan->markers.clear();
     // eligibility: whole progressive frames of up to three components; everything else keeps the host coder
     bool ok = jf.jpegtype == 2 && !jf.early_eof && jf.ncomp >= 1 && jf.ncomp <= 3 && jf.mcuh > 0 && jf.mcuv > 0;
     for (int c = 0; c < jf.ncomp; ++c) ok = ok && jf.trunc_bcv[c] >= jf.comp[c].bcv && jf.comp[c].nch > 0 && jf.comp[c].ncv > 0;
@@ -534,10 +544,10 @@ int recode_progressive_prepare(LepFile* lf, ProgPlan* plan) {
         }
         const size_t nmark = jf.rsti > 0 ? (units + (size_t)jf.rsti - 1) / (size_t)jf.rsti - 1 : 0;
         const size_t scan_index = plan->scans.size();
-        if (lf->rst_cnt_set && nmark > 0 && !(jf.rst_cnt.size() > scan_index && nmark <= jf.rst_cnt[scan_index])) return 0;   // markers withheld: host
+        if (rst_cnt_set && nmark > 0 && !(jf.rst_cnt.size() > scan_index && nmark <= jf.rst_cnt[scan_index])) return 0;   // markers withheld: host
         plan->markers.push_back((uint32_t)nmark);
         const size_t geo = blocks * (dc ? 8 : 432) + nmark * 2 + units / 4 + 64;
-        sc.out_cap = (uint32_t)std::min<size_t>(std::min<size_t>((size_t)lf->jpeg_size + 16, geo), 0xfffffff0u);
+        sc.out_cap = (uint32_t)std::min<size_t>(std::min<size_t>(jpeg_size + 16, geo), 0xfffffff0u);
         sc.corr_cap = (!dc && sc.sah != 0) ? (uint32_t)std::min<size_t>(blocks * 2 + 8, 0x7fffffffu) : 0u;
         plan->scans.push_back(sc);
         if (plan->scans.size() > 256) return 0;

@@ -257,6 +257,7 @@ static int split_file(const uint8_t* d, size_t n, JpegFile* jf) {
         if (type == 0xDA) {
             unsigned cpos = 0, crst = 0;
             jf->scan_start.push_back((uint32_t)jf->scan.size());
+            jf->scan_file_range.emplace_back((uint32_t)pos, (uint32_t)pos);
             for (;;) {
                 jf->scan_to_file.emplace_back((uint32_t)jf->scan.size(), (uint32_t)pos);
                 if (!rd1(&tmp)) { jf->early_eof = true; have_hdr = true; break; }
@@ -280,6 +281,7 @@ static int split_file(const uint8_t* d, size_t n, JpegFile* jf) {
                     jf->rst_err.push_back((uint8_t)crst);
                     ++scnc;
                     seg[0] = 0xFF; seg[1] = tmp;
+                    jf->scan_file_range.back().second = (uint32_t)(pos - 2);
                     break;
                 }
             }

@@ -155,6 +155,25 @@ int lep_jpeg_finish_gpu_progressive(lep_jpeg* j, const lep_huffprogdec_scan* sca
     for (auto& sc : v) { sc.result_off -= rows0; sc.t.rows_off -= rows0; }
     return lep::parse_jpeg_finish_gpu_progressive(&j->jf, v, reinterpret_cast<const lep::ScanDecodeRow*>(rows) + rows0) ? LEP_UNSUPPORTED_JPEG : 0;
 }
+int lep_jpeg_plan_progressive_check(lep_jpeg* j, size_t jpeg_len, lep_huffprog_image* image, lep_huffprog_scan* scans, uint32_t* file_first,
+                                    uint32_t* file_len, int cap, int* nscan, int* eligible) {
+    *eligible = 0; *nscan = 0;
+    lep::ProgPlan plan;
+    // (rst_cnt as the parser counted it: a scan that holds fewer restart markers than its length asks for is not planned)
+    if (lep::progressive_plan(&j->jf, jpeg_len, true, &plan) || !plan.gpu_ok) return 0;
+    const size_t n = plan.scans.size();
+    if ((int)n > cap || n != j->jf.scan_file_range.size()) return 0;
+    for (size_t q = 0; q < n; ++q) {
+        const auto& r = j->jf.scan_file_range[q];
+        if (r.second <= r.first || r.second > jpeg_len) return 0;
+        file_first[q] = r.first; file_len[q] = r.second - r.first;
+    }
+    memcpy(image, &plan.image, sizeof *image);
+    memcpy(scans, plan.scans.data(), sizeof(lep_huffprog_scan) * n);
+    *nscan = (int)n;
+    *eligible = 1;
+    return 0;
+}
 int lep_jpeg_scan_bytes(const lep_jpeg* j, const uint8_t** data, size_t* len) {
     *data = j->jf.scan.data(); *len = j->jf.scan.size();
     return 0;

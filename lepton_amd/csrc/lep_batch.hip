@@ -75,6 +75,27 @@ __global__ void lep_compare_kernel(const uint4* __restrict__ a, const uint4* __r
     if (diff) atomicOr(flag, value);
 }
 
+// Round-trip check of progressive files: one workgroup per scan compares what the GPU scan encoder has just written
+// with the file's own bytes of that scan (uploaded beside the un-stuffed copy the decoder read); any difference -- the
+// length, a byte, an encoder that gave up (bit 31 of its length) -- sets bit 1 of the image's flag word.
+struct ScanCheck { uint64_t out_off, ref_off; uint32_t ref_len, image; };
+__global__ void lep_scan_check_kernel(const uint8_t* __restrict__ out, const uint32_t* __restrict__ out_len, const uint8_t* __restrict__ ref,
+                                      const ScanCheck* __restrict__ items, uint32_t* flags) {
+    const ScanCheck it = items[blockIdx.x];
+    bool diff = out_len[blockIdx.x] != it.ref_len;
+    if (!diff) {
+        const uint4* a = reinterpret_cast<const uint4*>(out + it.out_off);   // both 16-byte aligned
+        const uint4* b = reinterpret_cast<const uint4*>(ref + it.ref_off);
+        const uint32_t n16 = it.ref_len / 16;
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) {
+            const uint4 x = a[i], y = b[i];
+            diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+        }
+        for (uint32_t i = n16 * 16 + threadIdx.x; i < it.ref_len; i += blockDim.x) diff |= out[it.out_off + i] != ref[it.ref_off + i];
+    }
+    if (diff) atomicOr(flags + it.image, 2u);
+}
+
 // Hundreds of host threads each allocating and freeing MB-sized vectors (un-stuffed scan data, containers) serialise on
 // the process-wide mmap lock when glibc serves them with mmap/munmap; keep such blocks inside the per-thread arenas.
 void tune_malloc_for_pool() {
@@ -96,13 +117,14 @@ struct Slot {   // one chunk's buffers (double-buffered)
     uint8_t* h_pscan = nullptr; size_t hpscan_cap = 0;     // ... and the pinned mirror, packed by the bytes actually written
     uint32_t* d_corr = nullptr; size_t corr_cap = 0;       // held-back correction bits of the refinement scans (dwords)
     uint32_t* d_pscanlen = nullptr; size_t pscanlen_cap = 0;
+    ScanCheck* d_pcheck = nullptr; size_t pcheck_cap = 0;   // compression with verify: what lep_scan_check_kernel compares
     hipEvent_t up = nullptr, done = nullptr;
     void release() {
         if (h_frames) (void)hipHostFree(h_frames);
         if (h_streams) (void)hipHostFree(h_streams);
         if (h_scan) (void)hipHostFree(h_scan);
         if (h_pscan) (void)hipHostFree(h_pscan);
-        for (void* p : {(void*)d_pscan, (void*)d_corr, (void*)d_pscanlen, (void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags, (void*)d_scan, (void*)d_scanlen, (void*)d_rows})
+        for (void* p : {(void*)d_pscan, (void*)d_corr, (void*)d_pscanlen, (void*)d_pcheck, (void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags, (void*)d_scan, (void*)d_scanlen, (void*)d_rows})
             if (p) (void)hipFree(p);
         if (up) (void)hipEventDestroy(up);
         if (done) (void)hipEventDestroy(done);
@@ -224,6 +246,12 @@ int prog_reserve(Slot* s, size_t scan_bytes, size_t corr_words, size_t nscan) {
         HIPOK(hipMalloc((void**)&s->d_pscanlen, nscan * 4));
         s->pscanlen_cap = nscan;
     }
+    if (nscan > s->pcheck_cap) {
+        if (s->d_pcheck) (void)hipFree(s->d_pcheck);
+        s->d_pcheck = nullptr; s->pcheck_cap = 0;
+        HIPOK(hipMalloc((void**)&s->d_pcheck, nscan * sizeof(ScanCheck)));
+        s->pcheck_cap = nscan;
+    }
     g_alloc_s += now_s() - t0;
     return 0;
 }
@@ -272,6 +300,7 @@ struct Chunk {
     std::vector<lep_huffprog_scan> pscan;
     std::vector<int> pfirst, pcount;       // per live image: first entry of pscan / number of scans, -1 = not on this path
     size_t pscan_bytes = 0, corr_words = 0;
+    std::vector<ScanCheck> pcheck;         // compression with verify: per pscan entry, the file's own bytes of that scan
 };
 
 Slot g_slots[2];         // one batch call at a time (the calls are not re-entrant)
@@ -393,12 +422,15 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         std::vector<lep_huffdec_image> himg(nl);
         std::vector<char> on_gpu(nl, 0);
         std::vector<char> need_host(nl, gpu_huffman ? 0 : 1);
-        // progressive files: their scans go to the GPU scan decoder too (lep_huffprogdec.h) -- unless the caller wants the
-        // round trip verified: the Huffman half of that check needs the host parser's frame for files a canonical encoder
-        // might not reproduce, and the sequential kernel's "canonical by construction" argument has not been made for them
+        // progressive files: their scans go to the GPU scan decoder too (lep_huffprogdec.h).  When the caller wants the round
+        // trip verified, the Huffman half of that check is made on the GPU as well: every scan of the frame is written again
+        // (lep_huffprog.h, the decompressor's kernel) and compared with the file's own bytes (no "canonical by construction"
+        // argument is made for these scans, unlike the sequential kernel's)
         std::vector<std::vector<lep_huffprogdec_scan>> pscans(nl);
         std::vector<int> prow_need(nl, 0);
         std::vector<char> on_prog(nl, 0);
+        struct ProgCheck { lep_huffprog_image img; std::vector<lep_huffprog_scan> scans; std::vector<uint32_t> first, len; };
+        std::vector<ProgCheck> pchk(verify ? nl : 0);
         if (gpu_huffman)
             parallel_for(nl, threads, [&](int k) {
                 const int i = c->live[k];
@@ -406,10 +438,18 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 int rc = lep_jpeg_open_gpu(jpgs[i].data, jpgs[i].len, &parsed[i], &himg[k], &ok);
                 if (rc) { status[i] = rc; return; }      // not a JPEG the reference would take either
                 if (ok) { on_gpu[k] = 1; return; }
-                if (!verify) {
+                {
                     pscans[k].resize(64);
                     int ns = 0, okp = 0;
-                    if (!lep_jpeg_open_gpu_progressive(parsed[i], pscans[k].data(), 64, &ns, &prow_need[k], &okp) && okp) { pscans[k].resize((size_t)ns); on_prog[k] = 1; return; }
+                    if (!lep_jpeg_open_gpu_progressive(parsed[i], pscans[k].data(), 64, &ns, &prow_need[k], &okp) && okp) {
+                        pscans[k].resize((size_t)ns);
+                        if (!verify) { on_prog[k] = 1; return; }
+                        ProgCheck& pc = pchk[k];
+                        pc.scans.resize((size_t)ns); pc.first.resize((size_t)ns); pc.len.resize((size_t)ns);
+                        int nc = 0, okc = 0;
+                        if (!lep_jpeg_plan_progressive_check(parsed[i], jpgs[i].len, &pc.img, pc.scans.data(), pc.first.data(), pc.len.data(), ns, &nc, &okc) &&
+                            okc && nc == ns) { on_prog[k] = 1; return; }
+                    }
                     pscans[k].clear();
                 }
                 need_host[k] = 1;
@@ -436,6 +476,10 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             row_off[k] = rows_total; rows_total += (size_t)prow_need[k];
             ++nprog;
         }
+        std::vector<std::vector<size_t>> praw_off(nl);   // ... and, for the round-trip check, as it stands in the file
+        if (verify)
+            for (int k = 0; k < nl; ++k) if (on_prog[k])
+                for (uint32_t n : pchk[k].len) { praw_off[k].push_back(scan_total); scan_total += ((size_t)n + 15) & ~(size_t)15; }
         ngpu += nprog;
         std::vector<lep_huffdec_row> rows(rows_total);
         if (ngpu) {
@@ -458,6 +502,8 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                         memcpy(s->h_scan + pscan_off[k][q], p + off, n);
                         memset(s->h_scan + pscan_off[k][q] + n, 0, room - n);
                     }
+                    for (size_t q = 0; q < praw_off[k].size(); ++q)
+                        memcpy(s->h_scan + praw_off[k][q], jpgs[c->live[k]].data + pchk[k].first[q], pchk[k].len[q]);
                     return;
                 }
                 memcpy(s->h_scan + scan_off[k], p, len);
@@ -571,12 +617,15 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 st.h2d_bytes += (double)fb;
             }
         }
+        for (int k = 0; k < nl; ++k) if ((on_gpu[k] || on_prog[k]) && parsed[c->live[k]]) st.gpu_huffman_files += 1;
         // drop failed images from the chunk
         Chunk keep;
+        std::vector<int> old_k;
         for (int k = 0; k < nl; ++k) {
             const int i = c->live[k];
             if (!parsed[i]) continue;
             keep.live.push_back(i); keep.frame_off.push_back(c->frame_off[k]); keep.host_desc.push_back(c->host_desc[k]);
+            old_k.push_back(k);
         }
         c->live.swap(keep.live); c->frame_off.swap(keep.frame_off); c->host_desc.swap(keep.host_desc);
         c->segs.clear(); c->offs.assign(1, 0); c->seg_first.clear();
@@ -610,6 +659,32 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 off += (size_t)c->host_desc[k].width_blocks[cc] * c->host_desc[k].height_blocks[cc] * 128;
             }
         }
+        // round-trip check of the progressive files the GPU decoded: their scans written again from the device frame
+        c->pimg.clear(); c->pscan.clear(); c->pcheck.clear(); c->pscan_bytes = 0; c->corr_words = 0;
+        if (verify)
+            for (size_t nk = 0; nk < c->live.size(); ++nk) {
+                const int k = old_k[nk];
+                if (!on_prog[k]) continue;
+                lep_huffprog_image pi = pchk[k].img;
+                for (int cc = 0; cc < 4; ++cc) pi.blocks[cc] = cc < c->dev_desc[nk].ncomp ? c->dev_desc[nk].blocks[cc] : nullptr;
+                for (size_t q = 0; q < pchk[k].scans.size(); ++q) {
+                    lep_huffprog_scan sc = pchk[k].scans[q];
+                    sc.image = (int32_t)c->pimg.size();
+                    sc.out_cap = (uint32_t)std::min<size_t>(sc.out_cap, (size_t)pchk[k].len[q] + 64);   // anything longer is a mismatch anyway
+                    sc.out_off = c->pscan_bytes;
+                    c->pscan_bytes += ((size_t)sc.out_cap + 15) & ~(size_t)15;
+                    sc.corr_off = (uint32_t)c->corr_words;
+                    c->corr_words += sc.corr_cap;
+                    c->pscan.push_back(sc);
+                    c->pcheck.push_back(ScanCheck{sc.out_off, (uint64_t)praw_off[k][q], pchk[k].len[q], (uint32_t)nk});
+                }
+                c->pimg.push_back(pi);
+            }
+        if (!c->pscan.empty()) {
+            if (c->corr_words > 0xfffffff0u) return LEP_GPU_ERROR;
+            if (int rc = prog_reserve(s, c->pscan_bytes + 256, c->corr_words + 16, c->pscan.size())) return rc;
+            HIPOK(hipMemcpyAsync(s->d_pcheck, c->pcheck.data(), c->pcheck.size() * sizeof(ScanCheck), hipMemcpyHostToDevice, s_copy));
+        }
         HIPOK(hipEventRecord(s->up, s_copy));
         return 0;
     };
@@ -635,6 +710,13 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 const size_t fb = frame_exact_bytes(c->host_desc[k]);   // the frame itself, not its rounded room in the slot
                 hipLaunchKernelGGL(lep_compare_kernel, dim3(256), dim3(256), 0, s_compute, (const uint4*)(s->d_frames + c->frame_off[k]),
                                    (const uint4*)(s->d_scratch + c->frame_off[k]), fb / 16, s->d_flags + k, 1u);
+            }
+            if (!c->pscan.empty()) {   // progressive files: the Huffman half, scan by scan against the file's bytes
+                rc = lep_gpu_huffman_progressive_encode_device(g, c->pimg.data(), (int)c->pimg.size(), c->pscan.data(), (int)c->pscan.size(), s->d_pscan,
+                                                               s->d_corr, s->d_pscanlen, s_compute);
+                if (rc) return rc;
+                hipLaunchKernelGGL(lep_scan_check_kernel, dim3((unsigned)c->pscan.size()), dim3(256), 0, s_compute, s->d_pscan, s->d_pscanlen, s->d_scan,
+                                   s->d_pcheck, s->d_flags);
             }
         }
         HIPOK(hipEventRecord(s->done, s_compute));
@@ -700,7 +782,10 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 }
                 if (!rc && verify) {
                     for (int q = s0; q < s1; ++q) if (sts[c->segs.size() + (size_t)q]) rc = LEP_ROUNDTRIP_FAILURE;
-                    if (flags[k]) rc = LEP_ROUNDTRIP_FAILURE;
+                    if (flags[k] & 1) rc = LEP_ROUNDTRIP_FAILURE;
+                    // a progressive scan the GPU encoder did not reproduce (trailing restart markers, which the host appends; a
+                    // non-canonical code choice): the per-file path decides (last loop of this function)
+                    else if (!rc && (flags[k] & 2)) rc = LEP_BUFFER_TOO_SMALL;
                 }
                 if (!rc) rc = lep_jpeg_write_lep(parsed[i], 0, strs, s1 - s0, &outs[i]);
                 // the Huffman half of the reference's round-trip check for the files whose scans the host parser took (their
@@ -896,7 +981,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         }
         // files the host re-coder handles read their frame where the D2H copy puts it: the slot's pinned buffer
         bool any_host = false;
-        for (size_t k = 0; k < c->live.size(); ++k) any_host |= c->hfirst[k] < 0 && c->pfirst[k] < 0;
+        for (size_t k = 0; k < c->live.size(); ++k) { any_host |= c->hfirst[k] < 0 && c->pfirst[k] < 0; if (c->hfirst[k] >= 0 || c->pfirst[k] >= 0) st.gpu_huffman_files += 1; }
         if (any_host) {
             if (int rc = host_frames_reserve(s, c->frame_bytes)) return rc;
             for (size_t k = 0; k < c->live.size(); ++k)

@@ -104,6 +104,7 @@ struct ProgPlan {
     std::vector<uint32_t> markers;        // restart markers each scan writes itself
 };
 int recode_progressive_prepare(LepFile* lf, ProgPlan* plan);
+int progressive_plan(JpegFile* jf, size_t jpeg_size, bool rst_cnt_set, ProgPlan* plan);
 int recode_progressive_finish(LepFile* lf, const ProgPlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& scan_bytes,
                               std::vector<uint8_t>* out);
 int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& seg_bytes,

@@ -249,7 +249,9 @@ struct lep_gpu {
     void* d_streams = nullptr; size_t streams_bytes = 0;
     void* d_lens = nullptr; size_t lens_bytes = 0;
     void* d_huff = nullptr; size_t huff_bytes = 0;      // HuffImage[] | HuffSegment[]
-    void* d_huffprog = nullptr; size_t huffprog_bytes = 0;   // ProgImage[] | ProgScan[]
+    void* d_huffprog[2] = {nullptr, nullptr}; size_t huffprog_bytes[2] = {0, 0};   // ProgImage[] | ProgScan[], one per arena set (two launches on two streams)
+    void* h_huffprog[2] = {nullptr, nullptr}; size_t h_huffprog_bytes[2] = {0, 0};   // pinned staging of the same: the upload does not wait for the stream
+    int huffprog_turn = 0;   // the two sets are used in turn: at most two launches are ever in flight (lep_batch.hip queues chunk k+1 before it fetches chunk k)
     void* d_huffprogdec = nullptr; size_t huffprogdec_bytes = 0;   // ProgDecScan[]
     void* d_huffdec = nullptr; size_t huffdec_bytes = 0;   // HuffDecImage[]
     void* d_huffpar = nullptr; size_t huffpar_bytes = 0;   // HuffParState[nimg][nsub] | int status[nimg] (parallel Huffman decode)
@@ -422,11 +424,12 @@ static void release_device_side(lep_gpu* g) {
     g->released = true;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffprog, g->d_huffprogdec, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
+    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffprog[0], g->d_huffprog[1], g->d_huffprogdec, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
         if (p) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);
+    for (void* p : {g->h_huffprog[0], g->h_huffprog[1]}) if (p) (void)hipHostFree(p);
 }
 
 void lep_gpu_destroy(lep_gpu* g) {
@@ -522,13 +525,24 @@ int lep_gpu_huffman_progressive_encode_device(lep_gpu* g, const lep_huffprog_ima
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
     HIPCHK(g, hipSetDevice(g->device));
     const size_t o_scan = (nimg * sizeof(lep_huffprog_image) + 255) & ~(size_t)255, total = o_scan + nscan * sizeof(lep_huffprog_scan);
-    if (int rc = ensure(g, &g->d_huffprog, &g->huffprog_bytes, total)) return rc;
-    HIPCHK(g, hipMemcpyAsync(g->d_huffprog, images, nimg * sizeof(lep_huffprog_image), hipMemcpyHostToDevice, st));
-    HIPCHK(g, hipMemcpyAsync((char*)g->d_huffprog + o_scan, scans, nscan * sizeof(lep_huffprog_scan), hipMemcpyHostToDevice, st));
-    HIPCHK(g, hipStreamSynchronize(st));   // the caller's arrays may go away
+    const int turn = (g->huffprog_turn ^= 1);
+    if (int rc = ensure(g, &g->d_huffprog[turn], &g->huffprog_bytes[turn], total)) return rc;
+    char* const d_desc = (char*)g->d_huffprog[turn];
+    // descriptors through a pinned copy of this set (its previous user, two launches ago, has been waited for by then): the
+    // caller's arrays may go away, and nothing here waits for the kernels already queued on the stream
+    if (g->h_huffprog_bytes[turn] < total) {
+        if (g->h_huffprog[turn]) HIPCHK(g, hipHostFree(g->h_huffprog[turn]));
+        g->h_huffprog[turn] = nullptr; g->h_huffprog_bytes[turn] = 0;
+        HIPCHK(g, hipHostMalloc(&g->h_huffprog[turn], total + total / 8, hipHostMallocDefault));
+        g->h_huffprog_bytes[turn] = total + total / 8;
+    }
+    char* const h_desc = (char*)g->h_huffprog[turn];
+    memcpy(h_desc, images, nimg * sizeof(lep_huffprog_image));
+    memcpy(h_desc + o_scan, scans, nscan * sizeof(lep_huffprog_scan));
+    HIPCHK(g, hipMemcpyAsync(d_desc, h_desc, total, hipMemcpyHostToDevice, st));
     HIPCHK(g, hipEventRecord(g->ev0, st));
-    hipLaunchKernelGGL(lep_huffman_progressive_encode_kernel, dim3(nscan), dim3(64), 0, st, (const lephuff::ProgImage*)g->d_huffprog,
-                       (const lephuff::ProgScan*)((char*)g->d_huffprog + o_scan), d_out, d_corr, d_out_len);
+    hipLaunchKernelGGL(lep_huffman_progressive_encode_kernel, dim3(nscan), dim3(64), 0, st, (const lephuff::ProgImage*)d_desc,
+                       (const lephuff::ProgScan*)(d_desc + o_scan), d_out, d_corr, d_out_len);
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;

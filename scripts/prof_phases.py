@@ -12,12 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "lepton_amd", "csrc")
 PROF_LIB = os.path.join(ROOT, "lepton_amd", "liblepton_mi355x_prof.so")
-SOURCES = ["lep_gpu.hip", "lep_batch.hip", "lep_api.cc", "jpeg_scan.cc", "jpeg_progressive.cc", "lep_container.cc", "jpeg_recode.cc"]
+SOURCES = ["lep_gpu.hip", "lep_batch.hip", "lep_api.cc", "jpeg_scan.cc", "jpeg_progressive.cc", "lep_container.cc", "jpeg_recode.cc", "lep_serve.cc"]
 
 
 def build():
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLEP_PROF", "-o", PROF_LIB]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-lz"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-ldl", "-lpthread"]
     subprocess.check_call(cmd, cwd=ROOT)
 
 

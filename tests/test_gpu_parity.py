@@ -408,7 +408,7 @@ def test_gpu_progressive_scans_are_recoded_on_the_gpu(gpu_codec):
 def test_gpu_progressive_scans_are_decoded_on_the_gpu(gpu_codec):
     """encode direction of progressive files: lep_huffprogdec.h (one wavefront per scan, dependency levels) + the arithmetic
     coder; the .lep files equal the reference's byte for byte, truncated progressive files still take the host parser, and
-    only scan bytes cross PCIe for the eligible ones.  With verify the host parser keeps these files (see lep_batch.hip)."""
+    only scan bytes cross PCIe for the eligible ones -- with and without the round-trip check."""
     names = [n for n in golden_cases() if n.startswith("prog_")]
     jpgs = [golden(n)[0] for n in names]
     leps = [golden(n)[1] for n in names]
@@ -420,8 +420,14 @@ def test_gpu_progressive_scans_are_decoded_on_the_gpu(gpu_codec):
     assert got[: len(names)] == leps and got[len(names): len(names) + 4] == want_big and got[-1] == golden("c420_160x120")[1]
     _, st2, stats2 = gpu_codec.compress_batch(big)
     assert st2 == [0] * 4 and stats2["h2d_bytes"] < 1.3 * sum(map(len, big)) + 65536     # frames (6.2 MB for the 1080p one alone) never crossed
-    got3, st3, _ = gpu_codec.compress_batch(big, verify=True)
+    # with verify the scans still go to the GPU decoder, and the Huffman half of the round-trip check is made there as well:
+    # every scan written again from the device frame (lep_huffprog.h) and compared with the file's own bytes
+    got3, st3, stats3 = gpu_codec.compress_batch(big, verify=True)
     assert st3 == [0] * 4 and got3 == want_big
+    assert stats3["gpu_huffman_files"] == 4 and stats3["redone_files"] == 0
+    assert stats3["h2d_bytes"] < 2.3 * sum(map(len, big)) + 65536     # un-stuffed scans + the file's own scan bytes; still no frame
+    got3b, st3b, stats3b = gpu_codec.compress_batch(jpgs + big, verify=True, chunk_images=5)
+    assert st3b == [0] * (len(names) + 4) and got3b == leps + want_big
     # a progressive file damaged inside a scan: whatever the GPU decoder makes of it, the answer is the host parser's
     bad = bytearray(big[2]); bad[len(bad) // 2] ^= 0x10
     try:
