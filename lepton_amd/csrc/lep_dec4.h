@@ -104,6 +104,17 @@ WDEV uint32_t mul24(uint32_t a, uint32_t b) {
     return (uint32_t)(((uint64_t)(a & 0xffffff) * (b & 0xffffff)) & 0xffffffffu);
 #endif
 }
+// the same where only bits below 24 of the product are wanted: the optimiser then drops the 24-bit masks and emits a full
+// v_mul_lo_u32 (quarter rate on CDNA) -- keep the instruction opaque
+WDEV uint32_t mul24_low(uint32_t a, uint32_t b) {
+#if LEP_ON_GPU
+    uint32_t r;
+    __asm__("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return mul24(a, b);
+#endif
+}
 // Branch::record_obs_and_update (branch.hh:82-100) on the packed word, per lane: straight-line common case (table
 // reciprocal), one divergent branch for the count-overflow case (once per ~250 observations of a Branch)
 WDEV uint32_t bupd_t(uint32_t w, uint32_t obs, const uint32_t* inv24) {
@@ -119,16 +130,18 @@ WDEV uint32_t bupd_t(uint32_t w, uint32_t obs, const uint32_t* inv24) {
     }
     return nw;
 }
-// the same for a uniform-vector word and observation; the rare path is taken on a ballot
+// the same for a uniform-vector word and observation (0 / 1): the count is bumped by adding 1 or 256 to the packed word,
+// a wrapped count shows up as a zero count byte and takes the exact rule on a ballot (once per ~250 observations)
 WDEV uint32_t bupd_u(uint32_t w, uint32_t obs, const uint32_t* inv24) {
-    const uint32_t f = (w & 255) + (obs ^ 1), t = ((w >> 8) & 255) + obs;
-    if (ucond((f | t) > 255)) {
+    const uint32_t w2 = w + 1u + obs * 255u;
+    const uint32_t f = w2 & 255u, t = (w2 >> 8) & 255u;
+    if (ucond((f < t ? f : t) == 0)) {   // the incremented count was 255
         const uint32_t f0 = w & 255, t0 = (w >> 8) & 255;
         if (ucond((obs ? f0 : t0) == 1)) return (w & 0xffff) | ((obs ? 0u : 255u) << 16);
         const uint32_t f2 = obs ? (1 + f0) >> 1 : 129u, t2 = obs ? 129u : (1 + t0) >> 1;
         return f2 | (t2 << 8) | ((mul24(f2 << 8, inv24[f2 + t2]) >> 24) << 16);
     }
-    return f | (t << 8) | ((mul24(f << 8, inv24[f + t]) >> 24) << 16);
+    return (w2 & 0xffffu) | (mul24_low(f, inv24[f + t]) & 0xff0000u);
 }
 
 // ---- bool decoder (boolreader.hh:184-258, 376-416; boolreader.cc:25-34) as uniform vector code ----------------------
@@ -189,6 +202,55 @@ struct BoolDec4 {
         return bit;
     }
 };
+
+// The same reader with its state on the SCALAR unit (wave-uniform values the compiler keeps in SGPRs).  Why both exist:
+// at 8 wavefronts per SIMD the coder kernels are bound by VALU issue (one wave-instruction per ~1.2 cycles per CU,
+// scripts/proto/inst_rates.hip, profiles/r02l_inst_rates.txt) while the scalar unit, which issues beside it from other
+// wavefronts at about the same rate, sat half idle (3400 VALU against 1500 SALU instructions per block).  A serial round
+// coded in this form takes its ~16 instructions per bin off the vector ALUs; the rounds are split between the two forms
+// (LEP_DEC4_SCALAR) so that both units are busy.  The state crosses over with four v_readfirstlane / v_mov per switch;
+// the stream words keep arriving through the vector cache (BoolDec4::raw, one request ahead).
+struct BoolDec4S {
+    uint32_t vhi, vlo;
+    int count;
+    uint32_t range;
+    WDEV void load(const BoolDec4& b) { vhi = uni(b.vhi); vlo = uni(b.vlo); count = (int)uni((uint32_t)b.count); range = uni(b.range); }
+    WDEV void store(BoolDec4& b) const { b.vhi = vec(vhi); b.vlo = vec(vlo); b.count = (int)vec((uint32_t)count); b.range = vec(range); }
+    WDEV void refill(BoolDec4& b) {
+        const uint32_t lo = b.wi * 4;
+        uint32_t w = __builtin_bswap32(uni(b.raw));
+        int nbits = 32;
+        if (lo + 4 > b.end) w = lo < b.end ? (w & ~(0xffffffffu >> ((b.end - lo) * 8))) : 0u;
+        if (lo < b.first) { w <<= (b.first - lo) * 8; nbits -= (int)(b.first - lo) * 8; }
+        const uint64_t add = ((uint64_t)w << 32) >> (count + 8);
+        vhi |= (uint32_t)(add >> 32); vlo |= (uint32_t)add;
+        count += nbits;
+        ++b.wi;
+        b.raw = b.fetch(b.wi);
+    }
+    WDEV uint32_t get(BoolDec4& b, uint32_t prob) {
+        const uint32_t split = 1 + (((range - 1) * prob) >> 8);
+        if (count < 0) refill(b);
+        const uint32_t big = split << 24;
+        const uint32_t bit = vhi >= big ? 1u : 0u;
+        vhi = bit ? vhi - big : vhi;
+        range = bit ? range - split : split;
+#ifdef LEP_TRACE_GET
+        LEP_TRACE_GET(prob, (int)bit);
+#endif
+        const int shift = __builtin_clz(range) - 24;
+        range <<= shift;
+        const uint64_t v = (((uint64_t)vhi << 32) | vlo) << shift;
+        vhi = (uint32_t)(v >> 32); vlo = (uint32_t)v;
+        count -= shift;
+        return bit;
+    }
+};
+
+// which serial rounds run on the scalar unit: 1 = non-zero count tree, 2 = 7x7 interior, 4 = edges, 8 = DC
+#ifndef LEP_DEC4_SCALAR
+#define LEP_DEC4_SCALAR 2   // measured (1024 x 4K, MI355X, profiles/r02m_*): 0: 1232 ms, 2: 1204, 3: 1212, 11: 1226, 7: 1400, 15: 1440
+#endif
 
 struct Dec4Wave {
     const ImageDev* img;
@@ -253,18 +315,84 @@ struct Dec4Wave {
         LSYNC();
     }
 
-    // ---- serial helpers (uniform vector code) ------------------------------------------------------------------------
-    WDEV uint32_t dec_global(uint32_t idx) {   // a Branch outside the prefetched set: coded straight from HBM
-        const uint32_t w = vload(model + idx);
-        const uint32_t bit = bc.get(w >> 16);
-        const uint32_t nw = bupd_u(w, bit, sh->inv24);
+    // ---- the serial code of a round, in either form -----------------------------------------------------------------------
+    // SC = false: uniform vector code on bc; SC = true: the state is taken over into SGPRs for the round and handed back by
+    // done().  Values a round passes in (packed probabilities read from a lane, Branch words) go through U().
+    template <bool SC>
+    struct Serial {
+        Dec4Wave& w;
+        BoolDec4S s;
+        WDEV explicit Serial(Dec4Wave& w_) : w(w_) { if (SC) s.load(w.bc); }
+        WDEV void done() { if (SC) s.store(w.bc); }
+        static WDEV uint32_t U(uint32_t x) { return SC ? uni(x) : vec(x); }
+        static WDEV bool is(bool c) { return SC ? c : ucond(c); }
+        WDEV uint32_t get(uint32_t prob) { return SC ? s.get(w.bc, prob) : w.bc.get(prob); }
+        WDEV uint32_t bupd(uint32_t word, uint32_t obs) {
+            if (!SC) return bupd_u(word, obs, w.sh->inv24);
+            const uint32_t w2 = word + 1u + obs * 255u;
+            const uint32_t f = w2 & 255u, t = (w2 >> 8) & 255u;
+            if ((f < t ? f : t) == 0) {   // the incremented count was 255
+                const uint32_t f0 = word & 255, t0 = (word >> 8) & 255;
+                if ((obs ? f0 : t0) == 1) return (word & 0xffff) | ((obs ? 0u : 255u) << 16);
+                const uint32_t f2 = obs ? (1 + f0) >> 1 : 129u, t2 = obs ? 129u : (1 + t0) >> 1;
+                return f2 | (t2 << 8) | ((((f2 << 8) * uni(w.sh->inv24[f2 + t2])) >> 24) << 16);
+            }
+            return (w2 & 0xffffu) | ((f * uni(w.sh->inv24[f + t])) & 0xff0000u);
+        }
+        WDEV uint32_t global_bin(uint32_t idx) {   // a Branch outside the prefetched set: coded straight from HBM
+            const uint32_t word = U(vload(w.model + idx));
+            const uint32_t bit = get(word >> 16);
+            const uint32_t nw = bupd(word, bit);
 #if LEP_ON_GPU
-        if (threadIdx.x == 0) model[idx] = nw;
+            if (threadIdx.x == 0) w.model[idx] = nw;
 #else
-        model[idx] = nw;
+            w.model[idx] = nw;
 #endif
-        return bit;
-    }
+            return bit;
+        }
+        // unary bins k.. of one packed exponent group (k = first bin to decode); returns the number of ones from bin 0 (<= 4)
+        template <int K>
+        WDEV int unary_from(uint32_t pk) {
+            if (K <= 0) { if (!is(get(pk & 255) != 0)) return 0; }
+            if (K <= 1) { if (!is(get((pk >> 8) & 255) != 0)) return 1; }
+            if (K <= 2) { if (!is(get((pk >> 16) & 255) != 0)) return 2; }
+            if (!is(get(pk >> 24) != 0)) return 3;
+            return 4;
+        }
+        WDEV int unary_tail(uint32_t gbase) {   // exponent bins 8..10 straight from HBM (|v| >= 128: rare)
+            int i = 8;
+#pragma nounroll
+            for (; i < 11; ++i) if (!is(global_bin(row_word(gbase, i)) != 0)) break;
+            return i;
+        }
+        // residual bits b..0 (b <= 3) of |v| from the packed probabilities of the residual group (word i = bit i)
+        WDEV uint32_t residual(uint32_t pk, int b, uint32_t v) {
+            if (b >= 3) v |= get(pk >> 24) << 3;
+            if (b >= 2) v |= get((pk >> 16) & 255) << 2;
+            if (b >= 1) v |= get((pk >> 8) & 255) << 1;
+            if (b >= 0) v |= get(pk & 255);
+            return v;
+        }
+        // a LEVELS-level binary tree decoded MSB first; the d-th decoded level has 2^d nodes stored as whole groups owned
+        // by lanes base + first(d) .., first = 0,1,2,3,5,9 (1,1,1,2,4,8 groups per level); levels 0..2 read fixed lanes
+        template <int LEVELS>
+        WDEV int tree(const uint32_t* PK, int base) {
+            uint32_t pk = U(lepwave::wave_read(PK, base));
+            uint32_t n = get(pk & 255);
+            pk = U(lepwave::wave_read(PK, base + 1));
+            n = (n << 1) | get((pk >> (n * 8)) & 255);
+            pk = U(lepwave::wave_read(PK, base + 2));
+            n = (n << 1) | get((pk >> (n * 8)) & 255);
+#pragma unroll
+            for (int d = 3; d < LEVELS; ++d) {
+                pk = U(lepwave::wave_read(PK, base + (1 << (d - 2)) + 1 + (int)uni(n >> 2)));
+                n = (n << 1) | get((pk >> ((n & 3) * 8)) & 255);
+            }
+            return (int)uni(n);
+        }
+    };
+
+    // ---- loads of wave-uniform addresses through the vector cache ----------------------------------------------------------
     static WDEV U4 vload4(const uint32_t* p) {   // every lane loads the same group through the vector cache
 #if LEP_ON_GPU
         uintptr_t a = (uintptr_t)p;
@@ -283,47 +411,6 @@ struct Dec4Wave {
         return *p;
 #endif
     }
-    // up to four unary bins from the packed probabilities of one exponent group; returns the number of ones (0..4).
-    // Fully unrolled with the probabilities extracted on the vector ALU: a SALU instruction costs about two VALU ones on
-    // this chip (profiles/r01_issue_microbench.txt), and the rolled loop spent 7 of them per bin on loop control.
-    WDEV int dec_unary4(uint32_t pk) {
-        const uint32_t pkv = vec(pk);
-        if (!ucond(bc.get(pkv & 255) != 0)) return 0;
-        if (!ucond(bc.get((pkv >> 8) & 255) != 0)) return 1;
-        if (!ucond(bc.get((pkv >> 16) & 255) != 0)) return 2;
-        if (!ucond(bc.get(pkv >> 24) != 0)) return 3;
-        return 4;
-    }
-    WDEV int dec_unary_tail(uint32_t gbase) {   // exponent bins 8..10 straight from HBM (|v| >= 128: rare)
-        int i = 8;
-#pragma nounroll
-        for (; i < 11; ++i) if (!ucond(dec_global(row_word(gbase, i)) != 0)) break;
-        return i;
-    }
-    // residual bits b..0 (b <= 3) of |v| from the packed probabilities of the residual group (word i = bit i); unrolled, the
-    // probabilities extracted on the vector ALU
-    WDEV uint32_t dec_residual(uint32_t pk, int b, uint32_t v) {
-        const uint32_t pkv = vec(pk);
-        if (b >= 3) v |= bc.get(pkv >> 24) << 3;
-        if (b >= 2) v |= bc.get((pkv >> 16) & 255) << 2;
-        if (b >= 1) v |= bc.get((pkv >> 8) & 255) << 1;
-        if (b >= 0) v |= bc.get(pkv & 255);
-        return v;
-    }
-    // a `levels`-level binary tree decoded MSB first; the d-th decoded level has 2^d nodes stored as whole groups owned
-    // by lanes base + first(d) .., first = 0,1,2,3,5,9 (1,1,1,2,4,8 groups per level)
-    WDEV int dec_tree(int levels, const uint32_t* PK, int base) {
-        int n = 0;
-#pragma nounroll
-        for (int d = 0; d < levels; ++d) {
-            const int g = d < 3 ? d : (1 << (d - 2)) + 1;
-            const uint32_t pk = lepwave::wave_read(PK, base + g + (n >> 2));
-            n = (n << 1) | (int)uni(bc.get((pk >> ((n & 3) * 8)) & 255));
-        }
-        LEP_BINS(nbins += (uint32_t)levels);
-        return n;
-    }
-
     // integer IDCT without DC (idct.cc:35-161), 8 lanes per pass
     WDEV void idct_rows() {
         constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
@@ -391,15 +478,34 @@ struct Dec4Wave {
         used = (prefix >> 2) == k ? 1 << (prefix & 3) : 0;
         bits = ((value >> i) & 1) ? used : 0;
     }
-    // owners adapt the used words of one group register: (used, bits) masks per lane (0 = lane not involved); a word slot
-    // that no lane needs is skipped on a ballot, the others are one straight-line bupd_t under the lanes' exec mask
+    // owners adapt the used words of one group register: (used, bits) masks per lane (0 = lane not involved).
+    // Per word slot the common case is STRAIGHT-LINE code for all 64 lanes, no exec masking: the count is bumped by adding
+    // 0 / 1 / 256 to the packed word, the probability recomputed through the reciprocal table and blended in only where the
+    // slot is used (15 VALU + 1 LDS read, no scalar instruction -- the branchy form cost 20 VALU + 8 SALU per used slot, and a
+    // SALU instruction is worth two VALU ones here).  A count that wraps (once per ~250 observations of a Branch) shows up
+    // as a zero count byte; those lanes redo the word with the exact rule (bupd_t) under one ballot branch.
+    // ALWAYS: bit k set = slot k is used by some lane in nearly every call, do not spend a ballot on skipping it.
+    template <int ALWAYS>
     WDEV void adapt_group(U4* W, const int* used, const int* bits) {
         const uint32_t* inv = sh->inv24;
-        LV(int, any);
+        LV(int, any); LV(uint32_t, oldw); LV(uint32_t, low);
 #define LEP_SLOT(k, fld)                                                                                              \
-        LANES(l) L(any) = (L(used) >> k) & 1;                                                                        \
-        if (lepwave::wave_ballot(any)) {                                                                              \
-            LANES(l) if ((L(used) >> k) & 1) L(W).fld = bupd_t(L(W).fld, (uint32_t)(L(bits) >> k) & 1u, inv);        \
+        if (!((ALWAYS >> k) & 1)) { LANES(l) L(any) = (L(used) >> k) & 1; }                                           \
+        if (((ALWAYS >> k) & 1) || lepwave::wave_ballot(any)) {                                                       \
+            LANES(l) {                                                                                                \
+                const uint32_t w = L(W).fld;                                                                          \
+                const uint32_t u1 = ((uint32_t)(L(used) & L(bits)) >> k) & 1u, u0 = ((uint32_t)(L(used) & ~L(bits)) >> k) & 1u;   \
+                const uint32_t w2 = w + (u0 | (u1 << 8));                                                             \
+                const uint32_t f = w2 & 255u, t = (w2 >> 8) & 255u;                                                   \
+                const uint32_t p = mul24_low(f, inv[f + t]);   /* f * 2^24 / (f + t): the probability is bits 16..23 */ \
+                const uint32_t m = mul24(u0 | u1, 0xff0000u);                                                         \
+                L(oldw) = w; L(low) = (f < t ? f : t) + ((u0 | u1) ^ 1u);   /* 0 iff a bumped count wrapped */ \
+                L(W).fld = (p & m) | (w2 & ~m);                                                                       \
+            }                                                                                                         \
+            LANES(l) L(any) = L(low) == 0;                                                                            \
+            if (lepwave::wave_ballot(any)) {                                                                          \
+                LANES(l) if (L(low) == 0) L(W).fld = bupd_t(L(oldw), (uint32_t)(L(bits) >> k) & 1u, inv);             \
+            }                                                                                                         \
         }
         LEP_SLOT(0, x) LEP_SLOT(1, y) LEP_SLOT(2, z) LEP_SLOT(3, w)
 #undef LEP_SLOT
@@ -420,7 +526,13 @@ struct Dec4Wave {
             L(a0) = adr; L(PK0) = pk;
         }
         LEP_MARK("nz_serial");
-        const int nz = dec_tree(6, PK0, 0);
+        int nz;
+        {
+            Serial<(LEP_DEC4_SCALAR & 1) != 0> sr(*this);
+            nz = sr.template tree<6>(PK0, 0);
+            sr.done();
+            LEP_BINS(nbins += 6);
+        }
         LEP_MARK("nz_update");
         LV(int, u0); LV(int, b0);
         LANES(l) {
@@ -432,7 +544,7 @@ struct Dec4Wave {
             }
             L(u0) = u; L(b0) = b;
         }
-        adapt_group(W0, u0, b0);
+        adapt_group<3>(W0, u0, b0);
         LANES(l) if (L(u0)) st4(model + L(a0), L(W0));
         return nz;
     }
@@ -463,24 +575,44 @@ struct Dec4Wave {
         LSYNC();
         // ---- serial (uniform vector) -----------------------------------------------------------------------------
         LEP_MARK("77_serial");
-        int zz = zz0, left = left0, cand = 0;
-        const int zz_end = zz0 + 16 < 49 ? zz0 + 16 : 49;
-        uint32_t sgw = vec(S.sign[ci * 48]);
+        int zz, left = left0, cand = 0;
+        const int pi_end = zz0 + 16 < 49 ? 16 : 49 - zz0;   // window positions 0 .. pi_end-1
+        {
+            // The loop is written around its commonest iteration, a zero coefficient (one bin, bit 0): `lane` is the only
+            // induction variable of the inner loop (position and candidate are folded into it), so that iteration is the bin
+            // itself + one lane read + add / compare / branch.  Runs while position < pi_end && left > 0 && cand < CANDS
+            // (true on entry: the caller checks zz < 49 && left > 0).
+            typedef Serial<(LEP_DEC4_SCALAR & 2) != 0> SR;
+            SR sr(*this);
+            uint32_t sgw = SR::U(S.sign[ci * 48]);
+            int pi = 0;
 #pragma nounroll
-        for (;;) {   // runs while zz < zz_end && left > 0 && cand < 4 (true on entry: the caller checks zz < 49 && left > 0)
-            const int lane = (zz - zz0) + 16 * cand;
-            int len = dec_unary4(lepwave::wave_read(PK0, lane));
-            LEP_BINS(++nbins);
-            if (len) {
+            for (;;) {
+                int lane = pi + 16 * cand;
+                const int lane_end = pi_end + 16 * cand;
+                uint32_t pkv;
+                bool found = false;
+#pragma nounroll
+                for (;;) {
+                    pkv = SR::U(lepwave::wave_read(PK0, lane));
+                    LEP_BINS(++nbins);
+                    if (SR::is(sr.get(pkv & 255) != 0)) { found = true; break; }
+                    if (++lane >= lane_end) break;
+                }
+                pi = lane - 16 * cand;
+                if (!found) break;   // the window is exhausted
+                zz = zz0 + pi;
+                int len = sr.template unary_from<1>(pkv);   // bin 0 was a one: 1..4
                 if (len == 4) {
-                    // exponent words 4..7 (|v| >= 8: 5 % of the interior non-zeros) are not prefetched -- that third of the round's
-                    // traffic was almost all waste; the serial code reads the group when it gets there, the owner re-reads it to adapt
-                    len += dec_unary4(pack_probs(vload4(model + ctx4_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])) + kGS)));
-                    if (len == 8) len = dec_unary_tail(ctx4_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])));
+                    // exponent words 4..7 (|v| >= 8: 5 % of the interior non-zeros) are not prefetched -- that third of the
+                    // round's traffic was almost all waste; the serial code reads the group when it gets there, the owner
+                    // re-reads it to adapt
+                    len = 4 + sr.template unary_from<0>(SR::U(pack_probs(vload4(model + ctx4_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])) + kGS))));
+                    if (len == 8) len = sr.unary_tail(ctx4_exp7(ci, nb0 - cand, zz, (int)uni(S.bsr[zz])));
                 }
                 LEP_BINS(nbins += (uint32_t)(2 * len - (len == 11)));
-                const uint32_t pos = bc.get(sgw >> 16);
-                sgw = bupd_u(sgw, pos, S.inv24);
+                const uint32_t pos = sr.get(sgw >> 16);
+                sgw = sr.bupd(sgw, pos);
                 --left;
                 uint32_t v = 1u << (len - 1);
                 if (len > 1) {
@@ -488,18 +620,20 @@ struct Dec4Wave {
                     if (b >= 4) {
                         const uint32_t rbase = ctx4_res(ci, (int)uni(S.a2r[zz]), nb0 - cand);
 #pragma nounroll
-                        for (; b >= 4; --b) v |= dec_global(row_word(rbase, b)) << b;
+                        for (; b >= 4; --b) v |= sr.global_bin(row_word(rbase, b)) << b;
                     }
-                    v = dec_residual(lepwave::wave_read(PK1, lane), b, v);
+                    v = sr.residual(SR::U(lepwave::wave_read(PK1, lane)), b, v);
                 }
                 S.here[zz] = (int16_t)(pos ? (int)v : -(int)v);
-                if (left == 0) { ++zz; break; }
+                ++pi;
+                if (left == 0) break;
                 cand = nb0 - nzbin_of(left);
-                if (cand >= LEP_DEC4_CANDS) { ++zz; break; }
+                if (cand >= LEP_DEC4_CANDS || pi >= pi_end) break;
             }
-            if (++zz >= zz_end) break;
+            zz = zz0 + pi;
+            sr.done();
+            S.sign[ci * 48] = sgw;
         }
-        S.sign[ci * 48] = sgw;
         LSYNC();
         // ---- owners adapt ---------------------------------------------------------------------------------------------------
         LEP_MARK("77_update");
@@ -522,8 +656,8 @@ struct Dec4Wave {
             }
             L(u0) = ua; L(b0) = ba; L(u1) = ub; L(b1) = bb; L(u2) = uc; L(b2) = bcc;
         }
-        adapt_group(W0, u0, b0);
-        adapt_group(W1, u1, b1);
+        adapt_group<3>(W0, u0, b0);
+        adapt_group<0>(W1, u1, b1);
         LANES(l) {
             if (L(u0)) st4(model + L(a0), L(W0));
             if (L(u1)) st4(model + L(a1), L(W1));
@@ -531,7 +665,7 @@ struct Dec4Wave {
         if (lepwave::wave_ballot(u2)) {   // exponent words 4..7: re-read by the owner (rare in the interior)
             LV(U4, W2);
             LANES(l) if (L(u2)) L(W2) = ld4(model + L(a0) + kGS);
-            adapt_group(W2, u2, b2);
+            adapt_group<0>(W2, u2, b2);
             LANES(l) if (L(u2)) st4(model + L(a0) + kGS, L(W2));
         }
         LSYNC();
@@ -576,57 +710,69 @@ struct Dec4Wave {
         // ---- serial (uniform vector) -----------------------------------------------------------------------------
         LEP_MARK("edge_serial");
         int ne[2] = {0, 0}, rc = 0;
+        typedef Serial<(LEP_DEC4_SCALAR & 4) != 0> SR;
+        SR sr(*this);
 #pragma nounroll
         for (int e = 0; e < 2 && !rc; ++e) {
             const bool horizontal = e == 0;
-            ne[e] = dec_tree(3, PK0, 56 + 3 * e);
+            ne[e] = sr.template tree<3>(PK0, 56 + 3 * e);
+            LEP_BINS(nbins += 3);
             int left = ne[e];
+            if (!left) continue;
             const int a_off = horizontal ? 50 : 57;
+            // lane of (position j, `left` non-zeros left) = e * 28 + combo_base(j) + left - 1, and combo_base(j + 1) =
+            // combo_base(j) + 7 - j: the lane is the induction variable (+ step per position, - 1 per non-zero), INFO / PK0 / PK2
+            // are all read from it (every combo lane of a position carries the position's INFO)
+            int lane = e * 28 + left - 1, step = 7;
 #pragma nounroll
-            for (int j = 0; j < 7 && left; ++j) {
-                const int base = e * 28 + combo_base(j);
-                const uint32_t info = lepwave::wave_read(INFO, base);
+            for (;;) {
+                const uint32_t info = lepwave::wave_read(INFO, lane);
                 if (info >> 31) { rc = 43; break; }
-                const int lane = base + left - 1;
-                int len = dec_unary4(lepwave::wave_read(PK0, lane));
+                const uint32_t pkv = SR::U(lepwave::wave_read(PK0, lane));
                 LEP_BINS(++nbins);
-                if (len) {
+                if (SR::is(sr.get(pkv & 255) != 0)) {
+                    const int j = 7 - step;
                     const int coord = horizontal ? j + 1 : (j + 1) * 8;
+                    int len = sr.template unary_from<1>(pkv);
                     if (len == 4) {
-                        len += dec_unary4(pack_probs(vload4(model + ctx4_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)) + kGS)));
-                        if (len == 8) len = dec_unary_tail(ctx4_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)));
+                        len = 4 + sr.template unary_from<0>(SR::U(pack_probs(vload4(model + ctx4_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)) + kGS))));
+                        if (len == 8) len = sr.unary_tail(ctx4_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15)));
                     }
                     LEP_BINS(nbins += (uint32_t)(2 * len - (len == 11)));
                     const int sslot = (int)(info & 255);
-                    const uint32_t sgw = vec(S.sign[sslot]);
-                    const uint32_t pos = bc.get(sgw >> 16);
-                    S.sign[sslot] = bupd_u(sgw, pos, S.inv24);
+                    const uint32_t sgw = SR::U(S.sign[sslot]);
+                    const uint32_t pos = sr.get(sgw >> 16);
+                    S.sign[sslot] = sr.bupd(sgw, pos);
                     uint32_t v = 1u << (len - 1);
                     if (len > 1) {
                         int b = len - 2;
                         const int thr = (int)((info >> 8) & 15);
                         if (b >= thr) {
                             const uint32_t Tt = ctx_thresh(ci, (int)((info >> 16) & 255), imin(len - thr, 7));
-                            int s = 1;
+                            int sx = 1;
 #pragma nounroll
                             for (; b >= thr; --b) {
-                                const uint32_t bit = dec_global(Tt + (uint32_t)s);
+                                const uint32_t bit = sr.global_bin(Tt + (uint32_t)sx);
                                 v |= bit << b;
-                                s = imin((s << 1) | (int)uni(bit), 127);
+                                sx = imin((sx << 1) | (int)uni(bit), 127);
                             }
                         }
                         if (b >= 4) {
                             const uint32_t rbase = ctx4_res(ci, coord, left);
 #pragma nounroll
-                            for (; b >= 4; --b) v |= dec_global(row_word(rbase, b)) << b;
+                            for (; b >= 4; --b) v |= sr.global_bin(row_word(rbase, b)) << b;
                         }
-                        v = dec_residual(lepwave::wave_read(PK2, lane), b, v);
+                        v = sr.residual(SR::U(lepwave::wave_read(PK2, lane)), b, v);
                     }
-                    --left;
                     S.here[a_off + j] = (int16_t)(pos ? (int)v : -(int)v);
+                    --lane;
+                    if (--left == 0) break;
                 }
+                lane += step;
+                if (--step == 0) break;
             }
         }
+        sr.done();
         LSYNC();
         if (rc) return rc;
         // ---- owners adapt ---------------------------------------------------------------------------------------------------
@@ -656,15 +802,15 @@ struct Dec4Wave {
             }
             L(u0) = ua; L(b0) = ba; L(u1) = ub; L(b1) = bb; L(u2) = uc; L(b2) = bcc;
         }
-        adapt_group(W0, u0, b0);
+        adapt_group<3>(W0, u0, b0);
         LANES(l) if (L(u0)) st4(model + L(a0), L(W0));
         if (lepwave::wave_ballot(u1)) {
             LANES(l) if (L(u1)) L(W1) = ld4(model + L(a0) + kGS);   // read on demand by the serial code: the owner re-reads it
-            adapt_group(W1, u1, b1);
+            adapt_group<0>(W1, u1, b1);
             LANES(l) if (L(u1)) st4(model + L(a0) + kGS, L(W1));
         }
         if (lepwave::wave_ballot(u2)) {
-            adapt_group(W2, u2, b2);
+            adapt_group<0>(W2, u2, b2);
             LANES(l) if (L(u2)) st4(model + L(a2), L(W2));
         }
         LSYNC();
@@ -684,25 +830,29 @@ struct Dec4Wave {
         }
         LEP_MARK("dc_serial");
         const int sslot = ci * 48 + sctx;
-        int len = dec_unary4(lepwave::wave_read(PK0, 0));
+        typedef Serial<(LEP_DEC4_SCALAR & 8) != 0> SR;
+        SR sr(*this);
+        int len = sr.template unary_from<0>(SR::U(lepwave::wave_read(PK0, 0)));
         if (len == 4) {
-            len += dec_unary4(lepwave::wave_read(PK0, 1));
+            len += sr.template unary_from<0>(SR::U(lepwave::wave_read(PK0, 1)));
             if (len == 8) {
-                uint32_t pk = lepwave::wave_read(PK0, 2);
+                uint32_t pk = SR::U(lepwave::wave_read(PK0, 2));
 #pragma nounroll
-                for (; len < 11; ++len) { if (!ucond(bc.get(pk & 255) != 0)) break; pk >>= 8; }
+                for (; len < 11; ++len) { if (!SR::is(sr.get(pk & 255) != 0)) break; pk >>= 8; }
             }
         }
         LEP_BINS(nbins += (uint32_t)(len ? 2 * len + 1 - (len == 11) : 1));
         uint32_t v = 0, pos = 1;
         if (len) {
-            const uint32_t sgw = vec(S.sign[sslot]);
-            pos = bc.get(sgw >> 16);
-            S.sign[sslot] = bupd_u(sgw, pos, S.inv24);
+            const uint32_t sgw = SR::U(S.sign[sslot]);
+            pos = sr.get(sgw >> 16);
+            S.sign[sslot] = sr.bupd(sgw, pos);
             v = 1u << (len - 1);
 #pragma nounroll
-            for (int i = len - 2; i >= 0; --i) v |= bc.get(lepwave::wave_read(RW, 3 + i) >> 16) << i;
+            for (int i = len - 2; i >= 0; --i) v |= sr.get(SR::U(lepwave::wave_read(RW, 3 + i)) >> 16) << i;
         }
+        sr.done();
+        v = vec(v);
         int d = (int16_t)(pos ? (int)v : -(int)v);
         int dc = d + pred;
         dc = dc < -1024 ? dc + 2049 : dc;
@@ -718,7 +868,7 @@ struct Dec4Wave {
             if (l < 3) mask_exp(l * 4, len, u, b);
             L(u0) = u; L(b0) = b;
         }
-        adapt_group(W0, u0, b0);
+        adapt_group<7>(W0, u0, b0);
         LANES(l) {
             if (L(u0)) st4(model + L(a0), L(W0));
             if (l >= 3 && l < 13 && l - 3 <= len - 2) S.resdc[a * 12 + (l - 3)] = bupd_t(L(RW), (L(VV) >> (l - 3)) & 1u, S.inv24);
@@ -870,7 +1020,10 @@ struct Dec4Wave {
                 L(nxt_above) = has_above ? arow[l] : (int16_t)0;
                 L(nxt_ns) = (has_above && l < (int)(sizeof(NSum) / 4)) ? ((const uint32_t*)&narow[0])[l] : 0u;
             }
-            for (int x = 0; x < w; ++x) {
+            // a truncated image's last row ends with the last coded block (at least one block of a row is always coded)
+            const int coded_here = (int)img->coded_blocks[comp] - yb * w;
+            const int x_end = imin(w, coded_here < 1 ? 1 : coded_here);
+            for (int x = 0; x < x_end; ++x) {
                 LEP_MARK("staging");
         LANES(l) {
                     if (x) { sh->left[l] = sh->here[l]; sh->aleft[l] = sh->above[l]; }
@@ -882,7 +1035,7 @@ struct Dec4Wave {
                 LSYNC();
                 LANES(l) {
                     if (has_above) sh->above[l] = L(nxt_above);
-                    if (has_above && x + 1 < w) {
+                    if (has_above && x + 1 < x_end) {
                         L(nxt_above) = arow[(int64_t)(x + 1) * 64 + l];
                         if (l < (int)(sizeof(NSum) / 4)) L(nxt_ns) = ((const uint32_t*)&narow[x + 1])[l];
                     }
@@ -895,7 +1048,6 @@ struct Dec4Wave {
                     row[(int64_t)x * 64 + l] = sh->here[l];
                     if (l < (int)(sizeof(NSum) / 4)) ((uint32_t*)&nrow[x])[l] = ((const uint32_t*)&sh->ns_here)[l];
                 }
-                if (x + 1 < w && yb * w + x + 1 >= img->coded_blocks[comp]) break;
             }
         }
         return 0;

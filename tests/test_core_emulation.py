@@ -22,6 +22,16 @@ def emu():
     return C.CDLL(EMU_SO)
 
 
+@pytest.fixture(scope="module")
+def emu_other_forms():
+    """the v4 decoder with the OTHER assignment of its serial rounds to the scalar / vector unit (lep_dec4.h LEP_DEC4_SCALAR:
+    the shipped build runs the 7x7 round on the scalar unit, this one everything but): every round is stepped in both forms"""
+    src = os.path.join(ROOT, "tests", "emu", "core_emu.cc")
+    so = os.path.join(ROOT, "tests", "emu", "libcore_emu_forms.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DLEP_DEC4_SCALAR=13", "-o", so, src])
+    return C.CDLL(so)
+
+
 @pytest.mark.parametrize("name", golden_cases())
 def test_kernel_source_on_cpu_matches_oracle(emu, name):
     jpg, _ = golden(name)
@@ -248,6 +258,32 @@ def test_v4_decoder_large_coefficients(emu):
     for c in range(d.ncomp):
         n = d.coded_blocks[c] * 128
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
+
+
+def test_v4_decoder_rounds_in_their_other_form(emu_other_forms):
+    """scalar-unit and vector-unit forms of every serial round decode the same frames: golden cases, the rare paths
+    (large coefficients), garbage streams"""
+    emu = emu_other_forms
+    for name in golden_cases():
+        jpg, _ = golden(name)
+        img = JpegImage(jpg)
+        d = img.desc
+        segs = img.plan()
+        want, bins = ob.oracle_encode(d, segs)
+        orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+        for c in range(d.ncomp):
+            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+        total = 0
+        for s, w in zip(segs, want):
+            nb = C.c_uint32(0)
+            assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0, name
+            total += nb.value
+        assert total == bins, name
+        for c in range(d.ncomp):
+            n = d.coded_blocks[c] * 128
+            assert C.string_at(d.blocks[c], n) == orig[c][:n], name
+    test_v4_decoder_large_coefficients(emu)
+    test_decoders_survive_garbage_streams(emu, 9)
 
 
 def test_inv24_table_update_is_exact(emu):
