@@ -149,6 +149,45 @@ struct BoolEnc3 {
     }
 };
 
+// The same writer with low / range / count on the SCALAR unit (see BoolDec4S in lep_dec4.h for the why): code_chunk hands
+// part of the bin groups to this form so that the scalar ALU, idle most of the time beside a VALU-bound coder loop, carries
+// some of the recurrence.  Byte emission (position, carry ripple, stores by lane 0) is BoolEnc3's: load() / store() move the
+// three state words across.
+struct BoolEnc3S {
+    uint32_t low, range;
+    int count;
+    WDEV void load(const BoolEnc3& b) { low = uni(b.low); range = uni(b.range); count = (int)uni((uint32_t)b.count); }
+    WDEV void store(BoolEnc3& b) const { b.low = vec(low); b.range = vec(range); b.count = (int)vec((uint32_t)count); }
+    WDEV void put(BoolEnc3& b, uint32_t bit, uint32_t prob) {
+        const uint32_t split = 1 + (((range - 1) * prob) >> 8);
+        uint32_t l = bit ? low + split : low;
+        uint32_t r = bit ? range - split : split;
+        int shift = __builtin_clz(r) - 24;
+        r <<= shift;
+        int c = count + shift;
+        if (c >= 0) {
+            const int offset = shift - c;
+            if (b.pos + 2 > b.cap) b.overflow = true;
+            if (!b.overflow) {
+                if ((l << (offset - 1)) & 0x80000000u) b.carry();
+                b.emit((uint8_t)(l >> (24 - offset)));
+                ++b.pos;
+            }
+            l <<= offset;
+            shift = c;
+            l &= 0xffffff;
+            c -= 8;
+        }
+        l <<= shift;
+        count = c; low = l; range = r;
+    }
+};
+
+// of every 4 groups of four bins, how many the scalar form codes (0 = none, 4 = all)
+#ifndef LEP_ENC3_SCALAR_GROUPS
+#define LEP_ENC3_SCALAR_GROUPS 2   // measured (1024 x 4K, MI355X, profiles/r02o_encoder_ab.json): 0: 1186 ms, 1: 1107, 2: 1092, 3: 1159, 4: 1278
+#endif
+
 struct Enc3Wave {
     const ImageDev* img;
     uint32_t* model;
@@ -169,6 +208,24 @@ struct Enc3Wave {
         // (entries are read back from LDS at a uniform address, four at a time, and everything derived from them stays
         // on the vector ALU: a SALU instruction costs about two VALU ones here, profiles/r01_issue_microbench.txt)
         int j = 0;
+#if LEP_ENC3_SCALAR_GROUPS > 0
+#pragma nounroll
+        for (; j + 16 <= n; j += 16) {   // 16 bins: LEP_ENC3_SCALAR_GROUPS groups on the scalar unit, the others on the vector ALU
+            BoolEnc3S sc;
+            sc.load(bc);
+#pragma unroll
+            for (int g = 0; g < LEP_ENC3_SCALAR_GROUPS; ++g) {
+                const U4 q = ld4(B + j + 4 * g);
+                code_bin_s(sc, uni(q.x)); code_bin_s(sc, uni(q.y)); code_bin_s(sc, uni(q.z)); code_bin_s(sc, uni(q.w));
+            }
+            sc.store(bc);
+#pragma unroll
+            for (int g = LEP_ENC3_SCALAR_GROUPS; g < 4; ++g) {
+                const U4 q = ld4(B + j + 4 * g);
+                code_bin(vec(q.x)); code_bin(vec(q.y)); code_bin(vec(q.z)); code_bin(vec(q.w));
+            }
+        }
+#endif
 #pragma nounroll
         for (; j + 4 <= n; j += 4) {
             const U4 q = ld4(B + j);   // one 16-byte LDS read
@@ -279,6 +336,15 @@ struct Enc3Wave {
             t = obs ? 129u : (1 + t0) >> 1;
         }
         return f | (t << 8) | (prob_of(f, t) << 16);
+    }
+    // the same through the scalar-unit writer (e in an SGPR); the sign Branch's probability is still computed on the vector ALU
+    WDEV void code_bin_s(BoolEnc3S& sc, uint32_t e) {
+        if (e & kResident3) {
+            const uint32_t slot = e & 127, bit = e >> 31;
+            const uint32_t w = uni(sh->sign[slot]);
+            sc.put(bc, bit, w >> 16);
+            sh->sign[slot] = bupd_uv(vec(w), vec(bit));
+        } else sc.put(bc, (e >> 8) & 1, e & 255);
     }
     // one entry of the resolved bin list through the bool coder (uniform vector value e)
     WDEV void code_bin(uint32_t e) {
