@@ -33,10 +33,10 @@ struct Enc3Shared {
     alignas(16) uint32_t bins[kBinChunk];   // P2: branch index | bit << 31;  after P3: probability | bit << 8
     uint16_t dup[kMaxDup3];     // positions (into bins) of bins whose Branch may repeat within the block
     uint32_t sign[96];          // the sign Branches live in LDS for the whole segment (never written back)
-    int32_t t[64];              // IDCT intermediate
+    alignas(16) int32_t t[64];              // IDCT intermediate
     int32_t icos_x[64], icos_y[64];
     int16_t here[64], left[64], above[64], aleft[64];   // aligned order
-    int16_t pix[64];
+    alignas(16) int16_t pix[64];
     uint16_t q[64];
     uint8_t thr[64];
     uint8_t r2a[64], a2r[64], nzbin[64];
@@ -280,50 +280,8 @@ struct Enc3Wave {
         LSYNC();
     }
 
-    // integer IDCT without DC (idct.cc:35-161), rows then columns, 8 lanes each
-    WDEV void idct_rows() {
-        constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
-        constexpr int w1pw7 = w1 + w7, w1mw7 = w1 - w7, w2pw6 = w2 + w6, w2mw6 = w2 - w6, w3pw5 = w3 + w5, w3mw5 = w3 - w5;
-        LANES(l) if (l < 8) {
-            const int y8 = l * 8;
-#define LEP_CQ5(i) ((int32_t)sh->here[sh->r2a[i]] * (int32_t)sh->q[i])
-            int32_t x0 = (l == 0 ? 0 : (int32_t)((uint32_t)LEP_CQ5(y8) << 11)) + 128;
-            int32_t x1 = (int32_t)((uint32_t)LEP_CQ5(y8 + 4) << 11);
-            int32_t x2 = LEP_CQ5(y8 + 6), x3 = LEP_CQ5(y8 + 2), x4 = LEP_CQ5(y8 + 1), x5 = LEP_CQ5(y8 + 7), x6 = LEP_CQ5(y8 + 5),
-                    x7 = LEP_CQ5(y8 + 3), x8;
-#undef LEP_CQ5
-            x8 = w7 * (x4 + x5); x4 = x8 + w1mw7 * x4; x5 = x8 - w1pw7 * x5;
-            x8 = w3 * (x6 + x7); x6 = x8 - w3mw5 * x6; x7 = x8 - w3pw5 * x7;
-            x8 = x0 + x1; x0 -= x1;
-            x1 = w6 * (x3 + x2); x2 = x1 - w2pw6 * x2; x3 = x1 + w2mw6 * x3;
-            x1 = x4 + x6; x4 -= x6; x6 = x5 + x7; x5 -= x7;
-            x7 = x8 + x3; x8 -= x3; x3 = x0 + x2; x0 -= x2;
-            x2 = (r2 * (x4 + x5) + 128) >> 8;
-            x4 = (r2 * (x4 - x5) + 128) >> 8;
-            int32_t* t = sh->t + y8;
-            t[0] = (x7 + x1) >> 8; t[1] = (x3 + x2) >> 8; t[2] = (x0 + x4) >> 8; t[3] = (x8 + x6) >> 8;
-            t[4] = (x8 - x6) >> 8; t[5] = (x0 - x4) >> 8; t[6] = (x3 - x2) >> 8; t[7] = (x7 - x1) >> 8;
-        }
-        LSYNC();
-        LANES(l) if (l < 8) {
-            const int32_t* t = sh->t + l;
-            int32_t y0 = (int32_t)((uint32_t)t[0] << 8) + 8192, y1 = (int32_t)((uint32_t)t[32] << 8);
-            int32_t y2 = t[48], y3 = t[16], y4 = t[8], y5 = t[56], y6 = t[40], y7 = t[24], y8;
-            y8 = w7 * (y4 + y5) + 4; y4 = (y8 + w1mw7 * y4) >> 3; y5 = (y8 - w1pw7 * y5) >> 3;
-            y8 = w3 * (y6 + y7) + 4; y6 = (y8 - w3mw5 * y6) >> 3; y7 = (y8 - w3pw5 * y7) >> 3;
-            y8 = y0 + y1; y0 -= y1;
-            y1 = w6 * (y3 + y2) + 4; y2 = (y1 - w2pw6 * y2) >> 3; y3 = (y1 + w2mw6 * y3) >> 3;
-            y1 = y4 + y6; y4 -= y6; y6 = y5 + y7; y5 -= y7;
-            y7 = y8 + y3; y8 -= y3; y3 = y0 + y2; y0 -= y2;
-            y2 = (r2 * (y4 + y5) + 128) >> 8;
-            y4 = (r2 * (y4 - y5) + 128) >> 8;
-            int16_t* o = sh->pix + l;
-            o[0] = (int16_t)((y7 + y1) >> 11); o[8] = (int16_t)((y3 + y2) >> 11); o[16] = (int16_t)((y0 + y4) >> 11);
-            o[24] = (int16_t)((y8 + y6) >> 11); o[32] = (int16_t)((y8 - y6) >> 11); o[40] = (int16_t)((y0 - y4) >> 11);
-            o[48] = (int16_t)((y3 - y2) >> 11); o[56] = (int16_t)((y7 - y1) >> 11);
-        }
-        LSYNC();
-    }
+    // integer IDCT without DC (idct.cc:35-161): lep_v3.h idct_no_dc; S.pix is column-major, LEP_PIX(S, y, x)
+    WDEV void idct_rows() { idct_no_dc(sh); }
     static WDEV int half16(int d) { return (int16_t)d / 2; }
 
     // Branch::record_obs_and_update (branch.hh:82-100) for a uniform-vector word and observation; rare paths on ballots
@@ -395,8 +353,8 @@ struct Enc3Wave {
             LV(int, emin); LV(int, emax); LV(int, s0); LV(int, s1); LV(int, tmp);
             LANES(l) {
                 int ev = 0, have = 0;
-                if (l < 8 && has_left) { have = 1; ev = (int16_t)(S.ns_left.vert[l] - half16(S.pix[l * 8] - S.pix[l * 8 + 1]) - (S.pix[l * 8] + 1024)); }
-                if (l >= 8 && l < 16 && has_above) { const int i = l - 8; have = 1; ev = (int16_t)(S.ns_above.horiz[i] - half16(S.pix[i] - S.pix[i + 8]) - (S.pix[i] + 1024)); }
+                if (l < 8 && has_left) { have = 1; ev = (int16_t)(S.ns_left.vert[l] - half16(LEP_PIX(S, l, 0) - LEP_PIX(S, l, 1)) - (LEP_PIX(S, l, 0) + 1024)); }
+                if (l >= 8 && l < 16 && has_above) { const int i = l - 8; have = 1; ev = (int16_t)(S.ns_above.horiz[i] - half16(LEP_PIX(S, 0, i) - LEP_PIX(S, 1, i)) - (LEP_PIX(S, 0, i) + 1024)); }
                 L(emax) = have ? ev : -0x7fffffff;
                 L(emin) = have ? -ev : -0x7fffffff;
                 L(s0) = l < 8 ? ev : 0;
@@ -677,8 +635,8 @@ struct Enc3Wave {
             if (l < 16) {
                 const int i = l & 7;
                 const int dcq = S.here[49] * (int)S.q[0];
-                if (l < 8) S.ns_here.horiz[i] = (int16_t)(dcq + S.pix[56 + i] + 1024 + half16(S.pix[56 + i] - S.pix[48 + i]));
-                else S.ns_here.vert[i] = (int16_t)(dcq + S.pix[i * 8 + 7] + 1024 + half16(S.pix[i * 8 + 7] - S.pix[i * 8 + 6]));
+                if (l < 8) S.ns_here.horiz[i] = (int16_t)(dcq + LEP_PIX(S, 7, i) + 1024 + half16(LEP_PIX(S, 7, i) - LEP_PIX(S, 6, i)));
+                else S.ns_here.vert[i] = (int16_t)(dcq + LEP_PIX(S, i, 7) + 1024 + half16(LEP_PIX(S, i, 7) - LEP_PIX(S, i, 6)));
             }
             if (l == 16) S.ns_here.nz = nz;
         }

@@ -134,6 +134,65 @@ WDEV uint32_t pack_probs(const U4& w) {
     return ((w.x >> 16) & 255) | ((w.y >> 8) & 0xff00) | (w.z & 0xff0000) | ((w.w << 8) & 0xff000000u);
 }
 
+// ---- integer IDCT without DC (idct.cc:35-161) shared by both coder kernels --------------------------------------------
+// SH has: int16_t here[64] (aligned order), uint8_t r2a[64], uint16_t q[64], int32_t t[64] (16-byte aligned),
+// int16_t pix[64] (16-byte aligned).  LDS instructions cost 2-4 VALU ones here (profiles/r02n_inst_rates.txt), so the
+// passes are arranged around wide accesses: all 64 lanes dequantise into raster order (t), 8 lanes read a row with two
+// 16-byte loads and write their results TRANSPOSED, 8 lanes read a column the same way and store its 8 pixels with one
+// 16-byte write -- pix is stored column-major: LEP_PIX(S, y, x).  24 LDS instructions instead of 48.
+#define LEP_PIX(S, y, x) (S).pix[(x) * 8 + (y)]
+template <class SH>
+WDEV void idct_no_dc(SH* sh) {
+    constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
+    constexpr int w1pw7 = w1 + w7, w1mw7 = w1 - w7, w2pw6 = w2 + w6, w2mw6 = w2 - w6, w3pw5 = w3 + w5, w3mw5 = w3 - w5;
+    LANES(l) sh->t[l] = l ? (int32_t)sh->here[sh->r2a[l]] * (int32_t)sh->q[l] : 0;   // raster order, DC left out
+    LSYNC();
+    LV(int32_t, o0); LV(int32_t, o1); LV(int32_t, o2); LV(int32_t, o3); LV(int32_t, o4); LV(int32_t, o5); LV(int32_t, o6); LV(int32_t, o7);
+    LANES(l) if (l < 8) {
+        const int32_t* in = sh->t + l * 8;
+        const U4 a = ld4(reinterpret_cast<const uint32_t*>(in)), b = ld4(reinterpret_cast<const uint32_t*>(in + 4));
+        int32_t x0 = (int32_t)(a.x << 11) + 128;
+        int32_t x1 = (int32_t)(b.x << 11);
+        int32_t x2 = (int32_t)b.z, x3 = (int32_t)a.z, x4 = (int32_t)a.y, x5 = (int32_t)b.w, x6 = (int32_t)b.y, x7 = (int32_t)a.w, x8;
+        x8 = w7 * (x4 + x5); x4 = x8 + w1mw7 * x4; x5 = x8 - w1pw7 * x5;
+        x8 = w3 * (x6 + x7); x6 = x8 - w3mw5 * x6; x7 = x8 - w3pw5 * x7;
+        x8 = x0 + x1; x0 -= x1;
+        x1 = w6 * (x3 + x2); x2 = x1 - w2pw6 * x2; x3 = x1 + w2mw6 * x3;
+        x1 = x4 + x6; x4 -= x6; x6 = x5 + x7; x5 -= x7;
+        x7 = x8 + x3; x8 -= x3; x3 = x0 + x2; x0 -= x2;
+        x2 = (r2 * (x4 + x5) + 128) >> 8;
+        x4 = (r2 * (x4 - x5) + 128) >> 8;
+        L(o0) = (x7 + x1) >> 8; L(o1) = (x3 + x2) >> 8; L(o2) = (x0 + x4) >> 8; L(o3) = (x8 + x6) >> 8;
+        L(o4) = (x8 - x6) >> 8; L(o5) = (x0 - x4) >> 8; L(o6) = (x3 - x2) >> 8; L(o7) = (x7 - x1) >> 8;
+    }
+    LSYNC();   // every row has been read before any is overwritten (the emulation steps lane by lane)
+    LANES(l) if (l < 8) {   // transposed: column k of row l goes to t[k * 8 + l]
+        int32_t* t = sh->t + l;
+        t[0] = L(o0); t[8] = L(o1); t[16] = L(o2); t[24] = L(o3); t[32] = L(o4); t[40] = L(o5); t[48] = L(o6); t[56] = L(o7);
+    }
+    LSYNC();
+    LANES(l) if (l < 8) {
+        const int32_t* in = sh->t + l * 8;   // column l, rows 0..7
+        const U4 a = ld4(reinterpret_cast<const uint32_t*>(in)), b = ld4(reinterpret_cast<const uint32_t*>(in + 4));
+        int32_t y0 = (int32_t)(a.x << 8) + 8192, y1 = (int32_t)(b.x << 8);
+        int32_t y2 = (int32_t)b.z, y3 = (int32_t)a.z, y4 = (int32_t)a.y, y5 = (int32_t)b.w, y6 = (int32_t)b.y, y7 = (int32_t)a.w, y8;
+        y8 = w7 * (y4 + y5) + 4; y4 = (y8 + w1mw7 * y4) >> 3; y5 = (y8 - w1pw7 * y5) >> 3;
+        y8 = w3 * (y6 + y7) + 4; y6 = (y8 - w3mw5 * y6) >> 3; y7 = (y8 - w3pw5 * y7) >> 3;
+        y8 = y0 + y1; y0 -= y1;
+        y1 = w6 * (y3 + y2) + 4; y2 = (y1 - w2pw6 * y2) >> 3; y3 = (y1 + w2mw6 * y3) >> 3;
+        y1 = y4 + y6; y4 -= y6; y6 = y5 + y7; y5 -= y7;
+        y7 = y8 + y3; y8 -= y3; y3 = y0 + y2; y0 -= y2;
+        y2 = (r2 * (y4 + y5) + 128) >> 8;
+        y4 = (r2 * (y4 - y5) + 128) >> 8;
+        const uint32_t p0 = (uint32_t)(uint16_t)((y7 + y1) >> 11) | ((uint32_t)(uint16_t)((y3 + y2) >> 11) << 16);
+        const uint32_t p1 = (uint32_t)(uint16_t)((y0 + y4) >> 11) | ((uint32_t)(uint16_t)((y8 + y6) >> 11) << 16);
+        const uint32_t p2 = (uint32_t)(uint16_t)((y8 - y6) >> 11) | ((uint32_t)(uint16_t)((y0 - y4) >> 11) << 16);
+        const uint32_t p3 = (uint32_t)(uint16_t)((y3 - y2) >> 11) | ((uint32_t)(uint16_t)((y7 - y1) >> 11) << 16);
+        st4(reinterpret_cast<uint32_t*>(sh->pix + l * 8), U4{p0, p1, p2, p3});   // column l, rows 0..7
+    }
+    LSYNC();
+}
+
 // ---- bool decoder (boolreader.hh:184-258, 376-416; boolreader.cc:25-34) -----------------------------------
 // 64-bit window refilled with one ALIGNED dword at a time; the next dword is requested one refill ahead and only
 // touched when it is consumed, so the load latency is off the serial chain.  Bytes outside [0, len) of the stream are

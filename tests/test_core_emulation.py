@@ -655,6 +655,68 @@ def _progressive_scans_on_the_emulation(emu, jpg, lep):
     return data, f
 
 
+def _progressive_check_on_the_emulation(emu, jpg, tweak=None):
+    """what lep_compress_batch's round-trip check does for a progressive file, with the scan coder stepped on the CPU: the plan
+    from the PARSED file (lep_jpeg_plan_progressive_check), every scan written again from the parser's frame, compared with
+    the file's own bytes of that scan.  None if the file is not eligible."""
+    from lepton_amd import abi
+
+    L = abi.lib()
+    src = JpegImage(jpg)
+    img = abi.HuffProgImage()
+    scans = (abi.HuffProgScan * 64)()
+    first = (C.c_uint32 * 64)()
+    flen = (C.c_uint32 * 64)()
+    nscan, ok = C.c_int(0), C.c_int(0)
+    assert L.lep_jpeg_plan_progressive_check(src.handle, len(jpg), C.byref(img), scans, first, flen, 64, C.byref(nscan), C.byref(ok)) == 0
+    if not ok.value:
+        return None
+    n = nscan.value
+    for c in range(src.desc.ncomp):
+        img.blocks[c] = src.desc.blocks[c]
+    if tweak:
+        tweak(src.desc)
+    out_total = corr_total = 0
+    for i in range(n):
+        scans[i].image = 0
+        scans[i].out_cap = min(scans[i].out_cap, flen[i] + 64)
+        scans[i].out_off = out_total
+        out_total += (scans[i].out_cap + 15) & ~15
+        scans[i].corr_off = corr_total
+        corr_total += scans[i].corr_cap
+    out = C.create_string_buffer(out_total + 64)
+    corr = (C.c_uint32 * (corr_total + 8))()
+    lens = (C.c_uint32 * n)()
+    emu.emu_huffman_progressive_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert emu.emu_huffman_progressive_encode(C.byref(img), scans, n, out, corr, lens) == 0
+    return [(lens[i], out.raw[scans[i].out_off: scans[i].out_off + min(lens[i], scans[i].out_cap)], jpg[first[i]: first[i] + flen[i]]) for i in range(n)]
+
+
+def test_progressive_round_trip_check_plan_on_cpu(emu):
+    """every scan of the eligible progressive fixtures (and of random progressive files) comes back byte for byte from the plan
+    the batch compressor's GPU round-trip check uses; a file whose scan bytes were altered does not"""
+    from lepton_amd import corpus
+
+    seen = 0
+    files = [golden(n)[0] for n in golden_cases() if n.startswith("prog_")]
+    files += [corpus.synth_jpeg(160, 120, 501, progressive=True), corpus.synth_jpeg(203, 149, 502, progressive=True, subsampling="4:4:4", quality=95),
+              corpus.synth_jpeg(96, 64, 503, progressive=True, quality=30, subsampling="4:2:2")]
+    for jpg in files:
+        res = _progressive_check_on_the_emulation(emu, jpg)
+        if res is None:
+            continue
+        seen += 1
+        for length, got, want in res:
+            assert length == len(want) and got == want
+    assert seen >= 4
+    # and it notices a frame that is not the file's: one coefficient changed -> some scan no longer matches
+    def tweak(d):
+        arr = (C.c_int16 * 64).from_address(d.blocks[0] + 128 * 3)
+        arr[2] = arr[2] + 4 if arr[2] >= 0 else arr[2] - 4
+    res = _progressive_check_on_the_emulation(emu, files[-3], tweak)
+    assert res is not None and any(l != len(w) or g != w for l, g, w in res)
+
+
 @pytest.mark.parametrize("name", [n for n in golden_cases() if n.startswith("prog_")])
 def test_gpu_progressive_scan_encoder_on_cpu_restores_the_jpeg(emu, name):
     """lep_huffprog.h (DC / AC first-stage and refinement scans, end-of-band runs, held-back correction bits) as a lane-loop
