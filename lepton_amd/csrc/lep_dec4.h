@@ -446,10 +446,28 @@ struct Dec4Wave {
     template <int ALWAYS>
     WDEV void adapt_group(U4* W, const int* used, const int* bits) {
         const uint32_t* inv = sh->inv24;
+#ifdef LEP_DEC4_ADAPT_BRANCHY   // the previous form (A/B builds): per-slot ballot, the update under the lanes' exec mask
+        {
+            LV(int, any0);
+#define LEP_SLOT0(k, fld)                                                                                             \
+            LANES(l) L(any0) = (L(used) >> k) & 1;                                                                    \
+            if (lepwave::wave_ballot(any0)) {                                                                         \
+                LANES(l) if ((L(used) >> k) & 1) L(W).fld = bupd_t(L(W).fld, (uint32_t)(L(bits) >> k) & 1u, inv);    \
+            }
+            LEP_SLOT0(0, x) LEP_SLOT0(1, y) LEP_SLOT0(2, z) LEP_SLOT0(3, w)
+#undef LEP_SLOT0
+            return;
+        }
+#endif
         LV(int, any); LV(uint32_t, oldw); LV(uint32_t, low);
+#ifdef LEP_DEC4_ALWAYS_OVERRIDE
+        constexpr int kAlways = LEP_DEC4_ALWAYS_OVERRIDE;
+#else
+        constexpr int kAlways = ALWAYS;
+#endif
 #define LEP_SLOT(k, fld)                                                                                              \
-        if (!((ALWAYS >> k) & 1)) { LANES(l) L(any) = (L(used) >> k) & 1; }                                           \
-        if (((ALWAYS >> k) & 1) || lepwave::wave_ballot(any)) {                                                       \
+        if (!((kAlways >> k) & 1)) { LANES(l) L(any) = (L(used) >> k) & 1; }                                           \
+        if (((kAlways >> k) & 1) || lepwave::wave_ballot(any)) {                                                       \
             LANES(l) {                                                                                                \
                 const uint32_t w = L(W).fld;                                                                          \
                 const uint32_t u1 = ((uint32_t)(L(used) & L(bits)) >> k) & 1u, u0 = ((uint32_t)(L(used) & ~L(bits)) >> k) & 1u;   \

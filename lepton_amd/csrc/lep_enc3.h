@@ -210,17 +210,20 @@ struct Enc3Wave {
         int j = 0;
 #if LEP_ENC3_SCALAR_GROUPS > 0
 #pragma nounroll
-        for (; j + 16 <= n; j += 16) {   // 16 bins: LEP_ENC3_SCALAR_GROUPS groups on the scalar unit, the others on the vector ALU
+#ifndef LEP_ENC3_PERIOD
+#define LEP_ENC3_PERIOD 1   // how many 16-bin periods share one switch pair (A/B builds)
+#endif
+        for (; j + 16 * LEP_ENC3_PERIOD <= n; j += 16 * LEP_ENC3_PERIOD) {   // LEP_ENC3_SCALAR_GROUPS of 4 groups on the scalar unit, the others on the vector ALU
             BoolEnc3S sc;
             sc.load(bc);
 #pragma unroll
-            for (int g = 0; g < LEP_ENC3_SCALAR_GROUPS; ++g) {
+            for (int g = 0; g < LEP_ENC3_SCALAR_GROUPS * LEP_ENC3_PERIOD; ++g) {
                 const U4 q = ld4(B + j + 4 * g);
                 code_bin_s(sc, uni(q.x)); code_bin_s(sc, uni(q.y)); code_bin_s(sc, uni(q.z)); code_bin_s(sc, uni(q.w));
             }
             sc.store(bc);
 #pragma unroll
-            for (int g = LEP_ENC3_SCALAR_GROUPS; g < 4; ++g) {
+            for (int g = LEP_ENC3_SCALAR_GROUPS * LEP_ENC3_PERIOD; g < 4 * LEP_ENC3_PERIOD; ++g) {
                 const U4 q = ld4(B + j + 4 * g);
                 code_bin(vec(q.x)); code_bin(vec(q.y)); code_bin(vec(q.z)); code_bin(vec(q.w));
             }
