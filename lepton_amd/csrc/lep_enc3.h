@@ -183,9 +183,15 @@ struct BoolEnc3S {
     }
 };
 
-// of every 4 groups of four bins, how many the scalar form codes (0 = none, 4 = all)
-#ifndef LEP_ENC3_SCALAR_GROUPS
-#define LEP_ENC3_SCALAR_GROUPS 2   // measured (1024 x 4K, MI355X, profiles/r02o_encoder_ab.json): 0: 1186 ms, 1: 1107, 2: 1092, 3: 1159, 4: 1278
+// how the bins of a chunk alternate between the two forms: LEP_ENC3_SG groups of four bins on the scalar unit, then LEP_ENC3_VG
+// groups on the vector ALU, and so on (the tail of a chunk stays on the vector ALU).  Measured, 1024 x 4K, MI355X
+// (profiles/r02o_encoder_ab.json, r02t_knobs_ab.json, r02u_*): all vector 1186 ms; 1+3: 1107; 2+2: 1092 (1077 with the IDCT change);
+// 3+1: 1159; all scalar: 1278; 4+4: 1060
+#ifndef LEP_ENC3_SG
+#define LEP_ENC3_SG 4
+#endif
+#ifndef LEP_ENC3_VG
+#define LEP_ENC3_VG 4
 #endif
 
 struct Enc3Wave {
@@ -208,22 +214,19 @@ struct Enc3Wave {
         // (entries are read back from LDS at a uniform address, four at a time, and everything derived from them stays
         // on the vector ALU: a SALU instruction costs about two VALU ones here, profiles/r01_issue_microbench.txt)
         int j = 0;
-#if LEP_ENC3_SCALAR_GROUPS > 0
+#if LEP_ENC3_SG > 0
 #pragma nounroll
-#ifndef LEP_ENC3_PERIOD
-#define LEP_ENC3_PERIOD 1   // how many 16-bin periods share one switch pair (A/B builds)
-#endif
-        for (; j + 16 * LEP_ENC3_PERIOD <= n; j += 16 * LEP_ENC3_PERIOD) {   // LEP_ENC3_SCALAR_GROUPS of 4 groups on the scalar unit, the others on the vector ALU
+        for (; j + 4 * (LEP_ENC3_SG + LEP_ENC3_VG) <= n; j += 4 * (LEP_ENC3_SG + LEP_ENC3_VG)) {   // SG groups on the scalar unit, then VG on the vector ALU
             BoolEnc3S sc;
             sc.load(bc);
 #pragma unroll
-            for (int g = 0; g < LEP_ENC3_SCALAR_GROUPS * LEP_ENC3_PERIOD; ++g) {
+            for (int g = 0; g < LEP_ENC3_SG; ++g) {
                 const U4 q = ld4(B + j + 4 * g);
                 code_bin_s(sc, uni(q.x)); code_bin_s(sc, uni(q.y)); code_bin_s(sc, uni(q.z)); code_bin_s(sc, uni(q.w));
             }
             sc.store(bc);
 #pragma unroll
-            for (int g = LEP_ENC3_SCALAR_GROUPS * LEP_ENC3_PERIOD; g < 4 * LEP_ENC3_PERIOD; ++g) {
+            for (int g = LEP_ENC3_SG; g < LEP_ENC3_SG + LEP_ENC3_VG; ++g) {
                 const U4 q = ld4(B + j + 4 * g);
                 code_bin(vec(q.x)); code_bin(vec(q.y)); code_bin(vec(q.z)); code_bin(vec(q.w));
             }
