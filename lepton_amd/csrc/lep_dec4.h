@@ -187,10 +187,11 @@ struct BoolDec4 {
 #endif
         if (ucond(count < 0)) refill();
         const uint32_t big = split << 24;
-        const uint32_t bit = vhi >= big ? 1u : 0u;
-        const uint32_t d = vhi - big;
-        vhi = d < vhi ? d : vhi;                 // subtract only when it does not wrap, i.e. when bit = 1 (d == vhi iff big == 0: never)
-        range = bit ? range - split : split;
+        uint32_t d;
+        const bool below = __builtin_sub_overflow(vhi, big, &d);   // one subtract: the borrow is the decoded bit's complement
+        const uint32_t bit = below ? 0u : 1u;
+        vhi = below ? vhi : d;
+        range = below ? split : range - split;
 #ifdef LEP_TRACE_GET
         LEP_TRACE_GET(prob, (int)bit);
 #endif

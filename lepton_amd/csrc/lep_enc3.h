@@ -30,7 +30,7 @@ constexpr int kMaxDup3 = 160;                  // 14 * 10 threshold bins
 constexpr uint32_t kResident3 = 1u << 30;      // bin whose Branch lives in LDS (sign table); resolved by the coder loop
 
 struct Enc3Shared {
-    alignas(16) uint32_t bins[kBinChunk];   // P2: branch index | bit << 31;  after P3: probability | bit << 8
+    alignas(16) uint32_t bins[kBinChunk];   // P2: branch index | bit << 31;  after P3: probability | bit << 31
     uint16_t dup[kMaxDup3];     // positions (into bins) of bins whose Branch may repeat within the block
     uint32_t sign[96];          // the sign Branches live in LDS for the whole segment (never written back)
     alignas(16) int32_t t[64];              // IDCT intermediate
@@ -114,13 +114,13 @@ struct BoolEnc3 {
         return *p;
 #endif
     }
-    WDEV void put(uint32_t bit, uint32_t prob) {
+    WDEV void put(uint32_t bit, uint32_t prob) { put_m(0u - bit, prob); }
+    WDEV void put_m(uint32_t m, uint32_t prob) {   // m = 0 / 0xffffffff: the bit as a mask (the bin list keeps the bit in bit 31: one arithmetic shift)
 #if LEP_ON_GPU
         const uint32_t split = 1 + (__umul24(range - 1, prob) >> 8);
 #else
         const uint32_t split = 1 + (((range - 1) * prob) >> 8);
 #endif
-        const uint32_t m = 0u - bit;
         uint32_t l = low + (split & m);
         uint32_t r = split + ((range - 2 * split) & m);
         int shift = __builtin_clz(r) - 24;
@@ -308,7 +308,7 @@ struct Enc3Wave {
             const uint32_t w = uni(sh->sign[slot]);
             sc.put(bc, bit, w >> 16);
             sh->sign[slot] = bupd_uv(vec(w), vec(bit));
-        } else sc.put(bc, (e >> 8) & 1, e & 255);
+        } else sc.put(bc, e >> 31, e & 255);
     }
     // one entry of the resolved bin list through the bool coder (uniform vector value e)
     WDEV void code_bin(uint32_t e) {
@@ -317,7 +317,7 @@ struct Enc3Wave {
             const uint32_t w = sh->sign[slot];
             bc.put(bit, w >> 16);
             sh->sign[slot] = bupd_uv(w, bit);
-        } else bc.put((e >> 8) & 1, e & 255);
+        } else bc.put_m((uint32_t)((int32_t)e >> 31), e & 255);
     }
 
     // Encodes the block staged in sh->here (+ left / above / aleft when present).  Returns 0 or an exit code (uniform).
@@ -576,7 +576,7 @@ struct Enc3Wave {
                                 const uint32_t w = h ? L(w1) : L(w0);
                                 const int bit = (int)(e >> 31);
                                 model[idx] = bupd(w, bit);
-                                B[j] = (w >> 16) | ((uint32_t)bit << 8);
+                                B[j] = (w >> 16) | ((uint32_t)bit << 31);
                             }
                         }
                     }
@@ -608,7 +608,7 @@ struct Enc3Wave {
                 }
                 if (!lepwave::wave_ballot(conf)) {
                     LANES(l) if (l < nn) {
-                        B[L(djpos)] = (L(dw) >> 16) | (L(dbit) << 8);
+                        B[L(djpos)] = (L(dw) >> 16) | (L(dbit) << 31);
                         model[L(didx)] = bupd(L(dw), (int)L(dbit));
                     }
                 } else {
@@ -616,7 +616,7 @@ struct Enc3Wave {
                         const uint32_t ridx = lepwave::wave_read(didx, r), rw = lepwave::wave_read(dw, r), rbit = lepwave::wave_read(dbit, r);
                         const uint32_t nw = bupd_s(rw, (int)rbit);
                         LANES(l) {
-                            if (l == r) { B[L(djpos)] = (rw >> 16) | (rbit << 8); L(dw) = nw; }
+                            if (l == r) { B[L(djpos)] = (rw >> 16) | (rbit << 31); L(dw) = nw; }
                             else if (L(didx) == ridx) { if (l > r) L(dw) = nw; else L(dlast) = 0; }
                         }
                     }
