@@ -939,7 +939,7 @@ struct Dec4Wave {
                 L(s1) = (l >= 8 && l < 16) ? ev : 0;
             }
             const int mx = lepwave::wave_max(emax), mn = -lepwave::wave_max(emin);
-            const int sumL = lepwave::wave_excl_scan(s0, tmp), sumA = lepwave::wave_excl_scan(s1, tmp);
+            const int sumL = lepwave::wave_sum(s0), sumA = lepwave::wave_sum(s1);
             int32_t avgmed = 0, unc = 0, unc2 = 0;
             if (has_left || has_above) {
                 int sum0 = has_left ? sumL : sumA, sum1 = (has_left && has_above) ? sumA : sum0;

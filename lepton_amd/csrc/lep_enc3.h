@@ -219,13 +219,13 @@ struct Enc3Wave {
         for (; j + 4 * (LEP_ENC3_SG + LEP_ENC3_VG) <= n; j += 4 * (LEP_ENC3_SG + LEP_ENC3_VG)) {   // SG groups on the scalar unit, then VG on the vector ALU
             BoolEnc3S sc;
             sc.load(bc);
-#pragma unroll
+#pragma unroll   // (rolled: a third of the code, 1.5 % slower -- profiles/r02x_dpp_ab.json)
             for (int g = 0; g < LEP_ENC3_SG; ++g) {
                 const U4 q = ld4(B + j + 4 * g);
                 code_bin_s(sc, uni(q.x)); code_bin_s(sc, uni(q.y)); code_bin_s(sc, uni(q.z)); code_bin_s(sc, uni(q.w));
             }
             sc.store(bc);
-#pragma unroll
+#pragma unroll   // (rolled: a third of the code, 1.5 % slower -- profiles/r02x_dpp_ab.json)
             for (int g = LEP_ENC3_SG; g < LEP_ENC3_SG + LEP_ENC3_VG; ++g) {
                 const U4 q = ld4(B + j + 4 * g);
                 code_bin(vec(q.x)); code_bin(vec(q.y)); code_bin(vec(q.z)); code_bin(vec(q.w));
@@ -367,7 +367,7 @@ struct Enc3Wave {
                 L(s1) = (l >= 8 && l < 16) ? ev : 0;
             }
             const int mx = lepwave::wave_max(emax), mn = -lepwave::wave_max(emin);
-            const int sumL = lepwave::wave_excl_scan(s0, tmp), sumA = lepwave::wave_excl_scan(s1, tmp);
+            const int sumL = lepwave::wave_sum(s0), sumA = lepwave::wave_sum(s1);
             if (has_left || has_above) {
                 int sum0 = has_left ? sumL : sumA, sum1 = (has_left && has_above) ? sumA : sum0;
                 dc_avgmed = (sum0 + sum1) >> 1;
@@ -538,7 +538,7 @@ struct Enc3Wave {
             (void)D;
             LEP_EMARK("e_p3a");
         LV(int, dtmp);
-            const int Dn = lepwave::wave_excl_scan(dcount, dtmp);   // threshold bins in this range
+            const int Dn = lepwave::wave_sum(dcount);   // threshold bins in this range
             LSYNC();
 
             // ---- P3: model words of all bins of the range in ONE HBM round trip ------------------------------

@@ -46,31 +46,61 @@ WDEV uint64_t wave_ballot(const int* pred) {
 #endif
 }
 
+// Cross-lane reductions and scans on the DPP path of the vector ALU: 4 row_shr steps inside the 16-lane rows, row_bcast15 /
+// row_bcast31 across them -- six v_add / v_max instructions.  (The __shfl forms these replace are ds_bpermute_b32 underneath:
+// an LDS instruction per step, ~6 cycles per CU each against ~1 for a DPP op, profiles/r02n_inst_rates.txt; the coder kernels
+// run 6 (decoder) to 9 (encoder) of these per 8x8 block.)
+#if LEP_ON_GPU
+template <int CTRL, int ROW_MASK>
+WDEV int dpp_or(int keep, int v) { return __builtin_amdgcn_update_dpp(keep, v, CTRL, ROW_MASK, 0xf, false); }   // lanes without a source get `keep`
+WDEV int wave_incl_sum(int v) {
+    v += dpp_or<0x111, 0xf>(0, v);   // row_shr:1
+    v += dpp_or<0x112, 0xf>(0, v);   // row_shr:2
+    v += dpp_or<0x114, 0xf>(0, v);   // row_shr:4
+    v += dpp_or<0x118, 0xf>(0, v);   // row_shr:8
+    v += dpp_or<0x142, 0xa>(0, v);   // row_bcast15 into rows 1 and 3
+    v += dpp_or<0x143, 0xc>(0, v);   // row_bcast31 into rows 2 and 3
+    return v;
+}
+WDEV int wave_incl_max(int v) {
+    const int lo = (int)0x80000000;
+    int t;
+    t = dpp_or<0x111, 0xf>(lo, v); v = t > v ? t : v;
+    t = dpp_or<0x112, 0xf>(lo, v); v = t > v ? t : v;
+    t = dpp_or<0x114, 0xf>(lo, v); v = t > v ? t : v;
+    t = dpp_or<0x118, 0xf>(lo, v); v = t > v ? t : v;
+    t = dpp_or<0x142, 0xa>(lo, v); v = t > v ? t : v;
+    t = dpp_or<0x143, 0xc>(lo, v); v = t > v ? t : v;
+    return v;
+}
+#endif
+
 // exclusive prefix sum over lanes; returns the total
 WDEV int wave_excl_scan(const int* in, int* out) {
 #if LEP_ON_GPU
-    const int lane = (int)(threadIdx.x & 63);
-    int v = in[0], s = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(s, d, 64);
-        if (lane >= d) s += t;
-    }
+    const int v = in[0], s = wave_incl_sum(v);
     out[0] = s - v;
-    return __builtin_amdgcn_readfirstlane(__shfl(s, 63, 64));
+    return __builtin_amdgcn_readlane(s, 63);
 #else
     int s = 0;
     for (int i = 0; i < 64; ++i) { int v = in[i]; out[i] = s; s += v; }
     return s;
 #endif
 }
+// sum over all lanes
+WDEV int wave_sum(const int* in) {
+#if LEP_ON_GPU
+    return __builtin_amdgcn_readlane(wave_incl_sum(in[0]), 63);
+#else
+    int s = 0;
+    for (int i = 0; i < 64; ++i) s += in[i];
+    return s;
+#endif
+}
 
 WDEV int wave_max(const int* in) {
 #if LEP_ON_GPU
-    int v = in[0];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { int t = __shfl_xor(v, d, 64); v = t > v ? t : v; }
-    return __builtin_amdgcn_readfirstlane(v);
+    return __builtin_amdgcn_readlane(wave_incl_max(in[0]), 63);
 #else
     int m = in[0];
     for (int i = 1; i < 64; ++i) m = in[i] > m ? in[i] : m;
