@@ -11,7 +11,13 @@
 #define LEP_ON_GPU 1
 #define LEP_NL 1
 #define LEP_LI(l) 0
-#define LANES(l) for (int l = (int)(threadIdx.x & 63), lep_once_ = 1; lep_once_; lep_once_ = 0)
+// The lane index is made opaque at every use (an empty asm the optimiser cannot see through): everything derived from it alone
+// -- LDS addresses, tap offsets, masks -- is otherwise a loop invariant of the block loop, gets hoisted out of it and, in kernels
+// pinned at 64 VGPRs, spilled: every block then reloaded ~20 such values from scratch (a memory instruction each) instead of
+// redoing a vector add.  With it the coder kernels' scratch drops from 164 / 196 to 8 / 16 bytes per lane and they run 4 % / 3 %
+// faster (profiles/r03b_lane_index_ab.json).
+static __device__ __forceinline__ int lep_lane_now() { int v = (int)(threadIdx.x & 63); __asm__ volatile("" : "+v"(v)); return v; }
+#define LANES(l) for (int l = lep_lane_now(), lep_once_ = 1; lep_once_; lep_once_ = 0)
 #define WSYNC() __syncthreads()
 // One wavefront per workgroup: lanes run in lockstep and a wave's LDS / global accesses are performed in program
 // order, so handing data between lanes needs no s_barrier and no counter drain -- only that the COMPILER keeps the
