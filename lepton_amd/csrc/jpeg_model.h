@@ -51,13 +51,16 @@ constexpr uint64_t kMaxFrameBlocks = 4423680;   // (576 MiB - 36 MiB) / 128 B, t
 
 struct HuffTable {
     bool set = false;
-    uint16_t clen[256];
-    uint16_t cval[256];
-    uint16_t l[256], r[256];   // decoding tree, leaf = 256 + symbol
+    // zero-filled until a DHT segment defines the table: the reference's tables are zeroed globals, and a file that codes with
+    // a table it never defined (a progressive header forced through the baseline re-coder by a hostile flag byte) is written
+    // with zero-length codes there -- found by the structured differential fuzz as a run-to-run difference
+    uint16_t clen[256] = {};
+    uint16_t cval[256] = {};
+    uint16_t l[256] = {}, r[256] = {};   // decoding tree, leaf = 256 + symbol
     int max_eobrun = 0;
     // first-level lookup derived FROM the tree (so that odd tables decode exactly as the walk does): index = the next 10
     // bits, entry = code length << 8 | symbol, 0 = longer than 10 bits or no such code (the bit-by-bit walk decides)
-    uint16_t lut[1024];
+    uint16_t lut[1024] = {};
 };
 
 struct JpegFile {

@@ -141,6 +141,9 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
     if (lf->embedded || !lf->has_prefix) {
         plan->head.push_back(0xFF); plan->head.push_back(0xD8);
         plan->head.insert(plan->head.end(), h, h + std::min(pos, hdrs));
+        // an SOS whose length field reaches past the stored header: the reference writes `pos` bytes from its header buffer
+        // (handle_initial_segments, recoder.cc:443-456), i.e. reads on into zero-filled arena memory -- zeros up to the bound
+        if (pos > hdrs) plan->head.resize(plan->head.size() + std::min(pos - hdrs, plan->scan_bound), 0);
     }
     if (plan->head.size() > plan->scan_bound) plan->head.resize(plan->scan_bound);
 
@@ -270,6 +273,7 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
     if (lf->embedded || !lf->has_prefix) {
         out.put(0xFF); out.put(0xD8);
         out.write(h, std::min(pos, hdrs));
+        for (size_t k = hdrs; k < pos; ++k) out.put(0);   // (see recode_prepare: a length field past the stored header)
     }
 
     // 2. the scan, segment by segment

@@ -134,3 +134,39 @@ def test_lep_container_rules_found_by_the_structure_aware_fuzz():
         LepFile(mu.lep_join(fixed, payload + bytes(1000), rest))        # "unknown data found" -> errorlevel 2 (jpgcoder.cc:4326-4337)
     assert e.value.code == 42
     LepFile(mu.lep_join(fixed, payload + b"CMP" + bytes(50), rest))     # an explicit end mark stops the section loop
+
+
+def test_recoder_rules_found_by_the_structure_aware_fuzz():
+    """two things the differential fuzz against the reference binary turned up in the baseline re-coder, both reached only through
+    a hostile flag byte: (1) a progressive header forced through it codes with Huffman tables no DHT before the first SOS
+    defined -- the reference's tables are zeroed globals (zero-length codes), ours were uninitialised memory and the output
+    changed from run to run; (2) an SOS whose length field reaches past the stored header -- the reference writes that many
+    bytes from its (zero-filled) header arena, recoder.cc:443-456.  Outputs below were checked byte for byte against
+    oracle/_ref/lepton (tests/fuzz/diff_lep_structured.py, seeds 4242 / 777 / 9001)."""
+    sys.path.insert(0, FUZZ)
+    import hashlib
+    import mutate as mu
+    import oracle_binding as ob
+    from lepton_amd.codec import LepFile
+
+    def restore(lep):
+        f = LepFile(lep)
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        return f.recode()
+
+    # (1) prog_truncated_mid with the flag byte forced odd: deterministic, and the short output of zero-length codes
+    lep = bytearray(golden("prog_truncated_mid")[1]); lep[3] = 0x7F
+    outs = {hashlib.md5(restore(bytes(lep))).hexdigest() for _ in range(4)}
+    assert len(outs) == 1
+    assert len(restore(bytes(lep))) < len(golden("prog_truncated_mid")[0])
+    # (2) the SOS length of a baseline file set to 0xffff, flag byte odd: header, then zeros up to the file's size
+    fixed, payload, rest = mu.lep_split(golden("lay_all22_64x48")[1])
+    k = payload.rfind(b"\xff\xda\x00\x0c")
+    assert k > 0
+    bad = payload[: k + 2] + b"\xff\xff" + payload[k + 4:]
+    fixed = bytearray(fixed); fixed[3] = 0x3F
+    out = restore(mu.lep_join(bytes(fixed), bad, rest))
+    jpg = golden("lay_all22_64x48")[0]
+    assert len(out) == len(jpg)
+    sos = out.find(b"\xff\xda\xff\xff")
+    assert sos > 0 and out[: sos] == jpg[: sos] and set(out[sos + 14: -2]) == {0} and out[-2:] == b"\xff\xd9"
