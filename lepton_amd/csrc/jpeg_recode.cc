@@ -62,6 +62,7 @@ struct RowCoder {
     LepFile& lf;
     JpegFile& jf;
     int ncomp;
+    int seg_first_mcu_row = 0;   // first MCU row of the thread segment being written
     RowCoder(LepFile& l) : lf(l), jf(l.jpeg), ncomp(l.jpeg.ncomp) {}
 
     // Huffman-code one MCU row starting at MCU index `mcu`; false on error
@@ -77,6 +78,17 @@ struct RowCoder {
             int sta = 0;
             while (sta == 0) {
                 const int16_t* src = jf.plane[cmp] + (size_t)dpos * 64;
+                if (jf.early_eof && dpos >= jf.trunc_bc[cmp]) {
+                    // A block behind the point where the file was cut: the reference's baseline decoder keeps only two block rows
+                    // per component (block_based_image.hh:60-66,84-95) and never touches these blocks, so its re-coder reads what
+                    // row y - 2 left in the ring (zeros if this thread never decoded that row).  Unobservable in an intact file --
+                    // the byte bound cuts the output first -- but not when damaged streams make the scan shorter
+                    // (tests/test_fuzz_host.py::test_recoder_rules_...).
+                    static const int16_t kZeroBlock[64] = {0};
+                    const Component& kc = jf.comp[cmp];
+                    const int up = dpos - 2 * kc.bch, mult = std::max(kc.bcv / std::max(jf.mcuv, 1), 1);
+                    src = (up >= 0 && (up / kc.bch) / mult >= seg_first_mcu_row) ? jf.plane[cmp] + (size_t)up * 64 : kZeroBlock;
+                }
                 for (int b = 0; b < 64; ++b) blk[b] = src[kZigzagToAligned[b]];
                 int16_t dc = blk[0];
                 blk[0] = (int16_t)(blk[0] - lastdc[cmp]);
@@ -301,6 +313,7 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
         w.seed(th.overhang_byte, th.num_overhang_bits);
         int16_t lastdc[4];
         memcpy(lastdc, th.last_dc, sizeof lastdc);
+        rc.seg_first_mcu_row = th.luma_y_start / std::max(luma_mul, 1);
         for (int mcu_row = 0; mcu_row < jf.mcuv; ++mcu_row) {
             int y0 = mcu_row * luma_mul, y1 = y0 + luma_mul;
             if (y0 >= jf.trunc_bcv[0]) break;                 // rows past the coded height are skipped

@@ -15,6 +15,7 @@
  * One routine serves both directions so the encoder and decoder cannot drift apart.
  */
 #include "lepton_oracle.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -160,6 +161,9 @@ static int rd(Coder *c, unsigned prob) {
     if (bit) { c->range -= split; c->value -= bigsplit; } else c->range = split;
     shift = norm_shift(c->range);
     c->range <<= shift; c->value <<= shift; c->rcount -= shift;
+#ifdef LEP_ORACLE_TRACE   /* the reference's own -DDEBUG_ARICODER format ("R <n> <prob> <bit>", boolreader.hh:397-413): diffable bin traces */
+    { static long n_traced = 0; fprintf(stderr, "R %ld %u %d\n", n_traced++, prob, bit); }
+#endif
     return bit;
 }
 

@@ -170,3 +170,24 @@ def test_recoder_rules_found_by_the_structure_aware_fuzz():
     assert len(out) == len(jpg)
     sos = out.find(b"\xff\xda\xff\xff")
     assert sos > 0 and out[: sos] == jpg[: sos] and set(out[sos + 14: -2]) == {0} and out[-2:] == b"\xff\xd9"
+
+
+def test_blocks_behind_a_truncation_point_are_the_ring_rows():
+    """a truncated baseline file whose second stream packet is dropped: the bool decoder runs into zeros, the scan comes out shorter
+    than the file's byte bound, and what the re-coder writes for the blocks BEHIND the point where the JPEG was cut becomes
+    visible: the reference's baseline decoder keeps two block rows per component and its re-coder reads row y - 2 there
+    (block_based_image.hh:60-66,84-95), not zeros.  Output pinned to the reference binary's (5745 bytes, md5 below; found by the
+    byte-level differential fuzz as "both succeed with different bytes")."""
+    import hashlib
+    import struct
+    import oracle_binding as ob
+    from lepton_amd.codec import LepFile
+
+    lep = golden("truncated")[1]
+    at = 28 + struct.unpack("<I", lep[24:28])[0] + 3
+    assert lep[at] == 0x10                                   # a 4096-byte packet of stream 0
+    cut = lep[: at + 1 + 4096] + lep[-4:]
+    f = LepFile(cut)
+    ob.oracle_decode(f.desc, f.segments, f.streams)
+    out = f.recode()
+    assert len(out) == 5745 and hashlib.md5(out).hexdigest() == "7b0b34cb4ca9001f1b4f321619826b63"
