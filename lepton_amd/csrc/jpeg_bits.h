@@ -25,6 +25,20 @@ struct BitReader {
     unsigned read(int nbits) {
         if (eof || !nbits) return 0;
         unsigned out;
+        if (nbits > 32 && avail > 0) {
+            // Only a corrupt DHT gets here (a DC category used as a bit count).  How many bits such a read consumes in the
+            // reference depends on where its 8-byte buffer stands (at most what is left in it + one refill, bitops.hh:262-300),
+            // and top_up() keeps this window fuller than that: fall back to the reference's phase first -- its buffer is
+            // refilled every 64 consumed bits counted from the start of the data -- then read as it does.
+            const long consumed = (long)next_byte * 8 - avail;
+            const int cb = (int)((64 - consumed % 64) % 64);   // what the reference's buffer still holds
+            if (cb <= avail && ((avail - cb) & 7) == 0) {        // (near the end of the data there may be nothing to give back)
+                const int drop = (avail - cb) >> 3;
+                next_byte -= drop;
+                window = drop >= 8 ? 0 : window >> (drop * 8);
+                avail = cb;
+            }
+        }
         if (nbits >= avail) {
             int took = avail;
             // nbits can be anything up to 255 on a corrupt DHT (a DC category is used as a bit count unchecked, like the

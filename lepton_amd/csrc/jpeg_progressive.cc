@@ -325,6 +325,16 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
     std::vector<size_t> scan_hdr_end;   // header position after each SOS
     size_t hpos = 0;
     int16_t blk[64];
+    // A truncated file decoded on one thread: the reference's decoder runs only as far as its re-coder WAITS for it, and that
+    // wait is clamped to the last block the JPEG held (wait_for_worker_on_dpos, uncompressed_components.hh:206-216) -- the first
+    // block of each later row, which the stream does code (decode_row always takes a row's first block), is never decoded and
+    // its re-coder reads zeros.  Invisible in an intact file (the byte bound cuts the output first); found by the byte-level
+    // differential fuzz with a damaged stream.  (Several segments: worker threads decode their rows eagerly; nothing to emulate.)
+    static const int16_t kNeverDecoded[64] = {0};
+    const bool lazy_tail = jf.early_eof && lf->segs.size() == 1;
+    auto block_at = [&](int c, int d) -> const int16_t* {
+        return (lazy_tail && d >= jf.trunc_bc[c]) ? kNeverDecoded : jf.plane[c] + (size_t)d * 64;
+    };
     for (;;) {
         uint8_t type = 0;
         while (type != 0xDA) {
@@ -344,10 +354,10 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
             int lastdc[4] = {0, 0, 0, 0};
             int sta = 0, rstw = jf.rsti;
             unsigned eobrun = 0;
-            auto dc_of = [&](int c, int d) -> int { return jf.plane[c][(size_t)d * 64 + kZigzagToAligned[0]]; };
+            auto dc_of = [&](int c, int d) -> int { return block_at(c, d)[kZigzagToAligned[0]]; };
             // one whole block of component cmp at dpos, sequential coding (encode_block_seq, jpgcoder.cc:5009-5066)
             auto sequential_block = [&]() {
-                const int16_t* src = jf.plane[cmp] + (size_t)dpos * 64;
+                const int16_t* src = block_at(cmp, dpos);
                 for (int b = 0; b < 64; ++b) blk[b] = src[kZigzagToAligned[b]];
                 const int16_t dc = blk[0];
                 blk[0] = (int16_t)(blk[0] - lastdc[cmp]);
@@ -418,7 +428,7 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
             } else {
                 const HuffTable& act = jf.htab[1][jf.comp[cmp].ac_tbl];
                 while (sta == 0) {
-                    const int16_t* src = jf.plane[cmp] + (size_t)dpos * 64;
+                    const int16_t* src = block_at(cmp, dpos);
                     for (int b = from; b <= to; ++b) blk[b] = (int16_t)fdiv2(src[kZigzagToAligned[b]], sal);
                     if (jf.cs_sah == 0) encode_ac_first(sw, act, blk, &eobrun, from, to);
                     else encode_ac_refine(sw, act, blk, &eobrun, from, to);

@@ -78,7 +78,7 @@ struct RowCoder {
             int sta = 0;
             while (sta == 0) {
                 const int16_t* src = jf.plane[cmp] + (size_t)dpos * 64;
-                if (jf.early_eof && dpos >= jf.trunc_bc[cmp]) {
+                if (jf.early_eof && dpos >= jf.trunc_bc[cmp] && dpos % jf.comp[cmp].bch != 0) {   // (a row's first block is always decoded: decode_row, lepton_codec.cc:7-47)
                     // A block behind the point where the file was cut: the reference's baseline decoder keeps only two block rows
                     // per component (block_based_image.hh:60-66,84-95) and never touches these blocks, so its re-coder reads what
                     // row y - 2 left in the ring (zeros if this thread never decoded that row).  Unobservable in an intact file --

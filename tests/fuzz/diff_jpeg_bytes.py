@@ -31,16 +31,17 @@ for trial in range(N):
     if os.path.exists(lp): os.unlink(lp)
     try:
         r=subprocess.run([REF,'-unjailed','-skipverify',jp,lp],capture_output=True,timeout=60); rc=r.returncode
+        codes={'ASSERTION_FAILURE':1,'CODING_ERROR':2,'SHORT_READ':3,'UNSUPPORTED_4_COLORS':4,'THREAD_PROTOCOL_ERROR':5,'COEFFICIENT_OUT_OF_RANGE':6,'STREAM_INCONSISTENT':7,'PROGRESSIVE_UNSUPPORTED':8,'FILE_NOT_FOUND':9,'SAMPLING_BEYOND_TWO_UNSUPPORTED':10,'SAMPLING_BEYOND_FOUR_UNSUPPORTED':11,'THREADING_PARTIAL_MCU':12,'VERSION_UNSUPPORTED':13,'ONLY_GARBAGE_NO_JPEG':14,'OS_ERROR':33,'HEADER_TOO_LARGE':34,'DIMENSIONS_TOO_LARGE':35,'MALLOCED_NULL':36,'OOM':37,'TOO_MUCH_MEMORY_NEEDED':38,'EARLY_EXIT':40,'ROUNDTRIP_FAILURE':41,'UNSUPPORTED_JPEG':42,'UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0':43}
+        named=[l.strip() for l in r.stderr.decode('latin1').split('\n') if l.strip() in codes]
+        if named: rc=codes[named[-1]]      # a failing run names its exit code on stderr whatever the process status says (and may leave a partial file)
         want=open(lp,'rb').read() if rc==0 and os.path.exists(lp) and os.path.getsize(lp)>0 else None
-        if want is None:
-            codes={'ASSERTION_FAILURE':1,'CODING_ERROR':2,'SHORT_READ':3,'UNSUPPORTED_4_COLORS':4,'THREAD_PROTOCOL_ERROR':5,'COEFFICIENT_OUT_OF_RANGE':6,'STREAM_INCONSISTENT':7,'PROGRESSIVE_UNSUPPORTED':8,'FILE_NOT_FOUND':9,'SAMPLING_BEYOND_TWO_UNSUPPORTED':10,'SAMPLING_BEYOND_FOUR_UNSUPPORTED':11,'THREADING_PARTIAL_MCU':12,'VERSION_UNSUPPORTED':13,'ONLY_GARBAGE_NO_JPEG':14,'OS_ERROR':33,'HEADER_TOO_LARGE':34,'DIMENSIONS_TOO_LARGE':35,'MALLOCED_NULL':36,'OOM':37,'TOO_MUCH_MEMORY_NEEDED':38,'EARLY_EXIT':40,'ROUNDTRIP_FAILURE':41,'UNSUPPORTED_JPEG':42,'UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0':43}
-            last=[l for l in r.stderr.decode('latin1').split('\n') if l.strip() in codes]
-            rc=codes[last[-1].strip()] if last else rc
     except subprocess.TimeoutExpired: want=None; rc='timeout'
     try:
         img=JpegImage(b); segs=img.plan(); streams,_=ob.oracle_encode(img.desc,segs); got=img.write_lep(streams); code=0
     except LeptonError as e: got=None; code=e.code
-    except RuntimeError as e: got=None; code=str(e)
+    except RuntimeError as e:
+        got=None; code=str(e)
+        if 'exit code' in code: code=int(code.rsplit(' ',1)[1])
     if got!=want or (got is None and code!=rc and isinstance(rc,int) and rc>=0):
         bad+=1; print('DIFF',trial,kind,name,'ref',rc,None if want is None else len(want),'ours',code,None if got is None else len(got)); open('/tmp/jdiff_%d_%d.jpg'%(seed,trial),'wb').write(b)
     elif got is None: refused+=1

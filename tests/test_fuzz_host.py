@@ -191,3 +191,40 @@ def test_blocks_behind_a_truncation_point_are_the_ring_rows():
     ob.oracle_decode(f.desc, f.segments, f.streams)
     out = f.recode()
     assert len(out) == 5745 and hashlib.md5(out).hexdigest() == "7b0b34cb4ca9001f1b4f321619826b63"
+
+
+def test_lazy_decode_rules_of_truncated_files():
+    """three more places where what the reference's re-coder reads for a truncated file is not what its stream codes -- all invisible in
+    an intact file (the byte bound cuts the output first), all found by the differential fuzz with damaged streams or headers:
+    a baseline row's FIRST block is decoded even behind the truncation point (decode_row always takes it), so the two-row-ring rule
+    excludes it; a one-thread PROGRESSIVE file's blocks behind the point are never decoded at all (the decoder only runs as far as
+    the re-coder waits for it, and that wait is clamped to the last block the JPEG held); and a DC category > 32 from a corrupt DHT,
+    used as a bit count, consumes what is left of the reference's 8-byte buffer plus one refill."""
+    import hashlib
+    import struct
+    import zlib
+    sys.path.insert(0, FUZZ)
+    import mutate as mu
+    import oracle_binding as ob
+    from lepton_amd.codec import JpegImage, LepFile, LeptonError
+
+    def restore(lep):
+        f = LepFile(lep)
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        return f.recode()
+
+    # header cut inside the EEE section: every component "held" one block; row 1's first luma block is still decoded and written
+    fixed, payload, rest = mu.lep_split(golden("truncated")[1])
+    k = payload.find(b"EEE")
+    out = restore(mu.lep_join(fixed, payload[: k + 14], rest))
+    assert len(out) == 724 and hashlib.md5(out).hexdigest() == "6ee884c157102edb5dcd2379d2f3e783"
+    # progressive, one thread, one damaged stream byte: the tail block the stream codes is written as zeros
+    lep = bytearray(golden("prog_truncated_dc")[1]); lep[844] ^= 4
+    out = restore(bytes(lep))
+    assert len(out) == 1100 and hashlib.md5(out).hexdigest() == "2c92db3a672a0476b06a1baaa7fe55d1"
+    # a DC Huffman table with category 0x58: both sides get as far as the coder and refuse with COEFFICIENT_OUT_OF_RANGE
+    jpg = bytearray(golden("trailing_garbage")[0]); assert jpg[205] == 0x07; jpg[205] = 0x58
+    img = JpegImage(bytes(jpg))
+    with pytest.raises(RuntimeError) as e:
+        ob.oracle_encode(img.desc, img.plan())
+    assert "exit code 6" in str(e.value)
