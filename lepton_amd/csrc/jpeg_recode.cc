@@ -241,6 +241,15 @@ int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pa
     out.bound = plan.scan_bound;
     out.buf.reserve(max_file_size + 16);
     out.write(plan.head.data(), plan.head.size());
+    // (the GPU encoder does not hand back the bit state a segment ends in; what can be held against the hand-offs here is the
+    // byte count: a segment that restores its part of the file exactly writes exactly segment_size bytes -- see recode_jpeg for
+    // the reference's assertions; a truncated .lep fails this on the segment whose stream ran dry)
+    if (seg_bytes.size() == lf->segs.size())
+        for (size_t q = 0; q + 1 < seg_bytes.size(); ++q) {
+            const Handoff& nx = lf->segs[q + 1];
+            if (nx.num_overhang_bits == 0xff || !(nx.luma_y_start != nx.luma_y_end || lf->version == 1)) continue;
+            if (seg_bytes[q].second != lf->segs[q].segment_size && !(q == 0 && out.buf.size() + seg_bytes[q].second >= out.bound)) return EX_ASSERTION_FAILURE;
+        }
     for (const auto& sb : seg_bytes) out.write(sb.first, sb.second);
     if (!jf.rst_err.empty()) {
         unsigned cum = jf.rsti ? (unsigned)((jf.mcuh * jf.mcuv - 1) / jf.rsti) : 0;
@@ -325,6 +334,18 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
         carry.overhang_byte = w.overhang_byte();
         carry.num_overhang_bits = (uint8_t)w.overhang_bits();
         memcpy(carry.last_dc, lastdc, sizeof lastdc);
+        // The state a thread segment ends in must be the state the next hand-off recorded -- the reference asserts it
+        // (recode_physical_thread, recoder.cc:625-640) and that is what stops a truncated or damaged multi-segment .lep from being
+        // "restored" as garbage: partial byte, its bit count, the last DC of every component, and for every thread but the first a
+        // segment that fills its byte bound exactly.  (Skipped, as there, for an empty next segment of a format >= 2 file.)
+        if (s + 1 < lf->segs.size()) {
+            const Handoff& nx = lf->segs[s + 1];
+            if (nx.num_overhang_bits != 0xff && (nx.luma_y_start != nx.luma_y_end || lf->version == 1)) {
+                if (carry.num_overhang_bits != nx.num_overhang_bits || carry.overhang_byte != nx.overhang_byte) return EX_ASSERTION_FAILURE;
+                if (memcmp(carry.last_dc, nx.last_dc, 3 * sizeof(int16_t))) return EX_ASSERTION_FAILURE;
+                if (s > 0 && o == &seg && !seg.buf.empty() && seg.bound != seg.buf.size()) return EX_ASSERTION_FAILURE;
+            }
+        }
         if (o == &seg) out.write(seg.buf.data(), seg.buf.size());
         else if (out.bound != file_bound) { out.bound = file_bound; out.attempted = out.buf.size(); }
     }

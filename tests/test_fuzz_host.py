@@ -228,3 +228,29 @@ def test_lazy_decode_rules_of_truncated_files():
     with pytest.raises(RuntimeError) as e:
         ob.oracle_encode(img.desc, img.plan())
     assert "exit code 6" in str(e.value)
+
+
+def test_a_truncated_multi_segment_file_is_refused_like_the_reference():
+    """the state a thread segment ends in must be the state the next hand-off recorded (recode_physical_thread, recoder.cc:625-640:
+    partial byte and its bit count, last DC per component, a bound filled exactly): a .lep cut inside its first segment's stream
+    decodes "successfully" into zeros, and it is these assertions that refuse it (the reference aborts with "Assert Failed:
+    outth.num_overhang_bits == ..."); cut further back, both sides restore the same shorter file.  Probed against the reference
+    binary at six cut points of two fixtures."""
+    import hashlib
+    import oracle_binding as ob
+    from lepton_amd.codec import LepFile, LeptonError
+
+    lep = golden("q30_256x256_4seg")[1]
+    for frac in (0.15, 0.30, 0.45):
+        f = LepFile(lep[: int(len(lep) * frac)])
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        with pytest.raises(LeptonError) as e:
+            f.recode()
+        assert e.value.code == 1
+    for frac in (0.60, 0.97):          # the second segment's stream is what is missing: nothing follows it to be held against
+        f = LepFile(lep[: int(len(lep) * frac)])
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        assert len(f.recode()) == 98760
+    f = LepFile(lep)
+    ob.oracle_decode(f.desc, f.segments, f.streams)
+    assert f.recode() == golden("q30_256x256_4seg")[0]
