@@ -1,5 +1,6 @@
-"""GPU tests written after this round's last hardware visit (not yet run on an MI355X): kept in a file that sorts last so that,
-under `pytest -x`, they cannot hide the results of the tests that have been through hardware."""
+"""GPU tests written after a round's last hardware visit go into this file, which sorts last: under `pytest -x` they cannot hide
+the results of the tests that have been through hardware.  (The one below has since passed on the MI355X:
+profiles/r03d_pytest_gpu_final.log, 113 of 113.)"""
 import pytest
 
 from conftest import golden
