@@ -69,6 +69,13 @@ __global__ __launch_bounds__(64, 8) void k(int n, uint32_t* out, const uint32_t*
         if (MODE == 45) __asm__ volatile(REP16("s_cmp_lt_u32 %0, %1\n s_cselect_b32 %0, %0, %1\n") : "+s"(s0) : "s"(s1) : "scc");
         if (MODE == 46) __asm__ volatile(REP16("v_and_b32 %0, %0, %1\n") : "+v"(a) : "v"(b));
         if (MODE == 47) __asm__ volatile(REP16("v_sub_u32 %0, %0, %1\n") : "+v"(a) : "v"(b));
+        // does a vector instruction cost less when few lanes are enabled?  (16 adds under a narrowed exec mask; the two scalar
+        // moves around them issue beside other waves' vector work)
+        if (MODE == 48) __asm__ volatile("s_mov_b64 %2, exec\n s_mov_b64 exec, 1\n" REP16("v_add_u32 %0, %0, %1\n") "s_mov_b64 exec, %2\n" : "+v"(a), "+v"(b), "+s"(sq) : );
+        if (MODE == 49) __asm__ volatile("s_mov_b64 %2, exec\n s_mov_b64 exec, 0xffff\n" REP16("v_add_u32 %0, %0, %1\n") "s_mov_b64 exec, %2\n" : "+v"(a), "+v"(b), "+s"(sq) : );
+        if (MODE == 50) __asm__ volatile("s_mov_b64 %2, exec\n s_mov_b32 exec_lo, -1\n s_mov_b32 exec_hi, 0\n" REP16("v_add_u32 %0, %0, %1\n") "s_mov_b64 exec, %2\n" : "+v"(a), "+v"(b), "+s"(sq) : );
+        if (MODE == 51) __asm__ volatile("s_mov_b64 %2, exec\n s_mov_b64 exec, 1\n" REP16("v_lshlrev_b32 %0, %1, %0\n") "s_mov_b64 exec, %2\n" : "+v"(a), "+v"(c), "+s"(sq) : );
+        if (MODE == 52) __asm__ volatile("s_mov_b64 %2, exec\n s_mov_b64 exec, 1\n" REP16("ds_read_b32 %0, %1\n") "s_waitcnt lgkmcnt(0)\n s_mov_b64 exec, %2\n" : "+v"(a), "+v"(d), "+s"(sq) : );
     }
     out[blockIdx.x * 64 + threadIdx.x] = a1 + a2 + a3 + e + w4.x + w4.y + w4.z + w4.w + a + b + c + d + (uint32_t)q + (uint32_t)(q >> 32) + s0 + s1 + (uint32_t)sq + lds[(a + threadIdx.x) & 255];
 }
@@ -100,5 +107,7 @@ int main() {
     ROW(38, "ds_read_b128 broadcast x16, one wait", 1) ROW(39, "ds_write_b32 x16, one wait", 1) ROW(40, "ds_read_u8 x16, one wait", 1) ROW(41, "ds_bpermute_b32 x16, one wait", 1)
     ROW(42, "ds_read_b32 aligned + wait each", 1) ROW(43, "v_mov_b32 dpp row_shr", 1) ROW(44, "pair: v_add + s_cbranch_scc1 (not taken)", 2)
     ROW(45, "pair: s_cmp + s_cselect", 2) ROW(46, "v_and_b32", 1) ROW(47, "v_sub_u32", 1)
+    ROW(48, "v_add_u32, exec = lane 0 only", 1) ROW(49, "v_add_u32, exec = lanes 0..15", 1) ROW(50, "v_add_u32, exec = lanes 0..31", 1)
+    ROW(51, "v_lshlrev_b32, exec = lane 0 only", 1) ROW(52, "ds_read_b32 x16, exec = lane 0 only, one wait", 1)
     return 0;
 }
