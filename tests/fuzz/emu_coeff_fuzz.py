@@ -37,7 +37,7 @@ def main():
     so = os.path.join(ROOT, "tests", "emu", "libcore_emu_fuzz.so")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "emu", "core_emu.cc")])
     emu = C.CDLL(so)
-    ran = bad = refused = 0
+    ran = bad = refused = refused_both = 0
     for k in range(cases):
         rng = np.random.default_rng(seed0 * 100003 + k)
         comps = LAYOUTS[rng.integers(len(LAYOUTS))]
@@ -53,7 +53,21 @@ def main():
             refused += 1
             continue
         d, segs = img.desc, img.plan()
-        want, _ = ob.oracle_encode(d, segs)
+        try:
+            want, _ = ob.oracle_encode(d, segs)
+        except RuntimeError as e:      # a frame the coder refuses (coefficient out of range, zero cosine term): same code from the kernel
+            code = int(str(e).split()[-1])
+            rcs = []
+            for s in segs:
+                b = C.create_string_buffer(1 << 22)
+                n = C.c_uint32(0)
+                rcs.append(emu.emu_encode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, b, 1 << 22, C.byref(n), None))
+            first = next((r for r in rcs if r), 0)
+            if first != code:
+                bad += 1
+                print("REFUSAL MISMATCH", seed0, k, w, h, comps, kw, "oracle", code, "kernel", rcs, flush=True)
+            refused_both += 1
+            continue
         ok = True
         for s, wv in zip(segs, want):
             cap = len(wv) + 4096
@@ -78,7 +92,7 @@ def main():
             print("DECODE MISMATCH", seed0, k, w, h, comps, kw, flush=True)
         ran += 1
         bad += not ok
-    print(f"seed {seed0}: ran {ran} refused {refused} bad {bad}")
+    print(f"seed {seed0}: ran {ran} not a file {refused} refused by both {refused_both} bad {bad}")
 
 
 if __name__ == "__main__":

@@ -158,8 +158,8 @@ def test_random_slices_against_the_reference_binary(tmp_path):
 def test_mutated_lep_files_against_the_reference_binary(tmp_path):
     """the decode direction on damaged input: bit flips in the header and in the streams, overwritten and inserted bytes,
     truncation of reference-written .lep files.  Either both sides refuse the file or both restore the same bytes (1200
-    mutants by hand: 1 difference -- a file whose packet framing was broken by inserted bytes, where both sides "succeed"
-    with different garbage; what it found is fixed: thread hint 0 or larger than the hand-off count, sizes beyond 128 MB
+    mutants by hand in round 1: 1 difference -- a file whose packet framing was broken by inserted bytes, where both sides
+    "succeeded" with different garbage: the reference's two-row ring, since reproduced, tests/test_fuzz_host.py; what else it found: thread hint 0 or larger than the hand-off count, sizes beyond 128 MB
     are assertion failures in the reference); 60 here"""
     from conftest import golden, golden_cases
 
