@@ -139,7 +139,15 @@ struct BitWriter {
         int off = 1;
         while (nacc & 7) { put((pattern & off) ? 1 : 0, 1); off <<= 1; }
     }
-    void seed(uint8_t overhang_byte, int nbits) { bytes.clear(); acc = (uint64_t)overhang_byte << 56; nacc = nbits; }
+    // state a thread segment starts in (abitwriter::reset_from_overhang_byte_and_num_bits, bitops.hh:203-214: buf = byte << 56,
+    // cbit2 = 64 - nbits).  A well-formed hand-off has nbits < 8; a damaged one can say anything up to 255, and what the
+    // reference's 64-bit buffer then does (nbits >= 64: cbit2 <= 0, the next write flushes the buffer and re-writes its value
+    // -cbit2 bits wider) amounts to: the byte's eight bits, then nbits - 8 zero bits.  Bits of the byte below the nbits it claims
+    // stay in the buffer and are OR-ed with what is written next, there as here.
+    void seed(uint8_t overhang_byte, int nbits) {
+        bytes.clear(); acc = (uint64_t)overhang_byte << 56; nacc = nbits;
+        while (nacc >= 8) { bytes.push_back((uint8_t)(acc >> 56)); acc <<= 8; nacc -= 8; }
+    }
     uint8_t overhang_byte() const { return (uint8_t)(acc >> 56); }
     int overhang_bits() const { return nacc; }
 };

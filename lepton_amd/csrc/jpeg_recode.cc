@@ -166,6 +166,7 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
     bool ok = !jf.early_eof && jf.ncomp >= 1 && jf.ncomp <= 3 && jf.cs_cmpc == jf.ncomp && jf.mcuh > 0 && jf.mcuv > 0 &&
               jf.trunc_bcv[0] >= jf.comp[0].bcv && !lf->segs.empty();
     for (const Handoff& th : lf->segs) if (th.num_overhang_bits == 0xff || th.num_overhang_bits > 7) ok = false;
+    if (ok && lf->version > 1 && (uint64_t)plan->head.size() + lf->segs[0].segment_size > 0xffffffffull) ok = false;   // the first thread's bound wraps (recode_jpeg): host path
     if (ok && jf.ncomp == 1) {
         const Component& k = jf.comp[jf.cs_cmp[0]];
         ok = k.hs == 1 && k.vs == 1 && k.bch == k.nch && k.bcv == k.ncv && k.bc == jf.mcuc;
@@ -316,7 +317,16 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
         // version >= 2: the first thread is bound by its segment size too (recoder.cc:598-613: new_bound = bytes_written +
         // segment_size, applied when it is tighter than the file's)
         const size_t file_bound = out.bound;
-        if (s == 0 && !legacy && lf->version > 1 && out.buf.size() + (size_t)th.segment_size < file_bound) out.bound = out.buf.size() + th.segment_size;
+        // -- a sum of two 32-bit values there (bounded_iostream::bytes_written() is an unsigned int): a segment size near 2^32
+        // wraps it to a bound in front of what is already written, and the next write trips always_assert(byte_position <=
+        // byte_bound) (bitops.cc:402); a bound of exactly zero means "none")
+        if (s == 0 && !legacy && lf->version > 1) {
+            const uint32_t nb = (uint32_t)out.buf.size() + th.segment_size;
+            if ((size_t)nb < file_bound) {
+                if (nb && (size_t)nb < out.buf.size()) return EX_ASSERTION_FAILURE;
+                out.bound = nb;
+            }
+        }
         BitWriter w;
         w.fillbit = (uint8_t)jf.padbit;
         w.seed(th.overhang_byte, th.num_overhang_bits);

@@ -249,8 +249,7 @@ int lep_file_open_next(const uint8_t* d, size_t len, const lep_file* prev, lep_f
     int rc = lep::parse_lep(d, len, &f->lf, prev ? &prev->lf.pending_header : nullptr);
     if (rc) return rc;
     lep::JpegFile& jf = f->lf.jpeg;
-    memset(jf.qtables, 0, sizeof jf.qtables);
-    if (!lep::setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : LEP_UNSUPPORTED_JPEG;
+    // (the embedded header has been interpreted inside parse_lep, where the reference does it)
     if (jf.warn > 0) return LEP_UNSUPPORTED_JPEG;   // errorlevel 1 in setup_imginfo_jpg (an unknown marker in the embedded header, jpgcoder.cc:4836-4840) stops the reference too
     if (jf.ncomp > 3) return LEP_UNSUPPORTED_4_COLORS;
     if (jf.early_eof) {
@@ -305,10 +304,17 @@ int lep_file_describe_into(lep_file* f, void* frame_mem, size_t frame_cap, lep_i
 
 int lep_file_segments(const lep_file* f, lep_segment* segs, lep_bytes* streams, int image_index) {
     const auto& s = f->lf.segs;   // <= LEP_MAX_SEGMENTS: parse_lep refuses files with more
+    // The baseline re-coder drives its decoder MCU row by MCU row: a row is taken when the MCU row's FIRST luma row is not in
+    // front of the hand-off's luma_y_start and its end not behind luma_y_end (recode_row_range, recoder.cc:505-510), so a
+    // (damaged) hand-off that starts or ends inside an MCU row skips that MCU row in every component.  The general re-coder's
+    // decoder (vp8_decode_thread, lepton_codec.cc:284-300) compares luma rows one by one, which is what the kernels do.
+    const lep::JpegFile& jf = f->lf.jpeg;
+    const bool by_mcu_row = (f->lf.flag == 'Z' || (f->lf.flag & 1) == ('Y' & 1)) && jf.mcuv > 0;
+    const int mul = by_mcu_row ? std::max(jf.comp[0].bcv / jf.mcuv, 1) : 1;
     for (size_t i = 0; i < s.size(); ++i) {
         segs[i].image = image_index;
-        segs[i].luma_y_start = s[i].luma_y_start;
-        segs[i].luma_y_end = s[i].luma_y_end;
+        segs[i].luma_y_start = (s[i].luma_y_start + mul - 1) / mul * mul;
+        segs[i].luma_y_end = i + 1 == s.size() ? s[i].luma_y_end : s[i].luma_y_end / mul * mul;
         segs[i].is_last = i + 1 == s.size();
         streams[i].data = const_cast<uint8_t*>(f->lf.streams[i].data());
         streams[i].len = streams[i].cap = f->lf.streams[i].size();

@@ -406,9 +406,18 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
     if (memcmp(mrk, "HDR", 3)) return EX_UNSUPPORTED_JPEG;   // "HDR marker not found": errorlevel 2
     read_full(mrk, 4);
     const uint32_t hdrs = get_le32(mrk);
-    if (hdrs > (128u << 20)) return EX_STREAM_INCONSISTENT;   // (the reference's arena allocator gives up long before)
+    // Sizes the reference would try to allocate from its main arena (576 MiB in the default build, jpgcoder.cc:827-838) and
+    // fail: OOM, whatever else is wrong with the file.  Between 128 MiB and the arena the reference allocates, zero-fills and
+    // reads what is there; an in-process daemon does not follow it there (refused as STREAM_INCONSISTENT: documented deviation).
+    const uint64_t kArena = ((uint64_t)576 << 20) - (1u << 20);
+    if (hdrs > kArena) return EX_BLOCK_OFFSET_OOM;
+    if (hdrs > (128u << 20)) return EX_STREAM_INCONSISTENT;
     jf.hdr.assign(hdrs, 0);
     read_full(jf.hdr.data(), hdrs);
+    // the embedded JPEG header is interpreted here, before the sections behind it are looked at (setup_imginfo_jpg, called at
+    // jpgcoder.cc:4215): its refusals (sampling factors, frame budget, ...) come before "PAD marker not found"
+    memset(jf.qtables, 0, sizeof jf.qtables);
+    if (!setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;
     read_full(mrk, 3);
     if (!memcmp(mrk, "P0D", 3)) { uint8_t b = 0xff; read_full(&b, 1); jf.padbit = (int8_t)b; }
     else if (!memcmp(mrk, "PAD", 3)) {
@@ -422,7 +431,8 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
         if (!memcmp(mrk, "CRS", 3)) {
             read_full(mrk, 4);
             const uint32_t c = get_le32(mrk);
-            if (c > (1u << 22) && (uint64_t)c > left() / 4 + 16) return EX_STREAM_INCONSISTENT;   // a count the data cannot back: multi-GB vector in the reference
+            if ((uint64_t)c * 4 > kArena) return EX_BLOCK_OFFSET_OOM;
+            if (c > (1u << 22) && (uint64_t)c > left() / 4 + 16) return EX_STREAM_INCONSISTENT;   // a count the data cannot back: a vector of hundreds of MB in the reference
             lf->rst_cnt_set = true;
             jf.rst_cnt.resize(c);
             for (uint32_t i = 0; i < c; ++i) { read_full(mrk, 4); jf.rst_cnt[i] = get_le32(mrk); }
@@ -436,12 +446,14 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
         } else if (!memcmp(mrk, "FRS", 3)) {
             read_full(mrk, 4);
             const uint32_t c = get_le32(mrk);
+            if (c >= jf.rst_err.size() && (uint64_t)c - jf.rst_err.size() > kArena) return EX_BLOCK_OFFSET_OOM;
             if ((c > (1u << 24) && (uint64_t)c > left() + 16) || c < jf.rst_err.size()) return EX_STREAM_INCONSISTENT;
             jf.rst_err.resize(c, 0);
             read_full(jf.rst_err.data(), c);
         } else if (!memcmp(mrk, "GRB", 3)) {
             read_full(mrk, 4);
             const uint32_t c = get_le32(mrk);
+            if (c > kArena) return EX_BLOCK_OFFSET_OOM;
             if (c > (128u << 20)) return EX_STREAM_INCONSISTENT;
             jf.garbage.assign(c, 0);
             read_full(jf.garbage.data(), c);
@@ -450,6 +462,7 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
             lf->embedded = lf->embedded || mrk[2] == 'E';
             read_full(mrk, 4);
             const uint32_t c = get_le32(mrk);
+            if (c > kArena) return EX_BLOCK_OFFSET_OOM;
             if (c > (128u << 20)) return EX_STREAM_INCONSISTENT;
             lf->has_prefix = true;
             lf->prefix_garbage.assign(c, 0);
@@ -498,6 +511,26 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
     if (lf->segs.size() > 16) return EX_ASSERTION_FAILURE;
     const bool baseline_recoder = lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1);   // jpgcoder.cc:2162; the general re-coder is single-threaded
     if (baseline_recoder && lf->segs[0].num_overhang_bits != 0xff && (size_t)std::min(lf->nthreads, 8) > lf->segs.size()) return EX_ASSERTION_FAILURE;
+    // Every worker thread's output buffer is allocated up front at its byte bound -- the sum of its logical threads' segment sizes
+    // as an int, the whole file's size if that is zero (recode_baseline_jpeg, recoder.cc:770-782; BoundedMemWriter::set_bound
+    // resizes) -- from the main arena of the default build (1024 MiB - 7 x 64 MiB, jpgcoder.cc:827-838): hand-offs that claim
+    // more than it holds end in OOM before a single bin is decoded, whatever the streams are.  Probed against the binary: the
+    // worker bounds may sum to 575.5 MiB beside a 256x256 image and 571.7 MiB beside a 1600x1200 one (what else lives in the
+    // arena grows with the file); the first thread writes to the output and is not counted.
+    if (baseline_recoder && lf->segs[0].num_overhang_bits != 0xff) {
+        const int P = std::min(lf->nthreads, 8), L = (int)lf->segs.size();
+        uint64_t total = 0;
+        for (int p = 1; p < P; ++p) {
+            int a = p * L / P, b = std::min((p + 1) * L / P, L);
+            if (L < P) { a = std::min(p, L); b = std::min(p + 1, L); }   // logical_thread_range_from_physical_thread_id, recoder.cc:547-559
+            int32_t work = 0;
+            for (int l = a; l < b; ++l) work = (int32_t)((uint32_t)work + lf->segs[l].segment_size);
+            if (!work) work = (int32_t)lf->jpeg_size;
+            if (work < 0) return EX_BLOCK_OFFSET_OOM;   // (size_t)(int) of a negative bound: no arena holds it
+            total += (uint64_t)work;
+        }
+        if (P > 1 && total + (512u << 10) + 4 * (uint64_t)n > ((uint64_t)576 << 20)) return EX_BLOCK_OFFSET_OOM;
+    }
     // the general re-coder decodes through decode_chunk, which gives up when the file has more logical threads than the
     // decoder was started with: `num_threads_needed > NUM_THREADS` -> CODING_ERROR (vp8_decoder.cc:415-417), NUM_THREADS =
     // min(8, thread hint) (read_fixed_ujpg_header, jpgcoder.cc:2167-2171)

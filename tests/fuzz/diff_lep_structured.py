@@ -17,29 +17,41 @@ from conftest import golden, golden_cases
 import oracle_binding as ob
 from lepton_amd.codec import LepFile, LeptonError
 REF='/root/repo/oracle/_ref/lepton'
+CODES={'ASSERTION_FAILURE':1,'CODING_ERROR':2,'SHORT_READ':3,'UNSUPPORTED_4_COLORS':4,'THREAD_PROTOCOL_ERROR':5,'COEFFICIENT_OUT_OF_RANGE':6,'STREAM_INCONSISTENT':7,'PROGRESSIVE_UNSUPPORTED':8,'FILE_NOT_FOUND':9,'SAMPLING_BEYOND_TWO_UNSUPPORTED':10,'SAMPLING_BEYOND_FOUR_UNSUPPORTED':11,'THREADING_PARTIAL_MCU':12,'VERSION_UNSUPPORTED':13,'ONLY_GARBAGE_NO_JPEG':14,'OS_ERROR':33,'HEADER_TOO_LARGE':34,'DIMENSIONS_TOO_LARGE':35,'MALLOCED_NULL':36,'OOM':37,'TOO_MUCH_MEMORY_NEEDED':38,'EARLY_EXIT':40,'ROUNDTRIP_FAILURE':41,'UNSUPPORTED_JPEG':42,'UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0':43}
 rnd=random.Random(int(sys.argv[1])); N=int(sys.argv[2])
 names=[n for n in golden_cases() if len(golden(n)[1])<40000]
 OUT=sys.argv[3] if len(sys.argv)>3 else '/tmp'
-lp,jp=os.path.join(OUT,'m.lep'),os.path.join(OUT,'m.jpg')
+blob=lambda n: golden(n)[1]
+if len(sys.argv)>4 and sys.argv[4]=='v2':     # format-2 fixtures (brotli header, every segment bound by its size); chained streams left out
+    import json
+    from conftest import GOLDEN
+    V2=os.path.join(GOLDEN,'v2')
+    names=[n for n in sorted(json.load(open(os.path.join(V2,'manifest.json')))) if not n.startswith(('chain','concat')) and os.path.getsize(os.path.join(V2,n+'.lep'))<150000]
+    blob=lambda n: open(os.path.join(V2,n+'.lep'),'rb').read()
+lp,jp=os.path.join(OUT,'m%s.lep'%sys.argv[1]),os.path.join(OUT,'m%s.jpg'%sys.argv[1])
 bad=0; same=0; refused=0
 for t in range(N):
     name=rnd.choice(names)
-    b=mu.mutate_lep_structured(rnd, golden(name)[1])
+    b=mu.mutate_lep_structured(rnd, blob(name))
     open(lp,'wb').write(b)
     if os.path.exists(jp): os.unlink(jp)
     try:
         r=subprocess.run([REF,'-unjailed',lp,jp],capture_output=True,timeout=60)
-        want=open(jp,'rb').read() if r.returncode==0 and os.path.exists(jp) else None
         rcode=r.returncode
+        named=[l.strip() for l in r.stderr.decode('latin1').split('\n') if l.strip() in CODES]
+        if named: rcode=CODES[named[-1]]      # a failing run names its exit code on stderr whatever the process status says
+        want=open(jp,'rb').read() if rcode==0 and os.path.exists(jp) else None
     except subprocess.TimeoutExpired:
         want=None; rcode='timeout'
     try:
         f=LepFile(b); ob.oracle_decode(f.desc,f.segments,f.streams); got=f.recode(); code=0
     except LeptonError as e: got=None; code=e.code
-    except RuntimeError as e: got=None; code=str(e)
-    if got!=want:
+    except RuntimeError as e:
+        got=None; code=str(e)
+        if 'exit code' in code: code=int(code.rsplit(' ',1)[1])
+    if got!=want or (got is None and isinstance(rcode,int) and rcode>0 and code!=rcode):
         bad+=1; print('DIFF',t,name,'ref',rcode,None if want is None else len(want),'ours',code,None if got is None else len(got))
-        open(os.path.join(OUT,'diff_%d.lep'%t),'wb').write(b)
+        open(os.path.join(OUT,'diff_%s_%d.lep'%(sys.argv[1],t)),'wb').write(b)
     elif got is None: refused+=1
     else: same+=1
 print('same',same,'refused',refused,'bad',bad)

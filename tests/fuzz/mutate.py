@@ -13,20 +13,42 @@ import sys
 import zlib
 
 
+def _brotli(encode, data):
+    """format >= 2 headers are brotli streams; the system's libbrotli through ctypes (any valid stream will do for a mutant)"""
+    import ctypes as C
+    if encode:
+        lib = C.CDLL("libbrotlienc.so.1")
+        cap = C.c_size_t(len(data) + (len(data) >> 2) + 1024)
+        out = C.create_string_buffer(cap.value)
+        ok = lib.BrotliEncoderCompress(C.c_int(5), C.c_int(22), C.c_int(0), C.c_size_t(len(data)), data, C.byref(cap), out)
+        return out.raw[:cap.value] if ok else None
+    lib = C.CDLL("libbrotlidec.so.1")
+    cap = C.c_size_t(max(1 << 16, len(data) * 64))
+    out = C.create_string_buffer(cap.value)
+    ok = lib.BrotliDecoderDecompress(C.c_size_t(len(data)), data, C.byref(cap), out)
+    return out.raw[:cap.value] if ok == 1 else None
+
+
 def lep_split(lep):
-    """(28-byte fixed prefix, inflated header payload, everything from "CMP" on) of a format-1 .lep, or None"""
+    """(28-byte fixed prefix, decompressed header payload, everything from "CMP" on) of a .lep (zlib header: format 1, brotli:
+    formats 2 and 4), or None"""
     if len(lep) < 32 or lep[:2] != b"\xcf\x84":
         return None
     zs = struct.unpack("<I", lep[24:28])[0]
-    try:
-        payload = zlib.decompress(lep[28:28 + zs])
-    except zlib.error:
-        return None
+    if lep[2] == 1:
+        try:
+            payload = zlib.decompress(lep[28:28 + zs])
+        except zlib.error:
+            return None
+    else:
+        payload = _brotli(False, lep[28:28 + zs])
+        if payload is None:
+            return None
     return lep[:28], payload, lep[28 + zs:]
 
 
 def lep_join(fixed, payload, rest):
-    z = zlib.compress(payload, 9)
+    z = zlib.compress(payload, 9) if fixed[2] == 1 else _brotli(True, payload)
     out = bytearray(fixed[:24]) + struct.pack("<I", len(z)) + z + rest
     if len(out) >= 4:
         out[-4:] = struct.pack("<I", len(out))   # the size trailer (vp8_encoder.cc:602-614)
@@ -41,9 +63,10 @@ def find_handoffs(payload):
     return pos if payload[pos:pos + 2] == b"HH" else -1
 
 
-def with_handoffs(lep, count=None, repeat=1, segment_size=None, thread_byte=None):
+def with_handoffs(lep, count=None, repeat=1, segment_size=None, thread_byte=None, field=None):
     """re-packs a .lep with `count` hand-off records (the last one repeated), the HH section `repeat` times, every
-    segment_size overwritten, byte 4 (thread hint) replaced"""
+    segment_size overwritten, byte 4 (thread hint) replaced; field = (record, byte offset, width, value): one field of one
+    record (luma_y_start u16 @0, segment_size u32 @2, overhang_byte @6, num_overhang_bits @7, last_dc[4] s16 @8)"""
     parts = lep_split(lep)
     if not parts:
         return lep
@@ -58,6 +81,9 @@ def with_handoffs(lep, count=None, repeat=1, segment_size=None, thread_byte=None
     if segment_size is not None:
         for r in recs:
             r[2:6] = struct.pack("<I", segment_size)
+    if field is not None and recs:
+        i, off, width, value = field
+        recs[i % len(recs)][off:off + width] = (value & ((1 << (8 * width)) - 1)).to_bytes(width, "little")
     sect = b"HH" + bytes([len(recs) & 255]) + b"".join(bytes(r) for r in recs)
     p2 = p[:pos] + sect * repeat + p[pos + 3 + 16 * n:]
     fixed = bytearray(fixed)
@@ -70,7 +96,11 @@ def mutate_lep_structured(rng, lep):
     parts = lep_split(lep)
     if not parts:
         return mutate(rng, lep)
-    k = rng.randrange(6)
+    k = rng.randrange(8)
+    if k >= 6:    # one field of one hand-off record
+        off, width = rng.choice([(0, 2), (2, 4), (6, 1), (7, 1), (8, 2), (10, 2), (12, 2), (14, 2)])
+        value = rng.choice([0, 1, 2, 7, 8, 9, 0xff, 0x100, 0x7fff, 0xffff, rng.randrange(1 << (8 * width)), rng.randrange(64)])
+        return with_handoffs(lep, field=(rng.randrange(16), off, width, value))
     if k == 0:
         return with_handoffs(lep, count=rng.choice([0, 1, 9, 16, 17, 32, 200, 255]))
     if k == 1:
