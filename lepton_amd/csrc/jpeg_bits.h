@@ -126,6 +126,7 @@ struct BitWriter {
     uint8_t fillbit = 1;
 
     void put(unsigned val, int nbits) {
+        if (excess) { put_after_oversized_seed(val, nbits); return; }
         while (nbits > 0) {
             int take = nbits > 32 ? 32 : nbits;
             uint64_t v = (val >> (nbits - take)) & (take == 32 ? 0xffffffffull : ((1ull << take) - 1));
@@ -140,12 +141,24 @@ struct BitWriter {
         while (nacc & 7) { put((pattern & off) ? 1 : 0, 1); off <<= 1; }
     }
     // state a thread segment starts in (abitwriter::reset_from_overhang_byte_and_num_bits, bitops.hh:203-214: buf = byte << 56,
-    // cbit2 = 64 - nbits).  A well-formed hand-off has nbits < 8; a damaged one can say anything up to 255, and what the
-    // reference's 64-bit buffer then does (nbits >= 64: cbit2 <= 0, the next write flushes the buffer and re-writes its value
-    // -cbit2 bits wider) amounts to: the byte's eight bits, then nbits - 8 zero bits.  Bits of the byte below the nbits it claims
-    // stay in the buffer and are OR-ed with what is written next, there as here.
+    // cbit2 = 64 - nbits).  A well-formed hand-off has nbits < 8; a damaged one can say anything up to 255.  Up to 64 the
+    // reference's 64-bit buffer simply holds the byte and nbits - 8 zero bits.  Beyond 64 cbit2 is negative and the first write
+    // (abitwriter::write, bitops.hh:120-163) flushes the eight buffer bytes, widens its value by the excess, and -- if that makes
+    // it wider than the buffer -- drops it and leaves the buffer "full" of zeros, which the next write flushes as eight more
+    // bytes.  Bits of the byte below the nbits it claims stay in the buffer and are OR-ed with what is written next, there as here.
+    int excess = 0;   // > 0: seeded with 64 + excess bits, first put() pending
     void seed(uint8_t overhang_byte, int nbits) {
-        bytes.clear(); acc = (uint64_t)overhang_byte << 56; nacc = nbits;
+        bytes.clear(); acc = (uint64_t)overhang_byte << 56; excess = 0;
+        if (nbits > 64) { excess = nbits - 64; nacc = 64; }
+        else nacc = nbits;
+        while (nacc >= 8) { bytes.push_back((uint8_t)(acc >> 56)); acc <<= 8; nacc -= 8; }
+    }
+    void put_after_oversized_seed(unsigned val, int nbits) {
+        const int wide = nbits + excess;
+        excess = 0;
+        if (wide > 64) { for (int i = 0; i < 8; ++i) bytes.push_back(0); return; }   // the value is lost, 64 zero bits take its place
+        acc = wide ? ((uint64_t)val & (~0ull >> (64 - wide))) << (64 - wide) : 0;
+        nacc = wide;
         while (nacc >= 8) { bytes.push_back((uint8_t)(acc >> 56)); acc <<= 8; nacc -= 8; }
     }
     uint8_t overhang_byte() const { return (uint8_t)(acc >> 56); }

@@ -314,7 +314,7 @@ int encode_ac_refine(ScanWriter& sw, const HuffTable& ac, const int16_t* blk, un
 int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
     JpegFile& jf = lf->jpeg;
     const size_t max_file_size = lf->jpeg_size;
-    if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
+    if ((int32_t)lf->jpeg_size <= (int32_t)jf.garbage.size()) return EX_ASSERTION_FAILURE;   // always_assert(max_file_size > grbs), both ints
     const uint8_t* h = jf.hdr.data();
     const size_t hdrs = jf.hdr.size();
 
@@ -449,7 +449,7 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
     // 2. merge: SOI, then per scan the header part up to its SOS, the scan bytes (FF00 stuffing, RSTn after the recorded
     //    bytes while the scan's marker budget lasts), misplaced RSTn at the scan end; then the rest of the header, garbage
     std::vector<uint8_t> out;
-    out.reserve(max_file_size + 16);
+    out.reserve(std::min<size_t>(max_file_size, (size_t)128 << 20) + 16);
     const size_t bound = max_file_size - jf.garbage.size();
     auto put = [&](uint8_t b) { if (out.size() < bound) out.push_back(b); };
     if (lf->has_prefix) for (uint8_t b : lf->prefix_garbage) put(b);
@@ -576,7 +576,7 @@ int recode_progressive_finish(LepFile* lf, const ProgPlan& plan, const std::vect
     const uint8_t* h = jf.hdr.data();
     const size_t hdrs = jf.hdr.size();
     std::vector<uint8_t> out;
-    out.reserve(max_file_size + 16);
+    out.reserve(std::min<size_t>(max_file_size, (size_t)128 << 20) + 16);
     const size_t bound = max_file_size - jf.garbage.size();
     auto put = [&](uint8_t b) { if (out.size() < bound) out.push_back(b); };
     if (lf->has_prefix) for (uint8_t b : lf->prefix_garbage) put(b);

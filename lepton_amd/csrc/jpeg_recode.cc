@@ -53,6 +53,24 @@ void encode_block(BitWriter& w, const HuffTable& dc, const HuffTable& ac, const 
 }
 
 // move whole bytes from the bit writer to the output, stuffing 00 after FF
+// > 0 when logical thread s is the first one of a worker (physical thread >= 1) of the reference's thread pool: the bound of
+// that worker's output buffer = the sum of its logical threads' segment sizes as an int, the file's size if that is zero
+// (logical_thread_range_from_physical_thread_id, recoder.cc:547-559; recode_baseline_jpeg, recoder.cc:770-782)
+int physical_range_start(const LepFile& lf, int s) {
+    if (lf.segs.empty() || lf.segs[0].num_overhang_bits == 0xff) return 0;   // one physical thread
+    const int P = std::max(1, std::min(lf.nthreads, 8)), L = (int)lf.segs.size();
+    for (int p = 1; p < P; ++p) {
+        int a = p * L / P, b = std::min((p + 1) * L / P, L);
+        if (L < P) { a = std::min(p, L); b = std::min(p + 1, L); }
+        if (a != s || b <= a) continue;
+        int32_t work = 0;
+        for (int l = a; l < b; ++l) work = (int32_t)((uint32_t)work + lf.segs[l].segment_size);
+        if (!work) work = (int32_t)lf.jpeg_size;
+        return work > 0 ? work : 0x7fffffff;
+    }
+    return 0;
+}
+
 void drain(BitWriter& w, BoundedOut& out) {
     for (uint8_t b : w.bytes) { out.put(b); if (b == 0xFF) out.put(0); }
     w.bytes.clear();
@@ -132,7 +150,7 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
     plan->segs.clear();
     if (lf->flag != 'Z') return 0;   // progressive / multi-scan files: recode_progressive (jpeg_progressive.cc), host only
     const size_t max_file_size = lf->jpeg_size;
-    if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
+    if ((int32_t)lf->jpeg_size <= (int32_t)jf.garbage.size()) return EX_ASSERTION_FAILURE;   // always_assert(max_file_size > grbs), both ints
     plan->scan_bound = max_file_size - jf.garbage.size();
     size_t pos = 0;
     const uint8_t* h = jf.hdr.data();
@@ -240,7 +258,7 @@ int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pa
     const size_t max_file_size = lf->jpeg_size;
     BoundedOut out;
     out.bound = plan.scan_bound;
-    out.buf.reserve(max_file_size + 16);
+    out.buf.reserve(std::min<size_t>(max_file_size, (size_t)128 << 20) + 16);   // (a SIZ section can claim up to 2^31 - 1)
     out.write(plan.head.data(), plan.head.size());
     // (the GPU encoder does not hand back the bit state a segment ends in; what can be held against the hand-offs here is the
     // byte count: a segment that restores its part of the file exactly writes exactly segment_size bytes -- see recode_jpeg for
@@ -273,7 +291,7 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
     // header[1] == 'Z' || (header[1] & 1) == ('Y' & 1), jpgcoder.cc:2162-2166
     if (!(lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1))) return recode_progressive(lf, result);
     const size_t max_file_size = lf->jpeg_size;
-    if (max_file_size <= jf.garbage.size()) return EX_ASSERTION_FAILURE;
+    if ((int32_t)lf->jpeg_size <= (int32_t)jf.garbage.size()) return EX_ASSERTION_FAILURE;   // always_assert(max_file_size > grbs), both ints
     BoundedOut out;
     out.bound = max_file_size - jf.garbage.size();
 
@@ -305,8 +323,13 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
     for (size_t s = 0; s < lf->segs.size(); ++s) {
         Handoff th = lf->segs[s];
         bool legacy = th.num_overhang_bits == 0xff;
+        // A pre-hand-off record takes the state the previous logical thread of the SAME physical thread ended in; the first one a
+        // physical thread runs starts clean: no pending bits, the byte and the last DCs of its own record
+        // (recode_physical_thread, recoder.cc:584-592).  A file whose first record is of that kind runs on one thread
+        // (recoder.cc:730-732); in any other file a damaged record of that kind can sit at the head of a worker's range.
+        const int work_bound = physical_range_start(*lf, (int)s);   // > 0: s opens a worker thread's range, its buffer's bound
         if (legacy) {
-            if (s == 0) carry.num_overhang_bits = 0;
+            if (s == 0 || work_bound > 0) { carry = lf->segs[s]; carry.num_overhang_bits = 0; }
             th.overhang_byte = carry.overhang_byte;
             th.num_overhang_bits = carry.num_overhang_bits;
             memcpy(th.last_dc, carry.last_dc, sizeof th.last_dc);
@@ -314,6 +337,7 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
         BoundedOut seg;
         BoundedOut* o = &out;
         if (s > 0 && !legacy) { seg.bound = th.segment_size ? th.segment_size : max_file_size; o = &seg; }
+        else if (s > 0 && work_bound > 0) { seg.bound = (size_t)work_bound; o = &seg; }
         // version >= 2: the first thread is bound by its segment size too (recoder.cc:598-613: new_bound = bytes_written +
         // segment_size, applied when it is tighter than the file's)
         const size_t file_bound = out.bound;

@@ -381,17 +381,20 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
     if (lf->version == 3) return EX_ASSERTION_FAILURE;     // ANS-coded streams: "ANS compile flag not selected" (jpgcoder.cc:461-468)
     lf->jpeg_size = get_le32(d + 20);
     uint32_t zsize = get_le32(d + 24);
-    if (zsize > (128u << 20) || lf->jpeg_size > (128u << 20)) return EX_ASSERTION_FAILURE;   // "Only support images < 128 megs" (jpgcoder.cc:4133-4136)
+    // "Only support images < 128 megs" (jpgcoder.cc:4133-4136).  max_file_size is an int there: a size of 2^31 and more passes
+    // this test and trips always_assert(max_file_size > grbs) once the header has been read (refusals of the header come first)
+    if (zsize > (128u << 20) || (int32_t)lf->jpeg_size > (128 << 20)) return EX_ASSERTION_FAILURE;
+    const size_t sane_size = (int32_t)lf->jpeg_size < 0 ? ((size_t)128 << 20) : (size_t)lf->jpeg_size;   // what a header may inflate to is never sized from such a claim
     if (28 + (uint64_t)zsize + 3 > n) return EX_SHORT_READ;
     std::vector<uint8_t> p;
     if (carried && !carried->empty()) {   // header_reader != NULL: the compressed header bytes are not even read (jpgcoder.cc:4139)
         p = *carried;
         zsize = 0;
     } else if (lf->version == 1) {
-        if (!unzlib(d + 28, zsize, (size_t)lf->jpeg_size + 2048, &p)) return EX_STREAM_INCONSISTENT;
+        if (!unzlib(d + 28, zsize, sane_size + 2048, &p)) return EX_STREAM_INCONSISTENT;
     } else {
         if (!brotli_available()) return EX_VERSION_UNSUPPORTED;   // no libbrotlidec on this host: said loudly, never guessed
-        if (!unbrotli(d + 28, zsize, (size_t)lf->jpeg_size * 2 + ((size_t)128 << 20), &p)) return EX_STREAM_INCONSISTENT;
+        if (!unbrotli(d + 28, zsize, sane_size * 2 + ((size_t)128 << 20), &p)) return EX_STREAM_INCONSISTENT;
     }
     // The header sections, read the way the reference reads them (read_ujpg, jpgcoder.cc:4193-4339): every field goes through
     // ReadFull into one 64-byte scratch buffer, and a header that ends early simply leaves that buffer -- or the zeroed
