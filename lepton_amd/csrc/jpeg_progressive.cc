@@ -342,7 +342,7 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
             type = hpos + 1 < hdrs ? h[hpos + 1] : 0;
             const unsigned len = 2 + (((unsigned)(hpos + 2 < hdrs ? h[hpos + 2] : 0)) << 8) + (hpos + 3 < hdrs ? h[hpos + 3] : 0);
             if (type == 0xC4 || type == 0xDA || type == 0xDD)
-                if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - hpos), h + hpos, false)) return EX_CODING_ERROR;
+                if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - hpos), h + hpos, false)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;   // parse_jfif_jpg: errorlevel 2
             hpos += len;
         }
         if (type != 0xDA) break;
@@ -515,7 +515,7 @@ int progressive_plan(JpegFile* jfp, size_t jpeg_size, bool rst_cnt_set, ProgPlan
             type = hpos + 1 < hdrs ? h[hpos + 1] : 0;
             const unsigned len = 2 + (((unsigned)(hpos + 2 < hdrs ? h[hpos + 2] : 0)) << 8) + (hpos + 3 < hdrs ? h[hpos + 3] : 0);
             if (type == 0xC4 || type == 0xDA || type == 0xDD)
-                if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - hpos), h + hpos, false)) return EX_CODING_ERROR;
+                if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - hpos), h + hpos, false)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;   // parse_jfif_jpg: errorlevel 2
             hpos += len;
         }
         if (type != 0xDA) break;

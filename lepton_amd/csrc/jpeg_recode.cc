@@ -156,12 +156,12 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
     const uint8_t* h = jf.hdr.data();
     const size_t hdrs = jf.hdr.size();
     for (;;) {
-        if (pos + 3 >= hdrs) return EX_CODING_ERROR;
-        if (h[pos] != 0xff) return EX_CODING_ERROR;
+        if (pos + 3 >= hdrs) return EX_UNSUPPORTED_JPEG;   // "overran headers" / "not start of segment": recode_baseline_jpeg fails, errorlevel 2 (jpgcoder.cc:1334-1338)
+        if (h[pos] != 0xff) return EX_UNSUPPORTED_JPEG;
         uint8_t type = h[pos + 1];
         unsigned len = 2 + ((unsigned)h[pos + 2] << 8) + h[pos + 3];
         if (type == 0xC4 || type == 0xDD || type == 0xDA)
-            if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - pos), h + pos, false)) return EX_CODING_ERROR;
+            if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - pos), h + pos, false)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;   // parse_jfif_jpg: errorlevel 2
         pos += len;
         if (type == 0xDA) break;
     }
@@ -300,12 +300,12 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
     const uint8_t* h = jf.hdr.data();
     const size_t hdrs = jf.hdr.size();
     for (;;) {
-        if (pos + 3 >= hdrs) return EX_CODING_ERROR;
-        if (h[pos] != 0xff) return EX_CODING_ERROR;
+        if (pos + 3 >= hdrs) return EX_UNSUPPORTED_JPEG;   // "overran headers" / "not start of segment": recode_baseline_jpeg fails, errorlevel 2 (jpgcoder.cc:1334-1338)
+        if (h[pos] != 0xff) return EX_UNSUPPORTED_JPEG;
         uint8_t type = h[pos + 1];
         unsigned len = 2 + ((unsigned)h[pos + 2] << 8) + h[pos + 3];
         if (type == 0xC4 || type == 0xDD || type == 0xDA)
-            if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - pos), h + pos, false)) return EX_CODING_ERROR;
+            if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - pos), h + pos, false)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;   // parse_jfif_jpg: errorlevel 2
         pos += len;
         if (type == 0xDA) break;
     }

@@ -270,6 +270,10 @@ int lep_file_open_next(const uint8_t* d, size_t len, const lep_file* prev, lep_f
         for (size_t i = 0; i + 1 < f->lf.segs.size(); ++i)
             if (f->lf.segs[i].luma_y_end % lcm) return LEP_THREADING_PARTIAL_MCU;
     }
+    // the general re-coder decodes through decode_chunk, which gives up when the file has more logical threads than the
+    // decoder was started with: `num_threads_needed > NUM_THREADS` -> CODING_ERROR (vp8_decoder.cc:415-417), NUM_THREADS =
+    // min(8, thread hint) (read_fixed_ujpg_header, jpgcoder.cc:2167-2171) -- after the split table has been read and checked
+    if (!(f->lf.flag == 'Z' || (f->lf.flag & 1) == ('Y' & 1)) && f->lf.segs.size() > (size_t)std::min(f->lf.nthreads, 8)) return LEP_CODING_ERROR;
     if (!f->lf.segs.empty()) f->lf.segs.back().luma_y_end = (uint16_t)jf.trunc_bcv[0];   // vp8_decoder.cc:366-368
     *out = f.release();
     return 0;

@@ -534,10 +534,7 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
         }
         if (P > 1 && total + (512u << 10) + 4 * (uint64_t)n > ((uint64_t)576 << 20)) return EX_BLOCK_OFFSET_OOM;
     }
-    // the general re-coder decodes through decode_chunk, which gives up when the file has more logical threads than the
-    // decoder was started with: `num_threads_needed > NUM_THREADS` -> CODING_ERROR (vp8_decoder.cc:415-417), NUM_THREADS =
-    // min(8, thread hint) (read_fixed_ujpg_header, jpgcoder.cc:2167-2171)
-    if (!baseline_recoder && lf->segs.size() > (size_t)std::min(lf->nthreads, 8)) return EX_CODING_ERROR;
+    // (more logical threads than the general re-coder's decoder was started with: lep_file_open_next, behind the split-table check)
     bool saw_eof = false;
     const size_t end = demux_packets(d, n, at, &lf->streams, &saw_eof);
     // Format versions >= 2 end their packets with a marker, so the reader knows where the file stops: 3 marker bytes, the

@@ -18,7 +18,9 @@ EMU_SO = os.environ.get("LEP_EMU_SO") or os.path.join(ROOT, "tests", "emu", "lib
 def emu():
     src = os.path.join(ROOT, "tests", "emu", "core_emu.cc")
     extra = os.environ.get("LEP_EMU_DEFINES", "").split()   # experiment variants of the kernels (-DLEP_...)
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared"] + extra + ["-o", EMU_SO, src])
+    tmp = "%s.%d" % (EMU_SO, os.getpid())    # (several pytest-xdist workers may build it at once: write aside, rename into place)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared"] + extra + ["-o", tmp, src])
+    os.replace(tmp, EMU_SO)
     return C.CDLL(EMU_SO)
 
 
@@ -28,7 +30,9 @@ def emu_other_forms():
     the shipped build runs the 7x7 round on the scalar unit, this one everything but): every round is stepped in both forms"""
     src = os.path.join(ROOT, "tests", "emu", "core_emu.cc")
     so = os.path.join(ROOT, "tests", "emu", "libcore_emu_forms.so")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DLEP_DEC4_SCALAR=13", "-o", so, src])
+    tmp = "%s.%d" % (so, os.getpid())
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DLEP_DEC4_SCALAR=13", "-o", tmp, src])
+    os.replace(tmp, so)
     return C.CDLL(so)
 
 

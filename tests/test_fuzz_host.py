@@ -254,3 +254,56 @@ def test_a_truncated_multi_segment_file_is_refused_like_the_reference():
     f = LepFile(lep)
     ob.oracle_decode(f.desc, f.segments, f.streams)
     assert f.recode() == golden("q30_256x256_4seg")[0]
+
+
+def test_hand_off_fields_a_damaged_file_can_carry():
+    """field-level mutants of the hand-off records (tests/fuzz/mutate.py with_handoffs(field=...), format 1 and 2), each pinned
+    to what the reference binary answers (tests/fuzz/diff_lep_structured.py found them):
+    * luma_y_start inside an MCU row: the baseline re-coder takes MCU rows whose FIRST luma row is not in front of it
+      (recode_row_range, recoder.cc:505-510) -- the decoder starts at the next MCU row, as a top row;
+    * overhang bit counts of 8..64 are the byte plus zero bits; beyond 64 the reference's 64-bit buffer goes negative: the first
+      value written is widened by the excess or, past the buffer's width, dropped with 64 zero bits in its place (bitops.hh:120-163);
+      bits of the byte below the count it claims are OR-ed with what is written next;
+    * format 2: the first thread's bound is a 32-bit sum that wraps in front of what is written: assertion (bitops.cc:402);
+    * a worker's buffer is allocated at its bound from a 576 MiB arena: OOM before anything is decoded (recoder.cc:770-782);
+    * a pre-hand-off record (bit count 0xff) at the head of a worker's range starts clean from its own record (recoder.cc:584-592)"""
+    import hashlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
+    import mutate as mu
+    import oracle_binding as ob
+    from conftest import GOLDEN
+    from lepton_amd.codec import LepFile, LeptonError
+
+    def v2(n):
+        return open(os.path.join(GOLDEN, "v2", n + ".lep"), "rb").read()
+
+    def restore(b):
+        try:
+            f = LepFile(b)
+            ob.oracle_decode(f.desc, f.segments, f.streams)
+            d = f.recode()
+            return len(d), hashlib.md5(d).hexdigest()
+        except LeptonError as e:
+            return e.code
+
+    g = lambda n: golden(n)[1]
+    two = lambda lep, a, b: mu.with_handoffs(mu.with_handoffs(lep, field=a), field=b)
+    cases = [
+        (mu.with_handoffs(g("lay_mixed_200x120"), field=(0, 0, 2, 1)), (11705, "8398c8cf9247384a9eb5c42cb69b2351")),
+        (mu.with_handoffs(g("truncated"), field=(0, 0, 2, 7)), (3458, "8a1a4b929284954d465b2105fc31cb81")),
+        (mu.with_handoffs(v2("narrowrst"), field=(0, 7, 1, 0x43)), (35243, "2c8cf49462c47d283b569fabde42087c")),
+        (mu.with_handoffs(v2("rst_c420_176x112"), field=(0, 7, 1, 0xb6)), (5108, "09c67225382fbf90c4cad8547a5c235d")),
+        (mu.with_handoffs(g("lay_mixed_200x120"), field=(0, 7, 1, 0xa3)), (13235, "646533b09590f8141c9bc6261f19fbd6")),
+        (mu.with_handoffs(g("lay_mixed_200x120"), field=(0, 7, 1, 0x40)), (13235, "54e435f09a320c604a8f8c67e02dc58d")),
+        (two(g("c420_160x120"), (0, 7, 1, 9), (0, 6, 1, 0xff)), (5799, "e6c9c839632a4a0d774b326a978dc4ff")),
+        (two(g("c420_160x120"), (0, 7, 1, 3), (0, 6, 1, 0xff)), (5801, "497555f575b54e08ced6294cec536a0f")),
+        (mu.with_handoffs(v2("gray_120x88"), field=(0, 2, 4, 0xffffffff)), 1),
+        (mu.with_handoffs(g("q30_256x256_4seg"), field=(1, 2, 4, 0x7fffffff)), 37),
+        (mu.with_handoffs(g("q30_256x256_4seg"), field=(1, 2, 4, 500 << 20)), (178322, "74fcf2c3adf1fb8dd53b30d717b329f5")),
+        (mu.with_handoffs(v2("q30_256x256_4seg"), field=(1, 7, 1, 0xff)), (178304, "f69435c2a9144ad58b1b660d09c681ca")),
+        (mu.with_handoffs(g("q30_256x256_4seg"), field=(1, 7, 1, 0xff)), (178304, "f69435c2a9144ad58b1b660d09c681ca")),
+    ]
+    for i, (lep, want) in enumerate(cases):
+        assert restore(lep) == want, i
