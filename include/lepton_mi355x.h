@@ -30,6 +30,8 @@ enum {
     LEP_UNSUPPORTED_4_COLORS = 4, LEP_COEFFICIENT_OUT_OF_RANGE = 6, LEP_STREAM_INCONSISTENT = 7,
     LEP_PROGRESSIVE_UNSUPPORTED = 8, LEP_SAMPLING_BEYOND_TWO_UNSUPPORTED = 10,
     LEP_THREADING_PARTIAL_MCU = 12, LEP_VERSION_UNSUPPORTED = 13, LEP_ONLY_GARBAGE_NO_JPEG = 14, LEP_OS_ERROR = 33,
+    LEP_SAMPLING_BEYOND_FOUR_UNSUPPORTED = 11,
+    LEP_OOM = 37,                      /* a .lep whose header claims sizes beyond the reference's 576 MiB arena (its allocator's exit code) */
     LEP_TOO_MUCH_MEMORY_NEEDED = 38,   /* coefficient frame beyond the reference's default budget of 4,423,680 blocks (566 MB) */
     LEP_ROUNDTRIP_FAILURE = 41, LEP_UNSUPPORTED_JPEG = 42, LEP_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 43,
     LEP_BUFFER_TOO_SMALL = 100, LEP_GPU_ERROR = 120

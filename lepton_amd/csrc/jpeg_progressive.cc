@@ -314,7 +314,11 @@ int encode_ac_refine(ScanWriter& sw, const HuffTable& ac, const int16_t* blk, un
 int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
     JpegFile& jf = lf->jpeg;
     const size_t max_file_size = lf->jpeg_size;
-    if ((int32_t)lf->jpeg_size <= (int32_t)jf.garbage.size()) return EX_ASSERTION_FAILURE;   // always_assert(max_file_size > grbs), both ints
+    // always_assert(max_file_size > grbs), both ints: where the reference first hands bytes to its output (merge_jpeg_streaming,
+    // jpgcoder.cc:2570-2572, called after each restart interval of recode_jpeg) -- what is wrong with the first scan's tables
+    // is reported before it
+    const bool all_garbage = (int32_t)lf->jpeg_size <= (int32_t)jf.garbage.size();
+    bool output_started = false;
     const uint8_t* h = jf.hdr.data();
     const size_t hdrs = jf.hdr.size();
 
@@ -438,11 +442,13 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
                 if (jf.cs_sah != 0) sw.flush_corr();
             }
             sw.w.pad((uint8_t)jf.padbit);
+            if (sta < 0) return EX_CODING_ERROR;
+            if (!output_started) { output_started = true; if (all_garbage) return EX_ASSERTION_FAILURE; }
             if (sta == 2) break;
             if (sta == 1 && jf.rsti > 0) rstp.push_back(sw.w.bytes.size() - 1);
-            if (sta < 0) return EX_CODING_ERROR;
         }
     }
+    if (all_garbage) return EX_ASSERTION_FAILURE;
     scnp.push_back(sw.w.bytes.size());
     const std::vector<uint8_t>& huff = sw.w.bytes;
 
@@ -481,8 +487,9 @@ int recode_progressive_prepare(LepFile* lf, ProgPlan* plan) {
     plan->gpu_ok = false;
     plan->scans.clear(); plan->scan_hdr_end.clear(); plan->markers.clear();
     if (lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1)) return 0;   // the baseline re-coder's files
-    if (lf->jpeg_size <= lf->jpeg.garbage.size()) return EX_ASSERTION_FAILURE;
-    return progressive_plan(&lf->jpeg, lf->jpeg_size, lf->rst_cnt_set, plan);
+    if (int rc = progressive_plan(&lf->jpeg, lf->jpeg_size, lf->rst_cnt_set, plan)) return rc;   // (what is wrong with the tables comes first, as in recode_progressive)
+    if ((int32_t)lf->jpeg_size <= (int32_t)lf->jpeg.garbage.size()) return EX_ASSERTION_FAILURE;
+    return 0;
 }
 
 // The plan itself, from a parsed JPEG: the decompressor's (above, the JpegFile rebuilt from a .lep header) and the

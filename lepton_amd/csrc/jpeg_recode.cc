@@ -285,6 +285,40 @@ int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pa
 
 int recode_progressive(LepFile* lf, std::vector<uint8_t>* result);   // jpeg_progressive.cc
 
+// The part of recode_baseline_jpeg that runs before the first row is decoded (recoder.cc:694-705): the all-garbage assertion and
+// handle_initial_segments -- the header walked up to the first SOS, its DHT / DRI / SOS segments interpreted.  A file refused
+// here is refused with this verdict whatever its streams hold; lep_file_open_next asks before anything is decoded.
+int baseline_header_pass(LepFile* lf) {
+    JpegFile& jf = lf->jpeg;
+    size_t pos = 0;
+    const uint8_t* h = jf.hdr.data();
+    const size_t hdrs = jf.hdr.size();
+    if (!(lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1))) {
+        // the general re-coder (recode_jpeg, jpgcoder.cc:3345-3372) waits for decoded blocks position by position; the tables in
+        // front of its first scan are interpreted before it waits for anything
+        for (uint8_t type = 0; type != 0xDA;) {
+            if (pos >= hdrs) break;
+            type = pos + 1 < hdrs ? h[pos + 1] : 0;
+            const unsigned len = 2 + (((unsigned)(pos + 2 < hdrs ? h[pos + 2] : 0)) << 8) + (pos + 3 < hdrs ? h[pos + 3] : 0);
+            if (type == 0xC4 || type == 0xDA || type == 0xDD)
+                if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - pos), h + pos, false)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;
+            pos += len;
+        }
+        return 0;
+    }
+    if ((int32_t)lf->jpeg_size <= (int32_t)jf.garbage.size()) return EX_ASSERTION_FAILURE;
+    for (;;) {
+        if (pos + 3 >= hdrs) return EX_UNSUPPORTED_JPEG;   // "overran headers"
+        if (h[pos] != 0xff) return EX_UNSUPPORTED_JPEG;    // "not start of segment"
+        const uint8_t type = h[pos + 1];
+        const unsigned len = 2 + ((unsigned)h[pos + 2] << 8) + h[pos + 3];
+        if (type == 0xC4 || type == 0xDD || type == 0xDA)
+            if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - pos), h + pos, false)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;
+        pos += len;
+        if (type == 0xDA) return 0;
+    }
+}
+
 int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
     JpegFile& jf = lf->jpeg;
     // 'Z' and 'Y' (a -startbyte slice) take the baseline re-coder, 'X' the general one: read_fixed_ujpg_header tests

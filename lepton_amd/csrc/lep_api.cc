@@ -275,6 +275,9 @@ int lep_file_open_next(const uint8_t* d, size_t len, const lep_file* prev, lep_f
     // min(8, thread hint) (read_fixed_ujpg_header, jpgcoder.cc:2167-2171) -- after the split table has been read and checked
     if (!(f->lf.flag == 'Z' || (f->lf.flag & 1) == ('Y' & 1)) && f->lf.segs.size() > (size_t)std::min(f->lf.nthreads, 8)) return LEP_CODING_ERROR;
     if (!f->lf.segs.empty()) f->lf.segs.back().luma_y_end = (uint16_t)jf.trunc_bcv[0];   // vp8_decoder.cc:366-368
+    // the baseline re-coder looks at the header's tables and allocates its workers' buffers before it decodes a row
+    if (int hrc = lep::baseline_header_pass(&f->lf)) return hrc;
+    if (lep::worker_bounds_exceed_arena(f->lf, len)) return LEP_OOM;
     *out = f.release();
     return 0;
 }

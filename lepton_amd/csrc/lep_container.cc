@@ -369,6 +369,29 @@ size_t demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vec
 
 // carried: what a previous file of the same stream left in the header reader behind a "CNT" section (`lepton -lepcat`
 // merges the headers of all its inputs into the first file's, concat.cc:67-108); this file then has no header of its own
+// Every worker thread's output buffer is allocated up front at its byte bound -- the sum of its logical threads' segment sizes
+// as an int, the whole file's size if that is zero (recode_baseline_jpeg, recoder.cc:770-782; BoundedMemWriter::set_bound
+// resizes) -- from the main arena of the default build (1024 MiB - 7 x 64 MiB, jpgcoder.cc:827-838): hand-offs that claim
+// more than it holds end in OOM before a single bin is decoded, whatever the streams are.  Probed against the binary: the
+// worker bounds may sum to 575.5 MiB beside a 256x256 image and 571.7 MiB beside a 1600x1200 one (what else lives in the
+// arena grows with the file); the first thread writes to the output and is not counted.
+bool worker_bounds_exceed_arena(const LepFile& lf, size_t file_bytes) {
+    const bool baseline_recoder = lf.flag == 'Z' || (lf.flag & 1) == ('Y' & 1);
+    if (!baseline_recoder || lf.segs.empty() || lf.segs[0].num_overhang_bits == 0xff) return false;
+    const int P = std::min(lf.nthreads, 8), L = (int)lf.segs.size();
+    uint64_t total = 0;
+    for (int p = 1; p < P; ++p) {
+        int a = p * L / P, b = std::min((p + 1) * L / P, L);
+        if (L < P) { a = std::min(p, L); b = std::min(p + 1, L); }   // logical_thread_range_from_physical_thread_id, recoder.cc:547-559
+        int32_t work = 0;
+        for (int l = a; l < b; ++l) work = (int32_t)((uint32_t)work + lf.segs[l].segment_size);
+        if (!work) work = (int32_t)lf.jpeg_size;
+        if (work < 0) return true;   // (size_t)(int) of a negative bound: no arena holds it
+        total += (uint64_t)work;
+    }
+    return P > 1 && total + (512u << 10) + 4 * (uint64_t)file_bytes > ((uint64_t)576 << 20);
+}
+
 int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t>* carried) {
     if (n >= 2 && n < 28 && d[0] == 0xCF && d[1] == 0x84) return EX_SHORT_READ;   // read_fixed_ujpg_header: ReadFull(22) != 22
     if (n < 28 || d[0] != 0xCF || d[1] != 0x84) return EX_VERSION_UNSUPPORTED;
@@ -411,10 +434,21 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
     const uint32_t hdrs = get_le32(mrk);
     // Sizes the reference would try to allocate from its main arena (576 MiB in the default build, jpgcoder.cc:827-838) and
     // fail: OOM, whatever else is wrong with the file.  Between 128 MiB and the arena the reference allocates, zero-fills and
-    // reads what is there; an in-process daemon does not follow it there (refused as STREAM_INCONSISTENT: documented deviation).
+    // reads what is there; an in-process daemon does not follow it there (garbage sections of that size are refused as
+    // STREAM_INCONSISTENT: documented deviation; the header's case is decided without the allocation, below).
     const uint64_t kArena = ((uint64_t)576 << 20) - (1u << 20);
     if (hdrs > kArena) return EX_BLOCK_OFFSET_OOM;
-    if (hdrs > (128u << 20)) return EX_STREAM_INCONSISTENT;
+    if (hdrs > (128u << 20)) {
+        // the reference allocates and zero-fills that much, reads what the file holds into it and interprets it; nothing is left
+        // for the sections behind it: "PAD marker not found" unless the header itself is refused first.  The same verdicts from
+        // what the file holds plus a short zero tail, without the allocation.
+        const size_t have = left();
+        jf.hdr.assign(have + 16, 0);
+        read_full(jf.hdr.data(), have);
+        memset(jf.qtables, 0, sizeof jf.qtables);
+        if (!setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;
+        return EX_UNSUPPORTED_JPEG;
+    }
     jf.hdr.assign(hdrs, 0);
     read_full(jf.hdr.data(), hdrs);
     // the embedded JPEG header is interpreted here, before the sections behind it are looked at (setup_imginfo_jpg, called at
@@ -514,26 +548,7 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
     if (lf->segs.size() > 16) return EX_ASSERTION_FAILURE;
     const bool baseline_recoder = lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1);   // jpgcoder.cc:2162; the general re-coder is single-threaded
     if (baseline_recoder && lf->segs[0].num_overhang_bits != 0xff && (size_t)std::min(lf->nthreads, 8) > lf->segs.size()) return EX_ASSERTION_FAILURE;
-    // Every worker thread's output buffer is allocated up front at its byte bound -- the sum of its logical threads' segment sizes
-    // as an int, the whole file's size if that is zero (recode_baseline_jpeg, recoder.cc:770-782; BoundedMemWriter::set_bound
-    // resizes) -- from the main arena of the default build (1024 MiB - 7 x 64 MiB, jpgcoder.cc:827-838): hand-offs that claim
-    // more than it holds end in OOM before a single bin is decoded, whatever the streams are.  Probed against the binary: the
-    // worker bounds may sum to 575.5 MiB beside a 256x256 image and 571.7 MiB beside a 1600x1200 one (what else lives in the
-    // arena grows with the file); the first thread writes to the output and is not counted.
-    if (baseline_recoder && lf->segs[0].num_overhang_bits != 0xff) {
-        const int P = std::min(lf->nthreads, 8), L = (int)lf->segs.size();
-        uint64_t total = 0;
-        for (int p = 1; p < P; ++p) {
-            int a = p * L / P, b = std::min((p + 1) * L / P, L);
-            if (L < P) { a = std::min(p, L); b = std::min(p + 1, L); }   // logical_thread_range_from_physical_thread_id, recoder.cc:547-559
-            int32_t work = 0;
-            for (int l = a; l < b; ++l) work = (int32_t)((uint32_t)work + lf->segs[l].segment_size);
-            if (!work) work = (int32_t)lf->jpeg_size;
-            if (work < 0) return EX_BLOCK_OFFSET_OOM;   // (size_t)(int) of a negative bound: no arena holds it
-            total += (uint64_t)work;
-        }
-        if (P > 1 && total + (512u << 10) + 4 * (uint64_t)n > ((uint64_t)576 << 20)) return EX_BLOCK_OFFSET_OOM;
-    }
+    // (worker bounds beyond the arena: worker_bounds_exceed_arena, called by lep_file_open_next behind the re-coder's header pass)
     // (more logical threads than the general re-coder's decoder was started with: lep_file_open_next, behind the split-table check)
     bool saw_eof = false;
     const size_t end = demux_packets(d, n, at, &lf->streams, &saw_eof);

@@ -36,6 +36,8 @@ void mux_streams(const std::vector<std::vector<uint8_t>>& streams, int version, 
 int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::vector<std::vector<uint8_t>>& streams,
               std::vector<uint8_t>* out);
 int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t>* carried = nullptr);
+bool worker_bounds_exceed_arena(const LepFile& lf, size_t file_bytes);   // lep_container.cc
+int baseline_header_pass(LepFile* lf);                                   // jpeg_recode.cc: what recode_baseline_jpeg checks before it decodes a row
 size_t demux_packets(const uint8_t* d, size_t n, size_t at, std::vector<std::vector<uint8_t>>* streams, bool* saw_eof = nullptr);
 bool brotli_available();
 
