@@ -124,9 +124,18 @@ struct BitWriter {
     uint64_t acc = 0;   // pending bits, left-aligned
     int nacc = 0;       // number of pending bits (< 8 after drain)
     uint8_t fillbit = 1;
+    // bits the reference's 64-bit buffer would hold at this point (64 - cbit2): it is emptied whenever it fills, at every pad
+    // and -- down to the last partial byte -- at the end of every MCU row (partial_bytewise_flush).  The baseline re-coder
+    // hands bytes to its bounded output only at those row ends, at pads, and behind a block that leaves the buffer exactly
+    // empty (no_remainder(), recoder.cc:366-369), so WHEN a byte bound is noticed depends on it (RowCoder::mcu_row).
+    int phase = 0;
+    bool buffer_empty() const { return phase == 0; }
+    void row_flush() { phase &= 7; }
 
     void put(unsigned val, int nbits) {
         if (excess) { put_after_oversized_seed(val, nbits); return; }
+        phase += nbits;
+        if (phase >= 64) phase -= 64;
         while (nbits > 0) {
             int take = nbits > 32 ? 32 : nbits;
             uint64_t v = (val >> (nbits - take)) & (take == 32 ? 0xffffffffull : ((1ull << take) - 1));
@@ -139,6 +148,7 @@ struct BitWriter {
     void pad(uint8_t pattern) {
         int off = 1;
         while (nacc & 7) { put((pattern & off) ? 1 : 0, 1); off <<= 1; }
+        phase = 0;
     }
     // state a thread segment starts in (abitwriter::reset_from_overhang_byte_and_num_bits, bitops.hh:203-214: buf = byte << 56,
     // cbit2 = 64 - nbits).  A well-formed hand-off has nbits < 8; a damaged one can say anything up to 255.  Up to 64 the
@@ -151,14 +161,16 @@ struct BitWriter {
         bytes.clear(); acc = (uint64_t)overhang_byte << 56; excess = 0;
         if (nbits > 64) { excess = nbits - 64; nacc = 64; }
         else nacc = nbits;
+        phase = nacc;
         while (nacc >= 8) { bytes.push_back((uint8_t)(acc >> 56)); acc <<= 8; nacc -= 8; }
     }
     void put_after_oversized_seed(unsigned val, int nbits) {
         const int wide = nbits + excess;
         excess = 0;
-        if (wide > 64) { for (int i = 0; i < 8; ++i) bytes.push_back(0); return; }   // the value is lost, 64 zero bits take its place
+        if (wide > 64) { for (int i = 0; i < 8; ++i) bytes.push_back(0); phase = 0; return; }   // the value is lost, 64 zero bits take its place
         acc = wide ? ((uint64_t)val & (~0ull >> (64 - wide))) << (64 - wide) : 0;
         nacc = wide;
+        phase = wide & 63;
         while (nacc >= 8) { bytes.push_back((uint8_t)(acc >> 56)); acc <<= 8; nacc -= 8; }
     }
     uint8_t overhang_byte() const { return (uint8_t)(acc >> 56); }

@@ -116,7 +116,7 @@ struct RowCoder {
                 int old_mcu = mcu;
                 if (ncomp == 1) { sta = next_mcuposn(jf, cmp, &dpos, &rstw); mcu = dpos / mcumul; }
                 else sta = next_mcupos(jf, &mcu, &cmp, &csc, &sub, &dpos, &rstw, ncomp);
-                drain(w, out);
+                if (sta == 0 && w.buffer_empty()) drain(w, out);   // (the bytes of a row reach the output at its end, see BitWriter::phase)
                 if (out.exceeded()) sta = 2;
                 if (old_mcu != mcu && mcu % jf.mcuh == 0) {
                     end_of_row = true;
@@ -398,6 +398,7 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
             if (y1 > th.luma_y_end) break;
             rc.mcu_row(w, mcu_row * jf.mcuh, *o, lastdc);
             drain(w, *o);
+            w.row_flush();
         }
         carry.overhang_byte = w.overhang_byte();
         carry.num_overhang_bits = (uint8_t)w.overhang_bits();
