@@ -350,7 +350,7 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
             hpos += len;
         }
         if (type != 0xDA) break;
-        scan_hdr_end.push_back(std::min(hpos, hdrs));
+        scan_hdr_end.push_back(hpos);   // (may lie behind the header: an SOS length field that reaches past it; the merge writes null bytes for the difference, jpgcoder.cc:2594-2598)
         scnp.push_back(sw.w.bytes.size());
         int cmp = jf.cs_cmp[0], csc = 0, mcu = 0, sub = 0, dpos = 0;
         const int from = jf.cs_from, to = jf.cs_to, sal = jf.cs_sal;
@@ -462,7 +462,7 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
     if (lf->embedded || !lf->has_prefix) { put(0xFF); put(0xD8); }
     size_t hp = 0, rpos = 0;
     for (size_t scan = 0; scan < scan_hdr_end.size(); ++scan) {
-        for (size_t i = hp; i < scan_hdr_end[scan]; ++i) put(h[i]);
+        for (size_t i = hp; i < scan_hdr_end[scan]; ++i) { if (out.size() >= bound) break; put(i < hdrs ? h[i] : (uint8_t)0); }
         hp = scan_hdr_end[scan];
         unsigned cpos = 0, nrst = 0;
         for (size_t i = scnp[scan]; i < scnp[scan + 1]; ++i) {
@@ -526,7 +526,7 @@ int progressive_plan(JpegFile* jfp, size_t jpeg_size, bool rst_cnt_set, ProgPlan
             hpos += len;
         }
         if (type != 0xDA) break;
-        plan->scan_hdr_end.push_back(std::min(hpos, hdrs));
+        plan->scan_hdr_end.push_back(hpos);
         if (rsti_seen >= 0 && rsti_seen != jf.rsti) return 0;   // a restart interval that changes between scans: host
         rsti_seen = jf.rsti;
         ProgScan sc;
@@ -590,7 +590,7 @@ int recode_progressive_finish(LepFile* lf, const ProgPlan& plan, const std::vect
     if (lf->embedded || !lf->has_prefix) { put(0xFF); put(0xD8); }
     size_t hp = 0;
     for (size_t scan = 0; scan < plan.scans.size(); ++scan) {
-        for (size_t i = hp; i < plan.scan_hdr_end[scan]; ++i) put(h[i]);
+        for (size_t i = hp; i < plan.scan_hdr_end[scan]; ++i) { if (out.size() >= bound) break; put(i < hdrs ? h[i] : (uint8_t)0); }
         hp = plan.scan_hdr_end[scan];
         const size_t room = out.size() < bound ? bound - out.size() : 0, n = std::min(room, scan_bytes[scan].second);
         out.insert(out.end(), scan_bytes[scan].first, scan_bytes[scan].first + n);

@@ -307,3 +307,27 @@ def test_hand_off_fields_a_damaged_file_can_carry():
     ]
     for i, (lep, want) in enumerate(cases):
         assert restore(lep) == want, i
+
+
+def test_sos_length_past_the_header_of_a_progressive_file():
+    """the general re-coder's merge writes "null bytes beyond buffer" for an SOS length field that reaches past the stored header
+    (merge_jpeg_streaming, jpgcoder.cc:2594-2598) -- found by the structured sweep over progressive fixtures, pinned to the
+    reference's output; and seventeen hand-offs are CODING_ERROR there, not the baseline re-coder's assertion"""
+    import hashlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
+    import mutate as mu
+    import oracle_binding as ob
+    from lepton_amd.codec import LepFile, LeptonError
+
+    lep = golden("prog_truncated_dc")[1]
+    fixed, payload, rest = mu.lep_split(lep)
+    i = payload.index(b"\xff\xda\x00\x0c")
+    f = LepFile(mu.lep_join(fixed, payload[: i + 2] + b"\xff" + payload[i + 3:], rest))
+    ob.oracle_decode(f.desc, f.segments, f.streams)
+    out = f.recode()
+    assert len(out) == 1100 and hashlib.md5(out).hexdigest() == "a33a16cf2195a549bb63e213c301a940"
+    with pytest.raises(LeptonError) as e:
+        LepFile(mu.with_handoffs(golden("prog_c420_320x240")[1], count=17))
+    assert e.value.code == 2
