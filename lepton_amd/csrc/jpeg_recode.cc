@@ -22,10 +22,11 @@ namespace {
 struct BoundedOut {   // bounded_iostream / BoundedMemWriter: bytes past the bound are dropped but counted
     std::vector<uint8_t> buf;
     size_t bound = 0, attempted = 0;
-    void put(uint8_t b) { ++attempted; if (!bound || buf.size() < bound) buf.push_back(b); }
+    bool shut = false;   // a bound of zero bytes (a worker's buffer resized to nothing); bound == 0 alone means "none"
+    void put(uint8_t b) { ++attempted; if (!shut && (!bound || buf.size() < bound)) buf.push_back(b); }
     void write(const uint8_t* d, size_t n) { for (size_t i = 0; i < n; ++i) put(d[i]); }
-    bool exceeded() const { return bound && attempted > bound; }
-    bool reached() const { return bound && buf.size() >= bound; }
+    bool exceeded() const { return shut ? attempted > 0 : (bound && attempted > bound); }
+    bool reached() const { return shut || (bound && buf.size() >= bound); }
 };
 
 static inline int blen16(unsigned v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
@@ -184,6 +185,7 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
     bool ok = !jf.early_eof && jf.ncomp >= 1 && jf.ncomp <= 3 && jf.cs_cmpc == jf.ncomp && jf.mcuh > 0 && jf.mcuv > 0 &&
               jf.trunc_bcv[0] >= jf.comp[0].bcv && !lf->segs.empty();
     for (const Handoff& th : lf->segs) if (th.num_overhang_bits == 0xff || th.num_overhang_bits > 7) ok = false;
+    for (size_t q = 1; q < lf->segs.size(); ++q) if (lf->version > 1 && !lf->segs[q].segment_size) ok = false;   // a worker bound of nothing: host path
     if (ok && lf->version > 1 && (uint64_t)plan->head.size() + lf->segs[0].segment_size > 0xffffffffull) ok = false;   // the first thread's bound wraps (recode_jpeg): host path
     if (ok && jf.ncomp == 1) {
         const Component& k = jf.comp[jf.cs_cmp[0]];
@@ -370,7 +372,10 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
         }
         BoundedOut seg;
         BoundedOut* o = &out;
-        if (s > 0 && !legacy) { seg.bound = th.segment_size ? th.segment_size : max_file_size; o = &seg; }
+        // (format 1: a worker's buffer is as large as its segment size, the whole file if that is zero; from format 2 on the
+        // thread re-bounds it to bytes_written + segment_size, and a segment size of zero leaves room for nothing:
+        // recode_physical_thread, recoder.cc:598-613, BoundedMemWriter::set_bound)
+        if (s > 0 && !legacy) { seg.bound = th.segment_size ? th.segment_size : max_file_size; seg.shut = !th.segment_size && lf->version > 1; o = &seg; }
         else if (s > 0 && work_bound > 0) { seg.bound = (size_t)work_bound; o = &seg; }
         // version >= 2: the first thread is bound by its segment size too (recoder.cc:598-613: new_bound = bytes_written +
         // segment_size, applied when it is tighter than the file's)

@@ -304,6 +304,7 @@ def test_hand_off_fields_a_damaged_file_can_carry():
         (mu.with_handoffs(g("q30_256x256_4seg"), field=(1, 2, 4, 500 << 20)), (178322, "74fcf2c3adf1fb8dd53b30d717b329f5")),
         (mu.with_handoffs(v2("q30_256x256_4seg"), field=(1, 7, 1, 0xff)), (178304, "f69435c2a9144ad58b1b660d09c681ca")),
         (mu.with_handoffs(g("q30_256x256_4seg"), field=(1, 7, 1, 0xff)), (178304, "f69435c2a9144ad58b1b660d09c681ca")),
+        (mu.with_handoffs(v2("q30_256x256_4seg"), field=(1, 2, 4, 0)), (89187, "adf95715ee513e460ee019f730634684")),   # format 2: a worker bound of zero bytes
     ]
     for i, (lep, want) in enumerate(cases):
         assert restore(lep) == want, i
