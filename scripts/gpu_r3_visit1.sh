@@ -1,8 +1,8 @@
 #!/bin/bash
 # First hardware visit of the next round (prepared at the end of round 2, when the GPU budget was spent):
 #  1. the GPU suite on the tree as it stands -- the host-side parity rules added after round 2's last visit (two-row ring behind a
-#     truncation point, hand-off consistency checks, zero-filled Huffman tables) have only been through the CPU suite and the
-#     lane-loop emulation;
+#     truncation point, hand-off consistency checks and field rules, refusals answered at open in the reference's order, output
+#     flush timing of the baseline re-coder) have only been through the CPU suite and the lane-loop emulation;
 #  2. the instruction-rate micro-benchmark with its new rows: does a vector instruction cost less under a narrowed exec mask
 #     (1 / 16 / 32 lanes)?  If it does, the serial rounds of both coders belong in lanes 0..15 and nothing else matters as much;
 #  3. the default bench line.

@@ -160,7 +160,8 @@ def mutate(rng, d):
 def main():
     out, count, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     here = os.path.dirname(os.path.abspath(__file__))
-    seeds = sorted(glob.glob(os.path.join(here, "..", "golden", "*.jpg")) + glob.glob(os.path.join(here, "..", "golden", "*.lep")))
+    seeds = sorted(glob.glob(os.path.join(here, "..", "golden", "*.jpg")) + glob.glob(os.path.join(here, "..", "golden", "*.lep")) +
+                   glob.glob(os.path.join(here, "..", "golden", "v2", "*.lep")))
     seeds = [s for s in seeds if os.path.getsize(s) < 60000]
     blobs = [open(s, "rb").read() for s in seeds]
     rng = random.Random(seed)
