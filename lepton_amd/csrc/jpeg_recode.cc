@@ -54,24 +54,6 @@ void encode_block(BitWriter& w, const HuffTable& dc, const HuffTable& ac, const 
 }
 
 // move whole bytes from the bit writer to the output, stuffing 00 after FF
-// > 0 when logical thread s is the first one of a worker (physical thread >= 1) of the reference's thread pool: the bound of
-// that worker's output buffer = the sum of its logical threads' segment sizes as an int, the file's size if that is zero
-// (logical_thread_range_from_physical_thread_id, recoder.cc:547-559; recode_baseline_jpeg, recoder.cc:770-782)
-int physical_range_start(const LepFile& lf, int s) {
-    if (lf.segs.empty() || lf.segs[0].num_overhang_bits == 0xff) return 0;   // one physical thread
-    const int P = std::max(1, std::min(lf.nthreads, 8)), L = (int)lf.segs.size();
-    for (int p = 1; p < P; ++p) {
-        int a = p * L / P, b = std::min((p + 1) * L / P, L);
-        if (L < P) { a = std::min(p, L); b = std::min(p + 1, L); }
-        if (a != s || b <= a) continue;
-        int32_t work = 0;
-        for (int l = a; l < b; ++l) work = (int32_t)((uint32_t)work + lf.segs[l].segment_size);
-        if (!work) work = (int32_t)lf.jpeg_size;
-        return work > 0 ? work : 0x7fffffff;
-    }
-    return 0;
-}
-
 void drain(BitWriter& w, BoundedOut& out) {
     for (uint8_t b : w.bytes) { out.put(b); if (b == 0xFF) out.put(0); }
     w.bytes.clear();
@@ -352,76 +334,103 @@ int recode_jpeg(LepFile* lf, std::vector<uint8_t>* result) {
         for (size_t k = hdrs; k < pos; ++k) out.put(0);   // (see recode_prepare: a length field past the stored header)
     }
 
-    // 2. the scan, segment by segment
+    // 2. the scan, logical thread by logical thread, grouped the way the reference groups them onto its physical threads
+    // (recode_baseline_jpeg / recode_physical_thread, recoder.cc:560-651, 757-800): physical thread 0 writes straight into the
+    // bounded output, every other one into a buffer of its own that is as large as its logical threads' segment sizes together
+    // (the whole file if that is zero) and is appended when all are done.  A file is normally one logical thread per physical
+    // thread; a damaged thread hint or hand-off count folds several onto one, and then the bounds are cumulative.
     RowCoder rc(*lf);
     const int luma_mul = jf.comp[0].bcv / jf.mcuv;
-    Handoff carry;
-    for (size_t s = 0; s < lf->segs.size(); ++s) {
-        Handoff th = lf->segs[s];
-        bool legacy = th.num_overhang_bits == 0xff;
-        // A pre-hand-off record takes the state the previous logical thread of the SAME physical thread ended in; the first one a
-        // physical thread runs starts clean: no pending bits, the byte and the last DCs of its own record
-        // (recode_physical_thread, recoder.cc:584-592).  A file whose first record is of that kind runs on one thread
-        // (recoder.cc:730-732); in any other file a damaged record of that kind can sit at the head of a worker's range.
-        const int work_bound = physical_range_start(*lf, (int)s);   // > 0: s opens a worker thread's range, its buffer's bound
-        if (legacy) {
-            if (s == 0 || work_bound > 0) { carry = lf->segs[s]; carry.num_overhang_bits = 0; }
-            th.overhang_byte = carry.overhang_byte;
-            th.num_overhang_bits = carry.num_overhang_bits;
-            memcpy(th.last_dc, carry.last_dc, sizeof th.last_dc);
+    const int L = (int)lf->segs.size();
+    const bool one_thread = lf->segs[0].num_overhang_bits == 0xff;   // a pre-hand-off first record: g_threaded = false (recoder.cc:730-732)
+    const int P = one_thread ? 1 : std::max(1, std::min(lf->nthreads, 8));
+    auto range_of = [&](int p, int* a, int* b) {   // logical_thread_range_from_physical_thread_id, recoder.cc:547-559
+        *a = p * L / P; *b = std::min((p + 1) * L / P, L);
+        if (L < P) { *a = std::min(p, L); *b = std::min(p + 1, L); }
+    };
+    const size_t file_bound = out.bound;
+    for (int p = 0; p < P; ++p) {
+        int first, last;
+        range_of(p, &first, &last);
+        if (first >= last) continue;
+        BoundedOut worker;                 // physical threads >= 1
+        BoundedOut* o = p ? &worker : &out;
+        size_t original_bound = file_bound;
+        if (p) {
+            int32_t work = 0;
+            for (int l = first; l < last; ++l) work = (int32_t)((uint32_t)work + lf->segs[l].segment_size);
+            if (!work) work = (int32_t)lf->jpeg_size;
+            original_bound = work > 0 ? (size_t)work : (size_t)0x7fffffff;   // (a negative size is OOM when the file is opened)
+            worker.bound = original_bound;
         }
-        BoundedOut seg;
-        BoundedOut* o = &out;
-        // (format 1: a worker's buffer is as large as its segment size, the whole file if that is zero; from format 2 on the
-        // thread re-bounds it to bytes_written + segment_size, and a segment size of zero leaves room for nothing:
-        // recode_physical_thread, recoder.cc:598-613, BoundedMemWriter::set_bound)
-        if (s > 0 && !legacy) { seg.bound = th.segment_size ? th.segment_size : max_file_size; seg.shut = !th.segment_size && lf->version > 1; o = &seg; }
-        else if (s > 0 && work_bound > 0) { seg.bound = (size_t)work_bound; o = &seg; }
-        // version >= 2: the first thread is bound by its segment size too (recoder.cc:598-613: new_bound = bytes_written +
-        // segment_size, applied when it is tighter than the file's)
-        const size_t file_bound = out.bound;
-        // -- a sum of two 32-bit values there (bounded_iostream::bytes_written() is an unsigned int): a segment size near 2^32
-        // wraps it to a bound in front of what is already written, and the next write trips always_assert(byte_position <=
-        // byte_bound) (bitops.cc:402); a bound of exactly zero means "none")
-        if (s == 0 && !legacy && lf->version > 1) {
-            const uint32_t nb = (uint32_t)out.buf.size() + th.segment_size;
-            if ((size_t)nb < file_bound) {
-                if (nb && (size_t)nb < out.buf.size()) return EX_ASSERTION_FAILURE;
-                out.bound = nb;
+        bool changed_bounds = false;
+        Handoff carry = lf->segs[first];
+        for (int s = first; s < last; ++s) {
+            Handoff th = lf->segs[s];
+            const bool legacy = th.num_overhang_bits == 0xff;
+            if (legacy) {
+                // a pre-hand-off record takes the state the previous logical thread of the SAME physical thread ended in; the first
+                // one a physical thread runs starts clean: no pending bits, the byte and the last DCs of its own record
+                // (recoder.cc:584-592)
+                if (s == first) carry.num_overhang_bits = 0;
+                th.overhang_byte = carry.overhang_byte;
+                th.num_overhang_bits = carry.num_overhang_bits;
+                memcpy(th.last_dc, carry.last_dc, sizeof th.last_dc);
+            } else {
+                // format 1 leaves the first thread's output unbounded and bounds a worker by its buffer; several logical threads
+                // on one physical thread -- and, from format 2 on, every thread -- are bound to bytes_written + segment_size where
+                // that is tighter (recoder.cc:598-613).  For physical thread 0 that is a sum of two 32-bit values
+                // (bounded_iostream::bytes_written() is an unsigned int): a segment size near 2^32 wraps it to a bound in front of
+                // what is already written, and the next write trips always_assert(byte_position <= byte_bound) (bitops.cc:402);
+                // a bound of exactly zero means "none" there.  A worker's buffer is RESIZED to its bound: zero leaves room for nothing.
+                const bool many_to_one = last - first != 1 && s != 0;
+                if (many_to_one || lf->version > 1) {
+                    if (p == 0) {
+                        const uint32_t nb = (uint32_t)o->buf.size() + th.segment_size;
+                        if ((size_t)nb < original_bound) {
+                            if (nb && (size_t)nb < o->buf.size()) return EX_ASSERTION_FAILURE;
+                            o->bound = nb; o->attempted = std::min(o->attempted, o->buf.size()); changed_bounds = true;
+                        } else if (o->bound != original_bound) { o->bound = original_bound; o->attempted = std::min(o->attempted, o->buf.size()); }
+                    } else {
+                        const size_t nb = o->buf.size() + (size_t)th.segment_size;
+                        if (nb < original_bound) { o->bound = nb; o->shut = nb == 0; changed_bounds = true; }
+                        else if (o->bound != original_bound) { o->bound = original_bound; o->shut = false; }
+                    }
+                }
+            }
+            BitWriter w;
+            w.fillbit = (uint8_t)jf.padbit;
+            w.seed(th.overhang_byte, th.num_overhang_bits);
+            int16_t lastdc[4];
+            memcpy(lastdc, th.last_dc, sizeof lastdc);
+            rc.seg_first_mcu_row = th.luma_y_start / std::max(luma_mul, 1);
+            for (int mcu_row = 0; mcu_row < jf.mcuv; ++mcu_row) {
+                int y0 = mcu_row * luma_mul, y1 = y0 + luma_mul;
+                if (y0 >= jf.trunc_bcv[0]) break;                 // rows past the coded height are skipped
+                if (y0 < th.luma_y_start) continue;
+                if (y1 > th.luma_y_end) break;
+                rc.mcu_row(w, mcu_row * jf.mcuh, *o, lastdc);
+                drain(w, *o);
+                w.row_flush();
+            }
+            carry.overhang_byte = w.overhang_byte();
+            carry.num_overhang_bits = (uint8_t)w.overhang_bits();
+            memcpy(carry.last_dc, lastdc, sizeof lastdc);
+            // The state a logical thread ends in must be the state the next hand-off recorded -- the reference asserts it
+            // (recoder.cc:625-645) and that is what stops a truncated or damaged multi-segment .lep from being "restored" as
+            // garbage: partial byte, its bit count, the last DC of every component (skipped for an empty next segment of a
+            // format >= 2 file), and a worker that has written anything must have filled its bound exactly.
+            if (s + 1 < L && lf->segs[s + 1].num_overhang_bits != 0xff) {
+                const Handoff& nx = lf->segs[s + 1];
+                if (nx.luma_y_start != nx.luma_y_end || lf->version == 1) {
+                    if (!one_thread && (carry.num_overhang_bits != nx.num_overhang_bits || carry.overhang_byte != nx.overhang_byte)) return EX_ASSERTION_FAILURE;
+                    if ((!one_thread || nx.segment_size > 1) && memcmp(carry.last_dc, nx.last_dc, 3 * sizeof(int16_t))) return EX_ASSERTION_FAILURE;
+                }
+                if (p > 0 && !o->buf.empty() && o->bound != o->buf.size()) return EX_ASSERTION_FAILURE;
             }
         }
-        BitWriter w;
-        w.fillbit = (uint8_t)jf.padbit;
-        w.seed(th.overhang_byte, th.num_overhang_bits);
-        int16_t lastdc[4];
-        memcpy(lastdc, th.last_dc, sizeof lastdc);
-        rc.seg_first_mcu_row = th.luma_y_start / std::max(luma_mul, 1);
-        for (int mcu_row = 0; mcu_row < jf.mcuv; ++mcu_row) {
-            int y0 = mcu_row * luma_mul, y1 = y0 + luma_mul;
-            if (y0 >= jf.trunc_bcv[0]) break;                 // rows past the coded height are skipped
-            if (y0 < th.luma_y_start) continue;
-            if (y1 > th.luma_y_end) break;
-            rc.mcu_row(w, mcu_row * jf.mcuh, *o, lastdc);
-            drain(w, *o);
-            w.row_flush();
-        }
-        carry.overhang_byte = w.overhang_byte();
-        carry.num_overhang_bits = (uint8_t)w.overhang_bits();
-        memcpy(carry.last_dc, lastdc, sizeof lastdc);
-        // The state a thread segment ends in must be the state the next hand-off recorded -- the reference asserts it
-        // (recode_physical_thread, recoder.cc:625-640) and that is what stops a truncated or damaged multi-segment .lep from being
-        // "restored" as garbage: partial byte, its bit count, the last DC of every component, and for every thread but the first a
-        // segment that fills its byte bound exactly.  (Skipped, as there, for an empty next segment of a format >= 2 file.)
-        if (s + 1 < lf->segs.size()) {
-            const Handoff& nx = lf->segs[s + 1];
-            if (nx.num_overhang_bits != 0xff && (nx.luma_y_start != nx.luma_y_end || lf->version == 1)) {
-                if (carry.num_overhang_bits != nx.num_overhang_bits || carry.overhang_byte != nx.overhang_byte) return EX_ASSERTION_FAILURE;
-                if (memcmp(carry.last_dc, nx.last_dc, 3 * sizeof(int16_t))) return EX_ASSERTION_FAILURE;
-                if (s > 0 && o == &seg && !seg.buf.empty() && seg.bound != seg.buf.size()) return EX_ASSERTION_FAILURE;
-            }
-        }
-        if (o == &seg) out.write(seg.buf.data(), seg.buf.size());
-        else if (out.bound != file_bound) { out.bound = file_bound; out.attempted = out.buf.size(); }
+        if (p == 0) { if (changed_bounds || out.bound != file_bound) { out.bound = file_bound; out.attempted = std::min(out.attempted, out.buf.size()); } }
+        else out.write(worker.buf.data(), worker.buf.size());
     }
 
     // 3. wrongly placed RST markers at the end of the scan, then the rest of the header, then garbage

@@ -14,11 +14,15 @@ REF='/root/repo/oracle/_ref/lepton'
 seed=int(sys.argv[1]); N=int(sys.argv[2])
 rnd=random.Random(seed)
 names=[n for n in golden_cases() if len(golden(n)[1])<40000]
+src=lambda n: golden(n)[1]
+if os.environ.get('LEP_FUZZ_DIR'):     # any other reference-written .lep files (e.g. larger ones with 4 or 8 thread segments)
+    D=os.environ['LEP_FUZZ_DIR']; names=sorted(n[:-4] for n in os.listdir(D) if n.endswith('.lep'))
+    src=lambda n: open(os.path.join(D,n+'.lep'),'rb').read()
 lp,jp='/tmp/b%d.lep'%seed,'/tmp/b%d.jpg'%seed
 same=refused=bad=0
 for trial in range(N):
     name=rnd.choice(names)
-    b=bytearray(golden(name)[1])
+    b=bytearray(src(name))
     kind=rnd.choice(["flip_stream","flip_hdr","trunc","flip_any","insert","insert_stream"])
     if kind=="flip_stream":
         for _ in range(rnd.randint(1,3)): b[rnd.randrange(len(b)//2,len(b))]^=1<<rnd.randrange(8)

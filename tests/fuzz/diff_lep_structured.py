@@ -22,6 +22,9 @@ rnd=random.Random(int(sys.argv[1])); N=int(sys.argv[2])
 names=[n for n in golden_cases() if len(golden(n)[1])<40000]
 OUT=sys.argv[3] if len(sys.argv)>3 else '/tmp'
 blob=lambda n: golden(n)[1]
+if os.environ.get('LEP_FUZZ_DIR'):     # any other reference-written .lep files (e.g. larger ones with 4 or 8 thread segments)
+    D=os.environ['LEP_FUZZ_DIR']; names=sorted(n[:-4] for n in os.listdir(D) if n.endswith('.lep'))
+    blob=lambda n: open(os.path.join(D,n+'.lep'),'rb').read()
 if len(sys.argv)>4 and sys.argv[4]=='v2':     # format-2 fixtures (brotli header, every segment bound by its size); chained streams left out
     import json
     from conftest import GOLDEN
