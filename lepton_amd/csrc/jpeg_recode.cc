@@ -168,6 +168,7 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
               jf.trunc_bcv[0] >= jf.comp[0].bcv && !lf->segs.empty();
     for (const Handoff& th : lf->segs) if (th.num_overhang_bits == 0xff || th.num_overhang_bits > 7) ok = false;
     for (size_t q = 1; q < lf->segs.size(); ++q) if (lf->version > 1 && !lf->segs[q].segment_size) ok = false;   // a worker bound of nothing: host path
+    if ((size_t)std::min(lf->nthreads, 8) != lf->segs.size()) ok = false;   // several logical threads folded onto one worker (a damaged thread hint): cumulative bounds, host path
     if (ok && lf->version > 1 && (uint64_t)plan->head.size() + lf->segs[0].segment_size > 0xffffffffull) ok = false;   // the first thread's bound wraps (recode_jpeg): host path
     if (ok && jf.ncomp == 1) {
         const Component& k = jf.comp[jf.cs_cmp[0]];
