@@ -244,3 +244,36 @@ def test_structured_lep_mutants_against_the_reference_binary(tmp_path):
         same += got is not None
         refused += got is None
     assert same >= 15 and refused >= 15
+
+
+def test_eight_thread_segments_round_trip_and_match_the_reference(tmp_path):
+    """the fixtures under tests/golden are small (one or two thread segments); a 760 KB file takes the reference's full thread
+    pool: eight hand-offs, seven worker buffers bound by their segment sizes.  Our file equals the reference's byte for byte
+    (where its binary is available) and restores through the host re-coder; a hand-off count folded onto fewer workers than
+    it has records (thread hint 4) still restores, through cumulative bounds (recoder.cc:598-613)"""
+    import numpy as np
+    from PIL import Image
+
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (20, 26, 3), dtype=np.uint8)
+    a = np.asarray(Image.fromarray(base).resize((640, 480), Image.BICUBIC)).astype(np.int16)
+    a = np.clip(a + rng.normal(0, 18, a.shape), 0, 255).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format="JPEG", quality=99, subsampling=0)
+    jpg = buf.getvalue()
+    img = JpegImage(jpg)
+    segs = img.plan()
+    assert len(segs) == 8
+    streams, _ = ob.oracle_encode(img.desc, segs)
+    lep = img.write_lep(streams)
+    if os.path.exists(REF):
+        jp, lp = str(tmp_path / "e.jpg"), str(tmp_path / "e.lep")
+        open(jp, "wb").write(jpg)
+        subprocess.run([REF, "-unjailed", "-skipverify", jp, lp], capture_output=True)
+        assert lep == open(lp, "rb").read()
+    for hint in (8, 4):
+        b = bytearray(lep)
+        b[4] = hint
+        f = LepFile(bytes(b))
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        assert f.recode() == jpg, hint
