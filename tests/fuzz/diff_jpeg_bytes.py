@@ -12,11 +12,15 @@ REF='/root/repo/oracle/_ref/lepton'
 seed=int(sys.argv[1]); N=int(sys.argv[2])
 rnd=random.Random(seed)
 names=[n for n in golden_cases() if len(golden(n)[0])<30000]
+src=lambda n: golden(n)[0]
+if os.environ.get('JPEG_FUZZ_DIR'):    # any other JPEGs (e.g. larger ones that take 4 or 8 thread segments)
+    D=os.environ['JPEG_FUZZ_DIR']; names=sorted(n[:-4] for n in os.listdir(D) if n.endswith('.jpg'))
+    src=lambda n: open(os.path.join(D,n+'.jpg'),'rb').read()
 jp,lp='/tmp/j%d.jpg'%seed,'/tmp/j%d.lep'%seed
 same=refused=bad=0
 for trial in range(N):
     name=rnd.choice(names)
-    b=bytearray(golden(name)[0])
+    b=bytearray(src(name))
     kind=rnd.choice(["flip_scan","flip_hdr","trunc","flip_any","insert","ff"])
     if kind=="flip_scan":
         for _ in range(rnd.randint(1,3)): b[rnd.randrange(len(b)//2,len(b))]^=1<<rnd.randrange(8)
