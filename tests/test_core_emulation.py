@@ -936,3 +936,32 @@ def test_gpu_scan_encoder_on_cpu_restores_the_format_2_fixtures(emu):
                 assert got == want, name
                 ran += 1
     assert ran >= 8
+
+
+def test_gpu_scan_encoder_on_cpu_gives_the_reference_s_answers_for_damaged_hand_offs(emu):
+    """the hand-off field mutants of tests/test_fuzz_host.py (each pinned to what the reference binary answers) through the GPU
+    path's host halves around the emulated scan encoder: plan (which sends what the kernel cannot reproduce to the host
+    re-coder: bit counts of 8 and more, pre-hand-off records, bounds that wrap or leave room for nothing), lane-loop kernel,
+    finish -- the same bytes, or the file is not eligible and the host re-coder is what runs on the GPU box too"""
+    import hashlib
+    import oracle_binding as ob
+    from lepton_amd.codec import LepFile, LeptonError
+    from test_fuzz_host import hand_off_field_cases
+
+    through_the_kernel = 0
+    for i, (lep, want) in enumerate(hand_off_field_cases()):
+        try:
+            f = LepFile(lep)
+        except LeptonError as e:
+            assert e.code == want, i
+            continue
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        try:
+            got = _emulated_gpu_scan_encode(emu, f)
+        except AssertionError as e:          # lep_file_recode_finish refused: its code is the assertion's message
+            got = int(str(e).split()[0])
+        if got is None:
+            continue
+        through_the_kernel += 1
+        assert (got if isinstance(got, int) else (len(got), hashlib.md5(got).hexdigest())) == want, i
+    assert through_the_kernel >= 3

@@ -256,37 +256,17 @@ def test_a_truncated_multi_segment_file_is_refused_like_the_reference():
     assert f.recode() == golden("q30_256x256_4seg")[0]
 
 
-def test_hand_off_fields_a_damaged_file_can_carry():
-    """field-level mutants of the hand-off records (tests/fuzz/mutate.py with_handoffs(field=...), format 1 and 2), each pinned
-    to what the reference binary answers (tests/fuzz/diff_lep_structured.py found them):
-    * luma_y_start inside an MCU row: the baseline re-coder takes MCU rows whose FIRST luma row is not in front of it
-      (recode_row_range, recoder.cc:505-510) -- the decoder starts at the next MCU row, as a top row;
-    * overhang bit counts of 8..64 are the byte plus zero bits; beyond 64 the reference's 64-bit buffer goes negative: the first
-      value written is widened by the excess or, past the buffer's width, dropped with 64 zero bits in its place (bitops.hh:120-163);
-      bits of the byte below the count it claims are OR-ed with what is written next;
-    * format 2: the first thread's bound is a 32-bit sum that wraps in front of what is written: assertion (bitops.cc:402);
-    * a worker's buffer is allocated at its bound from a 576 MiB arena: OOM before anything is decoded (recoder.cc:770-782);
-    * a pre-hand-off record (bit count 0xff) at the head of a worker's range starts clean from its own record (recoder.cc:584-592)"""
-    import hashlib
+def hand_off_field_cases():
+    """[(mutated .lep, what the reference binary answers: (restored length, md5) or its exit code)] -- see
+    test_hand_off_fields_a_damaged_file_can_carry"""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     import mutate as mu
-    import oracle_binding as ob
     from conftest import GOLDEN
-    from lepton_amd.codec import LepFile, LeptonError
 
     def v2(n):
         return open(os.path.join(GOLDEN, "v2", n + ".lep"), "rb").read()
-
-    def restore(b):
-        try:
-            f = LepFile(b)
-            ob.oracle_decode(f.desc, f.segments, f.streams)
-            d = f.recode()
-            return len(d), hashlib.md5(d).hexdigest()
-        except LeptonError as e:
-            return e.code
 
     g = lambda n: golden(n)[1]
     two = lambda lep, a, b: mu.with_handoffs(mu.with_handoffs(lep, field=a), field=b)
@@ -306,7 +286,34 @@ def test_hand_off_fields_a_damaged_file_can_carry():
         (mu.with_handoffs(g("q30_256x256_4seg"), field=(1, 7, 1, 0xff)), (178304, "f69435c2a9144ad58b1b660d09c681ca")),
         (mu.with_handoffs(v2("q30_256x256_4seg"), field=(1, 2, 4, 0)), (89187, "adf95715ee513e460ee019f730634684")),   # format 2: a worker bound of zero bytes
     ]
-    for i, (lep, want) in enumerate(cases):
+    return cases
+
+
+def test_hand_off_fields_a_damaged_file_can_carry():
+    """field-level mutants of the hand-off records (tests/fuzz/mutate.py with_handoffs(field=...), format 1 and 2), each pinned
+    to what the reference binary answers (tests/fuzz/diff_lep_structured.py found them):
+    * luma_y_start inside an MCU row: the baseline re-coder takes MCU rows whose FIRST luma row is not in front of it
+      (recode_row_range, recoder.cc:505-510) -- the decoder starts at the next MCU row, as a top row;
+    * overhang bit counts of 8..64 are the byte plus zero bits; beyond 64 the reference's 64-bit buffer goes negative: the first
+      value written is widened by the excess or, past the buffer's width, dropped with 64 zero bits in its place (bitops.hh:120-163);
+      bits of the byte below the count it claims are OR-ed with what is written next;
+    * format 2: the first thread's bound is a 32-bit sum that wraps in front of what is written: assertion (bitops.cc:402);
+    * a worker's buffer is allocated at its bound from a 576 MiB arena: OOM before anything is decoded (recoder.cc:770-782);
+    * a pre-hand-off record (bit count 0xff) at the head of a worker's range starts clean from its own record (recoder.cc:584-592)"""
+    import hashlib
+    import oracle_binding as ob
+    from lepton_amd.codec import LepFile, LeptonError
+
+    def restore(b):
+        try:
+            f = LepFile(b)
+            ob.oracle_decode(f.desc, f.segments, f.streams)
+            d = f.recode()
+            return len(d), hashlib.md5(d).hexdigest()
+        except LeptonError as e:
+            return e.code
+
+    for i, (lep, want) in enumerate(hand_off_field_cases()):
         assert restore(lep) == want, i
 
 
