@@ -965,3 +965,27 @@ def test_gpu_scan_encoder_on_cpu_gives_the_reference_s_answers_for_damaged_hand_
         through_the_kernel += 1
         assert (got if isinstance(got, int) else (len(got), hashlib.md5(got).hexdigest())) == want, i
     assert through_the_kernel >= 3
+
+
+def test_v4_decoder_on_a_first_segment_that_starts_inside_the_image(emu):
+    """a damaged hand-off can make the FIRST segment start at an MCU row other than 0 (lep_file_segments rounds a luma_y_start
+    inside an MCU row up, as the reference's baseline re-coder does): the decoder kernel treats that row as a top row, like any
+    later segment's first row -- frames equal the oracle's.  (Where such a shift turns the stream into garbage -- the truncated
+    fixture -- the kernels and the oracle part ways: an edge that still "has" more non-zeros than positions left is
+    impossible in a stream an encoder wrote, and lep_dec4.h's edge round holds one lane per REACHABLE (position, non-zeros
+    left) pair, 28 per edge, where the reference indexes its tables directly.  Garbage in, different garbage out: DESIGN.md 5.)"""
+    import oracle_binding as ob
+    from lepton_amd.codec import LepFile
+    from test_fuzz_host import hand_off_field_cases
+
+    for lep, _ in hand_off_field_cases()[:1]:
+        f = LepFile(lep)
+        d, segs = f.desc, f.segments
+        assert len(segs) == 1 and segs[0].luma_y_start > 0
+        ob.oracle_decode(d, segs, f.streams)
+        want = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+        for c in range(d.ncomp):
+            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+        s, wv = segs[0], f.streams[0]
+        assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
+        assert [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == want
