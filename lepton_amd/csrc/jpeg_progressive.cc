@@ -449,6 +449,10 @@ int recode_progressive(LepFile* lf, std::vector<uint8_t>* result) {
         }
     }
     if (all_garbage) return EX_ASSERTION_FAILURE;
+    // no scan at all (the walk left the header without meeting an SOS, e.g. behind a segment length that reaches past it): the
+    // reference's scan table is still empty when it stores the last position -- "out of memory error", errorlevel 2
+    // (jpgcoder.cc:3708-3714)
+    if (scan_hdr_end.empty()) return EX_UNSUPPORTED_JPEG;
     scnp.push_back(sw.w.bytes.size());
     const std::vector<uint8_t>& huff = sw.w.bytes;
 

@@ -556,6 +556,11 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
     // Format versions >= 2 end their packets with a marker, so the reader knows where the file stops: 3 marker bytes, the
     // 4-byte size trailer, and whatever follows is the next file of a chained stream (`cat a.lep b.lep | lepton -`,
     // jpgcoder.cc:1881-1897, test_suite/test_concat.sh).  Version 1 has no marker: its reader runs to the end of the input.
+    // the general re-coder's decoder hands every packet to the thread bound to its stream id; one for a thread that no hand-off
+    // created is always_assert(false && "Cannot send to thread that wasn't bound") (vp8_decoder.cc:236)
+    if (!baseline_recoder)
+        for (size_t i = lf->segs.size(); i < lf->streams.size(); ++i)
+            if (!lf->streams[i].empty()) return EX_ASSERTION_FAILURE;
     if (lf->version > 1 && saw_eof && end + 7 <= n) lf->consumed = end + 7;
     return 0;
 }

@@ -339,3 +339,45 @@ def test_sos_length_past_the_header_of_a_progressive_file():
     with pytest.raises(LeptonError) as e:
         LepFile(mu.with_handoffs(golden("prog_c420_320x240")[1], count=17))
     assert e.value.code == 2
+
+
+def test_general_re_coder_no_scan_and_unbound_stream_ids():
+    """two more answers of the general re-coder, found on larger progressive files: a header walk that never meets an SOS (a
+    segment length that reaches past the header) leaves the reference's scan table empty -- "out of memory error", errorlevel 2
+    (jpgcoder.cc:3708-3714); a packet for a stream id that no hand-off created is `Cannot send to thread that wasn't bound`
+    (vp8_decoder.cc:236).  Probed against the reference binary (its answers: 42, abort)."""
+    import io
+    import os
+    import sys
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
+    import mutate as mu
+    import oracle_binding as ob
+    from lepton_amd.codec import JpegImage, LepFile, LeptonError
+
+    fixed, payload, rest = mu.lep_split(golden("prog_c420_320x240")[1])
+    i = payload.index(b"\xff\xc2\x00\x11")
+    f = LepFile(mu.lep_join(fixed, payload[: i + 2] + b"\xff\xff" + payload[i + 4:], rest))
+    ob.oracle_decode(f.desc, f.segments, f.streams)
+    with pytest.raises(LeptonError) as e:
+        f.recode()
+    assert e.value.code == 42
+
+    rng = np.random.default_rng(8)
+    base = rng.integers(0, 256, (16, 20, 3), dtype=np.uint8)
+    a = np.asarray(Image.fromarray(base).resize((500, 400), Image.BICUBIC)).astype(np.int16)
+    a = np.clip(a + rng.normal(0, 14, a.shape), 0, 255).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format="JPEG", quality=97, subsampling=0, progressive=True)
+    img = JpegImage(buf.getvalue())
+    segs = img.plan()
+    assert len(segs) > 1                      # a progressive file of this size is coded on several threads
+    streams, _ = ob.oracle_encode(img.desc, segs)
+    lep = img.write_lep(streams)
+    g = LepFile(lep)
+    ob.oracle_decode(g.desc, g.segments, g.streams)
+    assert g.recode() == buf.getvalue()
+    with pytest.raises(LeptonError) as e:
+        LepFile(mu.with_handoffs(lep, count=1))
+    assert e.value.code == 1
