@@ -545,9 +545,8 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
     // more logical threads than stream ids (MuxReader::MAX_STREAM_ID = 16, MuxReader.hh:201): the reference dies in an
     // always_assert / out-of-bounds access (probed: abort with 17 and 32 hand-offs, SIGSEGV with 200); every caller of
     // lep_file_segments sizes its arrays LEP_MAX_SEGMENTS
-    const bool baseline_recoder = lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1);
+    const bool baseline_recoder = lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1);   // jpgcoder.cc:2162; the general re-coder is single-threaded
     if (lf->segs.size() > 16) return baseline_recoder ? EX_ASSERTION_FAILURE : EX_CODING_ERROR;   // (the general re-coder's decoder: more threads needed than it was started with, vp8_decoder.cc:415-417)
-    (void)0;   // jpgcoder.cc:2162; the general re-coder is single-threaded
     if (baseline_recoder && lf->segs[0].num_overhang_bits != 0xff && (size_t)std::min(lf->nthreads, 8) > lf->segs.size()) return EX_ASSERTION_FAILURE;
     // (worker bounds beyond the arena: worker_bounds_exceed_arena, called by lep_file_open_next behind the re-coder's header pass)
     // (more logical threads than the general re-coder's decoder was started with: lep_file_open_next, behind the split-table check)
