@@ -281,7 +281,8 @@ int baseline_header_pass(LepFile* lf) {
     if (!(lf->flag == 'Z' || (lf->flag & 1) == ('Y' & 1))) {
         // the general re-coder (recode_jpeg, jpgcoder.cc:3345-3372) waits for decoded blocks position by position; the tables in
         // front of its first scan are interpreted before it waits for anything
-        for (uint8_t type = 0; type != 0xDA;) {
+        uint8_t type = 0;
+        while (type != 0xDA) {
             if (pos >= hdrs) break;
             type = pos + 1 < hdrs ? h[pos + 1] : 0;
             const unsigned len = 2 + (((unsigned)(pos + 2 < hdrs ? h[pos + 2] : 0)) << 8) + (pos + 3 < hdrs ? h[pos + 3] : 0);
@@ -289,6 +290,9 @@ int baseline_header_pass(LepFile* lf) {
                 if (!parse_segment(&jf, type, len, (unsigned)std::min<size_t>(len, hdrs - pos), h + pos, false)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;
             pos += len;
         }
+        // no scan at all: nothing is ever waited for, and the re-coder ends in its all-garbage assertion or its empty scan
+        // table ("out of memory error", errorlevel 2) whatever the streams hold -- see recode_progressive
+        if (type != 0xDA) return (int32_t)lf->jpeg_size <= (int32_t)jf.garbage.size() ? EX_ASSERTION_FAILURE : EX_UNSUPPORTED_JPEG;
         return 0;
     }
     if ((int32_t)lf->jpeg_size <= (int32_t)jf.garbage.size()) return EX_ASSERTION_FAILURE;

@@ -358,10 +358,8 @@ def test_general_re_coder_no_scan_and_unbound_stream_ids():
 
     fixed, payload, rest = mu.lep_split(golden("prog_c420_320x240")[1])
     i = payload.index(b"\xff\xc2\x00\x11")
-    f = LepFile(mu.lep_join(fixed, payload[: i + 2] + b"\xff\xff" + payload[i + 4:], rest))
-    ob.oracle_decode(f.desc, f.segments, f.streams)
-    with pytest.raises(LeptonError) as e:
-        f.recode()
+    with pytest.raises(LeptonError) as e:      # answered when the file is opened: with no scan nothing is ever decoded
+        LepFile(mu.lep_join(fixed, payload[: i + 2] + b"\xff\xff" + payload[i + 4:], rest))
     assert e.value.code == 42
 
     rng = np.random.default_rng(8)
