@@ -148,6 +148,7 @@ int lep_jpeg_open_gpu_progressive(lep_jpeg* j, lep_huffprogdec_scan* scans, int 
     return 0;
 }
 int lep_jpeg_finish_gpu_progressive(lep_jpeg* j, const lep_huffprogdec_scan* scans, int nscan, const lep_huffdec_row* rows) {
+    if (nscan <= 0 || !scans || !rows) return LEP_ASSERTION_FAILURE;   // (public entry: v[0] is read below)
     std::vector<lep::ProgScanDecodePlan> v((size_t)nscan);
     memcpy(v.data(), scans, (size_t)nscan * sizeof(lep_huffprogdec_scan));
     // the descriptors as the caller launched them carry device addresses and arena offsets: rebase on the file's own
@@ -246,7 +247,7 @@ size_t lep_file_consumed(const lep_file* f) { return f->lf.consumed; }
 
 int lep_file_open_next(const uint8_t* d, size_t len, const lep_file* prev, lep_file** out) {
     std::unique_ptr<lep_file> f(new lep_file);
-    int rc = lep::parse_lep(d, len, &f->lf, prev ? &prev->lf.pending_header : nullptr);
+    int rc = lep::parse_lep(d, len, &f->lf, prev && prev->lf.header_pending ? &prev->lf.pending_header : nullptr);
     if (rc) return rc;
     lep::JpegFile& jf = f->lf.jpeg;
     // (the embedded header has been interpreted inside parse_lep, where the reference does it)
@@ -277,7 +278,7 @@ int lep_file_open_next(const uint8_t* d, size_t len, const lep_file* prev, lep_f
     if (!f->lf.segs.empty()) f->lf.segs.back().luma_y_end = (uint16_t)jf.trunc_bcv[0];   // vp8_decoder.cc:366-368
     // the baseline re-coder looks at the header's tables and allocates its workers' buffers before it decodes a row
     if (int hrc = lep::baseline_header_pass(&f->lf)) return hrc;
-    if (lep::worker_bounds_exceed_arena(f->lf, len)) return LEP_OOM;
+    if (lep::worker_bounds_exceed_arena(f->lf, f->lf.consumed)) return LEP_OOM;   // this file's own extent, not what is concatenated behind it
     *out = f.release();
     return 0;
 }

@@ -633,7 +633,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             lep_segment sg[LEP_MAX_SEGMENTS];
             lep_handoff ho[LEP_MAX_SEGMENTS];
             const int ns = lep_jpeg_plan(parsed[c->live[k]], 0, sg, (int)k);
-            (void)lep_jpeg_plan_handoffs(parsed[c->live[k]], 0, ho, LEP_MAX_SEGMENTS);
+            if (lep_jpeg_plan_handoffs(parsed[c->live[k]], 0, ho, LEP_MAX_SEGMENTS) != ns || ns < 0) return LEP_ASSERTION_FAILURE;   // (the two plans are one choice; ho[] is read below)
             c->seg_first.push_back((int)c->segs.size());
             const lep_image_desc& d = c->host_desc[k];
             size_t blocks = 0;

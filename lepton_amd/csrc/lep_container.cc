@@ -408,11 +408,14 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
     // this test and trips always_assert(max_file_size > grbs) once the header has been read (refusals of the header come first)
     if (zsize > (128u << 20) || (int32_t)lf->jpeg_size > (128 << 20)) return EX_ASSERTION_FAILURE;
     const size_t sane_size = (int32_t)lf->jpeg_size < 0 ? ((size_t)128 << 20) : (size_t)lf->jpeg_size;   // what a header may inflate to is never sized from such a claim
+    // header_reader != NULL (a "CNT" section of the previous file left it open, even with nothing behind it): the compressed
+    // header bytes are not read, and always_assert(compressed_header_size == 0 && "Special concatenation requires 0 size
+    // header") (jpgcoder.cc:4139, 4186-4188)
+    if (carried && zsize != 0) return EX_ASSERTION_FAILURE;
     if (28 + (uint64_t)zsize + 3 > n) return EX_SHORT_READ;
     std::vector<uint8_t> p;
-    if (carried && !carried->empty()) {   // header_reader != NULL: the compressed header bytes are not even read (jpgcoder.cc:4139)
-        p = *carried;
-        zsize = 0;
+    if (carried) {
+        p = *carried;   // (may be empty: "HDR marker not found" below, as the reference's drained reader answers)
     } else if (lf->version == 1) {
         if (!unzlib(d + 28, zsize, sane_size + 2048, &p)) return EX_STREAM_INCONSISTENT;
     } else {
@@ -448,6 +451,18 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
         memset(jf.qtables, 0, sizeof jf.qtables);
         if (!setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;
         return EX_UNSUPPORTED_JPEG;
+    }
+    if (hdrs > (1u << 20) && (uint64_t)hdrs > (uint64_t)left() + 16) {
+        // A claim of megabytes that the inflated header cannot back (54 bytes drove the shared daemon to +127 MB
+        // per request).  The reference zero-fills the claim and interprets it; what follows is decided by the bytes that exist
+        // plus at most one marker segment reaching into the zeros, and nothing is left for the "P0D" section behind it: the
+        // same verdicts from the backed bytes and a zero tail of two maximal segments, without the allocation.
+        const size_t have = left();
+        jf.hdr.assign(have + 2 * 65540, 0);
+        read_full(jf.hdr.data(), have);
+        memset(jf.qtables, 0, sizeof jf.qtables);
+        if (!setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;
+        return EX_UNSUPPORTED_JPEG;   // "PAD marker not found"
     }
     jf.hdr.assign(hdrs, 0);
     read_full(jf.hdr.data(), hdrs);
@@ -492,6 +507,7 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
             const uint32_t c = get_le32(mrk);
             if (c > kArena) return EX_BLOCK_OFFSET_OOM;
             if (c > (128u << 20)) return EX_STREAM_INCONSISTENT;
+            if (c > (1u << 20) && (uint64_t)c > (uint64_t)left() + 16) return EX_STREAM_INCONSISTENT;   // megabytes of zero fill from a claim the data cannot back: refused like CRS / FRS (documented deviation; the reference allocates)
             jf.garbage.assign(c, 0);
             read_full(jf.garbage.data(), c);
             lf->garbage_default_eoi = false;
@@ -501,6 +517,7 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
             const uint32_t c = get_le32(mrk);
             if (c > kArena) return EX_BLOCK_OFFSET_OOM;
             if (c > (128u << 20)) return EX_STREAM_INCONSISTENT;
+            if (c > (1u << 20) && (uint64_t)c > (uint64_t)left() + 16) return EX_STREAM_INCONSISTENT;   // as for GRB
             lf->has_prefix = true;
             lf->prefix_garbage.assign(c, 0);
             read_full(lf->prefix_garbage.data(), c);
@@ -514,6 +531,7 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
             jf.early_eof = true;
         } else if (!memcmp(mrk, "CNT", 3)) {   // the rest of this header belongs to the next file of the stream
             lf->pending_header.assign(p.begin() + pos, p.end());
+            lf->header_pending = true;
             break;
         } else if (!memcmp(mrk, "CMP", 3)) {
             break;

@@ -702,6 +702,47 @@ struct Dec4Wave {
             int lane = e * 28 + left - 1, step = 7;
 #pragma nounroll
             for (;;) {
+                if (SR::is(left > step)) {
+                    // More non-zeros claimed than positions left: no encoder writes that, a damaged stream can hold it.  The
+                    // reference indexes exponent_counts_x_ / residual_noise_counts_ with the claimed count all the same
+                    // (decoder.cc:58-141); no lane holds such a pair, so the rest of this edge is coded straight from HBM.
+                    // Once true it stays true to the end of the edge.
+#pragma nounroll
+                    for (int j = 7 - step; j < 7 && left; ++j) {
+                        const uint32_t info = lepwave::wave_read(INFO, e * 28 + combo_base(j));
+                        if (info >> 31) { rc = 43; break; }
+                        const int coord = horizontal ? j + 1 : (j + 1) * 8;
+                        const uint32_t gb = ctx4_expx(ci, left, horizontal ? j : j + 7, (int)((info >> 24) & 15));
+                        int len = 0;
+#pragma nounroll
+                        for (; len < 11; ++len) if (!SR::is(sr.global_bin(row_word(gb, len)) != 0)) break;
+                        LEP_BINS(nbins += (uint32_t)(len ? 2 * len + 1 - (len == 11) : 1));
+                        if (!len) continue;
+                        const int sslot = (int)(info & 255);
+                        const uint32_t sgw = SR::U(S.sign[sslot]);
+                        const uint32_t pos = sr.get(sgw >> 16);
+                        S.sign[sslot] = sr.bupd(sgw, pos);
+                        uint32_t v = 1u << (len - 1);
+                        int b = len - 2;
+                        const int thr = (int)((info >> 8) & 15);
+                        if (b >= thr) {
+                            const uint32_t Tt = ctx_thresh(ci, (int)((info >> 16) & 255), imin(len - thr, 7));
+                            int sx = 1;
+#pragma nounroll
+                            for (; b >= thr; --b) {
+                                const uint32_t bit = sr.global_bin(Tt + (uint32_t)sx);
+                                v |= bit << b;
+                                sx = imin((sx << 1) | (int)uni(bit), 127);
+                            }
+                        }
+                        const uint32_t rbase = ctx4_res(ci, coord, left);
+#pragma nounroll
+                        for (; b >= 0; --b) v |= sr.global_bin(row_word(rbase, b)) << b;
+                        S.here[a_off + j] = (int16_t)(pos ? (int)v : -(int)v);
+                        --left;
+                    }
+                    break;
+                }
                 const uint32_t info = lepwave::wave_read(INFO, lane);
                 if (info >> 31) { rc = 43; break; }
                 const uint32_t pkv = SR::U(lepwave::wave_read(PK0, lane));

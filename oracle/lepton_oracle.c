@@ -290,14 +290,21 @@ static int32_t lakhani(const int16_t *here, const int16_t *nbr, const int32_t *i
     return (int32_t)acc / icos[0];
 }
 
+/* Test knob (tests/test_core_emulation.py, tests/test_gpu_parity.py): the ENCODER claims this many more edge non-zeros than
+ * the block holds (capped at 7).  An encoder never writes such a stream; a damaged or hostile one can hold it, and the
+ * reference's decoder then simply indexes exponent_counts_x_ with a "non-zeros left" that exceeds the positions left
+ * (decoder.cc:58-141) -- the decode direction below does the same, so the stream decodes back to the original block. */
+int lor_test_edge_count_bias = 0;
 static int code_edge(Ctx *k, int16_t *here, const int16_t *nbr, int horizontal, int nz7x7, int est_eob) {
     Coder *c = k->c;
     int ci = k->ci;
     Br(*T)[4] = horizontal ? k->m->nz8x1[ci][est_eob][(nz7x7 + 3) / 7] : k->m->nz1x8[ci][est_eob][(nz7x7 + 3) / 7];
     int delta = horizontal ? 1 : 8, a_off = horizontal ? 50 : 57, zig15 = horizontal ? 0 : 7;
     int ne = 0, so_far = 0, i, lane, coord;
-    if (!c->decode)
+    if (!c->decode) {
         for (i = 0; i < 7; ++i) ne += here[a_off + i] != 0;
+        ne = imin(7, ne + lor_test_edge_count_bias); /* test knob, 0 outside tests: see lepton_oracle.h */
+    }
     for (i = 2; i >= 0; --i) {
         int bit = code(c, &T[i][so_far], (ne >> i) & 1);
         if (c->decode) ne |= bit << i;

@@ -46,6 +46,9 @@ int lor_decode_segment(lor_image *img, int luma_y_start, int luma_y_end, int is_
 
 size_t lor_model_bytes(void);
 
+/* test knob: see lepton_oracle.c (streams with impossible edge non-zero counts); 0 = off */
+extern int lor_test_edge_count_bias;
+
 #ifdef __cplusplus
 }
 #endif

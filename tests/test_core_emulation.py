@@ -989,3 +989,57 @@ def test_v4_decoder_on_a_first_segment_that_starts_inside_the_image(emu):
         s, wv = segs[0], f.streams[0]
         assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
         assert [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == want
+
+
+@pytest.fixture
+def edge_count_bias():
+    """oracle knob: its encoder claims 2 more edge non-zeros than a block holds (oracle/lepton_oracle.c)"""
+    L = ob.oracle()
+    knob = C.c_int.in_dll(L, "lor_test_edge_count_bias")
+    knob.value = 2
+    yield knob
+    knob.value = 0
+
+
+@pytest.mark.parametrize("gen", ["", "_v2", "_v4"])   # (the retired v3 generation shares v4's per-pair scheme and is not maintained)
+@pytest.mark.parametrize("name", ["c420_odd_203x149", "gray_120x88", "c444_96x80", "truncated"])
+def test_decoders_follow_the_reference_on_impossible_edge_counts(emu, edge_count_bias, name, gen):
+    """a stream that claims more edge non-zeros than positions remain.  The reference indexes
+    exponent_counts_x_ directly with the claimed count (decoder.cc:58-141) and decodes on; every kernel generation must read
+    the same Branches (the v4 edge round holds one lane per REACHABLE (position, non-zeros-left) pair and takes a direct path
+    for the others).  Expected frame: the original -- the biased encoder codes the true coefficients under the false count."""
+    jpg, _ = golden(name)
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)          # streams with impossible counts
+    edge_count_bias.value = 0
+    honest, _ = ob.oracle_encode(d, segs)
+    assert want != honest
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    ob.oracle_decode(d, segs, want)                 # the oracle (== reference decoder) restores the frame from them
+    assert [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == orig
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    for s, w in zip(segs, want):
+        assert getattr(emu, "emu_decode_segment" + gen)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), None) == 0
+    for c in range(d.ncomp):
+        n = d.coded_blocks[c] * 128
+        assert C.string_at(d.blocks[c], n) == orig[c][:n]
+
+
+def test_v4_other_forms_on_impossible_edge_counts(emu_other_forms, edge_count_bias):
+    """the same with the edge round's serial code on the scalar unit (LEP_DEC4_SCALAR=13)"""
+    jpg, _ = golden("c420_odd_203x149")
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, _ = ob.oracle_encode(d, segs)
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    for s, w in zip(segs, want):
+        assert emu_other_forms.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), None) == 0
+    for c in range(d.ncomp):
+        n = d.coded_blocks[c] * 128
+        assert C.string_at(d.blocks[c], n) == orig[c][:n]
