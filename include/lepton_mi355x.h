@@ -127,8 +127,18 @@ typedef struct lep_huff_segment {
     uint32_t out_cap;
     uint32_t pad;
 } lep_huff_segment;
+/* What a segment's writer ends in -- partial byte, its bit count, last DC per component -- i.e. what the NEXT hand-off must
+ * have recorded: the reference asserts all three at every segment end (recode_physical_thread, src/lepton/recoder.cc:625-640);
+ * lep_file_recode_finish holds them against the file's hand-offs.  attempted = bytes before clipping to out_cap. */
+typedef struct lep_huff_end {
+    uint32_t attempted;
+    uint8_t overhang_byte, num_overhang_bits;
+    int16_t last_dc[4];
+    uint16_t pad;
+} lep_huff_end;
+/* d_ends: nseg records in device memory, or NULL */
 int lep_gpu_huffman_encode_device(lep_gpu *g, const lep_huff_image *images, int nimg, const lep_huff_segment *segs, int nseg,
-                                  uint8_t *d_out, uint32_t *d_out_len, void *hip_stream);
+                                  uint8_t *d_out, uint32_t *d_out_len, lep_huff_end *d_ends, void *hip_stream);
 /* The same for PROGRESSIVE files (BASELINE.json configs[4]; replaces the scan loop of recode_jpeg, src/lepton/jpgcoder.cc:3309-3716,
  * with encode_dc_prg_*, encode_ac_prg_fs / _sa, encode_eobrun, encode_crbits :4991-5400): every scan of a progressive file is a
  * function of the finished frame alone, so one wavefront per (image, scan) writes that scan's bytes (FF00-stuffed, restart
@@ -292,7 +302,8 @@ int lep_file_recode(lep_file *f, lep_bytes *out);
  * eligible (*gpu_ok = 1), fills the image / per-segment parameters (blocks[], image index and out_off are the caller's to
  * set; out_cap is the segment's byte bound); _finish glues header, the segments' scan bytes and the trailer together. */
 int lep_file_recode_plan(lep_file *f, lep_huff_image *image, lep_huff_segment *segs, int *nseg, int *gpu_ok);
-int lep_file_recode_finish(lep_file *f, const lep_bytes *seg_bytes, int nseg, lep_bytes *out);
+/* ends: the kernel's per-segment end states (NULL: only the byte counts are held against the hand-offs) */
+int lep_file_recode_finish(lep_file *f, const lep_bytes *seg_bytes, const lep_huff_end *ends, int nseg, lep_bytes *out);
 /* progressive files: _plan fills the image and up to `cap` scan descriptors (out_cap / corr_cap = what each scan may need;
  * image index, out_off, corr_off and blocks[] are the caller's to set); *gpu_ok = 0: the file keeps the host re-coder
  * (truncated, sequential multi-scan, withheld restart markers ...).  _finish glues header pieces, scans and trailer. */

@@ -62,6 +62,10 @@ class HuffSegment(C.Structure):
                 ("out_off", C.c_uint64), ("out_cap", C.c_uint32), ("pad", C.c_uint32)]
 
 
+class HuffEnd(C.Structure):
+    _fields_ = [("attempted", C.c_uint32), ("overhang_byte", C.c_uint8), ("num_overhang_bits", C.c_uint8), ("last_dc", C.c_int16 * 4), ("pad", C.c_uint16)]
+
+
 class HuffProgImage(C.Structure):
     _fields_ = [("ncomp", C.c_int32), ("mcuh", C.c_int32), ("mcuv", C.c_int32), ("mcuc", C.c_int32), ("rsti", C.c_int32), ("padbit", C.c_int32),
                 ("hs", C.c_int32 * 4), ("vs", C.c_int32 * 4), ("bch", C.c_int32 * 4), ("bcv", C.c_int32 * 4), ("nch", C.c_int32 * 4),
@@ -195,8 +199,8 @@ def lib():
         L.lep_jpeg_finish_gpu.argtypes = [vp, P(HuffDecRow)]
         L.lep_gpu_huffman_decode_device.argtypes = [vp, P(HuffDecImage), C.c_int, vp, vp]
         L.lep_file_recode_plan.argtypes = [vp, P(HuffImage), P(HuffSegment), P(C.c_int), P(C.c_int)]
-        L.lep_file_recode_finish.argtypes = [vp, P(Bytes), C.c_int, P(Bytes)]
-        L.lep_gpu_huffman_encode_device.argtypes = [vp, P(HuffImage), C.c_int, P(HuffSegment), C.c_int, vp, vp, vp]
+        L.lep_file_recode_finish.argtypes = [vp, P(Bytes), vp, C.c_int, P(Bytes)]
+        L.lep_gpu_huffman_encode_device.argtypes = [vp, P(HuffImage), C.c_int, P(HuffSegment), C.c_int, vp, vp, vp, vp]
         L.lep_batch_release.argtypes = []
         L.lep_batch_release.restype = None
         L.lep_file_recode_plan_progressive.argtypes = [vp, P(HuffProgImage), P(HuffProgScan), C.c_int, P(C.c_int), P(C.c_int)]

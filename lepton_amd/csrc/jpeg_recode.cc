@@ -11,6 +11,7 @@
 
 #include "jpeg_bits.h"
 #include "lep_container.h"
+#include "../../include/lepton_mi355x.h"   // lep_huff_end
 
 namespace lep {
 
@@ -237,7 +238,7 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
 }
 
 // recode_finish: glue head + per-segment scan bytes + misplaced RST markers + the rest of the header + garbage together
-int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& seg_bytes,
+int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& seg_bytes, const lep_huff_end* ends,
                   std::vector<uint8_t>* result) {
     JpegFile& jf = lf->jpeg;
     const size_t max_file_size = lf->jpeg_size;
@@ -245,14 +246,22 @@ int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pa
     out.bound = plan.scan_bound;
     out.buf.reserve(std::min<size_t>(max_file_size, (size_t)128 << 20) + 16);   // (a SIZ section can claim up to 2^31 - 1)
     out.write(plan.head.data(), plan.head.size());
-    // (the GPU encoder does not hand back the bit state a segment ends in; what can be held against the hand-offs here is the
-    // byte count: a segment that restores its part of the file exactly writes exactly segment_size bytes -- see recode_jpeg for
-    // the reference's assertions; a truncated .lep fails this on the segment whose stream ran dry)
+    // The state a logical thread ends in must be the state the next hand-off recorded: the reference asserts partial byte, bit
+    // count and last DCs at every segment end (recode_physical_thread, recoder.cc:625-640; recode_jpeg above does the same for
+    // the host path).  `ends` is what lep_huffman_encode_kernel hands back (one logical thread per physical thread here:
+    // recode_prepare sends everything else to the host re-coder).  The byte count -- a segment that restores its part of the
+    // file exactly writes exactly segment_size bytes -- stays as the check for callers without end states.
     if (seg_bytes.size() == lf->segs.size())
         for (size_t q = 0; q + 1 < seg_bytes.size(); ++q) {
             const Handoff& nx = lf->segs[q + 1];
-            if (nx.num_overhang_bits == 0xff || !(nx.luma_y_start != nx.luma_y_end || lf->version == 1)) continue;
-            if (seg_bytes[q].second != lf->segs[q].segment_size && !(q == 0 && out.buf.size() + seg_bytes[q].second >= out.bound)) return EX_ASSERTION_FAILURE;
+            if (nx.num_overhang_bits == 0xff) continue;
+            if (nx.luma_y_start != nx.luma_y_end || lf->version == 1) {
+                if (ends) {
+                    if (ends[q].num_overhang_bits != nx.num_overhang_bits || ends[q].overhang_byte != nx.overhang_byte) return EX_ASSERTION_FAILURE;
+                    if (memcmp(ends[q].last_dc, nx.last_dc, 3 * sizeof(int16_t))) return EX_ASSERTION_FAILURE;
+                }
+                if (seg_bytes[q].second != lf->segs[q].segment_size && !(q == 0 && out.buf.size() + seg_bytes[q].second >= out.bound)) return EX_ASSERTION_FAILURE;
+            }
         }
     for (const auto& sb : seg_bytes) out.write(sb.first, sb.second);
     if (!jf.rst_err.empty()) {

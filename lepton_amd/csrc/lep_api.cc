@@ -393,12 +393,12 @@ int lep_file_recode_finish_progressive(lep_file* f, const lep_bytes* scan_bytes,
     return to_bytes(jpg, out);
 }
 
-int lep_file_recode_finish(lep_file* f, const lep_bytes* seg_bytes, int nseg, lep_bytes* out) {
+int lep_file_recode_finish(lep_file* f, const lep_bytes* seg_bytes, const lep_huff_end* ends, int nseg, lep_bytes* out) {
     if (!f->planned) return LEP_ASSERTION_FAILURE;
     std::vector<std::pair<const uint8_t*, size_t>> sb;
     for (int i = 0; i < nseg; ++i) sb.emplace_back(seg_bytes[i].data, seg_bytes[i].len);
     std::vector<uint8_t> jpg;
-    int rc = lep::recode_finish(&f->lf, f->plan, sb, &jpg);
+    int rc = lep::recode_finish(&f->lf, f->plan, sb, ends, &jpg);
     if (rc) return rc;
     return to_bytes(jpg, out);
 }

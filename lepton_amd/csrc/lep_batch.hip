@@ -111,7 +111,7 @@ struct Slot {   // one chunk's buffers (double-buffered)
     uint8_t* d_streams = nullptr; uint8_t* h_streams = nullptr; size_t streams_cap = 0, hstreams_cap = 0;   // device arena (worst-case sized for encode) / pinned mirror (actual bytes)
     uint32_t* d_len = nullptr; int32_t* d_status = nullptr; uint32_t* d_flags = nullptr; size_t seg_cap = 0, img_cap = 0;
     uint8_t* d_scan = nullptr; uint8_t* h_scan = nullptr; size_t scan_cap = 0;   // JPEG scan bytes of the GPU Huffman encoder
-    uint32_t* d_scanlen = nullptr; size_t scanlen_cap = 0;
+    uint32_t* d_scanlen = nullptr; size_t scanlen_cap = 0;   // nseg byte counts, then (16-byte aligned) nseg lep_huff_end records
     char* d_rows = nullptr; size_t rows_cap = 0;   // row records of the GPU Huffman decoder
     uint8_t* d_pscan = nullptr; size_t pscan_cap = 0;      // progressive files: the scans' device arena (sized for the worst case) ...
     uint8_t* h_pscan = nullptr; size_t hpscan_cap = 0;     // ... and the pinned mirror, packed by the bytes actually written
@@ -207,6 +207,9 @@ int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_
     return 0;
 }
 
+// the end-state records live behind the byte counts of the same allocation (16-byte aligned)
+lep_huff_end* huff_ends(Slot* s) { return (lep_huff_end*)((char*)s->d_scanlen + ((s->scanlen_cap * 4 + 15) & ~(size_t)15)); }
+
 int scan_reserve(Slot* s, size_t bytes, size_t nseg) {
     const double t0 = now_s();
     if (bytes > s->scan_cap) {
@@ -219,7 +222,7 @@ int scan_reserve(Slot* s, size_t bytes, size_t nseg) {
     }
     if (nseg > s->scanlen_cap) {
         if (s->d_scanlen) (void)hipFree(s->d_scanlen);
-        HIPOK(hipMalloc((void**)&s->d_scanlen, nseg * 4));
+        HIPOK(hipMalloc((void**)&s->d_scanlen, nseg * 4 + 16 + nseg * sizeof(lep_huff_end)));
         s->scanlen_cap = nseg;
     }
     g_alloc_s += now_s() - t0;
@@ -1004,7 +1007,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         int rc = lep_gpu_decode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
         if (rc) return rc;
         if (!c->hseg.empty()) {
-            rc = lep_gpu_huffman_encode_device(g, c->himg.data(), (int)c->himg.size(), c->hseg.data(), (int)c->hseg.size(), s->d_scan, s->d_scanlen, s_compute);
+            rc = lep_gpu_huffman_encode_device(g, c->himg.data(), (int)c->himg.size(), c->hseg.data(), (int)c->hseg.size(), s->d_scan, s->d_scanlen, huff_ends(s), s_compute);
             if (rc) return rc;
         }
         if (!c->pscan.empty()) {
@@ -1035,11 +1038,13 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         }
         std::vector<int32_t> sts(nseg);
         std::vector<uint32_t> slens(c->hseg.size()), plens(c->pscan.size());
+        std::vector<lep_huff_end> sends(c->hseg.size());
         std::vector<size_t> poff(c->pscan.size(), 0);   // packed offsets of the progressive scans in the pinned mirror
         if (nimg) {
             HIPOK(hipStreamWaitEvent(s_down, s->done, 0));
             HIPOK(hipMemcpyAsync(sts.data(), s->d_status, (size_t)nseg * 4, hipMemcpyDeviceToHost, s_down));
             if (!c->hseg.empty()) HIPOK(hipMemcpyAsync(slens.data(), s->d_scanlen, c->hseg.size() * 4, hipMemcpyDeviceToHost, s_down));
+            if (!c->hseg.empty()) HIPOK(hipMemcpyAsync(sends.data(), huff_ends(s), c->hseg.size() * sizeof(lep_huff_end), hipMemcpyDeviceToHost, s_down));
             if (!c->pscan.empty()) HIPOK(hipMemcpyAsync(plens.data(), s->d_pscanlen, c->pscan.size() * 4, hipMemcpyDeviceToHost, s_down));
             HIPOK(hipStreamSynchronize(s_down));
             if (!c->pscan.empty()) {
@@ -1088,7 +1093,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
             if (rc_all) break;
         }
         std::shared_ptr<Chunk> keep(cur.release());
-        writer = std::thread([&, keep, s, sts, slens, plens, poff]() {
+        writer = std::thread([&, keep, s, sts, slens, sends, plens, poff]() {
             const double t0 = now_s();
             parallel_for((int)keep->live.size(), threads, [&](int k) {
                 const int i = keep->live[k];
@@ -1098,7 +1103,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                     const int h0 = keep->hfirst[k], ns = keep->seg_first[k + 1] - keep->seg_first[k];
                     lep_bytes sb[LEP_MAX_SEGMENTS];
                     for (int q = 0; q < ns; ++q) { sb[q].data = s->h_scan + keep->hseg[h0 + q].out_off; sb[q].len = sb[q].cap = slens[h0 + q]; }
-                    rc = lep_file_recode_finish(files[i], sb, ns, &outs[i]);
+                    rc = lep_file_recode_finish(files[i], sb, sends.data() + h0, ns, &outs[i]);
                 } else if (!rc && keep->pfirst[k] >= 0) {   // progressive file, scans coded on the GPU: glue header pieces and scans
                     const int p0 = keep->pfirst[k], ns = keep->pcount[k];
                     std::vector<lep_bytes> sb((size_t)ns);

@@ -4,6 +4,8 @@
 #include <vector>
 #include "jpeg_model.h"
 
+struct lep_huff_end;   // include/lepton_mi355x.h: end state of a GPU-coded scan segment
+
 namespace lep {
 
 struct EncodeOptions {
@@ -110,7 +112,7 @@ int recode_progressive_prepare(LepFile* lf, ProgPlan* plan);
 int progressive_plan(JpegFile* jf, size_t jpeg_size, bool rst_cnt_set, ProgPlan* plan);
 int recode_progressive_finish(LepFile* lf, const ProgPlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& scan_bytes,
                               std::vector<uint8_t>* out);
-int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& seg_bytes,
+int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pair<const uint8_t*, size_t>>& seg_bytes, const lep_huff_end* ends,
                   std::vector<uint8_t>* out);
 
 }  // namespace lep

@@ -150,13 +150,14 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
 // JPEG Huffman re-encode of decoded frames: one wavefront per thread segment (lep_huff.h)
 __global__ __launch_bounds__(64, 8) void lep_huffman_encode_kernel(const lephuff::HuffImage* __restrict__ images,
                                                                    const lephuff::HuffSegment* __restrict__ segs, uint8_t* out,
-                                                                   uint32_t* out_len) {
+                                                                   uint32_t* out_len, lephuff::HuffEnd* ends) {
     __shared__ lephuff::HuffShared sh;
     const int s = blockIdx.x;
     const lephuff::HuffSegment seg = segs[s];
     lephuff::HuffWave w;
     const uint32_t n = w.run(images + seg.image, seg, &sh, out);
     if (threadIdx.x == 0) out_len[s] = n;
+    if (ends) w.export_end(ends + s);
 }
 
 // progressive files: one wavefront per (image, scan) (lep_huffprog.h)
@@ -458,10 +459,11 @@ int lep_gpu_decode_device(lep_gpu* g, const lep_image_desc* images, int nimg, co
                         const_cast<uint32_t*>(d_stream_len), d_status, hip_stream ? (hipStream_t)hip_stream : g->stream);
 }
 
-static_assert(sizeof(lep_huff_image) == sizeof(lephuff::HuffImage) && sizeof(lep_huff_segment) == sizeof(lephuff::HuffSegment), "C ABI mirrors");
+static_assert(sizeof(lep_huff_image) == sizeof(lephuff::HuffImage) && sizeof(lep_huff_segment) == sizeof(lephuff::HuffSegment) &&
+              sizeof(lep_huff_end) == sizeof(lephuff::HuffEnd) && sizeof(lep_huff_end) == 16, "C ABI mirrors");
 
 int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int nimg, const lep_huff_segment* segs, int nseg,
-                                  uint8_t* d_out, uint32_t* d_out_len, void* hip_stream) {
+                                  uint8_t* d_out, uint32_t* d_out_len, lep_huff_end* d_ends, void* hip_stream) {
     if (!g) return LEP_GPU_ERROR;
     if (nseg <= 0) return 0;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
@@ -473,7 +475,7 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
     HIPCHK(g, hipStreamSynchronize(st));   // the caller's arrays may go away
     HIPCHK(g, hipEventRecord(g->ev0, st));
     hipLaunchKernelGGL(lep_huffman_encode_kernel, dim3(nseg), dim3(64), 0, st, (const lephuff::HuffImage*)g->d_huff,
-                       (const lephuff::HuffSegment*)((char*)g->d_huff + o_seg), d_out, d_out_len);
+                       (const lephuff::HuffSegment*)((char*)g->d_huff + o_seg), d_out, d_out_len, (lephuff::HuffEnd*)d_ends);
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;

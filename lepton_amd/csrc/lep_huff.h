@@ -43,6 +43,13 @@ struct HuffSegment {
     uint32_t pad;
 };
 
+struct HuffEnd {             // state a segment's writer ends in: what the next hand-off recorded (recoder.cc:625-640)
+    uint32_t attempted;     // bytes the segment tried to write (not clipped to out_cap)
+    uint8_t overhang_byte, num_overhang_bits;
+    int16_t last_dc[4];
+    uint16_t pad;
+};
+
 struct HuffShared {
     uint32_t code[4][256];
     uint32_t bits[72];      // MSB-first bit buffer of the block being coded (+ carried partial byte in word 0)
@@ -225,6 +232,16 @@ struct HuffWave {
             }
         }
         return written < cap ? written : cap;
+    }
+    // the partial byte, its bit count and the last DCs this segment ends in (lane 0 stores them)
+    WDEV void export_end(HuffEnd* e) const {
+        LANES(l) if (l == 0) {
+            e->attempted = written;
+            e->overhang_byte = (uint8_t)(pend ? sh->bits[0] >> 24 : 0u);
+            e->num_overhang_bits = (uint8_t)pend;
+            for (int c = 0; c < 4; ++c) e->last_dc[c] = (int16_t)lastdc[c];
+            e->pad = 0;
+        }
     }
 };
 

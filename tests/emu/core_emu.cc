@@ -184,13 +184,14 @@ extern "C" int emu_check_inv24_update() {
 
 // GPU Huffman re-encoder (lep_huff.h) as a 64-lane loop emulation: scan bytes of one thread segment
 #include "../../lepton_amd/csrc/lep_huff.h"
-extern "C" int emu_huffman_encode_segment(const lep_huff_image* img, const lep_huff_segment* seg, uint8_t* out, uint32_t* len) {
+extern "C" int emu_huffman_encode_segment(const lep_huff_image* img, const lep_huff_segment* seg, uint8_t* out, uint32_t* len, lep_huff_end* end) {
     static lephuff::HuffShared sh;
     lephuff::HuffWave w;
     lephuff::HuffSegment s;
     memcpy(&s, seg, sizeof s);
     s.out_off = 0; s.image = 0;
     *len = w.run(reinterpret_cast<const lephuff::HuffImage*>(img), s, &sh, out);
+    if (end) w.export_end(reinterpret_cast<lephuff::HuffEnd*>(end));
     return 0;
 }
 

@@ -317,6 +317,7 @@ def test_gpu_huffman_encoder_on_cpu_restores_the_jpeg(emu, name):
     if not ok.value:
         pytest.skip("not eligible for the GPU Huffman encoder (truncated file, legacy hand-offs, ...): host path only")
     outs = (abi.Bytes * nseg.value)()
+    ends = (abi.HuffEnd * nseg.value)()
     keep = []
     for i in range(nseg.value):
         cap = min(segs[i].out_cap, len(jpg) + 1024)
@@ -324,11 +325,11 @@ def test_gpu_huffman_encoder_on_cpu_restores_the_jpeg(emu, name):
         buf = C.create_string_buffer(cap + 8)
         keep.append(buf)
         n = C.c_uint32(0)
-        assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(segs[i]), buf, C.byref(n)) == 0
+        assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) == 0
         outs[i].data = C.cast(buf, C.c_void_p).value
         outs[i].len = outs[i].cap = n.value
     out = abi.Bytes()
-    assert L.lep_file_recode_finish(f.handle, outs, nseg.value, C.byref(out)) == 0
+    assert L.lep_file_recode_finish(f.handle, outs, ends, nseg.value, C.byref(out)) == 0
     got = out.tobytes()
     L.lep_free(out.data)
     assert got == jpg
@@ -896,6 +897,7 @@ def _emulated_gpu_scan_encode(emu, f):
     if not ok.value:
         return None
     outs = (abi.Bytes * nseg.value)()
+    ends = (abi.HuffEnd * nseg.value)()
     keep = []
     for i in range(nseg.value):
         cap = min(segs[i].out_cap, 1 << 24)
@@ -903,11 +905,11 @@ def _emulated_gpu_scan_encode(emu, f):
         buf = C.create_string_buffer(cap + 8)
         keep.append(buf)
         n = C.c_uint32(0)
-        assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(segs[i]), buf, C.byref(n)) == 0
+        assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) == 0
         outs[i].data = C.cast(buf, C.c_void_p).value
         outs[i].len = outs[i].cap = n.value
     out = abi.Bytes()
-    rc = L.lep_file_recode_finish(f.handle, outs, nseg.value, C.byref(out))
+    rc = L.lep_file_recode_finish(f.handle, outs, ends, nseg.value, C.byref(out))
     assert rc == 0, rc
     got = out.tobytes()
     L.lep_free(out.data)
@@ -970,15 +972,14 @@ def test_gpu_scan_encoder_on_cpu_gives_the_reference_s_answers_for_damaged_hand_
 def test_v4_decoder_on_a_first_segment_that_starts_inside_the_image(emu):
     """a damaged hand-off can make the FIRST segment start at an MCU row other than 0 (lep_file_segments rounds a luma_y_start
     inside an MCU row up, as the reference's baseline re-coder does): the decoder kernel treats that row as a top row, like any
-    later segment's first row -- frames equal the oracle's.  (Where such a shift turns the stream into garbage -- the truncated
-    fixture -- the kernels and the oracle part ways: an edge that still "has" more non-zeros than positions left is
-    impossible in a stream an encoder wrote, and lep_dec4.h's edge round holds one lane per REACHABLE (position, non-zeros
-    left) pair, 28 per edge, where the reference indexes its tables directly.  Garbage in, different garbage out: DESIGN.md 5.)"""
+    later segment's first row -- frames equal the oracle's.  The second case is the truncated fixture, where the shift turns the
+    stream into garbage: edges that claim more non-zeros than positions are left.  Round 2's edge round read a neighbouring
+    pair's Branch there; it now indexes like the reference (decoder.cc:58-141) and the frame is the oracle's."""
     import oracle_binding as ob
     from lepton_amd.codec import LepFile
     from test_fuzz_host import hand_off_field_cases
 
-    for lep, _ in hand_off_field_cases()[:1]:
+    for lep, _ in hand_off_field_cases()[:2]:
         f = LepFile(lep)
         d, segs = f.desc, f.segments
         assert len(segs) == 1 and segs[0].luma_y_start > 0
@@ -1043,3 +1044,64 @@ def test_v4_other_forms_on_impossible_edge_counts(emu_other_forms, edge_count_bi
     for c in range(d.ncomp):
         n = d.coded_blocks[c] * 128
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
+
+
+def test_gpu_scan_encoder_end_states_are_held_against_the_hand_offs(emu):
+    """recode.cc:625-640 on the GPU path (missing #5): the scan encoder hands back the partial byte, its bit
+    count and the last DCs every segment ends in; lep_file_recode_finish refuses a file where they are not what the next
+    hand-off recorded -- all three, not only the byte count"""
+    from lepton_amd import abi
+    from lepton_amd.codec import LepFile
+
+    jpg, lep = golden("q30_256x256_4seg")
+    L = abi.lib()
+
+    def run(mutate):
+        f = LepFile(lep)
+        ob.oracle_decode(f.desc, f.segments, f.streams)
+        img = abi.HuffImage()
+        segs = (abi.HuffSegment * abi.MAX_SEGMENTS)()
+        nseg, ok = C.c_int(0), C.c_int(0)
+        assert L.lep_file_recode_plan(f.handle, C.byref(img), segs, C.byref(nseg), C.byref(ok)) == 0 and ok.value and nseg.value >= 2
+        N = nseg.value
+        outs = (abi.Bytes * N)()
+        ends = (abi.HuffEnd * N)()
+        keep = []
+        for i in range(N):
+            buf = C.create_string_buffer(segs[i].out_cap + 8)
+            keep.append(buf)
+            n = C.c_uint32(0)
+            assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) == 0
+            outs[i].data = C.cast(buf, C.c_void_p).value
+            outs[i].len = outs[i].cap = n.value
+        states = [(e.overhang_byte, e.num_overhang_bits, tuple(e.last_dc)[:3], e.attempted) for e in ends]
+        mutate(ends)
+        out = abi.Bytes()
+        rc = L.lep_file_recode_finish(f.handle, outs, ends, N, C.byref(out))
+        got = out.tobytes() if rc == 0 else None
+        if rc == 0:
+            L.lep_free(out.data)
+        return rc, got, states, f
+
+    rc, got, states, f = run(lambda e: None)
+    assert rc == 0 and got == jpg
+    # what the kernel hands back IS what the file's hand-offs recorded
+    src = JpegImage(jpg)
+    hs = (abi.Handoff * abi.MAX_SEGMENTS)()
+    N = L.lep_jpeg_plan_handoffs(src.handle, 0, hs, abi.MAX_SEGMENTS)
+    assert N == len(states) >= 2
+    for q in range(N - 1):
+        assert states[q][:3] == (hs[q + 1].overhang_byte, hs[q + 1].num_overhang_bits, tuple(hs[q + 1].last_dc)[:3])
+        assert states[q][3] == hs[q].segment_size
+
+    def dc(e):
+        e[N - 2].last_dc[2] += 1
+    def bits(e):
+        e[0].num_overhang_bits ^= 1
+    def byte(e):
+        e[0].overhang_byte ^= 0x80
+    for m in (dc, bits, byte):
+        assert run(m)[0] == 1          # ASSERTION_FAILURE, as recode_physical_thread answers
+    def last(e):                        # the last segment's end state is held against nothing
+        e[N - 1].last_dc[0] += 5
+    assert run(last)[0] == 0

@@ -398,6 +398,7 @@ def sweep_through_the_kernel_sources(emu, trials, seed):
         if not ok.value:
             continue
         outs = (abi.Bytes * nseg.value)()
+        ends = (abi.HuffEnd * nseg.value)()
         keep = []
         for i in range(nseg.value):
             cap = min(hsegs[i].out_cap, len(jpg) + 1024)
@@ -405,11 +406,11 @@ def sweep_through_the_kernel_sources(emu, trials, seed):
             buf = C.create_string_buffer(cap + 8)
             keep.append(buf)
             n = C.c_uint32(0)
-            assert emu.emu_huffman_encode_segment(C.byref(himg), C.byref(hsegs[i]), buf, C.byref(n)) == 0
+            assert emu.emu_huffman_encode_segment(C.byref(himg), C.byref(hsegs[i]), buf, C.byref(n), C.byref(ends[i])) == 0
             outs[i].data = C.cast(buf, C.c_void_p).value
             outs[i].len = outs[i].cap = n.value
         out = abi.Bytes()
-        assert L.lep_file_recode_finish(f.handle, outs, nseg.value, C.byref(out)) == 0
+        assert L.lep_file_recode_finish(f.handle, outs, ends, nseg.value, C.byref(out)) == 0
         assert out.tobytes() == host, trial
         L.lep_free(out.data)
         stats["reencoded"] += 1
