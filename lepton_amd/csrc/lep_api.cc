@@ -279,6 +279,7 @@ int lep_file_open_next(const uint8_t* d, size_t len, const lep_file* prev, lep_f
     // the baseline re-coder looks at the header's tables and allocates its workers' buffers before it decodes a row
     if (int hrc = lep::baseline_header_pass(&f->lf)) return hrc;
     if (lep::worker_bounds_exceed_arena(f->lf, f->lf.consumed)) return LEP_OOM;   // this file's own extent, not what is concatenated behind it
+    if (f->lf.unbound_stream_packet) return LEP_ASSERTION_FAILURE;   // "Cannot send to thread that wasn't bound": behind the header's own refusals
     *out = f.release();
     return 0;
 }

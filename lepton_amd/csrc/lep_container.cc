@@ -575,9 +575,11 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
     // jpgcoder.cc:1881-1897, test_suite/test_concat.sh).  Version 1 has no marker: its reader runs to the end of the input.
     // the general re-coder's decoder hands every packet to the thread bound to its stream id; one for a thread that no hand-off
     // created is always_assert(false && "Cannot send to thread that wasn't bound") (vp8_decoder.cc:236)
+    // -- met when the decoder routes that packet, i.e. behind every refusal the header earns (errorlevel from the embedded JPEG
+    // header, the re-coder's table pass, its empty scan table): recorded here, answered by lep_file_open_next after those
     if (!baseline_recoder)
         for (size_t i = lf->segs.size(); i < lf->streams.size(); ++i)
-            if (!lf->streams[i].empty()) return EX_ASSERTION_FAILURE;
+            if (!lf->streams[i].empty()) lf->unbound_stream_packet = true;
     if (lf->version > 1 && saw_eof && end + 7 <= n) lf->consumed = end + 7;
     return 0;
 }

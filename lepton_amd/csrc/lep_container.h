@@ -28,6 +28,7 @@ struct LepFile {
     std::vector<uint8_t> prefix_garbage;
     std::vector<std::vector<uint8_t>> streams;   // de-multiplexed, index = stream id = segment index
     size_t consumed = 0;                         // bytes of the input this file occupies (less than the input for a chained stream of v2+ files)
+    bool unbound_stream_packet = false;          // general re-coder: a packet for a stream id no hand-off created (vp8_decoder.cc:236)
     bool header_pending = false;                 // a "CNT" section was met: the next file of the stream reads pending_header, empty or not
     std::vector<uint8_t> pending_header;         // header bytes behind a "CNT" section: they belong to the next file of the stream
 };

@@ -85,3 +85,14 @@ def test_chained_header_rules():
     with pytest.raises(LeptonError) as e:
         lep_stream(bytes(bad))
     assert e.value.code == 1
+
+
+def test_refusals_of_the_header_come_before_a_packet_for_an_unbound_stream():
+    """two mutants the structure-aware differential fuzz found (tests/fuzz/diff_lep_structured.py, seed 11, format-2 fixtures):
+    a progressive file whose embedded JPEG header is damaged (an SOF length field of 0xffff; an SOS length field of 3) AND whose
+    packets are mis-framed so that one is addressed to a stream id no hand-off created.  The reference binary answers
+    UNSUPPORTED_JPEG for both ("out of memory error": the general re-coder's empty scan table; "unknown marker found") -- the
+    header's refusals come before its decoder ever routes the stray packet ("Cannot send to thread that wasn't bound")."""
+    d = os.path.join(GOLDEN, "fuzz")
+    for name in ("v2_prog_sof_length_ffff_and_misframed_packets", "v2_prog_sos_length_3_and_misframed_packets"):
+        assert refusal(open(os.path.join(d, name + ".lep"), "rb").read()) == 42, name
