@@ -1,0 +1,803 @@
+// lep_enc5.h -- the SPLIT-PHASE encoder ("v5"): the arithmetic coder of one thread segment cut into passes that each have
+// their own unit of parallelism, instead of one wavefront walking a segment's blocks with one useful lane in its serial part.
+//
+// Why it can be cut (encode direction only): every context of the block syntax (encoder.cc:194-402, model.hh:463-1139) is a
+// function of the quantised coefficients, which the encoder already holds -- nothing upstream of the bool coder depends on it.
+// And a Branch (branch.hh:82-100) adapts only on the bins coded with it, so the model is not ONE serial state but ~1,500
+// independent CHAINS per segment (all Branches that share a context family, a position and a "non-zeros left" class never
+// touch the others').  The only truly serial thing is the bool writer's range / low recurrence (boolwriter.hh:48-118), and
+// that needs nothing but a list of (probability, bit) pairs.
+//
+//   count   one wavefront per segment, lane = block (64 consecutive blocks of a row = a TILE): how many entries every chain
+//           of the segment will get (a function of the block's own coefficients) -> exact arena layout, nothing overflows
+//   emit    same walk with the contexts (aavrg / Lakhani priors, IDCT + DC prediction, neighbour summaries): every coded
+//           coefficient becomes 4-byte ENTRIES (<= 4 bins each) appended, in stream order, to its chain's private stream
+//   fold    lane = chain: walks its stream with its Branches in LDS, replaces every entry by the probabilities its bins
+//           are coded with (in place) -- the model never touches HBM (the 2 MB threshold table excepted)
+//   gather  the emit walk again: reads the probabilities back, writes the segment's bins in stream order
+//   write   lane = segment: the serial bool writer over the bin list, 64 segments per wavefront in true SIMT
+//
+// Results are bit-identical to lep_enc3.h / the oracle (tests/test_core_emulation.py steps these kernels on the CPU).
+// Reference citations are those of lep_core.h; the syntax walk below follows SegmentCoder<false>::code_block line by line.
+#pragma once
+#include "lep_v3.h"
+#ifdef LEP5_DEBUG
+#include <cstdio>
+#endif
+
+namespace lep5 {
+using namespace lep3;
+
+// ---- chains and their streams ------------------------------------------------------------------------------------------
+// rows: 0..48 interior positions (zig-zag order), 49..55 horizontal edge (x = 1..7), 56..62 vertical edge (y = 1..7),
+// 63 the threshold bins of all edge positions (their Branches are not keyed by the position: residual_threshold_counts_
+// [colour][prior class][min(len - thr, 7)][node], model.hh:1072-1099).  A stream = (colour index, row, class k): k =
+// kNzBin[non-zeros left] for the interior, edge non-zeros left (1..7) for an edge, min(len - thr, 7) for the threshold row.
+constexpr int kRows = 64, kClasses = 10;
+constexpr int kPRows = 63 + 14;                         // payload rows of a tile: the 63 coefficient rows + a threshold entry per edge position
+constexpr int kStreams = 2 * kRows * kClasses;          // 1280 4-byte-unit streams per segment
+WDEV int stream_id(int ci, int row, int k) { return (ci * kRows + row) * kClasses + k; }
+// slice of a coefficient chain: exponent Branches [12 bsr][11] then residual Branches [10]
+constexpr int kCoefSlice = 12 * 11 + 10;
+constexpr int kSignSlice = 48, kNzSlice = 6 * 32, kEdgeNzSlice = 8 * 12, kDcSlice = 17 * 11 + 10;
+constexpr uint32_t kThreshWords = 2u * 256 * 8 * 128;   // per segment, HBM: [ci][prior class][lt][128]
+
+// A coefficient's chain-local bin sequence: its exponent bins (nexp = min(len + 1, 11)), then its residual bins that use the
+// chain's own Branches (nres: all len - 1 of them in the interior, the ones below the noise threshold on an edge).  It is cut
+// into UNITS of four bins; an entry is one unit.  (The sign bin and an edge's threshold bins sit between the two in the
+// stream but belong to other chains; `gather` puts them back in order.)
+//   bits 0..9 residual bits (low nres bits of |v|), 10..13 nres, 14..17 len, 18..22 bsr (b17 for a DC entry), 23..26 class k
+//   (a for a DC entry), 27..29 unit
+WDEV uint32_t coef_entry(uint32_t vlow, int nres, int len, int bsr, int k, int u) {
+    return vlow | ((uint32_t)nres << 10) | ((uint32_t)len << 14) | ((uint32_t)bsr << 18) | ((uint32_t)k << 23) | ((uint32_t)u << 27);
+}
+WDEV int coef_units(int len, int nres) { return ((len < 11 ? len + 1 : 11) + nres + 3) >> 2; }
+// threshold entry: bits 0..9 the threshold bits (|v| >> thr, n of them), 10..13 n, 14..21 prior class, 23..26 lt, 27..29 unit
+WDEV uint32_t thresh_entry(uint32_t tbits, int n, int pcls, int lt, int u) {
+    return tbits | ((uint32_t)n << 10) | ((uint32_t)pcls << 14) | ((uint32_t)lt << 23) | ((uint32_t)u << 27);
+}
+// sign entry (one byte): bits 0..5 Branch slot inside the colour's [4][12] table, bit 6 the bit, bit 7 valid
+// sparse records, one per block ordinal of the segment (chains whose key needs the neighbours: filtered by the fold lanes):
+//   KEY (4 bytes, never overwritten): ci | 7x7 context bin << 1 | eob_x << 5 | eob_y << 8 | a << 11 -- what the fold lanes filter on
+//   NZ  (8 bytes): word 0 = number of non-zeros                           -> six probabilities in bytes 0..5
+//   EN  (2 x 4 bytes, horizontal then vertical): nzq | ne << 3            -> three probabilities
+//   DC  (6 x 4 bytes): word 0 = unit 0 of an entry like a coefficient's with k = a, bsr = b17 -> the units' probabilities
+constexpr int kKeyRec = 4, kNzRec = 8, kEnRec = 8, kDcRec = 24;
+
+struct SegPlan5 {            // one per segment, device memory; written by plan5 from the counts
+    uint64_t arena_off;      // byte offset of the segment's entry arena (16-byte aligned)
+    uint64_t bins_off;       // offset of the segment's bin list, in bins (uint16)
+    uint32_t sign_base[2], sign_cnt[2];       // byte streams, relative to arena_off
+    uint32_t key_base, nz_base, en_base, dc_base;   // byte offsets of the sparse regions
+    uint32_t nblocks;        // block ordinals (coded blocks of the segment)
+    uint32_t bins_cap;       // room in the bin list
+    uint32_t nbins;          // bins written by gather (without the start marker and the stop bins)
+    uint32_t arena_bytes;
+    int32_t status;          // exit code of the emit walk (COEFFICIENT_OUT_OF_RANGE, ...): the later passes skip the segment
+    uint32_t base[kStreams + 1];   // unit streams: index of the first unit (4-byte units, relative to arena_off); [kStreams] = end
+};
+
+// ---- Branch state in LDS: the packed word of lep_core.h (false | true << 8 | probability << 16) ----------------------------
+WDEV uint32_t mul24_5(uint32_t a, uint32_t b) {   // low 32 bits of the 24 x 24-bit product
+#if LEP_ON_GPU
+    return __umul24(a, b);
+#else
+    return (uint32_t)(((uint64_t)(a & 0xffffff) * (b & 0xffffff)) & 0xffffffffu);
+#endif
+}
+WDEV uint32_t bupd5(uint32_t w, uint32_t obs, const uint32_t* inv24) {
+    const uint32_t f = (w & 255) + (obs ^ 1), t = ((w >> 8) & 255) + obs;
+    uint32_t nw = f | (t << 8) | ((mul24_5(f << 8, inv24[f + t]) >> 24) << 16);
+    if ((f | t) > 255) {   // the incremented count was 255
+        const uint32_t f0 = w & 255, t0 = (w >> 8) & 255;
+        if ((obs ? f0 : t0) == 1) nw = (w & 0xffff) | ((obs ? 0u : 255u) << 16);
+        else {
+            const uint32_t f2 = obs ? (1 + f0) >> 1 : 129u, t2 = obs ? 129u : (1 + t0) >> 1;
+            nw = f2 | (t2 << 8) | ((mul24_5(f2 << 8, inv24[f2 + t2]) >> 24) << 16);
+        }
+    }
+    return nw;
+}
+WDEV uint32_t inv24_5(uint32_t d) {   // lep_dec4.h inv24_of: exact for every reachable count pair
+    if (d < 2) return 0;
+    return (0x1000000u + d - 1) / d - ((d == 337 || d == 469) ? 1u : 0u);
+}
+
+// ---- fold: lane = chain --------------------------------------------------------------------------------------------------
+// Every lane owns `SLICE` Branches in LDS, laid out [branch][lane] (a lane's words sit in one bank column: no conflicts
+// whatever the lanes index).  code(): one bin -- returns the probability it is coded with, adapts the Branch.
+struct FoldShared {
+    uint32_t inv24[512];
+    uint32_t slice[kDcSlice * 64];   // the largest slice (197 words per lane)
+};
+struct FoldLane {
+    uint32_t* s;   // &slice[lane]
+    const uint32_t* inv24;
+    WDEV uint32_t code(int branch, uint32_t bit) {
+        const uint32_t w = s[branch * 64];
+        s[branch * 64] = bupd5(w, bit, inv24);
+        return w >> 16;
+    }
+};
+WDEV void fold_init(FoldShared* sh, int words_per_lane) {
+    LANES(l) {
+        for (int d = l; d < 512; d += 64) sh->inv24[d] = inv24_5((uint32_t)d);
+        for (int i = 0; i < words_per_lane; ++i) sh->slice[i * 64 + l] = kBranchInit;
+    }
+    LSYNC();
+}
+
+// the bins of unit u of a coefficient entry through the lane's slice; exponent Branch = bsr * 11 + i, residual = rbase + b
+WDEV uint32_t fold_coef_unit(FoldLane& fl, uint32_t e, int rbase) {
+    const int nres = (int)(e >> 10) & 15, len = (int)(e >> 14) & 15, bsr = (int)(e >> 18) & 31, u = (int)(e >> 27) & 7;
+    const int nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
+    uint32_t probs = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int j = 4 * u + q;
+        if (j >= m) break;
+        uint32_t p;
+        if (j < nexp) p = fl.code(bsr * 11 + j, (uint32_t)(len != j));
+        else { const int b = nres - 1 - (j - nexp); p = fl.code(rbase + b, (e >> b) & 1u); }
+        probs |= p << (8 * q);
+    }
+    return probs;
+}
+
+// coefficient chains: lane = (segment seg0 + lane, stream sid): the same chain of 64 consecutive segments in one wavefront
+// (chains of one kind are about equally long: the lanes finish together)
+WDEV void fold_coef_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg, int sid, FoldShared* sh) {
+    fold_init(sh, kCoefSlice);
+    LANES(l) {
+        const int seg = seg0 + l;
+        if (seg < nseg) {
+            const SegPlan5& P = plans[seg];
+            uint32_t* units = reinterpret_cast<uint32_t*>(arena + P.arena_off);
+            FoldLane fl{sh->slice + l, sh->inv24};
+            if (!P.status)
+                for (uint32_t i = P.base[sid]; i < P.base[sid + 1]; ++i) units[i] = fold_coef_unit(fl, units[i], 132);
+        }
+    }
+}
+
+// threshold chains (edge residual bits at or above the noise threshold, encoder.cc:132-152): Branches in HBM,
+// thresh[ci][prior class][lt][node], node = 1, then min(2 * node + bit, 127)
+WDEV void fold_thresh_wave(const SegPlan5* plans, uint8_t* arena, uint32_t* thresh_models, int seg0, int nseg, int sid, int ci, FoldShared* sh) {
+    LANES(l) for (int d = l; d < 512; d += 64) sh->inv24[d] = inv24_5((uint32_t)d);
+    LSYNC();
+    LANES(l) {
+        const int seg = seg0 + l;
+        if (seg < nseg) {
+            const SegPlan5& P = plans[seg];
+            uint32_t* units = reinterpret_cast<uint32_t*>(arena + P.arena_off);
+            uint32_t* model = thresh_models + (size_t)seg * kThreshWords;
+            for (uint32_t i = P.base[sid]; i < (P.status ? 0u : P.base[sid + 1]); ++i) {
+                const uint32_t e = units[i];
+                const int n = (int)(e >> 10) & 15, pcls = (int)(e >> 14) & 255, lt = (int)(e >> 23) & 15, u = (int)(e >> 27) & 7;
+                uint32_t* T = model + (((uint32_t)ci * 256 + pcls) * 8 + lt) * 128;
+
+                int node = 1;
+                uint32_t probs = 0;
+                for (int t = 0; t < n && t < 4 * u + 4; ++t) {
+                    const uint32_t bit = (e >> (n - 1 - t)) & 1u;
+                    if (t >= 4 * u) {
+                        const uint32_t w = T[node];
+                        T[node] = bupd5(w, bit, sh->inv24);
+                        probs |= (w >> 16) << (8 * (t - 4 * u));
+                    }
+                    node = imin((node << 1) | (int)bit, 127);
+                }
+                units[i] = probs;
+            }
+        }
+    }
+}
+
+// sign chains: one byte per entry; lane = segment, the colour's 48 sign Branches in the lane's slice
+WDEV void fold_sign_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg, int ci, FoldShared* sh) {
+    fold_init(sh, kSignSlice);
+    LANES(l) {
+        const int seg = seg0 + l;
+        if (seg < nseg) {
+            const SegPlan5& P = plans[seg];
+            uint8_t* s = arena + P.arena_off + P.sign_base[ci];
+            FoldLane fl{sh->slice + l, sh->inv24};
+            for (uint32_t i = 0; i < (P.status ? 0u : P.sign_cnt[ci]); ++i) {
+                const uint32_t e = s[i];
+                if (e & 0x80u) s[i] = (uint8_t)fl.code((int)(e & 63u), (e >> 6) & 1u);
+            }
+        }
+    }
+}
+
+// sparse chains: lane = segment, the wave's key filters the records of the lane's segment
+// number of non-zeros of the 7x7 interior: six bins MSB first through T[level][prefix] (encoder.cc:200-213)
+WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg, int ci, int ctxbin, FoldShared* sh) {
+    fold_init(sh, kNzSlice);
+    LANES(l) {
+        const int seg = seg0 + l;
+        if (seg < nseg) {
+            const SegPlan5& P = plans[seg];
+            uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.nz_base);
+            const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
+            FoldLane fl{sh->slice + l, sh->inv24};
+            const uint32_t key = (uint32_t)ci | ((uint32_t)ctxbin << 1);
+            for (uint32_t b = 0; b < (P.status ? 0u : P.nblocks); ++b) {
+                if ((keys[b] & 31u) != key) continue;
+                const int nz = (int)rec[2 * b] & 63;
+                uint32_t lo = 0, hi = 0;
+                int so_far = 0;
+                for (int i = 5; i >= 0; --i) {
+                    const uint32_t bit = (uint32_t)(nz >> i) & 1u;
+                    const uint32_t p = fl.code(i * 32 + so_far, bit);
+                    const int q = 5 - i;
+                    if (q < 4) lo |= p << (8 * q); else hi |= p << (8 * (q - 4));
+                    so_far = (so_far << 1) | (int)bit;
+                }
+                rec[2 * b] = lo; rec[2 * b + 1] = hi;
+            }
+        }
+    }
+}
+// edge non-zero counts: three bins MSB first through T[nzq][level][prefix] of (ci, horizontal / vertical, eob)
+WDEV void fold_edgenz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg, int ci, int vertical, int eob, FoldShared* sh) {
+    fold_init(sh, kEdgeNzSlice);
+    LANES(l) {
+        const int seg = seg0 + l;
+        if (seg < nseg) {
+            const SegPlan5& P = plans[seg];
+            uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.en_base);
+            const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
+            FoldLane fl{sh->slice + l, sh->inv24};
+            for (uint32_t b = 0; b < (P.status ? 0u : P.nblocks); ++b) {
+                const uint32_t kw = keys[b];
+                if ((int)(kw & 1u) != ci || (int)((kw >> (vertical ? 8 : 5)) & 7u) != eob) continue;
+                const uint32_t e = rec[2 * b + vertical];
+                const int nzq = (int)e & 7, ne = (int)(e >> 3) & 7;
+                uint32_t probs = 0;
+                int so_far = 0;
+                for (int i = 2; i >= 0; --i) {
+                    const uint32_t bit = (uint32_t)(ne >> i) & 1u;
+                    probs |= fl.code(nzq * 12 + i * 4 + so_far, bit) << (8 * (2 - i));
+                    so_far = (so_far << 1) | (int)bit;
+                }
+                rec[2 * b + vertical] = probs;
+            }
+        }
+    }
+}
+// DC chains, key a = min(bit length of the uncertainty, 11): exponent Branches [17 b][11], residual Branches [10]
+WDEV void fold_dc_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg, int a, FoldShared* sh) {
+    fold_init(sh, kDcSlice);
+    LANES(l) {
+        const int seg = seg0 + l;
+        if (seg < nseg) {
+            const SegPlan5& P = plans[seg];
+            uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.dc_base);
+            const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
+            FoldLane fl{sh->slice + l, sh->inv24};
+            for (uint32_t b = 0; b < (P.status ? 0u : P.nblocks); ++b) {
+                if ((int)((keys[b] >> 11) & 15u) != a) continue;
+                const uint32_t e0 = rec[6 * b];
+                const int n = coef_units((int)(e0 >> 14) & 15, (int)(e0 >> 10) & 15);
+                for (int u = 0; u < n; ++u) rec[6 * b + u] = fold_coef_unit(fl, e0 | ((uint32_t)u << 27), 17 * 11);
+            }
+        }
+    }
+}
+
+// ---- write: lane = segment bool writer (boolwriter.hh:48-118, boolwriter.cc:17-35) ---------------------------------------
+// bins: probability | bit << 8.  The serial recurrence runs in every lane on its own segment; byte stores go to the lane's own
+// stream (the carry ripple re-reads bytes this lane wrote).
+WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* segs, int seg0, int nseg, uint8_t* streams, uint32_t* stream_len,
+                     int32_t* status) {
+    LANES(l) {
+        const int seg = seg0 + l;
+        if (seg < nseg) {
+            const SegPlan5& P = plans[seg];
+            const SegDev& sd = segs[seg];
+            if (P.status) status[sd.slot] = P.status;
+            else {
+                const uint16_t* b = bins + P.bins_off;
+                BoolCoder<false> bc;
+                bc.init_stream(streams + sd.stream_off, sd.stream_cap);
+                for (uint32_t i = 0; i < P.nbins; ++i) { const uint32_t e = b[i]; bc.put((int)(e >> 8) & 1, e & 255u); }
+                const uint32_t n = bc.finish();
+                stream_len[sd.slot] = n;
+                if (bc.overflow) status[sd.slot] = 100;   // LEP_BUFFER_TOO_SMALL
+            }
+        }
+    }
+}
+
+
+// ---- the walk: count / emit / gather -------------------------------------------------------------------------------------
+// One wavefront per segment; a TILE = up to 64 consecutive coded blocks of one block row; lane = block.  Per tile:
+//   phase 1  lane = block: the block's own numbers (non-zero counts, IDCT, neighbour summary), then DC prediction
+//   phase A  lane = block, row by row in stream order: what every coded coefficient contributes -> P[row][lane]
+//            (the first unit of its entry; 0 = not coded), threshold entries in rows 63..76
+//   phase B  lane = ROW: walks the 64 lanes of its row in block order and gives every entry its rank inside (tile, row, class)
+//            -- private counters, no conflicts, no ballots: RK[row][lane]
+//   phase C  lane = block, rows in stream order again: emit writes the units to stream base + cursor + rank, the sign bytes and
+//            the sparse records; gather reads the probabilities from the same places and appends the block's bins
+//   phase D  the cursors advance by the tile's totals
+enum { kCount = 0, kEmit = 1, kGather = 2 };
+
+struct Walk5Shared {
+    uint32_t cur[32 * 65], abv[32 * 65];   // transposed tiles: dword i (coefficients 2i, 2i + 1 in aligned order) of lane c at [i * 65 + c];
+                                           // column 64 = the block left of lane 0 (the previous tile's last one)
+    uint32_t P[kPRows * 65];               // [row * 65 + lane]: conflict-free for lane = block and for lane = row
+    uint16_t RK[kRows * 65];
+    uint16_t TB[8 * 65];                   // threshold units of the lane per class lt (phase A), then where its next one goes (phase C)
+    uint8_t SS[14 * 64];                   // sign Branch slot of the edge coefficients (needs the prior)
+    uint32_t cursor[2 * kRows * kClasses]; // units already given out, per colour index / row / class
+    uint16_t loc[kRows * 16];              // this tile's units per (row, class)
+    NSum ns[65];                           // neighbour summaries of the tile's blocks; [64] = the block left of lane 0
+    uint8_t r2a[64], a2r[64];
+};
+
+WDEV int tile_get(const uint32_t* T, int a, int col) { return (int16_t)(T[(a >> 1) * 65 + col] >> ((a & 1) * 16)); }
+
+template <int MODE>
+struct Walk5 {
+    const ImageDev* img;
+    Walk5Shared* sh;
+    const SegPlan5* plan;      // emit / gather
+    uint8_t* arena;            // segment's entry arena (emit / gather)
+    uint16_t* bins;            // segment's bin list (gather)
+    int comp, ci;
+    uint32_t ord0;             // block ordinal of lane 0 of the current tile
+    uint32_t sign_pos[2];      // sign bytes given out per colour index
+    uint32_t nbins;            // gather: bins written; count: bins an encoder will need (upper bound through the DC term)
+    int status;
+
+    WDEV uint32_t* units() const { return reinterpret_cast<uint32_t*>(arena); }
+
+    // load the tile [x0, x0 + nb) of row `row` (and of the row above) into the transposed arrays
+    WDEV void load_tile(const int16_t* row, const int16_t* arow, int x0, int nb, bool first_of_row) {
+        Walk5Shared& S = *sh;
+        LANES(l) {   // keep the last column of the previous tile as "left of lane 0"
+            if (l < 32) {
+                S.cur[l * 65 + 64] = first_of_row ? 0u : S.cur[l * 65 + 63];
+                S.abv[l * 65 + 64] = first_of_row ? 0u : S.abv[l * 65 + 63];
+            }
+            if (l == 0) { if (first_of_row) S.ns[64] = NSum{}; else S.ns[64] = S.ns[63]; }
+        }
+        LSYNC();
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(row + (int64_t)x0 * 64);
+        const uint32_t* asrc = arow ? reinterpret_cast<const uint32_t*>(arow + (int64_t)x0 * 64) : nullptr;
+        LANES(l) {
+            for (int k = 0; k < 32; ++k) {
+                const int d = k * 64 + l, b = d >> 5, i = d & 31;
+                S.cur[i * 65 + b] = b < nb ? src[d] : 0u;
+                S.abv[i * 65 + b] = (asrc && b < nb) ? asrc[d] : 0u;
+            }
+        }
+        LSYNC();
+    }
+
+    // one tile; has_above: the row above belongs to this segment; returns 0 or an exit code
+    WDEV int tile(int x0, int nb, bool has_above, NSum* nrow, const NSum* narow) {
+        Walk5Shared& S = *sh;
+        const int c = comp;
+        LV(int, act); LV(int, nz); LV(int, neh); LV(int, nev); LV(int, nsig); LV(int, err); LV(int, errdc);
+        LV(int, eobx); LV(int, eoby);
+        LV(int32_t, dc_e0);       // DC entry (unit 0)
+        LV(int, dc_sign);         // sign byte of the DC (0 = no sign bin)
+        LV(int, nzctxbin);
+        LV(int, lbins);           // bins of this block
+        LV(NSum, nsa);            // the summary of the block above
+
+        // ---- phase 1a: own numbers ---------------------------------------------------------------------------------
+        LANES(l) {
+            const int a = l < nb;
+            L(act) = a; L(err) = 0; L(errdc) = 0;
+            int n7 = 0, nh = 0, nv = 0, ex = 0, ey = 0;
+            if (a) {
+                for (int z = 0; z < 49; ++z)
+                    if (tile_get(S.cur, z, l) != 0) { ++n7; const int coord = S.a2r[z]; ex = ex > (coord & 7) ? ex : (coord & 7); ey = ey > (coord >> 3) ? ey : (coord >> 3); }
+                for (int j = 0; j < 7; ++j) { nh += tile_get(S.cur, 50 + j, l) != 0; nv += tile_get(S.cur, 57 + j, l) != 0; }
+            }
+            L(nz) = n7; L(neh) = nh; L(nev) = nv; L(eobx) = ex; L(eoby) = ey;
+            L(nsig) = a ? n7 + nh + nv + 1 : 0;
+            if (MODE != kCount && has_above && a) L(nsa) = narow[x0 + l];   // (written when that row was walked)
+            else L(nsa) = NSum{};
+        }
+        // ---- phase 1b: IDCT without DC, neighbour summary (block_context.hh:44-78) -------------------------------------
+        struct Px { int16_t r0[8], r1[8], c0[8], c1[8]; };   // pixel rows 0, 1 and columns 0, 1 of the block without its DC
+        LV(Px, px);
+        if (MODE != kCount) {
+            LANES(l) if (L(act)) {
+                const uint16_t* q = img->q[c];
+                constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
+                constexpr int w1pw7 = w1 + w7, w1mw7 = w1 - w7, w2pw6 = w2 + w6, w2mw6 = w2 - w6, w3pw5 = w3 + w5, w3mw5 = w3 - w5;
+                int32_t t[64];
+                int16_t pix[64];
+                for (int y = 0; y < 8; ++y) {
+                    const int y8 = y * 8;
+#define LEP5_CQ(i) ((int32_t)tile_get(S.cur, S.r2a[i], l) * (int32_t)q[i])
+                    int32_t x0_ = (y == 0 ? 0 : (int32_t)((uint32_t)LEP5_CQ(y8) << 11)) + 128;
+                    int32_t x1 = (int32_t)((uint32_t)LEP5_CQ(y8 + 4) << 11);
+                    int32_t x2 = LEP5_CQ(y8 + 6), x3 = LEP5_CQ(y8 + 2), x4 = LEP5_CQ(y8 + 1), x5 = LEP5_CQ(y8 + 7), x6 = LEP5_CQ(y8 + 5), x7 = LEP5_CQ(y8 + 3), x8;
+#undef LEP5_CQ
+                    x8 = w7 * (x4 + x5); x4 = x8 + w1mw7 * x4; x5 = x8 - w1pw7 * x5;
+                    x8 = w3 * (x6 + x7); x6 = x8 - w3mw5 * x6; x7 = x8 - w3pw5 * x7;
+                    x8 = x0_ + x1; x0_ -= x1;
+                    x1 = w6 * (x3 + x2); x2 = x1 - w2pw6 * x2; x3 = x1 + w2mw6 * x3;
+                    x1 = x4 + x6; x4 -= x6; x6 = x5 + x7; x5 -= x7;
+                    x7 = x8 + x3; x8 -= x3; x3 = x0_ + x2; x0_ -= x2;
+                    x2 = (r2 * (x4 + x5) + 128) >> 8;
+                    x4 = (r2 * (x4 - x5) + 128) >> 8;
+                    t[y8 + 0] = (x7 + x1) >> 8; t[y8 + 1] = (x3 + x2) >> 8; t[y8 + 2] = (x0_ + x4) >> 8; t[y8 + 3] = (x8 + x6) >> 8;
+                    t[y8 + 4] = (x8 - x6) >> 8; t[y8 + 5] = (x0_ - x4) >> 8; t[y8 + 6] = (x3 - x2) >> 8; t[y8 + 7] = (x7 - x1) >> 8;
+                }
+                for (int x = 0; x < 8; ++x) {
+                    int32_t y0 = (int32_t)((uint32_t)t[x] << 8) + 8192, y1 = (int32_t)((uint32_t)t[32 + x] << 8);
+                    int32_t y2 = t[48 + x], y3 = t[16 + x], y4 = t[8 + x], y5 = t[56 + x], y6 = t[40 + x], y7 = t[24 + x], y8;
+                    y8 = w7 * (y4 + y5) + 4; y4 = (y8 + w1mw7 * y4) >> 3; y5 = (y8 - w1pw7 * y5) >> 3;
+                    y8 = w3 * (y6 + y7) + 4; y6 = (y8 - w3mw5 * y6) >> 3; y7 = (y8 - w3pw5 * y7) >> 3;
+                    y8 = y0 + y1; y0 -= y1;
+                    y1 = w6 * (y3 + y2) + 4; y2 = (y1 - w2pw6 * y2) >> 3; y3 = (y1 + w2mw6 * y3) >> 3;
+                    y1 = y4 + y6; y4 -= y6; y6 = y5 + y7; y5 -= y7;
+                    y7 = y8 + y3; y8 -= y3; y3 = y0 + y2; y0 -= y2;
+                    y2 = (r2 * (y4 + y5) + 128) >> 8;
+                    y4 = (r2 * (y4 - y5) + 128) >> 8;
+                    pix[x] = (int16_t)((y7 + y1) >> 11); pix[8 + x] = (int16_t)((y3 + y2) >> 11);
+                    pix[16 + x] = (int16_t)((y0 + y4) >> 11); pix[24 + x] = (int16_t)((y8 + y6) >> 11);
+                    pix[32 + x] = (int16_t)((y8 - y6) >> 11); pix[40 + x] = (int16_t)((y0 - y4) >> 11);
+                    pix[48 + x] = (int16_t)((y3 - y2) >> 11); pix[56 + x] = (int16_t)((y7 - y1) >> 11);
+                }
+                const int dcq = tile_get(S.cur, 49, l) * (int)q[0];
+                NSum& me = S.ns[l];
+                for (int i = 0; i < 8; ++i) {
+                    me.horiz[i] = (int16_t)(dcq + pix[56 + i] + 1024 + (int16_t)(pix[56 + i] - pix[48 + i]) / 2);
+                    me.vert[i] = (int16_t)(dcq + pix[i * 8 + 7] + 1024 + (int16_t)(pix[i * 8 + 7] - pix[i * 8 + 6]) / 2);
+                    L(px).r0[i] = pix[i]; L(px).r1[i] = pix[8 + i]; L(px).c0[i] = pix[i * 8]; L(px).c1[i] = pix[i * 8 + 1];
+                }
+                me.nz = L(nz);
+                nrow[x0 + l] = me;   // for the row below
+            }
+            LSYNC();
+        }
+        // ---- phase 1c: contexts that need the neighbours' summaries: 7x7 non-zero context, DC prediction (model.hh:463-485, 674-832)
+        LANES(l) {
+            int32_t e0 = 0; int sgn = 0, bins_here = 0, ctxbin = 0;
+            if (L(act)) {
+                const bool has_left = x0 + l > 0;
+                const int dc = tile_get(S.cur, 49, l);
+                if (MODE != kCount) {
+                    const NSum& nl = S.ns[(l + 64) % 65];
+                    const NSum& na = L(nsa);
+                    int nzctx = 0;
+                    if (has_left && has_above) nzctx = (na.nz + nl.nz + 2) / 4;
+                    else if (has_above) nzctx = (na.nz + 1) / 2;
+                    else if (has_left) nzctx = (nl.nz + 1) / 2;
+                    ctxbin = kNzBin[nzctx];
+                    int32_t avgmed = 0, unc = 0, unc2 = 0;
+                    if (has_left || has_above) {
+                        int sum0 = 0, sum1 = 0, mn = 0x7fffffff, mx = -0x7fffffff, n = 0;
+                        if (has_left)
+                            for (int i = 0; i < 8; ++i, ++n) {
+                                const int ev = (int16_t)(nl.vert[i] - (int16_t)(L(px).c0[i] - L(px).c1[i]) / 2 - (L(px).c0[i] + 1024));
+                                sum0 += ev; mn = ev < mn ? ev : mn; mx = ev > mx ? ev : mx;
+                            }
+                        if (has_above)
+                            for (int i = 0; i < 8; ++i, ++n) {
+                                const int ev = (int16_t)(na.horiz[i] - (int16_t)(L(px).r0[i] - L(px).r1[i]) / 2 - (L(px).r0[i] + 1024));
+                                if (has_left) sum1 += ev; else sum0 += ev;
+                                mn = ev < mn ? ev : mn; mx = ev > mx ? ev : mx;
+                            }
+                        if (n == 8) sum1 = sum0;
+                        avgmed = (sum0 + sum1) >> 1;
+                        unc = (mx - mn) >> 3;
+                        sum0 -= avgmed; sum1 -= avgmed;
+                        unc2 = (iabs(sum0) < iabs(sum1) ? sum0 : sum1) >> 3;
+                    }
+                    const int pred = (avgmed / (int)img->q[c][0] + 4) >> 3;
+                    const int a = imin(bitlen((uint32_t)iabs(unc) & 0xffff), 11), b17 = imin(bitlen((uint32_t)iabs(unc2) & 0xffff), 16);
+                    int d = dc - pred;
+                    if (d < -1024) d += 2049;
+                    if (d > 1024) d -= 2049;
+                    int back = d + pred;
+                    if (back < -1024) back += 2049;
+                    if (back > 1024) back -= 2049;
+                    const int v = iabs(d), len = bitlen((uint32_t)v & 0xffff);
+                    if (back != dc || len > 11) L(errdc) = 6;   // the LAST check of the block in stream order: kept apart from the earlier ones
+                    const int nres = len > 1 ? len - 1 : 0;
+                    e0 = (int32_t)coef_entry((uint32_t)v & ((1u << nres) - 1u), nres, len > 11 ? 11 : len, b17, a, 0);
+                    if (len) sgn = 0x80 | (unc2 >= 0 ? (unc2 == 0 ? 3 : 2) : 1) | ((d >= 0) << 6);
+                    bins_here = (len < 11 ? len + 1 : 11) + (len ? 1 : 0) + nres;
+                } else bins_here = 22;
+                bins_here += 6 + 3 + 3;
+            }
+            L(dc_e0) = e0; L(dc_sign) = sgn; L(nzctxbin) = ctxbin; L(lbins) = bins_here;
+        }
+
+        // ---- phase A: rows in stream order -> P, SS ----------------------------------------------------------------------
+        LV(int, left);
+        LANES(l) { L(left) = L(nz); for (int r = l; r < kRows * 16; r += 64) S.loc[r] = 0; for (int t = 0; t < 8; ++t) S.TB[t * 65 + l] = 0; }
+        for (int zz = 0; zz < 49; ++zz) {
+            LANES(l) {
+                uint32_t e = 0;
+                if (L(act) && L(left) > 0) {
+                    const int cf = tile_get(S.cur, zz, l), v = iabs(cf), len = bitlen((uint32_t)v);
+                    int bsr = 0;
+                    if (MODE != kCount) {
+                        const bool has_left = x0 + l > 0;
+                        int prior = 0;
+                        if (has_left && has_above) prior = (uint16_t)((iabs(tile_get(S.cur, zz, (l + 64) % 65)) + iabs(tile_get(S.abv, zz, l))) * 13 + 6 * iabs(tile_get(S.abv, zz, (l + 64) % 65))) >> 5;
+                        else if (has_left) prior = (int16_t)iabs(tile_get(S.cur, zz, (l + 64) % 65));
+                        else if (has_above) prior = (int16_t)iabs(tile_get(S.abv, zz, l));
+                        bsr = bitlen((uint32_t)imin(iabs(prior), 1023));
+                        if (len > 11 && !L(err)) L(err) = 6;
+                    }
+                    const int lc = len > 11 ? 11 : len, nres = lc > 1 ? lc - 1 : 0;
+                    e = coef_entry((uint32_t)v & ((1u << nres) - 1u), nres, lc, bsr, kNzBin[L(left)], 0);
+                    L(lbins) += (lc < 11 ? lc + 1 : 11) + (lc ? 1 : 0) + nres;
+                    if (v) --L(left);
+                }
+                S.P[zz * 65 + l] = e;
+            }
+        }
+        for (int eg = 0; eg < 2; ++eg) {   // horizontal edge (neighbour = above), then vertical (neighbour = left)
+            const bool horizontal = eg == 0;
+            LANES(l) L(left) = horizontal ? L(neh) : L(nev);
+            for (int j = 0; j < 7; ++j) {
+                const int coord = horizontal ? j + 1 : (j + 1) * 8, row = 49 + eg * 7 + j, a_here = (horizontal ? 50 : 57) + j;
+                LANES(l) {
+                    uint32_t e = 0, te = 0; int slot = 0;
+                    if (L(act) && L(left) > 0) {
+                        const int cf = tile_get(S.cur, a_here, l), v = iabs(cf), len = bitlen((uint32_t)v);
+                        const int lc = len > 11 ? 11 : len;
+                        const int thr = img->min_thresh[c][coord];
+                        int bsr = 0, pcls = 0;
+                        if (MODE != kCount) {
+                            const bool nbr_ok = horizontal ? has_above : (x0 + l > 0);
+                            int32_t prior = 0;
+                            if (nbr_ok) {
+                                const uint32_t* NB = horizontal ? S.abv : S.cur;
+                                const int ncol = horizontal ? l : (l + 64) % 65;
+                                const int32_t* icos = horizontal ? img->icos_x[c] + coord * 8 : img->icos_y[c] + coord;
+                                const int step = horizontal ? 8 : 1;
+                                if (icos[0] == 0) { if (!L(err)) L(err) = 43; }
+                                else {
+                                    uint32_t acc = (uint32_t)(int32_t)tile_get(NB, S.r2a[coord], ncol) * (uint32_t)icos[0];
+                                    for (int i = 1; i < 8; ++i) {
+                                        const int32_t xi = tile_get(S.cur, S.r2a[coord + i * step], l), ai = tile_get(NB, S.r2a[coord + i * step], ncol);
+                                        const int32_t term = (i & 1) ? xi + ai : xi - ai;
+                                        acc -= (uint32_t)icos[i] * (uint32_t)term;
+                                    }
+                                    prior = (int32_t)acc / icos[0];
+                                }
+                            }
+                            const uint32_t ap = prior < 0 ? 0u - (uint32_t)prior : (uint32_t)prior;
+                            bsr = bitlen(ap > 1023 ? 1023 : ap);
+                            const int16_t p16 = (int16_t)prior;
+                            slot = (p16 == 0 ? 0 : (p16 > 0 ? 1 : 2)) * 12 + bsr;
+                            pcls = imin((int)((ap & 0xffff) >> thr), 255);
+                            if (len > 11 && !L(err)) L(err) = 6;
+                        }
+                        int nres = lc > 1 ? lc - 1 : 0;
+                        if (lc > 1 && lc - 2 >= thr) {
+                            const int n = lc - 1 - thr;
+                            te = thresh_entry(((uint32_t)v >> thr) & ((1u << n) - 1u), n, pcls, imin(lc - thr, 7), 0);
+                            S.TB[imin(lc - thr, 7) * 65 + l] = (uint16_t)(S.TB[imin(lc - thr, 7) * 65 + l] + ((n + 3) >> 2));
+                            nres = thr;
+                        }
+                        e = coef_entry((uint32_t)v & ((1u << nres) - 1u), nres, lc, bsr, L(left), 0);
+                        L(lbins) += (lc < 11 ? lc + 1 : 11) + (lc ? 1 : 0) + (lc > 1 ? lc - 1 : 0);
+                        if (v) --L(left);
+                    }
+                    S.P[row * 65 + l] = e;
+                    S.P[(63 + eg * 7 + j) * 65 + l] = te;
+                    S.SS[(eg * 7 + j) * 64 + l] = (uint8_t)slot;
+                }
+            }
+        }
+        LSYNC();
+        {   // the first error in stream order ends the segment (lane order = block order; inside a block the DC check comes last)
+            LV(int, bad);
+            LANES(l) { if (!L(err)) L(err) = L(errdc); L(bad) = L(err) != 0; }
+            const uint64_t bm = lepwave::wave_ballot(bad);
+            if (MODE == kEmit && bm) {
+                const int first = __builtin_ctzll(bm);
+                return (int)(lepwave::wave_read((const uint32_t*)err, first) & 0xffff);
+            }
+        }
+
+        // ---- phase B: lane = row: ranks inside (tile, row, class) --------------------------------------------------------
+        LANES(l) {
+            const int r = l;
+            if (r < 63) {
+                for (int b = 0; b < 64; ++b) {
+                    const uint32_t e = S.P[r * 65 + b];
+                    if (!e) continue;
+                    const int k = (int)(e >> 23) & 15;
+                    S.RK[r * 65 + b] = S.loc[r * 16 + k];
+                    S.loc[r * 16 + k] = (uint16_t)(S.loc[r * 16 + k] + coef_units((int)(e >> 14) & 15, (int)(e >> 10) & 15));
+                }
+            }
+        }
+        // the threshold streams (row 63, class lt) are ordered block by block: a lane's units of one class are consecutive
+        for (int lt = 2; lt < 8; ++lt) {
+            LV(int, tc); LV(int, to);
+            LANES(l) L(tc) = S.TB[lt * 65 + l];
+            const int tot = lepwave::wave_excl_scan(tc, to);
+            LANES(l) { S.TB[lt * 65 + l] = (uint16_t)L(to); if (l == 0) S.loc[63 * 16 + lt] = (uint16_t)tot; }
+        }
+        LSYNC();
+
+        // ---- phase C: emit / gather ---------------------------------------------------------------------------------------
+        LV(int, sbase); LV(int, bbase);
+        const int nsig_tile = lepwave::wave_excl_scan(nsig, sbase);
+        const int bins_tile = lepwave::wave_excl_scan(lbins, bbase);
+        if (MODE != kCount) {
+            const uint32_t* base = plan->base;
+            uint8_t* signs = arena + plan->sign_base[ci] + sign_pos[ci];
+            uint32_t* U = units();
+            LV(uint32_t, bp);   // gather: next bin of this lane
+            LV(int, sp);        // next sign byte of this lane
+            LANES(l) { L(bp) = nbins + (uint32_t)L(bbase); L(sp) = L(sbase); }
+            // 7x7 non-zero count
+            LANES(l) if (L(act)) {
+                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->nz_base) + 2 * (ord0 + l);
+                if (MODE == kEmit) {
+                    rec[0] = (uint32_t)L(nz);
+                    reinterpret_cast<uint32_t*>(arena + plan->key_base)[ord0 + l] =
+                        (uint32_t)ci | ((uint32_t)L(nzctxbin) << 1) | ((uint32_t)L(eobx) << 5) | ((uint32_t)L(eoby) << 8) | ((((uint32_t)L(dc_e0) >> 23) & 15u) << 11);
+                }
+                else {
+                    const uint32_t lo = rec[0], hi = rec[1];
+                    for (int i = 5; i >= 0; --i) {
+                        const int q = 5 - i;
+                        const uint32_t p = q < 4 ? (lo >> (8 * q)) & 255u : (hi >> (8 * (q - 4))) & 255u;
+                        bins[L(bp)++] = (uint16_t)(p | ((((uint32_t)L(nz) >> i) & 1u) << 8));
+                    }
+                }
+            }
+            for (int row = 0; row < 63; ++row) {
+                const bool edge = row >= 49;
+                const int eg = row >= 56 ? 1 : 0, j = edge ? row - 49 - eg * 7 : 0;
+                if (row == 49 || row == 56) {   // the edge's non-zero count
+                    LANES(l) if (L(act)) {
+                        uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->en_base) + 2 * (ord0 + l) + eg;
+                        const int ne = eg ? L(nev) : L(neh);
+                        if (MODE == kEmit) rec[0] = (uint32_t)((L(nz) + 3) / 7) | ((uint32_t)ne << 3);
+                        else {
+                            const uint32_t pr = rec[0];
+                            for (int i = 2; i >= 0; --i) bins[L(bp)++] = (uint16_t)(((pr >> (8 * (2 - i))) & 255u) | ((((uint32_t)ne >> i) & 1u) << 8));
+                        }
+                    }
+                }
+                LANES(l) {
+                    const uint32_t e = S.P[row * 65 + l];
+                    if (e) {
+                        const int k = (int)(e >> 23) & 15, len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15;
+                        const int nexp = len < 11 ? len + 1 : 11, m = nexp + nres, n = (m + 3) >> 2;
+                        const int sid = stream_id(ci, row, k);
+                        const uint32_t at = base[sid] + S.cursor[sid] + S.RK[row * 65 + l];
+                        const int a_here = row < 49 ? row : (eg ? 57 : 50) + j;
+                        const int cf = tile_get(S.cur, a_here, l);
+                        const uint32_t te = edge ? S.P[(63 + eg * 7 + j) * 65 + l] : 0u;
+                        uint32_t tat = 0; int tn = 0;
+                        if (te) {
+                            const int lt = (int)(te >> 23) & 15, tsid = stream_id(ci, 63, lt);
+                            tn = (int)(te >> 10) & 15;
+                            tat = base[tsid] + S.cursor[tsid] + S.TB[lt * 65 + l];
+                            S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + ((tn + 3) >> 2));
+                        }
+                        const uint32_t sbyte = 0x80u | (uint32_t)(edge ? S.SS[(eg * 7 + j) * 64 + l] : 0) | ((uint32_t)(cf >= 0) << 6);
+                        if (MODE == kEmit) {
+                            for (int u = 0; u < n; ++u) U[at + u] = e | ((uint32_t)u << 27);
+                            for (int u = 0; u < (tn + 3) >> 2; ++u) U[tat + u] = te | ((uint32_t)u << 27);
+                            if (len) signs[L(sp)++] = (uint8_t)sbyte;
+                        } else {
+                            for (int q = 0; q < nexp; ++q) bins[L(bp)++] = (uint16_t)(((U[at + (q >> 2)] >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
+                            if (len) bins[L(bp)++] = (uint16_t)(signs[L(sp)++] | ((uint32_t)(cf >= 0) << 8));
+                            for (int t = 0; t < tn; ++t) bins[L(bp)++] = (uint16_t)(((U[tat + (t >> 2)] >> (8 * (t & 3))) & 255u) | (((te >> (tn - 1 - t)) & 1u) << 8));
+                            for (int q = nexp; q < m; ++q) bins[L(bp)++] = (uint16_t)(((U[at + (q >> 2)] >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
+                        }
+                    }
+                }
+            }
+            // DC
+            LANES(l) if (L(act)) {
+                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->dc_base) + 6 * (ord0 + l);
+                const uint32_t e = (uint32_t)L(dc_e0);
+                const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
+                if (MODE == kEmit) { rec[0] = e; signs[L(sp)++] = (uint8_t)L(dc_sign); }
+                else {
+                    for (int q = 0; q < nexp; ++q) bins[L(bp)++] = (uint16_t)(((rec[q >> 2] >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
+                    const uint32_t sb = signs[L(sp)++];
+                    if (len) bins[L(bp)++] = (uint16_t)(sb | ((((uint32_t)L(dc_sign) >> 6) & 1u) << 8));
+                    for (int q = nexp; q < m; ++q) bins[L(bp)++] = (uint16_t)(((rec[q >> 2] >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
+                }
+            }
+        }
+        LSYNC();
+        // ---- phase D: advance the cursors ---------------------------------------------------------------------------------
+        LANES(l) {
+            for (int r = l; r < kRows; r += 64)
+                for (int k = 0; k < kClasses; ++k) S.cursor[stream_id(ci, r, k)] += S.loc[r * 16 + k];
+        }
+        LSYNC();
+        sign_pos[ci] += (uint32_t)nsig_tile;
+        nbins += (uint32_t)bins_tile;
+        ord0 += (uint32_t)nb;
+        return 0;
+    }
+
+    // whole segment (lepton_codec.hh:41-100 row schedule, vp8_encoder.cc:239-445); ns: the segment's two-row NSum rings (zeroed)
+    WDEV int run(const ImageDev* image, const SegDev& seg, NSum* ns, Walk5Shared* shared, const SegPlan5* pl, uint8_t* arena_base, uint16_t* bins_base) {
+        img = image; sh = shared; plan = pl; status = 0;
+        arena = (MODE != kCount) ? arena_base + pl->arena_off : nullptr;
+        bins = (MODE == kGather) ? bins_base + pl->bins_off : nullptr;
+        ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0;
+        LANES(l) {
+            sh->r2a[l] = kR2A[l]; sh->a2r[l] = kA2R[l];
+            for (int i = l; i < 2 * kRows * kClasses; i += 64) sh->cursor[i] = 0;
+        }
+        LSYNC();
+        bool top[3] = {true, true, true};
+        SegmentCoder<false> sched;
+        sched.img = image;
+        for (uint32_t idx = 0;; ++idx) {
+            SegmentCoder<false>::RowSpec r = sched.row_spec(idx);
+            if (r.done) break;
+            if (r.luma_y >= seg.y1 && !seg.is_last) break;
+            if (r.skip) continue;
+            if (r.luma_y < seg.y0) continue;
+            comp = r.component; ci = comp ? 1 : 0;
+            const int w = img->width[comp], yb = r.curr_y;
+            const int16_t* row = img->blocks[comp] + (int64_t)yb * w * 64;
+            const bool has_above = !top[comp];
+            const int16_t* arow = has_above ? row - (int64_t)w * 64 : nullptr;
+            NSum* nrow = ns + img->ns_offset[comp] + (yb & 1) * w;
+            const NSum* narow = ns + img->ns_offset[comp] + ((yb & 1) ^ 1) * w;
+            top[comp] = false;
+            int nrow_blocks = img->coded_blocks[comp] - yb * w;   // vp8_encoder.cc:83-154: a row ends where the file was cut
+            nrow_blocks = nrow_blocks < 1 ? 1 : (nrow_blocks > w ? w : nrow_blocks);
+            for (int x0 = 0; x0 < nrow_blocks; x0 += 64) {
+                const int nb = nrow_blocks - x0 < 64 ? nrow_blocks - x0 : 64;
+                load_tile(row, arow, x0, nb, x0 == 0);
+                const int rc = tile(x0, nb, has_above, nrow, narow);
+                if (rc) return rc;
+            }
+        }
+        return 0;
+    }
+};
+
+
+// ---- plan: counts -> arena layout --------------------------------------------------------------------------------------------
+// counts of one segment as the count walk leaves them: [kStreams] units per stream, then sign bytes of the two colour indices,
+// block ordinals, bins (an upper bound through the DC term)
+constexpr int kCountWords = kStreams + 4;
+// one segment's layout (arena_off / bins_off are filled in by the prefix pass over the segments)
+WDEV void plan_segment(const uint32_t* counts, SegPlan5* P) {
+    uint32_t at = 0;
+    for (int i = 0; i < kStreams; ++i) { P->base[i] = at; at += counts[i]; }
+    P->base[kStreams] = at;
+    uint32_t bytes = at * 4;
+    P->sign_cnt[0] = counts[kStreams]; P->sign_cnt[1] = counts[kStreams + 1];
+    P->sign_base[0] = bytes; bytes += P->sign_cnt[0];
+    P->sign_base[1] = bytes; bytes += P->sign_cnt[1];
+    bytes = (bytes + 15u) & ~15u;
+    P->nblocks = counts[kStreams + 2];
+    P->key_base = bytes; bytes += ((P->nblocks * (uint32_t)kKeyRec) + 15u) & ~15u;
+    P->nz_base = bytes; bytes += P->nblocks * (uint32_t)kNzRec;
+    P->en_base = bytes; bytes += P->nblocks * (uint32_t)kEnRec;
+    P->dc_base = bytes; bytes += P->nblocks * (uint32_t)kDcRec;
+    P->arena_bytes = (bytes + 255u) & ~255u;
+    P->bins_cap = (counts[kStreams + 3] + 127u) & ~127u;
+    P->nbins = 0; P->status = 0; P->arena_off = 0; P->bins_off = 0;
+}
+// the count walk's results -> counts[kCountWords] (lane-strided copy of the cursors)
+template <class W>
+WDEV void export_counts(const W& w, const Walk5Shared* sh, uint32_t* counts) {
+    LANES(l) {
+        for (int i = l; i < kStreams; i += 64) counts[i] = sh->cursor[i];
+        if (l == 0) { counts[kStreams] = w.sign_pos[0]; counts[kStreams + 1] = w.sign_pos[1]; counts[kStreams + 2] = w.ord0; counts[kStreams + 3] = w.nbins; }
+    }
+}
+
+}  // namespace lep5

@@ -246,3 +246,68 @@ extern "C" int emu_huffman_decode_image_parallel(const lep_huffdec_image* img, l
     if (sync_blocks) for (int s = 0; s < nsub; ++s) sync_blocks[s] = st[(size_t)s].nblocks;
     return 0;
 }
+
+
+// split-phase encoder (lep_enc5.h): count -> plan -> emit -> fold (every chain) -> gather -> write, one segment, every pass
+// stepped as a 64-lane loop emulation; bins_out (optional): the (probability | bit << 8) list the writer consumed
+#include "../../lepton_amd/csrc/lep_enc5.h"
+extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins,
+                                     uint16_t* bins_out, uint32_t bins_out_cap) {
+    using namespace lep5;
+    ImageDev img;
+    int rc = derive_image(*d, &img, true);
+    if (rc) return rc;
+    std::vector<NSum> ns(img.ns_total);
+    SegDev seg;
+    seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = cap; seg.slot = 0;
+    static Walk5Shared wsh;
+    static FoldShared fsh;
+    std::vector<uint32_t> counts(kCountWords, 0);
+    static SegPlan5 plan;
+    {
+        Walk5<kCount> w;
+        memset(ns.data(), 0, ns.size() * sizeof(NSum));
+        w.run(&img, seg, ns.data(), &wsh, &plan, nullptr, nullptr);
+        export_counts(w, &wsh, counts.data());
+    }
+    plan_segment(counts.data(), &plan);
+    std::vector<uint8_t> arena(plan.arena_bytes + 64, 0xA5);   // poisoned: every byte read must have been written
+    std::vector<uint16_t> binlist(plan.bins_cap + 64, 0xA5A5);
+    {
+        Walk5<kEmit> w;
+        memset(ns.data(), 0, ns.size() * sizeof(NSum));
+        rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), nullptr);
+        if (rc) return rc;
+        if (w.sign_pos[0] != plan.sign_cnt[0] || w.sign_pos[1] != plan.sign_cnt[1] || w.ord0 != plan.nblocks) return 1001;
+        for (int i = 0; i < kStreams; ++i) if (wsh.cursor[i] != plan.base[i + 1] - plan.base[i]) return 1002;
+    }
+    std::vector<uint32_t> thresh(kThreshWords, kBranchInit);
+    for (int ci = 0; ci < 2; ++ci) {
+        for (int row = 0; row < kRows; ++row)
+            for (int k = 0; k < kClasses; ++k) {
+                const int sid = stream_id(ci, row, k);
+                if (plan.base[sid] == plan.base[sid + 1]) continue;
+                if (row < 63) fold_coef_wave(&plan, arena.data(), 0, 1, sid, &fsh);   // (row 63: the threshold chains of this colour index, class = lt)
+                else fold_thresh_wave(&plan, arena.data(), thresh.data(), 0, 1, sid, ci, &fsh);
+            }
+        fold_sign_wave(&plan, arena.data(), 0, 1, ci, &fsh);
+        for (int b = 0; b < 10; ++b) fold_nz_wave(&plan, arena.data(), 0, 1, ci, b, &fsh);
+        for (int v = 0; v < 2; ++v) for (int e = 0; e < 8; ++e) fold_edgenz_wave(&plan, arena.data(), 0, 1, ci, v, e, &fsh);
+    }
+    for (int a = 0; a < 12; ++a) fold_dc_wave(&plan, arena.data(), 0, 1, a, &fsh);
+    {
+        Walk5<kGather> w;
+        memset(ns.data(), 0, ns.size() * sizeof(NSum));
+        rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), binlist.data());
+        if (rc) return rc;
+        if (w.nbins > plan.bins_cap) return 1003;
+        plan.nbins = w.nbins;
+    }
+    if (bins) *bins = plan.nbins;
+    if (bins_out) memcpy(bins_out, binlist.data(), 2 * (size_t)(plan.nbins < bins_out_cap ? plan.nbins : bins_out_cap));
+    uint32_t slen = 0;
+    int32_t status = 0;
+    write_wave(&plan, binlist.data(), &seg, 0, 1, out, &slen, &status);
+    *len = slen;
+    return status == 100 ? LEP_BUFFER_TOO_SMALL : status;
+}

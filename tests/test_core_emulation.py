@@ -1105,3 +1105,28 @@ def test_gpu_scan_encoder_end_states_are_held_against_the_hand_offs(emu):
     def last(e):                        # the last segment's end state is held against nothing
         e[N - 1].last_dc[0] += 5
     assert run(last)[0] == 0
+
+
+def _v5_encode(emu, d, s, cap):
+    buf = C.create_string_buffer(cap)
+    n, nb = C.c_uint32(0), C.c_uint32(0)
+    rc = emu.emu_encode_segment_v5(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, cap, C.byref(n), C.byref(nb), None, 0)
+    return rc, buf.raw[: n.value], nb.value
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_split_phase_encoder_on_cpu_matches_oracle(emu, name):
+    """lep_enc5.h -- count / emit / fold per chain / gather / lane-per-segment writer -- stepped on the CPU: every segment's
+    stream == the oracle's, and the bin list has the oracle's number of bins (minus the start marker and the 32 stop bins)"""
+    jpg, _ = golden(name)
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    total = 0
+    for s, w in zip(segs, want):
+        rc, got, nb = _v5_encode(emu, d, s, len(w) + 4096)
+        assert rc == 0
+        assert got == w
+        total += nb
+    assert total == bins
