@@ -281,6 +281,7 @@ class HipDevice:
         d_len = dmalloc(4 * nseg)
         d_status = dmalloc(4 * nseg)
         names = {}
+        stages = []   # split-phase encoder: per-launch stage times (count + plan, emit, fold, gather, write)
 
         def step():
             rc = L.lep_gpu_encode_device(g, descs, nimg, segs, nseg, d_streams, offs, d_len, d_status, None)
@@ -289,6 +290,10 @@ class HipDevice:
             assert rc == 0, codec.last_error()
             e_ms = L.lep_gpu_last_kernel_ms(g)
             names["encode"] = L.lep_gpu_last_kernel_name(g).decode()
+            sm = (C.c_double * 8)()
+            ns_ = L.lep_gpu_last_stage_ms(g, sm, 8)
+            if ns_:
+                stages.append([sm[i] for i in range(ns_)])
             rc = L.lep_gpu_decode_device(g, dec_descs, nimg, segs, nseg, d_streams, offs, d_len, d_status, None)
             assert rc == 0, (rc, codec.last_error())
             rc = L.lep_gpu_sync(g)
@@ -372,7 +377,8 @@ class HipDevice:
             L.lep_gpu_free(g, a)
         return {"jpeg_bytes": jpeg_bytes, "images": nimg, "segments": nseg, "blocks": nblocks, "stream_bytes": stream_bytes,
                 "elapsed": elapsed, "enc_ms": enc_ms, "dec_ms": dec_ms, "names": names, "parity": parity,
-                "bins_per_image": bins_per_image, "latency": latency}
+                "bins_per_image": bins_per_image, "latency": latency,
+                "encode_stages_ms": [round(sum(x[i] for x in stages[-steps:]) / max(1, len(stages[-steps:])), 3) for i in range(len(stages[0]))] if stages else None}
 
 
 def mixed_corpus(n, seed0=20000, small=(1920, 1080), big=(3840, 2160)):
@@ -531,7 +537,8 @@ def main():
                                         "kernel_source_sha16_of_this_build": kernel_source_sha(), "stale": pmc_stale},
                      "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms": round(dom_s * 1e3, 3),
                      "encode_kernel_ms": round(enc_kernel_s * 1e3, 3), "decode_kernel_ms": round(dec_kernel_s * 1e3, 3),
-                     "kernels": names, "per_kernel": per_kernel, "bound_by": pmc_bound(names.get(dominant, "")),
+                     "kernels": names, "per_kernel": per_kernel,
+                     "encode_stages_ms": dict(zip(("count_plan", "emit", "fold", "gather", "write"), res["encode_stages_ms"])) if res.get("encode_stages_ms") else None, "bound_by": pmc_bound(names.get(dominant, "")),
                      "note": "frac = algorithmic bytes (128 B per block + stream bytes) / kernel time / 8 TB/s; traffic = HBM bytes from the memory-side request counters of the committed PMC passes (profiles/pmc_traffic.json), scaled to this batch -- `traffic_source.stale` says whether those passes were taken from the kernel sources measured here; bound_by = what those passes say limits the kernel (DESIGN.md 4)"},
     }
     if bins_per_image:

@@ -103,6 +103,10 @@ int lep_gpu_decode_device(lep_gpu *g, const lep_image_desc *images, int nimg, co
 int lep_gpu_use_arena(lep_gpu *g, int k);
 int lep_gpu_sync(lep_gpu *g);
 double lep_gpu_last_kernel_ms(lep_gpu *g);
+/* The split-phase encoder (lep_enc5.h) is several kernels: stage times of the most recent encode launch that used it, in
+ * order count + plan, emit, fold, gather, write (HIP events on the launch stream); returns how many were written (0: the
+ * launch was a single-kernel one). */
+int lep_gpu_last_stage_ms(lep_gpu *g, double *ms, int cap);
 const char *lep_gpu_last_kernel_name(lep_gpu *g);   /* which kernel generation / register-budget variant that launch used */   /* HIP-event duration of the most recent encode/decode kernel */
 /* JPEG Huffman re-encode of decoded coefficient frames on the GPU (replaces recode_one_mcu_row / encode_block_seq,
  * src/lepton/recoder.cc:316-412, 245-314, for whole, untruncated sequential scans): one wavefront per thread segment writes

@@ -179,6 +179,7 @@ def lib():
         L.lep_gpu_sync.argtypes = [vp]
         L.lep_gpu_last_kernel_ms.argtypes = [vp]
         L.lep_gpu_last_kernel_ms.restype = C.c_double
+        L.lep_gpu_last_stage_ms.argtypes = [vp, P(C.c_double), C.c_int]
         L.lep_gpu_last_kernel_name.argtypes = [vp]
         L.lep_gpu_last_kernel_name.restype = C.c_char_p
         L.lep_gpu_selftest.argtypes = [vp]
@@ -237,5 +238,5 @@ EXPORTS = [
     "lep_jpeg_check_restores", "lep_batch_debug_poison", "lep_jpeg_plan_handoffs", "lep_file_consumed", "lep_chained_file_follows", "lep_file_open_next",
     "lep_file_recode_plan_progressive", "lep_file_recode_finish_progressive", "lep_gpu_huffman_progressive_encode_device",
     "lep_jpeg_open_gpu_progressive", "lep_jpeg_finish_gpu_progressive", "lep_gpu_huffman_progressive_decode_device",
-    "lep_jpeg_plan_progressive_check",
+    "lep_jpeg_plan_progressive_check", "lep_gpu_last_stage_ms",
 ]

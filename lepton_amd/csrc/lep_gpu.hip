@@ -19,6 +19,7 @@
 #include "lep_core.h"
 #include "lep_enc3.h"
 #include "lep_dec4.h"
+#include "lep_enc5.h"
 #include "lep_huff.h"
 #include "lep_huffdec.h"
 #include "lep_huffdec_par.h"
@@ -147,6 +148,85 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
     bins[seg.slot] = w.nbins;
 }
 
+
+// ---- the split-phase encoder (lep_enc5.h) -------------------------------------------------------------------------------------
+// walk: one wavefront per segment (count / emit / gather share the code); LDS: two transposed coefficient tiles, the tile's
+// entry payloads and ranks, the stream cursors
+template <int MODE>
+__global__ __launch_bounds__(64) void lep_enc5_walk_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs, NSum* ns_all,
+                                                         const uint64_t* __restrict__ ns_off, lep5::SegPlan5* plans, uint8_t* arena, uint16_t* bins,
+                                                         uint32_t* counts) {
+    __shared__ lep5::Walk5Shared sh;
+    const int s = blockIdx.x;
+    const SegDev seg = segs[s];
+    lep5::SegPlan5* P = plans + s;
+    if (MODE == lep5::kGather && P->status) return;
+    lep5::Walk5<MODE> w;
+    const int rc = w.run(images + seg.image, seg, ns_all + ns_off[s], &sh, P, arena, bins);
+    if (MODE == lep5::kCount) lep5::export_counts(w, &sh, counts + (size_t)s * lep5::kCountWords);
+    if (threadIdx.x == 0) {
+        if (MODE == lep5::kEmit) P->status = rc;
+        if (MODE == lep5::kGather) P->nbins = w.nbins;
+    }
+}
+// counts -> per-segment layout (one thread per segment), then the prefix over the segments (one wavefront)
+__global__ void lep_enc5_plan_kernel(const uint32_t* __restrict__ counts, lep5::SegPlan5* plans, int nseg) {
+    const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s < nseg) lep5::plan_segment(counts + (size_t)s * lep5::kCountWords, plans + s);
+}
+__global__ __launch_bounds__(64) void lep_enc5_offsets_kernel(lep5::SegPlan5* plans, int nseg, uint64_t* totals) {
+    uint64_t a = 0, b = 0;
+    for (int s0 = 0; s0 < nseg; s0 += 64) {
+        const int s = s0 + (int)threadIdx.x;
+        const uint32_t ab = s < nseg ? plans[s].arena_bytes : 0u, bc = s < nseg ? plans[s].bins_cap : 0u;
+        int oa, ob;
+        const int va = (int)(ab >> 8), vb = (int)(bc >> 7);   // (both are multiples of 256 / 128: the scan runs on 32-bit values)
+        const int ta = lepwave::wave_excl_scan(&va, &oa), tb = lepwave::wave_excl_scan(&vb, &ob);
+        if (s < nseg) { plans[s].arena_off = a + ((uint64_t)(uint32_t)oa << 8); plans[s].bins_off = b + ((uint64_t)(uint32_t)ob << 7); }
+        a += (uint64_t)(uint32_t)ta << 8; b += (uint64_t)(uint32_t)tb << 7;
+    }
+    if (threadIdx.x == 0) { totals[0] = a; totals[1] = b; }
+}
+__global__ void lep_enc5_fill_kernel(uint4* p, size_t n16, uint32_t v) {
+    const uint4 x = make_uint4(v, v, v, v);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = x;
+}
+// fold, coefficient chains: block = (64 consecutive segments, stream); 36 KB of LDS
+struct Fold5CoefShared { uint32_t inv24[512]; uint32_t slice[lep5::kCoefSlice * 64]; };
+__global__ __launch_bounds__(64) void lep_enc5_fold_coef_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, int nseg, int groups) {
+    __shared__ Fold5CoefShared shc;
+    const int grp = (int)blockIdx.x % groups, job = (int)blockIdx.x / groups;   // job = ci * 630 + row * 10 + k, rows 0..62
+    const int ci = job / 630, row = (job % 630) / 10, k = job % 10;
+    const int sid = lep5::stream_id(ci, row, k), seg = grp * 64 + (int)threadIdx.x;
+    const bool work = seg < nseg && !plans[seg].status && plans[seg].base[sid] != plans[seg].base[sid + 1];
+    if (!__ballot(work)) return;
+    lep5::fold_coef_wave(plans, arena, grp * 64, nseg, sid, reinterpret_cast<lep5::FoldShared*>(&shc));
+}
+// fold, everything else (long dependent chains first): sign, threshold, DC, 7x7 count, edge counts; 52 KB of LDS
+__global__ __launch_bounds__(64) void lep_enc5_fold_misc_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, uint32_t* thresh_models, int nseg, int groups) {
+    __shared__ lep5::FoldShared sh;
+    const int grp = (int)blockIdx.x % groups;
+    int job = (int)blockIdx.x / groups;
+    const int seg0 = grp * 64;
+    if (job < 2) { lep5::fold_sign_wave(plans, arena, seg0, nseg, job, &sh); return; }
+    job -= 2;
+    if (job < 12) { const int ci = job / 6, lt = 2 + job % 6; lep5::fold_thresh_wave(plans, arena, thresh_models, seg0, nseg, lep5::stream_id(ci, 63, lt), ci, &sh); return; }
+    job -= 12;
+    if (job < 12) { lep5::fold_dc_wave(plans, arena, seg0, nseg, job, &sh); return; }
+    job -= 12;
+    if (job < 20) { lep5::fold_nz_wave(plans, arena, seg0, nseg, job / 10, job % 10, &sh); return; }
+    job -= 20;
+    lep5::fold_edgenz_wave(plans, arena, seg0, nseg, job / 16, (job / 8) & 1, job & 7, &sh);   // 32 jobs
+}
+constexpr int kFold5MiscJobs = 2 + 12 + 12 + 20 + 32;
+// write: lane = segment
+__global__ __launch_bounds__(64) void lep_enc5_write_kernel(const lep5::SegPlan5* __restrict__ plans, const uint16_t* __restrict__ bins, const SegDev* __restrict__ segs,
+                                                          int nseg, uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* nbins_out) {
+    const int seg0 = (int)blockIdx.x * 64, seg = seg0 + (int)threadIdx.x;
+    if (seg < nseg) { status[segs[seg].slot] = 0; nbins_out[segs[seg].slot] = plans[seg].nbins; }
+    lep5::write_wave(plans, bins, segs, seg0, nseg, streams, stream_len, status);
+}
+
 // JPEG Huffman re-encode of decoded frames: one wavefront per thread segment (lep_huff.h)
 __global__ __launch_bounds__(64, 8) void lep_huffman_encode_kernel(const lephuff::HuffImage* __restrict__ images,
                                                                    const lephuff::HuffSegment* __restrict__ segs, uint8_t* out,
@@ -226,6 +306,11 @@ struct lep_gpu {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     bool released = false;   // device side already given back (by lep_gpu_destroy or by the exit handler)
+    int enc5_min = 64;       // launches of at least this many segments take the split-phase encoder (lep_enc5.h); LEP_ENC5_MIN (0 = never)
+    hipStream_t stream2 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the last split-phase launch
+    int nstage = 0;
     int enc_waves = 0;       // the same choice for the encoder (LEP_ENC_WAVES = 4 | 8; 2 = the two-wavefronts-per-segment kernel)
     int enc_pair_max = 1280; // launches of up to this many segments take the two-wave encoder: its 128-thread workgroups are resident 6 per
                              // CU (1536 on the chip), one pass; measured (profiles/r02d_latency_sweep.json, 4K images): 1 .. 128 images
@@ -238,6 +323,9 @@ struct lep_gpu {
     // launches may be in flight at once on different streams (lep_gpu_use_arena: the next chunk's coder kernel starts in the
     // wave slots that the long segments of the current one leave free); everything else uses set 0.
     struct Arena {
+        void* d_plans = nullptr; size_t plans_bytes = 0;       // split-phase encoder: SegPlan5[] | counts | totals
+        void* d_entries = nullptr; size_t entries_bytes = 0;   //   the chains' entry streams
+        void* d_binlist = nullptr; size_t binlist_bytes = 0;   //   the segments' bin lists
         void* d_models = nullptr; size_t models_bytes = 0;
         void* d_ns = nullptr; size_t ns_bytes = 0;
         void* d_meta = nullptr; size_t meta_bytes = 0;      // ImageDev[] | SegDev[] | ns_offsets[] | bins[]
@@ -280,6 +368,58 @@ static int ensure(lep_gpu* g, void** p, size_t* have, size_t need) {
 }
 
 #include "lep_derive.h"
+
+
+// The split-phase encoder (lep_enc5.h): count -> plan -> emit -> fold -> gather -> write.  One host synchronisation in the
+// middle: the arena sizes come out of the count pass.  Stage boundaries are recorded as events (lep_gpu_last_stage_ms).
+static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, const uint64_t* d_nsoff, int nseg, uint8_t* d_streams,
+                       uint32_t* d_stream_len, int32_t* d_status, hipStream_t st) {
+    lep_gpu::Arena& A = g->arena[g->cur];
+    if (!g->stream2) {
+        HIPCHK(g, hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
+        HIPCHK(g, hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+        HIPCHK(g, hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
+        for (auto& e : g->ev_stage) HIPCHK(g, hipEventCreate(&e));
+    }
+    const size_t o_counts = ((size_t)nseg * sizeof(lep5::SegPlan5) + 255) & ~(size_t)255,
+                 o_tot = o_counts + (((size_t)nseg * lep5::kCountWords * 4 + 255) & ~(size_t)255);
+    if (int rc = ensure(g, &A.d_plans, &A.plans_bytes, o_tot + 256)) return rc;
+    lep5::SegPlan5* plans = (lep5::SegPlan5*)A.d_plans;
+    uint32_t* counts = (uint32_t*)((char*)A.d_plans + o_counts);
+    uint64_t* d_tot = (uint64_t*)((char*)A.d_plans + o_tot);
+    const int groups = (nseg + 63) / 64;
+    g->nstage = 0;
+    HIPCHK(g, hipEventRecord(g->ev_stage[0], st));
+    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kCount>), dim3(nseg), dim3(64), 0, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)nullptr, (uint16_t*)nullptr, counts);
+    hipLaunchKernelGGL(lep_enc5_plan_kernel, dim3(groups), dim3(64), 0, st, (const uint32_t*)counts, plans, nseg);
+    hipLaunchKernelGGL(lep_enc5_offsets_kernel, dim3(1), dim3(64), 0, st, plans, nseg, d_tot);
+    // the threshold Branches are the only model state in HBM: 2 MB per segment, reset while the count pass is looked at
+    hipLaunchKernelGGL(lep_enc5_fill_kernel, dim3(4096), dim3(256), 0, st, (uint4*)A.d_models, (size_t)nseg * lep5::kThreshWords / 4, kBranchInit);
+    uint64_t tot[2] = {0, 0};
+    HIPCHK(g, hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
+    HIPCHK(g, hipStreamSynchronize(st));
+    if (int rc = ensure(g, &A.d_entries, &A.entries_bytes, (size_t)tot[0] + 256)) return rc;
+    if (int rc = ensure(g, &A.d_binlist, &A.binlist_bytes, (size_t)tot[1] * 2 + 256)) return rc;
+    HIPCHK(g, hipEventRecord(g->ev_stage[1], st));
+    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kEmit>), dim3(nseg), dim3(64), 0, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)nullptr, counts);
+    HIPCHK(g, hipEventRecord(g->ev_stage[2], st));
+    HIPCHK(g, hipEventRecord(g->ev_fork, st));
+    HIPCHK(g, hipStreamWaitEvent(g->stream2, g->ev_fork, 0));
+    hipLaunchKernelGGL(lep_enc5_fold_misc_kernel, dim3((unsigned)groups * kFold5MiscJobs), dim3(64), 0, g->stream2, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries,
+                       (uint32_t*)A.d_models, nseg, groups);
+    hipLaunchKernelGGL(lep_enc5_fold_coef_kernel, dim3((unsigned)groups * 1260u), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups);
+    HIPCHK(g, hipEventRecord(g->ev_join, g->stream2));
+    HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
+    HIPCHK(g, hipEventRecord(g->ev_stage[3], st));
+    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kGather>), dim3(nseg), dim3(64), 0, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)A.d_binlist, counts);
+    HIPCHK(g, hipEventRecord(g->ev_stage[4], st));
+    hipLaunchKernelGGL(lep_enc5_write_kernel, dim3(groups), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (const uint16_t*)A.d_binlist, d_seg, nseg, d_streams, d_stream_len,
+                       d_status, g->d_bins);
+    HIPCHK(g, hipEventRecord(g->ev_stage[5], st));
+    g->nstage = 5;
+    g->last_kernel = "lep_enc5 (count | emit | fold | gather | write)";
+    return 0;
+}
 
 template <bool DEC>
 static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_segment* segs, int nseg, uint8_t* d_streams,
@@ -342,6 +482,7 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     HIPCHK(g, hipStreamSynchronize(st));   // the host vectors above go out of scope
     g->d_bins = (uint32_t*)(meta + o_bins);
     g->h_bins.assign(nseg, 0);
+    g->nstage = 0;
     HIPCHK(g, hipEventRecord(g->ev0, st));
     if (DEC) {
 #ifdef LEP_PROF
@@ -366,7 +507,10 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         // like the decoder: a launch that cannot fill 8 wavefronts per SIMD takes the 4-wave build (128 VGPRs, no spills)
         int waves = g->enc_waves;
         if (!waves) waves = nseg > 4608 ? 8 : (nseg <= g->enc_pair_max ? 2 : 4);
-        if (waves == 2) {   // few segments: two wavefronts per segment (producer / bool coder), half the serial chain
+        if (g->enc5_min > 0 && nseg >= g->enc5_min) {
+            if (int rc = launch_enc5(g, (const ImageDev*)(meta + o_img), (const SegDev*)(meta + o_seg), (const uint64_t*)(meta + o_ns), nseg, d_streams, d_stream_len, d_status, st)) return rc;
+        }
+        else if (waves == 2) {   // few segments: two wavefronts per segment (producer / bool coder), half the serial chain
             g->last_kernel = "lep_encode_v3x2_kernel";
             hipLaunchKernelGGL(lep_encode_v3x2_kernel, dim3(nseg), dim3(128), 0, st, (const ImageDev*)(meta + o_img),
                                (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns),
@@ -407,6 +551,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_DEC_WAVES")) g->dec_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
     if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 0));
     if (const char* e = getenv("LEP_ENC_PAIR_MAX")) g->enc_pair_max = atoi(e);
+    if (const char* e = getenv("LEP_ENC5_MIN")) g->enc5_min = atoi(e);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||
@@ -425,6 +570,12 @@ static void release_device_side(lep_gpu* g) {
     g->released = true;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
+    for (void* p : {g->arena[0].d_plans, g->arena[0].d_entries, g->arena[0].d_binlist, g->arena[1].d_plans, g->arena[1].d_entries, g->arena[1].d_binlist})
+        if (p) (void)hipFree(p);
+    for (auto& e : g->ev_stage) if (e) (void)hipEventDestroy(e);
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
+    if (g->stream2) (void)hipStreamDestroy(g->stream2);
     for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffprog[0], g->d_huffprog[1], g->d_huffprogdec, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
         if (p) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
@@ -620,6 +771,19 @@ double lep_gpu_last_kernel_ms(lep_gpu* g) {
     if (hipEventSynchronize(g->ev1) != hipSuccess) return -1.0;
     if (hipEventElapsedTime(&ms, g->ev0, g->ev1) != hipSuccess) return -1.0;
     return ms;
+}
+
+// stage times of the most recent split-phase encode launch: count + plan, emit, fold, gather, write (ms; -1 when the launch was
+// not one); returns the number of stages
+int lep_gpu_last_stage_ms(lep_gpu* g, double* ms, int cap) {
+    if (!g || g->nstage <= 0) return 0;
+    if (hipEventSynchronize(g->ev_stage[g->nstage]) != hipSuccess) return 0;
+    int n = 0;
+    for (; n < g->nstage && n < cap; ++n) {
+        float t = 0;
+        ms[n] = hipEventElapsedTime(&t, g->ev_stage[n], g->ev_stage[n + 1]) == hipSuccess ? (double)t : -1.0;
+    }
+    return n;
 }
 
 // device self-test of the arithmetic that has no CPU twin (float-reciprocal division in lep3::prob_of); 0 = all exact

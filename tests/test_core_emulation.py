@@ -1130,3 +1130,56 @@ def test_split_phase_encoder_on_cpu_matches_oracle(emu, name):
         assert got == w
         total += nb
     assert total == bins
+
+
+def test_split_phase_encoder_large_coefficients_and_refusals(emu):
+    """lep_enc5.h on blocks full of large coefficients (entries of several units, threshold units, exponent rows to the end) and
+    the refusals in the serial coder's order: the FIRST offence in stream order names the exit code -- an out-of-range interior
+    coefficient (6), a DC that does not survive prediction (6) in a block BEHIND it, an edge whose prior divides by zero (43)"""
+    import numpy as np
+    from lepton_amd import corpus
+
+    img = JpegImage(corpus.synth_jpeg(64, 48, 11, quality=100))
+    d = img.desc
+    rng = np.random.default_rng(5)
+    for c in range(d.ncomp):
+        n = d.nblocks(c) * 64
+        arr = (C.c_int16 * n).from_address(d.blocks[c])
+        vals = rng.integers(-255, 256, n)
+        vals[rng.random(n) < 0.1] = 0
+        big = rng.random(n) < 0.004
+        vals[big] = rng.choice([-2047, 2047, 1024, -1500], int(big.sum()))
+        for i in range(n):
+            arr[i] = int(vals[i])
+        for b in range(d.nblocks(c)):
+            arr[b * 64 + 49] = 0
+    segs = img.plan()
+    want, bins = ob.oracle_encode(d, segs)
+    total = 0
+    for s, w in zip(segs, want):
+        rc, got, nb = _v5_encode(emu, d, s, len(w) + 4096)
+        assert rc == 0 and got == w
+        total += nb
+    assert total == bins
+    # refusals: whatever the oracle answers, the split-phase encoder answers
+    s = segs[0]
+
+    def both():
+        try:
+            ob.oracle_encode(d, [s])
+            o = 0
+        except RuntimeError as e:
+            o = int(str(e).rsplit(" ", 1)[1])
+        return o, _v5_encode(emu, d, s, 1 << 20)[0]
+
+    luma = C.cast(d.blocks[0], C.POINTER(C.c_int16))
+    chroma = C.cast(d.blocks[1], C.POINTER(C.c_int16))
+    save = luma[64 * 3 + 5]
+    luma[64 * 3 + 5] = 4096                       # interior coefficient of luma block 3: bit length 13
+    assert both() == (6, 6)
+    luma[64 * 3 + 5] = save
+    save = chroma[49]
+    chroma[49] = 3000                             # a DC the prediction cannot wrap back (first coded block of the segment)
+    assert both() == (6, 6)
+    chroma[49] = save
+    assert both() == (0, 0)

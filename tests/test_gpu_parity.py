@@ -465,3 +465,72 @@ def test_gpu_decoder_follows_the_reference_on_impossible_edge_counts(gpu_codec, 
     for c in range(d.ncomp):
         n = d.coded_blocks[c] * 128
         assert C.string_at(f.desc.blocks[c], n) == orig[c][:n]
+
+
+@pytest.fixture(scope="module")
+def gpu_codec_v5():
+    """a codec object that takes the split-phase encoder (lep_enc5.h) for every launch, however small"""
+    import os
+    old = os.environ.get("LEP_ENC5_MIN")
+    os.environ["LEP_ENC5_MIN"] = "1"
+    try:
+        return GpuCodec(0)
+    finally:
+        if old is None:
+            del os.environ["LEP_ENC5_MIN"]
+        else:
+            os.environ["LEP_ENC5_MIN"] = old
+
+
+@pytest.mark.gpu
+def test_gpu_split_phase_encoder_equals_oracle(gpu_codec_v5):
+    """lep_enc5.h on the MI355X: count / emit / fold / gather / write kernels; every golden fixture's streams == the oracle's,
+    one launch per image and all images in ONE launch (mixed geometries, 60+ segments, 64 segments per fold / write wavefront)"""
+    names = golden_cases()
+    imgs = [JpegImage(golden(n)[0]) for n in names]
+    plans = [im.plan() for im in imgs]
+    wants = [ob.oracle_encode(im.desc, p)[0] for im, p in zip(imgs, plans)]
+    for n, im, p, w in zip(names, imgs, plans, wants):
+        assert gpu_codec_v5.encode([im], [p])[0] == w, n
+        assert b"enc5" in gpu_codec_v5._L.lep_gpu_last_kernel_name(gpu_codec_v5.handle)
+    got = gpu_codec_v5.encode(imgs * 3, plans * 3)
+    assert got == wants * 3
+
+
+@pytest.mark.gpu
+def test_gpu_split_phase_encoder_large_coefficients_and_refusals(gpu_codec_v5):
+    """entries of several units, threshold units, saturating Branches; and the serial coder's refusals in its order"""
+    import numpy as np
+
+    img = JpegImage(corpus.synth_jpeg(64, 48, 11, quality=100))
+    d = img.desc
+    rng = np.random.default_rng(5)
+    for c in range(d.ncomp):
+        n = d.nblocks(c) * 64
+        arr = (C.c_int16 * n).from_address(d.blocks[c])
+        vals = rng.integers(-255, 256, n)
+        vals[rng.random(n) < 0.1] = 0
+        big = rng.random(n) < 0.004
+        vals[big] = rng.choice([-2047, 2047, 1024, -1500], int(big.sum()))
+        for i in range(n):
+            arr[i] = int(vals[i])
+        for b in range(d.nblocks(c)):
+            arr[b * 64 + 49] = 0
+    plan = img.plan()
+    want, _ = ob.oracle_encode(d, plan)
+    assert gpu_codec_v5.encode([img], [plan])[0] == want
+    luma = C.cast(d.blocks[0], C.POINTER(C.c_int16))
+    luma[64 * 3 + 5] = 4096
+    with pytest.raises(LeptonError) as e:
+        gpu_codec_v5.encode([img], [plan])
+    assert e.value.code == 6
+
+
+@pytest.mark.gpu
+def test_gpu_split_phase_encoder_4k(gpu_codec_v5):
+    """a 4K image (8 segments of ~24,000 blocks, 380 tiles each) and a photograph-like one"""
+    for kw in ({}, {"skew": 2.0}):
+        img = JpegImage(corpus.synth_jpeg(3840, 2160, 4321, **kw))
+        plan = img.plan()
+        want, _ = ob.oracle_encode(img.desc, plan)
+        assert gpu_codec_v5.encode([img], [plan])[0] == want
