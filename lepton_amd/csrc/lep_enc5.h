@@ -74,7 +74,9 @@ struct SegPlan5 {            // one per segment, device memory; written by plan5
     uint32_t nbins;          // bins written by gather (without the start marker and the stop bins)
     uint32_t arena_bytes;
     int32_t status;          // exit code of the emit walk (COEFFICIENT_OUT_OF_RANGE, ...): the later passes skip the segment
-    uint32_t base[kStreams + 1];   // unit streams: index of the first unit (4-byte units, relative to arena_off); [kStreams] = end
+    uint32_t base[kStreams + 1];   // unit streams: index of the first unit (4-byte units, relative to arena_off; a multiple of 4: every
+                                   // stream starts on 16 bytes and is padded to 16, so that the fold lanes move whole dwordx4); [kStreams] = end
+    uint32_t cnt[kStreams];        // units in the stream
 };
 
 // ---- Branch state in LDS: the packed word of lep_core.h (false | true << 8 | probability << 16) ----------------------------
@@ -153,8 +155,18 @@ WDEV void fold_coef_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
             const SegPlan5& P = plans[seg];
             uint32_t* units = reinterpret_cast<uint32_t*>(arena + P.arena_off);
             FoldLane fl{sh->slice + l, sh->inv24};
-            if (!P.status)
-                for (uint32_t i = P.base[sid]; i < P.base[sid + 1]; ++i) units[i] = fold_coef_unit(fl, units[i], 132);
+            const uint32_t n = P.status ? 0u : P.cnt[sid];
+            uint32_t* p = units + P.base[sid];   // 16-byte aligned, padded to whole groups of four
+            U4 nxt = n ? ld4(p) : U4{0, 0, 0, 0};
+            for (uint32_t i = 0; i < n; i += 4) {   // four entries per dwordx4, the next group requested before this one is folded
+                U4 g = nxt;
+                if (i + 4 < n) nxt = ld4(p + i + 4);
+                g.x = fold_coef_unit(fl, g.x, 132);
+                if (i + 1 < n) g.y = fold_coef_unit(fl, g.y, 132);
+                if (i + 2 < n) g.z = fold_coef_unit(fl, g.z, 132);
+                if (i + 3 < n) g.w = fold_coef_unit(fl, g.w, 132);
+                st4(p + i, g);
+            }
         }
     }
 }
@@ -170,7 +182,7 @@ WDEV void fold_thresh_wave(const SegPlan5* plans, uint8_t* arena, uint32_t* thre
             const SegPlan5& P = plans[seg];
             uint32_t* units = reinterpret_cast<uint32_t*>(arena + P.arena_off);
             uint32_t* model = thresh_models + (size_t)seg * kThreshWords;
-            for (uint32_t i = P.base[sid]; i < (P.status ? 0u : P.base[sid + 1]); ++i) {
+            for (uint32_t i = P.base[sid]; i < (P.status ? 0u : P.base[sid] + P.cnt[sid]); ++i) {
                 const uint32_t e = units[i];
                 const int n = (int)(e >> 10) & 15, pcls = (int)(e >> 14) & 255, lt = (int)(e >> 23) & 15, u = (int)(e >> 27) & 7;
                 uint32_t* T = model + (((uint32_t)ci * 256 + pcls) * 8 + lt) * 128;
@@ -201,15 +213,42 @@ WDEV void fold_sign_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
             const SegPlan5& P = plans[seg];
             uint8_t* s = arena + P.arena_off + P.sign_base[ci];
             FoldLane fl{sh->slice + l, sh->inv24};
-            for (uint32_t i = 0; i < (P.status ? 0u : P.sign_cnt[ci]); ++i) {
-                const uint32_t e = s[i];
-                if (e & 0x80u) s[i] = (uint8_t)fl.code((int)(e & 63u), (e >> 6) & 1u);
+            const uint32_t n = P.status ? 0u : P.sign_cnt[ci];
+            uint32_t* p = reinterpret_cast<uint32_t*>(s);   // the stream starts on 16 bytes and is padded to 16
+            U4 nxt = n ? ld4(p) : U4{0, 0, 0, 0};
+            for (uint32_t i = 0; i < n; i += 16) {
+                U4 g = nxt;
+                if (i + 16 < n) nxt = ld4(p + (i >> 2) + 4);
+                uint32_t w[4] = {g.x, g.y, g.z, g.w};
+                for (int q = 0; q < 16 && i + q < n; ++q) {
+                    const uint32_t e = (w[q >> 2] >> (8 * (q & 3))) & 255u;
+                    if (e & 0x80u) {
+                        const uint32_t pr = fl.code((int)(e & 63u), (e >> 6) & 1u);
+                        w[q >> 2] = (w[q >> 2] & ~(255u << (8 * (q & 3)))) | (pr << (8 * (q & 3)));
+                    }
+                }
+                st4(p + (i >> 2), U4{w[0], w[1], w[2], w[3]});
             }
         }
     }
 }
 
-// sparse chains: lane = segment, the wave's key filters the records of the lane's segment
+// sparse chains: lane = segment, the wave's key filters the records of the lane's segment.  The key words are read four at
+// a time (the region starts on 16 bytes and is padded to 16), the next four requested before these are looked at.
+#define LEP5_FOR_KEYS(keys, nblocks, b, kw, ...)                                       \
+    {                                                                                  \
+        const uint32_t nb_ = (nblocks);                                                \
+        U4 nx_ = nb_ ? ld4(keys) : U4{0, 0, 0, 0};                                     \
+        for (uint32_t b0_ = 0; b0_ < nb_; b0_ += 4) {                                  \
+            const U4 g_ = nx_;                                                         \
+            if (b0_ + 4 < nb_) nx_ = ld4((keys) + b0_ + 4);                            \
+            const uint32_t w_[4] = {g_.x, g_.y, g_.z, g_.w};                           \
+            for (int q_ = 0; q_ < 4 && b0_ + q_ < nb_; ++q_) {                         \
+                const uint32_t b = b0_ + (uint32_t)q_, kw = w_[q_];                    \
+                __VA_ARGS__                                                            \
+            }                                                                          \
+        }                                                                              \
+    }
 // number of non-zeros of the 7x7 interior: six bins MSB first through T[level][prefix] (encoder.cc:200-213)
 WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg, int ci, int ctxbin, FoldShared* sh) {
     fold_init(sh, kNzSlice);
@@ -221,8 +260,8 @@ WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
             FoldLane fl{sh->slice + l, sh->inv24};
             const uint32_t key = (uint32_t)ci | ((uint32_t)ctxbin << 1);
-            for (uint32_t b = 0; b < (P.status ? 0u : P.nblocks); ++b) {
-                if ((keys[b] & 31u) != key) continue;
+            LEP5_FOR_KEYS(keys, P.status ? 0u : P.nblocks, b, kw, {
+                if ((kw & 31u) != key) continue;
                 const int nz = (int)rec[2 * b] & 63;
                 uint32_t lo = 0, hi = 0;
                 int so_far = 0;
@@ -234,7 +273,7 @@ WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
                     so_far = (so_far << 1) | (int)bit;
                 }
                 rec[2 * b] = lo; rec[2 * b + 1] = hi;
-            }
+            })
         }
     }
 }
@@ -248,8 +287,7 @@ WDEV void fold_edgenz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int 
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.en_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
             FoldLane fl{sh->slice + l, sh->inv24};
-            for (uint32_t b = 0; b < (P.status ? 0u : P.nblocks); ++b) {
-                const uint32_t kw = keys[b];
+            LEP5_FOR_KEYS(keys, P.status ? 0u : P.nblocks, b, kw, {
                 if ((int)(kw & 1u) != ci || (int)((kw >> (vertical ? 8 : 5)) & 7u) != eob) continue;
                 const uint32_t e = rec[2 * b + vertical];
                 const int nzq = (int)e & 7, ne = (int)(e >> 3) & 7;
@@ -261,7 +299,7 @@ WDEV void fold_edgenz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int 
                     so_far = (so_far << 1) | (int)bit;
                 }
                 rec[2 * b + vertical] = probs;
-            }
+            })
         }
     }
 }
@@ -275,12 +313,12 @@ WDEV void fold_dc_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.dc_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
             FoldLane fl{sh->slice + l, sh->inv24};
-            for (uint32_t b = 0; b < (P.status ? 0u : P.nblocks); ++b) {
-                if ((int)((keys[b] >> 11) & 15u) != a) continue;
+            LEP5_FOR_KEYS(keys, P.status ? 0u : P.nblocks, b, kw, {
+                if ((int)((kw >> 11) & 15u) != a) continue;
                 const uint32_t e0 = rec[6 * b];
                 const int n = coef_units((int)(e0 >> 14) & 15, (int)(e0 >> 10) & 15);
                 for (int u = 0; u < n; ++u) rec[6 * b + u] = fold_coef_unit(fl, e0 | ((uint32_t)u << 27), 17 * 11);
-            }
+            })
         }
     }
 }
@@ -297,12 +335,18 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
             const SegDev& sd = segs[seg];
             if (P.status) status[sd.slot] = P.status;
             else {
-                const uint16_t* b = bins + P.bins_off;
+                const uint32_t* b = reinterpret_cast<const uint32_t*>(bins + P.bins_off);   // 256-byte aligned; room to the next multiple of 128 bins
+                const uint32_t n = P.nbins;
                 BoolCoder<false> bc;
                 bc.init_stream(streams + sd.stream_off, sd.stream_cap);
-                for (uint32_t i = 0; i < P.nbins; ++i) { const uint32_t e = b[i]; bc.put((int)(e >> 8) & 1, e & 255u); }
-                const uint32_t n = bc.finish();
-                stream_len[sd.slot] = n;
+                U4 nxt = n ? ld4(b) : U4{0, 0, 0, 0};
+                for (uint32_t i = 0; i < n; i += 8) {   // eight bins per dwordx4, the next eight requested before these are coded
+                    const U4 g = nxt;
+                    if (i + 8 < n) nxt = ld4(b + (i >> 1) + 4);
+                    const uint32_t w[4] = {g.x, g.y, g.z, g.w};
+                    for (int q = 0; q < 8 && i + q < n; ++q) { const uint32_t e = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu; bc.put((int)(e >> 8) & 1, e & 255u); }
+                }
+                stream_len[sd.slot] = bc.finish();
                 if (bc.overflow) status[sd.slot] = 100;   // LEP_BUFFER_TOO_SMALL
             }
         }
@@ -312,28 +356,38 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
 
 // ---- the walk: count / emit / gather -------------------------------------------------------------------------------------
 // One wavefront per segment; a TILE = up to 64 consecutive coded blocks of one block row; lane = block.  Per tile:
-//   phase 1  lane = block: the block's own numbers (non-zero counts, IDCT, neighbour summary), then DC prediction
-//   phase A  lane = block, row by row in stream order: what every coded coefficient contributes -> P[row][lane]
-//            (the first unit of its entry; 0 = not coded), threshold entries in rows 63..76
-//   phase B  lane = ROW: walks the 64 lanes of its row in block order and gives every entry its rank inside (tile, row, class)
-//            -- private counters, no conflicts, no ballots: RK[row][lane]
-//   phase C  lane = block, rows in stream order again: emit writes the units to stream base + cursor + rank, the sign bytes and
-//            the sparse records; gather reads the probabilities from the same places and appends the block's bins
-//   phase D  the cursors advance by the tile's totals
+//   phase 1  lane = block: the block's own numbers (non-zero counts, where its sign bytes / threshold units / bins start:
+//            wave scans), IDCT + neighbour summary, then the contexts that need the neighbours' summaries (DC prediction)
+//   phase R  row by row in stream order: every lane works out what its coefficient of that row contributes (priors, classes);
+//            the lanes of one (row, class) are ranked in block order with ballots -- that is the entry's place in its stream;
+//            emit writes the units there (and sign bytes, threshold units, the sparse records), gather reads the probabilities
+//            from the same places and appends the block's bins.  count only adds the units up (LDS atomics: no order needed).
 enum { kCount = 0, kEmit = 1, kGather = 2 };
 
 struct Walk5Shared {
     uint32_t cur[32 * 65], abv[32 * 65];   // transposed tiles: dword i (coefficients 2i, 2i + 1 in aligned order) of lane c at [i * 65 + c];
                                            // column 64 = the block left of lane 0 (the previous tile's last one)
-    uint32_t P[kPRows * 65];               // [row * 65 + lane]: conflict-free for lane = block and for lane = row
-    uint16_t RK[kRows * 65];
-    uint16_t TB[8 * 65];                   // threshold units of the lane per class lt (phase A), then where its next one goes (phase C)
-    uint8_t SS[14 * 64];                   // sign Branch slot of the edge coefficients (needs the prior)
+    uint16_t TB[8 * 65];                   // where the lane's next threshold unit of class lt goes (relative to the tile's first)
     uint32_t cursor[2 * kRows * kClasses]; // units already given out, per colour index / row / class
-    uint16_t loc[kRows * 16];              // this tile's units per (row, class)
     NSum ns[65];                           // neighbour summaries of the tile's blocks; [64] = the block left of lane 0
     uint8_t r2a[64], a2r[64];
 };
+
+WDEV int lane_prefix(uint64_t m, int l) {   // set bits of m below lane l
+#if LEP_ON_GPU
+    (void)l;
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#else
+    return __builtin_popcountll(m & ((1ull << l) - 1));
+#endif
+}
+WDEV void lds_add(uint32_t* p, uint32_t v) {
+#if LEP_ON_GPU
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    *p += v;
+#endif
+}
 
 WDEV int tile_get(const uint32_t* T, int a, int col) { return (int16_t)(T[(a >> 1) * 65 + col] >> ((a & 1) * 16)); }
 
@@ -391,13 +445,42 @@ struct Walk5 {
         LANES(l) {
             const int a = l < nb;
             L(act) = a; L(err) = 0; L(errdc) = 0;
-            int n7 = 0, nh = 0, nv = 0, ex = 0, ey = 0;
+            int n7 = 0, nh = 0, nv = 0, ex = 0, ey = 0, lb = 0;
+            for (int t = 0; t < 8; ++t) S.TB[t * 65 + l] = 0;
             if (a) {
-                for (int z = 0; z < 49; ++z)
-                    if (tile_get(S.cur, z, l) != 0) { ++n7; const int coord = S.a2r[z]; ex = ex > (coord & 7) ? ex : (coord & 7); ey = ey > (coord >> 3) ? ey : (coord >> 3); }
-                for (int j = 0; j < 7; ++j) { nh += tile_get(S.cur, 50 + j, l) != 0; nv += tile_get(S.cur, 57 + j, l) != 0; }
+                // bins of the block that do not depend on its neighbours: 6 + 3 + 3 count bins, and per coded coefficient the
+                // exponent bins, the sign and len - 1 residual bins; zeros in front of a region's last non-zero cost one bin
+                int last = -1;
+                for (int z = 0; z < 49; ++z) {
+                    const int v = iabs(tile_get(S.cur, z, l));
+                    if (v) {
+                        ++n7; last = z;
+                        const int coord = S.a2r[z]; ex = ex > (coord & 7) ? ex : (coord & 7); ey = ey > (coord >> 3) ? ey : (coord >> 3);
+                        const int len = bitlen((uint32_t)v), lc = len > 11 ? 11 : len;
+                        lb += (lc < 11 ? lc + 1 : 11) + lc;
+                    }
+                }
+                lb += 12 + (last + 1 - n7);
+                for (int eg = 0; eg < 2; ++eg) {
+                    int lastj = -1, cnt = 0;
+                    for (int j = 0; j < 7; ++j) {
+                        const int v = iabs(tile_get(S.cur, (eg ? 57 : 50) + j, l));
+                        if (!v) continue;
+                        ++cnt; lastj = j;
+                        const int len = bitlen((uint32_t)v), lc = len > 11 ? 11 : len;
+                        lb += (lc < 11 ? lc + 1 : 11) + lc;
+                        const int thr = img->min_thresh[c][eg ? (j + 1) * 8 : j + 1];
+                        if (lc > 1 && lc - 2 >= thr) {   // threshold units of this coefficient (class lt = min(len - thr, 7))
+                            const int lt = imin(lc - thr, 7), un = (lc - 1 - thr + 3) >> 2;
+                            if (MODE == kCount) lds_add(&S.cursor[stream_id(ci, 63, lt)], (uint32_t)un);
+                            else S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + un);
+                        }
+                    }
+                    lb += lastj + 1 - cnt;
+                    if (eg) nv = cnt; else nh = cnt;
+                }
             }
-            L(nz) = n7; L(neh) = nh; L(nev) = nv; L(eobx) = ex; L(eoby) = ey;
+            L(nz) = n7; L(neh) = nh; L(nev) = nv; L(eobx) = ex; L(eoby) = ey; L(lbins) = lb;
             L(nsig) = a ? n7 + nh + nv + 1 : 0;
             if (MODE != kCount && has_above && a) L(nsa) = narow[x0 + l];   // (written when that row was walked)
             else L(nsa) = NSum{};
@@ -460,7 +543,7 @@ struct Walk5 {
         }
         // ---- phase 1c: contexts that need the neighbours' summaries: 7x7 non-zero context, DC prediction (model.hh:463-485, 674-832)
         LANES(l) {
-            int32_t e0 = 0; int sgn = 0, bins_here = 0, ctxbin = 0;
+            int32_t e0 = 0; int sgn = 0, bins_here = 0, ctxbin = 0;   // bins_here: the DC's bins
             if (L(act)) {
                 const bool has_left = x0 + l > 0;
                 const int dc = tile_get(S.cur, 49, l);
@@ -506,50 +589,97 @@ struct Walk5 {
                     e0 = (int32_t)coef_entry((uint32_t)v & ((1u << nres) - 1u), nres, len > 11 ? 11 : len, b17, a, 0);
                     if (len) sgn = 0x80 | (unc2 >= 0 ? (unc2 == 0 ? 3 : 2) : 1) | ((d >= 0) << 6);
                     bins_here = (len < 11 ? len + 1 : 11) + (len ? 1 : 0) + nres;
-                } else bins_here = 22;
-                bins_here += 6 + 3 + 3;
+                } else bins_here = 22;   // count: an upper bound (the DC needs the neighbours)
             }
-            L(dc_e0) = e0; L(dc_sign) = sgn; L(nzctxbin) = ctxbin; L(lbins) = bins_here;
+            L(dc_e0) = e0; L(dc_sign) = sgn; L(nzctxbin) = ctxbin; L(lbins) += bins_here;
         }
 
-        // ---- phase A: rows in stream order -> P, SS ----------------------------------------------------------------------
-        LV(int, left);
-        LANES(l) { L(left) = L(nz); for (int r = l; r < kRows * 16; r += 64) S.loc[r] = 0; for (int t = 0; t < 8; ++t) S.TB[t * 65 + l] = 0; }
-        for (int zz = 0; zz < 49; ++zz) {
-            LANES(l) {
-                uint32_t e = 0;
-                if (L(act) && L(left) > 0) {
-                    const int cf = tile_get(S.cur, zz, l), v = iabs(cf), len = bitlen((uint32_t)v);
-                    int bsr = 0;
-                    if (MODE != kCount) {
-                        const bool has_left = x0 + l > 0;
-                        int prior = 0;
-                        if (has_left && has_above) prior = (uint16_t)((iabs(tile_get(S.cur, zz, (l + 64) % 65)) + iabs(tile_get(S.abv, zz, l))) * 13 + 6 * iabs(tile_get(S.abv, zz, (l + 64) % 65))) >> 5;
-                        else if (has_left) prior = (int16_t)iabs(tile_get(S.cur, zz, (l + 64) % 65));
-                        else if (has_above) prior = (int16_t)iabs(tile_get(S.abv, zz, l));
-                        bsr = bitlen((uint32_t)imin(iabs(prior), 1023));
-                        if (len > 11 && !L(err)) L(err) = 6;
-                    }
-                    const int lc = len > 11 ? 11 : len, nres = lc > 1 ? lc - 1 : 0;
-                    e = coef_entry((uint32_t)v & ((1u << nres) - 1u), nres, lc, bsr, kNzBin[L(left)], 0);
-                    L(lbins) += (lc < 11 ? lc + 1 : 11) + (lc ? 1 : 0) + nres;
-                    if (v) --L(left);
-                }
-                S.P[zz * 65 + l] = e;
+        // ---- where this block's sign bytes, threshold units and bins start: wave scans over the lanes -------------------------
+        LV(int, sbase); LV(int, bbase);
+        const int nsig_tile = lepwave::wave_excl_scan(nsig, sbase);
+        int ttot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (MODE != kCount) {
+            for (int lt = 2; lt < 8; ++lt) {
+                LV(int, tc); LV(int, to);
+                LANES(l) L(tc) = S.TB[lt * 65 + l];
+                ttot[lt] = lepwave::wave_excl_scan(tc, to);
+                LANES(l) S.TB[lt * 65 + l] = (uint16_t)L(to);
             }
         }
-        for (int eg = 0; eg < 2; ++eg) {   // horizontal edge (neighbour = above), then vertical (neighbour = left)
+        int bins_tile = 0;
+        if (MODE == kGather) bins_tile = lepwave::wave_excl_scan(lbins, bbase);
+        else { LANES(l) L(bbase) = 0; }
+        LSYNC();
+
+        // ---- phase R: rows in stream order ---------------------------------------------------------------------------------
+        const uint32_t* base = MODE != kCount ? plan->base : nullptr;
+        uint8_t* signs = MODE != kCount ? arena + plan->sign_base[ci] + sign_pos[ci] : nullptr;
+        uint32_t* U = MODE != kCount ? units() : nullptr;
+        LV(uint32_t, bp);   // gather: next bin of this lane
+        LV(uint32_t, bacc); // gather: the bin at the even position before it, not stored yet
+        LV(int, sp);        // next sign byte of this lane
+        LV(int, left);
+        LANES(l) { L(bp) = nbins + (uint32_t)L(bbase); L(bacc) = kNoBin; L(sp) = L(sbase); L(left) = L(nz); }
+        // the number of non-zeros of the 7x7 interior (and the key word the sparse chains filter on)
+        if (MODE != kCount) {
+            LANES(l) if (L(act)) {
+                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->nz_base) + 2 * (ord0 + l);
+                if (MODE == kEmit) {
+                    rec[0] = (uint32_t)L(nz);
+                    reinterpret_cast<uint32_t*>(arena + plan->key_base)[ord0 + l] =
+                        (uint32_t)ci | ((uint32_t)L(nzctxbin) << 1) | ((uint32_t)L(eobx) << 5) | ((uint32_t)L(eoby) << 8) | ((((uint32_t)L(dc_e0) >> 23) & 15u) << 11);
+                } else {
+                    const uint32_t lo = rec[0], hi = rec[1];
+                    for (int i = 5; i >= 0; --i) {
+                        const int q = 5 - i;
+                        const uint32_t p = q < 4 ? (lo >> (8 * q)) & 255u : (hi >> (8 * (q - 4))) & 255u;
+                        put_bin(L(bp), L(bacc), p | ((((uint32_t)L(nz) >> i) & 1u) << 8));
+                    }
+                }
+            }
+        }
+        for (int row = 0; row < 63; ++row) {
+            const bool edge = row >= 49;
+            const int eg = row >= 56 ? 1 : 0, j = edge ? row - 49 - eg * 7 : 0;
             const bool horizontal = eg == 0;
-            LANES(l) L(left) = horizontal ? L(neh) : L(nev);
-            for (int j = 0; j < 7; ++j) {
-                const int coord = horizontal ? j + 1 : (j + 1) * 8, row = 49 + eg * 7 + j, a_here = (horizontal ? 50 : 57) + j;
+            if (row == 49 || row == 56) {   // an edge starts: its non-zero count (three bins)
                 LANES(l) {
-                    uint32_t e = 0, te = 0; int slot = 0;
-                    if (L(act) && L(left) > 0) {
-                        const int cf = tile_get(S.cur, a_here, l), v = iabs(cf), len = bitlen((uint32_t)v);
-                        const int lc = len > 11 ? 11 : len;
+                    L(left) = horizontal ? L(neh) : L(nev);
+                    if (MODE != kCount && L(act)) {
+                        uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->en_base) + 2 * (ord0 + l) + eg;
+                        const int ne = L(left);
+                        if (MODE == kEmit) rec[0] = (uint32_t)((L(nz) + 3) / 7) | ((uint32_t)ne << 3);
+                        else {
+                            const uint32_t pr = rec[0];
+                            for (int i = 2; i >= 0; --i) put_bin(L(bp), L(bacc), ((pr >> (8 * (2 - i))) & 255u) | ((((uint32_t)ne >> i) & 1u) << 8));
+                        }
+                    }
+                }
+            }
+            // what the lane's coefficient of this row contributes
+            LV(uint32_t, ee); LV(uint32_t, te); LV(int, kk); LV(int, nn); LV(int, cfv); LV(int, slot); LV(int, coded);
+            const int a_here = row < 49 ? row : (horizontal ? 50 : 57) + j;
+            const int coord = !edge ? 0 : (horizontal ? j + 1 : (j + 1) * 8);
+            LANES(l) {
+                uint32_t e = 0, t_e = 0; int k = 0, n = 0, sl = 0, cf = 0;
+                if (L(act) && L(left) > 0) {
+                    cf = tile_get(S.cur, a_here, l);
+                    const int v = iabs(cf), len = bitlen((uint32_t)v), lc = len > 11 ? 11 : len;
+                    int bsr = 0, nres = lc > 1 ? lc - 1 : 0;
+                    if (!edge) {
+                        if (MODE != kCount) {
+                            const bool has_left = x0 + l > 0;
+                            int prior = 0;
+                            if (has_left && has_above) prior = (uint16_t)((iabs(tile_get(S.cur, row, (l + 64) % 65)) + iabs(tile_get(S.abv, row, l))) * 13 + 6 * iabs(tile_get(S.abv, row, (l + 64) % 65))) >> 5;
+                            else if (has_left) prior = (int16_t)iabs(tile_get(S.cur, row, (l + 64) % 65));
+                            else if (has_above) prior = (int16_t)iabs(tile_get(S.abv, row, l));
+                            bsr = bitlen((uint32_t)imin(iabs(prior), 1023));
+                            if (len > 11 && !L(err)) L(err) = 6;
+                        }
+                        k = kNzBin[L(left)];
+                    } else {
                         const int thr = img->min_thresh[c][coord];
-                        int bsr = 0, pcls = 0;
+                        int pcls = 0;
                         if (MODE != kCount) {
                             const bool nbr_ok = horizontal ? has_above : (x0 + l > 0);
                             int32_t prior = 0;
@@ -572,24 +702,85 @@ struct Walk5 {
                             const uint32_t ap = prior < 0 ? 0u - (uint32_t)prior : (uint32_t)prior;
                             bsr = bitlen(ap > 1023 ? 1023 : ap);
                             const int16_t p16 = (int16_t)prior;
-                            slot = (p16 == 0 ? 0 : (p16 > 0 ? 1 : 2)) * 12 + bsr;
+                            sl = (p16 == 0 ? 0 : (p16 > 0 ? 1 : 2)) * 12 + bsr;
                             pcls = imin((int)((ap & 0xffff) >> thr), 255);
                             if (len > 11 && !L(err)) L(err) = 6;
                         }
-                        int nres = lc > 1 ? lc - 1 : 0;
                         if (lc > 1 && lc - 2 >= thr) {
-                            const int n = lc - 1 - thr;
-                            te = thresh_entry(((uint32_t)v >> thr) & ((1u << n) - 1u), n, pcls, imin(lc - thr, 7), 0);
-                            S.TB[imin(lc - thr, 7) * 65 + l] = (uint16_t)(S.TB[imin(lc - thr, 7) * 65 + l] + ((n + 3) >> 2));
+                            const int tn = lc - 1 - thr;
+                            t_e = thresh_entry(((uint32_t)v >> thr) & ((1u << tn) - 1u), tn, pcls, imin(lc - thr, 7), 0);
                             nres = thr;
                         }
-                        e = coef_entry((uint32_t)v & ((1u << nres) - 1u), nres, lc, bsr, L(left), 0);
-                        L(lbins) += (lc < 11 ? lc + 1 : 11) + (lc ? 1 : 0) + (lc > 1 ? lc - 1 : 0);
-                        if (v) --L(left);
+                        k = L(left);
                     }
-                    S.P[row * 65 + l] = e;
-                    S.P[(63 + eg * 7 + j) * 65 + l] = te;
-                    S.SS[(eg * 7 + j) * 64 + l] = (uint8_t)slot;
+                    e = coef_entry((uint32_t)v & ((1u << nres) - 1u), nres, lc, bsr, k, 0);
+                    n = coef_units(lc, nres);
+                    if (v) --L(left);
+                }
+                L(ee) = e; L(te) = t_e; L(kk) = k; L(nn) = n; L(cfv) = cf; L(slot) = sl; L(coded) = e != 0;
+            }
+            if (MODE == kCount) {   // only how many: no order needed
+                LANES(l) if (L(coded)) lds_add(&S.cursor[stream_id(ci, row, L(kk))], (uint32_t)L(nn));
+                continue;
+            }
+            // rank the lanes of every (row, class) in block order: the entry's place in its stream
+            LV(uint32_t, at);
+            uint64_t rem = lepwave::wave_ballot(coded);
+            if (!rem && !edge) { row = 48; continue; }   // no block of the tile has a non-zero left: the interior is done
+            while (rem) {
+                const int k0 = (int)lepwave::wave_read((const uint32_t*)kk, __builtin_ctzll(rem));
+                const int sid = stream_id(ci, row, k0);
+                const uint32_t b0 = base[sid] + S.cursor[sid];
+                LV(int, g); LV(int, g2);
+                LANES(l) { L(g) = L(coded) && L(kk) == k0; L(g2) = L(g) && L(nn) >= 2; }
+                const uint64_t m1 = lepwave::wave_ballot(g), m2 = lepwave::wave_ballot(g2);
+                int total = lepwave::popc64(m1) + lepwave::popc64(m2);
+                LANES(l) if (L(g)) L(at) = b0 + (uint32_t)(lane_prefix(m1, l) + lane_prefix(m2, l));
+                for (int q = 3; m2 && q <= 6; ++q) {   // entries of three and more units: large coefficients
+                    LANES(l) L(g2) = L(g) && L(nn) >= q;
+                    const uint64_t mq = lepwave::wave_ballot(g2);
+                    if (!mq) break;
+                    total += lepwave::popc64(mq);
+                    LANES(l) if (L(g)) L(at) += (uint32_t)lane_prefix(mq, l);
+                }
+                LSYNC();
+                LANES(l) if (l == 0) S.cursor[sid] += (uint32_t)total;
+                LSYNC();
+                rem &= ~m1;
+            }
+            // emit / gather
+            LANES(l) if (L(coded)) {
+                const uint32_t e = L(ee), t_e = L(te);
+                const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres, n = L(nn);
+                uint32_t tat = 0; int tn = 0;
+                if (t_e) {
+                    const int lt = (int)(t_e >> 23) & 15, tsid = stream_id(ci, 63, lt);
+                    tn = (int)(t_e >> 10) & 15;
+                    tat = base[tsid] + S.cursor[tsid] + S.TB[lt * 65 + l];
+                    S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + ((tn + 3) >> 2));
+                }
+                if (MODE == kEmit) {
+                    for (int u = 0; u < n; ++u) U[L(at) + u] = e | ((uint32_t)u << 27);
+                    for (int u = 0; u < (tn + 3) >> 2; ++u) U[tat + u] = t_e | ((uint32_t)u << 27);
+                    if (len) signs[L(sp)++] = (uint8_t)(0x80u | (uint32_t)L(slot) | ((uint32_t)(L(cfv) >= 0) << 6));
+                } else {
+                    uint32_t w = U[L(at)];
+                    for (int q = 0; q < nexp; ++q) {
+                        if (q && !(q & 3)) w = U[L(at) + (q >> 2)];
+                        put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
+                    }
+                    if (len) put_bin(L(bp), L(bacc), (uint32_t)signs[L(sp)++] | ((uint32_t)(L(cfv) >= 0) << 8));
+                    if (tn) {
+                        uint32_t tw = U[tat];
+                        for (int t = 0; t < tn; ++t) {
+                            if (t && !(t & 3)) tw = U[tat + (t >> 2)];
+                            put_bin(L(bp), L(bacc), ((tw >> (8 * (t & 3))) & 255u) | (((t_e >> (tn - 1 - t)) & 1u) << 8));
+                        }
+                    }
+                    for (int q = nexp; q < m; ++q) {
+                        if (!(q & 3) || q == nexp) w = U[L(at) + (q >> 2)];
+                        put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
+                    }
                 }
             }
         }
@@ -598,133 +789,53 @@ struct Walk5 {
             LV(int, bad);
             LANES(l) { if (!L(err)) L(err) = L(errdc); L(bad) = L(err) != 0; }
             const uint64_t bm = lepwave::wave_ballot(bad);
-            if (MODE == kEmit && bm) {
-                const int first = __builtin_ctzll(bm);
-                return (int)(lepwave::wave_read((const uint32_t*)err, first) & 0xffff);
-            }
+            if (MODE == kEmit && bm) return (int)(lepwave::wave_read((const uint32_t*)err, __builtin_ctzll(bm)) & 0xffff);
         }
-
-        // ---- phase B: lane = row: ranks inside (tile, row, class) --------------------------------------------------------
-        LANES(l) {
-            const int r = l;
-            if (r < 63) {
-                for (int b = 0; b < 64; ++b) {
-                    const uint32_t e = S.P[r * 65 + b];
-                    if (!e) continue;
-                    const int k = (int)(e >> 23) & 15;
-                    S.RK[r * 65 + b] = S.loc[r * 16 + k];
-                    S.loc[r * 16 + k] = (uint16_t)(S.loc[r * 16 + k] + coef_units((int)(e >> 14) & 15, (int)(e >> 10) & 15));
-                }
-            }
-        }
-        // the threshold streams (row 63, class lt) are ordered block by block: a lane's units of one class are consecutive
-        for (int lt = 2; lt < 8; ++lt) {
-            LV(int, tc); LV(int, to);
-            LANES(l) L(tc) = S.TB[lt * 65 + l];
-            const int tot = lepwave::wave_excl_scan(tc, to);
-            LANES(l) { S.TB[lt * 65 + l] = (uint16_t)L(to); if (l == 0) S.loc[63 * 16 + lt] = (uint16_t)tot; }
-        }
-        LSYNC();
-
-        // ---- phase C: emit / gather ---------------------------------------------------------------------------------------
-        LV(int, sbase); LV(int, bbase);
-        const int nsig_tile = lepwave::wave_excl_scan(nsig, sbase);
-        const int bins_tile = lepwave::wave_excl_scan(lbins, bbase);
+        // DC
         if (MODE != kCount) {
-            const uint32_t* base = plan->base;
-            uint8_t* signs = arena + plan->sign_base[ci] + sign_pos[ci];
-            uint32_t* U = units();
-            LV(uint32_t, bp);   // gather: next bin of this lane
-            LV(int, sp);        // next sign byte of this lane
-            LANES(l) { L(bp) = nbins + (uint32_t)L(bbase); L(sp) = L(sbase); }
-            // 7x7 non-zero count
-            LANES(l) if (L(act)) {
-                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->nz_base) + 2 * (ord0 + l);
-                if (MODE == kEmit) {
-                    rec[0] = (uint32_t)L(nz);
-                    reinterpret_cast<uint32_t*>(arena + plan->key_base)[ord0 + l] =
-                        (uint32_t)ci | ((uint32_t)L(nzctxbin) << 1) | ((uint32_t)L(eobx) << 5) | ((uint32_t)L(eoby) << 8) | ((((uint32_t)L(dc_e0) >> 23) & 15u) << 11);
-                }
-                else {
-                    const uint32_t lo = rec[0], hi = rec[1];
-                    for (int i = 5; i >= 0; --i) {
-                        const int q = 5 - i;
-                        const uint32_t p = q < 4 ? (lo >> (8 * q)) & 255u : (hi >> (8 * (q - 4))) & 255u;
-                        bins[L(bp)++] = (uint16_t)(p | ((((uint32_t)L(nz) >> i) & 1u) << 8));
-                    }
-                }
-            }
-            for (int row = 0; row < 63; ++row) {
-                const bool edge = row >= 49;
-                const int eg = row >= 56 ? 1 : 0, j = edge ? row - 49 - eg * 7 : 0;
-                if (row == 49 || row == 56) {   // the edge's non-zero count
-                    LANES(l) if (L(act)) {
-                        uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->en_base) + 2 * (ord0 + l) + eg;
-                        const int ne = eg ? L(nev) : L(neh);
-                        if (MODE == kEmit) rec[0] = (uint32_t)((L(nz) + 3) / 7) | ((uint32_t)ne << 3);
-                        else {
-                            const uint32_t pr = rec[0];
-                            for (int i = 2; i >= 0; --i) bins[L(bp)++] = (uint16_t)(((pr >> (8 * (2 - i))) & 255u) | ((((uint32_t)ne >> i) & 1u) << 8));
-                        }
-                    }
-                }
-                LANES(l) {
-                    const uint32_t e = S.P[row * 65 + l];
-                    if (e) {
-                        const int k = (int)(e >> 23) & 15, len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15;
-                        const int nexp = len < 11 ? len + 1 : 11, m = nexp + nres, n = (m + 3) >> 2;
-                        const int sid = stream_id(ci, row, k);
-                        const uint32_t at = base[sid] + S.cursor[sid] + S.RK[row * 65 + l];
-                        const int a_here = row < 49 ? row : (eg ? 57 : 50) + j;
-                        const int cf = tile_get(S.cur, a_here, l);
-                        const uint32_t te = edge ? S.P[(63 + eg * 7 + j) * 65 + l] : 0u;
-                        uint32_t tat = 0; int tn = 0;
-                        if (te) {
-                            const int lt = (int)(te >> 23) & 15, tsid = stream_id(ci, 63, lt);
-                            tn = (int)(te >> 10) & 15;
-                            tat = base[tsid] + S.cursor[tsid] + S.TB[lt * 65 + l];
-                            S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + ((tn + 3) >> 2));
-                        }
-                        const uint32_t sbyte = 0x80u | (uint32_t)(edge ? S.SS[(eg * 7 + j) * 64 + l] : 0) | ((uint32_t)(cf >= 0) << 6);
-                        if (MODE == kEmit) {
-                            for (int u = 0; u < n; ++u) U[at + u] = e | ((uint32_t)u << 27);
-                            for (int u = 0; u < (tn + 3) >> 2; ++u) U[tat + u] = te | ((uint32_t)u << 27);
-                            if (len) signs[L(sp)++] = (uint8_t)sbyte;
-                        } else {
-                            for (int q = 0; q < nexp; ++q) bins[L(bp)++] = (uint16_t)(((U[at + (q >> 2)] >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
-                            if (len) bins[L(bp)++] = (uint16_t)(signs[L(sp)++] | ((uint32_t)(cf >= 0) << 8));
-                            for (int t = 0; t < tn; ++t) bins[L(bp)++] = (uint16_t)(((U[tat + (t >> 2)] >> (8 * (t & 3))) & 255u) | (((te >> (tn - 1 - t)) & 1u) << 8));
-                            for (int q = nexp; q < m; ++q) bins[L(bp)++] = (uint16_t)(((U[at + (q >> 2)] >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
-                        }
-                    }
-                }
-            }
-            // DC
             LANES(l) if (L(act)) {
                 uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->dc_base) + 6 * (ord0 + l);
                 const uint32_t e = (uint32_t)L(dc_e0);
                 const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
                 if (MODE == kEmit) { rec[0] = e; signs[L(sp)++] = (uint8_t)L(dc_sign); }
                 else {
-                    for (int q = 0; q < nexp; ++q) bins[L(bp)++] = (uint16_t)(((rec[q >> 2] >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
+                    uint32_t w = rec[0];
+                    for (int q = 0; q < nexp; ++q) {
+                        if (q && !(q & 3)) w = rec[q >> 2];
+                        put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
+                    }
                     const uint32_t sb = signs[L(sp)++];
-                    if (len) bins[L(bp)++] = (uint16_t)(sb | ((((uint32_t)L(dc_sign) >> 6) & 1u) << 8));
-                    for (int q = nexp; q < m; ++q) bins[L(bp)++] = (uint16_t)(((rec[q >> 2] >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
+                    if (len) put_bin(L(bp), L(bacc), sb | ((((uint32_t)L(dc_sign) >> 6) & 1u) << 8));
+                    for (int q = nexp; q < m; ++q) {
+                        if (!(q & 3) || q == nexp) w = rec[q >> 2];
+                        put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
+                    }
+                    flush_bin(L(bp), L(bacc));
                 }
             }
-        }
-        LSYNC();
-        // ---- phase D: advance the cursors ---------------------------------------------------------------------------------
-        LANES(l) {
-            for (int r = l; r < kRows; r += 64)
-                for (int k = 0; k < kClasses; ++k) S.cursor[stream_id(ci, r, k)] += S.loc[r * 16 + k];
-        }
-        LSYNC();
+            LSYNC();
+            LANES(l) if (l == 0) for (int lt = 2; lt < 8; ++lt) S.cursor[stream_id(ci, 63, lt)] += (uint32_t)ttot[lt];
+            LSYNC();
+        } else bins_tile = lepwave::wave_sum(lbins);
         sign_pos[ci] += (uint32_t)nsig_tile;
         nbins += (uint32_t)bins_tile;
         ord0 += (uint32_t)nb;
         return 0;
     }
+
+    // gather: append one bin (probability | bit << 8) of this lane.  Bins leave in pairs: the one at an even position waits in
+    // `acc` for its neighbour (a lane's bins are consecutive, so both halves of an aligned dword are its own -- except where
+    // its run starts on an odd position or ends on an even one: those go out as 16-bit stores)
+    static constexpr uint32_t kNoBin = 0xffffffffu;
+    WDEV void put_bin(uint32_t& pos, uint32_t& acc, uint32_t v) {
+        if (pos & 1u) {
+            if (acc != kNoBin) *reinterpret_cast<uint32_t*>(bins + pos - 1) = acc | (v << 16);
+            else bins[pos] = (uint16_t)v;
+            acc = kNoBin;
+        } else acc = v;
+        ++pos;
+    }
+    WDEV void flush_bin(uint32_t pos, uint32_t acc) { if ((pos & 1u) && acc != kNoBin) bins[pos - 1] = (uint16_t)acc; }
 
     // whole segment (lepton_codec.hh:41-100 row schedule, vp8_encoder.cc:239-445); ns: the segment's two-row NSum rings (zeroed)
     WDEV int run(const ImageDev* image, const SegDev& seg, NSum* ns, Walk5Shared* shared, const SegPlan5* pl, uint8_t* arena_base, uint16_t* bins_base) {
@@ -775,13 +886,12 @@ constexpr int kCountWords = kStreams + 4;
 // one segment's layout (arena_off / bins_off are filled in by the prefix pass over the segments)
 WDEV void plan_segment(const uint32_t* counts, SegPlan5* P) {
     uint32_t at = 0;
-    for (int i = 0; i < kStreams; ++i) { P->base[i] = at; at += counts[i]; }
+    for (int i = 0; i < kStreams; ++i) { P->base[i] = at; P->cnt[i] = counts[i]; at += (counts[i] + 3u) & ~3u; }
     P->base[kStreams] = at;
     uint32_t bytes = at * 4;
     P->sign_cnt[0] = counts[kStreams]; P->sign_cnt[1] = counts[kStreams + 1];
-    P->sign_base[0] = bytes; bytes += P->sign_cnt[0];
-    P->sign_base[1] = bytes; bytes += P->sign_cnt[1];
-    bytes = (bytes + 15u) & ~15u;
+    P->sign_base[0] = bytes; bytes += (P->sign_cnt[0] + 15u) & ~15u;
+    P->sign_base[1] = bytes; bytes += (P->sign_cnt[1] + 15u) & ~15u;
     P->nblocks = counts[kStreams + 2];
     P->key_base = bytes; bytes += ((P->nblocks * (uint32_t)kKeyRec) + 15u) & ~15u;
     P->nz_base = bytes; bytes += P->nblocks * (uint32_t)kNzRec;

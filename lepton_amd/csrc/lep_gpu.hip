@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void lep_enc5_fold_coef_kernel(const lep5::SegP
     const int grp = (int)blockIdx.x % groups, job = (int)blockIdx.x / groups;   // job = ci * 630 + row * 10 + k, rows 0..62
     const int ci = job / 630, row = (job % 630) / 10, k = job % 10;
     const int sid = lep5::stream_id(ci, row, k), seg = grp * 64 + (int)threadIdx.x;
-    const bool work = seg < nseg && !plans[seg].status && plans[seg].base[sid] != plans[seg].base[sid + 1];
+    const bool work = seg < nseg && !plans[seg].status && plans[seg].cnt[sid] != 0;
     if (!__ballot(work)) return;
     lep5::fold_coef_wave(plans, arena, grp * 64, nseg, sid, reinterpret_cast<lep5::FoldShared*>(&shc));
 }

@@ -279,14 +279,14 @@ extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, in
         rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), nullptr);
         if (rc) return rc;
         if (w.sign_pos[0] != plan.sign_cnt[0] || w.sign_pos[1] != plan.sign_cnt[1] || w.ord0 != plan.nblocks) return 1001;
-        for (int i = 0; i < kStreams; ++i) if (wsh.cursor[i] != plan.base[i + 1] - plan.base[i]) return 1002;
+        for (int i = 0; i < kStreams; ++i) if (wsh.cursor[i] != plan.cnt[i]) return 1002;
     }
     std::vector<uint32_t> thresh(kThreshWords, kBranchInit);
     for (int ci = 0; ci < 2; ++ci) {
         for (int row = 0; row < kRows; ++row)
             for (int k = 0; k < kClasses; ++k) {
                 const int sid = stream_id(ci, row, k);
-                if (plan.base[sid] == plan.base[sid + 1]) continue;
+                if (!plan.cnt[sid]) continue;
                 if (row < 63) fold_coef_wave(&plan, arena.data(), 0, 1, sid, &fsh);   // (row 63: the threshold chains of this colour index, class = lt)
                 else fold_thresh_wave(&plan, arena.data(), thresh.data(), 0, 1, sid, ci, &fsh);
             }
