@@ -323,9 +323,70 @@ WDEV void fold_dc_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
     }
 }
 
-// ---- write: lane = segment bool writer (boolwriter.hh:48-118, boolwriter.cc:17-35) ---------------------------------------
-// bins: probability | bit << 8.  The serial recurrence runs in every lane on its own segment; byte stores go to the lane's own
-// stream (the carry ripple re-reads bytes this lane wrote).
+// ---- write: lane = segment bool writer ------------------------------------------------------------------------------------
+// The bool writer (boolwriter.hh:48-118, boolwriter.cc:17-35) as every lane runs it on its own segment.  Two things differ from
+// the serial form, neither in the bytes: (1) byte output is DEFERRED -- low is 64 bits wide and the whole bytes above the 24 + 7
+// bits the recurrence works on are taken off every four bins (at most 7 bits per bin: 4 bytes), so the per-bin path is the
+// recurrence alone and the output path is wave-uniform control flow; (2) a carry does not ripple back through bytes in memory:
+// the newest byte that is not 0xFF and the 0xFFs behind it are held back (a carry can only reach those), everything in front is
+// final.  Checked against lepdev::BoolCoder<false> on random and adversarial bin sequences (tests/test_core_emulation.py).
+struct BoolEnc5 {
+    uint64_t low;
+    uint32_t range;
+    int count;
+    int cache;          // the newest byte that is not 0xFF and not final yet (-1: none)
+    uint32_t ffn;       // 0xFF bytes behind it, not final either
+    uint8_t* out;
+    uint32_t pos, cap;  // bytes made final (written when below cap)
+    WDEV void init(uint8_t* o, uint32_t c) { out = o; cap = c; pos = 0; low = 0; range = 255; count = -24; cache = -1; ffn = 0; }
+    WDEV void emit(uint32_t b) { if (pos < cap) out[pos] = (uint8_t)b; ++pos; }
+    WDEV void push(uint32_t b) {      // one more byte of the code value, behind the held ones
+        if (b == 0xffu) { ++ffn; return; }
+        if (cache >= 0) emit((uint32_t)cache);
+        for (; ffn; --ffn) emit(0xffu);
+        cache = (int)b;
+    }
+    WDEV void carry() {               // +1 into the held bytes: the 0xFFs wrap to 00, the byte in front of them takes it
+        if (ffn) {
+            if (cache >= 0) emit((uint32_t)cache + 1u);
+            for (; ffn > 1; --ffn) emit(0u);
+            ffn = 0; cache = 0;
+        } else if (cache >= 0) ++cache;
+    }
+    WDEV void bin(uint32_t bit, uint32_t prob) {   // boolwriter.hh:48-118 without the byte output
+        const uint32_t split = 1 + (((range - 1) * prob) >> 8);
+        uint32_t r = split;
+        if (bit) { low += split; r = range - split; }
+        const int shift = __builtin_clz(r) - 24;
+        range = r << shift;
+        low <<= shift;
+        count += shift;
+    }
+    WDEV void flush() {               // every whole byte above the 24 + (count & 7) bits the coder still works on
+        if (count < 0) return;
+        const int nb = (count >> 3) + 1;
+        count -= 8 * nb;
+        const int keep = 32 + count;
+        const uint64_t o = low >> keep;
+        low &= (1ull << keep) - 1;
+        if ((o >> (8 * nb)) & 1u) carry();
+        for (int i = nb - 1; i >= 0; --i) push((uint32_t)(o >> (8 * i)) & 255u);
+    }
+    WDEV uint32_t finish(bool* overflow) {
+        flush();
+        for (int i = 0; i < 32; ++i) { bin(0, 128); if ((i & 3) == 3) flush(); }
+        flush();
+        if (cache >= 0) emit((uint32_t)cache);
+        uint32_t last = cache >= 0 ? (uint32_t)cache : 0u;
+        if (ffn) last = 0xffu;
+        for (; ffn; --ffn) emit(0xffu);
+        *overflow = pos >= cap;
+        if (!*overflow && pos && (last & 0xe0u) == 0xc0u) emit(0u);
+        return pos;
+    }
+};
+
+// bins: probability | bit << 8.
 WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* segs, int seg0, int nseg, uint8_t* streams, uint32_t* stream_len,
                      int32_t* status) {
     LANES(l) {
@@ -337,17 +398,22 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
             else {
                 const uint32_t* b = reinterpret_cast<const uint32_t*>(bins + P.bins_off);   // 256-byte aligned; room to the next multiple of 128 bins
                 const uint32_t n = P.nbins;
-                BoolCoder<false> bc;
-                bc.init_stream(streams + sd.stream_off, sd.stream_cap);
+                BoolEnc5 bc;
+                bc.init(streams + sd.stream_off, sd.stream_cap);
+                bc.bin(0, 128);   // the start marker (vpx_start_encode)
                 U4 nxt = n ? ld4(b) : U4{0, 0, 0, 0};
                 for (uint32_t i = 0; i < n; i += 8) {   // eight bins per dwordx4, the next eight requested before these are coded
                     const U4 g = nxt;
                     if (i + 8 < n) nxt = ld4(b + (i >> 1) + 4);
                     const uint32_t w[4] = {g.x, g.y, g.z, g.w};
-                    for (int q = 0; q < 8 && i + q < n; ++q) { const uint32_t e = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu; bc.put((int)(e >> 8) & 1, e & 255u); }
+                    for (int h = 0; h < 2; ++h) {
+                        for (int q = 4 * h; q < 4 * h + 4 && i + q < n; ++q) { const uint32_t e = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu; bc.bin((e >> 8) & 1u, e & 255u); }
+                        bc.flush();
+                    }
                 }
-                stream_len[sd.slot] = bc.finish();
-                if (bc.overflow) status[sd.slot] = 100;   // LEP_BUFFER_TOO_SMALL
+                bool overflow = false;
+                stream_len[sd.slot] = bc.finish(&overflow);
+                if (overflow) status[sd.slot] = 100;   // LEP_BUFFER_TOO_SMALL
             }
         }
     }
@@ -370,7 +436,6 @@ struct Walk5Shared {
     uint16_t TB[8 * 65];                   // where the lane's next threshold unit of class lt goes (relative to the tile's first)
     uint32_t cursor[2 * kRows * kClasses]; // units already given out, per colour index / row / class
     NSum ns[65];                           // neighbour summaries of the tile's blocks; [64] = the block left of lane 0
-    uint8_t r2a[64], a2r[64];
 };
 
 WDEV int lane_prefix(uint64_t m, int l) {   // set bits of m below lane l
@@ -389,6 +454,8 @@ WDEV void lds_add(uint32_t* p, uint32_t v) {
 #endif
 }
 
+// kNzBin for 0 <= left <= 49 without a memory access
+WDEV int nzbin5(int left) { return left < 16 ? (int)((0x7776666555443210ull >> (4 * left)) & 15) : (left < 21 ? 7 : (left < 32 ? 8 : 9)); }
 WDEV int tile_get(const uint32_t* T, int a, int col) { return (int16_t)(T[(a >> 1) * 65 + col] >> ((a & 1) * 16)); }
 
 template <int MODE>
@@ -455,7 +522,7 @@ struct Walk5 {
                     const int v = iabs(tile_get(S.cur, z, l));
                     if (v) {
                         ++n7; last = z;
-                        const int coord = S.a2r[z]; ex = ex > (coord & 7) ? ex : (coord & 7); ey = ey > (coord >> 3) ? ey : (coord >> 3);
+                        const int coord = kA2R[z]; ex = ex > (coord & 7) ? ex : (coord & 7); ey = ey > (coord >> 3) ? ey : (coord >> 3);
                         const int len = bitlen((uint32_t)v), lc = len > 11 ? 11 : len;
                         lb += (lc < 11 ? lc + 1 : 11) + lc;
                     }
@@ -495,9 +562,10 @@ struct Walk5 {
                 constexpr int w1pw7 = w1 + w7, w1mw7 = w1 - w7, w2pw6 = w2 + w6, w2mw6 = w2 - w6, w3pw5 = w3 + w5, w3mw5 = w3 - w5;
                 int32_t t[64];
                 int16_t pix[64];
+#pragma unroll
                 for (int y = 0; y < 8; ++y) {
                     const int y8 = y * 8;
-#define LEP5_CQ(i) ((int32_t)tile_get(S.cur, S.r2a[i], l) * (int32_t)q[i])
+#define LEP5_CQ(i) ((int32_t)tile_get(S.cur, kR2A[i], l) * (int32_t)q[i])
                     int32_t x0_ = (y == 0 ? 0 : (int32_t)((uint32_t)LEP5_CQ(y8) << 11)) + 128;
                     int32_t x1 = (int32_t)((uint32_t)LEP5_CQ(y8 + 4) << 11);
                     int32_t x2 = LEP5_CQ(y8 + 6), x3 = LEP5_CQ(y8 + 2), x4 = LEP5_CQ(y8 + 1), x5 = LEP5_CQ(y8 + 7), x6 = LEP5_CQ(y8 + 5), x7 = LEP5_CQ(y8 + 3), x8;
@@ -513,6 +581,7 @@ struct Walk5 {
                     t[y8 + 0] = (x7 + x1) >> 8; t[y8 + 1] = (x3 + x2) >> 8; t[y8 + 2] = (x0_ + x4) >> 8; t[y8 + 3] = (x8 + x6) >> 8;
                     t[y8 + 4] = (x8 - x6) >> 8; t[y8 + 5] = (x0_ - x4) >> 8; t[y8 + 6] = (x3 - x2) >> 8; t[y8 + 7] = (x7 - x1) >> 8;
                 }
+#pragma unroll
                 for (int x = 0; x < 8; ++x) {
                     int32_t y0 = (int32_t)((uint32_t)t[x] << 8) + 8192, y1 = (int32_t)((uint32_t)t[32 + x] << 8);
                     int32_t y2 = t[48 + x], y3 = t[16 + x], y4 = t[8 + x], y5 = t[56 + x], y6 = t[40 + x], y7 = t[24 + x], y8;
@@ -554,7 +623,7 @@ struct Walk5 {
                     if (has_left && has_above) nzctx = (na.nz + nl.nz + 2) / 4;
                     else if (has_above) nzctx = (na.nz + 1) / 2;
                     else if (has_left) nzctx = (nl.nz + 1) / 2;
-                    ctxbin = kNzBin[nzctx];
+                    ctxbin = nzbin5(nzctx);
                     int32_t avgmed = 0, unc = 0, unc2 = 0;
                     if (has_left || has_above) {
                         int sum0 = 0, sum1 = 0, mn = 0x7fffffff, mx = -0x7fffffff, n = 0;
@@ -638,21 +707,23 @@ struct Walk5 {
                 }
             }
         }
+        // gather works one row behind: the probabilities of row r are requested when its places are known and turned into bins
+        // while row r + 1 is worked out (a load on the critical path costs more than everything else in the row)
+        LV(uint32_t, p_e); LV(uint32_t, p_te); LV(uint32_t, p_at); LV(uint32_t, p_tat); LV(int, p_cf); LV(uint32_t, p_w0); LV(uint32_t, p_w1); LV(uint32_t, p_tw); LV(uint32_t, p_sg);
+        LV(uint32_t, enw);
+        LANES(l) { L(p_e) = 0; L(enw) = 0; }
         for (int row = 0; row < 63; ++row) {
             const bool edge = row >= 49;
             const int eg = row >= 56 ? 1 : 0, j = edge ? row - 49 - eg * 7 : 0;
             const bool horizontal = eg == 0;
-            if (row == 49 || row == 56) {   // an edge starts: its non-zero count (three bins)
+            const bool edge_start = row == 49 || row == 56;   // an edge starts with its non-zero count (three bins)
+            if (edge_start) {
                 LANES(l) {
                     L(left) = horizontal ? L(neh) : L(nev);
                     if (MODE != kCount && L(act)) {
                         uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->en_base) + 2 * (ord0 + l) + eg;
-                        const int ne = L(left);
-                        if (MODE == kEmit) rec[0] = (uint32_t)((L(nz) + 3) / 7) | ((uint32_t)ne << 3);
-                        else {
-                            const uint32_t pr = rec[0];
-                            for (int i = 2; i >= 0; --i) put_bin(L(bp), L(bacc), ((pr >> (8 * (2 - i))) & 255u) | ((((uint32_t)ne >> i) & 1u) << 8));
-                        }
+                        if (MODE == kEmit) rec[0] = (uint32_t)((L(nz) + 3) / 7) | ((uint32_t)L(left) << 3);
+                        else L(enw) = rec[0];   // (requested here, used behind the previous row's bins)
                     }
                 }
             }
@@ -676,7 +747,7 @@ struct Walk5 {
                             bsr = bitlen((uint32_t)imin(iabs(prior), 1023));
                             if (len > 11 && !L(err)) L(err) = 6;
                         }
-                        k = kNzBin[L(left)];
+                        k = nzbin5(L(left));
                     } else {
                         const int thr = img->min_thresh[c][coord];
                         int pcls = 0;
@@ -690,9 +761,10 @@ struct Walk5 {
                                 const int step = horizontal ? 8 : 1;
                                 if (icos[0] == 0) { if (!L(err)) L(err) = 43; }
                                 else {
-                                    uint32_t acc = (uint32_t)(int32_t)tile_get(NB, S.r2a[coord], ncol) * (uint32_t)icos[0];
+                                    uint32_t acc = (uint32_t)(int32_t)tile_get(NB, kR2A[coord], ncol) * (uint32_t)icos[0];
+#pragma unroll
                                     for (int i = 1; i < 8; ++i) {
-                                        const int32_t xi = tile_get(S.cur, S.r2a[coord + i * step], l), ai = tile_get(NB, S.r2a[coord + i * step], ncol);
+                                        const int32_t xi = tile_get(S.cur, kR2A[coord + i * step], l), ai = tile_get(NB, kR2A[coord + i * step], ncol);
                                         const int32_t term = (i & 1) ? xi + ai : xi - ai;
                                         acc -= (uint32_t)icos[i] * (uint32_t)term;
                                     }
@@ -748,41 +820,43 @@ struct Walk5 {
                 LSYNC();
                 rem &= ~m1;
             }
-            // emit / gather
-            LANES(l) if (L(coded)) {
-                const uint32_t e = L(ee), t_e = L(te);
-                const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres, n = L(nn);
-                uint32_t tat = 0; int tn = 0;
-                if (t_e) {
-                    const int lt = (int)(t_e >> 23) & 15, tsid = stream_id(ci, 63, lt);
-                    tn = (int)(t_e >> 10) & 15;
-                    tat = base[tsid] + S.cursor[tsid] + S.TB[lt * 65 + l];
-                    S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + ((tn + 3) >> 2));
+            // emit: write the units; gather: request this row's probabilities, turn the PREVIOUS row's into bins
+            LANES(l) {
+                uint32_t c_e = 0, c_te = 0, c_at = 0, c_tat = 0, c_w0 = 0, c_w1 = 0, c_tw = 0, c_sg = 0;
+                if (L(coded)) {
+                    const uint32_t e = L(ee), t_e = L(te);
+                    const int len = (int)(e >> 14) & 15, n = L(nn);
+                    uint32_t tat = 0; int tn = 0;
+                    if (t_e) {
+                        const int lt = (int)(t_e >> 23) & 15, tsid = stream_id(ci, 63, lt);
+                        tn = (int)(t_e >> 10) & 15;
+                        tat = base[tsid] + S.cursor[tsid] + S.TB[lt * 65 + l];
+                        S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + ((tn + 3) >> 2));
+                    }
+                    if (MODE == kEmit) {
+                        for (int u = 0; u < n; ++u) U[L(at) + u] = e | ((uint32_t)u << 27);
+                        for (int u = 0; u < (tn + 3) >> 2; ++u) U[tat + u] = t_e | ((uint32_t)u << 27);
+                        if (len) signs[L(sp)++] = (uint8_t)(0x80u | (uint32_t)L(slot) | ((uint32_t)(L(cfv) >= 0) << 6));
+                    } else {
+                        c_e = e; c_te = t_e; c_at = L(at); c_tat = tat;
+                        c_w0 = U[c_at];
+                        if (n > 1) c_w1 = U[c_at + 1];
+                        if (tn) c_tw = U[tat];
+                        if (len) c_sg = signs[L(sp)++];
+                    }
                 }
-                if (MODE == kEmit) {
-                    for (int u = 0; u < n; ++u) U[L(at) + u] = e | ((uint32_t)u << 27);
-                    for (int u = 0; u < (tn + 3) >> 2; ++u) U[tat + u] = t_e | ((uint32_t)u << 27);
-                    if (len) signs[L(sp)++] = (uint8_t)(0x80u | (uint32_t)L(slot) | ((uint32_t)(L(cfv) >= 0) << 6));
-                } else {
-                    uint32_t w = U[L(at)];
-                    for (int q = 0; q < nexp; ++q) {
-                        if (q && !(q & 3)) w = U[L(at) + (q >> 2)];
-                        put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
+                if (MODE == kGather) {
+                    if (L(p_e)) gather_coef(L(bp), L(bacc), U, L(p_e), L(p_te), L(p_at), L(p_tat), L(p_cf), L(p_w0), L(p_w1), L(p_tw), L(p_sg));
+                    if (edge_start && L(act)) {
+                        const uint32_t pr = L(enw), ne = (uint32_t)(horizontal ? L(neh) : L(nev));
+                        for (int i = 2; i >= 0; --i) put_bin(L(bp), L(bacc), ((pr >> (8 * (2 - i))) & 255u) | (((ne >> i) & 1u) << 8));
                     }
-                    if (len) put_bin(L(bp), L(bacc), (uint32_t)signs[L(sp)++] | ((uint32_t)(L(cfv) >= 0) << 8));
-                    if (tn) {
-                        uint32_t tw = U[tat];
-                        for (int t = 0; t < tn; ++t) {
-                            if (t && !(t & 3)) tw = U[tat + (t >> 2)];
-                            put_bin(L(bp), L(bacc), ((tw >> (8 * (t & 3))) & 255u) | (((t_e >> (tn - 1 - t)) & 1u) << 8));
-                        }
-                    }
-                    for (int q = nexp; q < m; ++q) {
-                        if (!(q & 3) || q == nexp) w = U[L(at) + (q >> 2)];
-                        put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
-                    }
+                    L(p_e) = c_e; L(p_te) = c_te; L(p_at) = c_at; L(p_tat) = c_tat; L(p_cf) = L(cfv); L(p_w0) = c_w0; L(p_w1) = c_w1; L(p_tw) = c_tw; L(p_sg) = c_sg;
                 }
             }
+        }
+        if (MODE == kGather) {
+            LANES(l) if (L(p_e)) gather_coef(L(bp), L(bacc), U, L(p_e), L(p_te), L(p_at), L(p_tat), L(p_cf), L(p_w0), L(p_w1), L(p_tw), L(p_sg));
         }
         LSYNC();
         {   // the first error in stream order ends the segment (lane order = block order; inside a block the DC check comes last)
@@ -835,6 +909,26 @@ struct Walk5 {
         } else acc = v;
         ++pos;
     }
+    // the bins of one coefficient in stream order: exponent, sign, threshold bits, the residual bits below the threshold
+    WDEV void gather_coef(uint32_t& pos, uint32_t& acc, const uint32_t* U, uint32_t e, uint32_t t_e, uint32_t at, uint32_t tat, int cf, uint32_t w0,
+                          uint32_t w1, uint32_t tw, uint32_t sg) {
+        const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
+        const int tn = t_e ? (int)(t_e >> 10) & 15 : 0;
+        uint32_t w = w0;
+        for (int q = 0; q < nexp; ++q) {
+            if (q == 4) w = w1; else if (q == 8) w = U[at + 2];
+            put_bin(pos, acc, ((w >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
+        }
+        if (len) put_bin(pos, acc, sg | ((uint32_t)(cf >= 0) << 8));
+        for (int t = 0; t < tn; ++t) {
+            if (t && !(t & 3)) tw = U[tat + (t >> 2)];
+            put_bin(pos, acc, ((tw >> (8 * (t & 3))) & 255u) | (((t_e >> (tn - 1 - t)) & 1u) << 8));
+        }
+        for (int q = nexp; q < m; ++q) {
+            if (q == nexp || !(q & 3)) w = (q >> 2) == 0 ? w0 : ((q >> 2) == 1 ? w1 : U[at + (q >> 2)]);
+            put_bin(pos, acc, ((w >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
+        }
+    }
     WDEV void flush_bin(uint32_t pos, uint32_t acc) { if ((pos & 1u) && acc != kNoBin) bins[pos - 1] = (uint16_t)acc; }
 
     // whole segment (lepton_codec.hh:41-100 row schedule, vp8_encoder.cc:239-445); ns: the segment's two-row NSum rings (zeroed)
@@ -844,7 +938,6 @@ struct Walk5 {
         bins = (MODE == kGather) ? bins_base + pl->bins_off : nullptr;
         ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0;
         LANES(l) {
-            sh->r2a[l] = kR2A[l]; sh->a2r[l] = kA2R[l];
             for (int i = l; i < 2 * kRows * kClasses; i += 64) sh->cursor[i] = 0;
         }
         LSYNC();

@@ -311,3 +311,43 @@ extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, in
     *len = slen;
     return status == 100 ? LEP_BUFFER_TOO_SMALL : status;
 }
+
+
+// lep5::BoolEnc5 (deferred byte output, carry cache) against the serial writer of lep_core.h on random and adversarial bin
+// sequences: uniform, nearly-certain bins coded wrong (long shifts), runs that produce 0xFF bytes and carries into them, tiny
+// output buffers (overflow verdicts).  Returns 0, or 1 + the trial that differed.
+extern "C" int emu_check_bool_writer5(int trials) {
+    uint64_t rs = 88172645463325252ull;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 11); };
+    std::vector<uint8_t> a(1 << 16), b(1 << 16);
+    for (int trial = 0; trial < trials; ++trial) {
+        const int n = (int)(rnd() % 3000), mode = trial % 6;
+        std::vector<uint16_t> bins((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            uint32_t p, bit;
+            if (mode == 0) { p = rnd() % 256; bit = rnd() & 1; }
+            else if (mode == 1) { p = 1 + rnd() % 3; bit = (rnd() % 8) != 0; }
+            else if (mode == 2) { p = 250 + rnd() % 6; bit = (rnd() % 8) == 0; }
+            else if (mode == 3) { p = 128; bit = 1; }
+            else if (mode == 4) { p = rnd() % 256; bit = (rnd() % 256) < p ? 0 : 1; }
+            else { p = (rnd() & 1) ? 255 : 1; bit = rnd() & 1; }
+            bins[(size_t)i] = (uint16_t)(p | (bit << 8));
+        }
+        const uint32_t cap = (trial % 50 == 0) ? rnd() % 200 : 1u << 16;
+        memset(a.data(), 0xAA, a.size()); memset(b.data(), 0xBB, b.size());
+        lepdev::BoolCoder<false> ref;
+        ref.init_stream(a.data(), cap);
+        for (int i = 0; i < n; ++i) ref.put(bins[(size_t)i] >> 8, bins[(size_t)i] & 255);
+        const uint32_t la = ref.finish();
+        lep5::BoolEnc5 e;
+        e.init(b.data(), cap);
+        e.bin(0, 128);
+        int g = 1;
+        for (int i = 0; i < n; ++i) { e.bin(bins[(size_t)i] >> 8, bins[(size_t)i] & 255); if (++g == 4) { e.flush(); g = 0; } }
+        bool ov = false;
+        const uint32_t lb = e.finish(&ov);
+        if (ref.overflow != ov) return 1 + trial;
+        if (!ov && (la != lb || memcmp(a.data(), b.data(), la))) return 1 + trial;
+    }
+    return 0;
+}

@@ -1183,3 +1183,9 @@ def test_split_phase_encoder_large_coefficients_and_refusals(emu):
     assert both() == (6, 6)
     chroma[49] = save
     assert both() == (0, 0)
+
+
+def test_deferred_bool_writer_equals_the_serial_one(emu):
+    """lep5::BoolEnc5 -- the lane-per-segment writer's deferred byte output and carry cache -- writes the bytes of
+    lepdev::BoolCoder<false> (boolwriter.hh:48-118) for 12,000 random and adversarial bin sequences, overflow verdicts included"""
+    assert emu.emu_check_bool_writer5(12000) == 0
