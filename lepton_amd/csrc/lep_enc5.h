@@ -233,22 +233,9 @@ WDEV void fold_sign_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
     }
 }
 
-// sparse chains: lane = segment, the wave's key filters the records of the lane's segment.  The key words are read four at
-// a time (the region starts on 16 bytes and is padded to 16), the next four requested before these are looked at.
-#define LEP5_FOR_KEYS(keys, nblocks, b, kw, ...)                                       \
-    {                                                                                  \
-        const uint32_t nb_ = (nblocks);                                                \
-        U4 nx_ = nb_ ? ld4(keys) : U4{0, 0, 0, 0};                                     \
-        for (uint32_t b0_ = 0; b0_ < nb_; b0_ += 4) {                                  \
-            const U4 g_ = nx_;                                                         \
-            if (b0_ + 4 < nb_) nx_ = ld4((keys) + b0_ + 4);                            \
-            const uint32_t w_[4] = {g_.x, g_.y, g_.z, g_.w};                           \
-            for (int q_ = 0; q_ < 4 && b0_ + q_ < nb_; ++q_) {                         \
-                const uint32_t b = b0_ + (uint32_t)q_, kw = w_[q_];                    \
-                __VA_ARGS__                                                            \
-            }                                                                          \
-        }                                                                              \
-    }
+// sparse chains: lane = segment, the wave's key filters the records of the lane's segment.  Key words and records are read a
+// group of four blocks at a time (the regions start on 16 bytes and are padded), the next group requested before this one is
+// looked at: a record fetched only once its key has matched would put a trip to HBM on every match.
 // number of non-zeros of the 7x7 interior: six bins MSB first through T[level][prefix] (encoder.cc:200-213)
 WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg, int ci, int ctxbin, FoldShared* sh) {
     fold_init(sh, kNzSlice);
@@ -259,21 +246,27 @@ WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.nz_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
             FoldLane fl{sh->slice + l, sh->inv24};
-            const uint32_t key = (uint32_t)ci | ((uint32_t)ctxbin << 1);
-            LEP5_FOR_KEYS(keys, P.status ? 0u : P.nblocks, b, kw, {
-                if ((kw & 31u) != key) continue;
-                const int nz = (int)rec[2 * b] & 63;
-                uint32_t lo = 0, hi = 0;
-                int so_far = 0;
-                for (int i = 5; i >= 0; --i) {
-                    const uint32_t bit = (uint32_t)(nz >> i) & 1u;
-                    const uint32_t p = fl.code(i * 32 + so_far, bit);
-                    const int q = 5 - i;
-                    if (q < 4) lo |= p << (8 * q); else hi |= p << (8 * (q - 4));
-                    so_far = (so_far << 1) | (int)bit;
+            const uint32_t key = (uint32_t)ci | ((uint32_t)ctxbin << 1), nb = P.status ? 0u : P.nblocks;
+            U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0}, nr0 = nb ? ld4(rec) : U4{0, 0, 0, 0}, nr1 = nb ? ld4(rec + 4) : U4{0, 0, 0, 0};
+            for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
+                const U4 k4 = nk, r0 = nr0, r1 = nr1;
+                if (b0 + 4 < nb) { nk = ld4(keys + b0 + 4); nr0 = ld4(rec + 2 * (b0 + 4)); nr1 = ld4(rec + 2 * (b0 + 4) + 4); }
+                const uint32_t kw[4] = {k4.x, k4.y, k4.z, k4.w}, nzv[4] = {r0.x, r0.z, r1.x, r1.z};
+                for (int q = 0; q < 4 && b0 + q < nb; ++q) {
+                    if ((kw[q] & 31u) != key) continue;
+                    const int nz = (int)nzv[q] & 63;
+                    uint32_t lo = 0, hi = 0;
+                    int so_far = 0;
+                    for (int i = 5; i >= 0; --i) {
+                        const uint32_t bit = (uint32_t)(nz >> i) & 1u;
+                        const uint32_t p = fl.code(i * 32 + so_far, bit);
+                        const int t = 5 - i;
+                        if (t < 4) lo |= p << (8 * t); else hi |= p << (8 * (t - 4));
+                        so_far = (so_far << 1) | (int)bit;
+                    }
+                    rec[2 * (b0 + q)] = lo; rec[2 * (b0 + q) + 1] = hi;
                 }
-                rec[2 * b] = lo; rec[2 * b + 1] = hi;
-            })
+            }
         }
     }
 }
@@ -287,19 +280,26 @@ WDEV void fold_edgenz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int 
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.en_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
             FoldLane fl{sh->slice + l, sh->inv24};
-            LEP5_FOR_KEYS(keys, P.status ? 0u : P.nblocks, b, kw, {
-                if ((int)(kw & 1u) != ci || (int)((kw >> (vertical ? 8 : 5)) & 7u) != eob) continue;
-                const uint32_t e = rec[2 * b + vertical];
-                const int nzq = (int)e & 7, ne = (int)(e >> 3) & 7;
-                uint32_t probs = 0;
-                int so_far = 0;
-                for (int i = 2; i >= 0; --i) {
-                    const uint32_t bit = (uint32_t)(ne >> i) & 1u;
-                    probs |= fl.code(nzq * 12 + i * 4 + so_far, bit) << (8 * (2 - i));
-                    so_far = (so_far << 1) | (int)bit;
+            const uint32_t nb = P.status ? 0u : P.nblocks;
+            U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0}, nr0 = nb ? ld4(rec) : U4{0, 0, 0, 0}, nr1 = nb ? ld4(rec + 4) : U4{0, 0, 0, 0};
+            for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
+                const U4 k4 = nk, r0 = nr0, r1 = nr1;
+                if (b0 + 4 < nb) { nk = ld4(keys + b0 + 4); nr0 = ld4(rec + 2 * (b0 + 4)); nr1 = ld4(rec + 2 * (b0 + 4) + 4); }
+                const uint32_t kw[4] = {k4.x, k4.y, k4.z, k4.w};
+                const uint32_t ev[4] = {vertical ? r0.y : r0.x, vertical ? r0.w : r0.z, vertical ? r1.y : r1.x, vertical ? r1.w : r1.z};
+                for (int q = 0; q < 4 && b0 + q < nb; ++q) {
+                    if ((int)(kw[q] & 1u) != ci || (int)((kw[q] >> (vertical ? 8 : 5)) & 7u) != eob) continue;
+                    const int nzq = (int)ev[q] & 7, ne = (int)(ev[q] >> 3) & 7;
+                    uint32_t probs = 0;
+                    int so_far = 0;
+                    for (int i = 2; i >= 0; --i) {
+                        const uint32_t bit = (uint32_t)(ne >> i) & 1u;
+                        probs |= fl.code(nzq * 12 + i * 4 + so_far, bit) << (8 * (2 - i));
+                        so_far = (so_far << 1) | (int)bit;
+                    }
+                    rec[2 * (b0 + q) + vertical] = probs;
                 }
-                rec[2 * b + vertical] = probs;
-            })
+            }
         }
     }
 }
@@ -313,12 +313,27 @@ WDEV void fold_dc_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.dc_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
             FoldLane fl{sh->slice + l, sh->inv24};
-            LEP5_FOR_KEYS(keys, P.status ? 0u : P.nblocks, b, kw, {
-                if ((int)((kw >> 11) & 15u) != a) continue;
-                const uint32_t e0 = rec[6 * b];
-                const int n = coef_units((int)(e0 >> 14) & 15, (int)(e0 >> 10) & 15);
-                for (int u = 0; u < n; ++u) rec[6 * b + u] = fold_coef_unit(fl, e0 | ((uint32_t)u << 27), 17 * 11);
-            })
+            const uint32_t nb = P.status ? 0u : P.nblocks;
+            U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0};
+            uint32_t ne0 = nb ? rec[0] : 0u, ne1 = nb > 1 ? rec[6] : 0u, ne2 = nb > 2 ? rec[12] : 0u, ne3 = nb > 3 ? rec[18] : 0u;
+            for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
+                const U4 k4 = nk;
+                const uint32_t kw[4] = {k4.x, k4.y, k4.z, k4.w}, ev[4] = {ne0, ne1, ne2, ne3};
+                if (b0 + 4 < nb) {
+                    nk = ld4(keys + b0 + 4);
+                    const uint32_t* r = rec + 6 * (b0 + 4);
+                    ne0 = r[0];
+                    if (b0 + 5 < nb) ne1 = r[6];
+                    if (b0 + 6 < nb) ne2 = r[12];
+                    if (b0 + 7 < nb) ne3 = r[18];
+                }
+                for (int q = 0; q < 4 && b0 + q < nb; ++q) {
+                    if ((int)((kw[q] >> 11) & 15u) != a) continue;
+                    const uint32_t e0 = ev[q];
+                    const int n = coef_units((int)(e0 >> 14) & 15, (int)(e0 >> 10) & 15);
+                    for (int u = 0; u < n; ++u) rec[6 * (b0 + q) + u] = fold_coef_unit(fl, e0 | ((uint32_t)u << 27), 17 * 11);
+                }
+            }
         }
     }
 }
@@ -327,61 +342,61 @@ WDEV void fold_dc_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
 // The bool writer (boolwriter.hh:48-118, boolwriter.cc:17-35) as every lane runs it on its own segment.  Two things differ from
 // the serial form, neither in the bytes: (1) byte output is DEFERRED -- low is 64 bits wide and the whole bytes above the 24 + 7
 // bits the recurrence works on are taken off every four bins (at most 7 bits per bin: 4 bytes), so the per-bin path is the
-// recurrence alone and the output path is wave-uniform control flow; (2) a carry does not ripple back through bytes in memory:
-// the newest byte that is not 0xFF and the 0xFFs behind it are held back (a carry can only reach those), everything in front is
-// final.  Checked against lepdev::BoolCoder<false> on random and adversarial bin sequences (tests/test_core_emulation.py).
+// recurrence alone and the output path is straight-line code in wave-uniform control flow; (2) bytes go to memory four at a time
+// from a staging register, and a carry is the top bit of the number added to it -- only one that leaves the staged bytes (all of
+// them 0xFF) ripples back through memory like the serial writer's.  Checked against lepdev::BoolCoder<false> on random and
+// adversarial bin sequences (tests/test_core_emulation.py).
 struct BoolEnc5 {
     uint64_t low;
     uint32_t range;
     int count;
-    int cache;          // the newest byte that is not 0xFF and not final yet (-1: none)
-    uint32_t ffn;       // 0xFF bytes behind it, not final either
+    uint64_t stage;     // bytes of the code value that are not in memory yet, newest in the low byte
+    int nst;            // how many (0..3 between flushes)
     uint8_t* out;
-    uint32_t pos, cap;  // bytes made final (written when below cap)
-    WDEV void init(uint8_t* o, uint32_t c) { out = o; cap = c; pos = 0; low = 0; range = 255; count = -24; cache = -1; ffn = 0; }
-    WDEV void emit(uint32_t b) { if (pos < cap) out[pos] = (uint8_t)b; ++pos; }
-    WDEV void push(uint32_t b) {      // one more byte of the code value, behind the held ones
-        if (b == 0xffu) { ++ffn; return; }
-        if (cache >= 0) emit((uint32_t)cache);
-        for (; ffn; --ffn) emit(0xffu);
-        cache = (int)b;
-    }
-    WDEV void carry() {               // +1 into the held bytes: the 0xFFs wrap to 00, the byte in front of them takes it
-        if (ffn) {
-            if (cache >= 0) emit((uint32_t)cache + 1u);
-            for (; ffn > 1; --ffn) emit(0u);
-            ffn = 0; cache = 0;
-        } else if (cache >= 0) ++cache;
-    }
+    uint32_t pos, cap;  // bytes handed to memory (written when below cap)
+    WDEV void init(uint8_t* o, uint32_t c) { out = o; cap = c; pos = 0; low = 0; range = 255; count = -24; stage = 0; nst = 0; }
     WDEV void bin(uint32_t bit, uint32_t prob) {   // boolwriter.hh:48-118 without the byte output
         const uint32_t split = 1 + (((range - 1) * prob) >> 8);
-        uint32_t r = split;
-        if (bit) { low += split; r = range - split; }
+        const uint32_t m = 0u - bit;
+        low += split & m;
+        const uint32_t r = split + ((range - 2 * split) & m);
         const int shift = __builtin_clz(r) - 24;
         range = r << shift;
         low <<= shift;
         count += shift;
     }
-    WDEV void flush() {               // every whole byte above the 24 + (count & 7) bits the coder still works on
-        if (count < 0) return;
-        const int nb = (count >> 3) + 1;
+    // a carry out of the staged bytes: back through the 0xFF bytes in memory (the serial writer's ripple; rare)
+    WDEV void ripple() {
+        uint32_t x = pos;
+        while (x > 0 && (x > cap || out[x - 1] == 0xffu)) { if (x <= cap) out[x - 1] = 0; --x; }
+        if (x > 0) out[x - 1] = (uint8_t)(out[x - 1] + 1);
+    }
+    // every whole byte above the 24 + (count & 7) bits the recurrence still works on joins the staged ones -- a carry is just
+    // the top bit of what is added -- and four staged bytes at a time go to memory
+    WDEV void flush() {
+        const int nb = count >= 0 ? (count >> 3) + 1 : 0;
         count -= 8 * nb;
         const int keep = 32 + count;
         const uint64_t o = low >> keep;
         low &= (1ull << keep) - 1;
-        if ((o >> (8 * nb)) & 1u) carry();
-        for (int i = nb - 1; i >= 0; --i) push((uint32_t)(o >> (8 * i)) & 255u);
+        stage = (stage << (8 * nb)) + o;
+        nst += nb;
+        if ((stage >> (8 * nst)) & 1u) { stage &= (1ull << (8 * nst)) - 1; ripple(); }
+        if (nst >= 4) {
+            const uint32_t v = (uint32_t)(stage >> (8 * (nst - 4)));
+            if (pos + 4 <= cap) { const uint32_t be = __builtin_bswap32(v); __builtin_memcpy(out + pos, &be, 4); }
+            else for (int i = 0; i < 4; ++i) if (pos + (uint32_t)i < cap) out[pos + i] = (uint8_t)(v >> (24 - 8 * i));
+            pos += 4; nst -= 4;
+            stage &= (1ull << (8 * nst)) - 1;
+        }
     }
     WDEV uint32_t finish(bool* overflow) {
         flush();
         for (int i = 0; i < 32; ++i) { bin(0, 128); if ((i & 3) == 3) flush(); }
         flush();
-        if (cache >= 0) emit((uint32_t)cache);
-        uint32_t last = cache >= 0 ? (uint32_t)cache : 0u;
-        if (ffn) last = 0xffu;
-        for (; ffn; --ffn) emit(0xffu);
+        for (; nst; --nst) { if (pos < cap) out[pos] = (uint8_t)(stage >> (8 * (nst - 1))); ++pos; }
         *overflow = pos >= cap;
-        if (!*overflow && pos && (last & 0xe0u) == 0xc0u) emit(0u);
+        if (!*overflow && pos && (out[pos - 1] & 0xe0u) == 0xc0u) { out[pos] = 0; ++pos; }
         return pos;
     }
 };
@@ -436,6 +451,9 @@ struct Walk5Shared {
     uint16_t TB[8 * 65];                   // where the lane's next threshold unit of class lt goes (relative to the tile's first)
     uint32_t cursor[2 * kRows * kClasses]; // units already given out, per colour index / row / class
     NSum ns[65];                           // neighbour summaries of the tile's blocks; [64] = the block left of lane 0
+    int32_t icos_x[64], icos_y[64];        // the component's quantisation-derived tables (a load from the image descriptor on the
+    uint16_t q[64];                        // critical path costs a trip to HBM: they are staged when the component changes)
+    uint8_t thr[64];
 };
 
 WDEV int lane_prefix(uint64_t m, int l) {   // set bits of m below lane l
@@ -473,9 +491,35 @@ struct Walk5 {
 
     WDEV uint32_t* units() const { return reinterpret_cast<uint32_t*>(arena); }
 
-    // load the tile [x0, x0 + nb) of row `row` (and of the row above) into the transposed arrays
-    WDEV void load_tile(const int16_t* row, const int16_t* arow, int x0, int nb, bool first_of_row) {
+    // A tile's coefficients travel global memory -> registers -> LDS: the loads of the NEXT tile are issued before the current one
+    // is worked on (fetch_tile), and written to the transposed arrays when its turn comes (store_tile).
+    struct TileDesc {
+        int comp, x0, nb, yb;
+        bool has_above;
+        const int16_t *row, *arow;
+        NSum* nrow;
+        const NSum* narow;
+    };
+    struct TileRegs { uint32_t c[32], a[32]; };
+    WDEV void fetch_tile(const TileDesc& t, TileRegs* regs) const {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(t.row + (int64_t)t.x0 * 64);
+        const uint32_t* asrc = t.arow ? reinterpret_cast<const uint32_t*>(t.arow + (int64_t)t.x0 * 64) : nullptr;
+        LANES(l) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const int d = k * 64 + l, b = d >> 5;
+                regs[LEP_LI(l)].c[k] = b < t.nb ? src[d] : 0u;
+                regs[LEP_LI(l)].a[k] = (asrc && b < t.nb && MODE != kCount) ? asrc[d] : 0u;
+            }
+        }
+    }
+    WDEV void store_tile(const TileDesc& t, const TileRegs* regs) {
         Walk5Shared& S = *sh;
+        const bool first_of_row = t.x0 == 0;
+        if (t.comp != comp) {   // the component's tables
+            comp = t.comp; ci = comp ? 1 : 0;
+            LANES(l) { S.q[l] = img->q[comp][l]; S.icos_x[l] = img->icos_x[comp][l]; S.icos_y[l] = img->icos_y[comp][l]; S.thr[l] = img->min_thresh[comp][l]; }
+        }
         LANES(l) {   // keep the last column of the previous tile as "left of lane 0"
             if (l < 32) {
                 S.cur[l * 65 + 64] = first_of_row ? 0u : S.cur[l * 65 + 63];
@@ -484,13 +528,12 @@ struct Walk5 {
             if (l == 0) { if (first_of_row) S.ns[64] = NSum{}; else S.ns[64] = S.ns[63]; }
         }
         LSYNC();
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(row + (int64_t)x0 * 64);
-        const uint32_t* asrc = arow ? reinterpret_cast<const uint32_t*>(arow + (int64_t)x0 * 64) : nullptr;
         LANES(l) {
+#pragma unroll
             for (int k = 0; k < 32; ++k) {
                 const int d = k * 64 + l, b = d >> 5, i = d & 31;
-                S.cur[i * 65 + b] = b < nb ? src[d] : 0u;
-                S.abv[i * 65 + b] = (asrc && b < nb) ? asrc[d] : 0u;
+                S.cur[i * 65 + b] = regs[LEP_LI(l)].c[k];
+                S.abv[i * 65 + b] = regs[LEP_LI(l)].a[k];
             }
         }
         LSYNC();
@@ -536,7 +579,7 @@ struct Walk5 {
                         ++cnt; lastj = j;
                         const int len = bitlen((uint32_t)v), lc = len > 11 ? 11 : len;
                         lb += (lc < 11 ? lc + 1 : 11) + lc;
-                        const int thr = img->min_thresh[c][eg ? (j + 1) * 8 : j + 1];
+                        const int thr = S.thr[eg ? (j + 1) * 8 : j + 1];
                         if (lc > 1 && lc - 2 >= thr) {   // threshold units of this coefficient (class lt = min(len - thr, 7))
                             const int lt = imin(lc - thr, 7), un = (lc - 1 - thr + 3) >> 2;
                             if (MODE == kCount) lds_add(&S.cursor[stream_id(ci, 63, lt)], (uint32_t)un);
@@ -557,7 +600,7 @@ struct Walk5 {
         LV(Px, px);
         if (MODE != kCount) {
             LANES(l) if (L(act)) {
-                const uint16_t* q = img->q[c];
+                const uint16_t* q = S.q;
                 constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
                 constexpr int w1pw7 = w1 + w7, w1mw7 = w1 - w7, w2pw6 = w2 + w6, w2mw6 = w2 - w6, w3pw5 = w3 + w5, w3mw5 = w3 - w5;
                 int32_t t[64];
@@ -644,7 +687,7 @@ struct Walk5 {
                         sum0 -= avgmed; sum1 -= avgmed;
                         unc2 = (iabs(sum0) < iabs(sum1) ? sum0 : sum1) >> 3;
                     }
-                    const int pred = (avgmed / (int)img->q[c][0] + 4) >> 3;
+                    const int pred = (avgmed / (int)S.q[0] + 4) >> 3;
                     const int a = imin(bitlen((uint32_t)iabs(unc) & 0xffff), 11), b17 = imin(bitlen((uint32_t)iabs(unc2) & 0xffff), 16);
                     int d = dc - pred;
                     if (d < -1024) d += 2049;
@@ -681,7 +724,6 @@ struct Walk5 {
         LSYNC();
 
         // ---- phase R: rows in stream order ---------------------------------------------------------------------------------
-        const uint32_t* base = MODE != kCount ? plan->base : nullptr;
         uint8_t* signs = MODE != kCount ? arena + plan->sign_base[ci] + sign_pos[ci] : nullptr;
         uint32_t* U = MODE != kCount ? units() : nullptr;
         LV(uint32_t, bp);   // gather: next bin of this lane
@@ -749,7 +791,7 @@ struct Walk5 {
                         }
                         k = nzbin5(L(left));
                     } else {
-                        const int thr = img->min_thresh[c][coord];
+                        const int thr = S.thr[coord];
                         int pcls = 0;
                         if (MODE != kCount) {
                             const bool nbr_ok = horizontal ? has_above : (x0 + l > 0);
@@ -757,7 +799,7 @@ struct Walk5 {
                             if (nbr_ok) {
                                 const uint32_t* NB = horizontal ? S.abv : S.cur;
                                 const int ncol = horizontal ? l : (l + 64) % 65;
-                                const int32_t* icos = horizontal ? img->icos_x[c] + coord * 8 : img->icos_y[c] + coord;
+                                const int32_t* icos = horizontal ? S.icos_x + coord * 8 : S.icos_y + coord;
                                 const int step = horizontal ? 8 : 1;
                                 if (icos[0] == 0) { if (!L(err)) L(err) = 43; }
                                 else {
@@ -802,7 +844,7 @@ struct Walk5 {
             while (rem) {
                 const int k0 = (int)lepwave::wave_read((const uint32_t*)kk, __builtin_ctzll(rem));
                 const int sid = stream_id(ci, row, k0);
-                const uint32_t b0 = base[sid] + S.cursor[sid];
+                const uint32_t b0 = S.cursor[sid];
                 LV(int, g); LV(int, g2);
                 LANES(l) { L(g) = L(coded) && L(kk) == k0; L(g2) = L(g) && L(nn) >= 2; }
                 const uint64_t m1 = lepwave::wave_ballot(g), m2 = lepwave::wave_ballot(g2);
@@ -830,7 +872,7 @@ struct Walk5 {
                     if (t_e) {
                         const int lt = (int)(t_e >> 23) & 15, tsid = stream_id(ci, 63, lt);
                         tn = (int)(t_e >> 10) & 15;
-                        tat = base[tsid] + S.cursor[tsid] + S.TB[lt * 65 + l];
+                        tat = S.cursor[tsid] + S.TB[lt * 65 + l];
                         S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + ((tn + 3) >> 2));
                     }
                     if (MODE == kEmit) {
@@ -937,35 +979,57 @@ struct Walk5 {
         arena = (MODE != kCount) ? arena_base + pl->arena_off : nullptr;
         bins = (MODE == kGather) ? bins_base + pl->bins_off : nullptr;
         ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0;
-        LANES(l) {
-            for (int i = l; i < 2 * kRows * kClasses; i += 64) sh->cursor[i] = 0;
+        LANES(l) {   // emit / gather: a cursor is the absolute place of the stream's next unit
+            for (int i = l; i < 2 * kRows * kClasses; i += 64) sh->cursor[i] = MODE == kCount ? 0u : pl->base[i];
         }
         LSYNC();
+        // the tiles of the segment in stream order (lepton_codec.hh:41-100; vp8_encoder.cc:83-154: a row ends where the file was cut)
         bool top[3] = {true, true, true};
         SegmentCoder<false> sched;
         sched.img = image;
-        for (uint32_t idx = 0;; ++idx) {
-            SegmentCoder<false>::RowSpec r = sched.row_spec(idx);
-            if (r.done) break;
-            if (r.luma_y >= seg.y1 && !seg.is_last) break;
-            if (r.skip) continue;
-            if (r.luma_y < seg.y0) continue;
-            comp = r.component; ci = comp ? 1 : 0;
-            const int w = img->width[comp], yb = r.curr_y;
-            const int16_t* row = img->blocks[comp] + (int64_t)yb * w * 64;
-            const bool has_above = !top[comp];
-            const int16_t* arow = has_above ? row - (int64_t)w * 64 : nullptr;
-            NSum* nrow = ns + img->ns_offset[comp] + (yb & 1) * w;
-            const NSum* narow = ns + img->ns_offset[comp] + ((yb & 1) ^ 1) * w;
-            top[comp] = false;
-            int nrow_blocks = img->coded_blocks[comp] - yb * w;   // vp8_encoder.cc:83-154: a row ends where the file was cut
-            nrow_blocks = nrow_blocks < 1 ? 1 : (nrow_blocks > w ? w : nrow_blocks);
-            for (int x0 = 0; x0 < nrow_blocks; x0 += 64) {
-                const int nb = nrow_blocks - x0 < 64 ? nrow_blocks - x0 : 64;
-                load_tile(row, arow, x0, nb, x0 == 0);
-                const int rc = tile(x0, nb, has_above, nrow, narow);
-                if (rc) return rc;
+        uint32_t idx = 0;
+        int row_x0 = 0, row_blocks = 0;
+        TileDesc rowd{};
+        auto next_tile = [&](TileDesc* t) -> bool {
+            for (;;) {
+                if (row_x0 < row_blocks) {
+                    *t = rowd;
+                    t->x0 = row_x0;
+                    t->nb = row_blocks - row_x0 < 64 ? row_blocks - row_x0 : 64;
+                    row_x0 += 64;
+                    return true;
+                }
+                SegmentCoder<false>::RowSpec r = sched.row_spec(idx++);
+                if (r.done) return false;
+                if (r.luma_y >= seg.y1 && !seg.is_last) return false;
+                if (r.skip) continue;
+                if (r.luma_y < seg.y0) continue;
+                const int cmp = r.component, w = img->width[cmp], yb = r.curr_y;
+                rowd.comp = cmp; rowd.yb = yb;
+                rowd.row = img->blocks[cmp] + (int64_t)yb * w * 64;
+                rowd.has_above = !top[cmp];
+                rowd.arow = rowd.has_above ? rowd.row - (int64_t)w * 64 : nullptr;
+                rowd.nrow = ns + img->ns_offset[cmp] + (yb & 1) * w;
+                rowd.narow = ns + img->ns_offset[cmp] + ((yb & 1) ^ 1) * w;
+                top[cmp] = false;
+                int nbk = img->coded_blocks[cmp] - yb * w;
+                row_blocks = nbk < 1 ? 1 : (nbk > w ? w : nbk);
+                row_x0 = 0;
             }
+        };
+        TileDesc cur_t{}, nxt_t{};
+        LV(TileRegs, regs);
+        bool have = next_tile(&cur_t);
+        if (have) fetch_tile(cur_t, regs);
+        comp = -1;
+        while (have) {
+            store_tile(cur_t, regs);
+            const bool more = next_tile(&nxt_t);
+            if (more) fetch_tile(nxt_t, regs);   // in flight while this tile is worked on
+            const int rc = tile(cur_t.x0, cur_t.nb, cur_t.has_above, cur_t.nrow, cur_t.narow);
+            if (rc) return rc;
+            cur_t = nxt_t;
+            have = more;
         }
         return 0;
     }

@@ -279,7 +279,7 @@ extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, in
         rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), nullptr);
         if (rc) return rc;
         if (w.sign_pos[0] != plan.sign_cnt[0] || w.sign_pos[1] != plan.sign_cnt[1] || w.ord0 != plan.nblocks) return 1001;
-        for (int i = 0; i < kStreams; ++i) if (wsh.cursor[i] != plan.cnt[i]) return 1002;
+        for (int i = 0; i < kStreams; ++i) if (wsh.cursor[i] != plan.base[i] + plan.cnt[i]) return 1002;
     }
     std::vector<uint32_t> thresh(kThreshWords, kBranchInit);
     for (int ci = 0; ci < 2; ++ci) {
