@@ -87,18 +87,18 @@ WDEV uint32_t mul24_5(uint32_t a, uint32_t b) {   // low 32 bits of the 24 x 24-
     return (uint32_t)(((uint64_t)(a & 0xffffff) * (b & 0xffffff)) & 0xffffffffu);
 #endif
 }
+// Branch::record_obs_and_update (branch.hh:82-100) on the packed word.  The probability comes from lep3::prob_of (on the GPU a
+// float reciprocal with an exact integer fix-up, no table: a table in LDS would put a second memory round trip behind every bin)
 WDEV uint32_t bupd5(uint32_t w, uint32_t obs, const uint32_t* inv24) {
-    const uint32_t f = (w & 255) + (obs ^ 1), t = ((w >> 8) & 255) + obs;
-    uint32_t nw = f | (t << 8) | ((mul24_5(f << 8, inv24[f + t]) >> 24) << 16);
+    (void)inv24;
+    uint32_t f = (w & 255) + (obs ^ 1), t = ((w >> 8) & 255) + obs;
     if ((f | t) > 255) {   // the incremented count was 255
         const uint32_t f0 = w & 255, t0 = (w >> 8) & 255;
-        if ((obs ? f0 : t0) == 1) nw = (w & 0xffff) | ((obs ? 0u : 255u) << 16);
-        else {
-            const uint32_t f2 = obs ? (1 + f0) >> 1 : 129u, t2 = obs ? 129u : (1 + t0) >> 1;
-            nw = f2 | (t2 << 8) | ((mul24_5(f2 << 8, inv24[f2 + t2]) >> 24) << 16);
-        }
+        if ((obs ? f0 : t0) == 1) return (w & 0xffff) | ((obs ? 0u : 255u) << 16);
+        f = obs ? (1 + f0) >> 1 : 129u;
+        t = obs ? 129u : (1 + t0) >> 1;
     }
-    return nw;
+    return f | (t << 8) | (prob_of(f, t) << 16);
 }
 WDEV uint32_t inv24_5(uint32_t d) {   // lep_dec4.h inv24_of: exact for every reachable count pair
     if (d < 2) return 0;
@@ -123,7 +123,6 @@ struct FoldLane {
 };
 WDEV void fold_init(FoldShared* sh, int words_per_lane) {
     LANES(l) {
-        for (int d = l; d < 512; d += 64) sh->inv24[d] = inv24_5((uint32_t)d);
         for (int i = 0; i < words_per_lane; ++i) sh->slice[i * 64 + l] = kBranchInit;
     }
     LSYNC();
@@ -133,15 +132,23 @@ WDEV void fold_init(FoldShared* sh, int words_per_lane) {
 WDEV uint32_t fold_coef_unit(FoldLane& fl, uint32_t e, int rbase) {
     const int nres = (int)(e >> 10) & 15, len = (int)(e >> 14) & 15, bsr = (int)(e >> 18) & 31, u = (int)(e >> 27) & 7;
     const int nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
-    uint32_t probs = 0;
+    // the (up to) four bins of a unit use four different Branches: all are read before any is adapted and written back, so
+    // the lane waits for LDS once per unit, not once per bin
+    int br[4]; uint32_t bit[4], w[4];
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int j = 4 * u + q;
-        if (j >= m) break;
-        uint32_t p;
-        if (j < nexp) p = fl.code(bsr * 11 + j, (uint32_t)(len != j));
-        else { const int b = nres - 1 - (j - nexp); p = fl.code(rbase + b, (e >> b) & 1u); }
-        probs |= p << (8 * q);
+        const int b = nres - 1 - (j - nexp);
+        br[q] = j < nexp ? bsr * 11 + j : rbase + (b < 0 ? 0 : b);
+        bit[q] = j < nexp ? (uint32_t)(len != j) : (e >> (b < 0 ? 0 : b)) & 1u;
+        if (j >= m) br[q] = -1;
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = br[q] >= 0 ? fl.s[br[q] * 64] : 0u;
+    uint32_t probs = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (br[q] >= 0) { fl.s[br[q] * 64] = bupd5(w[q], bit[q], fl.inv24); probs |= (w[q] >> 16) << (8 * q); }
     return probs;
 }
 
@@ -174,8 +181,6 @@ WDEV void fold_coef_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
 // threshold chains (edge residual bits at or above the noise threshold, encoder.cc:132-152): Branches in HBM,
 // thresh[ci][prior class][lt][node], node = 1, then min(2 * node + bit, 127)
 WDEV void fold_thresh_wave(const SegPlan5* plans, uint8_t* arena, uint32_t* thresh_models, int seg0, int nseg, int sid, int ci, FoldShared* sh) {
-    LANES(l) for (int d = l; d < 512; d += 64) sh->inv24[d] = inv24_5((uint32_t)d);
-    LSYNC();
     LANES(l) {
         const int seg = seg0 + l;
         if (seg < nseg) {
@@ -348,22 +353,30 @@ WDEV void fold_dc_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
 // adversarial bin sequences (tests/test_core_emulation.py).
 struct BoolEnc5 {
     uint64_t low;
-    uint32_t range;
+    uint32_t q24;       // (range - 1) << 24: the form the recurrence is shortest in (see bin())
     int count;
     uint64_t stage;     // bytes of the code value that are not in memory yet, newest in the low byte
     int nst;            // how many (0..3 between flushes)
     uint8_t* out;
     uint32_t pos, cap;  // bytes handed to memory (written when below cap)
-    WDEV void init(uint8_t* o, uint32_t c) { out = o; cap = c; pos = 0; low = 0; range = 255; count = -24; stage = 0; nst = 0; }
-    WDEV void bin(uint32_t bit, uint32_t prob) {   // boolwriter.hh:48-118 without the byte output
-        const uint32_t split = 1 + (((range - 1) * prob) >> 8);
-        const uint32_t m = 0u - bit;
-        low += split & m;
-        const uint32_t r = split + ((range - 2 * split) & m);
-        const int shift = __builtin_clz(r) - 24;
-        range = r << shift;
-        low <<= shift;
-        count += shift;
+    WDEV void init(uint8_t* o, uint32_t c) { out = o; cap = c; pos = 0; low = 0; q24 = 254u << 24; count = -24; stage = 0; nst = 0; }
+    // boolwriter.hh:48-118 without the byte output.  split = 1 + (((range - 1) * prob) >> 8); with the state kept as
+    // (range - 1) << 24 that product's high word IS split - 1, and the normalised next range is n << clz(n): the dependent chain of
+    // a bin is mul_hi -> add / sub -> select -> clz -> shift-add, five instructions (every lane waits out this chain 2.4 million
+    // times per segment: it, not the instruction count, is what the write pass takes)
+    WDEV void bin(uint32_t bit, uint32_t prob) {
+#if LEP_ON_GPU
+        const uint32_t s = __umulhi(q24, prob);
+#else
+        const uint32_t s = (uint32_t)(((uint64_t)q24 * prob) >> 32);
+#endif
+        const uint32_t q = q24 >> 24;
+        const uint32_t n = bit ? q - s : s + 1;          // the new range before it is normalised (1 .. 255)
+        const int f = __builtin_clz(n);                  // 24 .. 31
+        q24 = (n << f) - (1u << 24);
+        low += bit ? s + 1 : 0u;
+        low <<= f - 24;
+        count += f - 24;
     }
     // a carry out of the staged bytes: back through the 0xFF bytes in memory (the serial writer's ripple; rare)
     WDEV void ripple() {
@@ -416,14 +429,26 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
                 BoolEnc5 bc;
                 bc.init(streams + sd.stream_off, sd.stream_cap);
                 bc.bin(0, 128);   // the start marker (vpx_start_encode)
-                U4 nxt = n ? ld4(b) : U4{0, 0, 0, 0};
-                for (uint32_t i = 0; i < n; i += 8) {   // eight bins per dwordx4, the next eight requested before these are coded
+                // eight bins per dwordx4, the next eight requested before these are coded; the body has no per-bin conditions (a
+                // segment's last 0..7 bins take the loop behind it)
+                U4 nxt = ld4(b);
+                uint32_t i = 0;
+                for (; i + 8 <= n; i += 8) {
                     const U4 g = nxt;
-                    if (i + 8 < n) nxt = ld4(b + (i >> 1) + 4);
-                    const uint32_t w[4] = {g.x, g.y, g.z, g.w};
-                    for (int h = 0; h < 2; ++h) {
-                        for (int q = 4 * h; q < 4 * h + 4 && i + q < n; ++q) { const uint32_t e = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu; bc.bin((e >> 8) & 1u, e & 255u); }
-                        bc.flush();
+                    nxt = ld4(b + (i >> 1) + 4);   // (the list has room to the next multiple of 128 bins: never outside the arena)
+                    bc.bin((g.x >> 8) & 1u, g.x & 255u); bc.bin((g.x >> 24) & 1u, (g.x >> 16) & 255u);
+                    bc.bin((g.y >> 8) & 1u, g.y & 255u); bc.bin((g.y >> 24) & 1u, (g.y >> 16) & 255u);
+                    bc.flush();
+                    bc.bin((g.z >> 8) & 1u, g.z & 255u); bc.bin((g.z >> 24) & 1u, (g.z >> 16) & 255u);
+                    bc.bin((g.w >> 8) & 1u, g.w & 255u); bc.bin((g.w >> 24) & 1u, (g.w >> 16) & 255u);
+                    bc.flush();
+                }
+                {
+                    const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+                    for (int q = 0; i < n; ++i, ++q) {
+                        const uint32_t e = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                        bc.bin((e >> 8) & 1u, e & 255u);
+                        if ((q & 3) == 3) bc.flush();
                     }
                 }
                 bool overflow = false;
@@ -488,6 +513,7 @@ struct Walk5 {
     uint32_t sign_pos[2];      // sign bytes given out per colour index
     uint32_t nbins;            // gather: bins written; count: bins an encoder will need (upper bound through the DC term)
     int status;
+    uint32_t sign_base[2], key_base, nz_base, en_base, dc_base;   // the plan's offsets (read once: a load per tile from the plan would sit on the critical path)
 
     WDEV uint32_t* units() const { return reinterpret_cast<uint32_t*>(arena); }
 
@@ -551,6 +577,16 @@ struct Walk5 {
         LV(int, lbins);           // bins of this block
         LV(NSum, nsa);            // the summary of the block above
 
+        // gather: the block's sparse records (7x7 count, edge counts, DC units) are requested now and used after phase 1
+        LV(uint32_t, rnz0); LV(uint32_t, rnz1); LV(uint32_t, ren0); LV(uint32_t, ren1); LV(uint32_t, rdc0); LV(uint32_t, rdc1); LV(uint32_t, rdc2);
+        if (MODE == kGather) {
+            LANES(l) if (l < nb) {
+                const uint32_t* r1 = reinterpret_cast<const uint32_t*>(arena + nz_base) + 2 * (ord0 + l);
+                const uint32_t* r2 = reinterpret_cast<const uint32_t*>(arena + en_base) + 2 * (ord0 + l);
+                const uint32_t* r3 = reinterpret_cast<const uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
+                L(rnz0) = r1[0]; L(rnz1) = r1[1]; L(ren0) = r2[0]; L(ren1) = r2[1]; L(rdc0) = r3[0]; L(rdc1) = r3[1]; L(rdc2) = r3[2];
+            }
+        }
         // ---- phase 1a: own numbers ---------------------------------------------------------------------------------
         LANES(l) {
             const int a = l < nb;
@@ -724,7 +760,7 @@ struct Walk5 {
         LSYNC();
 
         // ---- phase R: rows in stream order ---------------------------------------------------------------------------------
-        uint8_t* signs = MODE != kCount ? arena + plan->sign_base[ci] + sign_pos[ci] : nullptr;
+        uint8_t* signs = MODE != kCount ? arena + sign_base[ci] + sign_pos[ci] : nullptr;
         uint32_t* U = MODE != kCount ? units() : nullptr;
         LV(uint32_t, bp);   // gather: next bin of this lane
         LV(uint32_t, bacc); // gather: the bin at the even position before it, not stored yet
@@ -734,13 +770,13 @@ struct Walk5 {
         // the number of non-zeros of the 7x7 interior (and the key word the sparse chains filter on)
         if (MODE != kCount) {
             LANES(l) if (L(act)) {
-                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->nz_base) + 2 * (ord0 + l);
+                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + nz_base) + 2 * (ord0 + l);
                 if (MODE == kEmit) {
                     rec[0] = (uint32_t)L(nz);
-                    reinterpret_cast<uint32_t*>(arena + plan->key_base)[ord0 + l] =
+                    reinterpret_cast<uint32_t*>(arena + key_base)[ord0 + l] =
                         (uint32_t)ci | ((uint32_t)L(nzctxbin) << 1) | ((uint32_t)L(eobx) << 5) | ((uint32_t)L(eoby) << 8) | ((((uint32_t)L(dc_e0) >> 23) & 15u) << 11);
                 } else {
-                    const uint32_t lo = rec[0], hi = rec[1];
+                    const uint32_t lo = L(rnz0), hi = L(rnz1);
                     for (int i = 5; i >= 0; --i) {
                         const int q = 5 - i;
                         const uint32_t p = q < 4 ? (lo >> (8 * q)) & 255u : (hi >> (8 * (q - 4))) & 255u;
@@ -763,9 +799,9 @@ struct Walk5 {
                 LANES(l) {
                     L(left) = horizontal ? L(neh) : L(nev);
                     if (MODE != kCount && L(act)) {
-                        uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->en_base) + 2 * (ord0 + l) + eg;
+                        uint32_t* rec = reinterpret_cast<uint32_t*>(arena + en_base) + 2 * (ord0 + l) + eg;
                         if (MODE == kEmit) rec[0] = (uint32_t)((L(nz) + 3) / 7) | ((uint32_t)L(left) << 3);
-                        else L(enw) = rec[0];   // (requested here, used behind the previous row's bins)
+                        else L(enw) = eg ? L(ren1) : L(ren0);
                     }
                 }
             }
@@ -858,7 +894,7 @@ struct Walk5 {
                     LANES(l) if (L(g)) L(at) += (uint32_t)lane_prefix(mq, l);
                 }
                 LSYNC();
-                LANES(l) if (l == 0) S.cursor[sid] += (uint32_t)total;
+                LANES(l) if (l == 0) S.cursor[sid] = b0 + (uint32_t)total;
                 LSYNC();
                 rem &= ~m1;
             }
@@ -910,20 +946,20 @@ struct Walk5 {
         // DC
         if (MODE != kCount) {
             LANES(l) if (L(act)) {
-                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + plan->dc_base) + 6 * (ord0 + l);
+                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
                 const uint32_t e = (uint32_t)L(dc_e0);
                 const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
                 if (MODE == kEmit) { rec[0] = e; signs[L(sp)++] = (uint8_t)L(dc_sign); }
                 else {
-                    uint32_t w = rec[0];
+                    uint32_t w = L(rdc0);
                     for (int q = 0; q < nexp; ++q) {
-                        if (q && !(q & 3)) w = rec[q >> 2];
+                        if (q == 4) w = L(rdc1); else if (q == 8) w = L(rdc2);
                         put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
                     }
                     const uint32_t sb = signs[L(sp)++];
                     if (len) put_bin(L(bp), L(bacc), sb | ((((uint32_t)L(dc_sign) >> 6) & 1u) << 8));
                     for (int q = nexp; q < m; ++q) {
-                        if (!(q & 3) || q == nexp) w = rec[q >> 2];
+                        if (!(q & 3) || q == nexp) w = (q >> 2) == 0 ? L(rdc0) : ((q >> 2) == 1 ? L(rdc1) : ((q >> 2) == 2 ? L(rdc2) : rec[q >> 2]));
                         put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
                     }
                     flush_bin(L(bp), L(bacc));
@@ -979,6 +1015,7 @@ struct Walk5 {
         arena = (MODE != kCount) ? arena_base + pl->arena_off : nullptr;
         bins = (MODE == kGather) ? bins_base + pl->bins_off : nullptr;
         ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0;
+        if (MODE != kCount) { sign_base[0] = pl->sign_base[0]; sign_base[1] = pl->sign_base[1]; key_base = pl->key_base; nz_base = pl->nz_base; en_base = pl->en_base; dc_base = pl->dc_base; }
         LANES(l) {   // emit / gather: a cursor is the absolute place of the stream's next unit
             for (int i = l; i < 2 * kRows * kClasses; i += 64) sh->cursor[i] = MODE == kCount ? 0u : pl->base[i];
         }
