@@ -106,24 +106,41 @@ WDEV uint32_t inv24_5(uint32_t d) {   // lep_dec4.h inv24_of: exact for every re
 }
 
 // ---- fold: lane = chain --------------------------------------------------------------------------------------------------
-// Every lane owns `SLICE` Branches in LDS, laid out [branch][lane] (a lane's words sit in one bank column: no conflicts
-// whatever the lanes index).  code(): one bin -- returns the probability it is coded with, adapts the Branch.
+// A Branch in LDS is 16 bits: false count | true count << 8.  Its probability is a function of the counts -- (f << 8) / (f + t),
+// branch.hh:108-125 -- with ONE exception: a Branch that saturates on "true" (counts (1, 255) met by another true) codes with
+// probability 0 from then on, where the same pair reached by counting gives 1 (branch.hh:86-91).  That state is stored as
+// t = 0.  (Saturating on "false" leaves (255, 1) with probability 255, which is what the formula gives.)  Half the LDS of the
+// packed word of lep_core.h: twice the resident fold wavefronts.
+WDEV uint32_t prob16(uint32_t w) { const uint32_t t = w >> 8; return t ? prob_of(w & 255u, t) : 0u; }
+WDEV uint32_t upd16(uint32_t w, uint32_t obs) {
+    uint32_t f = w & 255u, t = w >> 8;
+    if (t == 0) return obs ? w : (2u | (255u << 8));   // saturated true: counts (1, 255); a false makes them (2, 255)
+    if (obs) {
+        if (t == 255u) { if (f == 1u) return 1u; f = (1u + f) >> 1; t = 129u; }
+        else ++t;
+    } else {
+        if (f == 255u) { if (t == 1u) return w; t = (1u + t) >> 1; f = 129u; }
+        else ++f;
+    }
+    return f | (t << 8);
+}
+constexpr uint32_t kBranchInit16 = 1u | (1u << 8);
+// Every lane owns `SLICE` Branches in LDS, laid out [branch][lane] (lanes next to each other: no bank conflicts whatever the
+// lanes index).  code(): one bin -- returns the probability it is coded with, adapts the Branch.
 struct FoldShared {
-    uint32_t inv24[512];
-    uint32_t slice[kDcSlice * 64];   // the largest slice (197 words per lane)
+    uint16_t slice[kDcSlice * 64];   // the largest slice (197 Branches per lane)
 };
 struct FoldLane {
-    uint32_t* s;   // &slice[lane]
-    const uint32_t* inv24;
+    uint16_t* s;   // &slice[lane]
     WDEV uint32_t code(int branch, uint32_t bit) {
         const uint32_t w = s[branch * 64];
-        s[branch * 64] = bupd5(w, bit, inv24);
-        return w >> 16;
+        s[branch * 64] = (uint16_t)upd16(w, bit);
+        return prob16(w);
     }
 };
 WDEV void fold_init(FoldShared* sh, int words_per_lane) {
     LANES(l) {
-        for (int i = 0; i < words_per_lane; ++i) sh->slice[i * 64 + l] = kBranchInit;
+        for (int i = 0; i < words_per_lane; ++i) sh->slice[i * 64 + l] = (uint16_t)kBranchInit16;
     }
     LSYNC();
 }
@@ -148,7 +165,7 @@ WDEV uint32_t fold_coef_unit(FoldLane& fl, uint32_t e, int rbase) {
     uint32_t probs = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        if (br[q] >= 0) { fl.s[br[q] * 64] = bupd5(w[q], bit[q], fl.inv24); probs |= (w[q] >> 16) << (8 * q); }
+        if (br[q] >= 0) { fl.s[br[q] * 64] = (uint16_t)upd16(w[q], bit[q]); probs |= prob16(w[q]) << (8 * q); }
     return probs;
 }
 
@@ -161,7 +178,7 @@ WDEV void fold_coef_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
         if (seg < nseg) {
             const SegPlan5& P = plans[seg];
             uint32_t* units = reinterpret_cast<uint32_t*>(arena + P.arena_off);
-            FoldLane fl{sh->slice + l, sh->inv24};
+            FoldLane fl{sh->slice + l};
             const uint32_t n = P.status ? 0u : P.cnt[sid];
             uint32_t* p = units + P.base[sid];   // 16-byte aligned, padded to whole groups of four
             U4 nxt = n ? ld4(p) : U4{0, 0, 0, 0};
@@ -198,7 +215,7 @@ WDEV void fold_thresh_wave(const SegPlan5* plans, uint8_t* arena, uint32_t* thre
                     const uint32_t bit = (e >> (n - 1 - t)) & 1u;
                     if (t >= 4 * u) {
                         const uint32_t w = T[node];
-                        T[node] = bupd5(w, bit, sh->inv24);
+                        T[node] = bupd5(w, bit, nullptr);
                         probs |= (w >> 16) << (8 * (t - 4 * u));
                     }
                     node = imin((node << 1) | (int)bit, 127);
@@ -217,7 +234,7 @@ WDEV void fold_sign_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
         if (seg < nseg) {
             const SegPlan5& P = plans[seg];
             uint8_t* s = arena + P.arena_off + P.sign_base[ci];
-            FoldLane fl{sh->slice + l, sh->inv24};
+            FoldLane fl{sh->slice + l};
             const uint32_t n = P.status ? 0u : P.sign_cnt[ci];
             uint32_t* p = reinterpret_cast<uint32_t*>(s);   // the stream starts on 16 bytes and is padded to 16
             U4 nxt = n ? ld4(p) : U4{0, 0, 0, 0};
@@ -250,7 +267,7 @@ WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
             const SegPlan5& P = plans[seg];
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.nz_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
-            FoldLane fl{sh->slice + l, sh->inv24};
+            FoldLane fl{sh->slice + l};
             const uint32_t key = (uint32_t)ci | ((uint32_t)ctxbin << 1), nb = P.status ? 0u : P.nblocks;
             U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0}, nr0 = nb ? ld4(rec) : U4{0, 0, 0, 0}, nr1 = nb ? ld4(rec + 4) : U4{0, 0, 0, 0};
             for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
@@ -284,7 +301,7 @@ WDEV void fold_edgenz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int 
             const SegPlan5& P = plans[seg];
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.en_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
-            FoldLane fl{sh->slice + l, sh->inv24};
+            FoldLane fl{sh->slice + l};
             const uint32_t nb = P.status ? 0u : P.nblocks;
             U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0}, nr0 = nb ? ld4(rec) : U4{0, 0, 0, 0}, nr1 = nb ? ld4(rec + 4) : U4{0, 0, 0, 0};
             for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
@@ -317,7 +334,7 @@ WDEV void fold_dc_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
             const SegPlan5& P = plans[seg];
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.dc_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
-            FoldLane fl{sh->slice + l, sh->inv24};
+            FoldLane fl{sh->slice + l};
             const uint32_t nb = P.status ? 0u : P.nblocks;
             U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0};
             uint32_t ne0 = nb ? rec[0] : 0u, ne1 = nb > 1 ? rec[6] : 0u, ne2 = nb > 2 ? rec[12] : 0u, ne3 = nb > 3 ? rec[18] : 0u;
@@ -481,6 +498,40 @@ struct Walk5Shared {
     uint8_t thr[64];
 };
 
+// The walk's LDS block.  On the GPU it is the kernel's dynamic LDS, named directly at every use: a pointer to it kept in the
+// walker object loses its address space as soon as that object's address is taken anywhere, and every access then becomes a
+// FLAT instruction (measured: 441 flat against 10 ds instructions in the gather kernel, twice the wave time).
+#if LEP_ON_GPU
+extern __shared__ __attribute__((aligned(16))) unsigned char lep5_lds[];
+#define LEP5_WSH(self) (*reinterpret_cast<lep5::Walk5Shared*>(lep5::lep5_lds))
+#else
+#define LEP5_WSH(self) (*(self)->sh)
+#endif
+
+// Global memory through pointers whose address space the compiler cannot see (they come out of descriptors in memory): a plain
+// dereference is a FLAT instruction, which counts against the LDS wait counter as well -- every wait for an LDS read would then
+// also wait for the tile prefetch in flight.  gld / gst name the address space.
+#if LEP_ON_GPU
+template <class T> WDEV T gld(const T* p) { return *(const __attribute__((address_space(1))) T*)(uintptr_t)p; }
+template <class T> WDEV void gst(T* p, const T& v) { *(__attribute__((address_space(1))) T*)(uintptr_t)p = v; }
+#else
+template <class T> WDEV T gld(const T* p) { return *p; }
+template <class T> WDEV void gst(T* p, const T& v) { *p = v; }
+#endif
+
+WDEV NSum gld_ns(const NSum* p) {   // (a struct cannot be assigned through an address-space pointer: nine dwords)
+    uint32_t w[sizeof(NSum) / 4];
+    for (int i = 0; i < (int)(sizeof(NSum) / 4); ++i) w[i] = gld(reinterpret_cast<const uint32_t*>(p) + i);
+    NSum r;
+    __builtin_memcpy(&r, w, sizeof r);
+    return r;
+}
+WDEV void gst_ns(NSum* p, const NSum& v) {
+    uint32_t w[sizeof(NSum) / 4];
+    __builtin_memcpy(w, &v, sizeof v);
+    for (int i = 0; i < (int)(sizeof(NSum) / 4); ++i) gst(reinterpret_cast<uint32_t*>(p) + i, w[i]);
+}
+
 WDEV int lane_prefix(uint64_t m, int l) {   // set bits of m below lane l
 #if LEP_ON_GPU
     (void)l;
@@ -527,6 +578,46 @@ struct Walk5 {
         const NSum* narow;
     };
     struct TileRegs { uint32_t c[32], a[32]; };
+    struct TileIter {   // (an object of its own, not a lambda over the walker: see LEP5_WSH)
+        const ImageDev* img;
+        SegDev seg;
+        NSum* ns;
+        bool top[3];
+        SegmentCoder<false> sched;
+        uint32_t idx;
+        int row_x0, row_blocks;
+        TileDesc rowd;
+        WDEV void init(const ImageDev* image, const SegDev& s, NSum* n) {
+            img = image; seg = s; ns = n; top[0] = top[1] = top[2] = true; sched.img = image; idx = 0; row_x0 = 0; row_blocks = 0; rowd = TileDesc{};
+        }
+        WDEV bool next(TileDesc* t) {
+            for (;;) {
+                if (row_x0 < row_blocks) {
+                    *t = rowd;
+                    t->x0 = row_x0;
+                    t->nb = row_blocks - row_x0 < 64 ? row_blocks - row_x0 : 64;
+                    row_x0 += 64;
+                    return true;
+                }
+                SegmentCoder<false>::RowSpec r = sched.row_spec(idx++);
+                if (r.done) return false;
+                if (r.luma_y >= seg.y1 && !seg.is_last) return false;
+                if (r.skip) continue;
+                if (r.luma_y < seg.y0) continue;
+                const int cmp = r.component, w = img->width[cmp], yb = r.curr_y;
+                rowd.comp = cmp; rowd.yb = yb;
+                rowd.row = img->blocks[cmp] + (int64_t)yb * w * 64;
+                rowd.has_above = !top[cmp];
+                rowd.arow = rowd.has_above ? rowd.row - (int64_t)w * 64 : nullptr;
+                rowd.nrow = ns + img->ns_offset[cmp] + (yb & 1) * w;
+                rowd.narow = ns + img->ns_offset[cmp] + ((yb & 1) ^ 1) * w;
+                top[cmp] = false;
+                int nbk = img->coded_blocks[cmp] - yb * w;
+                row_blocks = nbk < 1 ? 1 : (nbk > w ? w : nbk);
+                row_x0 = 0;
+            }
+        }
+    };
     WDEV void fetch_tile(const TileDesc& t, TileRegs* regs) const {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(t.row + (int64_t)t.x0 * 64);
         const uint32_t* asrc = t.arow ? reinterpret_cast<const uint32_t*>(t.arow + (int64_t)t.x0 * 64) : nullptr;
@@ -534,13 +625,13 @@ struct Walk5 {
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
                 const int d = k * 64 + l, b = d >> 5;
-                regs[LEP_LI(l)].c[k] = b < t.nb ? src[d] : 0u;
-                regs[LEP_LI(l)].a[k] = (asrc && b < t.nb && MODE != kCount) ? asrc[d] : 0u;
+                regs[LEP_LI(l)].c[k] = b < t.nb ? gld(src + d) : 0u;
+                regs[LEP_LI(l)].a[k] = (asrc && b < t.nb && MODE != kCount) ? gld(asrc + d) : 0u;
             }
         }
     }
     WDEV void store_tile(const TileDesc& t, const TileRegs* regs) {
-        Walk5Shared& S = *sh;
+        Walk5Shared& S = LEP5_WSH(this);
         const bool first_of_row = t.x0 == 0;
         if (t.comp != comp) {   // the component's tables
             comp = t.comp; ci = comp ? 1 : 0;
@@ -567,7 +658,7 @@ struct Walk5 {
 
     // one tile; has_above: the row above belongs to this segment; returns 0 or an exit code
     WDEV int tile(int x0, int nb, bool has_above, NSum* nrow, const NSum* narow) {
-        Walk5Shared& S = *sh;
+        Walk5Shared& S = LEP5_WSH(this);
         const int c = comp;
         LV(int, act); LV(int, nz); LV(int, neh); LV(int, nev); LV(int, nsig); LV(int, err); LV(int, errdc);
         LV(int, eobx); LV(int, eoby);
@@ -584,7 +675,7 @@ struct Walk5 {
                 const uint32_t* r1 = reinterpret_cast<const uint32_t*>(arena + nz_base) + 2 * (ord0 + l);
                 const uint32_t* r2 = reinterpret_cast<const uint32_t*>(arena + en_base) + 2 * (ord0 + l);
                 const uint32_t* r3 = reinterpret_cast<const uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
-                L(rnz0) = r1[0]; L(rnz1) = r1[1]; L(ren0) = r2[0]; L(ren1) = r2[1]; L(rdc0) = r3[0]; L(rdc1) = r3[1]; L(rdc2) = r3[2];
+                L(rnz0) = gld(r1); L(rnz1) = gld(r1 + 1); L(ren0) = gld(r2); L(ren1) = gld(r2 + 1); L(rdc0) = gld(r3); L(rdc1) = gld(r3 + 1); L(rdc2) = gld(r3 + 2);
             }
         }
         // ---- phase 1a: own numbers ---------------------------------------------------------------------------------
@@ -628,7 +719,7 @@ struct Walk5 {
             }
             L(nz) = n7; L(neh) = nh; L(nev) = nv; L(eobx) = ex; L(eoby) = ey; L(lbins) = lb;
             L(nsig) = a ? n7 + nh + nv + 1 : 0;
-            if (MODE != kCount && has_above && a) L(nsa) = narow[x0 + l];   // (written when that row was walked)
+            if (MODE != kCount && has_above && a) L(nsa) = gld_ns(&narow[x0 + l]);   // (written when that row was walked)
             else L(nsa) = NSum{};
         }
         // ---- phase 1b: IDCT without DC, neighbour summary (block_context.hh:44-78) -------------------------------------
@@ -685,7 +776,7 @@ struct Walk5 {
                     L(px).r0[i] = pix[i]; L(px).r1[i] = pix[8 + i]; L(px).c0[i] = pix[i * 8]; L(px).c1[i] = pix[i * 8 + 1];
                 }
                 me.nz = L(nz);
-                nrow[x0 + l] = me;   // for the row below
+                gst_ns(&nrow[x0 + l], me);   // for the row below
             }
             LSYNC();
         }
@@ -772,9 +863,9 @@ struct Walk5 {
             LANES(l) if (L(act)) {
                 uint32_t* rec = reinterpret_cast<uint32_t*>(arena + nz_base) + 2 * (ord0 + l);
                 if (MODE == kEmit) {
-                    rec[0] = (uint32_t)L(nz);
-                    reinterpret_cast<uint32_t*>(arena + key_base)[ord0 + l] =
-                        (uint32_t)ci | ((uint32_t)L(nzctxbin) << 1) | ((uint32_t)L(eobx) << 5) | ((uint32_t)L(eoby) << 8) | ((((uint32_t)L(dc_e0) >> 23) & 15u) << 11);
+                    gst(rec, (uint32_t)L(nz));
+                    gst(reinterpret_cast<uint32_t*>(arena + key_base) + ord0 + l,
+                        (uint32_t)ci | ((uint32_t)L(nzctxbin) << 1) | ((uint32_t)L(eobx) << 5) | ((uint32_t)L(eoby) << 8) | ((((uint32_t)L(dc_e0) >> 23) & 15u) << 11));
                 } else {
                     const uint32_t lo = L(rnz0), hi = L(rnz1);
                     for (int i = 5; i >= 0; --i) {
@@ -800,7 +891,7 @@ struct Walk5 {
                     L(left) = horizontal ? L(neh) : L(nev);
                     if (MODE != kCount && L(act)) {
                         uint32_t* rec = reinterpret_cast<uint32_t*>(arena + en_base) + 2 * (ord0 + l) + eg;
-                        if (MODE == kEmit) rec[0] = (uint32_t)((L(nz) + 3) / 7) | ((uint32_t)L(left) << 3);
+                        if (MODE == kEmit) gst(rec, (uint32_t)((L(nz) + 3) / 7) | ((uint32_t)L(left) << 3));
                         else L(enw) = eg ? L(ren1) : L(ren0);
                     }
                 }
@@ -912,15 +1003,15 @@ struct Walk5 {
                         S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + ((tn + 3) >> 2));
                     }
                     if (MODE == kEmit) {
-                        for (int u = 0; u < n; ++u) U[L(at) + u] = e | ((uint32_t)u << 27);
-                        for (int u = 0; u < (tn + 3) >> 2; ++u) U[tat + u] = t_e | ((uint32_t)u << 27);
-                        if (len) signs[L(sp)++] = (uint8_t)(0x80u | (uint32_t)L(slot) | ((uint32_t)(L(cfv) >= 0) << 6));
+                        for (int u = 0; u < n; ++u) gst(U + L(at) + u, e | ((uint32_t)u << 27));
+                        for (int u = 0; u < (tn + 3) >> 2; ++u) gst(U + tat + u, t_e | ((uint32_t)u << 27));
+                        if (len) gst(signs + L(sp)++, (uint8_t)(0x80u | (uint32_t)L(slot) | ((uint32_t)(L(cfv) >= 0) << 6)));
                     } else {
                         c_e = e; c_te = t_e; c_at = L(at); c_tat = tat;
-                        c_w0 = U[c_at];
-                        if (n > 1) c_w1 = U[c_at + 1];
-                        if (tn) c_tw = U[tat];
-                        if (len) c_sg = signs[L(sp)++];
+                        c_w0 = gld(U + c_at);
+                        if (n > 1) c_w1 = gld(U + c_at + 1);
+                        if (tn) c_tw = gld(U + tat);
+                        if (len) c_sg = gld(signs + L(sp)++);
                     }
                 }
                 if (MODE == kGather) {
@@ -949,17 +1040,17 @@ struct Walk5 {
                 uint32_t* rec = reinterpret_cast<uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
                 const uint32_t e = (uint32_t)L(dc_e0);
                 const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
-                if (MODE == kEmit) { rec[0] = e; signs[L(sp)++] = (uint8_t)L(dc_sign); }
+                if (MODE == kEmit) { gst(rec, e); gst(signs + L(sp)++, (uint8_t)L(dc_sign)); }
                 else {
                     uint32_t w = L(rdc0);
                     for (int q = 0; q < nexp; ++q) {
                         if (q == 4) w = L(rdc1); else if (q == 8) w = L(rdc2);
                         put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
                     }
-                    const uint32_t sb = signs[L(sp)++];
+                    const uint32_t sb = gld(signs + L(sp)++);
                     if (len) put_bin(L(bp), L(bacc), sb | ((((uint32_t)L(dc_sign) >> 6) & 1u) << 8));
                     for (int q = nexp; q < m; ++q) {
-                        if (!(q & 3) || q == nexp) w = (q >> 2) == 0 ? L(rdc0) : ((q >> 2) == 1 ? L(rdc1) : ((q >> 2) == 2 ? L(rdc2) : rec[q >> 2]));
+                        if (!(q & 3) || q == nexp) w = (q >> 2) == 0 ? L(rdc0) : ((q >> 2) == 1 ? L(rdc1) : ((q >> 2) == 2 ? L(rdc2) : gld(rec + (q >> 2))));
                         put_bin(L(bp), L(bacc), ((w >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
                     }
                     flush_bin(L(bp), L(bacc));
@@ -981,8 +1072,8 @@ struct Walk5 {
     static constexpr uint32_t kNoBin = 0xffffffffu;
     WDEV void put_bin(uint32_t& pos, uint32_t& acc, uint32_t v) {
         if (pos & 1u) {
-            if (acc != kNoBin) *reinterpret_cast<uint32_t*>(bins + pos - 1) = acc | (v << 16);
-            else bins[pos] = (uint16_t)v;
+            if (acc != kNoBin) gst(reinterpret_cast<uint32_t*>(bins + pos - 1), acc | (v << 16));
+            else gst(bins + pos, (uint16_t)v);
             acc = kNoBin;
         } else acc = v;
         ++pos;
@@ -994,20 +1085,20 @@ struct Walk5 {
         const int tn = t_e ? (int)(t_e >> 10) & 15 : 0;
         uint32_t w = w0;
         for (int q = 0; q < nexp; ++q) {
-            if (q == 4) w = w1; else if (q == 8) w = U[at + 2];
+            if (q == 4) w = w1; else if (q == 8) w = gld(U + at + 2);
             put_bin(pos, acc, ((w >> (8 * (q & 3))) & 255u) | ((uint32_t)(len != q) << 8));
         }
         if (len) put_bin(pos, acc, sg | ((uint32_t)(cf >= 0) << 8));
         for (int t = 0; t < tn; ++t) {
-            if (t && !(t & 3)) tw = U[tat + (t >> 2)];
+            if (t && !(t & 3)) tw = gld(U + tat + (t >> 2));
             put_bin(pos, acc, ((tw >> (8 * (t & 3))) & 255u) | (((t_e >> (tn - 1 - t)) & 1u) << 8));
         }
         for (int q = nexp; q < m; ++q) {
-            if (q == nexp || !(q & 3)) w = (q >> 2) == 0 ? w0 : ((q >> 2) == 1 ? w1 : U[at + (q >> 2)]);
+            if (q == nexp || !(q & 3)) w = (q >> 2) == 0 ? w0 : ((q >> 2) == 1 ? w1 : gld(U + at + (q >> 2)));
             put_bin(pos, acc, ((w >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
         }
     }
-    WDEV void flush_bin(uint32_t pos, uint32_t acc) { if ((pos & 1u) && acc != kNoBin) bins[pos - 1] = (uint16_t)acc; }
+    WDEV void flush_bin(uint32_t pos, uint32_t acc) { if ((pos & 1u) && acc != kNoBin) gst(bins + pos - 1, (uint16_t)acc); }
 
     // whole segment (lepton_codec.hh:41-100 row schedule, vp8_encoder.cc:239-445); ns: the segment's two-row NSum rings (zeroed)
     WDEV int run(const ImageDev* image, const SegDev& seg, NSum* ns, Walk5Shared* shared, const SegPlan5* pl, uint8_t* arena_base, uint16_t* bins_base) {
@@ -1017,51 +1108,20 @@ struct Walk5 {
         ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0;
         if (MODE != kCount) { sign_base[0] = pl->sign_base[0]; sign_base[1] = pl->sign_base[1]; key_base = pl->key_base; nz_base = pl->nz_base; en_base = pl->en_base; dc_base = pl->dc_base; }
         LANES(l) {   // emit / gather: a cursor is the absolute place of the stream's next unit
-            for (int i = l; i < 2 * kRows * kClasses; i += 64) sh->cursor[i] = MODE == kCount ? 0u : pl->base[i];
+            for (int i = l; i < 2 * kRows * kClasses; i += 64) LEP5_WSH(this).cursor[i] = MODE == kCount ? 0u : pl->base[i];
         }
         LSYNC();
         // the tiles of the segment in stream order (lepton_codec.hh:41-100; vp8_encoder.cc:83-154: a row ends where the file was cut)
-        bool top[3] = {true, true, true};
-        SegmentCoder<false> sched;
-        sched.img = image;
-        uint32_t idx = 0;
-        int row_x0 = 0, row_blocks = 0;
-        TileDesc rowd{};
-        auto next_tile = [&](TileDesc* t) -> bool {
-            for (;;) {
-                if (row_x0 < row_blocks) {
-                    *t = rowd;
-                    t->x0 = row_x0;
-                    t->nb = row_blocks - row_x0 < 64 ? row_blocks - row_x0 : 64;
-                    row_x0 += 64;
-                    return true;
-                }
-                SegmentCoder<false>::RowSpec r = sched.row_spec(idx++);
-                if (r.done) return false;
-                if (r.luma_y >= seg.y1 && !seg.is_last) return false;
-                if (r.skip) continue;
-                if (r.luma_y < seg.y0) continue;
-                const int cmp = r.component, w = img->width[cmp], yb = r.curr_y;
-                rowd.comp = cmp; rowd.yb = yb;
-                rowd.row = img->blocks[cmp] + (int64_t)yb * w * 64;
-                rowd.has_above = !top[cmp];
-                rowd.arow = rowd.has_above ? rowd.row - (int64_t)w * 64 : nullptr;
-                rowd.nrow = ns + img->ns_offset[cmp] + (yb & 1) * w;
-                rowd.narow = ns + img->ns_offset[cmp] + ((yb & 1) ^ 1) * w;
-                top[cmp] = false;
-                int nbk = img->coded_blocks[cmp] - yb * w;
-                row_blocks = nbk < 1 ? 1 : (nbk > w ? w : nbk);
-                row_x0 = 0;
-            }
-        };
+        TileIter it;
+        it.init(image, seg, ns);
         TileDesc cur_t{}, nxt_t{};
         LV(TileRegs, regs);
-        bool have = next_tile(&cur_t);
+        bool have = it.next(&cur_t);
         if (have) fetch_tile(cur_t, regs);
         comp = -1;
         while (have) {
             store_tile(cur_t, regs);
-            const bool more = next_tile(&nxt_t);
+            const bool more = it.next(&nxt_t);
             if (more) fetch_tile(nxt_t, regs);   // in flight while this tile is worked on
             const int rc = tile(cur_t.x0, cur_t.nb, cur_t.has_above, cur_t.nrow, cur_t.narow);
             if (rc) return rc;

@@ -156,14 +156,14 @@ template <int MODE>
 __global__ __launch_bounds__(64) void lep_enc5_walk_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs, NSum* ns_all,
                                                          const uint64_t* __restrict__ ns_off, lep5::SegPlan5* plans, uint8_t* arena, uint16_t* bins,
                                                          uint32_t* counts) {
-    __shared__ lep5::Walk5Shared sh;
+    lep5::Walk5Shared* sh = reinterpret_cast<lep5::Walk5Shared*>(lep5::lep5_lds);   // dynamic LDS (sizeof(Walk5Shared) at launch)
     const int s = blockIdx.x;
     const SegDev seg = segs[s];
     lep5::SegPlan5* P = plans + s;
     if (MODE == lep5::kGather && P->status) return;
     lep5::Walk5<MODE> w;
-    const int rc = w.run(images + seg.image, seg, ns_all + ns_off[s], &sh, P, arena, bins);
-    if (MODE == lep5::kCount) lep5::export_counts(w, &sh, counts + (size_t)s * lep5::kCountWords);
+    const int rc = w.run(images + seg.image, seg, ns_all + ns_off[s], sh, P, arena, bins);
+    if (MODE == lep5::kCount) lep5::export_counts(w, sh, counts + (size_t)s * lep5::kCountWords);
     if (threadIdx.x == 0) {
         if (MODE == lep5::kEmit) P->status = rc;
         if (MODE == lep5::kGather) P->nbins = w.nbins;
@@ -192,7 +192,7 @@ __global__ void lep_enc5_fill_kernel(uint4* p, size_t n16, uint32_t v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = x;
 }
 // fold, coefficient chains: block = (64 consecutive segments, stream); 36 KB of LDS
-struct Fold5CoefShared { uint32_t inv24[512]; uint32_t slice[lep5::kCoefSlice * 64]; };
+struct Fold5CoefShared { uint16_t slice[lep5::kCoefSlice * 64]; };   // 18 KB: eight wavefronts per CU
 __global__ __launch_bounds__(64) void lep_enc5_fold_coef_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, int nseg, int groups) {
     __shared__ Fold5CoefShared shc;
     const int grp = (int)blockIdx.x % groups, job = (int)blockIdx.x / groups;   // job = ci * 630 + row * 10 + k, rows 0..62
@@ -390,7 +390,7 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     const int groups = (nseg + 63) / 64;
     g->nstage = 0;
     HIPCHK(g, hipEventRecord(g->ev_stage[0], st));
-    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kCount>), dim3(nseg), dim3(64), 0, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)nullptr, (uint16_t*)nullptr, counts);
+    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kCount>), dim3(nseg), dim3(64), sizeof(lep5::Walk5Shared), st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)nullptr, (uint16_t*)nullptr, counts);
     hipLaunchKernelGGL(lep_enc5_plan_kernel, dim3(groups), dim3(64), 0, st, (const uint32_t*)counts, plans, nseg);
     hipLaunchKernelGGL(lep_enc5_offsets_kernel, dim3(1), dim3(64), 0, st, plans, nseg, d_tot);
     // the threshold Branches are the only model state in HBM: 2 MB per segment, reset while the count pass is looked at
@@ -401,7 +401,7 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     if (int rc = ensure(g, &A.d_entries, &A.entries_bytes, (size_t)tot[0] + 256)) return rc;
     if (int rc = ensure(g, &A.d_binlist, &A.binlist_bytes, (size_t)tot[1] * 2 + 256)) return rc;
     HIPCHK(g, hipEventRecord(g->ev_stage[1], st));
-    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kEmit>), dim3(nseg), dim3(64), 0, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)nullptr, counts);
+    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kEmit>), dim3(nseg), dim3(64), sizeof(lep5::Walk5Shared), st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)nullptr, counts);
     HIPCHK(g, hipEventRecord(g->ev_stage[2], st));
     HIPCHK(g, hipEventRecord(g->ev_fork, st));
     HIPCHK(g, hipStreamWaitEvent(g->stream2, g->ev_fork, 0));
@@ -411,7 +411,7 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     HIPCHK(g, hipEventRecord(g->ev_join, g->stream2));
     HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
     HIPCHK(g, hipEventRecord(g->ev_stage[3], st));
-    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kGather>), dim3(nseg), dim3(64), 0, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)A.d_binlist, counts);
+    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kGather>), dim3(nseg), dim3(64), sizeof(lep5::Walk5Shared), st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)A.d_binlist, counts);
     HIPCHK(g, hipEventRecord(g->ev_stage[4], st));
     hipLaunchKernelGGL(lep_enc5_write_kernel, dim3(groups), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (const uint16_t*)A.d_binlist, d_seg, nseg, d_streams, d_stream_len,
                        d_status, g->d_bins);

@@ -351,3 +351,23 @@ extern "C" int emu_check_bool_writer5(int trials) {
     }
     return 0;
 }
+
+
+// the 16-bit Branch of the fold lanes (lep5::upd16 / prob16) against the packed word of lep_core.h (branch_update): random walks
+// with every bias, long enough to saturate either way and to renormalise; returns 0 or 1 + the walk that differed
+extern "C" int emu_check_branch16(int walks) {
+    uint64_t rs = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 11); };
+    for (int w = 0; w < walks; ++w) {
+        uint32_t a = lepdev::kBranchInit, b = lep5::kBranchInit16;
+        const uint32_t bias = (w % 9) * 32;   // 0: always false ... 256: always true
+        for (int i = 0; i < 3000; ++i) {
+            if (lep5::prob16(b) != (a >> 16)) return 1 + w;
+            uint32_t obs = (rnd() % 256) < bias ? 1u : 0u;
+            if (w % 7 == 3 && i > 300 && i < 310) obs ^= 1u;   // a few surprises after saturation
+            a = lepdev::branch_update(a, (int)obs);
+            b = lep5::upd16(b, obs);
+        }
+    }
+    return 0;
+}

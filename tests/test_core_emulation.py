@@ -1189,3 +1189,9 @@ def test_deferred_bool_writer_equals_the_serial_one(emu):
     """lep5::BoolEnc5 -- the lane-per-segment writer's deferred byte output and carry cache -- writes the bytes of
     lepdev::BoolCoder<false> (boolwriter.hh:48-118) for 12,000 random and adversarial bin sequences, overflow verdicts included"""
     assert emu.emu_check_bool_writer5(12000) == 0
+
+
+def test_sixteen_bit_branch_equals_the_packed_word(emu):
+    """the fold lanes keep a Branch as two counts (lep5::upd16 / prob16, the saturated-true state as t = 0): same probabilities
+    as lepdev::branch_update (branch.hh:82-100) along 900 random walks of every bias, saturation and renormalisation included"""
+    assert emu.emu_check_branch16(900) == 0
