@@ -63,12 +63,14 @@ WDEV uint32_t thresh_entry(uint32_t tbits, int n, int pcls, int lt, int u) {
 //   EN  (2 x 4 bytes, horizontal then vertical): nzq | ne << 3            -> three probabilities
 //   DC  (6 x 4 bytes): word 0 = unit 0 of an entry like a coefficient's with k = a, bsr = b17 -> the units' probabilities
 constexpr int kKeyRec = 4, kNzRec = 8, kEnRec = 8, kDcRec = 24;
+constexpr int kAtRows = 65;   // rows of a tile in the array of places: 63 coefficient rows, the DC entry, the DC sign byte
 
 struct SegPlan5 {            // one per segment, device memory; written by plan5 from the counts
     uint64_t arena_off;      // byte offset of the segment's entry arena (16-byte aligned)
     uint64_t bins_off;       // offset of the segment's bin list, in bins (uint16)
     uint32_t sign_base[2], sign_cnt[2];       // byte streams, relative to arena_off
     uint32_t key_base, nz_base, en_base, dc_base;   // byte offsets of the sparse regions
+    uint32_t at_base, ntiles;                       // the places emit gave out, for gather: [tile][65 rows][64 lanes] dwords
     uint32_t nblocks;        // block ordinals (coded blocks of the segment)
     uint32_t bins_cap;       // room in the bin list
     uint32_t nbins;          // bins written by gather (without the start marker and the stop bins)
@@ -488,7 +490,7 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
 enum { kCount = 0, kEmit = 1, kGather = 2 };
 
 struct Walk5Shared {
-    uint32_t cur[32 * 65], abv[32 * 65];   // transposed tiles: dword i (coefficients 2i, 2i + 1 in aligned order) of lane c at [i * 65 + c];
+    uint32_t cur[32 * 65];                 // transposed tile: dword i (coefficients 2i, 2i + 1 in aligned order) of lane c at [i * 65 + c];
                                            // column 64 = the block left of lane 0 (the previous tile's last one)
     uint16_t TB[8 * 65];                   // where the lane's next threshold unit of class lt goes (relative to the tile's first)
     uint32_t cursor[2 * kRows * kClasses]; // units already given out, per colour index / row / class
@@ -496,7 +498,9 @@ struct Walk5Shared {
     int32_t icos_x[64], icos_y[64];        // the component's quantisation-derived tables (a load from the image descriptor on the
     uint16_t q[64];                        // critical path costs a trip to HBM: they are staged when the component changes)
     uint8_t thr[64];
+    uint32_t abv[32 * 65];                 // the tile of the row above (emit only: count and gather launch without it)
 };
+constexpr size_t kWalkLdsNoAbove = sizeof(Walk5Shared) - sizeof(uint32_t) * 32 * 65;
 
 // The walk's LDS block.  On the GPU it is the kernel's dynamic LDS, named directly at every use: a pointer to it kept in the
 // walker object loses its address space as soon as that object's address is taken anywhere, and every access then becomes a
@@ -564,6 +568,8 @@ struct Walk5 {
     uint32_t sign_pos[2];      // sign bytes given out per colour index
     uint32_t nbins;            // gather: bins written; count: bins an encoder will need (upper bound through the DC term)
     int status;
+    uint32_t tile_no;          // tiles walked so far
+    uint32_t* AT;              // emit / gather: the segment's [tile][65][64] array of places
     uint32_t sign_base[2], key_base, nz_base, en_base, dc_base;   // the plan's offsets (read once: a load per tile from the plan would sit on the critical path)
 
     WDEV uint32_t* units() const { return reinterpret_cast<uint32_t*>(arena); }
@@ -626,7 +632,7 @@ struct Walk5 {
             for (int k = 0; k < 32; ++k) {
                 const int d = k * 64 + l, b = d >> 5;
                 regs[LEP_LI(l)].c[k] = b < t.nb ? gld(src + d) : 0u;
-                regs[LEP_LI(l)].a[k] = (asrc && b < t.nb && MODE != kCount) ? gld(asrc + d) : 0u;
+                regs[LEP_LI(l)].a[k] = (asrc && b < t.nb && MODE == kEmit) ? gld(asrc + d) : 0u;
             }
         }
     }
@@ -640,7 +646,7 @@ struct Walk5 {
         LANES(l) {   // keep the last column of the previous tile as "left of lane 0"
             if (l < 32) {
                 S.cur[l * 65 + 64] = first_of_row ? 0u : S.cur[l * 65 + 63];
-                S.abv[l * 65 + 64] = first_of_row ? 0u : S.abv[l * 65 + 63];
+                if (MODE == kEmit) S.abv[l * 65 + 64] = first_of_row ? 0u : S.abv[l * 65 + 63];
             }
             if (l == 0) { if (first_of_row) S.ns[64] = NSum{}; else S.ns[64] = S.ns[63]; }
         }
@@ -650,7 +656,7 @@ struct Walk5 {
             for (int k = 0; k < 32; ++k) {
                 const int d = k * 64 + l, b = d >> 5, i = d & 31;
                 S.cur[i * 65 + b] = regs[LEP_LI(l)].c[k];
-                S.abv[i * 65 + b] = regs[LEP_LI(l)].a[k];
+                if (MODE == kEmit) S.abv[i * 65 + b] = regs[LEP_LI(l)].a[k];
             }
         }
         LSYNC();
@@ -669,6 +675,7 @@ struct Walk5 {
         LV(NSum, nsa);            // the summary of the block above
 
         // gather: the block's sparse records (7x7 count, edge counts, DC units) are requested now and used after phase 1
+        LV(uint32_t, rdce); LV(uint32_t, rdcs);
         LV(uint32_t, rnz0); LV(uint32_t, rnz1); LV(uint32_t, ren0); LV(uint32_t, ren1); LV(uint32_t, rdc0); LV(uint32_t, rdc1); LV(uint32_t, rdc2);
         if (MODE == kGather) {
             LANES(l) if (l < nb) {
@@ -676,6 +683,7 @@ struct Walk5 {
                 const uint32_t* r2 = reinterpret_cast<const uint32_t*>(arena + en_base) + 2 * (ord0 + l);
                 const uint32_t* r3 = reinterpret_cast<const uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
                 L(rnz0) = gld(r1); L(rnz1) = gld(r1 + 1); L(ren0) = gld(r2); L(ren1) = gld(r2 + 1); L(rdc0) = gld(r3); L(rdc1) = gld(r3 + 1); L(rdc2) = gld(r3 + 2);
+                L(rdce) = gld(AT + ((size_t)tile_no * kAtRows + 63) * 64 + l); L(rdcs) = gld(AT + ((size_t)tile_no * kAtRows + 64) * 64 + l);
             }
         }
         // ---- phase 1a: own numbers ---------------------------------------------------------------------------------
@@ -719,13 +727,13 @@ struct Walk5 {
             }
             L(nz) = n7; L(neh) = nh; L(nev) = nv; L(eobx) = ex; L(eoby) = ey; L(lbins) = lb;
             L(nsig) = a ? n7 + nh + nv + 1 : 0;
-            if (MODE != kCount && has_above && a) L(nsa) = gld_ns(&narow[x0 + l]);   // (written when that row was walked)
+            if (MODE == kEmit && has_above && a) L(nsa) = gld_ns(&narow[x0 + l]);   // (written when that row was walked)
             else L(nsa) = NSum{};
         }
         // ---- phase 1b: IDCT without DC, neighbour summary (block_context.hh:44-78) -------------------------------------
         struct Px { int16_t r0[8], r1[8], c0[8], c1[8]; };   // pixel rows 0, 1 and columns 0, 1 of the block without its DC
         LV(Px, px);
-        if (MODE != kCount) {
+        if (MODE == kEmit) {
             LANES(l) if (L(act)) {
                 const uint16_t* q = S.q;
                 constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
@@ -786,7 +794,11 @@ struct Walk5 {
             if (L(act)) {
                 const bool has_left = x0 + l > 0;
                 const int dc = tile_get(S.cur, 49, l);
-                if (MODE != kCount) {
+                if (MODE == kGather) {   // what emit worked out: the DC entry and its sign byte
+                    e0 = (int32_t)L(rdce); sgn = (int)L(rdcs);
+                    const int len = (e0 >> 14) & 15, nres = (e0 >> 10) & 15;
+                    bins_here = (len < 11 ? len + 1 : 11) + (len ? 1 : 0) + nres;
+                } else if (MODE == kEmit) {
                     const NSum& nl = S.ns[(l + 64) % 65];
                     const NSum& na = L(nsa);
                     int nzctx = 0;
@@ -879,8 +891,8 @@ struct Walk5 {
         // gather works one row behind: the probabilities of row r are requested when its places are known and turned into bins
         // while row r + 1 is worked out (a load on the critical path costs more than everything else in the row)
         LV(uint32_t, p_e); LV(uint32_t, p_te); LV(uint32_t, p_at); LV(uint32_t, p_tat); LV(int, p_cf); LV(uint32_t, p_w0); LV(uint32_t, p_w1); LV(uint32_t, p_tw); LV(uint32_t, p_sg);
-        LV(uint32_t, enw);
-        LANES(l) { L(p_e) = 0; L(enw) = 0; }
+        LV(uint32_t, enw); LV(uint32_t, at_next);
+        LANES(l) { L(p_e) = 0; L(enw) = 0; L(at_next) = MODE == kGather ? gld(AT + (size_t)tile_no * kAtRows * 64 + l) : 0u; }
         for (int row = 0; row < 63; ++row) {
             const bool edge = row >= 49;
             const int eg = row >= 56 ? 1 : 0, j = edge ? row - 49 - eg * 7 : 0;
@@ -907,7 +919,7 @@ struct Walk5 {
                     const int v = iabs(cf), len = bitlen((uint32_t)v), lc = len > 11 ? 11 : len;
                     int bsr = 0, nres = lc > 1 ? lc - 1 : 0;
                     if (!edge) {
-                        if (MODE != kCount) {
+                        if (MODE == kEmit) {
                             const bool has_left = x0 + l > 0;
                             int prior = 0;
                             if (has_left && has_above) prior = (uint16_t)((iabs(tile_get(S.cur, row, (l + 64) % 65)) + iabs(tile_get(S.abv, row, l))) * 13 + 6 * iabs(tile_get(S.abv, row, (l + 64) % 65))) >> 5;
@@ -920,7 +932,7 @@ struct Walk5 {
                     } else {
                         const int thr = S.thr[coord];
                         int pcls = 0;
-                        if (MODE != kCount) {
+                        if (MODE == kEmit) {
                             const bool nbr_ok = horizontal ? has_above : (x0 + l > 0);
                             int32_t prior = 0;
                             if (nbr_ok) {
@@ -964,8 +976,15 @@ struct Walk5 {
                 LANES(l) if (L(coded)) lds_add(&S.cursor[stream_id(ci, row, L(kk))], (uint32_t)L(nn));
                 continue;
             }
-            // rank the lanes of every (row, class) in block order: the entry's place in its stream
             LV(uint32_t, at);
+            if (MODE == kGather) {   // the places emit gave out: the row's were requested a row ago, the next row's are requested now
+                const uint64_t rem = lepwave::wave_ballot(coded);
+                const bool skip = !rem && !edge;
+                const int next_row = skip ? 49 : row + 1;
+                LANES(l) { L(at) = L(at_next); if (next_row < 63) L(at_next) = gld(AT + ((size_t)tile_no * kAtRows + next_row) * 64 + l); }
+                if (skip) { row = 48; continue; }
+            } else {
+            // rank the lanes of every (row, class) in block order: the entry's place in its stream
             uint64_t rem = lepwave::wave_ballot(coded);
             if (!rem && !edge) { row = 48; continue; }   // no block of the tile has a non-zero left: the interior is done
             while (rem) {
@@ -988,6 +1007,8 @@ struct Walk5 {
                 LANES(l) if (l == 0) S.cursor[sid] = b0 + (uint32_t)total;
                 LSYNC();
                 rem &= ~m1;
+            }
+            LANES(l) if (L(coded)) gst(AT + ((size_t)tile_no * kAtRows + row) * 64 + l, L(at));   // for gather
             }
             // emit: write the units; gather: request this row's probabilities, turn the PREVIOUS row's into bins
             LANES(l) {
@@ -1040,7 +1061,10 @@ struct Walk5 {
                 uint32_t* rec = reinterpret_cast<uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
                 const uint32_t e = (uint32_t)L(dc_e0);
                 const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
-                if (MODE == kEmit) { gst(rec, e); gst(signs + L(sp)++, (uint8_t)L(dc_sign)); }
+                if (MODE == kEmit) {
+                    gst(rec, e); gst(signs + L(sp)++, (uint8_t)L(dc_sign));
+                    gst(AT + ((size_t)tile_no * kAtRows + 63) * 64 + l, e); gst(AT + ((size_t)tile_no * kAtRows + 64) * 64 + l, (uint32_t)L(dc_sign));
+                }
                 else {
                     uint32_t w = L(rdc0);
                     for (int q = 0; q < nexp; ++q) {
@@ -1063,6 +1087,7 @@ struct Walk5 {
         sign_pos[ci] += (uint32_t)nsig_tile;
         nbins += (uint32_t)bins_tile;
         ord0 += (uint32_t)nb;
+        ++tile_no;
         return 0;
     }
 
@@ -1105,7 +1130,8 @@ struct Walk5 {
         img = image; sh = shared; plan = pl; status = 0;
         arena = (MODE != kCount) ? arena_base + pl->arena_off : nullptr;
         bins = (MODE == kGather) ? bins_base + pl->bins_off : nullptr;
-        ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0;
+        ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0; tile_no = 0;
+        AT = MODE != kCount ? reinterpret_cast<uint32_t*>(arena + pl->at_base) : nullptr;
         if (MODE != kCount) { sign_base[0] = pl->sign_base[0]; sign_base[1] = pl->sign_base[1]; key_base = pl->key_base; nz_base = pl->nz_base; en_base = pl->en_base; dc_base = pl->dc_base; }
         LANES(l) {   // emit / gather: a cursor is the absolute place of the stream's next unit
             for (int i = l; i < 2 * kRows * kClasses; i += 64) LEP5_WSH(this).cursor[i] = MODE == kCount ? 0u : pl->base[i];
@@ -1136,7 +1162,7 @@ struct Walk5 {
 // ---- plan: counts -> arena layout --------------------------------------------------------------------------------------------
 // counts of one segment as the count walk leaves them: [kStreams] units per stream, then sign bytes of the two colour indices,
 // block ordinals, bins (an upper bound through the DC term)
-constexpr int kCountWords = kStreams + 4;
+constexpr int kCountWords = kStreams + 5;   // ... and the number of tiles
 // one segment's layout (arena_off / bins_off are filled in by the prefix pass over the segments)
 WDEV void plan_segment(const uint32_t* counts, SegPlan5* P) {
     uint32_t at = 0;
@@ -1151,6 +1177,9 @@ WDEV void plan_segment(const uint32_t* counts, SegPlan5* P) {
     P->nz_base = bytes; bytes += P->nblocks * (uint32_t)kNzRec;
     P->en_base = bytes; bytes += P->nblocks * (uint32_t)kEnRec;
     P->dc_base = bytes; bytes += P->nblocks * (uint32_t)kDcRec;
+    bytes = (bytes + 255u) & ~255u;
+    P->ntiles = counts[kStreams + 4];
+    P->at_base = bytes; bytes += P->ntiles * (uint32_t)(kAtRows * 64 * 4);
     P->arena_bytes = (bytes + 255u) & ~255u;
     P->bins_cap = (counts[kStreams + 3] + 127u) & ~127u;
     P->nbins = 0; P->status = 0; P->arena_off = 0; P->bins_off = 0;
@@ -1160,7 +1189,7 @@ template <class W>
 WDEV void export_counts(const W& w, const Walk5Shared* sh, uint32_t* counts) {
     LANES(l) {
         for (int i = l; i < kStreams; i += 64) counts[i] = sh->cursor[i];
-        if (l == 0) { counts[kStreams] = w.sign_pos[0]; counts[kStreams + 1] = w.sign_pos[1]; counts[kStreams + 2] = w.ord0; counts[kStreams + 3] = w.nbins; }
+        if (l == 0) { counts[kStreams] = w.sign_pos[0]; counts[kStreams + 1] = w.sign_pos[1]; counts[kStreams + 2] = w.ord0; counts[kStreams + 3] = w.nbins; counts[kStreams + 4] = w.tile_no; }
     }
 }
 

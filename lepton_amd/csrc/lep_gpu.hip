@@ -202,23 +202,33 @@ __global__ __launch_bounds__(64) void lep_enc5_fold_coef_kernel(const lep5::SegP
     if (!__ballot(work)) return;
     lep5::fold_coef_wave(plans, arena, grp * 64, nseg, sid, reinterpret_cast<lep5::FoldShared*>(&shc));
 }
-// fold, everything else (long dependent chains first): sign, threshold, DC, 7x7 count, edge counts; 52 KB of LDS
-__global__ __launch_bounds__(64) void lep_enc5_fold_misc_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, uint32_t* thresh_models, int nseg, int groups) {
+// fold, the other chains, by the LDS their Branches take (a kernel's resident wavefronts are what its largest job leaves room for):
+//   small  sign chains (long dependent chains: first), threshold chains (Branches in HBM), edge non-zero counts     12 KB
+//   big    DC chains, 7x7 non-zero counts                                                                          25 KB
+struct Fold5SmallShared { uint16_t slice[lep5::kEdgeNzSlice * 64]; };
+__global__ __launch_bounds__(64) void lep_enc5_fold_small_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, uint32_t* thresh_models, int nseg, int groups) {
+    __shared__ Fold5SmallShared shs;
+    lep5::FoldShared* sh = reinterpret_cast<lep5::FoldShared*>(&shs);
+    const int grp = (int)blockIdx.x % groups;
+    int job = (int)blockIdx.x / groups;
+    const int seg0 = grp * 64;
+    if (job < 2) { lep5::fold_sign_wave(plans, arena, seg0, nseg, job, sh); return; }
+    job -= 2;
+    if (job < 12) { const int ci = job / 6, lt = 2 + job % 6; lep5::fold_thresh_wave(plans, arena, thresh_models, seg0, nseg, lep5::stream_id(ci, 63, lt), ci, sh); return; }
+    job -= 12;
+    lep5::fold_edgenz_wave(plans, arena, seg0, nseg, job / 16, (job / 8) & 1, job & 7, sh);   // 32 jobs
+}
+constexpr int kFold5SmallJobs = 2 + 12 + 32;
+__global__ __launch_bounds__(64) void lep_enc5_fold_big_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, int nseg, int groups) {
     __shared__ lep5::FoldShared sh;
     const int grp = (int)blockIdx.x % groups;
     int job = (int)blockIdx.x / groups;
     const int seg0 = grp * 64;
-    if (job < 2) { lep5::fold_sign_wave(plans, arena, seg0, nseg, job, &sh); return; }
-    job -= 2;
-    if (job < 12) { const int ci = job / 6, lt = 2 + job % 6; lep5::fold_thresh_wave(plans, arena, thresh_models, seg0, nseg, lep5::stream_id(ci, 63, lt), ci, &sh); return; }
-    job -= 12;
     if (job < 12) { lep5::fold_dc_wave(plans, arena, seg0, nseg, job, &sh); return; }
     job -= 12;
-    if (job < 20) { lep5::fold_nz_wave(plans, arena, seg0, nseg, job / 10, job % 10, &sh); return; }
-    job -= 20;
-    lep5::fold_edgenz_wave(plans, arena, seg0, nseg, job / 16, (job / 8) & 1, job & 7, &sh);   // 32 jobs
+    lep5::fold_nz_wave(plans, arena, seg0, nseg, job / 10, job % 10, &sh);   // 20 jobs
 }
-constexpr int kFold5MiscJobs = 2 + 12 + 12 + 20 + 32;
+constexpr int kFold5BigJobs = 12 + 20;
 // write: lane = segment
 __global__ __launch_bounds__(64) void lep_enc5_write_kernel(const lep5::SegPlan5* __restrict__ plans, const uint16_t* __restrict__ bins, const SegDev* __restrict__ segs,
                                                           int nseg, uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* nbins_out) {
@@ -307,8 +317,8 @@ struct lep_gpu {
     bool timed = false;
     bool released = false;   // device side already given back (by lep_gpu_destroy or by the exit handler)
     int enc5_min = 64;       // launches of at least this many segments take the split-phase encoder (lep_enc5.h); LEP_ENC5_MIN (0 = never)
-    hipStream_t stream2 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     hipEvent_t ev_stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the last split-phase launch
     int nstage = 0;
     int enc_waves = 0;       // the same choice for the encoder (LEP_ENC_WAVES = 4 | 8; 2 = the two-wavefronts-per-segment kernel)
@@ -377,8 +387,10 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     lep_gpu::Arena& A = g->arena[g->cur];
     if (!g->stream2) {
         HIPCHK(g, hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
+        HIPCHK(g, hipStreamCreateWithFlags(&g->stream3, hipStreamNonBlocking));
         HIPCHK(g, hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
         HIPCHK(g, hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
+        HIPCHK(g, hipEventCreateWithFlags(&g->ev_join3, hipEventDisableTiming));
         for (auto& e : g->ev_stage) HIPCHK(g, hipEventCreate(&e));
     }
     const size_t o_counts = ((size_t)nseg * sizeof(lep5::SegPlan5) + 255) & ~(size_t)255,
@@ -390,7 +402,7 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     const int groups = (nseg + 63) / 64;
     g->nstage = 0;
     HIPCHK(g, hipEventRecord(g->ev_stage[0], st));
-    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kCount>), dim3(nseg), dim3(64), sizeof(lep5::Walk5Shared), st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)nullptr, (uint16_t*)nullptr, counts);
+    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kCount>), dim3(nseg), dim3(64), lep5::kWalkLdsNoAbove, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)nullptr, (uint16_t*)nullptr, counts);
     hipLaunchKernelGGL(lep_enc5_plan_kernel, dim3(groups), dim3(64), 0, st, (const uint32_t*)counts, plans, nseg);
     hipLaunchKernelGGL(lep_enc5_offsets_kernel, dim3(1), dim3(64), 0, st, plans, nseg, d_tot);
     // the threshold Branches are the only model state in HBM: 2 MB per segment, reset while the count pass is looked at
@@ -405,13 +417,17 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     HIPCHK(g, hipEventRecord(g->ev_stage[2], st));
     HIPCHK(g, hipEventRecord(g->ev_fork, st));
     HIPCHK(g, hipStreamWaitEvent(g->stream2, g->ev_fork, 0));
-    hipLaunchKernelGGL(lep_enc5_fold_misc_kernel, dim3((unsigned)groups * kFold5MiscJobs), dim3(64), 0, g->stream2, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries,
+    HIPCHK(g, hipStreamWaitEvent(g->stream3, g->ev_fork, 0));
+    hipLaunchKernelGGL(lep_enc5_fold_small_kernel, dim3((unsigned)groups * kFold5SmallJobs), dim3(64), 0, g->stream2, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries,
                        (uint32_t*)A.d_models, nseg, groups);
+    hipLaunchKernelGGL(lep_enc5_fold_big_kernel, dim3((unsigned)groups * kFold5BigJobs), dim3(64), 0, g->stream3, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups);
     hipLaunchKernelGGL(lep_enc5_fold_coef_kernel, dim3((unsigned)groups * 1260u), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups);
     HIPCHK(g, hipEventRecord(g->ev_join, g->stream2));
+    HIPCHK(g, hipEventRecord(g->ev_join3, g->stream3));
     HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
+    HIPCHK(g, hipStreamWaitEvent(st, g->ev_join3, 0));
     HIPCHK(g, hipEventRecord(g->ev_stage[3], st));
-    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kGather>), dim3(nseg), dim3(64), sizeof(lep5::Walk5Shared), st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)A.d_binlist, counts);
+    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kGather>), dim3(nseg), dim3(64), lep5::kWalkLdsNoAbove, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)A.d_binlist, counts);
     HIPCHK(g, hipEventRecord(g->ev_stage[4], st));
     hipLaunchKernelGGL(lep_enc5_write_kernel, dim3(groups), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (const uint16_t*)A.d_binlist, d_seg, nseg, d_streams, d_stream_len,
                        d_status, g->d_bins);
@@ -575,7 +591,9 @@ static void release_device_side(lep_gpu* g) {
     for (auto& e : g->ev_stage) if (e) (void)hipEventDestroy(e);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
+    if (g->ev_join3) (void)hipEventDestroy(g->ev_join3);
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
+    if (g->stream3) (void)hipStreamDestroy(g->stream3);
     for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffprog[0], g->d_huffprog[1], g->d_huffprogdec, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
         if (p) (void)hipFree(p);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
