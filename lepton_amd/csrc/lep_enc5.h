@@ -140,9 +140,12 @@ struct FoldLane {
         return prob16(w);
     }
 };
+// where lane l keeps its Branches inside a row of 64: lanes l and l + 32 share a dword (the LDS serves 32 lanes a cycle: two
+// lanes of one half-wave in one bank, at different rows, would be a conflict)
+WDEV int fold_col(int l) { return ((l & 31) << 1) | (l >> 5); }
 WDEV void fold_init(FoldShared* sh, int words_per_lane) {
     LANES(l) {
-        for (int i = 0; i < words_per_lane; ++i) sh->slice[i * 64 + l] = (uint16_t)kBranchInit16;
+        for (int i = 0; i < words_per_lane; ++i) sh->slice[i * 64 + fold_col(l)] = (uint16_t)kBranchInit16;
     }
     LSYNC();
 }
@@ -180,7 +183,7 @@ WDEV void fold_coef_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
         if (seg < nseg) {
             const SegPlan5& P = plans[seg];
             uint32_t* units = reinterpret_cast<uint32_t*>(arena + P.arena_off);
-            FoldLane fl{sh->slice + l};
+            FoldLane fl{sh->slice + fold_col(l)};
             const uint32_t n = P.status ? 0u : P.cnt[sid];
             uint32_t* p = units + P.base[sid];   // 16-byte aligned, padded to whole groups of four
             U4 nxt = n ? ld4(p) : U4{0, 0, 0, 0};
@@ -236,7 +239,7 @@ WDEV void fold_sign_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
         if (seg < nseg) {
             const SegPlan5& P = plans[seg];
             uint8_t* s = arena + P.arena_off + P.sign_base[ci];
-            FoldLane fl{sh->slice + l};
+            FoldLane fl{sh->slice + fold_col(l)};
             const uint32_t n = P.status ? 0u : P.sign_cnt[ci];
             uint32_t* p = reinterpret_cast<uint32_t*>(s);   // the stream starts on 16 bytes and is padded to 16
             U4 nxt = n ? ld4(p) : U4{0, 0, 0, 0};
@@ -269,7 +272,7 @@ WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
             const SegPlan5& P = plans[seg];
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.nz_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
-            FoldLane fl{sh->slice + l};
+            FoldLane fl{sh->slice + fold_col(l)};
             const uint32_t key = (uint32_t)ci | ((uint32_t)ctxbin << 1), nb = P.status ? 0u : P.nblocks;
             U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0}, nr0 = nb ? ld4(rec) : U4{0, 0, 0, 0}, nr1 = nb ? ld4(rec + 4) : U4{0, 0, 0, 0};
             for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
@@ -303,7 +306,7 @@ WDEV void fold_edgenz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int 
             const SegPlan5& P = plans[seg];
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.en_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
-            FoldLane fl{sh->slice + l};
+            FoldLane fl{sh->slice + fold_col(l)};
             const uint32_t nb = P.status ? 0u : P.nblocks;
             U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0}, nr0 = nb ? ld4(rec) : U4{0, 0, 0, 0}, nr1 = nb ? ld4(rec + 4) : U4{0, 0, 0, 0};
             for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
@@ -336,7 +339,7 @@ WDEV void fold_dc_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
             const SegPlan5& P = plans[seg];
             uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.dc_base);
             const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
-            FoldLane fl{sh->slice + l};
+            FoldLane fl{sh->slice + fold_col(l)};
             const uint32_t nb = P.status ? 0u : P.nblocks;
             U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0};
             uint32_t ne0 = nb ? rec[0] : 0u, ne1 = nb > 1 ? rec[6] : 0u, ne2 = nb > 2 ? rec[12] : 0u, ne3 = nb > 3 ? rec[18] : 0u;
@@ -448,22 +451,28 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
                 BoolEnc5 bc;
                 bc.init(streams + sd.stream_off, sd.stream_cap);
                 bc.bin(0, 128);   // the start marker (vpx_start_encode)
-                // eight bins per dwordx4, the next eight requested before these are coded; the body has no per-bin conditions (a
-                // segment's last 0..7 bins take the loop behind it)
-                U4 nxt = ld4(b);
+                // 32 bins (a 64-byte sector of this lane's list) per round: the NEXT round's four dwordx4 are requested before this
+                // round's bins are coded -- a round is ~3,500 cycles of recurrence, enough to cover a trip to HBM.  The body has no
+                // per-bin conditions; a segment's last 0..31 bins take the loop behind it.  (The list has room to the next
+                // multiple of 128 bins, and the arena behind it: the look-ahead never leaves it.)
+                U4 n0 = ld4(b), n1 = ld4(b + 4), n2 = ld4(b + 8), n3 = ld4(b + 12);
                 uint32_t i = 0;
-                for (; i + 8 <= n; i += 8) {
-                    const U4 g = nxt;
-                    nxt = ld4(b + (i >> 1) + 4);   // (the list has room to the next multiple of 128 bins: never outside the arena)
-                    bc.bin((g.x >> 8) & 1u, g.x & 255u); bc.bin((g.x >> 24) & 1u, (g.x >> 16) & 255u);
-                    bc.bin((g.y >> 8) & 1u, g.y & 255u); bc.bin((g.y >> 24) & 1u, (g.y >> 16) & 255u);
-                    bc.flush();
-                    bc.bin((g.z >> 8) & 1u, g.z & 255u); bc.bin((g.z >> 24) & 1u, (g.z >> 16) & 255u);
-                    bc.bin((g.w >> 8) & 1u, g.w & 255u); bc.bin((g.w >> 24) & 1u, (g.w >> 16) & 255u);
-                    bc.flush();
+#define LEP5_CODE8(g)                                                                                          \
+    bc.bin((g.x >> 8) & 1u, g.x & 255u); bc.bin((g.x >> 24) & 1u, (g.x >> 16) & 255u);                        \
+    bc.bin((g.y >> 8) & 1u, g.y & 255u); bc.bin((g.y >> 24) & 1u, (g.y >> 16) & 255u);                        \
+    bc.flush();                                                                                                \
+    bc.bin((g.z >> 8) & 1u, g.z & 255u); bc.bin((g.z >> 24) & 1u, (g.z >> 16) & 255u);                        \
+    bc.bin((g.w >> 8) & 1u, g.w & 255u); bc.bin((g.w >> 24) & 1u, (g.w >> 16) & 255u);                        \
+    bc.flush();
+                for (; i + 32 <= n; i += 32) {
+                    const U4 g0 = n0, g1 = n1, g2 = n2, g3 = n3;
+                    const uint32_t* nx = b + (i >> 1) + 16;
+                    n0 = ld4(nx); n1 = ld4(nx + 4); n2 = ld4(nx + 8); n3 = ld4(nx + 12);
+                    LEP5_CODE8(g0) LEP5_CODE8(g1) LEP5_CODE8(g2) LEP5_CODE8(g3)
                 }
+#undef LEP5_CODE8
                 {
-                    const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+                    const uint32_t w[16] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w};
                     for (int q = 0; i < n; ++i, ++q) {
                         const uint32_t e = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
                         bc.bin((e >> 8) & 1u, e & 255u);

@@ -421,7 +421,7 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     // dependent-instruction latency), and the writer needs the same time for 64 segments as for 8192.  So the segments go
     // through emit .. write in GROUPS, each group on a stream of its own: one group's writer and folds run beside the next
     // group's walks.  (LEP_ENC5_GROUPS=1: one group, with the stage boundaries recorded for lep_gpu_last_stage_ms.)
-    int G = g->enc5_groups > 0 ? g->enc5_groups : (nseg >= 4096 ? 4 : (nseg >= 1024 ? 2 : 1));
+    int G = g->enc5_groups > 0 ? g->enc5_groups : 1;   // measured (MI355X, 1024 x 4K, profiles/r04l_*): 1 group 784 ms, 2: 875, 4: 1232 -- streams with grids this large do not share the chip
     if (G > 4) G = 4;
     if (G == 1) {
         HIPCHK(g, hipEventRecord(g->ev_stage[1], st));
