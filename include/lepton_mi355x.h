@@ -273,6 +273,12 @@ int lep_jpeg_plan(const lep_jpeg *j, int max_threads, lep_segment *segs, int ima
 /* -maxencodethreads / -minencodethreads / -evensplit (jpgcoder.cc:1064-1095): they change how many thread segments a file gets
  * and where they are cut, i.e. the .lep bytes; 0 / 0 / 0 leaves the reference's defaults (8, 1, by compressed size) */
 int lep_jpeg_set_encode_options(lep_jpeg *j, int max_threads, int min_threads, int even_split);
+/* `lepton -brotliheader` (src/lepton/jpgcoder.cc:1116-1119, 4038): container format version 2 -- the header is a brotli stream
+ * (BrotliCodec::Compress, src/io/BrotliCompression.cc:45-98, with the vendored brotli 1.0.0 encoder: compiled into the library from
+ * the reference's dependency tree when build() finds it) and the packets end with FF FE FF.  1 = the default (zlib).  Returns
+ * LEP_VERSION_UNSUPPORTED for a version this build cannot write; lep_container_can_write_version asks without a file. */
+int lep_jpeg_set_container_version(lep_jpeg *j, int version);
+int lep_container_can_write_version(int version);
 /* whole .lep file from the per-segment streams (header + mux + trailer) */
 int lep_jpeg_write_lep(const lep_jpeg *j, int max_threads, const lep_bytes *streams, int nstreams, lep_bytes *out);
 /* The Huffman half of the reference's default round-trip check (src/lepton/validation.cc:97-218; `lepton` without

@@ -238,5 +238,5 @@ EXPORTS = [
     "lep_jpeg_check_restores", "lep_batch_debug_poison", "lep_jpeg_plan_handoffs", "lep_file_consumed", "lep_chained_file_follows", "lep_file_open_next",
     "lep_file_recode_plan_progressive", "lep_file_recode_finish_progressive", "lep_gpu_huffman_progressive_encode_device",
     "lep_jpeg_open_gpu_progressive", "lep_jpeg_finish_gpu_progressive", "lep_gpu_huffman_progressive_decode_device",
-    "lep_jpeg_plan_progressive_check", "lep_gpu_last_stage_ms",
+    "lep_jpeg_plan_progressive_check", "lep_gpu_last_stage_ms", "lep_jpeg_set_container_version", "lep_container_can_write_version",
 ]

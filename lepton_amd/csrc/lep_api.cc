@@ -199,6 +199,17 @@ int lep_jpeg_set_encode_options(lep_jpeg* j, int max_threads, int min_threads, i
     return 0;
 }
 
+// `lepton -brotliheader` (jpgcoder.cc:1116-1119): container format 2 -- brotli header, packet end marker.  Needs the reference's own
+// brotli encoder in the library (build() compiles it from where it lies); LEP_VERSION_UNSUPPORTED when it is not there.
+int lep_jpeg_set_container_version(lep_jpeg* j, int version) {
+    if (!j) return LEP_ASSERTION_FAILURE;
+    if (version != 1 && version != 2) return LEP_VERSION_UNSUPPORTED;
+    if (version == 2 && !lep::brotli_encoder_available()) return LEP_VERSION_UNSUPPORTED;
+    j->opt.format_version = version;
+    return 0;
+}
+int lep_container_can_write_version(int version) { return version == 1 || (version == 2 && lep::brotli_encoder_available()) ? 1 : 0; }
+
 int lep_jpeg_is_progressive(const lep_jpeg* j) { return j->jf.progressive_needed ? 1 : 0; }
 
 int lep_jpeg_plan(const lep_jpeg* j, int max_threads, lep_segment* segs, int image_index) {
@@ -236,7 +247,7 @@ int lep_jpeg_write_lep(const lep_jpeg* j, int max_threads, const lep_bytes* stre
     std::vector<std::vector<uint8_t>> st(nstreams);
     for (int i = 0; i < nstreams; ++i) st[i].assign(streams[i].data, streams[i].data + streams[i].len);
     std::vector<uint8_t> file;
-    int rc = lep::write_lep(j->jf, s, st, &file);
+    int rc = lep::write_lep(j->jf, s, st, &file, j->opt.format_version);
     if (rc) return rc;
     return to_bytes(file, out);
 }

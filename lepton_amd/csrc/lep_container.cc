@@ -326,14 +326,65 @@ void mux_streams(const std::vector<std::vector<uint8_t>>& streams, int version, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// BrotliCodec::Compress (src/io/BrotliCompression.cc:45-98) with the reference's own encoder: quality 10 (BrotliCompression.hh:47),
+// size hint, lgwin = lgblock = bit length of the size + 1, clamped to the encoder's window range
+#ifdef LEP_HAVE_BROTLI_ENC
+}  // namespace lep
+// The encoder's C ABI (brotli/encode.h of brotli 1.0.0), declared here so that nothing but the object files is needed to build:
+// they are compiled from the reference's dependency tree in this container and travel with the snapshot.
+extern "C" {
+struct BrotliEncoderStateStruct;
+typedef struct BrotliEncoderStateStruct BrotliEncoderState;
+BrotliEncoderState* BrotliEncoderCreateInstance(void* (*alloc)(void*, size_t), void (*dealloc)(void*, void*), void* opaque);
+int BrotliEncoderSetParameter(BrotliEncoderState* state, int param, uint32_t value);
+size_t BrotliEncoderMaxCompressedSize(size_t input_size);
+int BrotliEncoderCompressStream(BrotliEncoderState* state, int op, size_t* available_in, const uint8_t** next_in, size_t* available_out, uint8_t** next_out, size_t* total_out);
+int BrotliEncoderIsFinished(BrotliEncoderState* state);
+void BrotliEncoderDestroyInstance(BrotliEncoderState* state);
+}
+enum { BROTLI_OPERATION_PROCESS = 0, BROTLI_OPERATION_FINISH = 2, BROTLI_PARAM_QUALITY = 1, BROTLI_PARAM_LGWIN = 2, BROTLI_PARAM_LGBLOCK = 3, BROTLI_PARAM_SIZE_HINT = 5,
+       BROTLI_MIN_WINDOW_BITS = 10, BROTLI_MAX_WINDOW_BITS = 24 };
+namespace lep {
+bool brotli_encoder_available() { return true; }
+static bool brotli10(const std::vector<uint8_t>& in, std::vector<uint8_t>* out) {
+    BrotliEncoderState* st = BrotliEncoderCreateInstance(nullptr, nullptr, nullptr);
+    if (!st) return false;
+    size_t size = in.size();
+    BrotliEncoderSetParameter(st, BROTLI_PARAM_SIZE_HINT, (uint32_t)size);
+    BrotliEncoderSetParameter(st, BROTLI_PARAM_QUALITY, 10);
+    uint32_t lgwin = 1;
+    for (size_t t = size; t; t >>= 1) ++lgwin;
+    lgwin = std::min<uint32_t>(std::max<uint32_t>(lgwin, BROTLI_MIN_WINDOW_BITS), BROTLI_MAX_WINDOW_BITS);
+    BrotliEncoderSetParameter(st, BROTLI_PARAM_LGWIN, lgwin);
+    BrotliEncoderSetParameter(st, BROTLI_PARAM_LGBLOCK, lgwin);
+    out->resize(BrotliEncoderMaxCompressedSize(size) + 16);
+    const uint8_t* next_in = in.data();
+    uint8_t* next_out = out->data();
+    size_t avail_out = out->size(), total = 0;
+    bool ok = true;
+    for (;;) {
+        if (!BrotliEncoderCompressStream(st, size == 0 ? BROTLI_OPERATION_FINISH : BROTLI_OPERATION_PROCESS, &size, &next_in, &avail_out, &next_out, &total)) { ok = false; break; }
+        if (size == 0 && BrotliEncoderIsFinished(st)) break;
+    }
+    BrotliEncoderDestroyInstance(st);
+    if (ok) out->resize((size_t)(next_out - out->data()));
+    return ok;
+}
+#else
+bool brotli_encoder_available() { return false; }
+static bool brotli10(const std::vector<uint8_t>&, std::vector<uint8_t>*) { return false; }
+#endif
+
 int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::vector<std::vector<uint8_t>>& streams,
-              std::vector<uint8_t>* out) {
+              std::vector<uint8_t>* out, int format_version) {
+    if (format_version != 1 && format_version != 2) return EX_VERSION_UNSUPPORTED;
+    if (format_version == 2 && !brotli_encoder_available()) return EX_VERSION_UNSUPPORTED;   // said loudly: the system's brotli writes other bytes
     std::vector<uint8_t> payload = build_header_payload(jf, segs), z;
-    if (!zlib9(payload, &z)) return EX_OS_ERROR;
+    if (format_version == 1 ? !zlib9(payload, &z) : !brotli10(payload, &z)) return EX_OS_ERROR;
     out->clear();
     out->reserve(z.size() + 64);
     out->push_back(0xCF); out->push_back(0x84);
-    out->push_back(1);                                     // format version
+    out->push_back((uint8_t)format_version);
     out->push_back(jf.start_byte ? 'Y' : (jf.progressive_needed ? 'X' : 'Z'));   // jpgcoder.cc:4046-4052
     out->push_back((uint8_t)segs.size());
     out->insert(out->end(), 3, 0);
@@ -342,7 +393,7 @@ int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::v
     put_le32(*out, (uint32_t)z.size());
     out->insert(out->end(), z.begin(), z.end());
     out->insert(out->end(), {'C', 'M', 'P'});
-    mux_streams(streams, 1, out);
+    mux_streams(streams, format_version, out);
     put_le32(*out, (uint32_t)out->size() + 4);
     return 0;
 }

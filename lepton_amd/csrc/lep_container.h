@@ -13,7 +13,9 @@ struct EncodeOptions {
     unsigned min_threads = 1;    // -minencodethreads (jpgcoder.cc:1088)
     bool even_split = false;     // -evensplit        (jpgcoder.cc:1064)
     bool allow_progressive = true;   // build default -DDEFAULT_ALLOW_PROGRESSIVE (CMakeLists.txt:343)
+    int format_version = 1;      // 2 = `lepton -brotliheader` (jpgcoder.cc:1116-1119): brotli header, packet end marker
 };
+bool brotli_encoder_available();   // the vendored brotli 1.0.0 encoder was compiled into this library (build())
 
 struct LepFile {
     int version = 0;
@@ -37,8 +39,11 @@ std::vector<Handoff> plan_segments(const JpegFile& jf, const EncodeOptions& opt)
 std::vector<uint8_t> serialize_handoffs(const std::vector<Handoff>& segs);
 bool deserialize_handoffs(const uint8_t* d, size_t n, std::vector<Handoff>* out);
 void mux_streams(const std::vector<std::vector<uint8_t>>& streams, int version, std::vector<uint8_t>* out);
+// version 1: zlib header (vendored zlib 1.2.8 == system zlib at level 9: cmp-equal files); version 2: brotli header --
+// byte-equal to the reference's only with ITS encoder (dependencies/brotli 1.0.0, compiled in from where it lies when
+// build() finds it; the system's 1.0.9 writes other bytes): VERSION_UNSUPPORTED without it
 int write_lep(const JpegFile& jf, const std::vector<Handoff>& segs, const std::vector<std::vector<uint8_t>>& streams,
-              std::vector<uint8_t>* out);
+              std::vector<uint8_t>* out, int format_version = 1);
 int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t>* carried = nullptr);
 bool worker_bounds_exceed_arena(const LepFile& lf, size_t file_bytes);   // lep_container.cc
 int baseline_header_pass(LepFile* lf);                                   // jpeg_recode.cc: what recode_baseline_jpeg checks before it decodes a row

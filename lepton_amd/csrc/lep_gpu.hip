@@ -558,7 +558,7 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         // like the decoder: a launch that cannot fill 8 wavefronts per SIMD takes the 4-wave build (128 VGPRs, no spills)
         int waves = g->enc_waves;
         if (!waves) waves = nseg > 4608 ? 8 : (nseg <= g->enc_pair_max ? 2 : 4);
-        if (g->enc5_min > 0 && nseg >= g->enc5_min) {
+        if (g->enc5_min > 0 && !g->enc_waves && nseg >= g->enc5_min) {   // (LEP_ENC_WAVES asks for one of the single-kernel forms)
             if (int rc = launch_enc5(g, (const ImageDev*)(meta + o_img), (const SegDev*)(meta + o_seg), (const uint64_t*)(meta + o_ns), nseg, d_streams, d_stream_len, d_status, st)) return rc;
         }
         else if (waves == 2) {   // few segments: two wavefronts per segment (producer / bool coder), half the serial chain

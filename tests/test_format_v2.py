@@ -77,3 +77,51 @@ def test_gpu_v2_files_and_chained_streams(gpu_codec):
     assert st == [0] * (len(names) + 1)
     assert [hashlib.md5(b).hexdigest() for b in back[:-1]] == [MAN[n]["restored_md5"] for n in names]
     assert back[-1] == golden("c420_160x120")[0]
+
+
+def _write_v2(name, streams_of):
+    from lepton_amd import abi
+    from lepton_amd.codec import JpegImage
+
+    L = abi.lib()
+    img = JpegImage(golden(name)[0])
+    assert L.lep_jpeg_set_container_version(img.handle, 2) == 0
+    return img.write_lep(streams_of(img))
+
+
+WRITTEN_BY_THE_REFERENCE = [n for n in sorted(MAN) if not n.startswith(("chain", "concat", "narrowrst"))]
+
+
+@pytest.mark.parametrize("name", WRITTEN_BY_THE_REFERENCE)
+def test_v2_writer_equals_the_reference(name):
+    """`lepton -brotliheader` (jpgcoder.cc:1116-1119, 4038): format-2 files written here -- the header through the reference's own
+    brotli 1.0.0 encoder with BrotliCodec::Compress's parameters (src/io/BrotliCompression.cc:45-98), the packets closed with
+    FF FE FF -- are byte-equal to the files the reference binary wrote from the same JPEGs (tests/golden/v2, make_golden_v2.py)"""
+    from lepton_amd import abi
+
+    if not abi.lib().lep_container_can_write_version(2):
+        pytest.skip("this build of the library has no brotli 1.0.0 encoder (build() compiles it where /root/reference is)")
+    assert _write_v2(name, lambda img: ob.oracle_encode(img.desc, img.plan())[0]) == v2(name)
+
+
+def test_v2_writer_refuses_what_it_cannot_write():
+    from lepton_amd import abi
+    from lepton_amd.codec import JpegImage
+
+    L = abi.lib()
+    img = JpegImage(golden("c420_160x120")[0])
+    assert L.lep_jpeg_set_container_version(img.handle, 3) == 13      # ANS coding: VERSION_UNSUPPORTED, like the default reference build
+    assert L.lep_jpeg_set_container_version(img.handle, 1) == 0
+    assert L.lep_container_can_write_version(1) == 1 and L.lep_container_can_write_version(4) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_v2_writer_equals_the_reference(gpu_codec):
+    from lepton_amd import abi
+
+    if not abi.lib().lep_container_can_write_version(2):
+        pytest.skip("no brotli 1.0.0 encoder in this build")
+    for name in WRITTEN_BY_THE_REFERENCE:
+        got = _write_v2(name, lambda img: gpu_codec.encode([img], [img.plan()])[0])
+        assert got == v2(name), name
+        assert gpu_codec.decompress(got) == golden(name)[0]
