@@ -317,6 +317,13 @@ int lep_file_recode_finish(lep_file *f, const lep_bytes *seg_bytes, const lep_hu
 /* progressive files: _plan fills the image and up to `cap` scan descriptors (out_cap / corr_cap = what each scan may need;
  * image index, out_off, corr_off and blocks[] are the caller's to set); *gpu_ok = 0: the file keeps the host re-coder
  * (truncated, sequential multi-scan, withheld restart markers ...).  _finish glues header pieces, scans and trailer. */
+/* Compression with verification, baseline files: the plan that writes the parsed file's scan again on the GPU from its coefficient frame
+ * (lep_gpu_huffman_encode_device; images[].blocks and the segments' out_off are the caller's to set) and, per thread segment, the
+ * bytes of the file it must reproduce -- the Huffman half of the reference's round-trip check (src/lepton/validation.cc:97-218),
+ * executed, not argued.  *eligible = 0: the file keeps the host check (lep_jpeg_check_restores). */
+int lep_jpeg_plan_scan_check(lep_jpeg *j, size_t jpeg_len, lep_huff_image *image, lep_huff_segment *segs, uint32_t *file_first, uint32_t *file_len, int cap,
+                             int *nseg, int *eligible);
+int lep_jpeg_scan_file_range(const lep_jpeg *j, uint32_t *first, uint32_t *len);
 int lep_file_recode_plan_progressive(lep_file *f, lep_huffprog_image *image, lep_huffprog_scan *scans, int cap, int *nscan, int *gpu_ok);
 int lep_file_recode_finish_progressive(lep_file *f, const lep_bytes *scan_bytes, int nscan, lep_bytes *out);
 
@@ -377,6 +384,8 @@ typedef struct lep_batch_stats {
     double alloc_s;              /* inside pipeline_s: (re)allocation of the pinned / device staging buffers (kept between calls) */
     double redone_files;         /* compress: files whose streams outgrew the space reserved from their JPEG size and went through lep_compress */
     double gpu_huffman_files;    /* files whose Huffman scans the GPU decoded (compress) / wrote (decompress); the rest took the host coder */
+    double gpu_verified_scans;   /* compress with verify: thread segments (baseline) and scans (progressive) written again on the GPU from the
+                                    device frame and compared with the file's own bytes -- the Huffman half of the round-trip check */
 } lep_batch_stats;
 int lep_compress_batch(lep_gpu *g, const lep_bytes *jpgs, int n, lep_bytes *outs, int32_t *status,
                        const lep_batch_options *opt, lep_batch_stats *stats);

@@ -103,7 +103,7 @@ class BatchOptions(C.Structure):
 class BatchStats(C.Structure):
     _fields_ = [("wall_s", C.c_double), ("pipeline_s", C.c_double), ("parse_s", C.c_double), ("stage_s", C.c_double),
                 ("write_s", C.c_double), ("h2d_bytes", C.c_double), ("d2h_bytes", C.c_double), ("alloc_s", C.c_double), ("redone_files", C.c_double),
-                ("gpu_huffman_files", C.c_double)]
+                ("gpu_huffman_files", C.c_double), ("gpu_verified_scans", C.c_double)]
 
 
 SERVE_PROCESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Bytes), C.c_int, C.POINTER(Bytes), C.POINTER(C.c_int32))
@@ -238,5 +238,5 @@ EXPORTS = [
     "lep_jpeg_check_restores", "lep_batch_debug_poison", "lep_jpeg_plan_handoffs", "lep_file_consumed", "lep_chained_file_follows", "lep_file_open_next",
     "lep_file_recode_plan_progressive", "lep_file_recode_finish_progressive", "lep_gpu_huffman_progressive_encode_device",
     "lep_jpeg_open_gpu_progressive", "lep_jpeg_finish_gpu_progressive", "lep_gpu_huffman_progressive_decode_device",
-    "lep_jpeg_plan_progressive_check", "lep_gpu_last_stage_ms", "lep_jpeg_set_container_version", "lep_container_can_write_version",
+    "lep_jpeg_plan_progressive_check", "lep_gpu_last_stage_ms", "lep_jpeg_set_container_version", "lep_container_can_write_version", "lep_jpeg_plan_scan_check", "lep_jpeg_scan_file_range",
 ]

@@ -239,6 +239,58 @@ int lep_jpeg_plan_handoffs(const lep_jpeg* j, int max_threads, lep_handoff* out,
     return (int)s.size();
 }
 
+// The Huffman half of the round-trip check for a baseline file, planned for the GPU (validation.cc:97-218 restores the file and
+// compares): the parameters lep_gpu_huffman_encode_device needs to write the file's scan again from its coefficient frame --
+// exactly what lep_file_recode_plan would hand out for the .lep this file is about to become (same header, same hand-offs: the
+// plan is made through the same recode_prepare) -- and, per thread segment, where the bytes it must reproduce stand in the file.
+int lep_jpeg_plan_scan_check(lep_jpeg* j, size_t jpeg_len, lep_huff_image* image, lep_huff_segment* segs, uint32_t* file_first, uint32_t* file_len, int cap,
+                             int* nseg, int* eligible) {
+    *eligible = 0; *nseg = 0;
+    if (!j || j->jf.scan_file_range.size() != 1 || j->jf.progressive_needed || j->jf.start_byte || j->jf.embedded || j->jf.early_eof) return 0;
+    std::vector<lep::Handoff> hs = lep::plan_segments(j->jf, j->opt);
+    if (hs.empty() || (int)hs.size() > cap) return 0;
+    lep::LepFile lf;
+    lf.version = j->opt.format_version; lf.flag = 'Z'; lf.nthreads = (int)hs.size(); lf.jpeg_size = (uint32_t)jpeg_len;
+    lf.segs = hs;
+    lf.rst_cnt_set = !j->jf.rst_cnt.empty();
+    // the parsed JPEG is lent to the plan (recode_prepare re-reads the tables in front of the scan from the same header bytes)
+    // and handed back whatever happens; an empty garbage section stands for the default EOI, as in a .lep that is read back
+    struct Lend {
+        lep::JpegFile& home; lep::JpegFile& away; bool default_eoi;
+        Lend(lep::JpegFile& h, lep::JpegFile& a) : home(h), away(a), default_eoi(h.garbage.empty()) { away = std::move(home); if (default_eoi) away.garbage = {0xFF, 0xD9}; }
+        ~Lend() { if (default_eoi) away.garbage.clear(); home = std::move(away); }
+    };
+    lep::RecodePlan plan;
+    int rc;
+    {
+        Lend lend(j->jf, lf.jpeg);
+        rc = lep::recode_prepare(&lf, &plan);
+    }
+    if (rc || !plan.gpu_ok || plan.segs.size() != hs.size()) return 0;
+    const auto& r = j->jf.scan_file_range[0];
+    uint64_t at = r.first;
+    for (size_t q = 0; q < hs.size(); ++q) {
+        file_first[q] = (uint32_t)at; file_len[q] = hs[q].segment_size;
+        at += hs[q].segment_size;
+    }
+    // the hand-offs' byte counts must tile the scan as it stands in the file: up to the marker that ends it, less the restart
+    // markers that stand wrongly at its end (the re-coder appends those from the FRS section; they are not a segment's bytes)
+    const uint64_t tail_rst = j->jf.rst_err.empty() ? 0u : 2u * (uint64_t)j->jf.rst_err[0];
+    if (at + tail_rst != r.second || at > jpeg_len) return 0;
+    memcpy(image, &plan.image, sizeof *image);
+    memcpy(segs, plan.segs.data(), sizeof(lep_huff_segment) * plan.segs.size());
+    *nseg = (int)hs.size();
+    *eligible = 1;
+    return 0;
+}
+
+// where the (single) scan of a parsed baseline file stands in the file: first entropy-coded byte, length up to the marker that ends it
+int lep_jpeg_scan_file_range(const lep_jpeg* j, uint32_t* first, uint32_t* len) {
+    if (!j || j->jf.scan_file_range.size() != 1) return LEP_ASSERTION_FAILURE;
+    *first = j->jf.scan_file_range[0].first; *len = j->jf.scan_file_range[0].second - j->jf.scan_file_range[0].first;
+    return 0;
+}
+
 int lep_jpeg_write_lep(const lep_jpeg* j, int max_threads, const lep_bytes* streams, int nstreams, lep_bytes* out) {
     lep::EncodeOptions o = j->opt;
     if (max_threads > 0) o.max_threads = (unsigned)max_threads;

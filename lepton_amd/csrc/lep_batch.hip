@@ -96,6 +96,16 @@ __global__ void lep_scan_check_kernel(const uint8_t* __restrict__ out, const uin
     if (diff) atomicOr(flags + it.image, 2u);
 }
 
+// the same against reference bytes at any alignment (a baseline file's thread segments, as they stand in the file)
+__global__ void lep_scan_check_bytes_kernel(const uint8_t* __restrict__ out, const uint32_t* __restrict__ out_len, const uint8_t* __restrict__ ref,
+                                            const ScanCheck* __restrict__ items, uint32_t* flags) {
+    const ScanCheck it = items[blockIdx.x];
+    bool diff = out_len[blockIdx.x] != it.ref_len;
+    if (!diff)
+        for (uint32_t i = threadIdx.x; i < it.ref_len; i += blockDim.x) diff |= out[it.out_off + i] != ref[it.ref_off + i];
+    if (diff) atomicOr(flags + it.image, 2u);
+}
+
 // Hundreds of host threads each allocating and freeing MB-sized vectors (un-stuffed scan data, containers) serialise on
 // the process-wide mmap lock when glibc serves them with mmap/munmap; keep such blocks inside the per-thread arenas.
 void tune_malloc_for_pool() {
@@ -118,12 +128,15 @@ struct Slot {   // one chunk's buffers (double-buffered)
     uint32_t* d_corr = nullptr; size_t corr_cap = 0;       // held-back correction bits of the refinement scans (dwords)
     uint32_t* d_pscanlen = nullptr; size_t pscanlen_cap = 0;
     ScanCheck* d_pcheck = nullptr; size_t pcheck_cap = 0;   // compression with verify: what lep_scan_check_kernel compares
+    uint8_t* d_vscan = nullptr; size_t vscan_cap = 0;       // ... and for baseline files: their scans written again from the device frame,
+    uint32_t* d_vscanlen = nullptr; ScanCheck* d_vcheck = nullptr; size_t vseg_cap = 0;   // per thread segment
     hipEvent_t up = nullptr, done = nullptr;
     void release() {
         if (h_frames) (void)hipHostFree(h_frames);
         if (h_streams) (void)hipHostFree(h_streams);
         if (h_scan) (void)hipHostFree(h_scan);
         if (h_pscan) (void)hipHostFree(h_pscan);
+        for (void* p : {(void*)d_vscan, (void*)d_vscanlen, (void*)d_vcheck}) if (p) (void)hipFree(p);
         for (void* p : {(void*)d_pscan, (void*)d_corr, (void*)d_pscanlen, (void*)d_pcheck, (void*)d_frames, (void*)d_scratch, (void*)d_streams, (void*)d_len, (void*)d_status, (void*)d_flags, (void*)d_scan, (void*)d_scanlen, (void*)d_rows})
             if (p) (void)hipFree(p);
         if (up) (void)hipEventDestroy(up);
@@ -258,6 +271,25 @@ int prog_reserve(Slot* s, size_t scan_bytes, size_t corr_words, size_t nscan) {
     g_alloc_s += now_s() - t0;
     return 0;
 }
+int vscan_reserve(Slot* s, size_t bytes, size_t nseg) {
+    const double t0 = now_s();
+    if (bytes > s->vscan_cap) {
+        if (s->d_vscan) (void)hipFree(s->d_vscan);
+        s->d_vscan = nullptr; s->vscan_cap = 0;
+        HIPOK(hipMalloc((void**)&s->d_vscan, bytes));
+        s->vscan_cap = bytes;
+    }
+    if (nseg > s->vseg_cap) {
+        if (s->d_vscanlen) (void)hipFree(s->d_vscanlen);
+        if (s->d_vcheck) (void)hipFree(s->d_vcheck);
+        s->d_vscanlen = nullptr; s->d_vcheck = nullptr; s->vseg_cap = 0;
+        HIPOK(hipMalloc((void**)&s->d_vscanlen, nseg * 4));
+        HIPOK(hipMalloc((void**)&s->d_vcheck, nseg * sizeof(ScanCheck)));
+        s->vseg_cap = nseg;
+    }
+    g_alloc_s += now_s() - t0;
+    return 0;
+}
 int prog_host_reserve(Slot* s, size_t bytes) {
     if (bytes <= s->hpscan_cap) return 0;
     const double t0 = now_s();
@@ -304,6 +336,13 @@ struct Chunk {
     std::vector<int> pfirst, pcount;       // per live image: first entry of pscan / number of scans, -1 = not on this path
     size_t pscan_bytes = 0, corr_words = 0;
     std::vector<ScanCheck> pcheck;         // compression with verify: per pscan entry, the file's own bytes of that scan
+    // compression with verify, baseline files the GPU decoded: the Huffman half of the round trip (their scans written again)
+    std::vector<lep_huff_image> vimg;
+    std::vector<lep_huff_segment> vseg;
+    std::vector<ScanCheck> vcheck;
+    std::vector<char> vchecked;            // per live image: its scan goes through that check
+    size_t vscan_bytes = 0;
+    bool pcheck_image(int k) const { for (const ScanCheck& p : pcheck) if ((int)p.image == k) return true; return false; }
 };
 
 Slot g_slots[2];         // one batch call at a time (the calls are not re-entrant)
@@ -483,6 +522,12 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         if (verify)
             for (int k = 0; k < nl; ++k) if (on_prog[k])
                 for (uint32_t n : pchk[k].len) { praw_off[k].push_back(scan_total); scan_total += ((size_t)n + 15) & ~(size_t)15; }
+        std::vector<size_t> vraw_off(nl, 0);             // baseline files: the whole scan as it stands in the file, for the same check
+        std::vector<uint32_t> vraw_first(nl, 0), vraw_len(nl, 0);
+        if (verify)
+            for (int k = 0; k < nl; ++k) if (on_gpu[k] && !lep_jpeg_scan_file_range(parsed[c->live[k]], &vraw_first[k], &vraw_len[k])) {
+                vraw_off[k] = scan_total; scan_total += ((size_t)vraw_len[k] + 15) & ~(size_t)15;
+            }
         ngpu += nprog;
         std::vector<lep_huffdec_row> rows(rows_total);
         if (ngpu) {
@@ -511,6 +556,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 }
                 memcpy(s->h_scan + scan_off[k], p, len);
                 memset(s->h_scan + scan_off[k] + len, 0, (((size_t)himg[k].scan_len + 64 + 15) & ~(size_t)15) - len);
+                if (vraw_len[k]) memcpy(s->h_scan + vraw_off[k], jpgs[c->live[k]].data + vraw_first[k], vraw_len[k]);
             });
         }
         st.parse_s += now_s() - t0;
@@ -683,6 +729,36 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 }
                 c->pimg.push_back(pi);
             }
+        // ... and of the baseline files it decoded (their frame exists only on the device): every thread segment's scan bytes
+        // written again by the decompressor's kernel and held against the file's.  A file that cannot take this path -- or whose
+        // bytes do not come back -- goes through the per-file path, which restores it on the host and compares.
+        c->vimg.clear(); c->vseg.clear(); c->vcheck.clear(); c->vscan_bytes = 0;
+        c->vchecked.assign(c->live.size(), 0);
+        if (verify)
+            for (size_t nk = 0; nk < c->live.size(); ++nk) {
+                const int k = old_k[nk];
+                if (!on_gpu[k] || !vraw_len[k]) continue;
+                lep_huff_image vi;
+                lep_huff_segment vs[LEP_MAX_SEGMENTS];
+                uint32_t ff[LEP_MAX_SEGMENTS], fl[LEP_MAX_SEGMENTS];
+                int ns = 0, ok = 0;
+                if (lep_jpeg_plan_scan_check(parsed[c->live[nk]], jpgs[c->live[nk]].len, &vi, vs, ff, fl, LEP_MAX_SEGMENTS, &ns, &ok) || !ok) continue;
+                for (int cc = 0; cc < 4; ++cc) vi.blocks[cc] = cc < c->dev_desc[nk].ncomp ? c->dev_desc[nk].blocks[cc] : nullptr;
+                for (int q = 0; q < ns; ++q) {
+                    vs[q].image = (int32_t)c->vimg.size();
+                    vs[q].out_cap = (uint32_t)std::min<size_t>(vs[q].out_cap, (size_t)fl[q] + 64);   // anything longer is a mismatch anyway
+                    vs[q].out_off = c->vscan_bytes;
+                    c->vscan_bytes += ((size_t)vs[q].out_cap + 15) & ~(size_t)15;
+                    c->vseg.push_back(vs[q]);
+                    c->vcheck.push_back(ScanCheck{vs[q].out_off, (uint64_t)vraw_off[k] + (ff[q] - vraw_first[k]), fl[q], (uint32_t)nk});
+                }
+                c->vimg.push_back(vi);
+                c->vchecked[nk] = 1;
+            }
+        if (!c->vseg.empty()) {
+            if (int rc = vscan_reserve(s, c->vscan_bytes + 256, c->vseg.size())) return rc;
+            HIPOK(hipMemcpyAsync(s->d_vcheck, c->vcheck.data(), c->vcheck.size() * sizeof(ScanCheck), hipMemcpyHostToDevice, s_copy));
+        }
         if (!c->pscan.empty()) {
             if (c->corr_words > 0xfffffff0u) return LEP_GPU_ERROR;
             if (int rc = prog_reserve(s, c->pscan_bytes + 256, c->corr_words + 16, c->pscan.size())) return rc;
@@ -713,6 +789,13 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 const size_t fb = frame_exact_bytes(c->host_desc[k]);   // the frame itself, not its rounded room in the slot
                 hipLaunchKernelGGL(lep_compare_kernel, dim3(256), dim3(256), 0, s_compute, (const uint4*)(s->d_frames + c->frame_off[k]),
                                    (const uint4*)(s->d_scratch + c->frame_off[k]), fb / 16, s->d_flags + k, 1u);
+            }
+            st.gpu_verified_scans += (double)(c->vseg.size() + c->pscan.size());
+            if (!c->vseg.empty()) {    // baseline files: the Huffman half, thread segment by thread segment against the file's bytes
+                rc = lep_gpu_huffman_encode_device(g, c->vimg.data(), (int)c->vimg.size(), c->vseg.data(), (int)c->vseg.size(), s->d_vscan, s->d_vscanlen, nullptr, s_compute);
+                if (rc) return rc;
+                hipLaunchKernelGGL(lep_scan_check_bytes_kernel, dim3((unsigned)c->vseg.size()), dim3(256), 0, s_compute, s->d_vscan, s->d_vscanlen, s->d_scan,
+                                   s->d_vcheck, s->d_flags);
             }
             if (!c->pscan.empty()) {   // progressive files: the Huffman half, scan by scan against the file's bytes
                 rc = lep_gpu_huffman_progressive_encode_device(g, c->pimg.data(), (int)c->pimg.size(), c->pscan.data(), (int)c->pscan.size(), s->d_pscan,
@@ -789,11 +872,13 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                     // a progressive scan the GPU encoder did not reproduce (trailing restart markers, which the host appends; a
                     // non-canonical code choice): the per-file path decides (last loop of this function)
                     else if (!rc && (flags[k] & 2)) rc = LEP_BUFFER_TOO_SMALL;
+                    // a baseline file the GPU decoded whose scan could not go through the check above: the per-file path restores
+                    // it on the host and compares (nothing is released on an argument)
+                    else if (!rc && !host_parsed[i] && !c->vchecked[k] && !c->pcheck_image(k)) rc = LEP_BUFFER_TOO_SMALL;
                 }
                 if (!rc) rc = lep_jpeg_write_lep(parsed[i], 0, strs, s1 - s0, &outs[i]);
                 // the Huffman half of the reference's round-trip check for the files whose scans the host parser took (their
-                // frame is still in this slot's pinned staging): a scan the GPU decoder accepted is canonical by construction
-                // -- every code valid, no block ending in a coded zero, one pad-bit pattern, restart markers in step
+                // frame is still in this slot's pinned staging); the files the GPU decoded had theirs on the GPU (flags, above)
                 if (!rc && verify && host_parsed[i]) {
                     rc = lep_jpeg_check_restores(parsed[i], outs[i].data, outs[i].len, jpgs[i].data, jpgs[i].len);
                     if (rc) { lep_free(outs[i].data); outs[i].data = nullptr; outs[i].len = outs[i].cap = 0; }

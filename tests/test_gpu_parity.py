@@ -534,3 +534,20 @@ def test_gpu_split_phase_encoder_4k(gpu_codec_v5):
         plan = img.plan()
         want, _ = ob.oracle_encode(img.desc, plan)
         assert gpu_codec_v5.encode([img], [plan])[0] == want
+
+
+@pytest.mark.gpu
+def test_gpu_verify_executes_the_huffman_half_for_baseline_files(gpu_codec):
+    """with `verify`, a baseline file the GPU decoded has the Huffman half of the round-trip check
+    (validation.cc:97-218) EXECUTED on the GPU -- every thread segment's scan bytes written again from the device frame by the
+    decompressor's kernel and compared with the file's own -- not argued from the decoder's acceptance.  Same .lep bytes as
+    without the check; the counter says how many segments / scans went through it."""
+    names = [n for n in golden_cases() if not n.startswith(("prog", "truncated", "slice", "embedded", "permissive"))]
+    jpgs = [golden(n)[0] for n in names] + [corpus.synth_jpeg(1024, 768, 77), corpus.synth_jpeg(640, 480, 78, skew=2.0)]
+    plain, st0, stats0 = gpu_codec.compress_batch(jpgs)
+    checked, st1, stats1 = gpu_codec.compress_batch(jpgs, verify=True)
+    assert st0 == st1 == [0] * len(jpgs) and plain == checked
+    assert stats0["gpu_verified_scans"] == 0
+    assert stats1["gpu_verified_scans"] >= stats1["gpu_huffman_files"] > len(jpgs) // 2   # at least one segment per GPU-decoded file
+    back, st2, _ = gpu_codec.decompress_batch(checked)
+    assert st2 == [0] * len(jpgs) and back == jpgs
