@@ -507,6 +507,7 @@ struct Walk5Shared {
     int32_t icos_x[64], icos_y[64];        // the component's quantisation-derived tables (a load from the image descriptor on the
     uint16_t q[64];                        // critical path costs a trip to HBM: they are staged when the component changes)
     uint8_t thr[64];
+    uint16_t errx[2 * 64];                 // emit: the lanes' first refusal per half of the block (interior; edges and DC)
     uint32_t abv[32 * 65];                 // the tile of the row above (emit only: count and gather launch without it)
 };
 constexpr size_t kWalkLdsNoAbove = sizeof(Walk5Shared) - sizeof(uint32_t) * 32 * 65;
@@ -565,8 +566,15 @@ WDEV void lds_add(uint32_t* p, uint32_t v) {
 WDEV int nzbin5(int left) { return left < 16 ? (int)((0x7776666555443210ull >> (4 * left)) & 15) : (left < 21 ? 7 : (left < 32 ? 8 : 9)); }
 WDEV int tile_get(const uint32_t* T, int a, int col) { return (int16_t)(T[(a >> 1) * 65 + col] >> ((a & 1) * 16)); }
 
-template <int MODE>
+// NW = 2: two wavefronts walk a segment together -- both see the same tile in LDS; wavefront 0 codes the 7x7 interiors, wavefront
+// 1 everything that needs the neighbours' pixels and the block's sparse records (edges, DC, the three counts).  Each half has its
+// own streams, its own run of sign bytes and its own run of bins inside every block, so the halves only meet at the tile's
+// boundaries.  (Compiled without a GPU, NW = 2 runs the two halves one after the other: the same split, checked bit for bit.)
+#define LEP5_XSYNC() do { if (NW > 1) WSYNC(); else LSYNC(); } while (0)
+template <int MODE, int NW = 1>
 struct Walk5 {
+    static constexpr int kLoadWaves = LEP_ON_GPU ? NW : 1;   // wavefronts that share a tile's loads
+    int wave;                  // this wavefront's number inside the workgroup (0 when there is one)
     const ImageDev* img;
     Walk5Shared* sh;
     const SegPlan5* plan;      // emit / gather
@@ -638,42 +646,70 @@ struct Walk5 {
         const uint32_t* asrc = t.arow ? reinterpret_cast<const uint32_t*>(t.arow + (int64_t)t.x0 * 64) : nullptr;
         LANES(l) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const int d = k * 64 + l, b = d >> 5;
-                regs[LEP_LI(l)].c[k] = b < t.nb ? gld(src + d) : 0u;
-                regs[LEP_LI(l)].a[k] = (asrc && b < t.nb && MODE == kEmit) ? gld(asrc + d) : 0u;
+            for (int kk = 0; kk < 32 / kLoadWaves; ++kk) {
+                const int d = (kk + wave * (32 / kLoadWaves)) * 64 + l, b = d >> 5;
+                regs[LEP_LI(l)].c[kk] = b < t.nb ? gld(src + d) : 0u;
+                regs[LEP_LI(l)].a[kk] = (asrc && b < t.nb && MODE == kEmit) ? gld(asrc + d) : 0u;
             }
         }
     }
     WDEV void store_tile(const TileDesc& t, const TileRegs* regs) {
         Walk5Shared& S = LEP5_WSH(this);
         const bool first_of_row = t.x0 == 0;
-        if (t.comp != comp) {   // the component's tables
-            comp = t.comp; ci = comp ? 1 : 0;
-            LANES(l) { S.q[l] = img->q[comp][l]; S.icos_x[l] = img->icos_x[comp][l]; S.icos_y[l] = img->icos_y[comp][l]; S.thr[l] = img->min_thresh[comp][l]; }
-        }
-        LANES(l) {   // keep the last column of the previous tile as "left of lane 0"
-            if (l < 32) {
-                S.cur[l * 65 + 64] = first_of_row ? 0u : S.cur[l * 65 + 63];
-                if (MODE == kEmit) S.abv[l * 65 + 64] = first_of_row ? 0u : S.abv[l * 65 + 63];
+        const bool new_comp = t.comp != comp;
+        if (new_comp) { comp = t.comp; ci = comp ? 1 : 0; }
+        LEP5_XSYNC();   // (every wavefront is done with the previous tile)
+        if (wave == 0) {
+            if (new_comp) {   // the component's tables
+                LANES(l) { S.q[l] = img->q[comp][l]; S.icos_x[l] = img->icos_x[comp][l]; S.icos_y[l] = img->icos_y[comp][l]; S.thr[l] = img->min_thresh[comp][l]; }
             }
-            if (l == 0) { if (first_of_row) S.ns[64] = NSum{}; else S.ns[64] = S.ns[63]; }
+            LANES(l) {   // keep the last column of the previous tile as "left of lane 0"
+                if (l < 32) {
+                    S.cur[l * 65 + 64] = first_of_row ? 0u : S.cur[l * 65 + 63];
+                    if (MODE == kEmit) S.abv[l * 65 + 64] = first_of_row ? 0u : S.abv[l * 65 + 63];
+                }
+                if (l == 0) { if (first_of_row) S.ns[64] = NSum{}; else S.ns[64] = S.ns[63]; }
+            }
         }
-        LSYNC();
+        LEP5_XSYNC();
         LANES(l) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const int d = k * 64 + l, b = d >> 5, i = d & 31;
-                S.cur[i * 65 + b] = regs[LEP_LI(l)].c[k];
-                if (MODE == kEmit) S.abv[i * 65 + b] = regs[LEP_LI(l)].a[k];
+            for (int kk = 0; kk < 32 / kLoadWaves; ++kk) {
+                const int d = (kk + wave * (32 / kLoadWaves)) * 64 + l, b = d >> 5, i = d & 31;
+                S.cur[i * 65 + b] = regs[LEP_LI(l)].c[kk];
+                if (MODE == kEmit) S.abv[i * 65 + b] = regs[LEP_LI(l)].a[kk];
             }
         }
-        LSYNC();
+        LEP5_XSYNC();
     }
 
     // one tile; has_above: the row above belongs to this segment; returns 0 or an exit code
+    struct TileTotals { int nsig, bins; };
     WDEV int tile(int x0, int nb, bool has_above, NSum* nrow, const NSum* narow) {
         Walk5Shared& S = LEP5_WSH(this);
+        TileTotals tt;
+        if (NW == 1) tt = half<3>(x0, nb, has_above, nrow, narow);
+        else if (!LEP_ON_GPU) { half<1>(x0, nb, has_above, nrow, narow); tt = half<2>(x0, nb, has_above, nrow, narow); }
+        else if (wave == 0) tt = half<1>(x0, nb, has_above, nrow, narow);
+        else tt = half<2>(x0, nb, has_above, nrow, narow);
+        if (MODE == kEmit) {   // the first refusal in stream order ends the segment (lane order = block order; inside a block: interior, edges, DC)
+            LEP5_XSYNC();
+            LV(int, err); LV(int, bad);
+            LANES(l) { L(err) = S.errx[l] ? S.errx[l] : (NW > 1 ? S.errx[64 + l] : 0); L(bad) = L(err) != 0; }
+            const uint64_t bm = lepwave::wave_ballot(bad);
+            if (bm) return (int)(lepwave::wave_read((const uint32_t*)err, __builtin_ctzll(bm)) & 0xffff);
+        }
+        sign_pos[ci] += (uint32_t)tt.nsig;
+        nbins += (uint32_t)tt.bins;
+        ord0 += (uint32_t)nb;
+        ++tile_no;
+        return 0;
+    }
+    // HALF: 1 = the 7x7 interiors, 2 = the sparse records, the edges and the DC, 3 = the whole block
+    template <int HALF>
+    WDEV TileTotals half(int x0, int nb, bool has_above, NSum* nrow, const NSum* narow) {
+        Walk5Shared& S = LEP5_WSH(this);
+        constexpr bool kInt = (HALF & 1) != 0, kEdge = (HALF & 2) != 0;
         const int c = comp;
         LV(int, act); LV(int, nz); LV(int, neh); LV(int, nev); LV(int, nsig); LV(int, err); LV(int, errdc);
         LV(int, eobx); LV(int, eoby);
@@ -681,6 +717,7 @@ struct Walk5 {
         LV(int, dc_sign);         // sign byte of the DC (0 = no sign bin)
         LV(int, nzctxbin);
         LV(int, lbins);           // bins of this block
+        LV(int, ibins);           // ... of its 7x7 interior
         LV(NSum, nsa);            // the summary of the block above
 
         // gather: the block's sparse records (7x7 count, edge counts, DC units) are requested now and used after phase 1
@@ -688,19 +725,22 @@ struct Walk5 {
         LV(uint32_t, rnz0); LV(uint32_t, rnz1); LV(uint32_t, ren0); LV(uint32_t, ren1); LV(uint32_t, rdc0); LV(uint32_t, rdc1); LV(uint32_t, rdc2);
         if (MODE == kGather) {
             LANES(l) if (l < nb) {
-                const uint32_t* r1 = reinterpret_cast<const uint32_t*>(arena + nz_base) + 2 * (ord0 + l);
-                const uint32_t* r2 = reinterpret_cast<const uint32_t*>(arena + en_base) + 2 * (ord0 + l);
-                const uint32_t* r3 = reinterpret_cast<const uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
-                L(rnz0) = gld(r1); L(rnz1) = gld(r1 + 1); L(ren0) = gld(r2); L(ren1) = gld(r2 + 1); L(rdc0) = gld(r3); L(rdc1) = gld(r3 + 1); L(rdc2) = gld(r3 + 2);
-                L(rdce) = gld(AT + ((size_t)tile_no * kAtRows + 63) * 64 + l); L(rdcs) = gld(AT + ((size_t)tile_no * kAtRows + 64) * 64 + l);
+                if (kEdge) {
+                    const uint32_t* r1 = reinterpret_cast<const uint32_t*>(arena + nz_base) + 2 * (ord0 + l);
+                    const uint32_t* r2 = reinterpret_cast<const uint32_t*>(arena + en_base) + 2 * (ord0 + l);
+                    const uint32_t* r3 = reinterpret_cast<const uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
+                    L(rnz0) = gld(r1); L(rnz1) = gld(r1 + 1); L(ren0) = gld(r2); L(ren1) = gld(r2 + 1); L(rdc0) = gld(r3); L(rdc1) = gld(r3 + 1); L(rdc2) = gld(r3 + 2);
+                    L(rdcs) = gld(AT + ((size_t)tile_no * kAtRows + 64) * 64 + l);
+                }
+                L(rdce) = gld(AT + ((size_t)tile_no * kAtRows + 63) * 64 + l);   // (both halves: the DC's bins are part of the block's)
             }
         }
         // ---- phase 1a: own numbers ---------------------------------------------------------------------------------
         LANES(l) {
             const int a = l < nb;
             L(act) = a; L(err) = 0; L(errdc) = 0;
-            int n7 = 0, nh = 0, nv = 0, ex = 0, ey = 0, lb = 0;
-            for (int t = 0; t < 8; ++t) S.TB[t * 65 + l] = 0;
+            int n7 = 0, nh = 0, nv = 0, ex = 0, ey = 0, lb = 0, ib = 0;
+            if (kEdge) for (int t = 0; t < 8; ++t) S.TB[t * 65 + l] = 0;
             if (a) {
                 // bins of the block that do not depend on its neighbours: 6 + 3 + 3 count bins, and per coded coefficient the
                 // exponent bins, the sign and len - 1 residual bins; zeros in front of a region's last non-zero cost one bin
@@ -714,7 +754,9 @@ struct Walk5 {
                         lb += (lc < 11 ? lc + 1 : 11) + lc;
                     }
                 }
-                lb += 12 + (last + 1 - n7);
+                lb += last + 1 - n7;
+                ib = lb;
+                lb += 12;
                 for (int eg = 0; eg < 2; ++eg) {
                     int lastj = -1, cnt = 0;
                     for (int j = 0; j < 7; ++j) {
@@ -724,7 +766,7 @@ struct Walk5 {
                         const int len = bitlen((uint32_t)v), lc = len > 11 ? 11 : len;
                         lb += (lc < 11 ? lc + 1 : 11) + lc;
                         const int thr = S.thr[eg ? (j + 1) * 8 : j + 1];
-                        if (lc > 1 && lc - 2 >= thr) {   // threshold units of this coefficient (class lt = min(len - thr, 7))
+                        if (kEdge && lc > 1 && lc - 2 >= thr) {   // threshold units of this coefficient (class lt = min(len - thr, 7))
                             const int lt = imin(lc - thr, 7), un = (lc - 1 - thr + 3) >> 2;
                             if (MODE == kCount) lds_add(&S.cursor[stream_id(ci, 63, lt)], (uint32_t)un);
                             else S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + un);
@@ -734,15 +776,15 @@ struct Walk5 {
                     if (eg) nv = cnt; else nh = cnt;
                 }
             }
-            L(nz) = n7; L(neh) = nh; L(nev) = nv; L(eobx) = ex; L(eoby) = ey; L(lbins) = lb;
+            L(nz) = n7; L(neh) = nh; L(nev) = nv; L(eobx) = ex; L(eoby) = ey; L(lbins) = lb; L(ibins) = ib;
             L(nsig) = a ? n7 + nh + nv + 1 : 0;
-            if (MODE == kEmit && has_above && a) L(nsa) = gld_ns(&narow[x0 + l]);   // (written when that row was walked)
+            if (MODE == kEmit && kEdge && has_above && a) L(nsa) = gld_ns(&narow[x0 + l]);   // (written when that row was walked)
             else L(nsa) = NSum{};
         }
         // ---- phase 1b: IDCT without DC, neighbour summary (block_context.hh:44-78) -------------------------------------
         struct Px { int16_t r0[8], r1[8], c0[8], c1[8]; };   // pixel rows 0, 1 and columns 0, 1 of the block without its DC
         LV(Px, px);
-        if (MODE == kEmit) {
+        if (MODE == kEmit && kEdge) {
             LANES(l) if (L(act)) {
                 const uint16_t* q = S.q;
                 constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
@@ -808,6 +850,7 @@ struct Walk5 {
                     const int len = (e0 >> 14) & 15, nres = (e0 >> 10) & 15;
                     bins_here = (len < 11 ? len + 1 : 11) + (len ? 1 : 0) + nres;
                 } else if (MODE == kEmit) {
+                  if (kEdge) {
                     const NSum& nl = S.ns[(l + 64) % 65];
                     const NSum& na = L(nsa);
                     int nzctx = 0;
@@ -849,6 +892,7 @@ struct Walk5 {
                     e0 = (int32_t)coef_entry((uint32_t)v & ((1u << nres) - 1u), nres, len > 11 ? 11 : len, b17, a, 0);
                     if (len) sgn = 0x80 | (unc2 >= 0 ? (unc2 == 0 ? 3 : 2) : 1) | ((d >= 0) << 6);
                     bins_here = (len < 11 ? len + 1 : 11) + (len ? 1 : 0) + nres;
+                  }
                 } else bins_here = 22;   // count: an upper bound (the DC needs the neighbours)
             }
             L(dc_e0) = e0; L(dc_sign) = sgn; L(nzctxbin) = ctxbin; L(lbins) += bins_here;
@@ -858,7 +902,7 @@ struct Walk5 {
         LV(int, sbase); LV(int, bbase);
         const int nsig_tile = lepwave::wave_excl_scan(nsig, sbase);
         int ttot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (MODE != kCount) {
+        if (MODE != kCount && kEdge) {
             for (int lt = 2; lt < 8; ++lt) {
                 LV(int, tc); LV(int, to);
                 LANES(l) L(tc) = S.TB[lt * 65 + l];
@@ -878,9 +922,12 @@ struct Walk5 {
         LV(uint32_t, bacc); // gather: the bin at the even position before it, not stored yet
         LV(int, sp);        // next sign byte of this lane
         LV(int, left);
-        LANES(l) { L(bp) = nbins + (uint32_t)L(bbase); L(bacc) = kNoBin; L(sp) = L(sbase); L(left) = L(nz); }
+        LANES(l) {
+            L(bp) = nbins + (uint32_t)L(bbase) + (kEdge || !L(act) ? 0u : 6u); L(bacc) = kNoBin;
+            L(sp) = L(sbase) + (kInt ? 0 : L(nz)); L(left) = L(nz);
+        }
         // the number of non-zeros of the 7x7 interior (and the key word the sparse chains filter on)
-        if (MODE != kCount) {
+        if (MODE != kCount && kEdge) {
             LANES(l) if (L(act)) {
                 uint32_t* rec = reinterpret_cast<uint32_t*>(arena + nz_base) + 2 * (ord0 + l);
                 if (MODE == kEmit) {
@@ -894,6 +941,7 @@ struct Walk5 {
                         const uint32_t p = q < 4 ? (lo >> (8 * q)) & 255u : (hi >> (8 * (q - 4))) & 255u;
                         put_bin(L(bp), L(bacc), p | ((((uint32_t)L(nz) >> i) & 1u) << 8));
                     }
+                    if (!kInt) { flush_bin(L(bp), L(bacc)); L(bacc) = kNoBin; L(bp) += (uint32_t)L(ibins); }   // (the other half's run)
                 }
             }
         }
@@ -901,8 +949,9 @@ struct Walk5 {
         // while row r + 1 is worked out (a load on the critical path costs more than everything else in the row)
         LV(uint32_t, p_e); LV(uint32_t, p_te); LV(uint32_t, p_at); LV(uint32_t, p_tat); LV(int, p_cf); LV(uint32_t, p_w0); LV(uint32_t, p_w1); LV(uint32_t, p_tw); LV(uint32_t, p_sg);
         LV(uint32_t, enw); LV(uint32_t, at_next);
-        LANES(l) { L(p_e) = 0; L(enw) = 0; L(at_next) = MODE == kGather ? gld(AT + (size_t)tile_no * kAtRows * 64 + l) : 0u; }
-        for (int row = 0; row < 63; ++row) {
+        constexpr int kRow0 = kInt ? 0 : 49, kRowEnd = kEdge ? 63 : 49;
+        LANES(l) { L(p_e) = 0; L(enw) = 0; L(at_next) = MODE == kGather ? gld(AT + ((size_t)tile_no * kAtRows + kRow0) * 64 + l) : 0u; }
+        for (int row = kRow0; row < kRowEnd; ++row) {
             const bool edge = row >= 49;
             const int eg = row >= 56 ? 1 : 0, j = edge ? row - 49 - eg * 7 : 0;
             const bool horizontal = eg == 0;
@@ -990,7 +1039,7 @@ struct Walk5 {
                 const uint64_t rem = lepwave::wave_ballot(coded);
                 const bool skip = !rem && !edge;
                 const int next_row = skip ? 49 : row + 1;
-                LANES(l) { L(at) = L(at_next); if (next_row < 63) L(at_next) = gld(AT + ((size_t)tile_no * kAtRows + next_row) * 64 + l); }
+                LANES(l) { L(at) = L(at_next); if (next_row < kRowEnd) L(at_next) = gld(AT + ((size_t)tile_no * kAtRows + next_row) * 64 + l); }
                 if (skip) { row = 48; continue; }
             } else {
             // rank the lanes of every (row, class) in block order: the entry's place in its stream
@@ -1055,17 +1104,17 @@ struct Walk5 {
             }
         }
         if (MODE == kGather) {
-            LANES(l) if (L(p_e)) gather_coef(L(bp), L(bacc), U, L(p_e), L(p_te), L(p_at), L(p_tat), L(p_cf), L(p_w0), L(p_w1), L(p_tw), L(p_sg));
+            LANES(l) {
+                if (L(p_e)) gather_coef(L(bp), L(bacc), U, L(p_e), L(p_te), L(p_at), L(p_tat), L(p_cf), L(p_w0), L(p_w1), L(p_tw), L(p_sg));
+                if (!kEdge) flush_bin(L(bp), L(bacc));
+            }
         }
         LSYNC();
-        {   // the first error in stream order ends the segment (lane order = block order; inside a block the DC check comes last)
-            LV(int, bad);
-            LANES(l) { if (!L(err)) L(err) = L(errdc); L(bad) = L(err) != 0; }
-            const uint64_t bm = lepwave::wave_ballot(bad);
-            if (MODE == kEmit && bm) return (int)(lepwave::wave_read((const uint32_t*)err, __builtin_ctzll(bm)) & 0xffff);
+        if (MODE == kEmit) {   // (inside a block the DC check comes last)
+            LANES(l) { if (!L(err)) L(err) = L(errdc); S.errx[(HALF == 2 ? 64 : 0) + l] = (uint16_t)L(err); }
         }
         // DC
-        if (MODE != kCount) {
+        if (MODE != kCount && kEdge) {
             LANES(l) if (L(act)) {
                 uint32_t* rec = reinterpret_cast<uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
                 const uint32_t e = (uint32_t)L(dc_e0);
@@ -1092,12 +1141,9 @@ struct Walk5 {
             LSYNC();
             LANES(l) if (l == 0) for (int lt = 2; lt < 8; ++lt) S.cursor[stream_id(ci, 63, lt)] += (uint32_t)ttot[lt];
             LSYNC();
-        } else bins_tile = lepwave::wave_sum(lbins);
-        sign_pos[ci] += (uint32_t)nsig_tile;
-        nbins += (uint32_t)bins_tile;
-        ord0 += (uint32_t)nb;
-        ++tile_no;
-        return 0;
+        }
+        if (MODE == kCount) bins_tile = lepwave::wave_sum(lbins);
+        return TileTotals{nsig_tile, bins_tile};
     }
 
     // gather: append one bin (probability | bit << 8) of this lane.  Bins leave in pairs: the one at an even position waits in
@@ -1135,17 +1181,18 @@ struct Walk5 {
     WDEV void flush_bin(uint32_t pos, uint32_t acc) { if ((pos & 1u) && acc != kNoBin) gst(bins + pos - 1, (uint16_t)acc); }
 
     // whole segment (lepton_codec.hh:41-100 row schedule, vp8_encoder.cc:239-445); ns: the segment's two-row NSum rings (zeroed)
-    WDEV int run(const ImageDev* image, const SegDev& seg, NSum* ns, Walk5Shared* shared, const SegPlan5* pl, uint8_t* arena_base, uint16_t* bins_base) {
-        img = image; sh = shared; plan = pl; status = 0;
+    WDEV int run(const ImageDev* image, const SegDev& seg, NSum* ns, Walk5Shared* shared, const SegPlan5* pl, uint8_t* arena_base, uint16_t* bins_base,
+                 int wave_no = 0) {
+        img = image; sh = shared; plan = pl; status = 0; wave = wave_no;
         arena = (MODE != kCount) ? arena_base + pl->arena_off : nullptr;
         bins = (MODE == kGather) ? bins_base + pl->bins_off : nullptr;
         ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0; tile_no = 0;
         AT = MODE != kCount ? reinterpret_cast<uint32_t*>(arena + pl->at_base) : nullptr;
         if (MODE != kCount) { sign_base[0] = pl->sign_base[0]; sign_base[1] = pl->sign_base[1]; key_base = pl->key_base; nz_base = pl->nz_base; en_base = pl->en_base; dc_base = pl->dc_base; }
         LANES(l) {   // emit / gather: a cursor is the absolute place of the stream's next unit
-            for (int i = l; i < 2 * kRows * kClasses; i += 64) LEP5_WSH(this).cursor[i] = MODE == kCount ? 0u : pl->base[i];
+            for (int i = l; i < 2 * kRows * kClasses; i += 64) LEP5_WSH(this).cursor[i] = MODE == kCount ? 0u : pl->base[i];   // (every wavefront: the same values)
         }
-        LSYNC();
+        LEP5_XSYNC();
         // the tiles of the segment in stream order (lepton_codec.hh:41-100; vp8_encoder.cc:83-154: a row ends where the file was cut)
         TileIter it;
         it.init(image, seg, ns);
@@ -1163,6 +1210,7 @@ struct Walk5 {
             cur_t = nxt_t;
             have = more;
         }
+        LEP5_XSYNC();   // (count: the cursors are complete)
         return 0;
     }
 };

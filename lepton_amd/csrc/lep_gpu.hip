@@ -150,10 +150,10 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
 
 
 // ---- the split-phase encoder (lep_enc5.h) -------------------------------------------------------------------------------------
-// walk: one wavefront per segment (count / emit / gather share the code); LDS: two transposed coefficient tiles, the tile's
-// entry payloads and ranks, the stream cursors
-template <int MODE>
-__global__ __launch_bounds__(64) void lep_enc5_walk_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs, NSum* ns_all,
+// walk: one or two wavefronts per segment (count / emit / gather share the code; NW = 2: lep_enc5.h Walk5); LDS: two transposed
+// coefficient tiles, the tile's entry payloads and ranks, the stream cursors
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void lep_enc5_walk_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs, NSum* ns_all,
                                                          const uint64_t* __restrict__ ns_off, lep5::SegPlan5* plans, uint8_t* arena, uint16_t* bins,
                                                          uint32_t* counts) {
     lep5::Walk5Shared* sh = reinterpret_cast<lep5::Walk5Shared*>(lep5::lep5_lds);   // dynamic LDS (sizeof(Walk5Shared) at launch)
@@ -161,8 +161,9 @@ __global__ __launch_bounds__(64) void lep_enc5_walk_kernel(const ImageDev* __res
     const SegDev seg = segs[s];
     lep5::SegPlan5* P = plans + s;
     if (MODE == lep5::kGather && P->status) return;
-    lep5::Walk5<MODE> w;
-    const int rc = w.run(images + seg.image, seg, ns_all + ns_off[s], sh, P, arena, bins);
+    lep5::Walk5<MODE, NW> w;
+    const int rc = w.run(images + seg.image, seg, ns_all + ns_off[s], sh, P, arena, bins, (int)(threadIdx.x >> 6));
+    if (threadIdx.x >= 64) return;
     if (MODE == lep5::kCount) lep5::export_counts(w, sh, counts + (size_t)s * lep5::kCountWords);
     if (threadIdx.x == 0) {
         if (MODE == lep5::kEmit) P->status = rc;
@@ -319,9 +320,7 @@ struct lep_gpu {
     int enc5_min = 64;       // launches of at least this many segments take the split-phase encoder (lep_enc5.h); LEP_ENC5_MIN (0 = never)
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
-    hipStream_t gstream[4] = {nullptr, nullptr, nullptr, nullptr};   // one per segment group of a split-phase launch
-    hipEvent_t ev_gjoin[4] = {nullptr, nullptr, nullptr, nullptr};
-    int enc5_groups = 0;     // LEP_ENC5_GROUPS (0 = by launch size)
+    int enc5_waves = 2;      // LEP_ENC5_WAVES: wavefronts per segment in the split-phase walks (1 | 2)
     hipEvent_t ev_stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the last split-phase launch
     int nstage = 0;
     int enc_waves = 0;       // the same choice for the encoder (LEP_ENC_WAVES = 4 | 8; 2 = the two-wavefronts-per-segment kernel)
@@ -394,8 +393,6 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
         HIPCHK(g, hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
         HIPCHK(g, hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
         HIPCHK(g, hipEventCreateWithFlags(&g->ev_join3, hipEventDisableTiming));
-        for (auto& e : g->gstream) HIPCHK(g, hipStreamCreateWithFlags(&e, hipStreamNonBlocking));
-        for (auto& e : g->ev_gjoin) HIPCHK(g, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : g->ev_stage) HIPCHK(g, hipEventCreate(&e));
     }
     const size_t o_counts = ((size_t)nseg * sizeof(lep5::SegPlan5) + 255) & ~(size_t)255,
@@ -407,7 +404,16 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     const int groups = (nseg + 63) / 64;
     g->nstage = 0;
     HIPCHK(g, hipEventRecord(g->ev_stage[0], st));
-    hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kCount>), dim3(nseg), dim3(64), lep5::kWalkLdsNoAbove, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)nullptr, (uint16_t*)nullptr, counts);
+    const bool two = g->enc5_waves == 2;
+    auto walk = [&](int mode, uint8_t* entries, uint16_t* binlist) {
+        const size_t lds = mode == lep5::kEmit ? sizeof(lep5::Walk5Shared) : lep5::kWalkLdsNoAbove;
+#define LEP_WALK(MODE, NW) hipLaunchKernelGGL((lep_enc5_walk_kernel<MODE, NW>), dim3(nseg), dim3(64 * NW), lds, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, entries, binlist, counts)
+        if (mode == lep5::kCount) { if (two) LEP_WALK(lep5::kCount, 2); else LEP_WALK(lep5::kCount, 1); }
+        else if (mode == lep5::kEmit) { if (two) LEP_WALK(lep5::kEmit, 2); else LEP_WALK(lep5::kEmit, 1); }
+        else { if (two) LEP_WALK(lep5::kGather, 2); else LEP_WALK(lep5::kGather, 1); }
+#undef LEP_WALK
+    };
+    walk(lep5::kCount, nullptr, nullptr);
     hipLaunchKernelGGL(lep_enc5_plan_kernel, dim3(groups), dim3(64), 0, st, (const uint32_t*)counts, plans, nseg);
     hipLaunchKernelGGL(lep_enc5_offsets_kernel, dim3(1), dim3(64), 0, st, plans, nseg, d_tot);
     // the threshold Branches are the only model state in HBM: 2 MB per segment, reset while the count pass is looked at
@@ -417,15 +423,11 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     HIPCHK(g, hipStreamSynchronize(st));
     if (int rc = ensure(g, &A.d_entries, &A.entries_bytes, (size_t)tot[0] + 256)) return rc;
     if (int rc = ensure(g, &A.d_binlist, &A.binlist_bytes, (size_t)tot[1] * 2 + 256)) return rc;
-    // Every stage leaves part of the chip idle (the walks are bound by LDS per wavefront, the folds and the writer by
-    // dependent-instruction latency), and the writer needs the same time for 64 segments as for 8192.  So the segments go
-    // through emit .. write in GROUPS, each group on a stream of its own: one group's writer and folds run beside the next
-    // group's walks.  (LEP_ENC5_GROUPS=1: one group, with the stage boundaries recorded for lep_gpu_last_stage_ms.)
-    int G = g->enc5_groups > 0 ? g->enc5_groups : 1;   // measured (MI355X, 1024 x 4K, profiles/r04l_*): 1 group 784 ms, 2: 875, 4: 1232 -- streams with grids this large do not share the chip
-    if (G > 4) G = 4;
-    if (G == 1) {
+    // (Segment groups on streams of their own -- one group's writer and folds beside the next group's walks -- were measured
+    // and dropped: MI355X, 1024 x 4K, profiles/r04l_*: 1 group 784 ms, 2: 875, 4: 1232; launches this large do not share the chip.)
+    {
         HIPCHK(g, hipEventRecord(g->ev_stage[1], st));
-        hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kEmit>), dim3(nseg), dim3(64), sizeof(lep5::Walk5Shared), st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)nullptr, counts);
+        walk(lep5::kEmit, (uint8_t*)A.d_entries, nullptr);
         HIPCHK(g, hipEventRecord(g->ev_stage[2], st));
         HIPCHK(g, hipEventRecord(g->ev_fork, st));
         HIPCHK(g, hipStreamWaitEvent(g->stream2, g->ev_fork, 0));
@@ -439,36 +441,15 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join3, 0));
         HIPCHK(g, hipEventRecord(g->ev_stage[3], st));
-        hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kGather>), dim3(nseg), dim3(64), lep5::kWalkLdsNoAbove, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, (uint8_t*)A.d_entries, (uint16_t*)A.d_binlist, counts);
+        walk(lep5::kGather, (uint8_t*)A.d_entries, (uint16_t*)A.d_binlist);
         HIPCHK(g, hipEventRecord(g->ev_stage[4], st));
         hipLaunchKernelGGL(lep_enc5_write_kernel, dim3(groups), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (const uint16_t*)A.d_binlist, d_seg, nseg, d_streams, d_stream_len,
                            d_status, g->d_bins);
         HIPCHK(g, hipEventRecord(g->ev_stage[5], st));
         g->nstage = 5;
-    } else {
-        HIPCHK(g, hipEventRecord(g->ev_fork, st));
-        const int per = ((nseg + G - 1) / G + 63) & ~63;   // whole fold / write wavefronts per group
-        for (int gi = 0; gi < G; ++gi) {
-            const int s0 = gi * per, n = std::min(per, nseg - s0);
-            if (n <= 0) break;
-            hipStream_t sg = g->gstream[gi];
-            const int grp = (n + 63) / 64;
-            const lep5::SegPlan5* pl = plans + s0;
-            HIPCHK(g, hipStreamWaitEvent(sg, g->ev_fork, 0));
-            hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kEmit>), dim3(n), dim3(64), sizeof(lep5::Walk5Shared), sg, d_img, d_seg + s0, (NSum*)A.d_ns, d_nsoff + s0, plans + s0, (uint8_t*)A.d_entries,
-                               (uint16_t*)nullptr, counts);
-            hipLaunchKernelGGL(lep_enc5_fold_small_kernel, dim3((unsigned)grp * kFold5SmallJobs), dim3(64), 0, sg, pl, (uint8_t*)A.d_entries, (uint32_t*)A.d_models + (size_t)s0 * lep5::kThreshWords, n, grp);
-            hipLaunchKernelGGL(lep_enc5_fold_big_kernel, dim3((unsigned)grp * kFold5BigJobs), dim3(64), 0, sg, pl, (uint8_t*)A.d_entries, n, grp);
-            hipLaunchKernelGGL(lep_enc5_fold_coef_kernel, dim3((unsigned)grp * 1260u), dim3(64), 0, sg, pl, (uint8_t*)A.d_entries, n, grp);
-            hipLaunchKernelGGL((lep_enc5_walk_kernel<lep5::kGather>), dim3(n), dim3(64), lep5::kWalkLdsNoAbove, sg, d_img, d_seg + s0, (NSum*)A.d_ns, d_nsoff + s0, plans + s0, (uint8_t*)A.d_entries,
-                               (uint16_t*)A.d_binlist, counts);
-            hipLaunchKernelGGL(lep_enc5_write_kernel, dim3(grp), dim3(64), 0, sg, pl, (const uint16_t*)A.d_binlist, d_seg + s0, n, d_streams, d_stream_len, d_status, g->d_bins);
-            HIPCHK(g, hipEventRecord(g->ev_gjoin[gi], sg));
-            HIPCHK(g, hipStreamWaitEvent(st, g->ev_gjoin[gi], 0));
-        }
     }
     HIPCHK(g, hipGetLastError());
-    g->last_kernel = G == 1 ? "lep_enc5 (count | emit | fold | gather | write)" : "lep_enc5 (count | emit | fold | gather | write, segment groups pipelined)";
+    g->last_kernel = "lep_enc5 (count | emit | fold | gather | write)";
     return 0;
 }
 
@@ -603,7 +584,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 0));
     if (const char* e = getenv("LEP_ENC_PAIR_MAX")) g->enc_pair_max = atoi(e);
     if (const char* e = getenv("LEP_ENC5_MIN")) g->enc5_min = atoi(e);
-    if (const char* e = getenv("LEP_ENC5_GROUPS")) g->enc5_groups = atoi(e);
+    if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||
@@ -628,8 +609,6 @@ static void release_device_side(lep_gpu* g) {
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     if (g->ev_join3) (void)hipEventDestroy(g->ev_join3);
-    for (auto& e : g->ev_gjoin) if (e) (void)hipEventDestroy(e);
-    for (auto& e : g->gstream) if (e) (void)hipStreamDestroy(e);
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     if (g->stream3) (void)hipStreamDestroy(g->stream3);
     for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffprog[0], g->d_huffprog[1], g->d_huffprogdec, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})

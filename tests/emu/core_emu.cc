@@ -251,8 +251,9 @@ extern "C" int emu_huffman_decode_image_parallel(const lep_huffdec_image* img, l
 // split-phase encoder (lep_enc5.h): count -> plan -> emit -> fold (every chain) -> gather -> write, one segment, every pass
 // stepped as a 64-lane loop emulation; bins_out (optional): the (probability | bit << 8) list the writer consumed
 #include "../../lepton_amd/csrc/lep_enc5.h"
-extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins,
-                                     uint16_t* bins_out, uint32_t bins_out_cap) {
+template <int NW>
+static int encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins,
+                             uint16_t* bins_out, uint32_t bins_out_cap) {
     using namespace lep5;
     ImageDev img;
     int rc = derive_image(*d, &img, true);
@@ -265,7 +266,7 @@ extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, in
     std::vector<uint32_t> counts(kCountWords, 0);
     static SegPlan5 plan;
     {
-        Walk5<kCount> w;
+        Walk5<kCount, NW> w;
         memset(ns.data(), 0, ns.size() * sizeof(NSum));
         w.run(&img, seg, ns.data(), &wsh, &plan, nullptr, nullptr);
         export_counts(w, &wsh, counts.data());
@@ -274,7 +275,7 @@ extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, in
     std::vector<uint8_t> arena(plan.arena_bytes + 64, 0xA5);   // poisoned: every byte read must have been written
     std::vector<uint16_t> binlist(plan.bins_cap + 64, 0xA5A5);
     {
-        Walk5<kEmit> w;
+        Walk5<kEmit, NW> w;
         memset(ns.data(), 0, ns.size() * sizeof(NSum));
         rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), nullptr);
         if (rc) return rc;
@@ -296,7 +297,7 @@ extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, in
     }
     for (int a = 0; a < 12; ++a) fold_dc_wave(&plan, arena.data(), 0, 1, a, &fsh);
     {
-        Walk5<kGather> w;
+        Walk5<kGather, NW> w;
         memset(ns.data(), 0, ns.size() * sizeof(NSum));
         rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), binlist.data());
         if (rc) return rc;
@@ -310,6 +311,15 @@ extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, in
     write_wave(&plan, binlist.data(), &seg, 0, 1, out, &slen, &status);
     *len = slen;
     return status == 100 ? LEP_BUFFER_TOO_SMALL : status;
+}
+extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins,
+                                     uint16_t* bins_out, uint32_t bins_out_cap) {
+    return encode_segment_v5<1>(d, y0, y1, is_last, out, cap, len, bins, bins_out, bins_out_cap);
+}
+// ... with the walks split into their two halves (what two wavefronts per segment run side by side on the GPU)
+extern "C" int emu_encode_segment_v5_halves(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins,
+                                            uint16_t* bins_out, uint32_t bins_out_cap) {
+    return encode_segment_v5<2>(d, y0, y1, is_last, out, cap, len, bins, bins_out, bins_out_cap);
 }
 
 

@@ -1107,17 +1107,22 @@ def test_gpu_scan_encoder_end_states_are_held_against_the_hand_offs(emu):
     assert run(last)[0] == 0
 
 
-def _v5_encode(emu, d, s, cap):
+V5_ENTRIES = ("emu_encode_segment_v5", "emu_encode_segment_v5_halves")   # one wavefront per segment; the walks' two halves apart
+
+
+def _v5_encode(emu, d, s, cap, entry="emu_encode_segment_v5"):
     buf = C.create_string_buffer(cap)
     n, nb = C.c_uint32(0), C.c_uint32(0)
-    rc = emu.emu_encode_segment_v5(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, cap, C.byref(n), C.byref(nb), None, 0)
+    rc = getattr(emu, entry)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, cap, C.byref(n), C.byref(nb), None, 0)
     return rc, buf.raw[: n.value], nb.value
 
 
+@pytest.mark.parametrize("entry", V5_ENTRIES)
 @pytest.mark.parametrize("name", golden_cases())
-def test_split_phase_encoder_on_cpu_matches_oracle(emu, name):
+def test_split_phase_encoder_on_cpu_matches_oracle(emu, name, entry):
     """lep_enc5.h -- count / emit / fold per chain / gather / lane-per-segment writer -- stepped on the CPU: every segment's
-    stream == the oracle's, and the bin list has the oracle's number of bins (minus the start marker and the 32 stop bins)"""
+    stream == the oracle's, and the bin list has the oracle's number of bins (minus the start marker and the 32 stop bins).
+    `_halves`: the walks run as the two halves (7x7 interiors | records, edges, DC) two wavefronts share on the GPU"""
     jpg, _ = golden(name)
     img = JpegImage(jpg)
     d = img.desc
@@ -1125,14 +1130,15 @@ def test_split_phase_encoder_on_cpu_matches_oracle(emu, name):
     want, bins = ob.oracle_encode(d, segs)
     total = 0
     for s, w in zip(segs, want):
-        rc, got, nb = _v5_encode(emu, d, s, len(w) + 4096)
+        rc, got, nb = _v5_encode(emu, d, s, len(w) + 4096, entry)
         assert rc == 0
         assert got == w
         total += nb
     assert total == bins
 
 
-def test_split_phase_encoder_large_coefficients_and_refusals(emu):
+@pytest.mark.parametrize("entry", V5_ENTRIES)
+def test_split_phase_encoder_large_coefficients_and_refusals(emu, entry):
     """lep_enc5.h on blocks full of large coefficients (entries of several units, threshold units, exponent rows to the end) and
     the refusals in the serial coder's order: the FIRST offence in stream order names the exit code -- an out-of-range interior
     coefficient (6), a DC that does not survive prediction (6) in a block BEHIND it, an edge whose prior divides by zero (43)"""
@@ -1157,7 +1163,7 @@ def test_split_phase_encoder_large_coefficients_and_refusals(emu):
     want, bins = ob.oracle_encode(d, segs)
     total = 0
     for s, w in zip(segs, want):
-        rc, got, nb = _v5_encode(emu, d, s, len(w) + 4096)
+        rc, got, nb = _v5_encode(emu, d, s, len(w) + 4096, entry)
         assert rc == 0 and got == w
         total += nb
     assert total == bins
@@ -1170,7 +1176,7 @@ def test_split_phase_encoder_large_coefficients_and_refusals(emu):
             o = 0
         except RuntimeError as e:
             o = int(str(e).rsplit(" ", 1)[1])
-        return o, _v5_encode(emu, d, s, 1 << 20)[0]
+        return o, _v5_encode(emu, d, s, 1 << 20, entry)[0]
 
     luma = C.cast(d.blocks[0], C.POINTER(C.c_int16))
     chroma = C.cast(d.blocks[1], C.POINTER(C.c_int16))
@@ -1182,6 +1188,12 @@ def test_split_phase_encoder_large_coefficients_and_refusals(emu):
     chroma[49] = 3000                             # a DC the prediction cannot wrap back (first coded block of the segment)
     assert both() == (6, 6)
     chroma[49] = save
+    assert both() == (0, 0)
+    # an interior refusal in a block BEHIND a block whose DC is refused: the DC's block comes first in the stream
+    s1, s2 = luma[64 * 5 + 5], luma[64 * 2 + 49]
+    luma[64 * 5 + 5], luma[64 * 2 + 49] = 4096, 3000
+    assert both() == (6, 6)
+    luma[64 * 5 + 5], luma[64 * 2 + 49] = s1, s2
     assert both() == (0, 0)
 
 

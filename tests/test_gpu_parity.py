@@ -467,19 +467,22 @@ def test_gpu_decoder_follows_the_reference_on_impossible_edge_counts(gpu_codec, 
         assert C.string_at(f.desc.blocks[c], n) == orig[c][:n]
 
 
-@pytest.fixture(scope="module")
-def gpu_codec_v5():
-    """a codec object that takes the split-phase encoder (lep_enc5.h) for every launch, however small"""
+@pytest.fixture(scope="module", params=[2, 1], ids=["two_wavefronts_per_segment", "one_wavefront_per_segment"])
+def gpu_codec_v5(request):
+    """a codec object that takes the split-phase encoder (lep_enc5.h) for every launch, however small; its walks with two
+    wavefronts per segment (the default) and with one"""
     import os
-    old = os.environ.get("LEP_ENC5_MIN")
+    old = {k: os.environ.get(k) for k in ("LEP_ENC5_MIN", "LEP_ENC5_WAVES")}
     os.environ["LEP_ENC5_MIN"] = "1"
+    os.environ["LEP_ENC5_WAVES"] = str(request.param)
     try:
         return GpuCodec(0)
     finally:
-        if old is None:
-            del os.environ["LEP_ENC5_MIN"]
-        else:
-            os.environ["LEP_ENC5_MIN"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.gpu
