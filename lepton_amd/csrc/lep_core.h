@@ -88,6 +88,7 @@ LEP_TABLE uint8_t kNzBin[50] = {0, 1, 2, 3, 4, 4, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 
 LEP_DEV int bitlen(uint32_t v) { return v ? 32 - __builtin_clz(v) : 0; }
 LEP_DEV int iabs(int v) { return v < 0 ? -v : v; }
 LEP_DEV int imin(int a, int b) { return a < b ? a : b; }
+LEP_DEV int imax(int a, int b) { return a > b ? a : b; }
 
 // ---- adaptive binary arithmetic coder ------------------------------------------------------------
 template <bool DEC>

@@ -38,8 +38,8 @@ constexpr int kPRows = 63 + 14;                         // payload rows of a til
 constexpr int kStreams = 2 * kRows * kClasses;          // 1280 4-byte-unit streams per segment
 WDEV int stream_id(int ci, int row, int k) { return (ci * kRows + row) * kClasses + k; }
 // slice of a coefficient chain: exponent Branches [12 bsr][11] then residual Branches [10]
-constexpr int kCoefSlice = 12 * 11 + 10;
-constexpr int kSignSlice = 48, kNzSlice = 6 * 32, kEdgeNzSlice = 8 * 12, kDcSlice = 17 * 11 + 10;
+constexpr int kCoefSlice = 12 * 11 + 10 + 1;   // (+ 1: the Branch the bins a unit does not have are pointed at, see fold_coef_unit)
+constexpr int kSignSlice = 48, kNzSlice = 6 * 32, kEdgeNzSlice = 8 * 12, kDcSlice = 17 * 11 + 10 + 1;
 constexpr uint32_t kThreshWords = 2u * 256 * 8 * 128;   // per segment, HBM: [ci][prior class][lt][128]
 
 // A coefficient's chain-local bin sequence: its exponent bins (nexp = min(len + 1, 11)), then its residual bins that use the
@@ -113,18 +113,29 @@ WDEV uint32_t inv24_5(uint32_t d) {   // lep_dec4.h inv24_of: exact for every re
 // probability 0 from then on, where the same pair reached by counting gives 1 (branch.hh:86-91).  That state is stored as
 // t = 0.  (Saturating on "false" leaves (255, 1) with probability 255, which is what the formula gives.)  Half the LDS of the
 // packed word of lep_core.h: twice the resident fold wavefronts.
-WDEV uint32_t prob16(uint32_t w) { const uint32_t t = w >> 8; return t ? prob_of(w & 255u, t) : 0u; }
+// Both are straight-line code: a lane's bins take every path there is, and 64 lanes take them all at once -- with branches the
+// compiler's exec-mask bookkeeping was three quarters of the fold kernels' instructions.
+WDEV uint32_t prob16(uint32_t w) {
+    const uint32_t f = w & 255u, t = w >> 8;
+#if LEP_ON_GPU
+    // floor(256 f / (f + t)) from the hardware reciprocal: the product is off by less than 2^-14 (1 ulp of rcp, half of the
+    // multiply, quotient < 256) and a quotient that is not whole is at least 1 / 510 away from the next whole number, so adding
+    // 2^-10 before truncating lands on the right side in every case (lep_gpu_selftest checks all 255 x 255 pairs on the device)
+    const uint32_t p = (uint32_t)__builtin_fmaf((float)(f << 8), __builtin_amdgcn_rcpf((float)(f + t)), 0x1p-10f);
+#else
+    const uint32_t p = (f << 8) / (f + t);
+#endif
+    return t ? p : 0u;
+}
 WDEV uint32_t upd16(uint32_t w, uint32_t obs) {
-    uint32_t f = w & 255u, t = w >> 8;
-    if (t == 0) return obs ? w : (2u | (255u << 8));   // saturated true: counts (1, 255); a false makes them (2, 255)
-    if (obs) {
-        if (t == 255u) { if (f == 1u) return 1u; f = (1u + f) >> 1; t = 129u; }
-        else ++t;
-    } else {
-        if (f == 255u) { if (t == 1u) return w; t = (1u + t) >> 1; f = 129u; }
-        else ++f;
-    }
-    return f | (t << 8);
+    const uint32_t sh = obs << 3, t = w >> 8;
+    const uint32_t hot = (w >> sh) & 255u, cold = (w >> (8u - sh)) & 255u;   // the count that grows, the other one
+    const uint32_t half = (1u + cold) >> 1;
+    const uint32_t renorm = (129u << sh) | (half << (8u - sh));            // the grown count was 255: both halve
+    const uint32_t stuck = obs ? 1u : w;                                     // ... and the other one 1: saturated (true: the t = 0 state)
+    uint32_t r = w + (1u << sh);
+    r = hot == 255u ? (cold == 1u ? stuck : renorm) : r;
+    return t == 0u ? (obs ? w : (2u | (255u << 8))) : r;                     // saturated true: counts (1, 255); a false makes them (2, 255)
 }
 constexpr uint32_t kBranchInit16 = 1u | (1u << 8);
 // Every lane owns `SLICE` Branches in LDS, laid out [branch][lane] (lanes next to each other: no bank conflicts whatever the
@@ -150,7 +161,9 @@ WDEV void fold_init(FoldShared* sh, int words_per_lane) {
     LSYNC();
 }
 
-// the bins of unit u of a coefficient entry through the lane's slice; exponent Branch = bsr * 11 + i, residual = rbase + b
+// the bins of unit u of a coefficient entry through the lane's slice; exponent Branch = bsr * 11 + i, residual = rbase + b.
+// Straight-line: a bin the unit does not have goes through the spare Branch at rbase + 10, whose state nobody reads (its byte
+// of the result is not one gather looks at).
 WDEV uint32_t fold_coef_unit(FoldLane& fl, uint32_t e, int rbase) {
     const int nres = (int)(e >> 10) & 15, len = (int)(e >> 14) & 15, bsr = (int)(e >> 18) & 31, u = (int)(e >> 27) & 7;
     const int nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
@@ -160,17 +173,16 @@ WDEV uint32_t fold_coef_unit(FoldLane& fl, uint32_t e, int rbase) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int j = 4 * u + q;
-        const int b = nres - 1 - (j - nexp);
-        br[q] = j < nexp ? bsr * 11 + j : rbase + (b < 0 ? 0 : b);
-        bit[q] = j < nexp ? (uint32_t)(len != j) : (e >> (b < 0 ? 0 : b)) & 1u;
-        if (j >= m) br[q] = -1;
+        const int b = imax(nres - 1 - (j - nexp), 0);
+        br[q] = j < nexp ? bsr * 11 + j : rbase + b;
+        bit[q] = j < nexp ? (uint32_t)(len != j) : (e >> b) & 1u;
+        br[q] = j >= m ? rbase + 10 : br[q];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = br[q] >= 0 ? fl.s[br[q] * 64] : 0u;
+    for (int q = 0; q < 4; ++q) w[q] = fl.s[br[q] * 64];
     uint32_t probs = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        if (br[q] >= 0) { fl.s[br[q] * 64] = (uint16_t)upd16(w[q], bit[q]); probs |= prob16(w[q]) << (8 * q); }
+    for (int q = 0; q < 4; ++q) { fl.s[br[q] * 64] = (uint16_t)upd16(w[q], bit[q]); probs |= prob16(w[q]) << (8 * q); }
     return probs;
 }
 
@@ -190,10 +202,10 @@ WDEV void fold_coef_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
             for (uint32_t i = 0; i < n; i += 4) {   // four entries per dwordx4, the next group requested before this one is folded
                 U4 g = nxt;
                 if (i + 4 < n) nxt = ld4(p + i + 4);
-                g.x = fold_coef_unit(fl, g.x, 132);
-                if (i + 1 < n) g.y = fold_coef_unit(fl, g.y, 132);
-                if (i + 2 < n) g.z = fold_coef_unit(fl, g.z, 132);
-                if (i + 3 < n) g.w = fold_coef_unit(fl, g.w, 132);
+                g.x = fold_coef_unit(fl, g.x, 132);   // (behind the stream's last unit: zeros, written by emit -- harmless bins)
+                g.y = fold_coef_unit(fl, g.y, 132);
+                g.z = fold_coef_unit(fl, g.z, 132);
+                g.w = fold_coef_unit(fl, g.w, 132);
                 st4(p + i, g);
             }
         }
@@ -1210,7 +1222,13 @@ struct Walk5 {
             cur_t = nxt_t;
             have = more;
         }
-        LEP5_XSYNC();   // (count: the cursors are complete)
+        LEP5_XSYNC();   // (the cursors are complete)
+        if (MODE == kEmit && wave == 0) {   // every stream is padded to whole groups of four units: the fold takes them group by group
+            LANES(l) {
+                for (int i = l; i < kStreams; i += 64)
+                    for (uint32_t j = LEP5_WSH(this).cursor[i]; j < pl->base[i + 1]; ++j) gst(units() + j, 0u);
+            }
+        }
         return 0;
     }
 };

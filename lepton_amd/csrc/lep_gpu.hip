@@ -115,6 +115,7 @@ __global__ void lep_selftest_kernel(uint32_t* mismatches) {
         if (lep4::bupd_t(w, obs, inv24) != branch_update(w, (int)obs)) atomicAdd(mismatches, 1u);
     }
     if (lep3::prob_of(f, t) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);
+    if (lep5::prob16(f | (t << 8)) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);   // the fold kernels' form (lep_enc5.h)
     for (int obs = 0; obs < 2; ++obs) {
         const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);
         if (lep3::bupd(w, obs) != branch_update(w, obs)) atomicAdd(mismatches, 1u);

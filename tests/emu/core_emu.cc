@@ -381,3 +381,21 @@ extern "C" int emu_check_branch16(int walks) {
     }
     return 0;
 }
+
+// the count walk's result for one segment: counts[lep5::kCountWords] (units per stream, sign bytes, blocks, bins bound, tiles)
+extern "C" int emu_v5_counts(const lep_image_desc* d, int y0, int y1, int is_last, uint32_t* counts) {
+    using namespace lep5;
+    ImageDev img;
+    int rc = derive_image(*d, &img, true);
+    if (rc) return rc;
+    std::vector<NSum> ns(img.ns_total);
+    SegDev seg;
+    seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = 0; seg.slot = 0;
+    static Walk5Shared wsh;
+    static SegPlan5 plan;
+    Walk5<kCount> w;
+    memset(ns.data(), 0, ns.size() * sizeof(NSum));
+    w.run(&img, seg, ns.data(), &wsh, &plan, nullptr, nullptr);
+    export_counts(w, &wsh, counts);
+    return 0;
+}
