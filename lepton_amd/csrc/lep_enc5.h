@@ -57,19 +57,31 @@ WDEV uint32_t thresh_entry(uint32_t tbits, int n, int pcls, int lt, int u) {
     return tbits | ((uint32_t)n << 10) | ((uint32_t)pcls << 14) | ((uint32_t)lt << 23) | ((uint32_t)u << 27);
 }
 // sign entry (one byte): bits 0..5 Branch slot inside the colour's [4][12] table, bit 6 the bit, bit 7 valid
-// sparse records, one per block ordinal of the segment (chains whose key needs the neighbours: filtered by the fold lanes):
-//   KEY (4 bytes, never overwritten): ci | 7x7 context bin << 1 | eob_x << 5 | eob_y << 8 | a << 11 -- what the fold lanes filter on
+// sparse records, one per block ordinal of the segment (chains whose key needs the neighbours).  emit writes them in block
+// order; `bucket` sorts them into one stream per chain (the fold lanes had filtered the block-ordered records by key before:
+// 64 chains x every block's key and record -- two thirds of the fold stage's memory requests) and leaves the places for gather:
+//   KEY (4 bytes): ci | 7x7 context bin << 1 | eob_x << 5 | eob_y << 8 | a << 11 -- the record's four chains
 //   NZ  (8 bytes): word 0 = number of non-zeros                           -> six probabilities in bytes 0..5
 //   EN  (2 x 4 bytes, horizontal then vertical): nzq | ne << 3            -> three probabilities
 //   DC  (6 x 4 bytes): word 0 = unit 0 of an entry like a coefficient's with k = a, bsr = b17 -> the units' probabilities
 constexpr int kKeyRec = 4, kNzRec = 8, kEnRec = 8, kDcRec = 24;
+// the sparse chains: 7x7 counts (ci, context bin), horizontal / vertical edge counts (ci, eob_x / eob_y), DC (a)
+constexpr int kClsNz = 0, kClsEh = 20, kClsEv = 36, kClsDc = 52, kNumCls = 64;
+WDEV void key_classes(uint32_t key, int c[4]) {
+    const int ci = (int)(key & 1u);
+    c[0] = kClsNz + ci * 10 + (int)((key >> 1) & 15u); c[1] = kClsEh + ci * 8 + (int)((key >> 5) & 7u);
+    c[2] = kClsEv + ci * 8 + (int)((key >> 8) & 7u); c[3] = kClsDc + (int)((key >> 11) & 15u);
+}
 constexpr int kAtRows = 65;   // rows of a tile in the array of places: 63 coefficient rows, the DC entry, the DC sign byte
 
 struct SegPlan5 {            // one per segment, device memory; written by plan5 from the counts
     uint64_t arena_off;      // byte offset of the segment's entry arena (16-byte aligned)
     uint64_t bins_off;       // offset of the segment's bin list, in bins (uint16)
     uint32_t sign_base[2], sign_cnt[2];       // byte streams, relative to arena_off
-    uint32_t key_base, nz_base, en_base, dc_base;   // byte offsets of the sparse regions
+    uint32_t key_base, nz_base, en_base, dc_base;   // byte offsets of the sparse regions (block order, written by emit)
+    uint32_t cls_base;       // bucket's table: [kNumCls] first record of the chain's stream, [kNumCls] records
+    uint32_t place_base;     // [4][nblocks]: the block's place in its 7x7 count / horizontal / vertical / DC stream
+    uint32_t nzs_base, ens_base[2], dcs_base;       // the chains' streams (every chain padded to four records)
     uint32_t at_base, ntiles;                       // the places emit gave out, for gather: [tile][65 rows][64 lanes] dwords
     uint32_t nblocks;        // block ordinals (coded blocks of the segment)
     uint32_t bins_cap;       // room in the bin list
@@ -272,9 +284,7 @@ WDEV void fold_sign_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int ns
     }
 }
 
-// sparse chains: lane = segment, the wave's key filters the records of the lane's segment.  Key words and records are read a
-// group of four blocks at a time (the regions start on 16 bytes and are padded), the next group requested before this one is
-// looked at: a record fetched only once its key has matched would put a trip to HBM on every match.
+// sparse chains: lane = segment; every chain has a stream of its own (bucket_wave), padded to four records
 // number of non-zeros of the 7x7 interior: six bins MSB first through T[level][prefix] (encoder.cc:200-213)
 WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg, int ci, int ctxbin, FoldShared* sh) {
     fold_init(sh, kNzSlice);
@@ -282,29 +292,31 @@ WDEV void fold_nz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
         const int seg = seg0 + l;
         if (seg < nseg) {
             const SegPlan5& P = plans[seg];
-            uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.nz_base);
-            const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
+            const uint32_t* ctab = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.cls_base);
+            const int c = kClsNz + ci * 10 + ctxbin;
+            const uint32_t n = P.status ? 0u : ctab[kNumCls + c];
+            uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.nzs_base) + 2 * (size_t)(n ? ctab[c] : 0u);
             FoldLane fl{sh->slice + fold_col(l)};
-            const uint32_t key = (uint32_t)ci | ((uint32_t)ctxbin << 1), nb = P.status ? 0u : P.nblocks;
-            U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0}, nr0 = nb ? ld4(rec) : U4{0, 0, 0, 0}, nr1 = nb ? ld4(rec + 4) : U4{0, 0, 0, 0};
-            for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
-                const U4 k4 = nk, r0 = nr0, r1 = nr1;
-                if (b0 + 4 < nb) { nk = ld4(keys + b0 + 4); nr0 = ld4(rec + 2 * (b0 + 4)); nr1 = ld4(rec + 2 * (b0 + 4) + 4); }
-                const uint32_t kw[4] = {k4.x, k4.y, k4.z, k4.w}, nzv[4] = {r0.x, r0.z, r1.x, r1.z};
-                for (int q = 0; q < 4 && b0 + q < nb; ++q) {
-                    if ((kw[q] & 31u) != key) continue;
+            U4 nxt = n ? ld4(rec) : U4{0, 0, 0, 0};
+            for (uint32_t i = 0; i < n; i += 2) {   // two records per dwordx4 (behind the last one: zeros)
+                U4 g = nxt;
+                if (i + 2 < n) nxt = ld4(rec + 2 * (i + 2));
+                uint32_t nzv[2] = {g.x, g.z}, lo[2], hi[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
                     const int nz = (int)nzv[q] & 63;
-                    uint32_t lo = 0, hi = 0;
+                    lo[q] = 0; hi[q] = 0;
                     int so_far = 0;
-                    for (int i = 5; i >= 0; --i) {
-                        const uint32_t bit = (uint32_t)(nz >> i) & 1u;
-                        const uint32_t p = fl.code(i * 32 + so_far, bit);
-                        const int t = 5 - i;
-                        if (t < 4) lo |= p << (8 * t); else hi |= p << (8 * (t - 4));
+#pragma unroll
+                    for (int b = 5; b >= 0; --b) {
+                        const uint32_t bit = (uint32_t)(nz >> b) & 1u;
+                        const uint32_t p = fl.code(b * 32 + so_far, bit);
+                        const int t = 5 - b;
+                        if (t < 4) lo[q] |= p << (8 * t); else hi[q] |= p << (8 * (t - 4));
                         so_far = (so_far << 1) | (int)bit;
                     }
-                    rec[2 * (b0 + q)] = lo; rec[2 * (b0 + q) + 1] = hi;
                 }
+                st4(rec + 2 * i, U4{lo[0], hi[0], lo[1], hi[1]});
             }
         }
     }
@@ -316,28 +328,30 @@ WDEV void fold_edgenz_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int 
         const int seg = seg0 + l;
         if (seg < nseg) {
             const SegPlan5& P = plans[seg];
-            uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.en_base);
-            const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
+            const uint32_t* ctab = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.cls_base);
+            const int c = (vertical ? kClsEv : kClsEh) + ci * 8 + eob;
+            const uint32_t n = P.status ? 0u : ctab[kNumCls + c];
+            uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.ens_base[vertical]) + (size_t)(n ? ctab[c] : 0u);
             FoldLane fl{sh->slice + fold_col(l)};
-            const uint32_t nb = P.status ? 0u : P.nblocks;
-            U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0}, nr0 = nb ? ld4(rec) : U4{0, 0, 0, 0}, nr1 = nb ? ld4(rec + 4) : U4{0, 0, 0, 0};
-            for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
-                const U4 k4 = nk, r0 = nr0, r1 = nr1;
-                if (b0 + 4 < nb) { nk = ld4(keys + b0 + 4); nr0 = ld4(rec + 2 * (b0 + 4)); nr1 = ld4(rec + 2 * (b0 + 4) + 4); }
-                const uint32_t kw[4] = {k4.x, k4.y, k4.z, k4.w};
-                const uint32_t ev[4] = {vertical ? r0.y : r0.x, vertical ? r0.w : r0.z, vertical ? r1.y : r1.x, vertical ? r1.w : r1.z};
-                for (int q = 0; q < 4 && b0 + q < nb; ++q) {
-                    if ((int)(kw[q] & 1u) != ci || (int)((kw[q] >> (vertical ? 8 : 5)) & 7u) != eob) continue;
-                    const int nzq = (int)ev[q] & 7, ne = (int)(ev[q] >> 3) & 7;
+            U4 nxt = n ? ld4(rec) : U4{0, 0, 0, 0};
+            for (uint32_t i = 0; i < n; i += 4) {
+                U4 g = nxt;
+                if (i + 4 < n) nxt = ld4(rec + i + 4);
+                uint32_t w[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nzq = (int)w[q] & 7, ne = (int)(w[q] >> 3) & 7;
                     uint32_t probs = 0;
                     int so_far = 0;
-                    for (int i = 2; i >= 0; --i) {
-                        const uint32_t bit = (uint32_t)(ne >> i) & 1u;
-                        probs |= fl.code(nzq * 12 + i * 4 + so_far, bit) << (8 * (2 - i));
+#pragma unroll
+                    for (int b = 2; b >= 0; --b) {
+                        const uint32_t bit = (uint32_t)(ne >> b) & 1u;
+                        probs |= fl.code(nzq * 12 + b * 4 + so_far, bit) << (8 * (2 - b));
                         so_far = (so_far << 1) | (int)bit;
                     }
-                    rec[2 * (b0 + q) + vertical] = probs;
+                    w[q] = probs;
                 }
+                st4(rec + i, U4{w[0], w[1], w[2], w[3]});
             }
         }
     }
@@ -349,29 +363,16 @@ WDEV void fold_dc_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg
         const int seg = seg0 + l;
         if (seg < nseg) {
             const SegPlan5& P = plans[seg];
-            uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.dc_base);
-            const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.key_base);
+            const uint32_t* ctab = reinterpret_cast<const uint32_t*>(arena + P.arena_off + P.cls_base);
+            const uint32_t n = P.status ? 0u : ctab[kNumCls + kClsDc + a];
+            uint32_t* rec = reinterpret_cast<uint32_t*>(arena + P.arena_off + P.dcs_base) + 6 * (size_t)(n ? ctab[kClsDc + a] : 0u);
             FoldLane fl{sh->slice + fold_col(l)};
-            const uint32_t nb = P.status ? 0u : P.nblocks;
-            U4 nk = nb ? ld4(keys) : U4{0, 0, 0, 0};
-            uint32_t ne0 = nb ? rec[0] : 0u, ne1 = nb > 1 ? rec[6] : 0u, ne2 = nb > 2 ? rec[12] : 0u, ne3 = nb > 3 ? rec[18] : 0u;
-            for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
-                const U4 k4 = nk;
-                const uint32_t kw[4] = {k4.x, k4.y, k4.z, k4.w}, ev[4] = {ne0, ne1, ne2, ne3};
-                if (b0 + 4 < nb) {
-                    nk = ld4(keys + b0 + 4);
-                    const uint32_t* r = rec + 6 * (b0 + 4);
-                    ne0 = r[0];
-                    if (b0 + 5 < nb) ne1 = r[6];
-                    if (b0 + 6 < nb) ne2 = r[12];
-                    if (b0 + 7 < nb) ne3 = r[18];
-                }
-                for (int q = 0; q < 4 && b0 + q < nb; ++q) {
-                    if ((int)((kw[q] >> 11) & 15u) != a) continue;
-                    const uint32_t e0 = ev[q];
-                    const int n = coef_units((int)(e0 >> 14) & 15, (int)(e0 >> 10) & 15);
-                    for (int u = 0; u < n; ++u) rec[6 * (b0 + q) + u] = fold_coef_unit(fl, e0 | ((uint32_t)u << 27), 17 * 11);
-                }
+            uint32_t nxt = n ? rec[0] : 0u;
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t e0 = nxt;
+                if (i + 1 < n) nxt = rec[6 * (i + 1)];
+                const int nu = coef_units((int)(e0 >> 14) & 15, (int)(e0 >> 10) & 15);
+                for (int u = 0; u < nu; ++u) rec[6 * i + u] = fold_coef_unit(fl, e0 | ((uint32_t)u << 27), 17 * 11);
             }
         }
     }
@@ -578,6 +579,81 @@ WDEV void lds_add(uint32_t* p, uint32_t v) {
 WDEV int nzbin5(int left) { return left < 16 ? (int)((0x7776666555443210ull >> (4 * left)) & 15) : (left < 21 ? 7 : (left < 32 ? 8 : 9)); }
 WDEV int tile_get(const uint32_t* T, int a, int col) { return (int16_t)(T[(a >> 1) * 65 + col] >> ((a & 1) * 16)); }
 
+// ---- bucket: the block-ordered sparse records -> one stream per chain --------------------------------------------------------
+// One wavefront per segment, lane = block (64 consecutive ordinals at a time).  First pass: records per chain (LDS atomics).
+// Second pass: the lanes of one chain are ranked in block order with ballots, as the walk ranks a row's entries; the record goes
+// to its chain's stream, the place into place[kind][ordinal] for gather.
+struct BucketShared { uint32_t cnt[kNumCls], cur[kNumCls]; };
+WDEV void bucket_wave(const SegPlan5* P, uint8_t* arena_base, BucketShared* sh) {
+    if (P->status) return;
+    uint8_t* arena = arena_base + P->arena_off;
+    const uint32_t nb = P->nblocks;
+    const uint32_t* keys = reinterpret_cast<const uint32_t*>(arena + P->key_base);
+    const uint32_t* nzr = reinterpret_cast<const uint32_t*>(arena + P->nz_base);
+    const uint32_t* enr = reinterpret_cast<const uint32_t*>(arena + P->en_base);
+    const uint32_t* dcr = reinterpret_cast<const uint32_t*>(arena + P->dc_base);
+    uint32_t* ctab = reinterpret_cast<uint32_t*>(arena + P->cls_base);
+    uint32_t* place = reinterpret_cast<uint32_t*>(arena + P->place_base);
+    uint32_t* nzs = reinterpret_cast<uint32_t*>(arena + P->nzs_base);
+    uint32_t* ens[2] = {reinterpret_cast<uint32_t*>(arena + P->ens_base[0]), reinterpret_cast<uint32_t*>(arena + P->ens_base[1])};
+    uint32_t* dcs = reinterpret_cast<uint32_t*>(arena + P->dcs_base);
+    LANES(l) sh->cnt[l] = 0;
+    LSYNC();
+    for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+        LANES(l) if (b0 + l < nb) {
+            int c[4];
+            key_classes(gld(keys + b0 + l), c);
+            for (int q = 0; q < 4; ++q) lds_add(&sh->cnt[c[q]], 1u);
+        }
+    }
+    LSYNC();
+    LANES(l) if (l < 4) {   // a chain's stream starts where the ones of its kind before it end (each padded to four records)
+        const int lo = l == 0 ? kClsNz : (l == 1 ? kClsEh : (l == 2 ? kClsEv : kClsDc)), hi = l == 0 ? kClsEh : (l == 1 ? kClsEv : (l == 2 ? kClsDc : kNumCls));
+        uint32_t at = 0;
+        for (int c = lo; c < hi; ++c) { sh->cur[c] = at; at += (sh->cnt[c] + 3u) & ~3u; }
+    }
+    LSYNC();
+    LANES(l) {
+        const uint32_t first = sh->cur[l], n = sh->cnt[l];
+        gst(ctab + l, first); gst(ctab + kNumCls + l, n);
+        for (uint32_t j = first + n; j < first + ((n + 3u) & ~3u); ++j) {   // the padding: records that fold to nothing out of bounds
+            if (l < kClsEh) { gst(nzs + 2 * j, 0u); gst(nzs + 2 * j + 1, 0u); }
+            else if (l < kClsEv) gst(ens[0] + j, 0u);
+            else if (l < kClsDc) gst(ens[1] + j, 0u);
+            else gst(dcs + 6 * j, 0u);
+        }
+    }
+    LSYNC();
+    for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+        LV(int, act); LV(int, cls); LV(uint32_t, at);
+        LV(uint32_t, key);
+        LANES(l) { L(act) = b0 + l < nb; L(key) = L(act) ? gld(keys + b0 + l) : 0u; }
+        for (int q = 0; q < 4; ++q) {
+            LANES(l) { int c[4]; key_classes(L(key), c); L(cls) = c[q]; }
+            uint64_t rem = lepwave::wave_ballot(act);
+            while (rem) {
+                const int c0 = (int)lepwave::wave_read((const uint32_t*)cls, __builtin_ctzll(rem));
+                const uint32_t first = sh->cur[c0];
+                LV(int, g);
+                LANES(l) L(g) = L(act) && L(cls) == c0;
+                const uint64_t m = lepwave::wave_ballot(g);
+                LANES(l) if (L(g)) L(at) = first + (uint32_t)lane_prefix(m, l);
+                LSYNC();
+                LANES(l) if (l == 0) sh->cur[c0] = first + (uint32_t)lepwave::popc64(m);
+                LSYNC();
+                rem &= ~m;
+            }
+            LANES(l) if (L(act)) {
+                const uint32_t b = b0 + l, j = L(at);
+                gst(place + (size_t)q * nb + b, j);
+                if (q == 0) gst(nzs + 2 * j, gld(nzr + 2 * b));
+                else if (q < 3) gst(ens[q - 1] + j, gld(enr + 2 * b + (q - 1)));
+                else gst(dcs + 6 * j, gld(dcr + 6 * b));
+            }
+        }
+    }
+}
+
 // NW = 2: two wavefronts walk a segment together -- both see the same tile in LDS; wavefront 0 codes the 7x7 interiors, wavefront
 // 1 everything that needs the neighbours' pixels and the block's sparse records (edges, DC, the three counts).  Each half has its
 // own streams, its own run of sign bytes and its own run of bins inside every block, so the halves only meet at the tile's
@@ -600,6 +676,7 @@ struct Walk5 {
     uint32_t tile_no;          // tiles walked so far
     uint32_t* AT;              // emit / gather: the segment's [tile][65][64] array of places
     uint32_t sign_base[2], key_base, nz_base, en_base, dc_base;   // the plan's offsets (read once: a load per tile from the plan would sit on the critical path)
+    uint32_t place_base, nzs_base, ens_base[2], dcs_base, plan_nblocks;
 
     WDEV uint32_t* units() const { return reinterpret_cast<uint32_t*>(arena); }
 
@@ -733,15 +810,20 @@ struct Walk5 {
         LV(NSum, nsa);            // the summary of the block above
 
         // gather: the block's sparse records (7x7 count, edge counts, DC units) are requested now and used after phase 1
-        LV(uint32_t, rdce); LV(uint32_t, rdcs);
+        LV(uint32_t, rdce); LV(uint32_t, rdcs); LV(uint32_t, rdcp);
         LV(uint32_t, rnz0); LV(uint32_t, rnz1); LV(uint32_t, ren0); LV(uint32_t, ren1); LV(uint32_t, rdc0); LV(uint32_t, rdc1); LV(uint32_t, rdc2);
         if (MODE == kGather) {
             LANES(l) if (l < nb) {
-                if (kEdge) {
-                    const uint32_t* r1 = reinterpret_cast<const uint32_t*>(arena + nz_base) + 2 * (ord0 + l);
-                    const uint32_t* r2 = reinterpret_cast<const uint32_t*>(arena + en_base) + 2 * (ord0 + l);
-                    const uint32_t* r3 = reinterpret_cast<const uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
-                    L(rnz0) = gld(r1); L(rnz1) = gld(r1 + 1); L(ren0) = gld(r2); L(ren1) = gld(r2 + 1); L(rdc0) = gld(r3); L(rdc1) = gld(r3 + 1); L(rdc2) = gld(r3 + 2);
+                if (kEdge) {   // the block's records, where bucket put them
+                    const uint32_t* pl = reinterpret_cast<const uint32_t*>(arena + place_base) + ord0 + l;
+                    const uint32_t nbl = plan_nblocks;
+                    const uint32_t p0 = gld(pl), p1 = gld(pl + nbl), p2 = gld(pl + 2 * (size_t)nbl), p3 = gld(pl + 3 * (size_t)nbl);
+                    const uint32_t* r1 = reinterpret_cast<const uint32_t*>(arena + nzs_base) + 2 * (size_t)p0;
+                    const uint32_t* r3 = reinterpret_cast<const uint32_t*>(arena + dcs_base) + 6 * (size_t)p3;
+                    L(rnz0) = gld(r1); L(rnz1) = gld(r1 + 1);
+                    L(ren0) = gld(reinterpret_cast<const uint32_t*>(arena + ens_base[0]) + p1); L(ren1) = gld(reinterpret_cast<const uint32_t*>(arena + ens_base[1]) + p2);
+                    L(rdc0) = gld(r3); L(rdc1) = gld(r3 + 1); L(rdc2) = gld(r3 + 2);
+                    L(rdcp) = p3;
                     L(rdcs) = gld(AT + ((size_t)tile_no * kAtRows + 64) * 64 + l);
                 }
                 L(rdce) = gld(AT + ((size_t)tile_no * kAtRows + 63) * 64 + l);   // (both halves: the DC's bins are part of the block's)
@@ -1128,7 +1210,8 @@ struct Walk5 {
         // DC
         if (MODE != kCount && kEdge) {
             LANES(l) if (L(act)) {
-                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + dc_base) + 6 * (ord0 + l);
+                uint32_t* rec = MODE == kEmit ? reinterpret_cast<uint32_t*>(arena + dc_base) + 6 * (ord0 + l)
+                                              : reinterpret_cast<uint32_t*>(arena + dcs_base) + 6 * (size_t)L(rdcp);
                 const uint32_t e = (uint32_t)L(dc_e0);
                 const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
                 if (MODE == kEmit) {
@@ -1200,7 +1283,8 @@ struct Walk5 {
         bins = (MODE == kGather) ? bins_base + pl->bins_off : nullptr;
         ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0; tile_no = 0;
         AT = MODE != kCount ? reinterpret_cast<uint32_t*>(arena + pl->at_base) : nullptr;
-        if (MODE != kCount) { sign_base[0] = pl->sign_base[0]; sign_base[1] = pl->sign_base[1]; key_base = pl->key_base; nz_base = pl->nz_base; en_base = pl->en_base; dc_base = pl->dc_base; }
+        if (MODE != kCount) { sign_base[0] = pl->sign_base[0]; sign_base[1] = pl->sign_base[1]; key_base = pl->key_base; nz_base = pl->nz_base; en_base = pl->en_base; dc_base = pl->dc_base;
+            place_base = pl->place_base; nzs_base = pl->nzs_base; ens_base[0] = pl->ens_base[0]; ens_base[1] = pl->ens_base[1]; dcs_base = pl->dcs_base; plan_nblocks = pl->nblocks; }
         LANES(l) {   // emit / gather: a cursor is the absolute place of the stream's next unit
             for (int i = l; i < 2 * kRows * kClasses; i += 64) LEP5_WSH(this).cursor[i] = MODE == kCount ? 0u : pl->base[i];   // (every wavefront: the same values)
         }
@@ -1252,6 +1336,13 @@ WDEV void plan_segment(const uint32_t* counts, SegPlan5* P) {
     P->nz_base = bytes; bytes += P->nblocks * (uint32_t)kNzRec;
     P->en_base = bytes; bytes += P->nblocks * (uint32_t)kEnRec;
     P->dc_base = bytes; bytes += P->nblocks * (uint32_t)kDcRec;
+    P->cls_base = bytes; bytes += 2u * kNumCls * 4u;
+    P->place_base = bytes; bytes += 4u * P->nblocks * 4u;
+    bytes = (bytes + 15u) & ~15u;
+    P->nzs_base = bytes; bytes += (P->nblocks + 4u * 20u) * (uint32_t)kNzRec;
+    P->ens_base[0] = bytes; bytes += (P->nblocks + 4u * 16u) * 4u;
+    P->ens_base[1] = bytes; bytes += (P->nblocks + 4u * 16u) * 4u;
+    P->dcs_base = bytes; bytes += (P->nblocks + 4u * 12u) * (uint32_t)kDcRec;
     bytes = (bytes + 255u) & ~255u;
     P->ntiles = counts[kStreams + 4];
     P->at_base = bytes; bytes += P->ntiles * (uint32_t)(kAtRows * 64 * 4);

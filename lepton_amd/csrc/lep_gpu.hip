@@ -193,7 +193,12 @@ __global__ void lep_enc5_fill_kernel(uint4* p, size_t n16, uint32_t v) {
     const uint4 x = make_uint4(v, v, v, v);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = x;
 }
-// fold, coefficient chains: block = (64 consecutive segments, stream); 36 KB of LDS
+// bucket: the sparse records of a segment -> one stream per chain (one wavefront per segment)
+__global__ __launch_bounds__(64) void lep_enc5_bucket_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena) {
+    __shared__ lep5::BucketShared sh;
+    lep5::bucket_wave(plans + blockIdx.x, arena, &sh);
+}
+// fold, coefficient chains: block = (64 consecutive segments, stream); 18 KB of LDS
 struct Fold5CoefShared { uint16_t slice[lep5::kCoefSlice * 64]; };   // 18 KB: eight wavefronts per CU
 __global__ __launch_bounds__(64) void lep_enc5_fold_coef_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, int nseg, int groups) {
     __shared__ Fold5CoefShared shc;
@@ -208,11 +213,11 @@ __global__ __launch_bounds__(64) void lep_enc5_fold_coef_kernel(const lep5::SegP
 //   small  sign chains (long dependent chains: first), threshold chains (Branches in HBM), edge non-zero counts     12 KB
 //   big    DC chains, 7x7 non-zero counts                                                                          25 KB
 struct Fold5SmallShared { uint16_t slice[lep5::kEdgeNzSlice * 64]; };
-__global__ __launch_bounds__(64) void lep_enc5_fold_small_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, uint32_t* thresh_models, int nseg, int groups) {
+__global__ __launch_bounds__(64) void lep_enc5_fold_small_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, uint32_t* thresh_models, int nseg, int groups, int job0) {
     __shared__ Fold5SmallShared shs;
     lep5::FoldShared* sh = reinterpret_cast<lep5::FoldShared*>(&shs);
     const int grp = (int)blockIdx.x % groups;
-    int job = (int)blockIdx.x / groups;
+    int job = (int)blockIdx.x / groups + job0;
     const int seg0 = grp * 64;
     if (job < 2) { lep5::fold_sign_wave(plans, arena, seg0, nseg, job, sh); return; }
     job -= 2;
@@ -221,10 +226,10 @@ __global__ __launch_bounds__(64) void lep_enc5_fold_small_kernel(const lep5::Seg
     lep5::fold_edgenz_wave(plans, arena, seg0, nseg, job / 16, (job / 8) & 1, job & 7, sh);   // 32 jobs
 }
 constexpr int kFold5SmallJobs = 2 + 12 + 32;
-__global__ __launch_bounds__(64) void lep_enc5_fold_big_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, int nseg, int groups) {
+__global__ __launch_bounds__(64) void lep_enc5_fold_big_kernel(const lep5::SegPlan5* __restrict__ plans, uint8_t* arena, int nseg, int groups, int job0) {
     __shared__ lep5::FoldShared sh;
     const int grp = (int)blockIdx.x % groups;
-    int job = (int)blockIdx.x / groups;
+    int job = (int)blockIdx.x / groups + job0;
     const int seg0 = grp * 64;
     if (job < 12) { lep5::fold_dc_wave(plans, arena, seg0, nseg, job, &sh); return; }
     job -= 12;
@@ -322,6 +327,7 @@ struct lep_gpu {
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     int enc5_waves = 2;      // LEP_ENC5_WAVES: wavefronts per segment in the split-phase walks (1 | 2)
+    int enc5_fold_apart = 0; // LEP_ENC5_FOLD_APART: the fold launches one after the other, a launch per kind of chain (for the profiler)
     hipEvent_t ev_stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the last split-phase launch
     int nstage = 0;
     int enc_waves = 0;       // the same choice for the encoder (LEP_ENC_WAVES = 4 | 8; 2 = the two-wavefronts-per-segment kernel)
@@ -430,12 +436,22 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
         HIPCHK(g, hipEventRecord(g->ev_stage[1], st));
         walk(lep5::kEmit, (uint8_t*)A.d_entries, nullptr);
         HIPCHK(g, hipEventRecord(g->ev_stage[2], st));
+        hipLaunchKernelGGL(lep_enc5_bucket_kernel, dim3(nseg), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries);
         HIPCHK(g, hipEventRecord(g->ev_fork, st));
         HIPCHK(g, hipStreamWaitEvent(g->stream2, g->ev_fork, 0));
         HIPCHK(g, hipStreamWaitEvent(g->stream3, g->ev_fork, 0));
+        if (g->enc5_fold_apart) {   // measurement aid (LEP_ENC5_FOLD_APART=1): every kind of chain as a launch of its own, one after the other
+            const int small0[4] = {0, 2, 14, 46}, big0[3] = {0, 12, 32};   // sign | threshold | edge counts;  DC | 7x7 counts
+            for (int i = 0; i < 3; ++i)
+                hipLaunchKernelGGL(lep_enc5_fold_small_kernel, dim3((unsigned)groups * (small0[i + 1] - small0[i])), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries,
+                                   (uint32_t*)A.d_models, nseg, groups, small0[i]);
+            for (int i = 0; i < 2; ++i)
+                hipLaunchKernelGGL(lep_enc5_fold_big_kernel, dim3((unsigned)groups * (big0[i + 1] - big0[i])), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups, big0[i]);
+        } else {
         hipLaunchKernelGGL(lep_enc5_fold_small_kernel, dim3((unsigned)groups * kFold5SmallJobs), dim3(64), 0, g->stream2, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries,
-                           (uint32_t*)A.d_models, nseg, groups);
-        hipLaunchKernelGGL(lep_enc5_fold_big_kernel, dim3((unsigned)groups * kFold5BigJobs), dim3(64), 0, g->stream3, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups);
+                           (uint32_t*)A.d_models, nseg, groups, 0);
+        hipLaunchKernelGGL(lep_enc5_fold_big_kernel, dim3((unsigned)groups * kFold5BigJobs), dim3(64), 0, g->stream3, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups, 0);
+        }
         hipLaunchKernelGGL(lep_enc5_fold_coef_kernel, dim3((unsigned)groups * 1260u), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups);
         HIPCHK(g, hipEventRecord(g->ev_join, g->stream2));
         HIPCHK(g, hipEventRecord(g->ev_join3, g->stream3));
@@ -586,6 +602,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_ENC_PAIR_MAX")) g->enc_pair_max = atoi(e);
     if (const char* e = getenv("LEP_ENC5_MIN")) g->enc5_min = atoi(e);
     if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||

@@ -282,6 +282,10 @@ static int encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_las
         if (w.sign_pos[0] != plan.sign_cnt[0] || w.sign_pos[1] != plan.sign_cnt[1] || w.ord0 != plan.nblocks) return 1001;
         for (int i = 0; i < kStreams; ++i) if (wsh.cursor[i] != plan.base[i] + plan.cnt[i]) return 1002;
     }
+    {
+        static BucketShared bsh;
+        bucket_wave(&plan, arena.data(), &bsh);
+    }
     std::vector<uint32_t> thresh(kThreshWords, kBranchInit);
     for (int ci = 0; ci < 2; ++ci) {
         for (int row = 0; row < kRows; ++row)
