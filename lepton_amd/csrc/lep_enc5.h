@@ -511,19 +511,25 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
 //            from the same places and appends the block's bins.  count only adds the units up (LDS atomics: no order needed).
 enum { kCount = 0, kEmit = 1, kGather = 2 };
 
+// (members in the order the passes need them: a launch takes the front of the block its pass uses -- gather 10 KB, count 15 KB,
+// emit all 26 KB -- and the resident workgroups per CU follow from that)
 struct Walk5Shared {
     uint32_t cur[32 * 65];                 // transposed tile: dword i (coefficients 2i, 2i + 1 in aligned order) of lane c at [i * 65 + c];
                                            // column 64 = the block left of lane 0 (the previous tile's last one)
     uint16_t TB[8 * 65];                   // where the lane's next threshold unit of class lt goes (relative to the tile's first)
-    uint32_t cursor[2 * kRows * kClasses]; // units already given out, per colour index / row / class
-    NSum ns[65];                           // neighbour summaries of the tile's blocks; [64] = the block left of lane 0
-    int32_t icos_x[64], icos_y[64];        // the component's quantisation-derived tables (a load from the image descriptor on the
-    uint16_t q[64];                        // critical path costs a trip to HBM: they are staged when the component changes)
-    uint8_t thr[64];
+    uint16_t q[64];                        // the component's quantisation-derived tables (a load from the image descriptor on the
+    uint8_t thr[64];                       // critical path costs a trip to HBM: they are staged when the component changes)
     uint16_t errx[2 * 64];                 // emit: the lanes' first refusal per half of the block (interior; edges and DC)
-    uint32_t abv[32 * 65];                 // the tile of the row above (emit only: count and gather launch without it)
+    uint32_t tcur[2 * 8];                  // emit / gather: threshold units already given out, per colour index / class lt
+    // ---- count and emit
+    uint32_t cursor[2 * kRows * kClasses]; // units already given out, per colour index / row / class (row 63 = threshold: count only)
+    // ---- emit
+    NSum ns[65];                           // neighbour summaries of the tile's blocks; [64] = the block left of lane 0
+    int32_t icos_x[64], icos_y[64];
+    uint32_t abv[32 * 65];                 // the tile of the row above
 };
-constexpr size_t kWalkLdsNoAbove = sizeof(Walk5Shared) - sizeof(uint32_t) * 32 * 65;
+constexpr size_t kWalkLdsGather = offsetof(Walk5Shared, cursor), kWalkLdsCount = offsetof(Walk5Shared, ns);
+constexpr size_t walk_lds_bytes(int mode) { return mode == 2 ? kWalkLdsGather : (mode == 0 ? kWalkLdsCount : sizeof(Walk5Shared)); }
 
 // The walk's LDS block.  On the GPU it is the kernel's dynamic LDS, named directly at every use: a pointer to it kept in the
 // walker object loses its address space as soon as that object's address is taken anywhere, and every access then becomes a
@@ -750,14 +756,17 @@ struct Walk5 {
         LEP5_XSYNC();   // (every wavefront is done with the previous tile)
         if (wave == 0) {
             if (new_comp) {   // the component's tables
-                LANES(l) { S.q[l] = img->q[comp][l]; S.icos_x[l] = img->icos_x[comp][l]; S.icos_y[l] = img->icos_y[comp][l]; S.thr[l] = img->min_thresh[comp][l]; }
+                LANES(l) {
+                    S.q[l] = img->q[comp][l]; S.thr[l] = img->min_thresh[comp][l];
+                    if (MODE == kEmit) { S.icos_x[l] = img->icos_x[comp][l]; S.icos_y[l] = img->icos_y[comp][l]; }
+                }
             }
             LANES(l) {   // keep the last column of the previous tile as "left of lane 0"
                 if (l < 32) {
                     S.cur[l * 65 + 64] = first_of_row ? 0u : S.cur[l * 65 + 63];
                     if (MODE == kEmit) S.abv[l * 65 + 64] = first_of_row ? 0u : S.abv[l * 65 + 63];
                 }
-                if (l == 0) { if (first_of_row) S.ns[64] = NSum{}; else S.ns[64] = S.ns[63]; }
+                if (MODE == kEmit && l == 0) { if (first_of_row) S.ns[64] = NSum{}; else S.ns[64] = S.ns[63]; }
             }
         }
         LEP5_XSYNC();
@@ -1172,7 +1181,7 @@ struct Walk5 {
                     if (t_e) {
                         const int lt = (int)(t_e >> 23) & 15, tsid = stream_id(ci, 63, lt);
                         tn = (int)(t_e >> 10) & 15;
-                        tat = S.cursor[tsid] + S.TB[lt * 65 + l];
+                        tat = S.tcur[ci * 8 + lt] + S.TB[lt * 65 + l];
                         S.TB[lt * 65 + l] = (uint16_t)(S.TB[lt * 65 + l] + ((tn + 3) >> 2));
                     }
                     if (MODE == kEmit) {
@@ -1234,7 +1243,7 @@ struct Walk5 {
                 }
             }
             LSYNC();
-            LANES(l) if (l == 0) for (int lt = 2; lt < 8; ++lt) S.cursor[stream_id(ci, 63, lt)] += (uint32_t)ttot[lt];
+            LANES(l) if (l == 0) for (int lt = 2; lt < 8; ++lt) S.tcur[ci * 8 + lt] += (uint32_t)ttot[lt];
             LSYNC();
         }
         if (MODE == kCount) bins_tile = lepwave::wave_sum(lbins);
@@ -1286,7 +1295,8 @@ struct Walk5 {
         if (MODE != kCount) { sign_base[0] = pl->sign_base[0]; sign_base[1] = pl->sign_base[1]; key_base = pl->key_base; nz_base = pl->nz_base; en_base = pl->en_base; dc_base = pl->dc_base;
             place_base = pl->place_base; nzs_base = pl->nzs_base; ens_base[0] = pl->ens_base[0]; ens_base[1] = pl->ens_base[1]; dcs_base = pl->dcs_base; plan_nblocks = pl->nblocks; }
         LANES(l) {   // emit / gather: a cursor is the absolute place of the stream's next unit
-            for (int i = l; i < 2 * kRows * kClasses; i += 64) LEP5_WSH(this).cursor[i] = MODE == kCount ? 0u : pl->base[i];   // (every wavefront: the same values)
+            if (MODE != kGather) for (int i = l; i < 2 * kRows * kClasses; i += 64) LEP5_WSH(this).cursor[i] = MODE == kCount ? 0u : pl->base[i];   // (every wavefront: the same values)
+            if (MODE != kCount && l < 16) LEP5_WSH(this).tcur[l] = pl->base[stream_id(l >> 3, 63, l & 7)];
         }
         LEP5_XSYNC();
         // the tiles of the segment in stream order (lepton_codec.hh:41-100; vp8_encoder.cc:83-154: a row ends where the file was cut)
@@ -1308,6 +1318,8 @@ struct Walk5 {
         }
         LEP5_XSYNC();   // (the cursors are complete)
         if (MODE == kEmit && wave == 0) {   // every stream is padded to whole groups of four units: the fold takes them group by group
+            LANES(l) if (l < 16) LEP5_WSH(this).cursor[stream_id(l >> 3, 63, l & 7)] = LEP5_WSH(this).tcur[l];
+            LSYNC();
             LANES(l) {
                 for (int i = l; i < kStreams; i += 64)
                     for (uint32_t j = LEP5_WSH(this).cursor[i]; j < pl->base[i + 1]; ++j) gst(units() + j, 0u);
