@@ -399,6 +399,9 @@ def reference_benchmark_jpeg():
 
 
 def main():
+    import faulthandler
+
+    faulthandler.enable()   # a crash inside the library names the Python line that called it
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -458,6 +461,7 @@ def main():
     log("[rank %d] corpus: %d unique %dx%d JPEGs in %.1fs" % (rank, nuniq, args.width, args.height, time.perf_counter() - t0))
     res = dev.resident(uniq, args.images, args.steps, args.warmup, barrier, with_latency=(world == 1 and not args.no_extras))
     names, parity, latency, bins_per_image = res["names"], res["parity"], res["latency"], res["bins_per_image"]
+    log("[rank %d] resident steps done (%.1fs)" % (rank, time.perf_counter() - t0))
 
     # ---- strong scaling (BASELINE.json configs[3]): ONE mixed 1080p / 4K corpus, the same list on every rank, dealt by JPEG
     # bytes; every rank pushes its share through the host-memory pipeline; no data-path collective
@@ -477,6 +481,7 @@ def main():
             del files, fig
         except Exception as e:   # the headline figure must not depend on it
             mixed_err = repr(e)[:300]
+        log("[rank %d] mixed corpus done (%.1fs) %s" % (rank, time.perf_counter() - t0, mixed_err or ""))
 
     # PCIe- and host-inclusive companion figure (never `value`): JPEG files in host memory -> .lep files in host memory and
     # back through the batch pipeline (host split, GPU Huffman decode, GPU arithmetic coding, containers on the host pool; and
@@ -491,6 +496,7 @@ def main():
             e2e_local = {"e2e_bytes": e2e["jpeg_MB"] * 1e6, "e2e_c_s_max": e2e["_cs"]["wall_s"], "e2e_d_s_max": e2e["_ds"]["wall_s"]}
         except Exception as e:   # the headline figure must not depend on it
             e2e = {"error": repr(e)[:300]}
+        log("[rank %d] end to end done (%.1fs)" % (rank, time.perf_counter() - t0))
     local = {"jpeg_bytes": res["jpeg_bytes"], "images": res["images"], "segments": res["segments"], "blocks": res["blocks"],
              "stream_bytes": res["stream_bytes"], "elapsed_max": res["elapsed"], "enc_ms_max": res["enc_ms"], "dec_ms_max": res["dec_ms"],
              "ranks": 1}

@@ -330,6 +330,7 @@ struct lep_gpu {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     int enc5_waves = 2;      // LEP_ENC5_WAVES: wavefronts per segment in the split-phase walks (1 | 2)
     int enc5_fold_apart = 0; // LEP_ENC5_FOLD_APART: the fold launches one after the other, a launch per kind of chain (for the profiler)
+    size_t enc5_scratch_max = ~(size_t)0;   // LEP_ENC5_SCRATCH_MAX (bytes): a launch that needs more takes the single-kernel encoder (tests: the out-of-memory path)
     hipEvent_t ev_stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the last split-phase launch
     int nstage = 0;
     int enc_waves = 0;       // the same choice for the encoder (LEP_ENC_WAVES = 4 | 8; 2 = the two-wavefronts-per-segment kernel)
@@ -344,14 +345,19 @@ struct lep_gpu {
     // launches may be in flight at once on different streams (lep_gpu_use_arena: the next chunk's coder kernel starts in the
     // wave slots that the long segments of the current one leave free); everything else uses set 0.
     struct Arena {
-        void* d_plans = nullptr; size_t plans_bytes = 0;       // split-phase encoder: SegPlan5[] | counts | totals
-        void* d_entries = nullptr; size_t entries_bytes = 0;   //   the chains' entry streams
-        void* d_binlist = nullptr; size_t binlist_bytes = 0;   //   the segments' bin lists
         void* d_models = nullptr; size_t models_bytes = 0;
         void* d_ns = nullptr; size_t ns_bytes = 0;
         void* d_meta = nullptr; size_t meta_bytes = 0;      // ImageDev[] | SegDev[] | ns_offsets[] | bins[]
     } arena[2];
     int cur = 0;
+    // split-phase encoder scratch: ONE set (a 4K image takes ~140 MB of it), shared by the two arena sets -- a split-phase launch
+    // waits for the one before it (ev_enc5_done), which fills the chip on its own anyway
+    struct Enc5Scratch {
+        void* d_plans = nullptr; size_t plans_bytes = 0;       // SegPlan5[] | counts | totals
+        void* d_entries = nullptr; size_t entries_bytes = 0;   // the chains' entry streams, records, places
+        void* d_binlist = nullptr; size_t binlist_bytes = 0;   // the segments' bin lists
+    } enc5;
+    hipEvent_t ev_enc5_done = nullptr;
     uint32_t* d_bins = nullptr;
     std::vector<uint32_t> h_bins;
     // host-variant staging
@@ -383,7 +389,11 @@ static int ensure(lep_gpu* g, void** p, size_t* have, size_t need) {
     if (*p) HIPCHK(g, hipFree(*p));
     *p = nullptr; *have = 0;
     size_t want = need + need / 8;
-    HIPCHK(g, hipMalloc(p, want));
+    if (hipMalloc(p, want) != hipSuccess) {   // (the head room is a convenience: without it before giving up)
+        (void)hipGetLastError();
+        *p = nullptr; want = need;
+        HIPCHK(g, hipMalloc(p, want));
+    }
     *have = want;
     return 0;
 }
@@ -393,10 +403,13 @@ static int ensure(lep_gpu* g, void** p, size_t* have, size_t need) {
 
 // The split-phase encoder (lep_enc5.h): count -> plan -> emit -> fold -> gather -> write.  One host synchronisation in the
 // middle: the arena sizes come out of the count pass.  Stage boundaries are recorded as events (lep_gpu_last_stage_ms).
+constexpr int kEnc5NoMemory = -1000;   // launch_enc5: the scratch could not be allocated (nothing has been written for the caller yet)
 static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, const uint64_t* d_nsoff, int nseg, uint8_t* d_streams,
                        uint32_t* d_stream_len, int32_t* d_status, hipStream_t st) {
     lep_gpu::Arena& A = g->arena[g->cur];
+    lep_gpu::Enc5Scratch& E = g->enc5;
     if (!g->stream2) {
+        HIPCHK(g, hipEventCreateWithFlags(&g->ev_enc5_done, hipEventDisableTiming));
         HIPCHK(g, hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
         HIPCHK(g, hipStreamCreateWithFlags(&g->stream3, hipStreamNonBlocking));
         HIPCHK(g, hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
@@ -406,10 +419,11 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     }
     const size_t o_counts = ((size_t)nseg * sizeof(lep5::SegPlan5) + 255) & ~(size_t)255,
                  o_tot = o_counts + (((size_t)nseg * lep5::kCountWords * 4 + 255) & ~(size_t)255);
-    if (int rc = ensure(g, &A.d_plans, &A.plans_bytes, o_tot + 256)) return rc;
-    lep5::SegPlan5* plans = (lep5::SegPlan5*)A.d_plans;
-    uint32_t* counts = (uint32_t*)((char*)A.d_plans + o_counts);
-    uint64_t* d_tot = (uint64_t*)((char*)A.d_plans + o_tot);
+    HIPCHK(g, hipStreamWaitEvent(st, g->ev_enc5_done, 0));   // (the scratch is the previous split-phase launch's until its writer is done)
+    if (int rc = ensure(g, &E.d_plans, &E.plans_bytes, o_tot + 256)) return rc;
+    lep5::SegPlan5* plans = (lep5::SegPlan5*)E.d_plans;
+    uint32_t* counts = (uint32_t*)((char*)E.d_plans + o_counts);
+    uint64_t* d_tot = (uint64_t*)((char*)E.d_plans + o_tot);
     const int groups = (nseg + 63) / 64;
     g->nstage = 0;
     HIPCHK(g, hipEventRecord(g->ev_stage[0], st));
@@ -430,43 +444,48 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     uint64_t tot[2] = {0, 0};
     HIPCHK(g, hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
     HIPCHK(g, hipStreamSynchronize(st));
-    if (int rc = ensure(g, &A.d_entries, &A.entries_bytes, (size_t)tot[0] + 256)) return rc;
-    if (int rc = ensure(g, &A.d_binlist, &A.binlist_bytes, (size_t)tot[1] * 2 + 256)) return rc;
+    // no room for the scratch (~140 MB per 4K image): the single-kernel encoder takes the launch -- it needs none
+    if ((size_t)tot[0] + (size_t)tot[1] * 2 > g->enc5_scratch_max || ensure(g, &E.d_entries, &E.entries_bytes, (size_t)tot[0] + 256) || ensure(g, &E.d_binlist, &E.binlist_bytes, (size_t)tot[1] * 2 + 256)) {
+        (void)hipGetLastError();
+        g->err.clear();
+        return kEnc5NoMemory;
+    }
     // (Segment groups on streams of their own -- one group's writer and folds beside the next group's walks -- were measured
     // and dropped: MI355X, 1024 x 4K, profiles/r04l_*: 1 group 784 ms, 2: 875, 4: 1232; launches this large do not share the chip.)
     {
         HIPCHK(g, hipEventRecord(g->ev_stage[1], st));
-        walk(lep5::kEmit, (uint8_t*)A.d_entries, nullptr);
+        walk(lep5::kEmit, (uint8_t*)E.d_entries, nullptr);
         HIPCHK(g, hipEventRecord(g->ev_stage[2], st));
-        hipLaunchKernelGGL(lep_enc5_bucket_kernel, dim3(nseg), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries);
+        hipLaunchKernelGGL(lep_enc5_bucket_kernel, dim3(nseg), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)E.d_entries);
         HIPCHK(g, hipEventRecord(g->ev_fork, st));
         HIPCHK(g, hipStreamWaitEvent(g->stream2, g->ev_fork, 0));
         HIPCHK(g, hipStreamWaitEvent(g->stream3, g->ev_fork, 0));
         if (g->enc5_fold_apart) {   // measurement aid (LEP_ENC5_FOLD_APART=1): every kind of chain as a launch of its own, one after the other
             const int small0[4] = {0, 2, 14, 46}, big0[3] = {0, 12, 32};   // sign | threshold | edge counts;  DC | 7x7 counts
             for (int i = 0; i < 3; ++i)
-                hipLaunchKernelGGL(lep_enc5_fold_small_kernel, dim3((unsigned)groups * (small0[i + 1] - small0[i])), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries,
+                hipLaunchKernelGGL(lep_enc5_fold_small_kernel, dim3((unsigned)groups * (small0[i + 1] - small0[i])), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)E.d_entries,
                                    (uint32_t*)A.d_models, nseg, groups, small0[i]);
             for (int i = 0; i < 2; ++i)
-                hipLaunchKernelGGL(lep_enc5_fold_big_kernel, dim3((unsigned)groups * (big0[i + 1] - big0[i])), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups, big0[i]);
+                hipLaunchKernelGGL(lep_enc5_fold_big_kernel, dim3((unsigned)groups * (big0[i + 1] - big0[i])), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)E.d_entries, nseg, groups, big0[i]);
         } else {
-        hipLaunchKernelGGL(lep_enc5_fold_small_kernel, dim3((unsigned)groups * kFold5SmallJobs), dim3(64), 0, g->stream2, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries,
+        hipLaunchKernelGGL(lep_enc5_fold_small_kernel, dim3((unsigned)groups * kFold5SmallJobs), dim3(64), 0, g->stream2, (const lep5::SegPlan5*)plans, (uint8_t*)E.d_entries,
                            (uint32_t*)A.d_models, nseg, groups, 0);
-        hipLaunchKernelGGL(lep_enc5_fold_big_kernel, dim3((unsigned)groups * kFold5BigJobs), dim3(64), 0, g->stream3, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups, 0);
+        hipLaunchKernelGGL(lep_enc5_fold_big_kernel, dim3((unsigned)groups * kFold5BigJobs), dim3(64), 0, g->stream3, (const lep5::SegPlan5*)plans, (uint8_t*)E.d_entries, nseg, groups, 0);
         }
-        hipLaunchKernelGGL(lep_enc5_fold_coef_kernel, dim3((unsigned)groups * 1260u), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)A.d_entries, nseg, groups);
+        hipLaunchKernelGGL(lep_enc5_fold_coef_kernel, dim3((unsigned)groups * 1260u), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (uint8_t*)E.d_entries, nseg, groups);
         HIPCHK(g, hipEventRecord(g->ev_join, g->stream2));
         HIPCHK(g, hipEventRecord(g->ev_join3, g->stream3));
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join3, 0));
         HIPCHK(g, hipEventRecord(g->ev_stage[3], st));
-        walk(lep5::kGather, (uint8_t*)A.d_entries, (uint16_t*)A.d_binlist);
+        walk(lep5::kGather, (uint8_t*)E.d_entries, (uint16_t*)E.d_binlist);
         HIPCHK(g, hipEventRecord(g->ev_stage[4], st));
-        hipLaunchKernelGGL(lep_enc5_write_kernel, dim3(groups), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (const uint16_t*)A.d_binlist, d_seg, nseg, d_streams, d_stream_len,
+        hipLaunchKernelGGL(lep_enc5_write_kernel, dim3(groups), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (const uint16_t*)E.d_binlist, d_seg, nseg, d_streams, d_stream_len,
                            d_status, g->d_bins);
         HIPCHK(g, hipEventRecord(g->ev_stage[5], st));
         g->nstage = 5;
     }
+    HIPCHK(g, hipEventRecord(g->ev_enc5_done, st));
     HIPCHK(g, hipGetLastError());
     g->last_kernel = "lep_enc5 (count | emit | fold | gather | write)";
     return 0;
@@ -558,9 +577,13 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         // like the decoder: a launch that cannot fill 8 wavefronts per SIMD takes the 4-wave build (128 VGPRs, no spills)
         int waves = g->enc_waves;
         if (!waves) waves = nseg > 4608 ? 8 : (nseg <= g->enc_pair_max ? 2 : 4);
+        bool done = false;
         if (g->enc5_min > 0 && !g->enc_waves && nseg >= g->enc5_min) {   // (LEP_ENC_WAVES asks for one of the single-kernel forms)
-            if (int rc = launch_enc5(g, (const ImageDev*)(meta + o_img), (const SegDev*)(meta + o_seg), (const uint64_t*)(meta + o_ns), nseg, d_streams, d_stream_len, d_status, st)) return rc;
+            const int rc = launch_enc5(g, (const ImageDev*)(meta + o_img), (const SegDev*)(meta + o_seg), (const uint64_t*)(meta + o_ns), nseg, d_streams, d_stream_len, d_status, st);
+            if (rc && rc != kEnc5NoMemory) return rc;
+            done = rc == 0;
         }
+        if (done) {}
         else if (waves == 2) {   // few segments: two wavefronts per segment (producer / bool coder), half the serial chain
             g->last_kernel = "lep_encode_v3x2_kernel";
             hipLaunchKernelGGL(lep_encode_v3x2_kernel, dim3(nseg), dim3(128), 0, st, (const ImageDev*)(meta + o_img),
@@ -605,6 +628,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_ENC5_MIN")) g->enc5_min = atoi(e);
     if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
+    if (const char* e = getenv("LEP_ENC5_SCRATCH_MAX")) g->enc5_scratch_max = (size_t)strtoull(e, nullptr, 10);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||
@@ -623,8 +647,9 @@ static void release_device_side(lep_gpu* g) {
     g->released = true;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    for (void* p : {g->arena[0].d_plans, g->arena[0].d_entries, g->arena[0].d_binlist, g->arena[1].d_plans, g->arena[1].d_entries, g->arena[1].d_binlist})
+    for (void* p : {g->enc5.d_plans, g->enc5.d_entries, g->enc5.d_binlist})
         if (p) (void)hipFree(p);
+    if (g->ev_enc5_done) (void)hipEventDestroy(g->ev_enc5_done);
     for (auto& e : g->ev_stage) if (e) (void)hipEventDestroy(e);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);

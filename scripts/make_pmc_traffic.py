@@ -82,7 +82,6 @@ note_256 = None
 if dec:
     v = small[dec[0]]
     note_256 = {"images_per_launch": 256, "read_sectors_per_block": round(v.get("TCC_EA0_RDREQ_sum", 0) / (256 * BLOCKS_4K), 1),
-                "l2_requests_per_block": round(v.get("TCC_REQ_sum", 0) / (256 * BLOCKS_4K), 1),
                 "l2_hit_rate": round(v.get("TCC_HIT_sum", 0) / ((v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0)) or 1.0), 3)}
 json.dump({
     "source": "rocprofv3 --pmc, five separate passes (SQ wave time; SQ instruction counts; TCC_EA0_RDREQ / WRREQ / HIT / MISS; WRREQ_64B / RDREQ_32B / REQ / READ; "

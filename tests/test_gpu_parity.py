@@ -554,3 +554,18 @@ def test_gpu_verify_executes_the_huffman_half_for_baseline_files(gpu_codec):
     assert stats1["gpu_verified_scans"] >= stats1["gpu_huffman_files"] > len(jpgs) // 2   # at least one segment per GPU-decoded file
     back, st2, _ = gpu_codec.decompress_batch(checked)
     assert st2 == [0] * len(jpgs) and back == jpgs
+
+
+@pytest.mark.gpu
+def test_gpu_split_phase_encoder_without_room_for_its_scratch(monkeypatch):
+    """lep_gpu.hip launch_enc5: when the scratch of the split-phase encoder cannot be had (LEP_ENC5_SCRATCH_MAX stands in for a
+    failed hipMalloc), the launch goes to the single-kernel encoder, which needs none -- same streams, no error"""
+    monkeypatch.setenv("LEP_ENC5_MIN", "1")
+    monkeypatch.setenv("LEP_ENC5_SCRATCH_MAX", "1")
+    codec = GpuCodec(0)
+    names = golden_cases()[:6]
+    imgs = [JpegImage(golden(n)[0]) for n in names]
+    plans = [im.plan() for im in imgs]
+    wants = [ob.oracle_encode(im.desc, p)[0] for im, p in zip(imgs, plans)]
+    assert codec.encode(imgs, plans) == wants
+    assert b"lep_encode_v3" in codec._L.lep_gpu_last_kernel_name(codec.handle)
