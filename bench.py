@@ -238,6 +238,14 @@ class HipDevice:
         jpeg_bytes = sum(len(uniq[i]) for i in order)
         nimg = len(order)
         allocs = []
+        try:
+            return self._resident(L, g, codec, uniq, imgs, plans, order, nuniq, jpeg_bytes, nimg, allocs, steps, warmup, barrier, check_parity, with_latency)
+        finally:
+            for a in allocs:   # the resident frames are no longer needed (or could not all be had); what follows wants the memory
+                L.lep_gpu_free(g, a)
+
+    def _resident(self, L, g, codec, uniq, imgs, plans, order, nuniq, jpeg_bytes, nimg, allocs, steps, warmup, barrier, check_parity, with_latency):
+        from lepton_amd import abi
 
         def dmalloc(n):
             p = C.c_void_p()
@@ -373,8 +381,6 @@ class HipDevice:
             t0 = time.perf_counter(); one = codec.compress(uniq[0]); t1 = time.perf_counter(); assert codec.decompress(one) == uniq[0]; t2 = time.perf_counter()
             latency["whole_file_host_to_host"] = {"compress_ms": round((t1 - t0) * 1e3, 1), "decompress_ms": round((t2 - t1) * 1e3, 1),
                                                   "note": "lep_compress / lep_decompress of one 4K JPEG: host Huffman + PCIe + kernels + container"}
-        for a in allocs:   # the resident frames are no longer needed; what follows wants the memory
-            L.lep_gpu_free(g, a)
         return {"jpeg_bytes": jpeg_bytes, "images": nimg, "segments": nseg, "blocks": nblocks, "stream_bytes": stream_bytes,
                 "elapsed": elapsed, "enc_ms": enc_ms, "dec_ms": dec_ms, "names": names, "parity": parity,
                 "bins_per_image": bins_per_image, "latency": latency,
@@ -594,6 +600,7 @@ def main():
                 "encode_kernel_ms": round(r2["enc_ms"] / k2, 3), "decode_kernel_ms": round(r2["dec_ms"] / k2, 3), "parity": r2["parity"]}
         except Exception as e:
             out["value_skewed"] = {"error": repr(e)[:300]}
+        log("[rank 0] skewed corpus, resident: %s" % str(out["value_skewed"])[:200])
         # secondary corpora through the host-to-host pipeline: the photograph-like one, BASELINE.json configs[2] (1024 x 1080p),
         # configs[4] (4K progressive) and the file `lepton -benchmark` itself codes
         extras = {}
@@ -609,6 +616,7 @@ def main():
                 extras[key] = fig
             except Exception as e:
                 extras[key] = {"workload": label, "error": repr(e)[:300]}
+            log("[rank 0] extra %s: %s" % (key, str({k: v for k, v in extras[key].items() if k != "workload"})[:200]))
         try:   # the reference's own benchmark input (src/lepton/benchmark.cc:116-119), so that numbers line up with `lepton -benchmark`
             rb = reference_benchmark_jpeg()
             fig = dev.pipeline([rb] * 512, "512 copies of the file `lepton -benchmark` codes (bigger_hdr + 76 x bigger_rep, 2,589,088 B, 3264x2448 4:2:0)")
