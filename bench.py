@@ -221,6 +221,7 @@ class HipDevice:
         self.L.lep_gpu_sync(self.g)
 
     def pipeline(self, jpgs, label, verify=False):
+        self.L.lep_gpu_trim(self.g)   # (as resident(): nothing cached from the phase before)
         return pipeline_figure(self.codec, jpgs, label, verify=verify)
 
     def resident(self, uniq, images, steps, warmup, barrier, check_parity=True, with_latency=False):
@@ -238,6 +239,7 @@ class HipDevice:
         jpeg_bytes = sum(len(uniq[i]) for i in order)
         nimg = len(order)
         allocs = []
+        L.lep_gpu_trim(g)   # every figure starts from the same state: nothing cached from the phase before
         try:
             return self._resident(L, g, codec, uniq, imgs, plans, order, nuniq, jpeg_bytes, nimg, allocs, steps, warmup, barrier, check_parity, with_latency)
         finally:

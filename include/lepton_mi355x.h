@@ -220,6 +220,11 @@ int lep_gpu_huffman_decode_parallel_device(lep_gpu *g, const lep_huffdec_image *
 /* Device self-test of kernel arithmetic that has no CPU twin (exhaustive: the float-reciprocal Branch probability of the
  * kernels against integer division, src/vp8/model/branch.hh:82-125).  0 = exact everywhere. */
 int lep_gpu_selftest(lep_gpu *g);
+/* Gives back the device memory the object caches between launches (per-segment models, neighbour rings, the split-phase
+ * encoder's scratch: ~140 MB per 4K image of the largest launch so far).  The next launch re-acquires what it needs.  The
+ * library does this itself before it reports an allocation failure; a caller that keeps large buffers of its own beside the
+ * codec calls it between phases.  Waits for the device. */
+int lep_gpu_trim(lep_gpu *g);
 /* Profiling builds (-DLEP_PROF) only: per-phase shader-clock totals [64 segments][32 slots] of the last decoder launch. */
 int lep_gpu_debug_prof(lep_gpu *g, uint64_t *out);
 int lep_gpu_malloc(lep_gpu *g, size_t bytes, void **dptr);

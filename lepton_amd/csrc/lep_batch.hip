@@ -146,6 +146,19 @@ struct Slot {   // one chunk's buffers (double-buffered)
 };
 
 #define HIPOK(call) do { if ((call) != hipSuccess) return LEP_GPU_ERROR; } while (0)
+// device memory for the pipeline's staging: when the device has none left, what the codec object caches between launches
+// (models, the split-phase encoder's scratch -- re-acquired on demand) is given back first
+static lep_gpu* g_batch_gpu = nullptr;   // the codec object of the batch call in progress
+static hipError_t dev_alloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && g_batch_gpu) {
+        (void)hipGetLastError();
+        (void)lep_gpu_trim(g_batch_gpu);
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) *p = nullptr;
+    return e;
+}
 
 struct Joiner {   // a background thread that is joined on every way out of the function, error returns included
     std::thread t;
@@ -185,15 +198,15 @@ int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_
     if (frames > s->frames_cap) {
         if (s->d_frames) (void)hipFree(s->d_frames);
         if (s->d_scratch) (void)hipFree(s->d_scratch);
-        s->d_frames = s->d_scratch = nullptr;
-        HIPOK(hipMalloc((void**)&s->d_frames, frames));
+        s->d_frames = s->d_scratch = nullptr; s->frames_cap = 0;   // (a capacity never outlives its allocation: the next hipMalloc may fail)
+        HIPOK(dev_alloc((void**)&s->d_frames, frames));
         s->frames_cap = frames;
     }
-    if (scratch && !s->d_scratch) HIPOK(hipMalloc((void**)&s->d_scratch, s->frames_cap));
+    if (scratch && !s->d_scratch) HIPOK(dev_alloc((void**)&s->d_scratch, s->frames_cap));
     if (streams > s->streams_cap) {
         if (s->d_streams) (void)hipFree(s->d_streams);
         s->d_streams = nullptr; s->streams_cap = 0;
-        HIPOK(hipMalloc((void**)&s->d_streams, streams));
+        HIPOK(dev_alloc((void**)&s->d_streams, streams));
         s->streams_cap = streams;
     }
     if (host_streams > s->hstreams_cap) {
@@ -206,13 +219,15 @@ int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_
     if (nseg > s->seg_cap) {
         if (s->d_len) (void)hipFree(s->d_len);
         if (s->d_status) (void)hipFree(s->d_status);
-        HIPOK(hipMalloc((void**)&s->d_len, nseg * 4));
-        HIPOK(hipMalloc((void**)&s->d_status, nseg * 8));   // [nseg] coder statuses + [nseg] verification-decode statuses
+        s->d_len = nullptr; s->d_status = nullptr; s->seg_cap = 0;
+        HIPOK(dev_alloc((void**)&s->d_len, nseg * 4));
+        HIPOK(dev_alloc((void**)&s->d_status, nseg * 8));   // [nseg] coder statuses + [nseg] verification-decode statuses
         s->seg_cap = nseg;
     }
     if (nimg > s->img_cap) {
         if (s->d_flags) (void)hipFree(s->d_flags);
-        HIPOK(hipMalloc((void**)&s->d_flags, nimg * 4));
+        s->d_flags = nullptr; s->img_cap = 0;
+        HIPOK(dev_alloc((void**)&s->d_flags, nimg * 4));
         s->img_cap = nimg;
     }
     if (!s->up) HIPOK(hipEventCreateWithFlags(&s->up, hipEventDisableTiming));
@@ -230,12 +245,13 @@ int scan_reserve(Slot* s, size_t bytes, size_t nseg) {
         if (s->d_scan) (void)hipFree(s->d_scan);
         s->h_scan = s->d_scan = nullptr; s->scan_cap = 0;
         HIPOK(hipHostMalloc((void**)&s->h_scan, bytes, hipHostMallocDefault));
-        HIPOK(hipMalloc((void**)&s->d_scan, bytes));
+        HIPOK(dev_alloc((void**)&s->d_scan, bytes));
         s->scan_cap = bytes;
     }
     if (nseg > s->scanlen_cap) {
         if (s->d_scanlen) (void)hipFree(s->d_scanlen);
-        HIPOK(hipMalloc((void**)&s->d_scanlen, nseg * 4 + 16 + nseg * sizeof(lep_huff_end)));
+        s->d_scanlen = nullptr; s->scanlen_cap = 0;
+        HIPOK(dev_alloc((void**)&s->d_scanlen, nseg * 4 + 16 + nseg * sizeof(lep_huff_end)));
         s->scanlen_cap = nseg;
     }
     g_alloc_s += now_s() - t0;
@@ -247,25 +263,25 @@ int prog_reserve(Slot* s, size_t scan_bytes, size_t corr_words, size_t nscan) {
     if (scan_bytes > s->pscan_cap) {
         if (s->d_pscan) (void)hipFree(s->d_pscan);
         s->d_pscan = nullptr; s->pscan_cap = 0;
-        HIPOK(hipMalloc((void**)&s->d_pscan, scan_bytes));
+        HIPOK(dev_alloc((void**)&s->d_pscan, scan_bytes));
         s->pscan_cap = scan_bytes;
     }
     if (corr_words > s->corr_cap) {
         if (s->d_corr) (void)hipFree(s->d_corr);
         s->d_corr = nullptr; s->corr_cap = 0;
-        HIPOK(hipMalloc((void**)&s->d_corr, corr_words * 4));
+        HIPOK(dev_alloc((void**)&s->d_corr, corr_words * 4));
         s->corr_cap = corr_words;
     }
     if (nscan > s->pscanlen_cap) {
         if (s->d_pscanlen) (void)hipFree(s->d_pscanlen);
         s->d_pscanlen = nullptr; s->pscanlen_cap = 0;
-        HIPOK(hipMalloc((void**)&s->d_pscanlen, nscan * 4));
+        HIPOK(dev_alloc((void**)&s->d_pscanlen, nscan * 4));
         s->pscanlen_cap = nscan;
     }
     if (nscan > s->pcheck_cap) {
         if (s->d_pcheck) (void)hipFree(s->d_pcheck);
         s->d_pcheck = nullptr; s->pcheck_cap = 0;
-        HIPOK(hipMalloc((void**)&s->d_pcheck, nscan * sizeof(ScanCheck)));
+        HIPOK(dev_alloc((void**)&s->d_pcheck, nscan * sizeof(ScanCheck)));
         s->pcheck_cap = nscan;
     }
     g_alloc_s += now_s() - t0;
@@ -276,15 +292,15 @@ int vscan_reserve(Slot* s, size_t bytes, size_t nseg) {
     if (bytes > s->vscan_cap) {
         if (s->d_vscan) (void)hipFree(s->d_vscan);
         s->d_vscan = nullptr; s->vscan_cap = 0;
-        HIPOK(hipMalloc((void**)&s->d_vscan, bytes));
+        HIPOK(dev_alloc((void**)&s->d_vscan, bytes));
         s->vscan_cap = bytes;
     }
     if (nseg > s->vseg_cap) {
         if (s->d_vscanlen) (void)hipFree(s->d_vscanlen);
         if (s->d_vcheck) (void)hipFree(s->d_vcheck);
         s->d_vscanlen = nullptr; s->d_vcheck = nullptr; s->vseg_cap = 0;
-        HIPOK(hipMalloc((void**)&s->d_vscanlen, nseg * 4));
-        HIPOK(hipMalloc((void**)&s->d_vcheck, nseg * sizeof(ScanCheck)));
+        HIPOK(dev_alloc((void**)&s->d_vscanlen, nseg * 4));
+        HIPOK(dev_alloc((void**)&s->d_vcheck, nseg * sizeof(ScanCheck)));
         s->vseg_cap = nseg;
     }
     g_alloc_s += now_s() - t0;
@@ -376,6 +392,7 @@ void lep_batch_debug_poison(int value) {
 int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs, int32_t* status, const lep_batch_options* o,
                        lep_batch_stats* stats) {
     if (!g || n < 0) return LEP_GPU_ERROR;
+    g_batch_gpu = g;
     const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
     // With the Huffman decode on the GPU, chunk k+1 is decoded WHILE the arithmetic coder of chunk k runs: a chunk's thread
     // segments (one coder wavefront each) fill 7 of the 8 wave slots of every SIMD (7 x 4 x 256 = 7168), the eighth holds
@@ -536,7 +553,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             if (rows_total * sizeof(lep_huffdec_row) > s->rows_cap) {
                 if (s->d_rows) (void)hipFree(s->d_rows);
                 s->d_rows = nullptr; s->rows_cap = 0;
-                HIPOK(hipMalloc((void**)&s->d_rows, rows_total * sizeof(lep_huffdec_row)));
+                HIPOK(dev_alloc((void**)&s->d_rows, rows_total * sizeof(lep_huffdec_row)));
                 s->rows_cap = rows_total * sizeof(lep_huffdec_row);
             }
             g_alloc_s += now_s() - ta;
@@ -923,6 +940,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
 int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* outs, int32_t* status, const lep_batch_options* o,
                          lep_batch_stats* stats) {
     if (!g || n < 0) return LEP_GPU_ERROR;
+    g_batch_gpu = g;
     const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
     const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
     const size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;

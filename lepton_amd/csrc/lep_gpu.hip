@@ -384,7 +384,19 @@ struct lep_gpu {
         }                                                                                      \
     } while (0)
 
-static int ensure(lep_gpu* g, void** p, size_t* have, size_t need) {
+// before an allocation failure is reported: the cached memory no launch that is being set up depends on -- the split-phase
+// encoder's scratch (its launches take the single-kernel encoder when they cannot have it) and the other arena set's models
+static void release_idle_caches(lep_gpu* g) {
+    (void)hipDeviceSynchronize();
+    lep_gpu::Arena& O = g->arena[g->cur ^ 1];
+    void** ps[] = {&g->enc5.d_entries, &g->enc5.d_binlist, &O.d_models, &O.d_ns};
+    size_t* ns[] = {&g->enc5.entries_bytes, &g->enc5.binlist_bytes, &O.models_bytes, &O.ns_bytes};
+    for (int i = 0; i < 4; ++i) {
+        if (*ps[i]) (void)hipFree(*ps[i]);
+        *ps[i] = nullptr; *ns[i] = 0;
+    }
+}
+static int ensure(lep_gpu* g, void** p, size_t* have, size_t need, bool may_release = true) {
     if (*have >= need) return 0;
     if (*p) HIPCHK(g, hipFree(*p));
     *p = nullptr; *have = 0;
@@ -392,7 +404,12 @@ static int ensure(lep_gpu* g, void** p, size_t* have, size_t need) {
     if (hipMalloc(p, want) != hipSuccess) {   // (the head room is a convenience: without it before giving up)
         (void)hipGetLastError();
         *p = nullptr; want = need;
-        HIPCHK(g, hipMalloc(p, want));
+        if (hipMalloc(p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            *p = nullptr;
+            if (may_release) release_idle_caches(g);
+            HIPCHK(g, hipMalloc(p, want));
+        }
     }
     *have = want;
     return 0;
@@ -445,7 +462,7 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     HIPCHK(g, hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
     HIPCHK(g, hipStreamSynchronize(st));
     // no room for the scratch (~140 MB per 4K image): the single-kernel encoder takes the launch -- it needs none
-    if ((size_t)tot[0] + (size_t)tot[1] * 2 > g->enc5_scratch_max || ensure(g, &E.d_entries, &E.entries_bytes, (size_t)tot[0] + 256) || ensure(g, &E.d_binlist, &E.binlist_bytes, (size_t)tot[1] * 2 + 256)) {
+    if ((size_t)tot[0] + (size_t)tot[1] * 2 > g->enc5_scratch_max || ensure(g, &E.d_entries, &E.entries_bytes, (size_t)tot[0] + 256, false) || ensure(g, &E.d_binlist, &E.binlist_bytes, (size_t)tot[1] * 2 + 256, false)) {
         (void)hipGetLastError();
         g->err.clear();
         return kEnc5NoMemory;
@@ -895,7 +912,28 @@ int lep_gpu_debug_prof(lep_gpu* g, uint64_t* out /* [64][32] */) {
 #endif
 }
 
-int lep_gpu_malloc(lep_gpu* g, size_t bytes, void** dptr) { HIPCHK(g, hipSetDevice(g->device)); HIPCHK(g, hipMalloc(dptr, bytes ? bytes : 16)); return 0; }
+// give back what the object caches between launches (models, neighbour rings, the split-phase encoder's scratch): all of it
+// is re-acquired by the next launch that needs it.  Waits for the device first.
+int lep_gpu_trim(lep_gpu* g) {
+    HIPCHK(g, hipSetDevice(g->device));
+    HIPCHK(g, hipDeviceSynchronize());
+    void** ps[] = {&g->enc5.d_entries, &g->enc5.d_binlist, &g->arena[0].d_models, &g->arena[1].d_models, &g->arena[0].d_ns, &g->arena[1].d_ns};
+    size_t* ns[] = {&g->enc5.entries_bytes, &g->enc5.binlist_bytes, &g->arena[0].models_bytes, &g->arena[1].models_bytes, &g->arena[0].ns_bytes, &g->arena[1].ns_bytes};
+    for (int i = 0; i < 6; ++i) {
+        if (*ps[i]) (void)hipFree(*ps[i]);
+        *ps[i] = nullptr; *ns[i] = 0;
+    }
+    return 0;
+}
+int lep_gpu_malloc(lep_gpu* g, size_t bytes, void** dptr) {
+    HIPCHK(g, hipSetDevice(g->device));
+    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) {   // (no room: the caches first)
+        (void)hipGetLastError();
+        if (int rc = lep_gpu_trim(g)) return rc;
+        HIPCHK(g, hipMalloc(dptr, bytes ? bytes : 16));
+    }
+    return 0;
+}
 int lep_gpu_free(lep_gpu* g, void* dptr) { HIPCHK(g, hipFree(dptr)); return 0; }
 int lep_gpu_memcpy_h2d(lep_gpu* g, void* dst, const void* src, size_t bytes) { HIPCHK(g, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
 int lep_gpu_memcpy_d2h(lep_gpu* g, void* dst, const void* src, size_t bytes) { HIPCHK(g, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
