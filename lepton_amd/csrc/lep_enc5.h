@@ -66,6 +66,10 @@ WDEV uint32_t thresh_entry(uint32_t tbits, int n, int pcls, int lt, int u) {
 //   DC  (6 x 4 bytes): word 0 = unit 0 of an entry like a coefficient's with k = a, bsr = b17 -> the units' probabilities
 constexpr int kKeyRec = 4, kNzRec = 8, kEnRec = 8, kDcRec = 24;
 // the sparse chains: 7x7 counts (ci, context bin), horizontal / vertical edge counts (ci, eob_x / eob_y), DC (a)
+// The array of places: rows of a tile, lane by lane -- 63 coefficient rows and the DC's entry (its sign in bit 31).  A word per
+// CODED coefficient in the block's own order would be 2.3 x smaller, and was measured: every lane then stores and loads at an
+// address of its own (64 sectors per instruction instead of 4) -- emit 129 -> 171 ms, gather 165 -> 242 ms (MI355X, 1024 x 4K).
+constexpr int kAtRows = 64;
 constexpr int kClsNz = 0, kClsEh = 20, kClsEv = 36, kClsDc = 52, kNumCls = 64;
 WDEV void key_classes(uint32_t key, int c[4]) {
     const int ci = (int)(key & 1u);
@@ -81,7 +85,7 @@ struct SegPlan5 {            // one per segment, device memory; written by plan5
     uint32_t cls_base;       // bucket's table: [kNumCls] first record of the chain's stream, [kNumCls] records
     uint32_t place_base;     // [4][nblocks]: the block's place in its 7x7 count / horizontal / vertical / DC stream
     uint32_t nzs_base, ens_base[2], dcs_base;       // the chains' streams (every chain padded to four records)
-    uint32_t at_base, ncoded;                       // the places emit gave out, for gather: a dword per coded coefficient (and per block's DC)
+    uint32_t at_base, ntiles;                       // the places emit gave out, for gather: [tile][64 rows][64 lanes] dwords
     uint32_t nblocks;        // block ordinals (coded blocks of the segment)
     uint32_t bins_cap;       // room in the bin list
     uint32_t nbins;          // bins written by gather (without the start marker and the stop bins)
@@ -678,8 +682,8 @@ struct Walk5 {
     uint32_t sign_pos[2];      // sign bytes given out per colour index
     uint32_t nbins;            // gather: bins written; count: bins an encoder will need (upper bound through the DC term)
     int status;
-    uint32_t coded_pos;        // coded coefficients (+ one DC per block) walked so far
-    uint32_t* AT;              // emit / gather: the segment's array of places, a word per coded coefficient
+    uint32_t tile_no;          // tiles walked so far
+    uint32_t* AT;              // emit / gather: the segment's [tile][64][64] array of places
     uint32_t sign_base[2], key_base, nz_base, en_base, dc_base;   // the plan's offsets (read once: a load per tile from the plan would sit on the critical path)
     uint32_t place_base, nzs_base, ens_base[2], dcs_base, plan_nblocks;
 
@@ -781,7 +785,7 @@ struct Walk5 {
     }
 
     // one tile; has_above: the row above belongs to this segment; returns 0 or an exit code
-    struct TileTotals { int nsig, bins, coded; };
+    struct TileTotals { int nsig, bins; };
     WDEV int tile(int x0, int nb, bool has_above, NSum* nrow, const NSum* narow) {
         Walk5Shared& S = LEP5_WSH(this);
         TileTotals tt;
@@ -799,7 +803,7 @@ struct Walk5 {
         sign_pos[ci] += (uint32_t)tt.nsig;
         nbins += (uint32_t)tt.bins;
         ord0 += (uint32_t)nb;
-        coded_pos += (uint32_t)tt.coded;
+        ++tile_no;
         return 0;
     }
     // HALF: 1 = the 7x7 interiors, 2 = the sparse records, the edges and the DC, 3 = the whole block
@@ -819,8 +823,6 @@ struct Walk5 {
 
         // gather: the block's sparse records (7x7 count, edge counts, DC units) are requested now and used after phase 1
         LV(uint32_t, rdce); LV(uint32_t, rdcp);
-        LV(int, c7); LV(int, ch); LV(int, cv);   // coded coefficients (zeros in front of the last non-zero included) of the interior and the two edges
-        LV(uint32_t, cb);                        // the block's first word in the array of places
         LV(uint32_t, rnz0); LV(uint32_t, rnz1); LV(uint32_t, ren0); LV(uint32_t, ren1); LV(uint32_t, rdc0); LV(uint32_t, rdc1); LV(uint32_t, rdc2);
         if (MODE == kGather) {
             LANES(l) if (l < nb) {
@@ -841,7 +843,7 @@ struct Walk5 {
         LANES(l) {
             const int a = l < nb;
             L(act) = a; L(err) = 0; L(errdc) = 0;
-            int n7 = 0, nh = 0, nv = 0, ex = 0, ey = 0, lb = 0, ib = 0, k7 = 0, kh = 0, kv = 0;
+            int n7 = 0, nh = 0, nv = 0, ex = 0, ey = 0, lb = 0, ib = 0;
             if (kEdge) for (int t = 0; t < 8; ++t) S.TB[t * 65 + l] = 0;
             if (a) {
                 // bins of the block that do not depend on its neighbours: 6 + 3 + 3 count bins, and per coded coefficient the
@@ -857,7 +859,6 @@ struct Walk5 {
                     }
                 }
                 lb += last + 1 - n7;
-                k7 = last + 1;
                 ib = lb;
                 lb += 12;
                 for (int eg = 0; eg < 2; ++eg) {
@@ -876,26 +877,15 @@ struct Walk5 {
                         }
                     }
                     lb += lastj + 1 - cnt;
-                    if (eg) { nv = cnt; kv = lastj + 1; } else { nh = cnt; kh = lastj + 1; }
+                    if (eg) nv = cnt; else nh = cnt;
                 }
             }
             L(nz) = n7; L(neh) = nh; L(nev) = nv; L(eobx) = ex; L(eoby) = ey; L(lbins) = lb; L(ibins) = ib;
             L(nsig) = a ? n7 + nh + nv + 1 : 0;
-            L(c7) = k7; L(ch) = kh; L(cv) = kv;
             if (MODE == kEmit && kEdge && has_above && a) L(nsa) = gld_ns(&narow[x0 + l]);   // (written when that row was walked)
             else L(nsa) = NSum{};
-        }
-        // the places emit gives out are kept for gather, one word per coded coefficient in the block's own order (interior rows
-        // 0 .. last, the two edges, then the DC's entry): where the block's words start
-        int coded_tile;
-        {
-            LV(int, ncod); LV(int, cbase);
-            LANES(l) L(ncod) = L(act) ? L(c7) + L(ch) + L(cv) + 1 : 0;
-            coded_tile = lepwave::wave_excl_scan(ncod, cbase);
-            LANES(l) {
-                L(cb) = coded_pos + (uint32_t)L(cbase);
-                if (MODE == kGather && L(act)) L(rdce) = gld(AT + L(cb) + (uint32_t)(L(c7) + L(ch) + L(cv)));   // the DC's entry, sign in bit 31
-            }
+            // gather: the DC's entry as emit worked it out, its sign in bit 31 (both halves: the DC's bins are part of the block's)
+            if (MODE == kGather && a) L(rdce) = gld(AT + ((size_t)tile_no * kAtRows + 63) * 64 + l);
         }
         // ---- phase 1b: IDCT without DC, neighbour summary (block_context.hh:44-78) -------------------------------------
         struct Px { int16_t r0[8], r1[8], c0[8], c1[8]; };   // pixel rows 0, 1 and columns 0, 1 of the block without its DC
@@ -1066,7 +1056,7 @@ struct Walk5 {
         LV(uint32_t, p_e); LV(uint32_t, p_te); LV(uint32_t, p_at); LV(uint32_t, p_tat); LV(int, p_cf); LV(uint32_t, p_w0); LV(uint32_t, p_w1); LV(uint32_t, p_tw); LV(uint32_t, p_sg);
         LV(uint32_t, enw); LV(uint32_t, at_next);
         constexpr int kRow0 = kInt ? 0 : 49, kRowEnd = kEdge ? 63 : 49;
-        LANES(l) { L(p_e) = 0; L(enw) = 0; L(at_next) = MODE == kGather ? gld(AT + L(cb) + (uint32_t)(kInt ? 0 : L(c7))) : 0u; }
+        LANES(l) { L(p_e) = 0; L(enw) = 0; L(at_next) = MODE == kGather ? gld(AT + ((size_t)tile_no * kAtRows + kRow0) * 64 + l) : 0u; }
         for (int row = kRow0; row < kRowEnd; ++row) {
             const bool edge = row >= 49;
             const int eg = row >= 56 ? 1 : 0, j = edge ? row - 49 - eg * 7 : 0;
@@ -1155,10 +1145,7 @@ struct Walk5 {
                 const uint64_t rem = lepwave::wave_ballot(coded);
                 const bool skip = !rem && !edge;
                 const int next_row = skip ? 49 : row + 1;
-                LANES(l) {   // (a lane without a coefficient in that row reads a neighbour's word and does not use it)
-                    L(at) = L(at_next);
-                    if (next_row < kRowEnd) L(at_next) = gld(AT + L(cb) + (uint32_t)(next_row < 49 ? next_row : (next_row < 56 ? L(c7) + next_row - 49 : L(c7) + L(ch) + next_row - 56)));
-                }
+                LANES(l) { L(at) = L(at_next); if (next_row < kRowEnd) L(at_next) = gld(AT + ((size_t)tile_no * kAtRows + next_row) * 64 + l); }
                 if (skip) { row = 48; continue; }
             } else {
             // rank the lanes of every (row, class) in block order: the entry's place in its stream
@@ -1185,7 +1172,7 @@ struct Walk5 {
                 LSYNC();
                 rem &= ~m1;
             }
-            LANES(l) if (L(coded)) gst(AT + L(cb) + (uint32_t)(row < 49 ? row : (row < 56 ? L(c7) + row - 49 : L(c7) + L(ch) + row - 56)), L(at));   // for gather
+            LANES(l) if (L(coded)) gst(AT + ((size_t)tile_no * kAtRows + row) * 64 + l, L(at));   // for gather
             }
             // emit: write the units; gather: request this row's probabilities, turn the PREVIOUS row's into bins
             LANES(l) {
@@ -1241,7 +1228,7 @@ struct Walk5 {
                 const int len = (int)(e >> 14) & 15, nres = (int)(e >> 10) & 15, nexp = len < 11 ? len + 1 : 11, m = nexp + nres;
                 if (MODE == kEmit) {
                     gst(rec, e); gst(signs + L(sp)++, (uint8_t)L(dc_sign));
-                    gst(AT + L(cb) + (uint32_t)(L(c7) + L(ch) + L(cv)), e | ((((uint32_t)L(dc_sign) >> 6) & 1u) << 31));
+                    gst(AT + ((size_t)tile_no * kAtRows + 63) * 64 + l, e | ((((uint32_t)L(dc_sign) >> 6) & 1u) << 31));
                 }
                 else {
                     uint32_t w = L(rdc0);
@@ -1263,7 +1250,7 @@ struct Walk5 {
             LSYNC();
         }
         if (MODE == kCount) bins_tile = lepwave::wave_sum(lbins);
-        return TileTotals{nsig_tile, bins_tile, coded_tile};
+        return TileTotals{nsig_tile, bins_tile};
     }
 
     // gather: append one bin (probability | bit << 8) of this lane.  Bins leave in pairs: the one at an even position waits in
@@ -1306,7 +1293,7 @@ struct Walk5 {
         img = image; sh = shared; plan = pl; status = 0; wave = wave_no;
         arena = (MODE != kCount) ? arena_base + pl->arena_off : nullptr;
         bins = (MODE == kGather) ? bins_base + pl->bins_off : nullptr;
-        ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0; coded_pos = 0;
+        ord0 = 0; sign_pos[0] = sign_pos[1] = 0; nbins = 0; tile_no = 0;
         AT = MODE != kCount ? reinterpret_cast<uint32_t*>(arena + pl->at_base) : nullptr;
         if (MODE != kCount) { sign_base[0] = pl->sign_base[0]; sign_base[1] = pl->sign_base[1]; key_base = pl->key_base; nz_base = pl->nz_base; en_base = pl->en_base; dc_base = pl->dc_base;
             place_base = pl->place_base; nzs_base = pl->nzs_base; ens_base[0] = pl->ens_base[0]; ens_base[1] = pl->ens_base[1]; dcs_base = pl->dcs_base; plan_nblocks = pl->nblocks; }
@@ -1372,8 +1359,8 @@ WDEV void plan_segment(const uint32_t* counts, SegPlan5* P) {
     P->ens_base[1] = bytes; bytes += (P->nblocks + 4u * 16u) * 4u;
     P->dcs_base = bytes; bytes += (P->nblocks + 4u * 12u) * (uint32_t)kDcRec;
     bytes = (bytes + 255u) & ~255u;
-    P->ncoded = counts[kStreams + 4];
-    P->at_base = bytes; bytes += (P->ncoded + 64u) * 4u;
+    P->ntiles = counts[kStreams + 4];
+    P->at_base = bytes; bytes += P->ntiles * (uint32_t)(kAtRows * 64 * 4);
     P->arena_bytes = (bytes + 255u) & ~255u;
     P->bins_cap = (counts[kStreams + 3] + 127u) & ~127u;
     P->nbins = 0; P->status = 0; P->arena_off = 0; P->bins_off = 0;
@@ -1383,7 +1370,7 @@ template <class W>
 WDEV void export_counts(const W& w, const Walk5Shared* sh, uint32_t* counts) {
     LANES(l) {
         for (int i = l; i < kStreams; i += 64) counts[i] = sh->cursor[i];
-        if (l == 0) { counts[kStreams] = w.sign_pos[0]; counts[kStreams + 1] = w.sign_pos[1]; counts[kStreams + 2] = w.ord0; counts[kStreams + 3] = w.nbins; counts[kStreams + 4] = w.coded_pos; }
+        if (l == 0) { counts[kStreams] = w.sign_pos[0]; counts[kStreams + 1] = w.sign_pos[1]; counts[kStreams + 2] = w.ord0; counts[kStreams + 3] = w.nbins; counts[kStreams + 4] = w.tile_no; }
     }
 }
 

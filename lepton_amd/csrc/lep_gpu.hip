@@ -465,6 +465,8 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     if ((size_t)tot[0] + (size_t)tot[1] * 2 > g->enc5_scratch_max || ensure(g, &E.d_entries, &E.entries_bytes, (size_t)tot[0] + 256, false) || ensure(g, &E.d_binlist, &E.binlist_bytes, (size_t)tot[1] * 2 + 256, false)) {
         (void)hipGetLastError();
         g->err.clear();
+        static bool told = false;
+        if (!told) { told = true; fprintf(stderr, "lepton-mi355x: no room for the split-phase encoder's scratch (%.1f GB for %d segments): single-kernel encoder\n", ((double)tot[0] + 2.0 * (double)tot[1]) / 1e9, nseg); }
         return kEnc5NoMemory;
     }
     // (Segment groups on streams of their own -- one group's writer and folds beside the next group's walks -- were measured
