@@ -199,6 +199,7 @@ def pipeline_figure(codec, jpgs, label, verify=False):
             "compress_MBps": round(mb / cs["wall_s"], 1), "decompress_MBps": round(mb / ds["wall_s"], 1),
             "value": round(mb / (cs["wall_s"] + ds["wall_s"]), 1), "files_per_s": round(len(jpgs) / (cs["wall_s"] + ds["wall_s"]), 1),
             "unit": "MB/s = JPEG bytes / (compress seconds + decompress seconds), the headline's definition",
+            "seconds": {d: {k: round(st[k], 3) for k in ("wall_s", "pipeline_s", "parse_s", "stage_s", "write_s", "alloc_s")} for d, st in (("compress", cs), ("decompress", ds))},
             "parity": "every file restored bit-exact", "_cs": cs, "_ds": ds}
 
 
@@ -618,7 +619,7 @@ def main():
                 extras[key] = fig
             except Exception as e:
                 extras[key] = {"workload": label, "error": repr(e)[:300]}
-            log("[rank 0] extra %s: %s" % (key, str({k: v for k, v in extras[key].items() if k != "workload"})[:200]))
+            log("[rank 0] extra %s: %s" % (key, str({k: v for k, v in extras[key].items() if k not in ("workload", "unit", "parity", "jpeg_MB", "lep_MB")})[:600]))
         try:   # the reference's own benchmark input (src/lepton/benchmark.cc:116-119), so that numbers line up with `lepton -benchmark`
             rb = reference_benchmark_jpeg()
             fig = dev.pipeline([rb] * 512, "512 copies of the file `lepton -benchmark` codes (bigger_hdr + 76 x bigger_rep, 2,589,088 B, 3264x2448 4:2:0)")

@@ -837,6 +837,7 @@ struct Walk5 {
                     L(rdc0) = gld(r3); L(rdc1) = gld(r3 + 1); L(rdc2) = gld(r3 + 2);
                     L(rdcp) = p3;
                 }
+                L(rdce) = gld(AT + ((size_t)tile_no * kAtRows + 63) * 64 + l);   // the DC's entry as emit worked it out, its sign in bit 31 (both halves: the DC's bins are part of the block's)
             }
         }
         // ---- phase 1a: own numbers ---------------------------------------------------------------------------------
@@ -884,8 +885,6 @@ struct Walk5 {
             L(nsig) = a ? n7 + nh + nv + 1 : 0;
             if (MODE == kEmit && kEdge && has_above && a) L(nsa) = gld_ns(&narow[x0 + l]);   // (written when that row was walked)
             else L(nsa) = NSum{};
-            // gather: the DC's entry as emit worked it out, its sign in bit 31 (both halves: the DC's bins are part of the block's)
-            if (MODE == kGather && a) L(rdce) = gld(AT + ((size_t)tile_no * kAtRows + 63) * 64 + l);
         }
         // ---- phase 1b: IDCT without DC, neighbour summary (block_context.hh:44-78) -------------------------------------
         struct Px { int16_t r0[8], r1[8], c0[8], c1[8]; };   // pixel rows 0, 1 and columns 0, 1 of the block without its DC
