@@ -276,6 +276,13 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_progressive_decode_kernel(c
     lephuff::ProgDecWave w;
     w.run_scan(scans + blockIdx.x, &sh, rows);
 }
+// ... all levels in ONE launch: a scan waits, MCU row by MCU row, for the scans of its file it follows (lep_huffprogdec.h ProgDeps)
+__global__ __launch_bounds__(64, 8) void lep_huffman_progressive_pipelined_kernel(const lephuff::ProgDecScan* __restrict__ scans, lephuff::HuffDecRow* rows,
+                                                                                 const lephuff::ProgDeps* __restrict__ deps, uint32_t* progress) {
+    __shared__ lephuff::HuffDecShared sh;
+    lephuff::ProgDecWave w;
+    w.run_scan(scans + blockIdx.x, &sh, rows, deps + blockIdx.x, progress, (int)blockIdx.x);
+}
 
 // JPEG Huffman scan decode: one wavefront per image (lep_huffdec.h)
 // <= 64 VGPRs and 4.5 KB of LDS: one of these waves fits on a SIMD beside seven coder waves, and it runs at raised priority
@@ -328,6 +335,8 @@ struct lep_gpu {
     int enc5_min = 64;       // launches of at least this many segments take the split-phase encoder (lep_enc5.h); LEP_ENC5_MIN (0 = never)
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+    int huffprog_pipeline = 1;          // LEP_HUFFPROG_PIPELINE=0: progressive scan decode level by level, whatever the launch size
+    int huffprog_pipeline_max = 4096;   // LEP_HUFFPROG_PIPELINE_MAX: scans per launch up to which the levels go out as one pipelined launch
     int enc5_waves = 2;      // LEP_ENC5_WAVES: wavefronts per segment in the split-phase walks (1 | 2)
     int enc5_fold_apart = 0; // LEP_ENC5_FOLD_APART: the fold launches one after the other, a launch per kind of chain (for the profiler)
     size_t enc5_scratch_max = ~(size_t)0;   // LEP_ENC5_SCRATCH_MAX (bytes): a launch that needs more takes the single-kernel encoder (tests: the out-of-memory path)
@@ -645,6 +654,8 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 0));
     if (const char* e = getenv("LEP_ENC_PAIR_MAX")) g->enc_pair_max = atoi(e);
     if (const char* e = getenv("LEP_ENC5_MIN")) g->enc5_min = atoi(e);
+    if (const char* e = getenv("LEP_HUFFPROG_PIPELINE")) g->huffprog_pipeline = atoi(e);
+    if (const char* e = getenv("LEP_HUFFPROG_PIPELINE_MAX")) g->huffprog_pipeline_max = atoi(e);
     if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
     if (const char* e = getenv("LEP_ENC5_SCRATCH_MAX")) g->enc5_scratch_max = (size_t)strtoull(e, nullptr, 10);
@@ -745,16 +756,41 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu* g, const lep_huffprogdec_
     for (int i = 0; i < nscan; ++i) { if (scans[i].level < 0 || scans[i].level > 63) return LEP_ASSERTION_FAILURE; maxlevel = std::max(maxlevel, (int)scans[i].level); }
     std::vector<lep_huffprogdec_scan> sorted;
     sorted.reserve((size_t)nscan);
-    std::vector<int> first((size_t)maxlevel + 2, 0);
+    std::vector<int> first((size_t)maxlevel + 2, 0), order;
+    order.reserve((size_t)nscan);
     for (int lv = 0; lv <= maxlevel; ++lv) {
         first[(size_t)lv] = (int)sorted.size();
-        for (int i = 0; i < nscan; ++i) if (scans[i].level == lv) sorted.push_back(scans[i]);
+        for (int i = 0; i < nscan; ++i) if (scans[i].level == lv) { sorted.push_back(scans[i]); order.push_back(i); }
     }
     first[(size_t)maxlevel + 1] = (int)sorted.size();
-    if (int rc = ensure(g, &g->d_huffprogdec, &g->huffprogdec_bytes, (size_t)nscan * sizeof(lep_huffprogdec_scan))) return rc;
+    // Small launches wait for the chain of a file's dependent scans, not for throughput: all levels go out as ONE launch in which
+    // a scan follows the scans in front of it MCU row by MCU row.  (Beyond what is resident at once the levels are launched one
+    // after the other as before: the chip is full either way.)
+    std::vector<lephuff::ProgDeps> deps;
+    bool pipelined = g->huffprog_pipeline && maxlevel > 0 && nscan <= g->huffprog_pipeline_max;
+    if (pipelined) {
+        deps.resize((size_t)nscan);
+        pipelined = lephuff::prog_scan_deps(reinterpret_cast<const lephuff::ProgDecScan*>(sorted.data()), order.data(), nscan, deps.data());
+    }
+    const size_t o_deps = ((size_t)nscan * sizeof(lep_huffprogdec_scan) + 255) & ~(size_t)255, o_prog = o_deps + (((size_t)nscan * sizeof(lephuff::ProgDeps) + 255) & ~(size_t)255),
+                 total = o_prog + (size_t)nscan * 4;
+    if (int rc = ensure(g, &g->d_huffprogdec, &g->huffprogdec_bytes, total)) return rc;
     HIPCHK(g, hipMemcpyAsync(g->d_huffprogdec, sorted.data(), (size_t)nscan * sizeof(lep_huffprogdec_scan), hipMemcpyHostToDevice, st));
+    if (pipelined) {
+        HIPCHK(g, hipMemcpyAsync((char*)g->d_huffprogdec + o_deps, deps.data(), (size_t)nscan * sizeof(lephuff::ProgDeps), hipMemcpyHostToDevice, st));
+        HIPCHK(g, hipMemsetAsync((char*)g->d_huffprogdec + o_prog, 0, (size_t)nscan * 4, st));
+    }
     HIPCHK(g, hipStreamSynchronize(st));
     HIPCHK(g, hipEventRecord(g->ev0, st));
+    if (pipelined) {
+        hipLaunchKernelGGL(lep_huffman_progressive_pipelined_kernel, dim3(nscan), dim3(64), 0, st, (const lephuff::ProgDecScan*)g->d_huffprogdec, (lephuff::HuffDecRow*)d_rows,
+                           (const lephuff::ProgDeps*)((char*)g->d_huffprogdec + o_deps), (uint32_t*)((char*)g->d_huffprogdec + o_prog));
+        HIPCHK(g, hipGetLastError());
+        HIPCHK(g, hipEventRecord(g->ev1, st));
+        g->timed = true;
+        g->last_kernel = "lep_huffman_progressive_pipelined_kernel";
+        return 0;
+    }
     for (int lv = 0; lv <= maxlevel; ++lv) {
         const int n = first[(size_t)lv + 1] - first[(size_t)lv];
         if (n <= 0) continue;

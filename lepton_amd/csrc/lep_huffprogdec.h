@@ -17,6 +17,8 @@
 // SPMD layer of lep_wave.h: tests/emu runs it on the CPU against the host parser (frame, hand-off rows, pad bit).
 #pragma once
 #include "lep_huffdec.h"
+#include <algorithm>
+#include <vector>
 
 namespace lephuff {
 
@@ -34,10 +36,59 @@ struct ProgDecScan {
     uint64_t result_off;    // this scan's final record {bit position, last DC, pad bits | status << 8} in the rows arena
 };
 
+// Pipelining between the scans of one image (one launch for all dependency levels).  A 4K file of libjpeg's default script is
+// ten scans in three levels, and the longest scan of every level is a luma scan (bytes: 276 k first stage, 348 k and 654 k
+// refinement): level by level a file waits for their SUM.  Refinement scans cannot be cut into subsequences the way sequential
+// scans are (lep_huffdec_par.h) -- what a code means depends on which coefficients of ITS block are already non-zero, and a
+// wavefront started in the middle does not know its block -- but a scan only needs the scans it follows to be AHEAD of it, not
+// finished.  So every scan publishes the number of MCU rows it has completed (a release store after the rows' coefficients),
+// and a scan that follows others waits, MCU row by MCU row, until all of them have passed the row it is about to enter: the
+// file then takes about as long as its longest scan.  Waiting cannot deadlock: a scan only ever waits for scans of a lower
+// index in the launch, workgroups are started in index order, and the lowest unfinished one therefore never waits.
+struct ProgDeps { int32_t dep[4]; };   // indices (into the launch) of the scans this one follows, -1 = none
+
 struct ProgDecWave : HuffDecWave {
     const ProgDecScan* sc;
     uint32_t eobrun;
     int peobrun;
+    const ProgDeps* deps = nullptr;   // pipelined launches only
+    uint32_t* progress = nullptr;     // [scan of the launch]: MCU rows completed
+    int self = 0;
+    uint32_t ready = 0;               // MCU rows every scan this one follows is known to have completed
+
+    WDEV void publish(uint32_t rows_done) {
+        if (!progress) return;
+#if LEP_ON_GPU
+        __threadfence();   // (every lane: the rows' coefficients were stored lane-parallel)
+        if (threadIdx.x == 0) __hip_atomic_store(progress + self, rows_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        progress[self] = rows_done;
+#endif
+    }
+    // before the first block of MCU row `row` is touched
+    WDEV void await(uint32_t row) {
+        if (!progress || row < ready) return;
+        for (;;) {
+            uint32_t m = 0x7fffffffu;
+            for (int i = 0; i < 4; ++i) {
+                const int d = deps->dep[i];
+                if (d < 0) continue;
+#if LEP_ON_GPU
+                const uint32_t v = __hip_atomic_load(progress + d, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+                const uint32_t v = progress[d];
+#endif
+                m = v < m ? v : m;
+            }
+            ready = m;
+            if (row < ready) return;
+#if LEP_ON_GPU
+            __builtin_amdgcn_s_sleep(64);
+#else
+            return;   // (the emulation runs the scans one after the other, in launch order: never here)
+#endif
+        }
+    }
 
     // next_mcuposn (jpgcoder.cc:5432-5456): 0 go on, 1 restart interval over, 2 scan over
     WDEV int next_noninterleaved(int cmp, int* dpos, int* rstw) const {
@@ -65,6 +116,18 @@ struct ProgDecWave : HuffDecWave {
         if (*dpos > bch * bcv) return -1;
         if (sc->t.rsti > 0 && *rstw == 0) return 1;
         return 0;
+    }
+
+    // one-component scans, pipelined launches: a block row is entered (wait for the scans in front) / left (publish).  MCU row =
+    // block row / vertical sampling factor of the component.
+    WDEV void enter_row(int cmp, int dpos, int* row_end) {
+        const int bch = sc->t.bch[cmp], br = dpos / bch;
+        *row_end = (br + 1) * bch;
+        await((uint32_t)(br / sc->t.vs[cmp]));
+    }
+    WDEV void leave_rows(int cmp, int dpos) {
+        if (!progress) return;
+        publish((uint32_t)((dpos / sc->t.bch[cmp]) / sc->t.vs[cmp]));   // block rows below dpos's are complete: so are the MCU rows below its
     }
 
     // Both AC block decoders keep the serial part to one step per CODE: what a code places goes into the block image in LDS
@@ -214,8 +277,15 @@ struct ProgDecWave : HuffDecWave {
         return rc;
     }
 
-    WDEV void run_scan(const ProgDecScan* scan, HuffDecShared* shared, HuffDecRow* rows_arena) {
+    WDEV void run_scan(const ProgDecScan* scan, HuffDecShared* shared, HuffDecRow* rows_arena, const ProgDeps* follow = nullptr, uint32_t* rows_done = nullptr,
+                       int index = 0) {
         sc = scan; img = &scan->t; sh = shared; status = 0;
+        deps = follow; progress = rows_done; self = index; ready = 0;
+        if (progress) {   // a scan that follows none never waits
+            bool any = false;
+            for (int i = 0; i < 4; ++i) any = any || deps->dep[i] >= 0;
+            if (!any) ready = 0x7fffffffu;
+        }
         LANES(l) {
             for (int i = l; i < 512; i += 64) sh->lut_ac[0][i] = img->lut[2][i];
             for (int i = l; i < 2 * 256; i += 64) {
@@ -238,6 +308,7 @@ struct ProgDecWave : HuffDecWave {
         const bool dc = scan->to == 0;
         const int sal = scan->sal;
         int cmp = scan->cmp[0], csc = 0, sub = 0, dpos = 0, mcu = 0;
+        int row_end = 0;   // one-component scans: the block position at which the current block row ends (0: not entered yet)
         bool do_row = scan->want_rows != 0;
         for (;;) {   // one restart interval per iteration
             lastdc[0] = lastdc[1] = lastdc[2] = lastdc[3] = 0;
@@ -251,6 +322,7 @@ struct ProgDecWave : HuffDecWave {
                         LANES(l) if (l == 0) { rows[r].bitpos = bp; for (int c = 0; c < 4; ++c) rows[r].last_dc[c] = (int16_t)lastdc[c]; rows[r].aux = 0; }
                         do_row = false;
                     }
+                    await((uint32_t)(mcu / mcuh));
                     int16_t* dst = img->blocks[cmp] + (int64_t)dpos * 64 + 49;
                     if (scan->sah == 0) {
                         uint32_t n = 0;
@@ -279,7 +351,11 @@ struct ProgDecWave : HuffDecWave {
                         else if (hs > 1) dpos = (int)(m * (uint32_t)scan->mbs[cmp] + sb);
                         else dpos = mcu;
                     }
-                    if (scan->want_rows && mcu % mcuh == 0 && old_mcu != mcu) do_row = true;
+                    if (old_mcu != mcu && mcu % mcuh == 0) {
+                        if (scan->want_rows) do_row = true;
+                        LSYNC();
+                        publish((uint32_t)(mcu / mcuh));
+                    }
                     if (ucond(bitpos > img->scan_len * 8u)) { sta = -1; break; }
                 }
             } else if (dc) {                       // DC scan of one component
@@ -290,6 +366,7 @@ struct ProgDecWave : HuffDecWave {
                         LANES(l) if (l == 0) { rows[r].bitpos = bp; for (int c = 0; c < 4; ++c) rows[r].last_dc[c] = (int16_t)lastdc[c]; rows[r].aux = 0; }
                         do_row = false;
                     }
+                    if (dpos >= row_end) enter_row(cmp, dpos, &row_end);
                     int16_t* dst = img->blocks[cmp] + (int64_t)dpos * 64 + 49;
                     if (scan->sah == 0) {
                         uint32_t n = 0;
@@ -304,14 +381,17 @@ struct ProgDecWave : HuffDecWave {
                     }
                     sta = next_noninterleaved(cmp, &dpos, &rstw);
                     if (scan->want_rows && cmp == 0 && dpos % img->bch[cmp] == 0) do_row = true;
+                    if (dpos >= row_end) { LSYNC(); leave_rows(cmp, dpos); }
                     if (ucond(bitpos > img->scan_len * 8u)) { sta = -1; break; }
                 }
             } else {                               // AC scan of one component
                 while (sta == 0) {
+                    if (dpos >= row_end) enter_row(cmp, dpos, &row_end);
                     const int rc = scan->sah == 0 ? ac_first_block(cmp, dpos) : ac_refine_block(cmp, dpos);
                     if (rc < 0) { sta = -1; break; }
                     if (scan->sah == 0) sta = skip_run(cmp, &dpos, &rstw);
                     if (sta == 0) sta = next_noninterleaved(cmp, &dpos, &rstw);
+                    if (dpos >= row_end) leave_rows(cmp, dpos);   // (flush_block has ordered the lanes' stores)
                     if (ucond(bitpos > img->scan_len * 8u)) { sta = -1; break; }
                 }
                 // a run that reaches past the end of its restart interval or scan (the reference tolerates it in the refinement
@@ -325,6 +405,7 @@ struct ProgDecWave : HuffDecWave {
             if (sta == 2) break;
         }
         if (!status && uni(bitpos) != img->scan_len * 8u) status = 2;   // bytes left over, or missing
+        publish(0x7fffffffu);   // whatever happened: nobody waits for this scan any more
         const uint32_t bp = uni(bitpos);
         HuffDecRow* fin = rows_arena + scan->result_off;
         LANES(l) if (l == 0) {
@@ -334,5 +415,52 @@ struct ProgDecWave : HuffDecWave {
         }
     }
 };
+
+// host side: which scans of the launch (already in launch order: dependency level by dependency level) each scan follows.
+// Scan j follows an earlier scan i of the same file (same frame) when they share a component and their bands meet; of those,
+// the ones another of them follows in turn are implied.  false: some scan follows more than four others (no pipelining then).
+// `order[k]` = the scan's place in its file's scan sequence (the caller's order), so that "earlier" means what it means in the file.
+inline bool prog_scan_deps(const ProgDecScan* scans, const int* order, int n, ProgDeps* out) {
+    auto meets = [&](int i, int j) {
+        const ProgDecScan &a = scans[i], &b = scans[j];
+        if (a.t.blocks[0] != b.t.blocks[0]) return false;
+        if (a.from > b.to || b.from > a.to) return false;
+        for (int x = 0; x < a.cmpc; ++x)
+            for (int y = 0; y < b.cmpc; ++y)
+                if (a.cmp[x] == b.cmp[y]) return true;
+        return false;
+    };
+    // the scans of one file are few (ten for libjpeg's script): bucket the launch by frame, compare inside the buckets
+    struct Ref { const void* key; int idx; };
+    std::vector<Ref> refs((size_t)n);
+    for (int i = 0; i < n; ++i) refs[(size_t)i] = Ref{(const void*)scans[i].t.blocks[0], i};
+    std::stable_sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.key < b.key; });
+    bool ok = true;
+    for (int b0 = 0; b0 < n && ok;) {
+        int b1 = b0;
+        while (b1 < n && refs[b1].key == refs[b0].key) ++b1;
+        for (int x = b0; x < b1 && ok; ++x) {
+            const int j = refs[x].idx;
+            int cand[64], nc = 0;
+            for (int y = b0; y < b1; ++y) {
+                const int i = refs[y].idx;
+                if (i != j && order[i] < order[j] && meets(i, j)) { if (nc < 64) cand[nc++] = i; else ok = false; }
+            }
+            int nd = 0;
+            for (int d = 0; d < 4; ++d) out[j].dep[d] = -1;
+            for (int u = 0; u < nc && ok; ++u) {
+                bool implied = false;
+                for (int v = 0; v < nc; ++v)
+                    if (v != u && order[cand[u]] < order[cand[v]] && meets(cand[u], cand[v])) { implied = true; break; }
+                if (implied) continue;
+                if (cand[u] >= j) ok = false;          // a scan may only wait for scans in front of it in the launch
+                else if (nd < 4) out[j].dep[nd++] = cand[u];
+                else ok = false;
+            }
+        }
+        b0 = b1;
+    }
+    return ok;
+}
 
 }  // namespace lephuff

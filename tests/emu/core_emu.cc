@@ -228,6 +228,34 @@ extern "C" int emu_huffman_progressive_decode(const lep_huffprogdec_scan* scans,
     return 0;
 }
 
+// ... as ONE pipelined launch (all levels; a scan follows the scans of its file in front of it MCU row by MCU row): the launch
+// order, the dependencies the host works out (returned through deps_out[nscan][4], indices into the caller's array) and the
+// waiting / publishing code, run one scan after the other in launch order.  waits_out: how often a scan found the scans in front
+// of it not far enough (0 here by construction; the code path that polls is the GPU's).
+extern "C" int emu_huffman_progressive_decode_pipelined(const lep_huffprogdec_scan* scans, int nscan, lep_huffdec_row* rows, int32_t* deps_out) {
+    static lephuff::HuffDecShared sh;
+    std::vector<lephuff::ProgDecScan> sorted;
+    std::vector<int> order;
+    for (int lv = 0; lv < 64; ++lv)
+        for (int i = 0; i < nscan; ++i)
+            if (scans[i].level == lv) { sorted.push_back(*reinterpret_cast<const lephuff::ProgDecScan*>(scans + i)); order.push_back(i); }
+    if ((int)sorted.size() != nscan) return -1;
+    std::vector<lephuff::ProgDeps> deps((size_t)nscan);
+    if (!lephuff::prog_scan_deps(sorted.data(), order.data(), nscan, deps.data())) return -2;
+    std::vector<uint32_t> progress((size_t)nscan, 0u);
+    for (int k = 0; k < nscan; ++k) {
+        for (int d = 0; d < 4; ++d) {
+            const int j = deps[(size_t)k].dep[d];
+            if (j >= k) return -3;                                  // a scan may only follow scans in front of it in the launch
+            deps_out[order[(size_t)k] * 4 + d] = j < 0 ? -1 : order[(size_t)j];
+        }
+        lephuff::ProgDecWave w;
+        w.run_scan(&sorted[(size_t)k], &sh, reinterpret_cast<lephuff::HuffDecRow*>(rows), &deps[(size_t)k], progress.data(), k);
+        if (progress[(size_t)k] != 0x7fffffffu) return -4;          // every scan says when it is done, whatever happened to it
+    }
+    return 0;
+}
+
 // several wavefronts per image (lep_huffdec_par.h): the three passes run one wave after the other
 #include "../../lepton_amd/csrc/lep_huffdec_par.h"
 extern "C" int emu_huffman_decode_image_parallel(const lep_huffdec_image* img, lep_huffdec_row* rows, int nsub, uint32_t* sync_blocks) {

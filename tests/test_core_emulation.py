@@ -774,9 +774,10 @@ def test_gpu_progressive_scan_encoder_on_random_files(emu):
     assert done == 14
 
 
-def _progressive_decode_on_the_emulation(emu, jpg):
-    """progressive scans of `jpg` through lep_huffprogdec.h (lane-loop emulation).  Returns (handle, frame planes, status):
-    status None = not eligible, -1 = the kernels found it irregular, 0 = decoded and finished"""
+def _progressive_decode_on_the_emulation(emu, jpg, pipelined=False, deps_out=None):
+    """progressive scans of `jpg` through lep_huffprogdec.h (lane-loop emulation), level by level or as the one pipelined launch
+    small batches take.  Returns (handle, frame planes, status): status None = not eligible, -1 = the kernels found it irregular,
+    0 = decoded and finished"""
     from lepton_amd import abi
 
     L = abi.lib()
@@ -806,8 +807,16 @@ def _progressive_decode_on_the_emulation(emu, jpg):
         for c in range(d.ncomp):
             scans[i].t.blocks[c] = C.addressof(planes[c])
     rows = (abi.HuffDecRow * (need.value + 4))()
-    emu.emu_huffman_progressive_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    assert emu.emu_huffman_progressive_decode(scans, nscan.value, rows) == 0
+    if pipelined:
+        deps = (C.c_int32 * (4 * nscan.value))()
+        emu.emu_huffman_progressive_decode_pipelined.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        assert emu.emu_huffman_progressive_decode_pipelined(scans, nscan.value, rows, deps) == 0
+        if deps_out is not None:
+            deps_out.extend([sorted(x for x in deps[4 * i: 4 * i + 4] if x >= 0), tuple(scans[i].cmp[k] for k in range(scans[i].cmpc)), scans[i].from_, scans[i].to, scans[i].sah]
+                            for i in range(nscan.value))
+    else:
+        emu.emu_huffman_progressive_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        assert emu.emu_huffman_progressive_decode(scans, nscan.value, rows) == 0
     rc = L.lep_jpeg_finish_gpu_progressive(h, scans, nscan.value, rows)
     return h, planes, (0 if rc == 0 else -1)
 
@@ -837,14 +846,38 @@ def _same_as_the_host_parser(jpg, h, planes):
     assert got == host.write_lep(fake), "container (hand-offs / pad bit / restart counts) differs from the host parser's"
 
 
+def test_progressive_scans_follow_the_right_scans(emu):
+    """lep_huffprogdec.h prog_scan_deps: in the one pipelined launch a scan waits for exactly the scans of its file whose
+    coefficients it reads or overwrites -- same component, bands that meet, earlier in the file -- minus those another of them
+    already waits for.  libjpeg's default script (ten scans): the luma refinement follows BOTH first-stage luma scans, the last
+    luma scan follows only the refinement in front of it, the DC refinement follows the DC scan, chroma follows chroma"""
+    from lepton_amd import abi, corpus
+
+    jpg = corpus.synth_jpeg(160, 120, 3, progressive=True)
+    deps = []
+    h, planes, st = _progressive_decode_on_the_emulation(emu, jpg, pipelined=True, deps_out=deps)
+    assert st == 0
+    _same_as_the_host_parser(jpg, h, planes)
+    abi.lib().lep_jpeg_close(h)
+    assert len(deps) == 10
+    follows = [d[0] for d in deps]
+    assert follows[:5] == [[], [], [], [], []]                  # first-stage scans: the frame starts zeroed
+    for j, (dj, cmpj, fj, tj, sahj) in enumerate(deps):          # the general rule, checked against a direct statement of it
+        want = [i for i in range(j) if set(deps[i][1]) & set(cmpj) and not (deps[i][2] > tj or fj > deps[i][3])]
+        want = [i for i in want if not any(i < k and set(deps[i][1]) & set(deps[k][1]) and not (deps[i][2] > deps[k][3] or deps[k][2] > deps[i][3]) for k in want)]
+        assert dj == want, (j, dj, want)
+    assert follows[5] == [1, 4] and follows[6] == [0] and follows[9] == [5]
+
+
+@pytest.mark.parametrize("pipelined", [False, True], ids=["level_by_level", "one_pipelined_launch"])
 @pytest.mark.parametrize("name", [n for n in golden_cases() if n.startswith("prog_")])
-def test_gpu_progressive_scan_decoder_on_cpu_equals_the_host_parser(emu, name):
+def test_gpu_progressive_scan_decoder_on_cpu_equals_the_host_parser(emu, name, pipelined):
     """lep_huffprogdec.h (DC / AC first-stage and refinement scans, end-of-band runs, correction bits, dependency levels) as a
     lane-loop emulation: the frame and the .lep header equal the host parser's; truncated files are left to the host"""
     from lepton_amd import abi
 
     jpg, _ = golden(name)
-    h, planes, st = _progressive_decode_on_the_emulation(emu, jpg)
+    h, planes, st = _progressive_decode_on_the_emulation(emu, jpg, pipelined=pipelined)
     if "truncated" in name:
         assert st is None
         return

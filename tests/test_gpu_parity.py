@@ -569,3 +569,37 @@ def test_gpu_split_phase_encoder_without_room_for_its_scratch(monkeypatch):
     wants = [ob.oracle_encode(im.desc, p)[0] for im, p in zip(imgs, plans)]
     assert codec.encode(imgs, plans) == wants
     assert b"lep_encode_v3" in codec._L.lep_gpu_last_kernel_name(codec.handle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipelined", ["1", "0"], ids=["one_pipelined_launch", "level_by_level"])
+def test_gpu_progressive_scans_pipelined_or_level_by_level(monkeypatch, pipelined):
+    """lep_huffprogdec.h both ways on the MI355X: all dependency levels of the progressive files of a batch as ONE launch in which
+    a scan follows the scans of its file MCU row by MCU row (small launches), or a launch per level (LEP_HUFFPROG_PIPELINE=0 /
+    large launches): the same .lep bytes as the reference, damaged files included (a scan that gives up still tells the scans
+    waiting for it that it is done)"""
+    monkeypatch.setenv("LEP_HUFFPROG_PIPELINE", pipelined)
+    codec = GpuCodec(0)
+    names = [n for n in golden_cases() if n.startswith("prog_")]
+    jpgs = [golden(n)[0] for n in names]
+    leps = [golden(n)[1] for n in names]
+    big = [corpus.synth_jpeg(1920, 1080, 94, progressive=True), corpus.synth_jpeg(640, 480, 95, progressive=True, subsampling="4:4:4", quality=97),
+           corpus.synth_jpeg(333, 241, 97, progressive=True, subsampling="4:2:2")]
+    want_big = [codec.compress(j) for j in big]
+    for _ in range(3):   # (a race between a scan and the one it follows would not show every time)
+        got, st, _ = codec.compress_batch(jpgs + big * 4)
+        assert st == [0] * (len(names) + 12) and got == leps + want_big * 4
+    bad = []
+    for k in (3, 5, 7):   # damage inside different scans: early ones are followed by others
+        b = bytearray(big[0]); b[len(b) * k // 9] ^= 0x24
+        bad.append(bytes(b))
+    want = []
+    for b in bad:
+        try:
+            want.append((0, codec.compress(b)))
+        except LeptonError as e:
+            want.append((e.code, None))
+    got2, st2, _ = codec.compress_batch(bad + big)
+    assert st2[3:] == [0, 0, 0] and got2[3:] == want_big
+    for (code, w), s, g_ in zip(want, st2[:3], got2[:3]):
+        assert (s, g_) == (code, w) or (code == 41 and s == 0)   # per-file compress also runs the round-trip check
