@@ -55,6 +55,8 @@ struct ProgDecWave : HuffDecWave {
     uint32_t* progress = nullptr;     // [scan of the launch]: MCU rows completed
     int self = 0;
     uint32_t ready = 0;               // MCU rows every scan this one follows is known to have completed
+    uint32_t polls = 0;
+    static constexpr uint32_t kMaxPolls = 4u << 20;   // x ~2 us of sleep: about eight seconds
 
     WDEV void publish(uint32_t rows_done) {
         if (!progress) return;
@@ -83,6 +85,9 @@ struct ProgDecWave : HuffDecWave {
             ready = m;
             if (row < ready) return;
 #if LEP_ON_GPU
+            // (the safety net under the argument above: a scan that has polled for seconds gives up -- status 4, the file goes
+            // to the host parser like any irregular one -- instead of holding its wave slot for ever)
+            if (++polls > kMaxPolls) { status = 4; ready = 0x7fffffffu; return; }
             __builtin_amdgcn_s_sleep(64);
 #else
             return;   // (the emulation runs the scans one after the other, in launch order: never here)
@@ -323,6 +328,7 @@ struct ProgDecWave : HuffDecWave {
                         do_row = false;
                     }
                     await((uint32_t)(mcu / mcuh));
+                    if (status) { sta = -1; break; }
                     int16_t* dst = img->blocks[cmp] + (int64_t)dpos * 64 + 49;
                     if (scan->sah == 0) {
                         uint32_t n = 0;
@@ -366,7 +372,7 @@ struct ProgDecWave : HuffDecWave {
                         LANES(l) if (l == 0) { rows[r].bitpos = bp; for (int c = 0; c < 4; ++c) rows[r].last_dc[c] = (int16_t)lastdc[c]; rows[r].aux = 0; }
                         do_row = false;
                     }
-                    if (dpos >= row_end) enter_row(cmp, dpos, &row_end);
+                    if (dpos >= row_end) { enter_row(cmp, dpos, &row_end); if (status) { sta = -1; break; } }
                     int16_t* dst = img->blocks[cmp] + (int64_t)dpos * 64 + 49;
                     if (scan->sah == 0) {
                         uint32_t n = 0;
@@ -386,7 +392,7 @@ struct ProgDecWave : HuffDecWave {
                 }
             } else {                               // AC scan of one component
                 while (sta == 0) {
-                    if (dpos >= row_end) enter_row(cmp, dpos, &row_end);
+                    if (dpos >= row_end) { enter_row(cmp, dpos, &row_end); if (status) { sta = -1; break; } }
                     const int rc = scan->sah == 0 ? ac_first_block(cmp, dpos) : ac_refine_block(cmp, dpos);
                     if (rc < 0) { sta = -1; break; }
                     if (scan->sah == 0) sta = skip_run(cmp, &dpos, &rstw);
@@ -398,7 +404,7 @@ struct ProgDecWave : HuffDecWave {
                 // stage and complains in the first): not canonical either way
                 if (sta > 0 && eobrun > 0) sta = -1;
             }
-            if (sta == -1) { status = 1; break; }
+            if (sta == -1) { if (!status) status = 1; break; }
             const int got = unpad(padbit == -1 ? 255 : padbit);
             if (padbit == -1) padbit = (int8_t)got;
             else if (padbit != got) { status = 3; break; }
