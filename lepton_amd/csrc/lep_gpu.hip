@@ -274,14 +274,16 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_progressive_encode_kernel(c
 __global__ __launch_bounds__(64, 8) void lep_huffman_progressive_decode_kernel(const lephuff::ProgDecScan* __restrict__ scans, lephuff::HuffDecRow* rows) {
     __shared__ lephuff::HuffDecShared sh;
     lephuff::ProgDecWave w;
-    w.run_scan(scans + blockIdx.x, &sh, rows);
+    w.run_scan<false>(scans + blockIdx.x, &sh, rows);
 }
 // ... all levels in ONE launch: a scan waits, MCU row by MCU row, for the scans of its file it follows (lep_huffprogdec.h ProgDeps)
-__global__ __launch_bounds__(64, 8) void lep_huffman_progressive_pipelined_kernel(const lephuff::ProgDecScan* __restrict__ scans, lephuff::HuffDecRow* rows,
+// (128 VGPRs: at 64 the waiting code's spills trip a register-pair alignment check in this compiler's backend; a launch of this
+// kind is small, what it needs is a short chain)
+__global__ __launch_bounds__(64, 4) void lep_huffman_progressive_pipelined_kernel(const lephuff::ProgDecScan* __restrict__ scans, lephuff::HuffDecRow* rows,
                                                                                  const lephuff::ProgDeps* __restrict__ deps, uint32_t* progress) {
     __shared__ lephuff::HuffDecShared sh;
     lephuff::ProgDecWave w;
-    w.run_scan(scans + blockIdx.x, &sh, rows, deps + blockIdx.x, progress, (int)blockIdx.x);
+    w.run_scan<true>(scans + blockIdx.x, &sh, rows, deps + blockIdx.x, progress, (int)blockIdx.x);
 }
 
 // JPEG Huffman scan decode: one wavefront per image (lep_huffdec.h)

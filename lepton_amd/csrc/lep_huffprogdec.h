@@ -55,7 +55,6 @@ struct ProgDecWave : HuffDecWave {
     uint32_t* progress = nullptr;     // [scan of the launch]: MCU rows completed
     int self = 0;
     uint32_t ready = 0;               // MCU rows every scan this one follows is known to have completed
-    uint32_t polls = 0;
     static constexpr uint32_t kMaxPolls = 4u << 20;   // x ~2 us of sleep: about eight seconds
 
     WDEV void publish(uint32_t rows_done) {
@@ -70,7 +69,7 @@ struct ProgDecWave : HuffDecWave {
     // before the first block of MCU row `row` is touched
     WDEV void await(uint32_t row) {
         if (!progress || row < ready) return;
-        for (;;) {
+        for (uint32_t polls = 0;;) {
             uint32_t m = 0x7fffffffu;
             for (int i = 0; i < 4; ++i) {
                 const int d = deps->dep[i];
@@ -282,11 +281,13 @@ struct ProgDecWave : HuffDecWave {
         return rc;
     }
 
+    // PIPE: compiled with the waiting / publishing code (the level-by-level kernel is compiled without: it is held to 64 VGPRs)
+    template <bool PIPE = false>
     WDEV void run_scan(const ProgDecScan* scan, HuffDecShared* shared, HuffDecRow* rows_arena, const ProgDeps* follow = nullptr, uint32_t* rows_done = nullptr,
                        int index = 0) {
         sc = scan; img = &scan->t; sh = shared; status = 0;
-        deps = follow; progress = rows_done; self = index; ready = 0;
-        if (progress) {   // a scan that follows none never waits
+        deps = follow; progress = PIPE ? rows_done : nullptr; self = index; ready = 0;
+        if (PIPE && progress) {   // a scan that follows none never waits
             bool any = false;
             for (int i = 0; i < 4; ++i) any = any || deps->dep[i] >= 0;
             if (!any) ready = 0x7fffffffu;
@@ -327,8 +328,7 @@ struct ProgDecWave : HuffDecWave {
                         LANES(l) if (l == 0) { rows[r].bitpos = bp; for (int c = 0; c < 4; ++c) rows[r].last_dc[c] = (int16_t)lastdc[c]; rows[r].aux = 0; }
                         do_row = false;
                     }
-                    await((uint32_t)(mcu / mcuh));
-                    if (status) { sta = -1; break; }
+                    if (PIPE) { await((uint32_t)(mcu / mcuh)); if (status) { sta = -1; break; } }
                     int16_t* dst = img->blocks[cmp] + (int64_t)dpos * 64 + 49;
                     if (scan->sah == 0) {
                         uint32_t n = 0;
@@ -359,8 +359,7 @@ struct ProgDecWave : HuffDecWave {
                     }
                     if (old_mcu != mcu && mcu % mcuh == 0) {
                         if (scan->want_rows) do_row = true;
-                        LSYNC();
-                        publish((uint32_t)(mcu / mcuh));
+                        if (PIPE) { LSYNC(); publish((uint32_t)(mcu / mcuh)); }
                     }
                     if (ucond(bitpos > img->scan_len * 8u)) { sta = -1; break; }
                 }
@@ -372,7 +371,7 @@ struct ProgDecWave : HuffDecWave {
                         LANES(l) if (l == 0) { rows[r].bitpos = bp; for (int c = 0; c < 4; ++c) rows[r].last_dc[c] = (int16_t)lastdc[c]; rows[r].aux = 0; }
                         do_row = false;
                     }
-                    if (dpos >= row_end) { enter_row(cmp, dpos, &row_end); if (status) { sta = -1; break; } }
+                    if (PIPE && dpos >= row_end) { enter_row(cmp, dpos, &row_end); if (status) { sta = -1; break; } }
                     int16_t* dst = img->blocks[cmp] + (int64_t)dpos * 64 + 49;
                     if (scan->sah == 0) {
                         uint32_t n = 0;
@@ -387,31 +386,31 @@ struct ProgDecWave : HuffDecWave {
                     }
                     sta = next_noninterleaved(cmp, &dpos, &rstw);
                     if (scan->want_rows && cmp == 0 && dpos % img->bch[cmp] == 0) do_row = true;
-                    if (dpos >= row_end) { LSYNC(); leave_rows(cmp, dpos); }
+                    if (PIPE && dpos >= row_end) { LSYNC(); leave_rows(cmp, dpos); }
                     if (ucond(bitpos > img->scan_len * 8u)) { sta = -1; break; }
                 }
             } else {                               // AC scan of one component
                 while (sta == 0) {
-                    if (dpos >= row_end) { enter_row(cmp, dpos, &row_end); if (status) { sta = -1; break; } }
+                    if (PIPE && dpos >= row_end) { enter_row(cmp, dpos, &row_end); if (status) { sta = -1; break; } }
                     const int rc = scan->sah == 0 ? ac_first_block(cmp, dpos) : ac_refine_block(cmp, dpos);
                     if (rc < 0) { sta = -1; break; }
                     if (scan->sah == 0) sta = skip_run(cmp, &dpos, &rstw);
                     if (sta == 0) sta = next_noninterleaved(cmp, &dpos, &rstw);
-                    if (dpos >= row_end) leave_rows(cmp, dpos);   // (flush_block has ordered the lanes' stores)
+                    if (PIPE && dpos >= row_end) leave_rows(cmp, dpos);   // (flush_block has ordered the lanes' stores)
                     if (ucond(bitpos > img->scan_len * 8u)) { sta = -1; break; }
                 }
                 // a run that reaches past the end of its restart interval or scan (the reference tolerates it in the refinement
                 // stage and complains in the first): not canonical either way
                 if (sta > 0 && eobrun > 0) sta = -1;
             }
-            if (sta == -1) { if (!status) status = 1; break; }
+            if (sta == -1) { if (!PIPE || !status) status = 1; break; }
             const int got = unpad(padbit == -1 ? 255 : padbit);
             if (padbit == -1) padbit = (int8_t)got;
             else if (padbit != got) { status = 3; break; }
             if (sta == 2) break;
         }
         if (!status && uni(bitpos) != img->scan_len * 8u) status = 2;   // bytes left over, or missing
-        publish(0x7fffffffu);   // whatever happened: nobody waits for this scan any more
+        if (PIPE) publish(0x7fffffffu);   // whatever happened: nobody waits for this scan any more
         const uint32_t bp = uni(bitpos);
         HuffDecRow* fin = rows_arena + scan->result_off;
         LANES(l) if (l == 0) {

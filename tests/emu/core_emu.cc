@@ -250,7 +250,7 @@ extern "C" int emu_huffman_progressive_decode_pipelined(const lep_huffprogdec_sc
             deps_out[order[(size_t)k] * 4 + d] = j < 0 ? -1 : order[(size_t)j];
         }
         lephuff::ProgDecWave w;
-        w.run_scan(&sorted[(size_t)k], &sh, reinterpret_cast<lephuff::HuffDecRow*>(rows), &deps[(size_t)k], progress.data(), k);
+        w.run_scan<true>(&sorted[(size_t)k], &sh, reinterpret_cast<lephuff::HuffDecRow*>(rows), &deps[(size_t)k], progress.data(), k);
         if (progress[(size_t)k] != 0x7fffffffu) return -4;          // every scan says when it is done, whatever happened to it
     }
     return 0;
