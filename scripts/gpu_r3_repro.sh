@@ -2,7 +2,10 @@
 set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/r3repro; mkdir -p $OUT
-A="--mixed-images 0 --no-cpu-baseline --steps 1"
-timeout 900 /opt/rocm/bin/rocgdb -batch -ex "handle SIGUSR1 nostop noprint" -ex run -ex "bt 40" -ex "info sharedlibrary lepton" --args python bench.py $A > $OUT/b.gdb 2>&1
-grep "rank 0" $OUT/b.gdb | cut -c1-200
-grep -A50 "received signal" $OUT/b.gdb | cut -c1-260 | head -80
+for seq in c1080p mixed,c1080p e2e,c1080p; do
+  timeout 400 python scripts/repro_extras.py $seq > $OUT/seq_$seq.out 2> $OUT/seq_$seq.err; echo "$seq rc=$?"
+  grep "^c1080p" $OUT/seq_$seq.out | python -c "
+import sys, ast
+for l in sys.stdin:
+    d = ast.literal_eval(l[len('c1080p '):]); print('   c1080p', d['compress_MBps'], d['decompress_MBps'], d['seconds'])"
+done
