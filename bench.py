@@ -222,7 +222,9 @@ class HipDevice:
         self.L.lep_gpu_sync(self.g)
 
     def pipeline(self, jpgs, label, verify=False):
-        self.L.lep_gpu_trim(self.g)   # (as resident(): nothing cached from the phase before)
+        # (no lep_gpu_trim between the phases: giving the cached models and scratch back and taking smaller ones again made the 1080p
+        # figure HALF as fast -- 1485 -> 737 MB/s compress, MI355X -- the device heap hands out memory in smaller pieces after 100+ GB
+        # have come and gone; the library releases its caches by itself when an allocation fails)
         return pipeline_figure(self.codec, jpgs, label, verify=verify)
 
     def resident(self, uniq, images, steps, warmup, barrier, check_parity=True, with_latency=False):
@@ -240,7 +242,6 @@ class HipDevice:
         jpeg_bytes = sum(len(uniq[i]) for i in order)
         nimg = len(order)
         allocs = []
-        L.lep_gpu_trim(g)   # every figure starts from the same state: nothing cached from the phase before
         try:
             return self._resident(L, g, codec, uniq, imgs, plans, order, nuniq, jpeg_bytes, nimg, allocs, steps, warmup, barrier, check_parity, with_latency)
         finally:

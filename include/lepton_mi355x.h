@@ -223,7 +223,8 @@ int lep_gpu_selftest(lep_gpu *g);
 /* Gives back the device memory the object caches between launches (per-segment models, neighbour rings, the split-phase
  * encoder's scratch: ~140 MB per 4K image of the largest launch so far).  The next launch re-acquires what it needs.  The
  * library does this itself before it reports an allocation failure; a caller that keeps large buffers of its own beside the
- * codec calls it between phases.  Waits for the device. */
+ * codec calls it between phases.  Waits for the device.  Not for routine use: memory taken again after 100+ GB were given back
+ * was measured to serve the kernels slower (bench.py's 1080p pipeline figure: half the rate after a trim). */
 int lep_gpu_trim(lep_gpu *g);
 /* Profiling builds (-DLEP_PROF) only: per-phase shader-clock totals [64 segments][32 slots] of the last decoder launch. */
 int lep_gpu_debug_prof(lep_gpu *g, uint64_t *out);
