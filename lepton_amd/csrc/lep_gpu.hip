@@ -341,6 +341,7 @@ struct lep_gpu {
     int huffprog_pipeline_max = 16384;  // LEP_HUFFPROG_PIPELINE_MAX: scans per launch up to which the levels go out as one pipelined launch (measured to 10240:
                                         // 1024 4K files, 798 -> 938 MB/s; workgroups start in index order, so a scan's predecessors are always running or done)
     int enc5_waves = 2;      // LEP_ENC5_WAVES: wavefronts per segment in the split-phase walks (1 | 2)
+    int enc5_gather_wgs = 0; // LEP_ENC5_GATHER_WGS: resident gather workgroups per CU held to this (through the LDS a launch asks for)
     int enc5_fold_apart = 0; // LEP_ENC5_FOLD_APART: the fold launches one after the other, a launch per kind of chain (for the profiler)
     size_t enc5_scratch_max = ~(size_t)0;   // LEP_ENC5_SCRATCH_MAX (bytes): a launch that needs more takes the single-kernel encoder (tests: the out-of-memory path)
     hipEvent_t ev_stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries of the last split-phase launch
@@ -458,7 +459,8 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     HIPCHK(g, hipEventRecord(g->ev_stage[0], st));
     const bool two = g->enc5_waves == 2;
     auto walk = [&](int mode, uint8_t* entries, uint16_t* binlist) {
-        const size_t lds = lep5::walk_lds_bytes(mode);
+        size_t lds = lep5::walk_lds_bytes(mode);
+        if (mode == lep5::kGather && g->enc5_gather_wgs > 0) lds = std::max(lds, (size_t)(160 * 1024 / g->enc5_gather_wgs) & ~(size_t)255);   // (measurement aid: fewer resident workgroups)
 #define LEP_WALK(MODE, NW) hipLaunchKernelGGL((lep_enc5_walk_kernel<MODE, NW>), dim3(nseg), dim3(64 * NW), lds, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, entries, binlist, counts)
         if (mode == lep5::kCount) { if (two) LEP_WALK(lep5::kCount, 2); else LEP_WALK(lep5::kCount, 1); }
         else if (mode == lep5::kEmit) { if (two) LEP_WALK(lep5::kEmit, 2); else LEP_WALK(lep5::kEmit, 1); }
@@ -661,6 +663,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_HUFFPROG_PIPELINE_MAX")) g->huffprog_pipeline_max = atoi(e);
     if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
+    if (const char* e = getenv("LEP_ENC5_GATHER_WGS")) g->enc5_gather_wgs = atoi(e);
     if (const char* e = getenv("LEP_ENC5_SCRATCH_MAX")) g->enc5_scratch_max = (size_t)strtoull(e, nullptr, 10);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
