@@ -514,8 +514,9 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
 //            from the same places and appends the block's bins.  count only adds the units up (LDS atomics: no order needed).
 enum { kCount = 0, kEmit = 1, kGather = 2 };
 
-// (members in the order the passes need them: a launch takes the front of the block its pass uses -- gather 10 KB, count 15 KB,
-// emit all 26 KB -- and the resident workgroups per CU follow from that)
+// (members in the order the passes need them: a launch takes the front of the block its pass uses -- gather 18 KB (its staging
+// block lies over the cursors the other two passes keep there), count 15 KB, emit all 26 KB -- and the resident workgroups per CU
+// follow from that)
 struct Walk5Shared {
     uint32_t cur[32 * 65];                 // transposed tile: dword i (coefficients 2i, 2i + 1 in aligned order) of lane c at [i * 65 + c];
                                            // column 64 = the block left of lane 0 (the previous tile's last one)
@@ -524,14 +525,20 @@ struct Walk5Shared {
     uint8_t thr[64];                       // critical path costs a trip to HBM: they are staged when the component changes)
     uint16_t errx[2 * 64];                 // emit: the lanes' first refusal per half of the block (interior; edges and DC)
     uint32_t tcur[2 * 8];                  // emit / gather: threshold units already given out, per colour index / class lt
-    // ---- count and emit
-    uint32_t cursor[2 * kRows * kClasses]; // units already given out, per colour index / row / class (row 63 = threshold: count only)
-    // ---- emit
-    NSum ns[65];                           // neighbour summaries of the tile's blocks; [64] = the block left of lane 0
-    int32_t icos_x[64], icos_y[64];
-    uint32_t abv[32 * 65];                 // the tile of the row above
+    union {
+        // ---- gather: per wavefront, the 32 bins (one 64-byte sector of the bin list) every lane is filling: dword d of lane l at [d * 64 + l]
+        uint32_t stg[2][16 * 64];
+        struct {
+            // ---- count and emit
+            uint32_t cursor[2 * kRows * kClasses]; // units already given out, per colour index / row / class (row 63 = threshold: count only)
+            // ---- emit
+            NSum ns[65];                           // neighbour summaries of the tile's blocks; [64] = the block left of lane 0
+            int32_t icos_x[64], icos_y[64];
+            uint32_t abv[32 * 65];                 // the tile of the row above
+        };
+    };
 };
-constexpr size_t kWalkLdsGather = offsetof(Walk5Shared, cursor), kWalkLdsCount = offsetof(Walk5Shared, ns);
+constexpr size_t kWalkLdsGather = offsetof(Walk5Shared, stg) + sizeof(uint32_t) * 2 * 16 * 64, kWalkLdsCount = offsetof(Walk5Shared, ns);
 constexpr size_t walk_lds_bytes(int mode) { return mode == 2 ? kWalkLdsGather : (mode == 0 ? kWalkLdsCount : sizeof(Walk5Shared)); }
 
 // The walk's LDS block.  On the GPU it is the kernel's dynamic LDS, named directly at every use: a pointer to it kept in the
@@ -555,6 +562,14 @@ template <class T> WDEV T gld(const T* p) { return *p; }
 template <class T> WDEV void gst(T* p, const T& v) { *p = v; }
 #endif
 
+WDEV void gst4(uint32_t* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {   // one 16-byte store (p: 16-byte aligned)
+#if LEP_ON_GPU
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    *(__attribute__((address_space(1))) u32x4*)(uintptr_t)p = u32x4{x, y, z, w};
+#else
+    p[0] = x; p[1] = y; p[2] = z; p[3] = w;
+#endif
+}
 WDEV NSum gld_ns(const NSum* p) {   // (a struct cannot be assigned through an address-space pointer: nine dwords)
     uint32_t w[sizeof(NSum) / 4];
     for (int i = 0; i < (int)(sizeof(NSum) / 4); ++i) w[i] = gld(reinterpret_cast<const uint32_t*>(p) + i);
@@ -826,13 +841,15 @@ struct Walk5 {
         LV(uint32_t, rnz0); LV(uint32_t, rnz1); LV(uint32_t, ren0); LV(uint32_t, ren1); LV(uint32_t, rdc0); LV(uint32_t, rdc1); LV(uint32_t, rdc2);
         if (MODE == kGather) {
             LANES(l) if (l < nb) {
-                if (kEdge) {   // the block's records, where bucket put them
-                    const uint32_t* pl = reinterpret_cast<const uint32_t*>(arena + place_base) + ord0 + l;
-                    const uint32_t nbl = plan_nblocks;
-                    const uint32_t p0 = gld(pl), p1 = gld(pl + nbl), p2 = gld(pl + 2 * (size_t)nbl), p3 = gld(pl + 3 * (size_t)nbl);
-                    const uint32_t* r1 = reinterpret_cast<const uint32_t*>(arena + nzs_base) + 2 * (size_t)p0;
-                    const uint32_t* r3 = reinterpret_cast<const uint32_t*>(arena + dcs_base) + 6 * (size_t)p3;
+                const uint32_t* pl = reinterpret_cast<const uint32_t*>(arena + place_base) + ord0 + l;   // the block's records, where bucket put them
+                const uint32_t nbl = plan_nblocks;
+                if (kInt) {    // (the six bins of the 7x7 count open the interior half's run)
+                    const uint32_t* r1 = reinterpret_cast<const uint32_t*>(arena + nzs_base) + 2 * (size_t)gld(pl);
                     L(rnz0) = gld(r1); L(rnz1) = gld(r1 + 1);
+                }
+                if (kEdge) {
+                    const uint32_t p1 = gld(pl + nbl), p2 = gld(pl + 2 * (size_t)nbl), p3 = gld(pl + 3 * (size_t)nbl);
+                    const uint32_t* r3 = reinterpret_cast<const uint32_t*>(arena + dcs_base) + 6 * (size_t)p3;
                     L(ren0) = gld(reinterpret_cast<const uint32_t*>(arena + ens_base[0]) + p1); L(ren1) = gld(reinterpret_cast<const uint32_t*>(arena + ens_base[1]) + p2);
                     L(rdc0) = gld(r3); L(rdc1) = gld(r3 + 1); L(rdc2) = gld(r3 + 2);
                     L(rdcp) = p3;
@@ -1024,29 +1041,29 @@ struct Walk5 {
         uint8_t* signs = MODE != kCount ? arena + sign_base[ci] + sign_pos[ci] : nullptr;
         uint32_t* U = MODE != kCount ? units() : nullptr;
         LV(uint32_t, bp);   // gather: next bin of this lane
-        LV(uint32_t, bacc); // gather: the bin at the even position before it, not stored yet
+        LV(uint32_t, bacc); // gather: where this lane stages its bins (see put_bin)
         LV(int, sp);        // next sign byte of this lane
         LV(int, left);
-        LANES(l) {
-            L(bp) = nbins + (uint32_t)L(bbase) + (kEdge || !L(act) ? 0u : 6u); L(bacc) = kNoBin;
+        LANES(l) {   // a block's bins: [7x7 count: 6][interior] -- the interior half's run -- [edges, DC] -- the other half's
+            L(bp) = nbins + (uint32_t)L(bbase) + (kInt || !L(act) ? 0u : 6u + (uint32_t)L(ibins));
+            L(bacc) = (uint32_t)l | ((L(bp) & 31u) << 8) | ((HALF == 2 ? 1u : 0u) << 16);
             L(sp) = L(sbase) + (kInt ? 0 : L(nz)); L(left) = L(nz);
         }
         // the number of non-zeros of the 7x7 interior (and the key word the sparse chains filter on)
-        if (MODE != kCount && kEdge) {
+        if (MODE == kEmit && kEdge) {
             LANES(l) if (L(act)) {
-                uint32_t* rec = reinterpret_cast<uint32_t*>(arena + nz_base) + 2 * (ord0 + l);
-                if (MODE == kEmit) {
-                    gst(rec, (uint32_t)L(nz));
-                    gst(reinterpret_cast<uint32_t*>(arena + key_base) + ord0 + l,
-                        (uint32_t)ci | ((uint32_t)L(nzctxbin) << 1) | ((uint32_t)L(eobx) << 5) | ((uint32_t)L(eoby) << 8) | ((((uint32_t)L(dc_e0) >> 23) & 15u) << 11));
-                } else {
-                    const uint32_t lo = L(rnz0), hi = L(rnz1);
-                    for (int i = 5; i >= 0; --i) {
-                        const int q = 5 - i;
-                        const uint32_t p = q < 4 ? (lo >> (8 * q)) & 255u : (hi >> (8 * (q - 4))) & 255u;
-                        put_bin(L(bp), L(bacc), p | ((((uint32_t)L(nz) >> i) & 1u) << 8));
-                    }
-                    if (!kInt) { flush_bin(L(bp), L(bacc)); L(bacc) = kNoBin; L(bp) += (uint32_t)L(ibins); }   // (the other half's run)
+                gst(reinterpret_cast<uint32_t*>(arena + nz_base) + 2 * (ord0 + l), (uint32_t)L(nz));
+                gst(reinterpret_cast<uint32_t*>(arena + key_base) + ord0 + l,
+                    (uint32_t)ci | ((uint32_t)L(nzctxbin) << 1) | ((uint32_t)L(eobx) << 5) | ((uint32_t)L(eoby) << 8) | ((((uint32_t)L(dc_e0) >> 23) & 15u) << 11));
+            }
+        }
+        if (MODE == kGather && kInt) {
+            LANES(l) if (L(act)) {
+                const uint32_t lo = L(rnz0), hi = L(rnz1);
+                for (int i = 5; i >= 0; --i) {
+                    const int q = 5 - i;
+                    const uint32_t p = q < 4 ? (lo >> (8 * q)) & 255u : (hi >> (8 * (q - 4))) & 255u;
+                    put_bin(L(bp), L(bacc), p | ((((uint32_t)L(nz) >> i) & 1u) << 8));
                 }
             }
         }
@@ -1252,17 +1269,32 @@ struct Walk5 {
         return TileTotals{nsig_tile, bins_tile};
     }
 
-    // gather: append one bin (probability | bit << 8) of this lane.  Bins leave in pairs: the one at an even position waits in
-    // `acc` for its neighbour (a lane's bins are consecutive, so both halves of an aligned dword are its own -- except where
-    // its run starts on an odd position or ends on an even one: those go out as 16-bit stores)
-    static constexpr uint32_t kNoBin = 0xffffffffu;
+    // gather: append one bin (probability | bit << 8) of this lane.  A lane's bins are consecutive in the segment's list; stored as
+    // they come -- four bytes at a time -- a 64-byte sector took sixteen stores spread over microseconds, and L2 wrote it back half
+    // filled again and again (35 write requests per block where 3 sectors are filled: the pass was bound by them).  So a lane
+    // stages the sector it is filling in LDS (32 bins, Walk5Shared::stg) and writes it when it is full -- four 16-byte stores back
+    // to back -- or, where its run starts or ends inside a sector that a neighbour shares, the part that is its own.
+    // `acc`: lane | first own bin of the current sector << 8 | which wavefront's staging block << 16.
     WDEV void put_bin(uint32_t& pos, uint32_t& acc, uint32_t v) {
-        if (pos & 1u) {
-            if (acc != kNoBin) gst(reinterpret_cast<uint32_t*>(bins + pos - 1), acc | (v << 16));
-            else gst(bins + pos, (uint16_t)v);
-            acc = kNoBin;
-        } else acc = v;
+        Walk5Shared& S = LEP5_WSH(this);
+        const uint32_t k = pos & 31u, l = acc & 63u;
+        reinterpret_cast<uint16_t*>(S.stg[(acc >> 16) & 1u])[(((k >> 1) * 64u + l) << 1) + (k & 1u)] = (uint16_t)v;
         ++pos;
+        if ((pos & 31u) == 0u) { write_staged(pos - 32u, (acc >> 8) & 63u, 32u, acc); acc &= ~0x3f00u; }
+    }
+    // bins [a, b) of the sector that starts at bin `first` leave the staging block
+    WDEV void write_staged(uint32_t first, uint32_t a, uint32_t b, uint32_t acc) {
+        Walk5Shared& S = LEP5_WSH(this);
+        const uint32_t* src = S.stg[(acc >> 16) & 1u] + (acc & 63u);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(bins + first);
+        if (a == 0u && b == 32u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gst4(dst + 4 * q, src[(4 * q) * 64], src[(4 * q + 1) * 64], src[(4 * q + 2) * 64], src[(4 * q + 3) * 64]);
+            return;
+        }
+        if (a & 1u) gst(bins + first + a, (uint16_t)(src[(a >> 1) * 64] >> 16));
+        for (uint32_t d = (a + 1u) >> 1; d < (b >> 1); ++d) gst(dst + d, src[d * 64]);
+        if ((b & 1u) && b > a) gst(bins + first + b - 1u, (uint16_t)src[(b >> 1) * 64]);
     }
     // the bins of one coefficient in stream order: exponent, sign, threshold bits, the residual bits below the threshold
     WDEV void gather_coef(uint32_t& pos, uint32_t& acc, const uint32_t* U, uint32_t e, uint32_t t_e, uint32_t at, uint32_t tat, int cf, uint32_t w0,
@@ -1284,7 +1316,11 @@ struct Walk5 {
             put_bin(pos, acc, ((w >> (8 * (q & 3))) & 255u) | (((e >> (nres - 1 - (q - nexp))) & 1u) << 8));
         }
     }
-    WDEV void flush_bin(uint32_t pos, uint32_t acc) { if ((pos & 1u) && acc != kNoBin) gst(bins + pos - 1, (uint16_t)acc); }
+    // the lane's run ends here: what it has staged of the sector it stands in
+    WDEV void flush_bin(uint32_t pos, uint32_t acc) {
+        const uint32_t k = pos & 31u, a = (acc >> 8) & 63u;
+        if (k > a) write_staged(pos - k, a, k, acc);
+    }
 
     // whole segment (lepton_codec.hh:41-100 row schedule, vp8_encoder.cc:239-445); ns: the segment's two-row NSum rings (zeroed)
     WDEV int run(const ImageDev* image, const SegDev& seg, NSum* ns, Walk5Shared* shared, const SegPlan5* pl, uint8_t* arena_base, uint16_t* bins_base,

@@ -153,10 +153,8 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
 // ---- the split-phase encoder (lep_enc5.h) -------------------------------------------------------------------------------------
 // walk: one or two wavefronts per segment (count / emit / gather share the code; NW = 2: lep_enc5.h Walk5); LDS: two transposed
 // coefficient tiles, the tile's entry payloads and ranks, the stream cursors
-// (gather with two wavefronts: held to 80 VGPRs -- six wavefronts per SIMD, twelve segments per CU instead of ten)
 template <int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MODE == lep5::kGather && NW == 2 ? 6 : 1, MODE == lep5::kGather && NW == 2 ? 6 : 8)))
-void lep_enc5_walk_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs, NSum* ns_all,
+__global__ __launch_bounds__(64 * NW) void lep_enc5_walk_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs, NSum* ns_all,
                                                          const uint64_t* __restrict__ ns_off, lep5::SegPlan5* plans, uint8_t* arena, uint16_t* bins,
                                                          uint32_t* counts) {
     lep5::Walk5Shared* sh = reinterpret_cast<lep5::Walk5Shared*>(lep5::lep5_lds);   // dynamic LDS (sizeof(Walk5Shared) at launch)
