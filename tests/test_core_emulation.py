@@ -911,7 +911,7 @@ def test_gpu_progressive_scan_decoder_on_random_files(emu):
         buf = io.BytesIO()
         Image.fromarray(a, "RGB").convert(mode).save(buf, **kw)
         jpg = buf.getvalue()
-        hdl, planes, st = _progressive_decode_on_the_emulation(emu, jpg)
+        hdl, planes, st = _progressive_decode_on_the_emulation(emu, jpg, pipelined=trial % 2 == 1)   # level by level / one pipelined launch, in turn
         assert st == 0, (trial, w, h_, mode, kw, st)
         _same_as_the_host_parser(jpg, hdl, planes)
         abi.lib().lep_jpeg_close(hdl)
