@@ -77,6 +77,13 @@ WDEV void key_classes(uint32_t key, int c[4]) {
     c[2] = kClsEv + ci * 8 + (int)((key >> 8) & 7u); c[3] = kClsDc + (int)((key >> 11) & 15u);
 }
 
+// gather and write run in PARTS (tile ranges of every segment): the writer is 128 wavefronts that take the same time whatever the
+// batch, so part k is written while part k + 1 is gathered.  emit leaves what both need to take a segment up at a part's first
+// tile: the walk's counters there.
+constexpr int kMaxParts = 8;
+struct Ckpt5 { uint32_t tile_no, ord0, sign_pos[2], nbins, tcur[16], pad[3]; };   // 96 bytes
+WDEV uint32_t part_first_tile(uint32_t ntiles, int part, int nparts) { return (uint32_t)(((uint64_t)ntiles * (uint32_t)part) / (uint32_t)nparts); }
+
 struct SegPlan5 {            // one per segment, device memory; written by plan5 from the counts
     uint64_t arena_off;      // byte offset of the segment's entry arena (16-byte aligned)
     uint64_t bins_off;       // offset of the segment's bin list, in bins (uint16)
@@ -85,6 +92,8 @@ struct SegPlan5 {            // one per segment, device memory; written by plan5
     uint32_t cls_base;       // bucket's table: [kNumCls] first record of the chain's stream, [kNumCls] records
     uint32_t place_base;     // [4][nblocks]: the block's place in its 7x7 count / horizontal / vertical / DC stream
     uint32_t nzs_base, ens_base[2], dcs_base;       // the chains' streams (every chain padded to four records)
+    uint32_t ckpt_base;      // [kMaxParts] Ckpt5: where gather / write may take the segment up again (written by emit)
+    uint32_t wstate_base;    // the bool writer's state between its parts
     uint32_t at_base, ntiles;                       // the places emit gave out, for gather: [tile][64 rows][64 lanes] dwords
     uint32_t nblocks;        // block ordinals (coded blocks of the segment)
     uint32_t bins_cap;       // room in the bin list
@@ -453,26 +462,42 @@ struct BoolEnc5 {
 };
 
 // bins: probability | bit << 8.
+// part / nparts: the bins between two of emit's checkpoints (Ckpt5::nbins); the coder's state waits in the segment's arena between
+// parts.  The start marker belongs to the first part, the stop bins and the stream's length to the last.
+struct WriterState5 { uint64_t low, stage; uint32_t q24; int32_t count, nst; uint32_t pos; };
 WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* segs, int seg0, int nseg, uint8_t* streams, uint32_t* stream_len,
-                     int32_t* status) {
+                     int32_t* status, uint8_t* arena_base = nullptr, int part = 0, int nparts = 1) {
     LANES(l) {
         const int seg = seg0 + l;
         if (seg < nseg) {
             const SegPlan5& P = plans[seg];
             const SegDev& sd = segs[seg];
-            if (P.status) status[sd.slot] = P.status;
+            const bool last = part + 1 >= nparts;
+            if (P.status) { if (last) status[sd.slot] = P.status; }
             else {
-                const uint32_t* b = reinterpret_cast<const uint32_t*>(bins + P.bins_off);   // 256-byte aligned; room to the next multiple of 128 bins
-                const uint32_t n = P.nbins;
+                const uint16_t* list = bins + P.bins_off;                        // 256-byte aligned; room to the next multiple of 128 bins
+                const uint32_t* b = reinterpret_cast<const uint32_t*>(list);
+                const Ckpt5* ck = arena_base ? reinterpret_cast<const Ckpt5*>(arena_base + P.arena_off + P.ckpt_base) : nullptr;
+                WriterState5* ws = arena_base ? reinterpret_cast<WriterState5*>(arena_base + P.arena_off + P.wstate_base) : nullptr;
+                uint32_t i = part > 0 ? ck[part].nbins : 0u;
+                const uint32_t n = last ? P.nbins : ck[part + 1].nbins;
                 BoolEnc5 bc;
                 bc.init(streams + sd.stream_off, sd.stream_cap);
-                bc.bin(0, 128);   // the start marker (vpx_start_encode)
+                if (part == 0) bc.bin(0, 128);   // the start marker (vpx_start_encode)
+                else { bc.low = ws->low; bc.stage = ws->stage; bc.q24 = ws->q24; bc.count = ws->count; bc.nst = ws->nst; bc.pos = ws->pos; }
+                int since = 1;   // bins since the last flush (at most four: seven bits each above the 31 the recurrence keeps)
+                for (; i < n && (i & 31u); ++i) {   // up to the next whole sector of the list
+                    const uint32_t e = list[i];
+                    bc.bin((e >> 8) & 1u, e & 255u);
+                    if (++since >= 4) { bc.flush(); since = 0; }
+                }
+                bc.flush(); since = 0;
                 // 32 bins (a 64-byte sector of this lane's list) per round: the NEXT round's four dwordx4 are requested before this
                 // round's bins are coded -- a round is ~3,500 cycles of recurrence, enough to cover a trip to HBM.  The body has no
-                // per-bin conditions; a segment's last 0..31 bins take the loop behind it.  (The list has room to the next
-                // multiple of 128 bins, and the arena behind it: the look-ahead never leaves it.)
-                U4 n0 = ld4(b), n1 = ld4(b + 4), n2 = ld4(b + 8), n3 = ld4(b + 12);
-                uint32_t i = 0;
+                // per-bin conditions; the last 0..31 bins take the loop behind it.  (The list has room to the next multiple of 128
+                // bins, and the arena behind it: the look-ahead never leaves it.)
+                if (i < n) {   // (i is a multiple of 32 here)
+                U4 n0 = ld4(b + (i >> 1)), n1 = ld4(b + (i >> 1) + 4), n2 = ld4(b + (i >> 1) + 8), n3 = ld4(b + (i >> 1) + 12);
 #define LEP5_CODE8(g)                                                                                          \
     bc.bin((g.x >> 8) & 1u, g.x & 255u); bc.bin((g.x >> 24) & 1u, (g.x >> 16) & 255u);                        \
     bc.bin((g.y >> 8) & 1u, g.y & 255u); bc.bin((g.y >> 24) & 1u, (g.y >> 16) & 255u);                        \
@@ -495,9 +520,13 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
                         if ((q & 3) == 3) bc.flush();
                     }
                 }
-                bool overflow = false;
-                stream_len[sd.slot] = bc.finish(&overflow);
-                if (overflow) status[sd.slot] = 100;   // LEP_BUFFER_TOO_SMALL
+                }
+                bc.flush();
+                if (last) {
+                    bool overflow = false;
+                    stream_len[sd.slot] = bc.finish(&overflow);
+                    if (overflow) status[sd.slot] = 100;   // LEP_BUFFER_TOO_SMALL
+                } else { ws->low = bc.low; ws->stage = bc.stage; ws->q24 = bc.q24; ws->count = bc.count; ws->nst = bc.nst; ws->pos = bc.pos; }
             }
         }
     }
@@ -1265,7 +1294,7 @@ struct Walk5 {
             LANES(l) if (l == 0) for (int lt = 2; lt < 8; ++lt) S.tcur[ci * 8 + lt] += (uint32_t)ttot[lt];
             LSYNC();
         }
-        if (MODE == kCount) bins_tile = lepwave::wave_sum(lbins);
+        if (MODE == kCount || (MODE == kEmit && kEdge)) bins_tile = lepwave::wave_sum(lbins);   // (emit: exact -- the DC's bins are known; for the checkpoints)
         return TileTotals{nsig_tile, bins_tile};
     }
 
@@ -1323,8 +1352,21 @@ struct Walk5 {
     }
 
     // whole segment (lepton_codec.hh:41-100 row schedule, vp8_encoder.cc:239-445); ns: the segment's two-row NSum rings (zeroed)
+    // emit: the state at the first tile of every part (the wavefront that holds the exact bin count writes it)
+    WDEV void checkpoints(uint32_t ntiles, int nparts) {
+        if (MODE != kEmit || (LEP_ON_GPU && wave != NW - 1)) return;
+        Ckpt5* ck = reinterpret_cast<Ckpt5*>(arena + plan->ckpt_base);
+        for (int q = 1; q < nparts; ++q) {
+            if (part_first_tile(ntiles, q, nparts) != tile_no) continue;
+            LANES(l) {
+                if (l < 16) gst(&ck[q].tcur[l], LEP5_WSH(this).tcur[l]);
+                if (l == 16) { gst(&ck[q].tile_no, tile_no); gst(&ck[q].ord0, ord0); gst(&ck[q].sign_pos[0], sign_pos[0]); gst(&ck[q].sign_pos[1], sign_pos[1]); gst(&ck[q].nbins, nbins); }
+            }
+        }
+    }
+    // part / nparts: gather only (the other passes walk the whole segment; emit leaves the checkpoints for nparts parts)
     WDEV int run(const ImageDev* image, const SegDev& seg, NSum* ns, Walk5Shared* shared, const SegPlan5* pl, uint8_t* arena_base, uint16_t* bins_base,
-                 int wave_no = 0) {
+                 int wave_no = 0, int part = 0, int nparts = 1) {
         img = image; sh = shared; plan = pl; status = 0; wave = wave_no;
         arena = (MODE != kCount) ? arena_base + pl->arena_off : nullptr;
         bins = (MODE == kGather) ? bins_base + pl->bins_off : nullptr;
@@ -1336,6 +1378,14 @@ struct Walk5 {
             if (MODE != kGather) for (int i = l; i < 2 * kRows * kClasses; i += 64) LEP5_WSH(this).cursor[i] = MODE == kCount ? 0u : pl->base[i];   // (every wavefront: the same values)
             if (MODE != kCount && l < 16) LEP5_WSH(this).tcur[l] = pl->base[stream_id(l >> 3, 63, l & 7)];
         }
+        const uint32_t ntiles = MODE != kCount ? pl->ntiles : 0u;
+        const uint32_t first = MODE == kGather ? part_first_tile(ntiles, part, nparts) : 0u;
+        const uint32_t end = MODE == kGather && part + 1 < nparts ? part_first_tile(ntiles, part + 1, nparts) : 0xffffffffu;
+        if (MODE == kGather && first > 0) {   // take the segment up where emit left the checkpoint
+            const Ckpt5* ck = reinterpret_cast<const Ckpt5*>(arena + pl->ckpt_base) + part;
+            tile_no = gld(&ck->tile_no); ord0 = gld(&ck->ord0); sign_pos[0] = gld(&ck->sign_pos[0]); sign_pos[1] = gld(&ck->sign_pos[1]); nbins = gld(&ck->nbins);
+            LANES(l) if (l < 16) LEP5_WSH(this).tcur[l] = gld(&ck->tcur[l]);
+        }
         LEP5_XSYNC();
         // the tiles of the segment in stream order (lepton_codec.hh:41-100; vp8_encoder.cc:83-154: a row ends where the file was cut)
         TileIter it;
@@ -1343,14 +1393,17 @@ struct Walk5 {
         TileDesc cur_t{}, nxt_t{};
         LV(TileRegs, regs);
         bool have = it.next(&cur_t);
-        if (have) fetch_tile(cur_t, regs);
+        for (uint32_t skip = 0; have && skip < first; ++skip) have = it.next(&cur_t);   // (the schedule is cheap to step through)
+        if (have && first < end) fetch_tile(cur_t, regs); else have = false;
         comp = -1;
+        if (MODE == kEmit) checkpoints(ntiles, nparts);   // (parts that start at tile 0)
         while (have) {
             store_tile(cur_t, regs);
-            const bool more = it.next(&nxt_t);
+            const bool more = it.next(&nxt_t) && tile_no + 1 < end;
             if (more) fetch_tile(nxt_t, regs);   // in flight while this tile is worked on
             const int rc = tile(cur_t.x0, cur_t.nb, cur_t.has_above, cur_t.nrow, cur_t.narow);
             if (rc) return rc;
+            if (MODE == kEmit) { LEP5_XSYNC(); checkpoints(ntiles, nparts); }
             cur_t = nxt_t;
             have = more;
         }
@@ -1393,6 +1446,9 @@ WDEV void plan_segment(const uint32_t* counts, SegPlan5* P) {
     P->ens_base[0] = bytes; bytes += (P->nblocks + 4u * 16u) * 4u;
     P->ens_base[1] = bytes; bytes += (P->nblocks + 4u * 16u) * 4u;
     P->dcs_base = bytes; bytes += (P->nblocks + 4u * 12u) * (uint32_t)kDcRec;
+    bytes = (bytes + 15u) & ~15u;
+    P->ckpt_base = bytes; bytes += (uint32_t)(kMaxParts * sizeof(Ckpt5));
+    P->wstate_base = bytes; bytes += 64u;
     bytes = (bytes + 255u) & ~255u;
     P->ntiles = counts[kStreams + 4];
     P->at_base = bytes; bytes += P->ntiles * (uint32_t)(kAtRows * 64 * 4);

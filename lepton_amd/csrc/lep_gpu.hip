@@ -156,19 +156,19 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
 template <int MODE, int NW>
 __global__ __launch_bounds__(64 * NW) void lep_enc5_walk_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs, NSum* ns_all,
                                                          const uint64_t* __restrict__ ns_off, lep5::SegPlan5* plans, uint8_t* arena, uint16_t* bins,
-                                                         uint32_t* counts) {
-    lep5::Walk5Shared* sh = reinterpret_cast<lep5::Walk5Shared*>(lep5::lep5_lds);   // dynamic LDS (sizeof(Walk5Shared) at launch)
+                                                         uint32_t* counts, int part, int nparts) {
+    lep5::Walk5Shared* sh = reinterpret_cast<lep5::Walk5Shared*>(lep5::lep5_lds);   // dynamic LDS (walk_lds_bytes(MODE) at launch)
     const int s = blockIdx.x;
     const SegDev seg = segs[s];
     lep5::SegPlan5* P = plans + s;
     if (MODE == lep5::kGather && P->status) return;
     lep5::Walk5<MODE, NW> w;
-    const int rc = w.run(images + seg.image, seg, ns_all + ns_off[s], sh, P, arena, bins, (int)(threadIdx.x >> 6));
+    const int rc = w.run(images + seg.image, seg, ns_all + ns_off[s], sh, P, arena, bins, (int)(threadIdx.x >> 6), part, nparts);
     if (threadIdx.x >= 64) return;
     if (MODE == lep5::kCount) lep5::export_counts(w, sh, counts + (size_t)s * lep5::kCountWords);
     if (threadIdx.x == 0) {
         if (MODE == lep5::kEmit) P->status = rc;
-        if (MODE == lep5::kGather) P->nbins = w.nbins;
+        if (MODE == lep5::kGather && part + 1 == nparts) P->nbins = w.nbins;
     }
 }
 // counts -> per-segment layout (one thread per segment), then the prefix over the segments (one wavefront)
@@ -238,10 +238,15 @@ __global__ __launch_bounds__(64) void lep_enc5_fold_big_kernel(const lep5::SegPl
 constexpr int kFold5BigJobs = 12 + 20;
 // write: lane = segment
 __global__ __launch_bounds__(64) void lep_enc5_write_kernel(const lep5::SegPlan5* __restrict__ plans, const uint16_t* __restrict__ bins, const SegDev* __restrict__ segs,
-                                                          int nseg, uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* nbins_out) {
+                                                          int nseg, uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* nbins_out, uint8_t* arena,
+                                                          int part, int nparts) {
+    __builtin_amdgcn_s_setprio(3);   // (128 wavefronts that run beside the next part's gather: one long dependency chain each)
     const int seg0 = (int)blockIdx.x * 64, seg = seg0 + (int)threadIdx.x;
-    if (seg < nseg) { status[segs[seg].slot] = 0; nbins_out[segs[seg].slot] = plans[seg].nbins; }
-    lep5::write_wave(plans, bins, segs, seg0, nseg, streams, stream_len, status);
+    if (seg < nseg) {
+        if (part == 0) status[segs[seg].slot] = 0;
+        if (part + 1 == nparts) nbins_out[segs[seg].slot] = plans[seg].nbins;
+    }
+    lep5::write_wave(plans, bins, segs, seg0, nseg, streams, stream_len, status, arena, part, nparts);
 }
 
 // JPEG Huffman re-encode of decoded frames: one wavefront per thread segment (lep_huff.h)
@@ -339,6 +344,8 @@ struct lep_gpu {
     int huffprog_pipeline_max = 16384;  // LEP_HUFFPROG_PIPELINE_MAX: scans per launch up to which the levels go out as one pipelined launch (measured to 10240:
                                         // 1024 4K files, 798 -> 938 MB/s; workgroups start in index order, so a scan's predecessors are always running or done)
     int enc5_waves = 2;      // LEP_ENC5_WAVES: wavefronts per segment in the split-phase walks (1 | 2)
+    int enc5_parts = 4;      // LEP_ENC5_PARTS: gather / write in this many parts (1..8), a part written while the next is gathered
+    hipEvent_t ev_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int enc5_gather_wgs = 0; // LEP_ENC5_GATHER_WGS: resident gather workgroups per CU held to this (through the LDS a launch asks for)
     int enc5_fold_apart = 0; // LEP_ENC5_FOLD_APART: the fold launches one after the other, a launch per kind of chain (for the profiler)
     size_t enc5_scratch_max = ~(size_t)0;   // LEP_ENC5_SCRATCH_MAX (bytes): a launch that needs more takes the single-kernel encoder (tests: the out-of-memory path)
@@ -438,6 +445,7 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     lep_gpu::Enc5Scratch& E = g->enc5;
     if (!g->stream2) {
         HIPCHK(g, hipEventCreateWithFlags(&g->ev_enc5_done, hipEventDisableTiming));
+        for (auto& e : g->ev_part) HIPCHK(g, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(g, hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
         HIPCHK(g, hipStreamCreateWithFlags(&g->stream3, hipStreamNonBlocking));
         HIPCHK(g, hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
@@ -456,10 +464,11 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     g->nstage = 0;
     HIPCHK(g, hipEventRecord(g->ev_stage[0], st));
     const bool two = g->enc5_waves == 2;
-    auto walk = [&](int mode, uint8_t* entries, uint16_t* binlist) {
+    const int nparts = std::min(std::max(g->enc5_parts, 1), (int)lep5::kMaxParts);
+    auto walk = [&](int mode, uint8_t* entries, uint16_t* binlist, int part = 0) {
         size_t lds = lep5::walk_lds_bytes(mode);
         if (mode == lep5::kGather && g->enc5_gather_wgs > 0) lds = std::max(lds, (size_t)(160 * 1024 / g->enc5_gather_wgs) & ~(size_t)255);   // (measurement aid: fewer resident workgroups)
-#define LEP_WALK(MODE, NW) hipLaunchKernelGGL((lep_enc5_walk_kernel<MODE, NW>), dim3(nseg), dim3(64 * NW), lds, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, entries, binlist, counts)
+#define LEP_WALK(MODE, NW) hipLaunchKernelGGL((lep_enc5_walk_kernel<MODE, NW>), dim3(nseg), dim3(64 * NW), lds, st, d_img, d_seg, (NSum*)A.d_ns, d_nsoff, plans, entries, binlist, counts, part, nparts)
         if (mode == lep5::kCount) { if (two) LEP_WALK(lep5::kCount, 2); else LEP_WALK(lep5::kCount, 1); }
         else if (mode == lep5::kEmit) { if (two) LEP_WALK(lep5::kEmit, 2); else LEP_WALK(lep5::kEmit, 1); }
         else { if (two) LEP_WALK(lep5::kGather, 2); else LEP_WALK(lep5::kGather, 1); }
@@ -509,10 +518,18 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join3, 0));
         HIPCHK(g, hipEventRecord(g->ev_stage[3], st));
-        walk(lep5::kGather, (uint8_t*)E.d_entries, (uint16_t*)E.d_binlist);
+        // gather and write in parts (tile ranges of every segment): the writer is 128 wavefronts that take the same time whatever the
+        // batch -- part k is written (second stream) while part k + 1 is gathered
+        for (int part = 0; part < nparts; ++part) {
+            walk(lep5::kGather, (uint8_t*)E.d_entries, (uint16_t*)E.d_binlist, part);
+            HIPCHK(g, hipEventRecord(g->ev_part[part], st));
+            HIPCHK(g, hipStreamWaitEvent(g->stream2, g->ev_part[part], 0));
+            hipLaunchKernelGGL(lep_enc5_write_kernel, dim3(groups), dim3(64), 0, g->stream2, (const lep5::SegPlan5*)plans, (const uint16_t*)E.d_binlist, d_seg, nseg, d_streams,
+                               d_stream_len, d_status, g->d_bins, (uint8_t*)E.d_entries, part, nparts);
+        }
         HIPCHK(g, hipEventRecord(g->ev_stage[4], st));
-        hipLaunchKernelGGL(lep_enc5_write_kernel, dim3(groups), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (const uint16_t*)E.d_binlist, d_seg, nseg, d_streams, d_stream_len,
-                           d_status, g->d_bins);
+        HIPCHK(g, hipEventRecord(g->ev_join, g->stream2));
+        HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
         HIPCHK(g, hipEventRecord(g->ev_stage[5], st));
         g->nstage = 5;
     }
@@ -662,6 +679,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
     if (const char* e = getenv("LEP_ENC5_GATHER_WGS")) g->enc5_gather_wgs = atoi(e);
+    if (const char* e = getenv("LEP_ENC5_PARTS")) g->enc5_parts = atoi(e);
     if (const char* e = getenv("LEP_ENC5_SCRATCH_MAX")) g->enc5_scratch_max = (size_t)strtoull(e, nullptr, 10);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
@@ -684,6 +702,7 @@ static void release_device_side(lep_gpu* g) {
     for (void* p : {g->enc5.d_plans, g->enc5.d_entries, g->enc5.d_binlist})
         if (p) (void)hipFree(p);
     if (g->ev_enc5_done) (void)hipEventDestroy(g->ev_enc5_done);
+    for (auto& e : g->ev_part) if (e) (void)hipEventDestroy(e);
     for (auto& e : g->ev_stage) if (e) (void)hipEventDestroy(e);
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);

@@ -281,7 +281,7 @@ extern "C" int emu_huffman_decode_image_parallel(const lep_huffdec_image* img, l
 #include "../../lepton_amd/csrc/lep_enc5.h"
 template <int NW>
 static int encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins,
-                             uint16_t* bins_out, uint32_t bins_out_cap) {
+                             uint16_t* bins_out, uint32_t bins_out_cap, int nparts = 1) {
     using namespace lep5;
     ImageDev img;
     int rc = derive_image(*d, &img, true);
@@ -305,7 +305,7 @@ static int encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_las
     {
         Walk5<kEmit, NW> w;
         memset(ns.data(), 0, ns.size() * sizeof(NSum));
-        rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), nullptr);
+        rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), nullptr, 0, 0, nparts);
         if (rc) return rc;
         if (w.sign_pos[0] != plan.sign_cnt[0] || w.sign_pos[1] != plan.sign_cnt[1] || w.ord0 != plan.nblocks) return 1001;
         for (int i = 0; i < kStreams; ++i) if (wsh.cursor[i] != plan.base[i] + plan.cnt[i]) return 1002;
@@ -328,19 +328,20 @@ static int encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_las
         for (int v = 0; v < 2; ++v) for (int e = 0; e < 8; ++e) fold_edgenz_wave(&plan, arena.data(), 0, 1, ci, v, e, &fsh);
     }
     for (int a = 0; a < 12; ++a) fold_dc_wave(&plan, arena.data(), 0, 1, a, &fsh);
-    {
+    for (int part = 0; part < nparts; ++part) {   // (every part: a walker of its own, as on the GPU)
         Walk5<kGather, NW> w;
         memset(ns.data(), 0, ns.size() * sizeof(NSum));
-        rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), binlist.data());
+        rc = w.run(&img, seg, ns.data(), &wsh, &plan, arena.data(), binlist.data(), 0, part, nparts);
         if (rc) return rc;
         if (w.nbins > plan.bins_cap) return 1003;
+        if (part + 1 < nparts && w.nbins != reinterpret_cast<const Ckpt5*>(arena.data() + plan.ckpt_base)[part + 1].nbins) return 1004;   // emit's bin count at the checkpoint
         plan.nbins = w.nbins;
     }
     if (bins) *bins = plan.nbins;
     if (bins_out) memcpy(bins_out, binlist.data(), 2 * (size_t)(plan.nbins < bins_out_cap ? plan.nbins : bins_out_cap));
     uint32_t slen = 0;
     int32_t status = 0;
-    write_wave(&plan, binlist.data(), &seg, 0, 1, out, &slen, &status);
+    for (int part = 0; part < nparts; ++part) write_wave(&plan, binlist.data(), &seg, 0, 1, out, &slen, &status, arena.data(), part, nparts);
     *len = slen;
     return status == 100 ? LEP_BUFFER_TOO_SMALL : status;
 }
@@ -352,6 +353,17 @@ extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, in
 extern "C" int emu_encode_segment_v5_halves(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins,
                                             uint16_t* bins_out, uint32_t bins_out_cap) {
     return encode_segment_v5<2>(d, y0, y1, is_last, out, cap, len, bins, bins_out, bins_out_cap);
+}
+// ... with gather and write in parts (tile ranges of the segment, taken up from emit's checkpoints; the writer's state carried over)
+extern "C" int emu_encode_segment_v5_parts(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins,
+                                           uint16_t* bins_out, uint32_t bins_out_cap) {
+    const int rc = encode_segment_v5<2>(d, y0, y1, is_last, out, cap, len, bins, bins_out, bins_out_cap, 4);
+    if (rc) return rc;
+    std::vector<uint8_t> again(cap);
+    uint32_t len2 = 0, bins2 = 0;
+    const int rc2 = encode_segment_v5<1>(d, y0, y1, is_last, again.data(), cap, &len2, &bins2, nullptr, 0, 7);   // one wavefront, seven parts: the same bytes
+    if (rc2) return rc2;
+    return (len2 == *len && !memcmp(again.data(), out, len2)) ? 0 : 1005;
 }
 
 

@@ -1140,7 +1140,7 @@ def test_gpu_scan_encoder_end_states_are_held_against_the_hand_offs(emu):
     assert run(last)[0] == 0
 
 
-V5_ENTRIES = ("emu_encode_segment_v5", "emu_encode_segment_v5_halves")   # one wavefront per segment; the walks' two halves apart
+V5_ENTRIES = ("emu_encode_segment_v5", "emu_encode_segment_v5_halves", "emu_encode_segment_v5_parts")   # one wavefront per segment; the walks' two halves apart; gather and write in parts
 
 
 def _v5_encode(emu, d, s, cap, entry="emu_encode_segment_v5"):
