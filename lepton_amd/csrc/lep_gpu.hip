@@ -344,7 +344,8 @@ struct lep_gpu {
     int huffprog_pipeline_max = 16384;  // LEP_HUFFPROG_PIPELINE_MAX: scans per launch up to which the levels go out as one pipelined launch (measured to 10240:
                                         // 1024 4K files, 798 -> 938 MB/s; workgroups start in index order, so a scan's predecessors are always running or done)
     int enc5_waves = 2;      // LEP_ENC5_WAVES: wavefronts per segment in the split-phase walks (1 | 2)
-    int enc5_parts = 4;      // LEP_ENC5_PARTS: gather / write in this many parts (1..8), a part written while the next is gathered
+    int enc5_parts = 8;      // LEP_ENC5_PARTS: gather / write in this many parts (1..8), a part written while the next is gathered
+                             // (MI355X, 1024 x 4K: 1 part 569 ms per launch, 4 parts 481, 8 parts 475)
     hipEvent_t ev_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int enc5_gather_wgs = 0; // LEP_ENC5_GATHER_WGS: resident gather workgroups per CU held to this (through the LDS a launch asks for)
     int enc5_fold_apart = 0; // LEP_ENC5_FOLD_APART: the fold launches one after the other, a launch per kind of chain (for the profiler)
