@@ -443,3 +443,11 @@ extern "C" int emu_v5_counts(const lep_image_desc* d, int y0, int y1, int is_las
     export_counts(w, &wsh, counts);
     return 0;
 }
+
+// lep_huffprogdec.h prog_scan_deps on descriptors a test made up (only the frame pointer, the components and the band are looked at)
+extern "C" int emu_prog_scan_deps(const lep_huffprogdec_scan* scans, const int* order, int n, int32_t* deps_out) {
+    std::vector<lephuff::ProgDeps> deps((size_t)n);
+    const bool ok = lephuff::prog_scan_deps(reinterpret_cast<const lephuff::ProgDecScan*>(scans), order, n, deps.data());
+    for (int i = 0; i < n; ++i) for (int d = 0; d < 4; ++d) deps_out[4 * i + d] = deps[(size_t)i].dep[d];
+    return ok ? 1 : 0;
+}

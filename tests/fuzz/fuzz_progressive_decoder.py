@@ -24,7 +24,7 @@ for trial in range(N):
     else: j[pos]^=1<<rnd.randrange(8)
     j=bytes(j)
     try:
-        h,planes,st=t._progressive_decode_on_the_emulation(emu,j)
+        h,planes,st=t._progressive_decode_on_the_emulation(emu,j,pipelined=bool(trial&1))   # level by level / one pipelined launch, in turn
     except AssertionError as e:
         inel+=1; continue   # open_gpu failed / sequential
     if st is None: inel+=1; continue

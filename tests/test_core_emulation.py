@@ -1240,3 +1240,42 @@ def test_sixteen_bit_branch_equals_the_packed_word(emu):
     """the fold lanes keep a Branch as two counts (lep5::upd16 / prob16, the saturated-true state as t = 0): same probabilities
     as lepdev::branch_update (branch.hh:82-100) along 900 random walks of every bias, saturation and renormalisation included"""
     assert emu.emu_check_branch16(900) == 0
+
+
+def test_progressive_scan_dependencies_on_made_up_scripts(emu):
+    """prog_scan_deps (lep_huffprogdec.h) on scan scripts libjpeg does not write: bands that overlap in part, DC refinement per
+    component behind an interleaved DC scan, two files whose scans alternate in the launch, a scan behind five independent ones
+    (no pipelining then), and a launch order that would make a scan wait for one behind it (refused)"""
+    from lepton_amd import abi
+
+    def run(rows, order=None):
+        n = len(rows)
+        scans = (abi.HuffProgDecScan * n)()
+        for i, (frame, comps, lo, hi) in enumerate(rows):
+            scans[i].t.blocks[0] = frame
+            scans[i].cmpc = len(comps)
+            for k, c in enumerate(comps):
+                scans[i].cmp[k] = c
+            scans[i].from_, scans[i].to = lo, hi
+        od = (C.c_int * n)(*(order or range(n)))
+        deps = (C.c_int32 * (4 * n))()
+        emu.emu_prog_scan_deps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        ok = emu.emu_prog_scan_deps(scans, od, n, deps)
+        return ok, [sorted(x for x in deps[4 * i: 4 * i + 4] if x >= 0) for i in range(n)]
+
+    A, B = 0x1000, 0x2000
+    # bands that meet in part: 3..10 follows 1..5; 11..63 follows nothing; 1..63 refinement follows all three directly
+    ok, d = run([(A, [0], 1, 5), (A, [0], 3, 10), (A, [0], 11, 63), (A, [0], 1, 63)])
+    assert ok and d == [[], [0], [], [1, 2]]          # (0 is implied through 1)
+    # interleaved DC, then DC refinement component by component; chroma AC scans follow nothing
+    ok, d = run([(A, [0, 1, 2], 0, 0), (A, [1], 0, 0), (A, [0], 0, 0), (A, [2], 1, 63), (A, [2], 0, 0)])
+    assert ok and d == [[], [0], [0], [], [0]]
+    # two files in one launch, scans alternating: a scan never follows the other file's
+    ok, d = run([(A, [0], 1, 63), (B, [0], 1, 63), (A, [0], 1, 63), (B, [0], 1, 63), (B, [0], 1, 63)], order=[0, 0, 1, 1, 2])
+    assert ok and d == [[], [], [0], [1], [3]]
+    # five independent bands in front of one scan that covers them all: more than four to wait for
+    ok, _ = run([(A, [0], 1, 2), (A, [0], 3, 4), (A, [0], 5, 6), (A, [0], 7, 8), (A, [0], 9, 10), (A, [0], 1, 63)])
+    assert not ok
+    # the scan that comes first in the FILE stands behind the one that follows it in the LAUNCH: a wait that could never end
+    ok, _ = run([(A, [0], 1, 63), (A, [0], 1, 63)], order=[1, 0])
+    assert not ok
