@@ -1,4 +1,4 @@
-"""Coefficient-domain sweep of the CURRENT coder kernels as lane-loop emulations against the oracle (test infrastructure, run by
+"""Coefficient-domain sweep of the CURRENT coder kernels (single-kernel encoder, split-phase encoder, decoder) as lane-loop emulations against the oracle (test infrastructure, run by
 hand: `python tests/fuzz/emu_coeff_fuzz.py <seed> <cases>`).  Frames are drawn directly as quantised coefficients
 (tests/jpeg_writer.py): geometry from one block up, every sampling layout the writer knows, density from almost empty to every
 coefficient set, amplitudes up to the 8-bit limits, flat and steep quantisation tables, restart intervals.  For every case:
@@ -66,6 +66,15 @@ def main():
             if first != code:
                 bad += 1
                 print("REFUSAL MISMATCH", seed0, k, w, h, comps, kw, "oracle", code, "kernel", rcs, flush=True)
+            rcs5 = []    # ... and from the split-phase encoder (two wavefronts per segment / gather and write in parts, and one / seven)
+            for s in segs:
+                b = C.create_string_buffer(1 << 22)
+                n, nb = C.c_uint32(0), C.c_uint32(0)
+                rcs5.append(emu.emu_encode_segment_v5_parts(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, b, 1 << 22, C.byref(n), C.byref(nb), None, 0))
+            first5 = next((r for r in rcs5 if r), 0)
+            if first5 != code:
+                bad += 1
+                print("REFUSAL MISMATCH (split-phase)", seed0, k, w, h, comps, kw, "oracle", code, "kernel", rcs5, flush=True)
             refused_both += 1
             continue
         ok = True
@@ -77,6 +86,12 @@ def main():
             if rc != 0 or b.raw[: n.value] != wv:
                 ok = False
                 print("ENCODE MISMATCH", seed0, k, w, h, comps, kw, "rc", rc, flush=True)
+                break
+            n5, nb5 = C.c_uint32(0), C.c_uint32(0)   # the split-phase encoder (lep_enc5.h), both launch forms, gather / write in parts
+            rc = emu.emu_encode_segment_v5_parts(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, b, cap, C.byref(n5), C.byref(nb5), None, 0)
+            if rc != 0 or b.raw[: n5.value] != wv:
+                ok = False
+                print("ENCODE MISMATCH (split-phase)", seed0, k, w, h, comps, kw, "rc", rc, flush=True)
                 break
         frames = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
         for c in range(d.ncomp):
