@@ -193,7 +193,10 @@ int lep_gpu_huffman_decode_device(lep_gpu *g, const lep_huffdec_image *images, i
 /* The same for PROGRESSIVE files (replaces the progressive branches of decode_jpeg's scan loop, src/lepton/jpgcoder.cc:2975-3260,
  * with decode_dc_prg_*, decode_ac_prg_fs / _sa, decode_eobrun_sa, skip_eobrun :4968-5335, :5462-5500): one wavefront per
  * (image, scan).  A refinement scan must see what the earlier scans of its band wrote, so every descriptor carries a
- * dependency `level`; the call launches level after level on the stream.  Each scan writes its coefficients into the
+ * dependency `level`.  Up to 16384 scans go out as ONE launch, ordered by level, in which a scan waits -- MCU row by MCU row,
+ * on a progress word the scans in front of it publish -- for the scans of its file (same frame pointers) whose component and
+ * band meet its own: a file then takes as long as its longest scan instead of the sum over its levels.  Larger calls (or
+ * LEP_HUFFPROG_PIPELINE=0) launch level after level on the stream.  Each scan writes its coefficients into the
  * zero-filled frame t.blocks, the first scan of a file also one record per MCU row at d_rows + t.rows_off, and every scan a
  * final record {bits consumed, last DC, pad bits | status << 8} at d_rows + result_off; a non-zero status anywhere sends the
  * whole file to the host parser.  lep_jpeg_open_gpu_progressive fills the descriptors. */
