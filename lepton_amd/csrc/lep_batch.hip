@@ -605,12 +605,14 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 launch.push_back(hi); which.push_back(k);
             }
             HIPOK(hipStreamWaitEvent(s_huff, s->up, 0));
-            // Several wavefronts per image (lep_huffdec_par.h) for the scans without restart intervals when the decode is
-            // EXPOSED -- the first chunk of a call has no coder kernel to hide behind: 1024 4K images, one chunk, compress
-            // 2.39 s -> 1.84 s at 16 wavefronts per image (MI355X, profiles/r02a_huffpar_*).  Later chunks keep the single-wave
-            // kernel, which is built to sit in the eighth wave slot beside the previous chunk's coder waves.
+            // Several wavefronts per image (lep_huffdec_par.h) for the scans without restart intervals, for EVERY chunk.  Round 2
+            // kept the single-wave kernel for the chunks behind the first: it was built to sit in the eighth wave slot beside the
+            // previous chunk's one-kernel encoder, which took as long as it did (~0.9 s for 896 4K images).  Beside the split-phase
+            // encoder (0.45 s per chunk) it became the pipeline's critical path -- kernel trace of 2688 x 4K, profiles/r05b_*: every
+            // chunk's encode launch waited ~0.5 s for the scan decode of its own images -- while the parallel form takes 0.31 s and
+            // shares the chip with the walks (they wait 60 % of their wave time): compress 1675 -> 2184 MB/s (profiles/r05c_*).
             // LEP_HUFFDEC_PAR=<n> forces n (0 = single wave) for every chunk.
-            const int par = getenv("LEP_HUFFDEC_PAR") ? atoi(getenv("LEP_HUFFDEC_PAR")) : (c == chunks[0].get() ? 16 : 0);
+            const int par = getenv("LEP_HUFFDEC_PAR") ? atoi(getenv("LEP_HUFFDEC_PAR")) : 16;
             if (par >= 2) {
                 std::vector<lep_huffdec_image> many, one;
                 for (const lep_huffdec_image& hi : launch) (hi.rsti ? one : many).push_back(hi);

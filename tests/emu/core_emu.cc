@@ -164,6 +164,54 @@ extern "C" int emu_decode_segment_v4(const lep_image_desc* d, int y0, int y1, in
     return rc;
 }
 
+// v5 decoder (lep_dec5.h): a workgroup of NW wavefronts decodes NW segments; the lane-parallel phases serve all of them at once.
+// The emulation runs the wavefronts of a phase one after the other between the workgroup barriers.
+#include "../../lepton_amd/csrc/lep_dec5.h"
+template <int NW>
+static int run_group_v5(const lep_image_desc* d, int nseg, const int* y0, const int* y1, const int* is_last, const uint8_t* const* in, const uint32_t* len,
+                        uint32_t* bins, int* rcs) {
+    ImageDev img;
+    int rc = derive_image(*d, &img, false);
+    if (rc) return rc;
+    std::vector<std::vector<uint32_t>> models(NW);
+    std::vector<std::vector<NSum>> nss(NW);
+    std::vector<PaddedStream> ps;
+    ps.reserve(NW);
+    static lep5d::Dec5Shared<NW> sh;
+    static lep5d::Dec5Group<NW> g;
+    for (int w = 0; w < NW; ++w) {
+        lep5d::Wave5& W = g.wv[w];
+        W.img = nullptr;
+        g.model_of[w] = nullptr;
+        if (w >= nseg) continue;
+        models[w].assign(lep5d::kModelWords5, kBranchInit);
+        for (uint32_t i = 0; i < lep5d::kGroups; ++i) { models[w][i * 3] = lep5d::kRecInitF; models[w][i * 3 + 1] = lep5d::kRecInitT; models[w][i * 3 + 2] = lep5d::kRecInitP; }
+        nss[w].resize(img.ns_total);
+        memset(nss[w].data(), 0, nss[w].size() * sizeof(NSum));
+        ps.emplace_back(in[w], len[w]);
+        W.img = &img;
+        W.seg.image = 0; W.seg.y0 = y0[w]; W.seg.y1 = y1[w]; W.seg.is_last = is_last[w]; W.seg.stream_off = 0; W.seg.stream_cap = 0; W.seg.slot = (uint32_t)w;
+        W.model = models[w].data(); W.ns = nss[w].data();
+        W.stream = ps.back().p; W.stream_len = len[w];
+        g.model_of[w] = W.model;
+    }
+    g.run(&sh);
+    for (int w = 0; w < nseg; ++w) { if (bins) bins[w] = g.wv[w].nbins; if (rcs) rcs[w] = g.wv[w].rc; }
+    return 0;
+}
+extern "C" int emu_decode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_last, const uint8_t* in, uint32_t len, uint32_t* bins) {
+    int rc = 0;
+    uint32_t nb = 0;
+    const int r = run_group_v5<1>(d, 1, &y0, &y1, &is_last, &in, &len, &nb, &rc);
+    if (bins) *bins = nb;
+    return r ? r : rc;
+}
+// up to four segments of one image as one workgroup; rcs[i] = exit code of segment i
+extern "C" int emu_decode_group_v5(const lep_image_desc* d, int nseg, const int* y0, const int* y1, const int* is_last, const uint8_t* const* in, const uint32_t* len,
+                                   uint32_t* bins, int* rcs) {
+    return run_group_v5<4>(d, nseg, y0, y1, is_last, in, len, bins, rcs);
+}
+
 // exhaustive check of the 24-bit table reciprocal used by lep4::bupd_t / bupd_u against Branch::record_obs_and_update
 extern "C" int emu_check_inv24_update() {
     static uint32_t inv[512];

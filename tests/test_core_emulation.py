@@ -31,7 +31,7 @@ def emu_other_forms():
     src = os.path.join(ROOT, "tests", "emu", "core_emu.cc")
     so = os.path.join(ROOT, "tests", "emu", "libcore_emu_forms.so")
     tmp = "%s.%d" % (so, os.getpid())
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DLEP_DEC4_SCALAR=13", "-o", tmp, src])
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DLEP_DEC4_SCALAR=13", "-DLEP_DEC5_SCALAR=13", "-o", tmp, src])
     os.replace(tmp, so)
     return C.CDLL(so)
 
@@ -116,7 +116,7 @@ def test_wave_cooperative_decoder_on_cpu_matches_oracle(emu, name):
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
 
 
-@pytest.mark.parametrize("gen", ["v3", "v4"])
+@pytest.mark.parametrize("gen", ["v3", "v4", "v5"])
 @pytest.mark.parametrize("name", golden_cases())
 def test_v3_decoder_on_cpu_matches_oracle(emu, name, gen):
     """lep_dec3.h (owner-lane model update, 32-bit window) as a 64-lane loop emulation: decoding the
@@ -230,8 +230,9 @@ def test_v3_encoder_many_bins_per_block(emu, enc_mode):
     assert emu.emu_encode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, len(buf), C.byref(n), None) == 6
 
 
-def test_v4_decoder_large_coefficients(emu):
-    """every rare path of lep_dec4.h at once: exponent bins beyond the prefetched groups, residual bits >= 4, threshold
+@pytest.mark.parametrize("gen", ["v4", "v5"])
+def test_v4_decoder_large_coefficients(emu, gen):
+    """every rare path of lep_dec4.h / lep_dec5.h at once: exponent bins beyond the prefetched groups, residual bits >= 4, threshold
     bins, long interior runs (several windows, all non-zero bins)"""
     import numpy as np
     from lepton_amd import corpus
@@ -256,7 +257,7 @@ def test_v4_decoder_large_coefficients(emu):
     total = 0
     for s, w in zip(segs, want):
         nb = C.c_uint32(0)
-        assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0
+        assert getattr(emu, "emu_decode_segment_" + gen)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0
         total += nb.value
     assert total == bins
     for c in range(d.ncomp):
@@ -277,16 +278,20 @@ def test_v4_decoder_rounds_in_their_other_form(emu_other_forms):
         orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
         for c in range(d.ncomp):
             C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
-        total = 0
-        for s, w in zip(segs, want):
-            nb = C.c_uint32(0)
-            assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0, name
-            total += nb.value
-        assert total == bins, name
-        for c in range(d.ncomp):
-            n = d.coded_blocks[c] * 128
-            assert C.string_at(d.blocks[c], n) == orig[c][:n], name
-    test_v4_decoder_large_coefficients(emu)
+        for gen in ("v4", "v5"):
+            for c in range(d.ncomp):
+                C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+            total = 0
+            for s, w in zip(segs, want):
+                nb = C.c_uint32(0)
+                assert getattr(emu, "emu_decode_segment_" + gen)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0, name
+                total += nb.value
+            assert total == bins, name
+            for c in range(d.ncomp):
+                n = d.coded_blocks[c] * 128
+                assert C.string_at(d.blocks[c], n) == orig[c][:n], name
+    test_v4_decoder_large_coefficients(emu, "v4")
+    test_v4_decoder_large_coefficients(emu, "v5")
     test_decoders_survive_garbage_streams(emu, 9)
 
 
@@ -428,7 +433,7 @@ def test_decoders_survive_garbage_streams(emu, seed):
     d = img.desc
     segs = img.plan()
     rng = np.random.default_rng(seed)
-    for fn in ("emu_decode_segment_v4", "emu_decode_segment_v3", "emu_decode_segment_v2", "emu_decode_segment"):
+    for fn in ("emu_decode_segment_v5", "emu_decode_segment_v4", "emu_decode_segment_v3", "emu_decode_segment_v2", "emu_decode_segment"):
         for kind in range(3):
             n = int(rng.integers(0, 400))
             if kind == 0:
@@ -610,6 +615,11 @@ def test_current_kernels_on_random_images_match_the_oracle(emu):
         for s, wv in zip(segs, want):
             assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
         got = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+        for c in range(d.ncomp):
+            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+        for s, wv in zip(segs, want):
+            assert emu.emu_decode_segment_v5(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
+        assert got == [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)], trial
         for c in range(d.ncomp):
             C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
         ob.oracle_decode(d, segs, want)
@@ -1021,8 +1031,11 @@ def test_v4_decoder_on_a_first_segment_that_starts_inside_the_image(emu):
         for c in range(d.ncomp):
             C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
         s, wv = segs[0], f.streams[0]
-        assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
-        assert [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == want
+        for gen in ("v4", "v5"):
+            for c in range(d.ncomp):
+                C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+            assert getattr(emu, "emu_decode_segment_" + gen)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
+            assert [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == want
 
 
 @pytest.fixture
@@ -1035,7 +1048,7 @@ def edge_count_bias():
     knob.value = 0
 
 
-@pytest.mark.parametrize("gen", ["", "_v2", "_v4"])   # (the retired v3 generation shares v4's per-pair scheme and is not maintained)
+@pytest.mark.parametrize("gen", ["", "_v2", "_v4", "_v5"])   # (the retired v3 generation shares v4's per-pair scheme and is not maintained)
 @pytest.mark.parametrize("name", ["c420_odd_203x149", "gray_120x88", "c444_96x80", "truncated"])
 def test_decoders_follow_the_reference_on_impossible_edge_counts(emu, edge_count_bias, name, gen):
     """a stream that claims more edge non-zeros than positions remain.  The reference indexes
@@ -1072,11 +1085,14 @@ def test_v4_other_forms_on_impossible_edge_counts(emu_other_forms, edge_count_bi
     orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
     for c in range(d.ncomp):
         C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
-    for s, w in zip(segs, want):
-        assert emu_other_forms.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), None) == 0
-    for c in range(d.ncomp):
-        n = d.coded_blocks[c] * 128
-        assert C.string_at(d.blocks[c], n) == orig[c][:n]
+    for gen in ("v4", "v5"):
+        for c in range(d.ncomp):
+            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+        for s, w in zip(segs, want):
+            assert getattr(emu_other_forms, "emu_decode_segment_" + gen)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), None) == 0
+        for c in range(d.ncomp):
+            n = d.coded_blocks[c] * 128
+            assert C.string_at(d.blocks[c], n) == orig[c][:n]
 
 
 def test_gpu_scan_encoder_end_states_are_held_against_the_hand_offs(emu):
@@ -1279,3 +1295,72 @@ def test_progressive_scan_dependencies_on_made_up_scripts(emu):
     # the scan that comes first in the FILE stands behind the one that follows it in the LAUNCH: a wait that could never end
     ok, _ = run([(A, [0], 1, 63), (A, [0], 1, 63)], order=[1, 0])
     assert not ok
+
+
+def _decode_group_v5(emu, d, segs, streams):
+    """up to four segments as one workgroup of lep_dec5.h; returns the exit codes"""
+    rcs_all = []
+    for i in range(0, len(segs), 4):
+        grp, ws = segs[i:i + 4], streams[i:i + 4]
+        n = len(grp)
+        y0 = (C.c_int * 4)(*[s.luma_y_start for s in grp])
+        y1 = (C.c_int * 4)(*[s.luma_y_end for s in grp])
+        il = (C.c_int * 4)(*[s.is_last for s in grp])
+        bufs = [C.create_string_buffer(bytes(w), max(1, len(w))) for w in ws]
+        ptrs = (C.c_void_p * 4)(*[C.cast(b, C.c_void_p).value for b in bufs])
+        lens = (C.c_uint32 * 4)(*[len(w) for w in ws])
+        rcs, nbs = (C.c_int * 4)(), (C.c_uint32 * 4)()
+        assert emu.emu_decode_group_v5(C.byref(d), n, y0, y1, il, ptrs, lens, nbs, rcs) == 0
+        rcs_all += [rcs[k] for k in range(n)]
+    return rcs_all
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_v5_decoder_workgroup_of_four_segments(emu, name):
+    """lep_dec5.h as a workgroup: four wavefronts = four segments, the lane-parallel phases (priors, Lakhani, IDCT + DC prediction,
+    update pass) serving all of them from 16-lane rows of one wavefront; the emulation runs the wavefronts of a phase one after
+    the other between the barriers.  Frames equal the oracle's; a file of fewer than four segments leaves wavefronts without one."""
+    jpg, _ = golden(name)
+    img = JpegImage(jpg)
+    d = img.desc
+    segs = img.plan()
+    want, _ = ob.oracle_encode(d, segs)
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    assert not any(_decode_group_v5(emu, d, segs, want))
+    for c in range(d.ncomp):
+        n = d.coded_blocks[c] * 128
+        assert C.string_at(d.blocks[c], n) == orig[c][:n]
+
+
+def test_v5_decoder_workgroup_with_unequal_and_damaged_segments(emu):
+    """eight segments of a photograph-like image (several-fold different block counts) in two workgroups, then the same with one
+    segment's stream replaced by garbage: the damaged segment ends with an exit code (or decodes garbage), its neighbours in the
+    workgroup still return the oracle's frame rows, and the workgroup's barriers are reached by every wavefront."""
+    import numpy as np
+    from lepton_amd import corpus
+
+    img = JpegImage(corpus.synth_jpeg(1920, 1080, 31, skew=2.0))
+    d = img.desc
+    segs = img.plan()
+    assert len(segs) >= 4
+    want, _ = ob.oracle_encode(d, segs)
+    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    assert not any(_decode_group_v5(emu, d, segs, want))
+    assert [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == orig
+    rng = np.random.default_rng(3)
+    bad = list(want)
+    bad[1] = bytes(rng.integers(0, 256, 300, dtype=np.uint8))
+    for c in range(d.ncomp):
+        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+    rcs = _decode_group_v5(emu, d, segs, bad)
+    assert all(rc == 0 for i, rc in enumerate(rcs) if i != 1) and rcs[1] in (0, 6, 7, 43)
+    w = d.width_blocks[0]
+    for i, s in enumerate(segs):
+        if i == 1:
+            continue
+        a, b = s.luma_y_start * w * 128, (s.luma_y_end if not s.is_last else d.height_blocks[0]) * w * 128
+        assert C.string_at(d.blocks[0], d.nblocks(0) * 128)[a:b] == orig[0][a:b], i
