@@ -329,7 +329,9 @@ int lep_file_recode_finish(lep_file *f, const lep_bytes *seg_bytes, const lep_hu
 /* Compression with verification, baseline files: the plan that writes the parsed file's scan again on the GPU from its coefficient frame
  * (lep_gpu_huffman_encode_device; images[].blocks and the segments' out_off are the caller's to set) and, per thread segment, the
  * bytes of the file it must reproduce -- the Huffman half of the reference's round-trip check (src/lepton/validation.cc:97-218),
- * executed, not argued.  *eligible = 0: the file keeps the host check (lep_jpeg_check_restores). */
+ * executed, not argued.  *eligible = 0: the file keeps the host check (lep_jpeg_check_restores).
+ * NOT a read-only call: the parsed file is lent to the plan for its duration (the tables in front of the scan are read again from the
+ * header bytes, a warning level may be set) -- the handle must not be used from another thread while it runs. */
 int lep_jpeg_plan_scan_check(lep_jpeg *j, size_t jpeg_len, lep_huff_image *image, lep_huff_segment *segs, uint32_t *file_first, uint32_t *file_len, int cap,
                              int *nseg, int *eligible);
 int lep_jpeg_scan_file_range(const lep_jpeg *j, uint32_t *first, uint32_t *len);

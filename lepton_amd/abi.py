@@ -146,6 +146,8 @@ def lib():
         L.lep_zlib0_wrap.argtypes = [C.c_char_p, C.c_size_t, P(Bytes)]
         L.lep_jpeg_check_restores.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.lep_jpeg_open_slice.argtypes = [vp, C.c_size_t, C.c_size_t, P(vp)]
+        L.lep_jpeg_plan_scan_check.argtypes = [vp, C.c_size_t, vp, vp, P(C.c_uint32), P(C.c_uint32), C.c_int, P(C.c_int), P(C.c_int)]
+        L.lep_jpeg_scan_file_range.argtypes = [vp, P(C.c_uint32), P(C.c_uint32)]
         L.lep_jpeg_open_embedded.argtypes = [vp, C.c_size_t, C.c_size_t, P(vp)]
         L.lep_batch_plan.argtypes = [P(C.c_size_t), P(C.c_size_t), C.c_int, P(BatchOptions), P(C.c_int), C.c_int]
         L.lep_jpeg_set_encode_options.argtypes = [vp, C.c_int, C.c_int, C.c_int]

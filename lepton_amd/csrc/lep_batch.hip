@@ -358,7 +358,8 @@ struct Chunk {
     std::vector<ScanCheck> vcheck;
     std::vector<char> vchecked;            // per live image: its scan goes through that check
     size_t vscan_bytes = 0;
-    bool pcheck_image(int k) const { for (const ScanCheck& p : pcheck) if ((int)p.image == k) return true; return false; }
+    std::vector<char> pchecked;            // per live image: its scans go through the progressive check (one flag per image: the writer
+                                           // used to scan `pcheck` for every image, images x scans comparisons per chunk -- ADVICE round 3)
 };
 
 Slot g_slots[2];         // one batch call at a time (the calls are not re-entrant)
@@ -729,6 +730,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         }
         // round-trip check of the progressive files the GPU decoded: their scans written again from the device frame
         c->pimg.clear(); c->pscan.clear(); c->pcheck.clear(); c->pscan_bytes = 0; c->corr_words = 0;
+        c->pchecked.assign(c->live.size(), 0);
         if (verify)
             for (size_t nk = 0; nk < c->live.size(); ++nk) {
                 const int k = old_k[nk];
@@ -745,6 +747,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                     c->corr_words += sc.corr_cap;
                     c->pscan.push_back(sc);
                     c->pcheck.push_back(ScanCheck{sc.out_off, (uint64_t)praw_off[k][q], pchk[k].len[q], (uint32_t)nk});
+                    c->pchecked[nk] = 1;
                 }
                 c->pimg.push_back(pi);
             }
@@ -893,7 +896,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                     else if (!rc && (flags[k] & 2)) rc = LEP_BUFFER_TOO_SMALL;
                     // a baseline file the GPU decoded whose scan could not go through the check above: the per-file path restores
                     // it on the host and compares (nothing is released on an argument)
-                    else if (!rc && !host_parsed[i] && !c->vchecked[k] && !c->pcheck_image(k)) rc = LEP_BUFFER_TOO_SMALL;
+                    else if (!rc && !host_parsed[i] && !c->vchecked[k] && !c->pchecked[k]) rc = LEP_BUFFER_TOO_SMALL;
                 }
                 if (!rc) rc = lep_jpeg_write_lep(parsed[i], 0, strs, s1 - s0, &outs[i]);
                 // the Huffman half of the reference's round-trip check for the files whose scans the host parser took (their

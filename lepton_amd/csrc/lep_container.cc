@@ -497,8 +497,8 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
         // for the sections behind it: "PAD marker not found" unless the header itself is refused first.  The same verdicts from
         // what the file holds plus a short zero tail, without the allocation.
         const size_t have = left();
-        jf.hdr.assign(have + 16, 0);
-        read_full(jf.hdr.data(), have);
+        jf.hdr.assign(have + std::min<size_t>((size_t)hdrs - std::min<size_t>(have, hdrs), 16), 0);   // never longer than the claim
+        read_full(jf.hdr.data(), std::min<size_t>(have, hdrs));
         memset(jf.qtables, 0, sizeof jf.qtables);
         if (!setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;
         return EX_UNSUPPORTED_JPEG;
@@ -508,8 +508,10 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
         // per request).  The reference zero-fills the claim and interprets it; what follows is decided by the bytes that exist
         // plus at most one marker segment reaching into the zeros, and nothing is left for the "P0D" section behind it: the
         // same verdicts from the backed bytes and a zero tail of two maximal segments, without the allocation.
+        // (the tail is the rest of the claim where that is shorter -- the reference's buffer is exactly the claim, and a last marker
+        // segment reaching past it is refused there: ADVICE round 3)
         const size_t have = left();
-        jf.hdr.assign(have + 2 * 65540, 0);
+        jf.hdr.assign(have + std::min<size_t>((size_t)hdrs - have, 2 * 65540), 0);
         read_full(jf.hdr.data(), have);
         memset(jf.qtables, 0, sizeof jf.qtables);
         if (!setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;

@@ -94,7 +94,7 @@ WDEV uint32_t spread4(uint32_t m) { return (m * 0x00204081u) & 0x01010101u; }   
 WDEV uint32_t haszero(uint32_t v) { return (v - 0x01010101u) & ~v & 0x80808080u; }   // != 0 iff some byte of v is zero
 
 // ---- LDS ---------------------------------------------------------------------------------------------------------------------
-constexpr int kQCap = 96;   // update-queue entries per segment (a typical block queues ~45; a full queue is flushed by its own wavefront)
+constexpr int kQCap = 128;   // update-queue entries per segment (a typical block queues ~45; a full queue is flushed by its own wavefront)
 struct Ctl5 {
     int32_t active;        // the segment has a block in flight
     int32_t cur;           // ring slot of the block in flight (blk[cur] = here, blk[cur ^ 1] = left; abv[cur] = above, abv[cur ^ 1] = above-left)
@@ -163,7 +163,8 @@ struct Wave5 {
     // the walk over the segment's rows (lepton_codec.hh:41-100)
     uint32_t idx;
     int comp, ci, w, yb, x, x_end;
-    bool has_above, top[3];
+    bool has_above;
+    uint32_t not_top;   // bit c: a row of component c has been decoded in this segment
     int16_t* row;
     const int16_t* arow;
     NSum* nrow;
@@ -298,7 +299,7 @@ struct Dec5Group {
         if (!m) return;
         const int n = lepwave::popc64(m);
         int qn = (int)uni((uint32_t)S.c.qn);
-        if (qn + n > kQCap) { LSYNC(); update_pass(1u << w); qn = 0; }
+        if (qn + n > kQCap) { LSYNC(); flush_own(w); qn = 0; }
         LANES(l) {
             if (L(used)) {
                 const int at = qn + lepwave::rank_below(m, l);
@@ -309,8 +310,18 @@ struct Dec5Group {
         LSYNC();
     }
 
+    // a segment's own wavefront empties its queue (a block with more entries than the queue holds: dense images).  Not inlined: the
+    // seven push sites of a block would each carry a copy of the pass, and the kernel's hot code should fit the instruction cache.
+#if LEP_ON_GPU
+    static __attribute__((noinline)) __device__ void flush_cold(Dec5Shared<NW>* sh_, uint32_t* m0, size_t stride, int w) { update_pass_on(sh_, m0, stride, 1u << w); }
+#else
+    static void flush_cold(Dec5Shared<NW>* sh_, uint32_t* m0, size_t stride, int w) { update_pass_on(sh_, m0, stride, 1u << w); }
+#endif
+    WDEV void flush_own(int w) { flush_cold(sh, model0, model_stride, w); }
+    WDEV void update_pass(uint32_t segmask) { update_pass_on(sh, model0, model_stride, segmask); }
     // lane = entry of any of the segments in `segmask`: counts bumped, probabilities recomputed, record stored
-    WDEV void update_pass(uint32_t segmask) {
+    static WDEV void update_pass_on(Dec5Shared<NW>* sh, uint32_t* model0, size_t model_stride, uint32_t segmask) {
+        LEP_MARK("update");
         int cnt[NW], total = 0;
         for (int q = 0; q < NW; ++q) { cnt[q] = ((segmask >> q) & 1) ? (int)uni((uint32_t)sh->seg[q].c.qn) : 0; total += cnt[q]; }
         if (!total) return;
@@ -320,14 +331,14 @@ struct Dec5Group {
             LV(uint32_t*, rec);
             LANES(l) {
                 int e = base + l, q = 0;
-                for (int k = 0; k + 1 < NW; ++k) if (e >= cnt[q] && q == k) { e -= cnt[q]; ++q; }
+                for (int k = 0; k + 1 < NW; ++k) if (q == k && e >= cnt[k]) { e -= cnt[k]; ++q; }
                 const int live = base + l < total;
                 uint32_t x = 0, f = 0, t = 0;
                 uint32_t* r = nullptr;
                 if (live) {
                     const U4 en = sh->seg[q].qe[e];
                     x = en.x; f = en.y; t = en.z;
-                    r = wv_model(q) + (x & 0xffffu) * 3;
+                    r = model0 + (size_t)q * model_stride + (x & 0xffffu) * 3;
                 }
                 L(e0) = x; L(cF) = f; L(cT) = t; L(on) = live; L(rec) = r; L(rel) = live && ((x >> 24) & 1);
             }
@@ -360,9 +371,10 @@ struct Dec5Group {
         LANES(l) if (l < NW && ((segmask >> l) & 1)) sh->seg[l].c.qn = 0;
         LSYNC();
     }
-    // model of segment q of the group (P lanes reach every segment's model: the pointers are kept in LDS-free form)
-    uint32_t* model_of[NW];
-    WDEV uint32_t* wv_model(int q) const { return model_of[q]; }
+    // model of segment q of the group (the update pass reaches every segment's): the segments of a workgroup are neighbours in the
+    // launch's model arena
+    uint32_t* model0;
+    size_t model_stride;
 
     // ---- S phases ---------------------------------------------------------------------------------------------------------------
     // round 1: the 6-bit count of interior non-zeros (model.hh:463-485): the whole tree, one record per lane
@@ -754,11 +766,11 @@ struct Dec5Group {
             LANES(l) { S.q[l] = W.img->q[c][l]; S.thr[l] = W.img->min_thresh[c][l]; }
             W.w = W.img->width[c]; W.yb = r.curr_y;
             W.row = W.img->blocks[c] + (int64_t)W.yb * W.w * 64;
-            W.has_above = !W.top[c];
+            W.has_above = ((W.not_top >> c) & 1u) != 0;
             W.arow = W.has_above ? W.row - (int64_t)W.w * 64 : nullptr;
             W.nrow = W.ns + W.img->ns_offset[c] + (W.yb & 1) * W.w;
             W.narow = W.ns + W.img->ns_offset[c] + ((W.yb & 1) ^ 1) * W.w;
-            W.top[c] = false;
+            W.not_top |= 1u << c;
             const int coded_here = (int)W.img->coded_blocks[c] - W.yb * W.w;
             W.x_end = imin(W.w, coded_here < 1 ? 1 : coded_here);
             W.x = 0;
@@ -810,6 +822,7 @@ struct Dec5Group {
     // ---- P phases: a row of 16 lanes per segment ---------------------------------------------------------------------------------------
     // neighbour priors of the 49 interior positions (model.hh:852-871) -> bsr; context of the non-zero count; `here` cleared
     WDEV void p_prologue() {
+        LEP_MARK("prologue");
         LANES(l) {
             const int sg = l >> 4, i = l & 15;
             if (sg < NW && sh->seg[sg].c.active) {
@@ -844,6 +857,7 @@ struct Dec5Group {
     }
     // eob_x / eob_y (encoder.cc:246-250) and the Lakhani priors (model.hh:928-1071) of the 14 edge positions
     WDEV void p_lakhani() {
+        LEP_MARK("lakhani");
         LV(int, tx); LV(int, ty); LV(int, badf);
         LANES(l) {
             const int sg = l >> 4, i = l & 15;
@@ -893,6 +907,7 @@ struct Dec5Group {
     }
     // integer IDCT of the ACs (idct.cc:35-161; lep_v3.h idct_no_dc, 16 lanes per segment) and the DC prediction (model.hh:674-832)
     WDEV void p_idct_dcpred() {
+        LEP_MARK("idct_dcpred");
         constexpr int w1 = 2841, w2 = 2676, w3 = 2408, w5 = 1609, w6 = 1108, w7 = 565, r2 = 181;
         constexpr int w1pw7 = w1 + w7, w1mw7 = w1 - w7, w2pw6 = w2 + w6, w2mw6 = w2 - w6, w3pw5 = w3 + w5, w3mw5 = w3 - w5;
         LANES(l) {
@@ -1001,6 +1016,7 @@ struct Dec5Group {
     // wavefront right after its DC round: the walk may start a row next whose first blocks have the block just finished above them
     // (rows of one or two blocks), and what it loads must be there.
     WDEV void publish_store(int w) {
+        LEP_MARK("publish");
         Wave5& W = LEP5_WV(w);
         Seg5& S = sh->seg[w];
         const int cur = W.x & 1;
@@ -1056,7 +1072,7 @@ struct Dec5Group {
             Wave5& W = LEP5_WV(w);
             init_segment(w);
             LSYNC();
-            W.nbins = 0; W.rc = 0; W.idx = 0; W.top[0] = W.top[1] = W.top[2] = true;
+            W.nbins = 0; W.rc = 0; W.idx = 0; W.not_top = 0;
             if (W.img) {
                 W.bc.init_stream(W.stream, W.stream_len);
                 if (next_row(w)) begin_block(w);

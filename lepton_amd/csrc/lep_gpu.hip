@@ -19,6 +19,7 @@
 #include "lep_core.h"
 #include "lep_enc3.h"
 #include "lep_dec4.h"
+#include "lep_dec5.h"
 #include "lep_enc5.h"
 #include "lep_huff.h"
 #include "lep_huffdec.h"
@@ -33,6 +34,7 @@ namespace {
 // the encoder uses the dense model layout (kModelBranches words), the decoder the group-aligned one (lep3::kModelWords);
 // segments are spaced by the larger so that one arena serves both
 constexpr size_t kModelStride = lep3::kModelWords > kModelBranches ? lep3::kModelWords : kModelBranches;
+static_assert(lep5d::kModelWords5 <= kModelStride, "the v5 decoder's model fits the arena's spacing");
 
 template <uint32_t WORDS = kModelBranches>
 __device__ void reset_segment_state(uint32_t* model, NSum* ns, int ns_count, int lane) {
@@ -116,6 +118,17 @@ __global__ void lep_selftest_kernel(uint32_t* mismatches) {
     }
     if (lep3::prob_of(f, t) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);
     if (lep5::prob16(f | (t << 8)) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);   // the fold kernels' form (lep_enc5.h)
+    if (lep5d::prob8(f, t) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);             // the v5 decoder's update pass (lep_dec5.h)
+    if (f == 1 && lep5d::prob8(0, t) != 0) atomicAdd(mismatches, 1u);                    // ... and its saturated state
+    for (uint32_t obs = 0; obs < 2; ++obs) {   // v5's count rule against the packed word's: same counts, same probability afterwards
+        const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);
+        const uint32_t want = branch_update(w, (int)obs);
+        uint32_t f5 = f, t5 = t;
+        lep5d::upd_ft(f5, t5, obs);
+        const uint32_t p5 = f5 ? lep5d::prob8(f5, t5) : 0u;
+        const bool sat = f5 == 0;   // stored form of (1, 255) with probability 0
+        if ((sat ? 1u : f5) != (want & 255) || t5 != ((want >> 8) & 255) || p5 != (want >> 16)) atomicAdd(mismatches, 1u);
+    }
     for (int obs = 0; obs < 2; ++obs) {
         const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);
         if (lep3::bupd(w, obs) != branch_update(w, obs)) atomicAdd(mismatches, 1u);
@@ -149,6 +162,49 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
     bins[seg.slot] = w.nbins;
 }
 
+
+// v5 decoder (lep_dec5.h): a workgroup of NW wavefronts = NW segments; the lane-parallel phases serve all of them from 16-lane rows
+// of one wavefront, the owner updates go through a queue in LDS.  WAVES = wavefronts per SIMD the register allocation is held to.
+__device__ void reset_segment_state_v5(uint32_t* model, NSum* ns, int ns_count, int lane) {
+    uint4* m4 = reinterpret_cast<uint4*>(model);
+    const uint32_t pat[3] = {lep5d::kRecInitF, lep5d::kRecInitT, lep5d::kRecInitP};
+    for (uint32_t i = lane; i < lep5d::kThreshOff5 / 4; i += 64) {   // records: the three words repeat (the padding behind them too)
+        const uint32_t b = (4 * i) % 3;
+        m4[i] = make_uint4(pat[b], pat[(b + 1) % 3], pat[(b + 2) % 3], pat[b]);
+    }
+    const uint4 init = make_uint4(kBranchInit, kBranchInit, kBranchInit, kBranchInit);
+    for (uint32_t i = lep5d::kThreshOff5 / 4 + lane; i < lep5d::kModelWords5 / 4; i += 64) m4[i] = init;
+    uint32_t* n32 = reinterpret_cast<uint32_t*>(ns);
+    const uint32_t words = (uint32_t)ns_count * (sizeof(NSum) / 4);
+    for (uint32_t i = lane; i < words; i += 64) n32[i] = 0;
+}
+template <int NW, int WAVES>
+__global__ __launch_bounds__(64 * NW, WAVES) void lep_decode_v5_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
+                                                                uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
+                                                                uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins, int nseg) {
+    __shared__ lep5d::Dec5Shared<NW> sh;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int s = (int)blockIdx.x * NW + wave;
+    lep5d::Dec5Group<NW> g;
+    lep5d::Wave5& W = g.wv[0];
+    W.img = nullptr;
+    g.model0 = models + (size_t)blockIdx.x * NW * kModelStride;
+    g.model_stride = kModelStride;
+    if (s < nseg) {
+        W.seg = segs[s];
+        W.img = images + W.seg.image;
+        W.model = models + (size_t)s * kModelStride;
+        W.ns = ns_area + ns_offsets[s];
+        W.stream = streams + W.seg.stream_off;
+        W.stream_len = stream_len[W.seg.slot];
+        reset_segment_state_v5(W.model, W.ns, W.img->ns_total, lane);
+    }
+    __syncthreads();
+    g.run(&sh);
+    if (lane != 0 || s >= nseg) return;
+    status[W.seg.slot] = W.rc;
+    bins[W.seg.slot] = W.nbins;
+}
 
 // ---- the split-phase encoder (lep_enc5.h) -------------------------------------------------------------------------------------
 // walk: one or two wavefronts per segment (count / emit / gather share the code; NW = 2: lep_enc5.h Walk5); LDS: two transposed
@@ -356,6 +412,11 @@ struct lep_gpu {
     int enc_pair_max = 1280; // launches of up to this many segments take the two-wave encoder: its 128-thread workgroups are resident 6 per
                              // CU (1536 on the chip), one pass; measured (profiles/r02d_latency_sweep.json, 4K images): 1 .. 128 images
                              // 300-343 ms against 450-496 ms for one wavefront per segment, 256 images 650 against 510.  LEP_ENC_PAIR_MAX
+    int dec5 = 0;            // LEP_DEC5=1: lep_dec5.h (workgroups of segments, shared lane-parallel phases) instead of lep_dec4.h.  Measured
+                             // (MI355X, 1024 x 4K, profiles/r05d_*, r05e_*): 1208 ms per launch against 1118 -- the phases it shares are a
+                             // sixth of the block's instructions, its barriers cost more than that -- so it is not the default
+    int dec5_group = 4;      // LEP_DEC5_GROUP = 1 | 4: segments (= wavefronts) per workgroup of the v5 decoder
+    int dec5_group_min = 16; // LEP_DEC5_GROUP_MIN: launches of fewer segments take one wavefront per workgroup
     int dec_waves = 0;       // register-budget build of the decoder: 0 = by batch size (8 waves per SIMD / 64 VGPRs once a launch can
                              // fill them, else 4 / 128 VGPRs, no spills); LEP_DEC_WAVES = 4 | 8 forces one
     std::string err;
@@ -562,6 +623,21 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     // carries the caller's index for the results.
     const bool permute = nseg > 8;
     std::vector<int> order(nseg);
+    const int dec_group = DEC ? (g->dec5 ? (g->dec5_group > 1 && nseg >= g->dec5_group_min ? g->dec5_group : 1) : 0) : 0;
+    if (dec_group > 1) {
+        // The v5 decoder takes four consecutive segments of the launch order as one workgroup, whose wavefronts meet at a barrier
+        // after every phase of every block: they should have about as many blocks to go through.  Segments sorted by their block
+        // count (largest first: the long ones start first), groups of four dealt round-robin -- workgroup b lands on XCD b % 8, so
+        // every XCD gets the same mix.
+        std::vector<int64_t> wgt(nseg);
+        for (int s = 0; s < nseg; ++s) {
+            const ImageDev& im = himg[segs[s].image];
+            const int y1 = segs[s].is_last ? im.height[0] : segs[s].luma_y_end;
+            wgt[s] = (int64_t)(y1 - segs[s].luma_y_start) * im.width[0];
+        }
+        for (int s = 0; s < nseg; ++s) order[s] = s;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wgt[a] > wgt[b]; });
+    } else
     if (permute) {
         std::vector<int> q[8];
         int rank = 0;
@@ -615,8 +691,20 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         // build, which does not spill, is faster)
         int waves = g->dec_waves;
         if (!waves) waves = nseg > 4608 ? 8 : 4;
+#define LEP_LAUNCH_DEC5(NW, W)                                                                                                 \
+    hipLaunchKernelGGL((lep_decode_v5_kernel<NW, W>), dim3((nseg + NW - 1) / NW), dim3(64 * NW), 0, st, (const ImageDev*)(meta + o_img), \
+                       (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns), \
+                       d_streams, d_stream_len, d_status, g->d_bins, nseg)
+        if (dec_group == 4) {
+            if (waves >= 8) { g->last_kernel = "lep_decode_v5_kernel<4, 8>"; LEP_LAUNCH_DEC5(4, 8); }
+            else { g->last_kernel = "lep_decode_v5_kernel<4, 4>"; LEP_LAUNCH_DEC5(4, 4); }
+        } else if (dec_group == 1) {
+            if (waves >= 8) { g->last_kernel = "lep_decode_v5_kernel<1, 8>"; LEP_LAUNCH_DEC5(1, 8); }
+            else { g->last_kernel = "lep_decode_v5_kernel<1, 4>"; LEP_LAUNCH_DEC5(1, 4); }
+        } else
         if (waves >= 8) { g->last_kernel = "lep_decode_v4_kernel<8>"; LEP_LAUNCH_DEC4(8); }
         else { g->last_kernel = "lep_decode_v4_kernel<4>"; LEP_LAUNCH_DEC4(4); }
+#undef LEP_LAUNCH_DEC5
 #undef LEP_LAUNCH_DEC4
     } else {
 #define LEP_LAUNCH_ENC3(W)                                                                                                     \
@@ -671,6 +759,9 @@ static void release_all_at_exit() {
 int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
+    if (const char* e = getenv("LEP_DEC5")) g->dec5 = atoi(e);
+    if (const char* e = getenv("LEP_DEC5_GROUP")) g->dec5_group = atoi(e) == 1 ? 1 : 4;
+    if (const char* e = getenv("LEP_DEC5_GROUP_MIN")) g->dec5_group_min = atoi(e);
     if (const char* e = getenv("LEP_DEC_WAVES")) g->dec_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
     if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 0));
     if (const char* e = getenv("LEP_ENC_PAIR_MAX")) g->enc_pair_max = atoi(e);

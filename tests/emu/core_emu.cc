@@ -173,7 +173,11 @@ static int run_group_v5(const lep_image_desc* d, int nseg, const int* y0, const 
     ImageDev img;
     int rc = derive_image(*d, &img, false);
     if (rc) return rc;
-    std::vector<std::vector<uint32_t>> models(NW);
+    std::vector<uint32_t> arena((size_t)NW * lep5d::kModelWords5, kBranchInit);   // the segments' models are neighbours, as in a launch
+    struct View { uint32_t* p; void assign(size_t, uint32_t) {} uint32_t& operator[](size_t i) { return p[i]; } uint32_t* data() { return p; } };
+    std::vector<View> models(NW);
+    for (int w = 0; w < NW; ++w) models[w].p = arena.data() + (size_t)w * lep5d::kModelWords5;
+
     std::vector<std::vector<NSum>> nss(NW);
     std::vector<PaddedStream> ps;
     ps.reserve(NW);
@@ -182,7 +186,6 @@ static int run_group_v5(const lep_image_desc* d, int nseg, const int* y0, const 
     for (int w = 0; w < NW; ++w) {
         lep5d::Wave5& W = g.wv[w];
         W.img = nullptr;
-        g.model_of[w] = nullptr;
         if (w >= nseg) continue;
         models[w].assign(lep5d::kModelWords5, kBranchInit);
         for (uint32_t i = 0; i < lep5d::kGroups; ++i) { models[w][i * 3] = lep5d::kRecInitF; models[w][i * 3 + 1] = lep5d::kRecInitT; models[w][i * 3 + 2] = lep5d::kRecInitP; }
@@ -193,8 +196,8 @@ static int run_group_v5(const lep_image_desc* d, int nseg, const int* y0, const 
         W.seg.image = 0; W.seg.y0 = y0[w]; W.seg.y1 = y1[w]; W.seg.is_last = is_last[w]; W.seg.stream_off = 0; W.seg.stream_cap = 0; W.seg.slot = (uint32_t)w;
         W.model = models[w].data(); W.ns = nss[w].data();
         W.stream = ps.back().p; W.stream_len = len[w];
-        g.model_of[w] = W.model;
     }
+    g.model0 = arena.data(); g.model_stride = lep5d::kModelWords5;
     g.run(&sh);
     for (int w = 0; w < nseg; ++w) { if (bins) bins[w] = g.wv[w].nbins; if (rcs) rcs[w] = g.wv[w].rc; }
     return 0;

@@ -63,12 +63,25 @@ def test_gpu_1080p_equals_oracle_and_roundtrips(gpu_codec):
 
 
 def test_gpu_4k_roundtrip_property(gpu_codec):
-    """BASELINE config 2 (single 4K 4:2:0): no oracle at this size in the GPU suite -- the property is the
-    bit-exact round trip JPEG -> .lep -> JPEG plus decode(encode(frame)) == frame."""
+    """BASELINE configs[1] (single 4K 4:2:0), the exact input the headline is quoted on: the oracle's eight streams (2 s of CPU)
+    from the single-kernel encoder (a launch of 8 segments) AND from the split-phase encoder (the same image 8 times: a launch of
+    64), the oracle's streams decoded back to the frame, then the properties: bit-exact round trip JPEG -> .lep -> JPEG,
+    decode(encode(frame)) == frame, the trailer's size field."""
     jpg = corpus.synth_jpeg(3840, 2160, 1234)
     img = JpegImage(jpg)
     plan = img.plan()
     assert len(plan) == 8 and img.desc.total_blocks() == 194400
+    want, _ = ob.oracle_encode(img.desc, plan)
+    assert gpu_codec.encode([img], [plan])[0] == want
+    assert b"enc5" not in abi.lib().lep_gpu_last_kernel_name(gpu_codec.handle)
+    got = gpu_codec.encode([img] * 8, [plan] * 8)
+    assert b"enc5" in abi.lib().lep_gpu_last_kernel_name(gpu_codec.handle)
+    assert all(g == want for g in got)
+    orig = [C.string_at(img.desc.blocks[c], img.desc.nblocks(c) * 128) for c in range(3)]
+    for c in range(3):
+        C.memset(img.desc.blocks[c], 0, img.desc.nblocks(c) * 128)
+    assert not any(_gpu_decode_streams(gpu_codec, img.desc, plan, want))
+    assert [C.string_at(img.desc.blocks[c], img.desc.nblocks(c) * 128) for c in range(3)] == orig
     lep = gpu_codec.compress(jpg)
     f = LepFile(lep)
     gpu_codec.decode([f])
@@ -133,6 +146,65 @@ def test_gpu_decoder_register_budget_builds(waves, monkeypatch):
         jpg = corpus.synth_jpeg(1280, 720, 77, quality=95)
         assert codec.decompress(codec.compress(jpg)) == jpg
         assert abi.lib().lep_gpu_last_kernel_name(codec.handle).decode() in ("lep_decode_v4_kernel<%s>" % waves, "lep_huffman_encode_kernel")
+    finally:
+        codec.close()
+
+
+def _gpu_decode_streams(codec, desc, segs, streams):
+    """lep_gpu_decode_host on raw per-segment streams; returns the per-segment exit codes"""
+    n = len(segs)
+    descs = (abi.ImageDesc * 1)(desc)
+    flat = (abi.Segment * n)(*[abi.Segment(0, s.luma_y_start, s.luma_y_end, s.is_last) for s in segs])
+    keep = [C.create_string_buffer(bytes(w), max(1, len(w))) for w in streams]
+    arr = (abi.Bytes * n)()
+    for k, b in enumerate(keep):
+        arr[k].data, arr[k].len, arr[k].cap = C.cast(b, C.c_void_p).value, len(streams[k]), len(streams[k])
+    status = (C.c_int32 * n)()
+    abi.lib().lep_gpu_decode_host(codec.handle, descs, 1, flat, n, arr, status)
+    return [status[k] for k in range(n)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,kernel", [({"LEP_DEC5": "0"}, "lep_decode_v4_kernel"), ({"LEP_DEC5": "1", "LEP_DEC5_GROUP": "1"}, "lep_decode_v5_kernel<1"),
+                                        ({"LEP_DEC5": "1", "LEP_DEC5_GROUP_MIN": "1"}, "lep_decode_v5_kernel<4")])
+def test_gpu_decoder_generations_and_workgroup_forms(env, kernel, monkeypatch):
+    """the three decode kernels a launch can take -- round 2's (lep_dec4.h), lep_dec5.h with one wavefront per workgroup, and
+    lep_dec5.h with four thread segments per workgroup (forced here for launches of any size: files of 1, 2, 4 and 8 segments, so
+    workgroups with idle wavefronts and ragged last workgroups are met) -- restore the reference-written goldens byte for byte,
+    return the oracle's frame from the oracle's streams, and refuse a garbage stream in one segment without disturbing its
+    neighbours in the workgroup"""
+    import numpy as np
+    import oracle_binding as ob
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    codec = GpuCodec(0)
+    try:
+        for name in golden_cases():
+            jpg, lep = golden(name)
+            assert codec.decompress(lep) == jpg, name
+        img = JpegImage(corpus.synth_jpeg(1920, 1080, 31, skew=2.0))
+        d, segs = img.desc, img.plan()
+        assert len(segs) == 8
+        want, _ = ob.oracle_encode(d, segs)
+        orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+        for c in range(d.ncomp):
+            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+        st = _gpu_decode_streams(codec, d, segs, want)
+        assert kernel in abi.lib().lep_gpu_last_kernel_name(codec.handle).decode()
+        assert not any(st) and [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == orig
+        bad = list(want)
+        bad[5] = bytes(np.random.default_rng(3).integers(0, 256, 300, dtype=np.uint8))
+        for c in range(d.ncomp):
+            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
+        st = _gpu_decode_streams(codec, d, segs, bad)
+        assert all(rc == 0 for i, rc in enumerate(st) if i != 5) and st[5] in (0, 6, 7, 43)
+        w = d.width_blocks[0]
+        got = C.string_at(d.blocks[0], d.nblocks(0) * 128)
+        for i, s in enumerate(segs):
+            if i != 5:
+                a, b = s.luma_y_start * w * 128, (d.height_blocks[0] if s.is_last else s.luma_y_end) * w * 128
+                assert got[a:b] == orig[0][a:b], i
     finally:
         codec.close()
 
