@@ -184,16 +184,16 @@ def pmc_bound(kernel):
         return None
 
 
-def pipeline_figure(codec, jpgs, label, verify=False):
+def pipeline_figure(codec, jpgs, label, verify=False, threads=0):
     """JPEG files in host memory -> .lep files in host memory and back through the batch pipeline; one warm-up call (staging
     buffers, kernel images), one timed call each way; every file must come back bit-exact"""
     mb = sum(map(len, jpgs)) / 1e6
-    warm, st0, _ = codec.compress_batch(jpgs, verify=verify)
+    warm, st0, _ = codec.compress_batch(jpgs, verify=verify, threads=threads)
     assert not any(st0), sorted(set(st0))
-    codec.decompress_batch(warm)
+    codec.decompress_batch(warm, threads=threads)
     del warm
-    leps, st1, cs = codec.compress_batch(jpgs, verify=verify)
-    back, st2, ds = codec.decompress_batch(leps)
+    leps, st1, cs = codec.compress_batch(jpgs, verify=verify, threads=threads)
+    back, st2, ds = codec.decompress_batch(leps, threads=threads)
     assert not any(st1) and not any(st2) and back == jpgs, label + ": round trip is not bit exact"
     return {"workload": label, "jpeg_MB": round(mb, 1), "lep_MB": round(sum(map(len, leps)) / 1e6, 1), "files": len(jpgs),
             "compress_MBps": round(mb / cs["wall_s"], 1), "decompress_MBps": round(mb / ds["wall_s"], 1),
@@ -210,13 +210,14 @@ class HipDevice:
 
     name = "hip"
 
-    def __init__(self, local_rank):
+    def __init__(self, local_rank, host_threads=0):
         from lepton_amd import abi
         from lepton_amd.codec import GpuCodec
 
         self.L = abi.lib()
         self.codec = GpuCodec(local_rank)
         self.g = self.codec.handle
+        self.host_threads = host_threads   # host pool of the batch pipeline (0 = every CPU this process may use): N ranks share the host
 
     def sync(self):
         self.L.lep_gpu_sync(self.g)
@@ -225,7 +226,7 @@ class HipDevice:
         # (no lep_gpu_trim between the phases: giving the cached models and scratch back and taking smaller ones again made the 1080p
         # figure HALF as fast -- 1485 -> 737 MB/s compress, MI355X -- the device heap hands out memory in smaller pieces after 100+ GB
         # have come and gone; the library releases its caches by itself when an allocation fails)
-        return pipeline_figure(self.codec, jpgs, label, verify=verify)
+        return pipeline_figure(self.codec, jpgs, label, verify=verify, threads=self.host_threads)
 
     def resident(self, uniq, images, steps, warmup, barrier, check_parity=True, with_latency=False):
         """`images` 4K frames (the `uniq` distinct ones replicated device-to-device) and their streams resident in HBM;
@@ -397,14 +398,81 @@ class HipDevice:
                 "encode_stages_ms": [round(sum(x[i] for x in stages[-steps:]) / max(1, len(stages[-steps:])), 3) for i in range(len(stages[0]))] if stages else None}
 
 
-def mixed_corpus(n, seed0=20000, small=(1920, 1080), big=(3840, 2160)):
-    """BASELINE.json configs[3] in the shape SURVEY.md 8(d) gives it: seeds seed0.., even seeds 1080p, odd seeds 4K -- 16 distinct
-    files of each size replicated to n (generating 10,000 distinct 4K JPEGs takes the host longer than coding them)."""
+def usable_cpus():
+    """CPUs this process may use: affinity mask capped by the cgroup quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """one rank per GPU: keep the rank's host threads (file splitting, container writing) on the CPUs of the NUMA node its GPU hangs off,
+    where the kernel exposes that (/sys/bus/pci/devices/<bdf>/numa_node); returns a note for the log"""
+    try:
+        import torch
+
+        bdf = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None
+        if not bdf:
+            return "no PCI id for device %d" % local_rank
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf.lower()).read())
+        if node < 0:
+            return "device %s: no NUMA node reported" % bdf
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        mine = cpus & os.sched_getaffinity(0)
+        if not mine:
+            return "device %s on node %d: none of its CPUs allowed here" % (bdf, node)
+        os.sched_setaffinity(0, mine)
+        return "device %s on NUMA node %d: pinned to %d CPUs" % (bdf, node, len(mine))
+    except Exception as e:
+        return "not pinned (%s)" % repr(e)[:80]
+
+
+def mixed_plan(n, distinct, small=(1920, 1080), big=(3840, 2160), seed0=20000):
+    """BASELINE.json configs[3] in the shape SURVEY.md 8(d) gives it: file i is seed seed0 + (i mod distinct), even seeds the small
+    size, odd seeds the big one.  Returns [(seed, w, h)] -- every rank computes the same list without generating anything."""
+    distinct = max(2, min(distinct, n) // 2 * 2)
+    return [(seed0 + i % distinct,) + (small if (i % distinct) % 2 == 0 else big) for i in range(n)]
+
+
+def mixed_files(plan, mine, workers):
+    """the files of `plan` this rank codes, generated with `workers` processes; a file found in $LEP_CORPUS_CACHE (a directory) is read
+    from there and a new one is left there -- a box that runs the bench twice, or a node that keeps the directory, generates once"""
     from lepton_amd import corpus
 
-    a = corpus.make_corpus(16, small[0], small[1], seed0)
-    b = corpus.make_corpus(16, big[0], big[1], seed0 + 5000)
-    return [(a if i % 2 == 0 else b)[(i // 2) % 16] for i in range(n)]
+    cache = os.environ.get("LEP_CORPUS_CACHE")
+    need = sorted({plan[i] for i in mine})
+    have = {}
+    if cache:
+        os.makedirs(cache, exist_ok=True)
+        for key in need:
+            p = os.path.join(cache, "mixed_%d_%dx%d.jpg" % key)
+            if os.path.exists(p):
+                have[key] = open(p, "rb").read()
+    todo = [k for k in need if k not in have]
+    if todo:
+        jobs = [(w, h, seed, 90, False, "4:2:0", 0.0) for seed, w, h in todo]
+        if workers <= 1 or len(jobs) <= 2:
+            made = [corpus._job(j) for j in jobs]
+        else:
+            from concurrent.futures import ProcessPoolExecutor
+
+            with ProcessPoolExecutor(max_workers=min(workers, len(jobs))) as ex:
+                made = list(ex.map(corpus._job, jobs, chunksize=1))
+        for key, data in zip(todo, made):
+            have[key] = data
+            if cache:
+                tmp = os.path.join(cache, ".%d.mixed_%d_%dx%d.jpg" % ((os.getpid(),) + key))
+                open(tmp, "wb").write(data)
+                os.replace(tmp, os.path.join(cache, "mixed_%d_%dx%d.jpg" % key))
+    return [have[plan[i]] for i in mine], len(todo)
 
 
 def reference_benchmark_jpeg():
@@ -431,7 +499,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory -> host-memory pipeline measurement (lep_compress_batch / lep_decompress_batch)")
     ap.add_argument("--e2e-images", type=int, default=2688)   # 3 pipeline chunks of 896 images = 7168 thread segments each
-    ap.add_argument("--mixed-images", type=int, default=1024, help="size of the mixed 1080p / 4K corpus of the strong-scaling figure (0 = skip)")
+    ap.add_argument("--mixed-images", type=int, default=-1, help="size of the mixed 1080p / 4K corpus of the strong-scaling figure (0 = skip; default: 10000 -- BASELINE.json configs[3] -- from 8 ranks on, 1024 below)")
+    ap.add_argument("--mixed-distinct", type=int, default=-1, help="distinct files in the mixed corpus (default: as many as the ranks' host CPUs generate in about a minute: all of them at 8 ranks x 16+ CPUs, 32 on a small host)")
     ap.add_argument("--mixed-shapes", default="1920x1080,3840x2160", help="the two image sizes of the mixed corpus (tests use small ones)")
     args = ap.parse_args()
 
@@ -462,7 +531,9 @@ def main():
 
         dev = bench_stub.StubDevice(local_rank)
     else:
-        dev = HipDevice(local_rank)
+        if world > 1:
+            log("[rank %d] %s" % (rank, pin_to_gpu_numa_node(local_rank)))
+        dev = HipDevice(local_rank, host_threads=max(1, usable_cpus() // world) if world > 1 else 0)
 
     def barrier():
         if dist:
@@ -481,19 +552,25 @@ def main():
 
     # ---- strong scaling (BASELINE.json configs[3]): ONE mixed 1080p / 4K corpus, the same list on every rank, dealt by JPEG
     # bytes; every rank pushes its share through the host-memory pipeline; no data-path collective
-    mixed_local = {"mixed_bytes": 0.0, "mixed_files": 0.0, "mixed_c_s_max": 0.0, "mixed_d_s_max": 0.0}
+    mixed_local = {"mixed_bytes": 0.0, "mixed_files": 0.0, "mixed_c_s_max": 0.0, "mixed_d_s_max": 0.0, "mixed_generated": 0.0}
     mixed_err = None
-    if args.mixed_images > 0:
+    mixed_n = args.mixed_images if args.mixed_images >= 0 else (10000 if world >= 8 else 1024)
+    cpus_per_rank = max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    # a 4K file takes a core ~1.5 s to synthesise, a 1080p one ~0.4 s: what a rank's cores make in about a minute
+    mixed_distinct = args.mixed_distinct if args.mixed_distinct > 0 else (mixed_n if cpus_per_rank * world * 60 >= mixed_n else 32)
+    if mixed_n > 0:
         try:
             shp = [tuple(int(v) for v in x.split("x")) for x in args.mixed_shapes.split(",")]
-            files = mixed_corpus(args.mixed_images, small=shp[0], big=shp[1])
-            sizes = [len(f) for f in files]
-            mine = shard.shard_indices(len(files), world, rank, sizes)
+            plan = mixed_plan(mixed_n, mixed_distinct, small=shp[0], big=shp[1])
+            est = [w * h for _, w, h in plan]   # dealt by pixels: a file's bytes follow its size class, and nobody has generated it yet
+            mine = shard.shard_indices(len(plan), world, rank, est)
+            files, made = mixed_files(plan, mine, cpus_per_rank)
+            log("[rank %d] mixed corpus: %d of %d files (%d generated here, %d distinct in all) in %.1fs" % (rank, len(mine), len(plan), made, len(set(plan)), time.perf_counter() - t0))
             barrier()
-            fig = dev.pipeline([files[i] for i in mine], "mixed")
-            mixed_local = {"mixed_bytes": float(sum(sizes[i] for i in mine)), "mixed_files": float(len(mine)),
+            fig = dev.pipeline(files, "mixed")
+            mixed_local = {"mixed_bytes": float(sum(map(len, files))), "mixed_files": float(len(mine)), "mixed_generated": float(made),
                            "mixed_c_s_max": fig["_cs"]["wall_s"], "mixed_d_s_max": fig["_ds"]["wall_s"]}
-            mixed_total = (len(files), sum(sizes))
+            mixed_total = (len(plan), len(set(plan)))
             del files, fig
         except Exception as e:   # the headline figure must not depend on it
             mixed_err = repr(e)[:300]
@@ -566,13 +643,15 @@ def main():
     if bins_per_image:
         bins_launch = bins_per_image * args.images
         out["bins_per_s"] = {"encode": round(bins_launch / enc_kernel_s / 1e6, 1), "decode": round(bins_launch / dec_kernel_s / 1e6, 1), "unit": "Mbins/s (per GPU, image 0's bin count x images)"}
-    if args.mixed_images > 0:
+    if mixed_n > 0:
         if mixed_err or not agg["mixed_bytes"]:
             out["mixed"] = {"error": mixed_err or "no files"}
         else:
             mmb = agg["mixed_bytes"] / 1e6
             out["mixed"] = {
-                "workload": "BASELINE.json configs[3]: %d mixed 1080p / 4K baseline JPEGs (alternating, 16 distinct of each), ONE corpus dealt to %d rank(s) by JPEG bytes (shard.shard_indices), host memory -> host memory" % (mixed_total[0], world),
+                "workload": "BASELINE.json configs[3]: %d mixed 1080p / 4K baseline JPEGs (alternating sizes, seeds 20000.., %d distinct), ONE corpus dealt to %d rank(s) by size class (shard.shard_indices over pixels), every rank generating only its own files, host memory -> host memory" % (mixed_total[0], mixed_total[1], world),
+                "distinct": mixed_total[1], "generated_by_the_ranks": int(agg.get("mixed_generated", 0)),
+                "scaling_curve": "this line is ONE point (n_gpus = %d); no 1 -> 8 curve has been measured until the driver's SCALE run exists" % world,
                 "scaling": "strong", "n_gpus": world, "files": int(agg["mixed_files"]), "jpeg_MB": round(mmb, 1),
                 "compress_MBps": round(mmb / agg["mixed_c_s_max"], 1), "decompress_MBps": round(mmb / agg["mixed_d_s_max"], 1),
                 "value": round(mmb / (agg["mixed_c_s_max"] + agg["mixed_d_s_max"]), 1),

@@ -540,15 +540,22 @@ int lep_batch_plan(const size_t* file_bytes, const size_t* frame_bytes, int n, c
             chunk_images = std::min<size_t>(1024, (live + k - 1) / k + 1);
         }
     }
+    // The first chunk's upload and scan decode have nothing to hide behind: LEP_BATCH_FIRST_CHUNK_DIV=<d> makes the first chunk of a
+    // call of several chunks 1/d of the others (measurement knob; 1 = all chunks alike, the default).
+    int first_div = 1;
+    if (auto_chunks && chunk_segments < 8192) {
+        if (const char* e = getenv("LEP_BATCH_FIRST_CHUNK_DIV")) first_div = std::max(1, atoi(e));
+    }
     int nchunks = 0;
     for (int i = 0; i < n;) {
         if (nchunks + 1 >= cap) return -1;
+        const size_t div = nchunks == 0 ? (size_t)first_div : 1;
         chunk_first[nchunks++] = i;
         size_t bytes = 0, nsegs = 0, count = 0;
         for (; i < n; ++i) {
             if (!frame_bytes[i]) continue;
             const size_t fb = (frame_bytes[i] + 255) & ~(size_t)255, sg = segments_guess(i);
-            if (count && (bytes + fb > chunk_budget || count >= chunk_images || nsegs + sg > chunk_segments)) break;
+            if (count && (bytes + fb > chunk_budget || count >= std::max<size_t>(chunk_images / div, 1) || nsegs + sg > std::max<size_t>(chunk_segments / div, 8))) break;
             bytes += fb; nsegs += sg; ++count;
         }
     }

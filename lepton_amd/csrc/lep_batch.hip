@@ -711,7 +711,10 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 // stream space: segments are cut by equal JPEG bytes, not blocks, so the segment's own scan bytes (+ 25 %)
                 // are the measure; the per-block term covers progressive files, whose hand-offs only count the first scan.
                 // What still overflows is redone per file (end of this function).
-                const size_t by_bytes = (size_t)ho[q].segment_size + ho[q].segment_size / 4, by_blocks = blocks * 40 / ns;
+                // (baseline files take the byte measure alone: the per-block term made a 4K segment's slot 1 MB for 0.2 MB of stream,
+                // and the whole arena comes down in one copy)
+                const bool prog = lep_jpeg_is_progressive(parsed[c->live[k]]) != 0;
+                const size_t by_bytes = (size_t)ho[q].segment_size + ho[q].segment_size / 4, by_blocks = prog ? blocks * 40 / ns : 0;
                 c->segs.push_back(sg[q]);
                 c->offs.push_back(c->offs.back() + ((std::max(by_bytes, by_blocks) + 65536 + 255) & ~(size_t)255));
             }
@@ -864,15 +867,28 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             HIPOK(hipMemcpyAsync(sts.data(), s->d_status, (size_t)nseg * (verify ? 8 : 4), hipMemcpyDeviceToHost, s_down));
             if (verify) HIPOK(hipMemcpyAsync(flags.data(), s->d_flags, (size_t)nimg * 4, hipMemcpyDeviceToHost, s_down));
             HIPOK(hipStreamSynchronize(s_down));
-            // pinned mirror packed by the bytes actually written
-            size_t total = 0;
-            for (int k = 0; k < nseg; ++k) { hoff[k] = total; if (!sts[k]) total += ((size_t)lens[k] + 15) & ~(size_t)15; }
-            if (int rc = slot_reserve(s, 0, 0, 0, 0, false, total + 256)) { rc_all = rc; break; }
-            for (int k = 0; k < nseg; ++k)
-                if (!sts[k] && lens[k]) {
-                    HIPOK(hipMemcpyAsync(s->h_streams + hoff[k], s->d_streams + c->offs[k], lens[k], hipMemcpyDeviceToHost, s_down));
-                    st.d2h_bytes += lens[k];
-                }
+            // The streams come down in ONE copy of the arena as it lies on the device (every segment's slot is its JPEG bytes + 25 %, so
+            // the slack costs a quarter more PCIe bytes) instead of one copy per segment: 7168 copies of ~200 KB took 250 ms per chunk
+            // where their bytes need 30 (kernel + copy trace, profiles/r05b_*) -- and the last chunk's are the call's tail.  An arena
+            // that is mostly slack (refused segments, tiny files in generous slots) keeps the packed form.
+            size_t total = 0, live_bytes = 0;
+            for (int k = 0; k < nseg; ++k) if (!sts[k]) live_bytes += lens[k];
+            const size_t extent = nseg ? (size_t)c->offs[nseg] : 0;
+            const bool whole = extent <= 2 * live_bytes + ((size_t)1 << 20);
+            if (whole) {
+                for (int k = 0; k < nseg; ++k) hoff[k] = (size_t)c->offs[k];
+                if (int rc = slot_reserve(s, 0, 0, 0, 0, false, extent + 256)) { rc_all = rc; break; }
+                if (extent) HIPOK(hipMemcpyAsync(s->h_streams, s->d_streams, extent, hipMemcpyDeviceToHost, s_down));
+                st.d2h_bytes += (double)extent;
+            } else {
+                for (int k = 0; k < nseg; ++k) { hoff[k] = total; if (!sts[k]) total += ((size_t)lens[k] + 15) & ~(size_t)15; }
+                if (int rc = slot_reserve(s, 0, 0, 0, 0, false, total + 256)) { rc_all = rc; break; }
+                for (int k = 0; k < nseg; ++k)
+                    if (!sts[k] && lens[k]) {
+                        HIPOK(hipMemcpyAsync(s->h_streams + hoff[k], s->d_streams + c->offs[k], lens[k], hipMemcpyDeviceToHost, s_down));
+                        st.d2h_bytes += lens[k];
+                    }
+            }
             HIPOK(hipStreamSynchronize(s_down));
         }
         // containers on the host pool, in the background
@@ -1177,6 +1193,25 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                         if (plens[q]) { HIPOK(hipMemcpyAsync(s->h_pscan + poff[q], s->d_pscan + c->pscan[q].out_off, plens[q], hipMemcpyDeviceToHost, s_down)); st.d2h_bytes += plens[q]; }
                 }
             }
+            // the scan bytes of the GPU-coded files come down in one copy of the arena range they lie in (same reasoning as the
+            // compressor's streams: 8195 copies per chunk took 370 ms), unless that range is mostly slack
+            size_t scan_lo = ~(size_t)0, scan_hi = 0, scan_live = 0;
+            for (int k = 0; k < nimg; ++k) {
+                if (c->pfirst[k] >= 0 || c->hfirst[k] < 0) continue;
+                const int h0 = c->hfirst[k], h1 = h0 + (c->seg_first[k + 1] - c->seg_first[k]);
+                bool ok = true;
+                for (int q = h0; q < h1; ++q) if (slens[q] >= c->hslot[q] && c->hslot[q] < c->hbound[q]) ok = false;
+                if (!ok) continue;
+                for (int q = h0; q < h1; ++q) if (slens[q]) {
+                    scan_lo = std::min<size_t>(scan_lo, c->hseg[q].out_off); scan_hi = std::max<size_t>(scan_hi, (size_t)c->hseg[q].out_off + slens[q]);
+                    scan_live += slens[q];
+                }
+            }
+            const bool scan_whole = scan_hi > scan_lo && scan_hi - scan_lo <= 2 * scan_live + ((size_t)1 << 20);
+            if (scan_whole) {
+                HIPOK(hipMemcpyAsync(s->h_scan + scan_lo, s->d_scan + scan_lo, scan_hi - scan_lo, hipMemcpyDeviceToHost, s_down));
+                st.d2h_bytes += (double)(scan_hi - scan_lo);
+            }
             for (int k = 0; k < nimg; ++k) {
                 if (c->pfirst[k] >= 0) continue;
                 bool on_gpu = c->hfirst[k] >= 0;
@@ -1188,7 +1223,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                         if (int rc = host_frames_reserve(s, c->frame_bytes)) { rc_all = rc; break; }
                         lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
                     }
-                    else for (int q = h0; q < h1; ++q)
+                    else if (!scan_whole) for (int q = h0; q < h1; ++q)
                         if (slens[q]) { HIPOK(hipMemcpyAsync(s->h_scan + c->hseg[q].out_off, s->d_scan + c->hseg[q].out_off, slens[q], hipMemcpyDeviceToHost, s_down)); st.d2h_bytes += slens[q]; }
                 }
                 if (!on_gpu) {

@@ -737,6 +737,14 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     return 0;
 }
 
+// The HIP runtime multiplexes a process's streams onto a few hardware queues -- four per device unless GPU_MAX_HW_QUEUES says
+// otherwise -- and two streams that share one run their work one after the other.  The batch pipeline keeps seven streams busy (copies
+// up, copies down, two coder launches, the scan decoder at raised priority, the split-phase encoder's two side streams): in the kernel
+// and copy trace of round 4 (profiles/r05b_*, r05c_*) the encoder's gather and write parts, which overlap in a process with three
+// streams, alternated strictly, and a chunk's upload waited for the previous chunk's decode kernel.  Eight queues unless the
+// environment already chose; read by the runtime when it initialises, i.e. before this library's first HIP call.
+__attribute__((constructor)) static void lep_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" {
 
 // Process exit.  The HIP runtime registers its own teardown with atexit() lazily, at the first HIP call -- i.e. AFTER the

@@ -71,3 +71,29 @@ def test_under_torchrun_the_ranks_are_the_launcher_s(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_gpus_8_codes_the_ten_thousand_file_corpus_once(tmp_path):
+    """BASELINE.json configs[3] at its stated size before an 8-GPU node exists: `bench.py --gpus 8` starts
+    eight ranks, every rank generates ONLY its own share of the 10,000 distinct files (seeds 20000..29999, dealt by size class -- no
+    rank needs the others' bytes to know its share), the line says n_gpus 8, mixed.files 10000, and that one point is not a curve."""
+    out, notes = run_bench(tmp_path, ["--gpus", "8", "--mixed-images", "10000", "--mixed-distinct", "10000", "--mixed-shapes", "32x24,64x48", "--no-end-to-end"])
+    assert out["n_gpus"] == 8
+    mixed = [n for n in notes if n["what"] == "pipeline" and n["label"].startswith("mixed")]
+    assert sorted(n["rank"] for n in mixed) == list(range(8))
+    assert sum(n["files"] for n in mixed) == 10000 == out["mixed"]["files"] and out["mixed"]["distinct"] == 10000
+    assert out["mixed"]["generated_by_the_ranks"] == 10000               # every file made exactly once, on the rank that codes it
+    assert len({n["digest"] for n in mixed}) == 8
+    b = [n["bytes"] for n in mixed]
+    assert max(b) / (sum(b) / 8) < 1.1
+    assert "no 1 -> 8 curve" in out["mixed"]["scaling_curve"] and out["mixed"]["n_gpus"] == 8
+
+
+def test_the_corpus_cache_is_filled_once(tmp_path):
+    """LEP_CORPUS_CACHE: a second run on the same box reads the mixed corpus instead of generating it"""
+    cache = str(tmp_path / "corpus")
+    out1, _ = run_bench(tmp_path, ["--gpus", "2"], {"LEP_CORPUS_CACHE": cache})
+    n = len(os.listdir(cache))
+    assert out1["mixed"]["generated_by_the_ranks"] == n == out1["mixed"]["distinct"]
+    out2, _ = run_bench(tmp_path, ["--gpus", "2"], {"LEP_CORPUS_CACHE": cache})
+    assert out2["mixed"]["generated_by_the_ranks"] == 0 and out2["mixed"]["jpeg_MB"] == out1["mixed"]["jpeg_MB"]
