@@ -155,13 +155,19 @@ def cpu_baseline(jpgs, budget_s=20.0):
 
 def pmc_traffic(kernel, images):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 passes (profiles/pmc_traffic.json: memory-side request
-    counters TCC_EA0_RDREQ x 64 B + TCC_EA0_WRREQ by size, separate --pmc passes, scripts/gpu_r2_visit1.sh), scaled from that
-    run's batch to this one; None when the kernel has not been through a PMC pass.  A table lookup, not a measurement of this
-    run: the entry names the kernel build it was taken from."""
+    counters TCC_EA0_RDREQ x 64 B + TCC_EA0_WRREQ by size, separate --pmc passes, scripts/gpu_r3_final.sh) FOR THE LAUNCH SIZE THAT
+    WAS MEASURED: the table is kept per images-per-launch (1024, 256) and a launch of another size gets None -- the decoder's bytes
+    per block double between 256 and 1024 images (its model falls out of L2), so scaling one figure linearly to another batch is
+    wrong.  A table lookup, not a measurement of this run: the entry names the kernel build it was taken from."""
     try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-        per_image = table[kernel.split("<")[0]]["hbm_bytes_per_image"]
-        return int(per_image * images)
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        name = kernel.split("<")[0]
+        by = t.get("by_images_per_launch")
+        if by is not None:
+            e = by.get(str(images), {}).get(name)
+            return int(e["hbm_bytes_per_launch"]) if e else None
+        e = t["kernels"][name]   # a table from before round 4: one launch size
+        return int(e["hbm_bytes_per_launch"]) if int(e.get("images_per_launch", t.get("images_per_launch", 0))) == images else None
     except Exception:
         return None
 
@@ -638,7 +644,7 @@ def main():
                      "encode_kernel_ms": round(enc_kernel_s * 1e3, 3), "decode_kernel_ms": round(dec_kernel_s * 1e3, 3),
                      "kernels": names, "per_kernel": per_kernel,
                      "encode_stages_ms": dict(zip(("count_plan", "emit", "fold", "gather", "write"), res["encode_stages_ms"])) if res.get("encode_stages_ms") else None, "bound_by": pmc_bound(names.get(dominant, "")),
-                     "note": "frac = algorithmic bytes (128 B per block + stream bytes) / kernel time / 8 TB/s; traffic = HBM bytes from the memory-side request counters of the committed PMC passes (profiles/pmc_traffic.json), scaled to this batch -- `traffic_source.stale` says whether those passes were taken from the kernel sources measured here; bound_by = what those passes say limits the kernel (DESIGN.md 4)"},
+                     "note": "frac = algorithmic bytes (128 B per block + stream bytes) / kernel time / 8 TB/s; traffic = HBM bytes from the memory-side request counters of the committed PMC passes (profiles/pmc_traffic.json) for THIS launch size (null for a size that was not measured: never scaled) -- `traffic_source.stale` says whether those passes were taken from the kernel sources measured here; bound_by = what those passes say limits the kernel (DESIGN.md 4)"},
     }
     if bins_per_image:
         bins_launch = bins_per_image * args.images

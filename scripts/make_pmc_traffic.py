@@ -83,7 +83,25 @@ if dec:
     v = small[dec[0]]
     note_256 = {"images_per_launch": 256, "read_sectors_per_block": round(v.get("TCC_EA0_RDREQ_sum", 0) / (256 * BLOCKS_4K), 1),
                 "l2_hit_rate": round(v.get("TCC_HIT_sum", 0) / ((v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0)) or 1.0), 3)}
+# the same table for the 256-image launch (request counters only: bytes counted at 64 per request, no 32-byte split) -- bench.py
+# looks a launch size up here and reports no traffic figure for a size that was not measured (it used to scale the 1024-image
+# figure linearly; the decoder's bytes per block DOUBLE between 256 and 1024 images)
+def small_entry(v):
+    rd, wr = v.get("TCC_EA0_RDREQ_sum", 0.0), v.get("TCC_EA0_WRREQ_sum", 0.0)
+    hit, miss = v.get("TCC_HIT_sum", 0.0), v.get("TCC_MISS_sum", 0.0)
+    return {"kernel_source_sha16": sha, "images_per_launch": 256, "hbm_bytes_per_launch": 64.0 * (rd + wr), "hbm_bytes_per_image": 64.0 * (rd + wr) / 256,
+            "read_sectors_per_block": round(rd / (256 * BLOCKS_4K), 1), "write_requests_per_block": round(wr / (256 * BLOCKS_4K), 1),
+            "bound": {"l2_hit_rate": round(hit / ((hit + miss) or 1.0), 3)}, "note": "64 B per request assumed (no 32-byte split in this pass)"}
+kernels_256 = {k.split("<")[0] if k.startswith("lep_decode") else k: small_entry(v) for k, v in small.items() if "TCC_EA0_RDREQ_sum" in v}
+enc5s = [k for k in small if k.startswith("lep_enc5_")]
+if enc5s:
+    tot = collections.defaultdict(float)
+    for k in enc5s:
+        for c, x in small[k].items():
+            tot[c] += x
+    kernels_256["lep_enc5 (count | emit | fold | gather | write)"] = small_entry(tot)
 json.dump({
+    "by_images_per_launch": {"1024": kernels, "256": kernels_256},
     "source": "rocprofv3 --pmc, five separate passes (SQ wave time; SQ instruction counts; TCC_EA0_RDREQ / WRREQ / HIT / MISS; WRREQ_64B / RDREQ_32B / REQ / READ; "
               "the request counters again at 256 images), --kernel-trace only -- python bench.py --steps 1 --warmup 0 --no-extras --no-end-to-end --no-cpu-baseline "
               "--mixed-images 0 (scripts/gpu_r3_final.sh, scripts/make_pmc_traffic.py; raw sums: pmc_summary.json beside this file's source in profiles/)",
