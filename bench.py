@@ -216,13 +216,14 @@ class HipDevice:
 
     name = "hip"
 
-    def __init__(self, local_rank, host_threads=0):
+    def __init__(self, local_rank, host_threads=0, trim=False):
         from lepton_amd import abi
         from lepton_amd.codec import GpuCodec
 
         self.L = abi.lib()
         self.codec = GpuCodec(local_rank)
         self.g = self.codec.handle
+        self.trim = trim   # --trim-between-phases: give the cached workspaces back before every phase (a serving process whose batches differ in size does)
         self.host_threads = host_threads   # host pool of the batch pipeline (0 = every CPU this process may use): N ranks share the host
 
     def sync(self):
@@ -232,6 +233,8 @@ class HipDevice:
         # (no lep_gpu_trim between the phases: giving the cached models and scratch back and taking smaller ones again made the 1080p
         # figure HALF as fast -- 1485 -> 737 MB/s compress, MI355X -- the device heap hands out memory in smaller pieces after 100+ GB
         # have come and gone; the library releases its caches by itself when an allocation fails)
+        if self.trim:
+            self.L.lep_gpu_trim(self.g)
         return pipeline_figure(self.codec, jpgs, label, verify=verify, threads=self.host_threads)
 
     def resident(self, uniq, images, steps, warmup, barrier, check_parity=True, with_latency=False):
@@ -503,6 +506,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trim-between-phases", action="store_true", help="lep_gpu_trim before every pipeline phase (measures what giving the workspaces back costs)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory -> host-memory pipeline measurement (lep_compress_batch / lep_decompress_batch)")
     ap.add_argument("--e2e-images", type=int, default=2688)   # 3 pipeline chunks of 896 images = 7168 thread segments each
     ap.add_argument("--mixed-images", type=int, default=-1, help="size of the mixed 1080p / 4K corpus of the strong-scaling figure (0 = skip; default: 10000 -- BASELINE.json configs[3] -- from 8 ranks on, 1024 below)")
@@ -539,7 +543,7 @@ def main():
     else:
         if world > 1:
             log("[rank %d] %s" % (rank, pin_to_gpu_numa_node(local_rank)))
-        dev = HipDevice(local_rank, host_threads=max(1, usable_cpus() // world) if world > 1 else 0)
+        dev = HipDevice(local_rank, host_threads=max(1, usable_cpus() // world) if world > 1 else 0, trim=args.trim_between_phases)
 
     def barrier():
         if dist:

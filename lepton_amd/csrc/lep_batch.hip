@@ -874,7 +874,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             size_t total = 0, live_bytes = 0;
             for (int k = 0; k < nseg; ++k) if (!sts[k]) live_bytes += lens[k];
             const size_t extent = nseg ? (size_t)c->offs[nseg] : 0;
-            const bool whole = extent <= 2 * live_bytes + ((size_t)1 << 20);
+            const bool whole = extent <= 3 * live_bytes + ((size_t)1 << 20);
             if (whole) {
                 for (int k = 0; k < nseg; ++k) hoff[k] = (size_t)c->offs[k];
                 if (int rc = slot_reserve(s, 0, 0, 0, 0, false, extent + 256)) { rc_all = rc; break; }
@@ -1207,7 +1207,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                     scan_live += slens[q];
                 }
             }
-            const bool scan_whole = scan_hi > scan_lo && scan_hi - scan_lo <= 2 * scan_live + ((size_t)1 << 20);
+            const bool scan_whole = scan_hi > scan_lo && scan_hi - scan_lo <= 3 * scan_live + ((size_t)1 << 20);
             if (scan_whole) {
                 HIPOK(hipMemcpyAsync(s->h_scan + scan_lo, s->d_scan + scan_lo, scan_hi - scan_lo, hipMemcpyDeviceToHost, s_down));
                 st.d2h_bytes += (double)(scan_hi - scan_lo);

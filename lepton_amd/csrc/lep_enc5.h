@@ -406,7 +406,9 @@ struct BoolEnc5 {
     int nst;            // how many (0..3 between flushes)
     uint8_t* out;
     uint32_t pos, cap;  // bytes handed to memory (written when below cap)
-    WDEV void init(uint8_t* o, uint32_t c) { out = o; cap = c; pos = 0; low = 0; q24 = 254u << 24; count = -24; stage = 0; nst = 0; }
+    uint32_t floor_;    // the first byte that is this writer's own (a chunk of a stream, see the chunked writer below): a carry that
+    uint32_t carry_out; // would ripple below it is counted here instead and added when the chunks are stitched
+    WDEV void init(uint8_t* o, uint32_t c) { out = o; cap = c; pos = 0; low = 0; q24 = 254u << 24; count = -24; stage = 0; nst = 0; floor_ = 0; carry_out = 0; }
     // boolwriter.hh:48-118 without the byte output.  split = 1 + (((range - 1) * prob) >> 8); with the state kept as
     // (range - 1) << 24 that product's high word IS split - 1, and the normalised next range is n << clz(n): the dependent chain of
     // a bin is mul_hi -> add / sub -> select -> clz -> shift-add, five instructions (every lane waits out this chain 2.4 million
@@ -428,8 +430,9 @@ struct BoolEnc5 {
     // a carry out of the staged bytes: back through the 0xFF bytes in memory (the serial writer's ripple; rare)
     WDEV void ripple() {
         uint32_t x = pos;
-        while (x > 0 && (x > cap || out[x - 1] == 0xffu)) { if (x <= cap) out[x - 1] = 0; --x; }
-        if (x > 0) out[x - 1] = (uint8_t)(out[x - 1] + 1);
+        while (x > floor_ && (x > cap || out[x - 1] == 0xffu)) { if (x <= cap) out[x - 1] = 0; --x; }
+        if (x > floor_) out[x - 1] = (uint8_t)(out[x - 1] + 1);
+        else if (floor_) ++carry_out;   // (x == 0 in a whole stream: the carry of a code value that cannot be, as in the serial writer)
     }
     // every whole byte above the 24 + (count & 7) bits the recurrence still works on joins the staged ones -- a carry is just
     // the top bit of what is added -- and four staged bytes at a time go to memory
@@ -532,6 +535,154 @@ WDEV void write_wave(const SegPlan5* plans, const uint16_t* bins, const SegDev* 
     }
 }
 
+
+// ---- write, stitched: lane = a CHUNK of a segment's bins --------------------------------------------------------------------
+// A launch of few segments leaves the lane-per-segment writer above with a handful of busy lanes on the whole chip and one serial
+// chain of 2.3 million bins each (144 ms whatever the launch).  The stream is the big-endian number sum_i add_i * 2^(-T_i) (add_i =
+// split, what a 1-bit adds to `low`; T_i = the shifts before bin i), so a stretch of bins can be coded by itself and ADDED in -- if
+// the stretch knows (a) the range it starts with and (b) T at its start.  Both come from the range recurrence alone, which forgets
+// its past: two runs over the same bins from different start ranges fall into step after some hundreds of bins (measured on real
+// bin lists: median 450, 99th percentile 5,000).  So, with K chunks per segment:
+//   range   lane = chunk: the recurrence alone (no `low`, no bytes) from kWarm5 bins before the chunk, started from an arbitrary
+//           range; leaves the range it reaches the chunk with (a guess), the range it ends with and the chunk's sum of shifts;
+//   link    lane = segment: walks its chunks -- a guess that is not what the chunk before ended with (rare) is redone from the
+//           right range -- and turns the sums of shifts into every chunk's T, i.e. its first output byte and bit phase;
+//   code    lane = chunk: the whole writer (BoolEnc5) from (range, T): bytes into the chunk's own stretch of the stream; what is
+//           still in `low` when the bins run out (the next 24..31 bits) is kept aside, so is a carry that would leave the stretch;
+//   stitch  lane = segment: adds every chunk's kept bits into the bytes behind it and the carries in front, ripples, applies the
+//           stream's end rule (boolwriter.cc:17-35).
+// The wavefront scan north_star names is here a scan over chunks: range states and bit offsets first, carries last.
+constexpr uint32_t kWarm5 = 16384;
+struct WChunk5 { uint32_t q_guess, q_end, shifts, q_start, t_start, keep, keep_bits, carry, pos_end, pad[7]; };   // 64 bytes
+static_assert(sizeof(WChunk5) == 64, "one record per (segment, chunk)");
+WDEV uint32_t chunk_first_bin(uint32_t nbins, int k, int K) { return (uint32_t)(((uint64_t)nbins * (uint32_t)k) / (uint32_t)K); }
+// the range recurrence of BoolEnc5::bin alone; returns the shift
+WDEV int range_step(uint32_t& q24, uint32_t bit, uint32_t prob) {
+#if LEP_ON_GPU
+    const uint32_t s = __umulhi(q24, prob);
+#else
+    const uint32_t s = (uint32_t)(((uint64_t)q24 * prob) >> 32);
+#endif
+    const uint32_t q = q24 >> 24;
+    const uint32_t n = bit ? q - s : s + 1;
+    const int f = __builtin_clz(n);
+    q24 = (n << f) - (1u << 24);
+    return f - 24;
+}
+// F(bit, prob) over bins [b0, b1) of a lane's list: whole 64-byte sectors (32 bins) as four 16-byte loads, the NEXT sector requested
+// before this one is coded (a lane's bins are its own: nothing coalesces, and a round of 32 bins is about the time of a trip to HBM);
+// the ragged head and tail bin by bin.  (A list has room to the next multiple of 128 bins: the look-ahead stays inside it.)
+// g(): called at least after every fourth bin (the writer's flush: four bins are at most 28 bits).
+template <class F, class G>
+WDEV void for_bins(const uint16_t* list, uint32_t b0, uint32_t b1, F&& f, G&& g) {
+    uint32_t i = b0;
+    for (; i < b1 && (i & 31u); ++i) { const uint32_t e = list[i]; f((e >> 8) & 1u, e & 255u); g(); }
+    if (i + 32 <= b1) {
+        const uint32_t* b = reinterpret_cast<const uint32_t*>(list);
+        U4 n0 = ld4(b + (i >> 1)), n1 = ld4(b + (i >> 1) + 4), n2 = ld4(b + (i >> 1) + 8), n3 = ld4(b + (i >> 1) + 12);
+#define LEP5_BINS8(v)                                                                                      \
+    f((v.x >> 8) & 1u, v.x & 255u); f((v.x >> 24) & 1u, (v.x >> 16) & 255u);                               \
+    f((v.y >> 8) & 1u, v.y & 255u); f((v.y >> 24) & 1u, (v.y >> 16) & 255u); g();                          \
+    f((v.z >> 8) & 1u, v.z & 255u); f((v.z >> 24) & 1u, (v.z >> 16) & 255u);                               \
+    f((v.w >> 8) & 1u, v.w & 255u); f((v.w >> 24) & 1u, (v.w >> 16) & 255u); g();
+        for (; i + 32 <= b1; i += 32) {
+            const U4 g0 = n0, g1 = n1, g2 = n2, g3 = n3;
+            const uint32_t* nx = b + (i >> 1) + 16;
+            n0 = ld4(nx); n1 = ld4(nx + 4); n2 = ld4(nx + 8); n3 = ld4(nx + 12);
+            LEP5_BINS8(g0) LEP5_BINS8(g1) LEP5_BINS8(g2) LEP5_BINS8(g3)
+        }
+#undef LEP5_BINS8
+    }
+    for (; i < b1; ++i) { const uint32_t e = list[i]; f((e >> 8) & 1u, e & 255u); g(); }
+}
+// bins [b0, b1) of `list` from range q24 (the start marker in front of bin 0 and the 32 stop bins behind the last one belong to the
+// first and the last chunk): the range afterwards, the sum of the shifts
+WDEV void range_run(const uint16_t* list, uint32_t b0, uint32_t b1, bool first, bool last, uint32_t& q24, uint32_t& shifts) {
+    uint32_t t = 0, q = q24;
+    if (first) t += (uint32_t)range_step(q, 0, 128);
+    for_bins(list, b0, b1, [&](uint32_t bit, uint32_t prob) { t += (uint32_t)range_step(q, bit, prob); }, []() {});
+    if (last) for (int i = 0; i < 32; ++i) t += (uint32_t)range_step(q, 0, 128);
+    shifts = t; q24 = q;
+}
+WDEV void wchunk_range_lane(const SegPlan5& P, const uint16_t* bins, WChunk5* rec, int k, int K, uint32_t warm = kWarm5) {
+    if (P.status) return;
+    const uint16_t* list = bins + P.bins_off;
+    const uint32_t b0 = chunk_first_bin(P.nbins, k, K), b1 = chunk_first_bin(P.nbins, k + 1, K);
+    uint32_t q24 = 254u << 24, sh = 0;
+    if (k > 0) {   // warm up: from kWarm5 bins before the chunk (or from the stream's true start, marker included, if that is nearer)
+        const bool from_start = b0 <= warm;
+        range_run(list, from_start ? 0u : b0 - warm, b0, from_start, false, q24, sh);
+    }
+    rec->q_guess = q24;
+    range_run(list, b0, b1, k == 0, k + 1 == K, q24, sh);
+    rec->q_end = q24; rec->shifts = sh;
+}
+// bytes the serial writer has handed out after a total shift of T, and its `count` then (BoolEnc5::flush: count starts at -24)
+WDEV uint32_t bytes_at(uint32_t T) { return T >= 24 ? ((T - 24) >> 3) + 1 : 0u; }
+WDEV int count_at(uint32_t T) { return (int)T - 24 - 8 * (int)bytes_at(T); }
+WDEV void wchunk_link_lane(const SegPlan5& P, const uint16_t* bins, WChunk5* recs, int K) {
+    if (P.status) return;
+    const uint16_t* list = bins + P.bins_off;
+    uint32_t T = 0, q = 254u << 24;
+    for (int k = 0; k < K; ++k) {
+        WChunk5& r = recs[k];
+        if (k > 0 && r.q_guess != q) {   // the warm-up had not fallen into step: this chunk's range run again, from the range it really starts with
+            uint32_t q24 = q, sh = 0;
+            range_run(list, chunk_first_bin(P.nbins, k, K), chunk_first_bin(P.nbins, k + 1, K), false, k + 1 == K, q24, sh);
+            r.q_end = q24; r.shifts = sh;
+        }
+        r.q_start = q; r.t_start = T;
+        q = r.q_end; T += r.shifts;
+    }
+}
+WDEV void wchunk_code_lane(const SegPlan5& P, const uint16_t* bins, const SegDev& sd, uint8_t* streams, WChunk5* rec, int k, int K) {
+    if (P.status) return;
+    const uint16_t* list = bins + P.bins_off;
+    const uint32_t b0 = chunk_first_bin(P.nbins, k, K), b1 = chunk_first_bin(P.nbins, k + 1, K);
+    BoolEnc5 bc;
+    bc.init(streams + sd.stream_off, sd.stream_cap);
+    bc.q24 = rec->q_start;
+    bc.pos = bytes_at(rec->t_start); bc.count = count_at(rec->t_start); bc.floor_ = bc.pos;
+    if (k == 0) { bc.bin(0, 128); bc.flush(); }
+    for_bins(list, b0, b1, [&](uint32_t bit, uint32_t prob) { bc.bin(bit, prob); }, [&]() { bc.flush(); });
+    bc.flush();
+    if (k + 1 == K) for (int i = 0; i < 32; ++i) { bc.bin(0, 128); if ((i & 3) == 3) bc.flush(); }
+    bc.flush();
+    for (; bc.nst; --bc.nst) { if (bc.pos < bc.cap) bc.out[bc.pos] = (uint8_t)(bc.stage >> (8 * (bc.nst - 1))); ++bc.pos; }
+    // what the recurrence still holds: the 32 + count bits behind the last byte handed out (count is -8 .. -1 after a flush)
+    rec->keep = (uint32_t)bc.low; rec->keep_bits = (uint32_t)(32 + bc.count); rec->carry = bc.carry_out; rec->pos_end = bc.pos;
+}
+// adds `v` (a carry) at byte x - 1 and below
+WDEV void add_back(uint8_t* out, uint32_t cap, uint32_t x, uint32_t v) {
+    while (v && x > 0) {
+        --x;
+        if (x < cap) { const uint32_t t = out[x] + v; out[x] = (uint8_t)t; v = t >> 8; }
+        else v = 0;   // (beyond the buffer nothing is stored: the stream is reported as too long anyway)
+    }
+}
+WDEV void wchunk_stitch_lane(const SegPlan5& P, const SegDev& sd, uint8_t* streams, uint32_t* stream_len, int32_t* status, const WChunk5* recs, int K) {
+    if (P.status) { status[sd.slot] = P.status; return; }
+    uint8_t* out = streams + sd.stream_off;
+    const uint32_t cap = sd.stream_cap;
+    for (int k = 0; k + 1 < K; ++k) {
+        const WChunk5& r = recs[k];
+        // chunk k's kept bits are the next `keep_bits` bits of the stream from byte pos_end on: a big-endian number of four bytes there
+        const uint32_t X = r.keep_bits ? r.keep << (32 - r.keep_bits) : 0u;
+        uint32_t carry = 0;
+        for (int j = 3; j >= 0; --j) {
+            const uint32_t x = r.pos_end + (uint32_t)j, add = (X >> (24 - 8 * j)) & 255u;
+            if (x < cap) { const uint32_t t = out[x] + add + carry; out[x] = (uint8_t)t; carry = t >> 8; }
+            else carry = 0;
+        }
+        add_back(out, cap, r.pos_end, carry);
+        add_back(out, cap, recs[k + 1].t_start >= 24 ? bytes_at(recs[k + 1].t_start) : 0u, recs[k + 1].carry);   // chunk k+1's carries that left its stretch
+    }
+    uint32_t pos = recs[K - 1].pos_end;
+    const bool overflow = pos >= cap;
+    if (!overflow && pos && (out[pos - 1] & 0xe0u) == 0xc0u) { out[pos] = 0; ++pos; }
+    stream_len[sd.slot] = pos;
+    if (overflow) status[sd.slot] = 100;   // LEP_BUFFER_TOO_SMALL
+}
 
 // ---- the walk: count / emit / gather -------------------------------------------------------------------------------------
 // One wavefront per segment; a TILE = up to 64 consecutive coded blocks of one block row; lane = block.  Per tile:

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -227,6 +228,24 @@ __global__ __launch_bounds__(64 * NW) void lep_enc5_walk_kernel(const ImageDev* 
         if (MODE == lep5::kGather && part + 1 == nparts) P->nbins = w.nbins;
     }
 }
+// the stitched writer (lep_enc5.h "write, stitched"): PHASE 0 range (lane = chunk), 1 link (lane = segment), 2 code (lane = chunk),
+// 3 stitch (lane = segment); K chunks per segment
+template <int PHASE>
+__global__ __launch_bounds__(64) void lep_enc5_wchunk_kernel(const lep5::SegPlan5* __restrict__ plans, const uint16_t* __restrict__ bins, const SegDev* __restrict__ segs,
+                                                         int nseg, int K, lep5::WChunk5* recs, uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* nbins_out) {
+    const int id = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (PHASE == 0 || PHASE == 2) {
+        const int seg = id / K, k = id - seg * K;
+        if (seg >= nseg) return;
+        if (PHASE == 2) __builtin_amdgcn_s_setprio(3);
+        if (PHASE == 0) lep5::wchunk_range_lane(plans[seg], bins, recs + (size_t)seg * K + k, k, K);
+        else lep5::wchunk_code_lane(plans[seg], bins, segs[seg], streams, recs + (size_t)seg * K + k, k, K);
+    } else {
+        if (id >= nseg) return;
+        if (PHASE == 1) { status[segs[id].slot] = 0; nbins_out[segs[id].slot] = plans[id].nbins; lep5::wchunk_link_lane(plans[id], bins, recs + (size_t)id * K, K); }
+        else lep5::wchunk_stitch_lane(plans[id], segs[id], streams, stream_len, status, recs + (size_t)id * K, K);
+    }
+}
 // counts -> per-segment layout (one thread per segment), then the prefix over the segments (one wavefront)
 __global__ void lep_enc5_plan_kernel(const uint32_t* __restrict__ counts, lep5::SegPlan5* plans, int nseg) {
     const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -393,7 +412,9 @@ struct lep_gpu {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     bool released = false;   // device side already given back (by lep_gpu_destroy or by the exit handler)
-    int enc5_min = 64;       // launches of at least this many segments take the split-phase encoder (lep_enc5.h); LEP_ENC5_MIN (0 = never)
+    int enc5_min = 8;        // launches of at least this many segments take the split-phase encoder (lep_enc5.h); LEP_ENC5_MIN (0 = never).  64 until
+                             // round 4: with the stitched writer a single 4K image (8 segments) takes 109 ms through it against 301 ms through the
+                             // two-wavefront single-kernel encoder (profiles/r05k_latency_stitched_writer_ab.json)
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     int huffprog_pipeline = 1;          // LEP_HUFFPROG_PIPELINE=0: progressive scan decode level by level, whatever the launch size
@@ -403,6 +424,8 @@ struct lep_gpu {
     int enc5_parts = 8;      // LEP_ENC5_PARTS: gather / write in this many parts (1..8), a part written while the next is gathered
                              // (MI355X, 1024 x 4K: 1 part 569 ms per launch, 4 parts 481, 8 parts 475)
     hipEvent_t ev_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int enc5_wchunks = 64;   // LEP_ENC5_WCHUNKS: the stitched writer for launches that leave lanes free: up to this many chunks per segment (power of
+                             // two; 0 = always the lane-per-segment writer beside gather)
     int enc5_gather_wgs = 0; // LEP_ENC5_GATHER_WGS: resident gather workgroups per CU held to this (through the LDS a launch asks for)
     int enc5_fold_apart = 0; // LEP_ENC5_FOLD_APART: the fold launches one after the other, a launch per kind of chain (for the profiler)
     size_t enc5_scratch_max = ~(size_t)0;   // LEP_ENC5_SCRATCH_MAX (bytes): a launch that needs more takes the single-kernel encoder (tests: the out-of-memory path)
@@ -421,6 +444,19 @@ struct lep_gpu {
                              // fill them, else 4 / 128 VGPRs, no spills); LEP_DEC_WAVES = 4 | 8 forces one
     std::string err;
     const char* last_kernel = "";   // name of the kernel the most recent launch used
+    // Device memory the object owns (round 4): every grow-only workspace below is a virtual address range of its own (hipMemAddressReserve)
+    // into which physical chunks of 64 MB (hipMemCreate) are mapped as it grows -- growing maps more chunks behind what is there, nothing
+    // is freed and taken again -- and a workspace that is given back (lep_gpu_trim, an allocation that fails elsewhere) is unmapped, its
+    // chunks handed to the driver; LEP_VMM=0: plain hipMalloc / hipFree as before (A/B).
+    struct VBuf { char* va = nullptr; size_t reserved = 0, mapped = 0; std::vector<hipMemGenericAllocationHandle_t> chunks; };
+    struct Vmm {
+        bool on = false;
+        size_t chunk = (size_t)64 << 20;
+        hipMemAllocationProp prop;
+        hipMemAccessDesc access;
+        std::map<void**, VBuf> bufs;   // keyed by the member that holds the workspace's pointer
+        size_t mapped_total = 0, creates = 0, releases = 0;
+    } vmm;
     // grow-only device workspace of a coder launch (models, neighbour summaries, descriptors).  There are two sets so that two
     // launches may be in flight at once on different streams (lep_gpu_use_arena: the next chunk's coder kernel starts in the
     // wave slots that the long segments of the current one leave free); everything else uses set 0.
@@ -436,6 +472,7 @@ struct lep_gpu {
         void* d_plans = nullptr; size_t plans_bytes = 0;       // SegPlan5[] | counts | totals
         void* d_entries = nullptr; size_t entries_bytes = 0;   // the chains' entry streams, records, places
         void* d_binlist = nullptr; size_t binlist_bytes = 0;   // the segments' bin lists
+        void* d_wchunks = nullptr; size_t wchunks_bytes = 0;   // the stitched writer's records, one per (segment, chunk)
     } enc5;
     hipEvent_t ev_enc5_done = nullptr;
     uint32_t* d_bins = nullptr;
@@ -464,6 +501,46 @@ struct lep_gpu {
         }                                                                                      \
     } while (0)
 
+// ---- workspaces ------------------------------------------------------------------------------------------------------------------
+static void vmm_init(lep_gpu* g) {
+    g->vmm.on = false;
+    if (const char* e = getenv("LEP_VMM")) if (atoi(e) == 0) return;
+    int ok = 0;
+    if (hipDeviceGetAttribute(&ok, hipDeviceAttributeVirtualMemoryManagementSupported, g->device) != hipSuccess || !ok) { (void)hipGetLastError(); return; }
+    memset(&g->vmm.prop, 0, sizeof g->vmm.prop);
+    g->vmm.prop.type = hipMemAllocationTypePinned;
+    g->vmm.prop.location.type = hipMemLocationTypeDevice;
+    g->vmm.prop.location.id = g->device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &g->vmm.prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { (void)hipGetLastError(); return; }
+    g->vmm.chunk = ((g->vmm.chunk + gran - 1) / gran) * gran;
+    g->vmm.access.location = g->vmm.prop.location;
+    g->vmm.access.flags = hipMemAccessFlagsProtReadWrite;
+    g->vmm.on = true;
+}
+// gives a workspace back: its chunks unmapped and released to the driver, the address range kept for the next time it grows
+static void vmm_unmap(lep_gpu* g, lep_gpu::VBuf& b) {
+    if (b.mapped) (void)hipMemUnmap(b.va, b.mapped);
+    for (hipMemGenericAllocationHandle_t h : b.chunks) { (void)hipMemRelease(h); ++g->vmm.releases; }
+    g->vmm.mapped_total -= b.mapped;
+    b.chunks.clear(); b.mapped = 0;
+}
+static void dev_release(lep_gpu* g, void** p, size_t* have) {
+    if (g->vmm.on) {
+        auto it = g->vmm.bufs.find(p);
+        if (it != g->vmm.bufs.end()) { vmm_unmap(g, it->second); *p = nullptr; if (have) *have = 0; return; }
+    }
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; if (have) *have = 0;
+}
+static void vmm_destroy(lep_gpu* g) {
+    for (auto& kv : g->vmm.bufs) {
+        vmm_unmap(g, kv.second);
+        if (kv.second.va) (void)hipMemAddressFree(kv.second.va, kv.second.reserved);
+        *kv.first = nullptr;
+    }
+    g->vmm.bufs.clear();
+}
 // before an allocation failure is reported: the cached memory no launch that is being set up depends on -- the split-phase
 // encoder's scratch (its launches take the single-kernel encoder when they cannot have it) and the other arena set's models
 static void release_idle_caches(lep_gpu* g) {
@@ -471,13 +548,46 @@ static void release_idle_caches(lep_gpu* g) {
     lep_gpu::Arena& O = g->arena[g->cur ^ 1];
     void** ps[] = {&g->enc5.d_entries, &g->enc5.d_binlist, &O.d_models, &O.d_ns};
     size_t* ns[] = {&g->enc5.entries_bytes, &g->enc5.binlist_bytes, &O.models_bytes, &O.ns_bytes};
-    for (int i = 0; i < 4; ++i) {
-        if (*ps[i]) (void)hipFree(*ps[i]);
-        *ps[i] = nullptr; *ns[i] = 0;
+    for (int i = 0; i < 4; ++i) dev_release(g, ps[i], ns[i]);
+}
+static int vmm_ensure(lep_gpu* g, void** p, size_t* have, size_t need, bool may_release) {
+    lep_gpu::Vmm& V = g->vmm;
+    lep_gpu::VBuf& b = V.bufs[p];
+    const size_t want = ((need + V.chunk - 1) / V.chunk) * V.chunk;
+    if (want > b.reserved) {   // a longer address range (what the workspace held is not kept: every launch fills it anew)
+        vmm_unmap(g, b);
+        if (b.va) (void)hipMemAddressFree(b.va, b.reserved);
+        b.va = nullptr; b.reserved = 0; *p = nullptr; *have = 0;
+        size_t res = want + want / 2;
+        res = ((std::max(res, (size_t)256 << 20) + V.chunk - 1) / V.chunk) * V.chunk;
+        void* va = nullptr;
+        HIPCHK(g, hipMemAddressReserve(&va, res, 0, nullptr, 0));
+        b.va = (char*)va; b.reserved = res;
     }
+    const size_t old = b.mapped;
+    while (b.mapped < want) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, V.chunk, &V.prop, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            bool again = false;
+            if (may_release) { may_release = false; release_idle_caches(g); again = hipMemCreate(&h, V.chunk, &V.prop, 0) == hipSuccess; if (!again) (void)hipGetLastError(); }
+            if (!again) {   // no room: what this call mapped is given back, the workspace stays as it was
+                while (b.mapped > old) { b.mapped -= V.chunk; (void)hipMemUnmap(b.va + b.mapped, V.chunk); (void)hipMemRelease(b.chunks.back()); b.chunks.pop_back(); ++V.releases; V.mapped_total -= V.chunk; }
+                g->err = "hipMemCreate: out of device memory";
+                return LEP_GPU_ERROR;
+            }
+        }
+        ++V.creates;
+        if (hipMemMap(b.va + b.mapped, V.chunk, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); g->err = "hipMemMap failed"; return LEP_GPU_ERROR; }
+        b.chunks.push_back(h); b.mapped += V.chunk; V.mapped_total += V.chunk;
+    }
+    if (b.mapped > old) HIPCHK(g, hipMemSetAccess(b.va + old, b.mapped - old, &V.access, 1));
+    *p = b.va; *have = b.mapped;
+    return 0;
 }
 static int ensure(lep_gpu* g, void** p, size_t* have, size_t need, bool may_release = true) {
     if (*have >= need) return 0;
+    if (g->vmm.on) return vmm_ensure(g, p, have, need, may_release);
     if (*p) HIPCHK(g, hipFree(*p));
     *p = nullptr; *have = 0;
     size_t want = need + need / 8;
@@ -580,6 +690,23 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join3, 0));
         HIPCHK(g, hipEventRecord(g->ev_stage[3], st));
+        // A launch that leaves most of the chip's lanes free takes the stitched writer: K chunks per segment, chosen so that the
+        // launch has at most 4096 chunk lanes (K = 64 for one image, 32 for 8, 2 for 256; from 512 images on the lane-per-segment writer
+        // beside gather is the faster one: measured, profiles/r05k_*); its four small kernels run behind the whole gather.
+        int K = 0;
+        if (g->enc5_wchunks >= 2) { K = 1; while (K * 2 <= g->enc5_wchunks && (long)nseg * K * 2 < 8192) K *= 2; }
+        if (K >= 2 && ensure(g, &E.d_wchunks, &E.wchunks_bytes, (size_t)nseg * K * sizeof(lep5::WChunk5) + 256, false)) { (void)hipGetLastError(); g->err.clear(); K = 0; }
+        if (K >= 2) {
+            for (int part = 0; part < nparts; ++part) walk(lep5::kGather, (uint8_t*)E.d_entries, (uint16_t*)E.d_binlist, part);
+            HIPCHK(g, hipEventRecord(g->ev_stage[4], st));
+            lep5::WChunk5* recs = (lep5::WChunk5*)E.d_wchunks;
+            const int lane_groups = (int)(((long)nseg * K + 63) / 64);
+#define LEP_WCHUNK(PHASE, GRID) hipLaunchKernelGGL((lep_enc5_wchunk_kernel<PHASE>), dim3(GRID), dim3(64), 0, st, (const lep5::SegPlan5*)plans, (const uint16_t*)E.d_binlist, d_seg, nseg, K, recs, d_streams, d_stream_len, d_status, g->d_bins)
+            LEP_WCHUNK(0, lane_groups); LEP_WCHUNK(1, groups); LEP_WCHUNK(2, lane_groups); LEP_WCHUNK(3, groups);
+#undef LEP_WCHUNK
+            HIPCHK(g, hipEventRecord(g->ev_stage[5], st));
+            g->nstage = 5;
+        } else {
         // gather and write in parts (tile ranges of every segment): the writer is 128 wavefronts that take the same time whatever the
         // batch -- part k is written (second stream) while part k + 1 is gathered
         for (int part = 0; part < nparts; ++part) {
@@ -594,6 +721,7 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
         HIPCHK(g, hipEventRecord(g->ev_stage[5], st));
         g->nstage = 5;
+        }
     }
     HIPCHK(g, hipEventRecord(g->ev_enc5_done, st));
     HIPCHK(g, hipGetLastError());
@@ -780,11 +908,13 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
     if (const char* e = getenv("LEP_ENC5_GATHER_WGS")) g->enc5_gather_wgs = atoi(e);
     if (const char* e = getenv("LEP_ENC5_PARTS")) g->enc5_parts = atoi(e);
+    if (const char* e = getenv("LEP_ENC5_WCHUNKS")) g->enc5_wchunks = atoi(e);
     if (const char* e = getenv("LEP_ENC5_SCRATCH_MAX")) g->enc5_scratch_max = (size_t)strtoull(e, nullptr, 10);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&g->stream) != hipSuccess ||
         hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess) { delete g; return LEP_GPU_ERROR; }
+    vmm_init(g);
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         g_live.push_back(g);
@@ -799,8 +929,7 @@ static void release_device_side(lep_gpu* g) {
     g->released = true;
     (void)hipSetDevice(g->device);
     (void)hipStreamSynchronize(g->stream);
-    for (void* p : {g->enc5.d_plans, g->enc5.d_entries, g->enc5.d_binlist})
-        if (p) (void)hipFree(p);
+    for (void** p : {&g->enc5.d_plans, &g->enc5.d_entries, &g->enc5.d_binlist, &g->enc5.d_wchunks}) dev_release(g, p, nullptr);
     if (g->ev_enc5_done) (void)hipEventDestroy(g->ev_enc5_done);
     for (auto& e : g->ev_part) if (e) (void)hipEventDestroy(e);
     for (auto& e : g->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -809,8 +938,10 @@ static void release_device_side(lep_gpu* g) {
     if (g->ev_join3) (void)hipEventDestroy(g->ev_join3);
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     if (g->stream3) (void)hipStreamDestroy(g->stream3);
-    for (void* p : {g->arena[0].d_models, g->arena[0].d_ns, g->arena[0].d_meta, g->arena[1].d_models, g->arena[1].d_ns, g->arena[1].d_meta, g->d_blocks, g->d_streams, g->d_lens, g->d_huff, g->d_huffprog[0], g->d_huffprog[1], g->d_huffprogdec, g->d_huffdec, g->d_huffpar, g->d_scan, g->d_scanlen})
-        if (p) (void)hipFree(p);
+    for (void** p : {&g->arena[0].d_models, &g->arena[0].d_ns, &g->arena[0].d_meta, &g->arena[1].d_models, &g->arena[1].d_ns, &g->arena[1].d_meta, &g->d_blocks, &g->d_streams, &g->d_lens, &g->d_huff,
+                     &g->d_huffprog[0], &g->d_huffprog[1], &g->d_huffprogdec, &g->d_huffdec, &g->d_huffpar, &g->d_scan, &g->d_scanlen})
+        dev_release(g, p, nullptr);
+    vmm_destroy(g);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -1080,10 +1211,7 @@ int lep_gpu_trim(lep_gpu* g) {
     HIPCHK(g, hipDeviceSynchronize());
     void** ps[] = {&g->enc5.d_entries, &g->enc5.d_binlist, &g->arena[0].d_models, &g->arena[1].d_models, &g->arena[0].d_ns, &g->arena[1].d_ns};
     size_t* ns[] = {&g->enc5.entries_bytes, &g->enc5.binlist_bytes, &g->arena[0].models_bytes, &g->arena[1].models_bytes, &g->arena[0].ns_bytes, &g->arena[1].ns_bytes};
-    for (int i = 0; i < 6; ++i) {
-        if (*ps[i]) (void)hipFree(*ps[i]);
-        *ps[i] = nullptr; *ns[i] = 0;
-    }
+    for (int i = 0; i < 6; ++i) dev_release(g, ps[i], ns[i]);
     return 0;
 }
 int lep_gpu_malloc(lep_gpu* g, size_t bytes, void** dptr) {

@@ -458,6 +458,60 @@ extern "C" int emu_check_bool_writer5(int trials) {
 }
 
 
+// the stitched writer (lep_enc5.h: range / link / code / stitch over K chunks of a bin list) against lepdev::BoolCoder<false>: bin
+// lists of up to 40,000 bins in the six flavours above, K = 2 .. 64, warm-ups from 8 bins (every guess wrong: the link pass redoes
+// the chunks) to longer than the list (every chunk warmed up from the stream's start), tiny buffers.  Returns 0 or 1 + the trial;
+// *redone counts the chunks whose guessed start range was wrong.
+extern "C" int emu_check_stitched_writer5(int trials, int* redone) {
+    uint64_t rs = 0x2545F4914F6CDD1Dull;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 11); };
+    std::vector<uint8_t> a(1 << 17), b(1 << 17);
+    int wrong = 0;
+    for (int trial = 0; trial < trials; ++trial) {
+        const int n = (int)(rnd() % (trial % 7 == 0 ? 40000 : 3000)), mode = trial % 6;
+        std::vector<uint16_t> bins((size_t)n + 256, 0);
+        for (int i = 0; i < n; ++i) {
+            uint32_t p, bit;
+            if (mode == 0) { p = rnd() % 256; bit = rnd() & 1; }
+            else if (mode == 1) { p = 1 + rnd() % 3; bit = (rnd() % 8) != 0; }
+            else if (mode == 2) { p = 250 + rnd() % 6; bit = (rnd() % 8) == 0; }
+            else if (mode == 3) { p = 128; bit = 1; }
+            else if (mode == 4) { p = rnd() % 256; bit = (rnd() % 256) < p ? 0 : 1; }
+            else { p = (rnd() & 1) ? 255 : 1; bit = rnd() & 1; }
+            bins[(size_t)i] = (uint16_t)(p | (bit << 8));
+        }
+        const uint32_t cap = (trial % 50 == 0) ? rnd() % 200 : 1u << 17;
+        memset(a.data(), 0xAA, a.size()); memset(b.data(), 0xBB, b.size());
+        lepdev::BoolCoder<false> ref;
+        ref.init_stream(a.data(), cap);
+        for (int i = 0; i < n; ++i) ref.put(bins[(size_t)i] >> 8, bins[(size_t)i] & 255);
+        const uint32_t la = ref.finish();
+        const int K = 2 << (rnd() % 6);
+        const uint32_t warms[5] = {8, 64, 700, 16384, 1u << 20};
+        const uint32_t warm = warms[rnd() % 5];
+        lep5::SegPlan5 P;
+        memset(&P, 0, sizeof P);
+        P.nbins = (uint32_t)n; P.bins_off = 0; P.status = 0;
+        SegDev sd;
+        memset(&sd, 0, sizeof sd);
+        sd.stream_off = 0; sd.stream_cap = cap; sd.slot = 0;
+        std::vector<lep5::WChunk5> recs((size_t)K);
+        memset(recs.data(), 0, recs.size() * sizeof(lep5::WChunk5));
+        for (int k = 0; k < K; ++k) lep5::wchunk_range_lane(P, bins.data(), &recs[(size_t)k], k, K, warm);
+        for (int k = 1; k < K; ++k) wrong += recs[(size_t)k].q_guess != recs[(size_t)k - 1].q_end;   // (before link: against the unlinked ends -- an upper bound)
+        lep5::wchunk_link_lane(P, bins.data(), recs.data(), K);
+        for (int k = K - 1; k >= 0; --k) lep5::wchunk_code_lane(P, bins.data(), sd, b.data(), &recs[(size_t)k], k, K);   // any order: the chunks do not meet
+        uint32_t lb = 0;
+        int32_t stt = 0;
+        lep5::wchunk_stitch_lane(P, sd, b.data(), &lb, &stt, recs.data(), K);
+        const bool ov = stt == 100;
+        if (ref.overflow != ov) return 1 + trial;
+        if (!ov && (la != lb || memcmp(a.data(), b.data(), la))) return 1 + trial;
+    }
+    if (redone) *redone = wrong;
+    return 0;
+}
+
 // the 16-bit Branch of the fold lanes (lep5::upd16 / prob16) against the packed word of lep_core.h (branch_update): random walks
 // with every bias, long enough to saturate either way and to renormalise; returns 0 or 1 + the walk that differed
 extern "C" int emu_check_branch16(int walks) {

@@ -1252,6 +1252,16 @@ def test_deferred_bool_writer_equals_the_serial_one(emu):
     assert emu.emu_check_bool_writer5(12000) == 0
 
 
+def test_stitched_bool_writer_equals_the_serial_one(emu):
+    """the stitched writer (lep_enc5.h: range / link / code / stitch -- a stream coded as K chunks whose start ranges are guessed from
+    a warm-up, whose bit offsets come out of a scan over the chunks, and whose bytes are added together with their carries) writes the
+    bytes of lepdev::BoolCoder<false> for 4,000 bin lists (to 40,000 bins, K = 2..64, warm-ups from 8 bins -- where nearly every guess
+    is wrong and the link pass redoes the chunk -- to longer than the list), overflow verdicts included"""
+    redone = C.c_int(0)
+    assert emu.emu_check_stitched_writer5(4000, C.byref(redone)) == 0
+    assert redone.value > 1000      # the wrong-guess path was walked
+
+
 def test_sixteen_bit_branch_equals_the_packed_word(emu):
     """the fold lanes keep a Branch as two counts (lep5::upd16 / prob16, the saturated-true state as t = 0): same probabilities
     as lepdev::branch_update (branch.hh:82-100) along 900 random walks of every bias, saturation and renormalisation included"""

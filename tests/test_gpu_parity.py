@@ -72,11 +72,27 @@ def test_gpu_4k_roundtrip_property(gpu_codec):
     plan = img.plan()
     assert len(plan) == 8 and img.desc.total_blocks() == 194400
     want, _ = ob.oracle_encode(img.desc, plan)
-    assert gpu_codec.encode([img], [plan])[0] == want
-    assert b"enc5" not in abi.lib().lep_gpu_last_kernel_name(gpu_codec.handle)
-    got = gpu_codec.encode([img] * 8, [plan] * 8)
+    assert gpu_codec.encode([img], [plan])[0] == want           # split-phase encoder, stitched writer at 64 chunks per segment
     assert b"enc5" in abi.lib().lep_gpu_last_kernel_name(gpu_codec.handle)
+    got = gpu_codec.encode([img] * 8, [plan] * 8)               # ... at 32 chunks per segment
     assert all(g == want for g in got)
+    for env in ({"LEP_ENC5_MIN": "0"}, {"LEP_ENC5_WCHUNKS": "0"}):   # the single-kernel encoder; the lane-per-segment writer beside gather
+        import os
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            other = GpuCodec(0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        try:
+            assert other.encode([img], [plan])[0] == want
+            assert (b"enc5" in abi.lib().lep_gpu_last_kernel_name(other.handle)) == ("LEP_ENC5_WCHUNKS" in env)
+        finally:
+            other.close()
     orig = [C.string_at(img.desc.blocks[c], img.desc.nblocks(c) * 128) for c in range(3)]
     for c in range(3):
         C.memset(img.desc.blocks[c], 0, img.desc.nblocks(c) * 128)
@@ -539,14 +555,16 @@ def test_gpu_decoder_follows_the_reference_on_impossible_edge_counts(gpu_codec, 
         assert C.string_at(f.desc.blocks[c], n) == orig[c][:n]
 
 
-@pytest.fixture(scope="module", params=[2, 1], ids=["two_wavefronts_per_segment", "one_wavefront_per_segment"])
+@pytest.fixture(scope="module", params=[(2, 64), (1, 64), (2, 0), (2, 4)], ids=["two_wavefronts_per_segment", "one_wavefront_per_segment", "lane_per_segment_writer", "four_chunks_per_segment"])
 def gpu_codec_v5(request):
     """a codec object that takes the split-phase encoder (lep_enc5.h) for every launch, however small; its walks with two
-    wavefronts per segment (the default) and with one"""
+    wavefronts per segment (the default) and with one; its writer stitched from up to 64 chunks per segment (the default for
+    small launches), from 4, and as one lane per segment"""
     import os
-    old = {k: os.environ.get(k) for k in ("LEP_ENC5_MIN", "LEP_ENC5_WAVES")}
+    old = {k: os.environ.get(k) for k in ("LEP_ENC5_MIN", "LEP_ENC5_WAVES", "LEP_ENC5_WCHUNKS")}
     os.environ["LEP_ENC5_MIN"] = "1"
-    os.environ["LEP_ENC5_WAVES"] = str(request.param)
+    os.environ["LEP_ENC5_WAVES"] = str(request.param[0])
+    os.environ["LEP_ENC5_WCHUNKS"] = str(request.param[1])
     try:
         return GpuCodec(0)
     finally:
