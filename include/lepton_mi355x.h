@@ -224,11 +224,15 @@ int lep_gpu_huffman_decode_parallel_device(lep_gpu *g, const lep_huffdec_image *
  * kernels against integer division, src/vp8/model/branch.hh:82-125).  0 = exact everywhere. */
 int lep_gpu_selftest(lep_gpu *g);
 /* Gives back the device memory the object caches between launches (per-segment models, neighbour rings, the split-phase
- * encoder's scratch: ~140 MB per 4K image of the largest launch so far).  The next launch re-acquires what it needs.  The
- * library does this itself before it reports an allocation failure; a caller that keeps large buffers of its own beside the
- * codec calls it between phases.  Waits for the device.  Not for routine use: memory taken again after 100+ GB were given back
- * was measured to serve the kernels slower (bench.py's 1080p pipeline figure: half the rate after a trim). */
+ * encoder's scratch: ~140 MB per 4K image of the largest launch so far) -- to the object's own POOL: the workspaces are virtual
+ * address ranges into which 64 MB chunks are mapped, a trimmed workspace is unmapped and its chunks wait for the next workspace that
+ * grows (of whatever kind).  Cheap in both directions (96 GB: 19 ms to unmap, 14 ms to map again) -- what is NOT cheap is taking
+ * memory from the driver, which clears it: ~40 ms per GB (hipMalloc of 96 GB: 3 - 4 s); round 3 measured that as "memory serves
+ * the kernels slower after a trim".  Waits for the device. */
 int lep_gpu_trim(lep_gpu *g);
+/* lep_gpu_trim, and the pool handed to the driver: for a process that wants the device's memory for something else.  (The
+ * library does this itself before it reports an allocation failure of its staging.) */
+int lep_gpu_release_memory(lep_gpu *g);
 /* Profiling builds (-DLEP_PROF) only: per-phase shader-clock totals [64 segments][32 slots] of the last decoder launch. */
 int lep_gpu_debug_prof(lep_gpu *g, uint64_t *out);
 int lep_gpu_malloc(lep_gpu *g, size_t bytes, void **dptr);

@@ -153,7 +153,7 @@ static hipError_t dev_alloc(void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipErrorOutOfMemory && g_batch_gpu) {
         (void)hipGetLastError();
-        (void)lep_gpu_trim(g_batch_gpu);
+        (void)lep_gpu_release_memory(g_batch_gpu);
         e = hipMalloc(p, bytes);
     }
     if (e != hipSuccess) *p = nullptr;

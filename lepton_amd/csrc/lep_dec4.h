@@ -1016,10 +1016,8 @@ struct Dec4Wave {
         init_tables();
         bc.init_stream(stream, len);
         bool top[3] = {true, true, true};
-        SegmentCoder<false> sched;   // only its row schedule is used (lepton_codec.hh:41-100)
-        sched.img = image;
         for (uint32_t idx = 0;; ++idx) {
-            SegmentCoder<false>::RowSpec r = sched.row_spec(idx);
+            RowSpec r = row_spec(image, idx);
             if (r.done) break;
             if (r.luma_y >= seg.y1 && !seg.is_last) break;
             if (r.skip) continue;

@@ -753,10 +753,8 @@ struct Dec5Group {
     WDEV bool next_row(int w) {
         Wave5& W = LEP5_WV(w);
         Seg5& S = sh->seg[w];
-        SegmentCoder<false> sched;   // only its row schedule is used
-        sched.img = W.img;
         for (;; ++W.idx) {
-            const SegmentCoder<false>::RowSpec r = sched.row_spec(W.idx);
+            const RowSpec r = row_spec(W.img, W.idx);
             if (r.done) return false;
             if (r.luma_y >= W.seg.y1 && !W.seg.is_last) return false;
             if (r.skip) continue;

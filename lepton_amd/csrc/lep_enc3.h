@@ -673,10 +673,8 @@ struct Enc3Wave {
     WDEV int run_rows(const SegDev& seg, NSum* ns) {
         const ImageDev* image = img;
         bool top[3] = {true, true, true};
-        SegmentCoder<false> sched;   // only its row schedule is used
-        sched.img = image;
         for (uint32_t idx = 0;; ++idx) {
-            SegmentCoder<false>::RowSpec r = sched.row_spec(idx);
+            RowSpec r = row_spec(image, idx);
             if (r.done) break;
             if (r.luma_y >= seg.y1 && !seg.is_last) break;
             if (r.skip) continue;

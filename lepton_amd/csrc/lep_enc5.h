@@ -899,12 +899,11 @@ struct Walk5 {
         SegDev seg;
         NSum* ns;
         bool top[3];
-        SegmentCoder<false> sched;
         uint32_t idx;
         int row_x0, row_blocks;
         TileDesc rowd;
         WDEV void init(const ImageDev* image, const SegDev& s, NSum* n) {
-            img = image; seg = s; ns = n; top[0] = top[1] = top[2] = true; sched.img = image; idx = 0; row_x0 = 0; row_blocks = 0; rowd = TileDesc{};
+            img = image; seg = s; ns = n; top[0] = top[1] = top[2] = true; idx = 0; row_x0 = 0; row_blocks = 0; rowd = TileDesc{};
         }
         WDEV bool next(TileDesc* t) {
             for (;;) {
@@ -915,7 +914,7 @@ struct Walk5 {
                     row_x0 += 64;
                     return true;
                 }
-                SegmentCoder<false>::RowSpec r = sched.row_spec(idx++);
+                RowSpec r = row_spec(img, idx++);
                 if (r.done) return false;
                 if (r.luma_y >= seg.y1 && !seg.is_last) return false;
                 if (r.skip) continue;

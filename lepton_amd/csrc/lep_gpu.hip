@@ -446,8 +446,13 @@ struct lep_gpu {
     const char* last_kernel = "";   // name of the kernel the most recent launch used
     // Device memory the object owns (round 4): every grow-only workspace below is a virtual address range of its own (hipMemAddressReserve)
     // into which physical chunks of 64 MB (hipMemCreate) are mapped as it grows -- growing maps more chunks behind what is there, nothing
-    // is freed and taken again -- and a workspace that is given back (lep_gpu_trim, an allocation that fails elsewhere) is unmapped, its
-    // chunks handed to the driver; LEP_VMM=0: plain hipMalloc / hipFree as before (A/B).
+    // is freed and taken again.  A workspace that is given back (lep_gpu_trim) is unmapped and its chunks go to the object's POOL, from
+    // which the next workspace that grows takes them: memory moves between the encoder's scratch, the decoder's models and the rings
+    // without passing through the driver.  Why that matters (MI355X, scripts/proto/vmm_costs.hip, profiles/r05m_*): the driver CLEARS
+    // what it hands out -- hipMalloc of 96 GB takes 2.9 - 4.1 s, hipMemCreate the same per byte -- while unmapping 96 GB of chunks takes
+    // 19 ms and mapping them again 14 ms.  Round 3's "2x cliff" after a trim was the next launch paying ~40 ms per GB for ~140 GB again.
+    // Only lep_gpu_release_memory (and an allocation that fails elsewhere) hands the pool to the driver.  LEP_VMM=0: plain hipMalloc /
+    // hipFree as before (A/B).
     struct VBuf { char* va = nullptr; size_t reserved = 0, mapped = 0; std::vector<hipMemGenericAllocationHandle_t> chunks; };
     struct Vmm {
         bool on = false;
@@ -455,6 +460,8 @@ struct lep_gpu {
         hipMemAllocationProp prop;
         hipMemAccessDesc access;
         std::map<void**, VBuf> bufs;   // keyed by the member that holds the workspace's pointer
+        std::vector<hipMemGenericAllocationHandle_t> pool;   // chunks of workspaces that were given back (lep_gpu_trim): unmapped, still ours --
+                                                             // the next workspace that grows, of whatever kind, maps them again
         size_t mapped_total = 0, creates = 0, releases = 0;
     } vmm;
     // grow-only device workspace of a coder launch (models, neighbour summaries, descriptors).  There are two sets so that two
@@ -518,12 +525,19 @@ static void vmm_init(lep_gpu* g) {
     g->vmm.access.flags = hipMemAccessFlagsProtReadWrite;
     g->vmm.on = true;
 }
-// gives a workspace back: its chunks unmapped and released to the driver, the address range kept for the next time it grows
-static void vmm_unmap(lep_gpu* g, lep_gpu::VBuf& b) {
+// gives a workspace back: its chunks unmapped and pooled (or released to the driver), the address range kept for the next time it grows
+static void vmm_unmap(lep_gpu* g, lep_gpu::VBuf& b, bool to_driver = false) {
     if (b.mapped) (void)hipMemUnmap(b.va, b.mapped);
-    for (hipMemGenericAllocationHandle_t h : b.chunks) { (void)hipMemRelease(h); ++g->vmm.releases; }
+    for (hipMemGenericAllocationHandle_t h : b.chunks) {
+        if (to_driver) { (void)hipMemRelease(h); ++g->vmm.releases; }
+        else g->vmm.pool.push_back(h);
+    }
     g->vmm.mapped_total -= b.mapped;
     b.chunks.clear(); b.mapped = 0;
+}
+static void vmm_drain_pool(lep_gpu* g) {
+    for (hipMemGenericAllocationHandle_t h : g->vmm.pool) { (void)hipMemRelease(h); ++g->vmm.releases; }
+    g->vmm.pool.clear();
 }
 static void dev_release(lep_gpu* g, void** p, size_t* have) {
     if (g->vmm.on) {
@@ -535,11 +549,12 @@ static void dev_release(lep_gpu* g, void** p, size_t* have) {
 }
 static void vmm_destroy(lep_gpu* g) {
     for (auto& kv : g->vmm.bufs) {
-        vmm_unmap(g, kv.second);
+        vmm_unmap(g, kv.second, true);
         if (kv.second.va) (void)hipMemAddressFree(kv.second.va, kv.second.reserved);
         *kv.first = nullptr;
     }
     g->vmm.bufs.clear();
+    vmm_drain_pool(g);
 }
 // before an allocation failure is reported: the cached memory no launch that is being set up depends on -- the split-phase
 // encoder's scratch (its launches take the single-kernel encoder when they cannot have it) and the other arena set's models
@@ -567,12 +582,12 @@ static int vmm_ensure(lep_gpu* g, void** p, size_t* have, size_t need, bool may_
     const size_t old = b.mapped;
     while (b.mapped < want) {
         hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, V.chunk, &V.prop, 0) != hipSuccess) {
+        if (!V.pool.empty()) { h = V.pool.back(); V.pool.pop_back(); --V.creates; }
+        else if (hipMemCreate(&h, V.chunk, &V.prop, 0) != hipSuccess) {
             (void)hipGetLastError();
-            bool again = false;
-            if (may_release) { may_release = false; release_idle_caches(g); again = hipMemCreate(&h, V.chunk, &V.prop, 0) == hipSuccess; if (!again) (void)hipGetLastError(); }
-            if (!again) {   // no room: what this call mapped is given back, the workspace stays as it was
-                while (b.mapped > old) { b.mapped -= V.chunk; (void)hipMemUnmap(b.va + b.mapped, V.chunk); (void)hipMemRelease(b.chunks.back()); b.chunks.pop_back(); ++V.releases; V.mapped_total -= V.chunk; }
+            if (may_release) { may_release = false; release_idle_caches(g); if (!V.pool.empty()) continue; }   // the idle workspaces' chunks are in the pool now
+            {   // no room: what this call mapped is given back, the workspace stays as it was
+                while (b.mapped > old) { b.mapped -= V.chunk; (void)hipMemUnmap(b.va + b.mapped, V.chunk); V.pool.push_back(b.chunks.back()); b.chunks.pop_back(); V.mapped_total -= V.chunk; }
                 g->err = "hipMemCreate: out of device memory";
                 return LEP_GPU_ERROR;
             }
@@ -1214,11 +1229,17 @@ int lep_gpu_trim(lep_gpu* g) {
     for (int i = 0; i < 6; ++i) dev_release(g, ps[i], ns[i]);
     return 0;
 }
+// ... and hand them to the driver (the pool too): for a process that wants the device's memory for something else
+int lep_gpu_release_memory(lep_gpu* g) {
+    if (int rc = lep_gpu_trim(g)) return rc;
+    vmm_drain_pool(g);
+    return 0;
+}
 int lep_gpu_malloc(lep_gpu* g, size_t bytes, void** dptr) {
     HIPCHK(g, hipSetDevice(g->device));
-    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) {   // (no room: the caches first)
+    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) {   // (no room: the caches first, pool included)
         (void)hipGetLastError();
-        if (int rc = lep_gpu_trim(g)) return rc;
+        if (int rc = lep_gpu_release_memory(g)) return rc;
         HIPCHK(g, hipMalloc(dptr, bytes ? bytes : 16));
     }
     return 0;

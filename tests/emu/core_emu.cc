@@ -1,14 +1,13 @@
-// core_emu.cc -- TEST ONLY: compiles the kernel source lepton_amd/csrc/lep_core.h with g++ and runs one
-// segment on the CPU exactly as lane 0 of the wavefront would, so kernel logic can be single-stepped
-// and diffed against the oracle without a GPU.  Never linked into the product.
+// core_emu.cc -- TEST ONLY: compiles the kernel headers under lepton_amd/csrc with g++ as lane-loop emulations (lep_wave.h) -- and the
+// single-lane coder of round 1 (lep_core_coder.h) -- so that kernel logic can be single-stepped and diffed against the oracle
+// without a GPU.  Never linked into the product.
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 #define LEP_DEV inline
 #include "../../lepton_amd/csrc/lep_derive.h"
-#include "retired/lep_enc2.h"
-#include "retired/lep_dec2.h"
+#include "lep_core_coder.h"   // the single-lane coder of round 1: test infrastructure
 
 using namespace lepdev;
 
@@ -53,75 +52,6 @@ struct PaddedStream {
         p = q;
     }
 };
-
-// v2 (wave-cooperative) encoder run as a 64-lane loop emulation
-extern "C" int emu_encode_segment_v2(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins) {
-    ImageDev img;
-    int rc = derive_image(*d, &img, true);
-    if (rc) return rc;
-    std::vector<uint32_t> model(kModelBranches, kBranchInit);
-    std::vector<NSum> ns(img.ns_total);
-    memset(ns.data(), 0, ns.size() * sizeof(NSum));
-    SegDev seg;
-    seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = cap;
-    static EncShared sh;
-    EncWave w;
-    rc = w.run(&img, seg, model.data(), ns.data(), &sh, out, cap);
-    if (rc) return rc;
-    *len = w.bc.finish();
-    if (w.bc.overflow) return LEP_BUFFER_TOO_SMALL;
-    if (bins) *bins = w.nbins;
-    return 0;
-}
-
-// exhaustive check of the reciprocal-multiply division used by branch_update_fast
-extern "C" int emu_check_fast_update() {
-    static uint32_t inv[512];
-    for (int d = 0; d < 512; ++d) inv[d] = d < 2 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d);
-    for (uint32_t f = 1; f < 256; ++f)
-        for (uint32_t t = 1; t < 256; ++t)
-            for (uint32_t p = 0; p < 256; p += 85)
-                for (int obs = 0; obs < 2; ++obs) {
-                    uint32_t w = f | (t << 8) | (p << 16);
-                    if (branch_update(w, obs) != branch_update_fast(w, obs, inv)) return 1;
-                }
-    return 0;
-}
-
-extern "C" int emu_decode_segment_v2(const lep_image_desc* d, int y0, int y1, int is_last, const uint8_t* in, uint32_t len, uint32_t* bins) {
-    ImageDev img;
-    int rc = derive_image(*d, &img, false);
-    if (rc) return rc;
-    std::vector<uint32_t> model(kModelBranches, kBranchInit);
-    std::vector<NSum> ns(img.ns_total);
-    memset(ns.data(), 0, ns.size() * sizeof(NSum));
-    SegDev seg;
-    seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = 0;
-    static DecShared sh;
-    DecWave w;
-    rc = w.run(&img, seg, model.data(), ns.data(), &sh, in, len);
-    if (bins) *bins = w.nbins;
-    return rc;
-}
-
-// v3 decoder (lep_dec3.h) as a 64-lane loop emulation
-#include "retired/lep_dec3.h"
-extern "C" int emu_decode_segment_v3(const lep_image_desc* d, int y0, int y1, int is_last, const uint8_t* in, uint32_t len, uint32_t* bins) {
-    ImageDev img;
-    int rc = derive_image(*d, &img, false);
-    if (rc) return rc;
-    std::vector<lep3::U4> model(lep3::kModelWords / 4, lep3::U4{kBranchInit, kBranchInit, kBranchInit, kBranchInit});
-    std::vector<NSum> ns(img.ns_total);
-    memset(ns.data(), 0, ns.size() * sizeof(NSum));
-    SegDev seg;
-    seg.image = 0; seg.y0 = y0; seg.y1 = y1; seg.is_last = is_last; seg.stream_off = 0; seg.stream_cap = 0;
-    static lep3::Dec3Shared sh;
-    lep3::Dec3Wave w;
-    PaddedStream ps(in, len);
-    rc = w.run(&img, seg, reinterpret_cast<uint32_t*>(model.data()), ns.data(), &sh, ps.p, len);
-    if (bins) *bins = w.nbins;
-    return rc;
-}
 
 // v3 encoder (lep_enc3.h) as a 64-lane loop emulation
 #include "../../lepton_amd/csrc/lep_enc3.h"

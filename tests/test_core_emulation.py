@@ -1,4 +1,4 @@
-"""The kernel source (lepton_amd/csrc/lep_core.h) compiled with g++ and single-stepped on the CPU
+"""The kernel headers (lepton_amd/csrc/*.h; and the single-lane coder tests/emu/lep_core_coder.h) compiled with g++ and single-stepped on the CPU
 (tests/emu/core_emu.cc) must produce the oracle's streams and frames.  Catches logic errors in the
 device code without a GPU; the real GPU parity tests are in test_gpu_parity.py."""
 import ctypes as C
@@ -59,68 +59,11 @@ def test_kernel_source_on_cpu_matches_oracle(emu, name):
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
 
 
-def test_reciprocal_multiply_update_is_exact(emu):
-    """branch_update_fast (mul-hi by ceil(2^32/d)) == exact integer division for every count pair"""
-    assert emu.emu_check_fast_update() == 0
-
-
-@pytest.mark.parametrize("name", golden_cases())
-def test_wave_cooperative_encoder_on_cpu_matches_oracle(emu, name):
-    """lep_enc2.h run as a 64-lane loop emulation (lep_wave.h) == oracle streams"""
-    jpg, _ = golden(name)
-    img = JpegImage(jpg)
-    d = img.desc
-    segs = img.plan()
-    want, bins = ob.oracle_encode(d, segs)
-    total = 0
-    for s, w in zip(segs, want):
-        cap = len(w) + 4096
-        buf = C.create_string_buffer(cap)
-        n, nb = C.c_uint32(0), C.c_uint32(0)
-        rc = emu.emu_encode_segment_v2(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, cap, C.byref(n), C.byref(nb))
-        assert rc == 0 and buf.raw[: n.value] == w
-        total += nb.value
-    assert total == bins
-
-
-def test_wave_cooperative_encoder_reports_out_of_range(emu):
-    from lepton_amd import corpus
-
-    img = JpegImage(corpus.synth_jpeg(64, 64, 9))
-    C.cast(img.desc.blocks[0], C.POINTER(C.c_int16))[5] = 4096
-    s = img.plan()[0]
-    buf = C.create_string_buffer(1 << 16)
-    n = C.c_uint32(0)
-    assert emu.emu_encode_segment_v2(C.byref(img.desc), s.luma_y_start, s.luma_y_end, s.is_last, buf, len(buf), C.byref(n), None) == 6
-
-
-@pytest.mark.parametrize("name", golden_cases())
-def test_wave_cooperative_decoder_on_cpu_matches_oracle(emu, name):
-    """lep_dec2.h as a 64-lane loop emulation: decoding the oracle's streams returns the coefficient frame"""
-    jpg, _ = golden(name)
-    img = JpegImage(jpg)
-    d = img.desc
-    segs = img.plan()
-    want, bins = ob.oracle_encode(d, segs)
-    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
-    for c in range(d.ncomp):
-        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
-    total = 0
-    for s, w in zip(segs, want):
-        nb = C.c_uint32(0)
-        assert emu.emu_decode_segment_v2(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, w, len(w), C.byref(nb)) == 0
-        total += nb.value
-    assert total == bins
-    for c in range(d.ncomp):
-        n = d.coded_blocks[c] * 128
-        assert C.string_at(d.blocks[c], n) == orig[c][:n]
-
-
-@pytest.mark.parametrize("gen", ["v3", "v4", "v5"])
+@pytest.mark.parametrize("gen", ["v4", "v5"])
 @pytest.mark.parametrize("name", golden_cases())
 def test_v3_decoder_on_cpu_matches_oracle(emu, name, gen):
-    """lep_dec3.h (owner-lane model update, 32-bit window) as a 64-lane loop emulation: decoding the
-    oracle's streams returns the coefficient frame and consumes exactly the oracle's number of bins"""
+    """lep_dec4.h / lep_dec5.h as 64-lane loop emulations: decoding the oracle's streams returns the coefficient frame and
+    consumes exactly the oracle's number of bins"""
     jpg, _ = golden(name)
     img = JpegImage(jpg)
     d = img.desc
@@ -140,7 +83,7 @@ def test_v3_decoder_on_cpu_matches_oracle(emu, name, gen):
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
 
 
-@pytest.mark.parametrize("gen", ["v3", "v4"])
+@pytest.mark.parametrize("gen", ["v4", "v5"])
 @pytest.mark.parametrize("shift", [1, 2, 3])
 def test_v3_decoder_unaligned_stream_start(emu, shift, gen):
     """the 64-bit window reads aligned dwords only: a stream that starts 1..3 bytes into a dword (streams packed back to
@@ -433,7 +376,7 @@ def test_decoders_survive_garbage_streams(emu, seed):
     d = img.desc
     segs = img.plan()
     rng = np.random.default_rng(seed)
-    for fn in ("emu_decode_segment_v5", "emu_decode_segment_v4", "emu_decode_segment_v3", "emu_decode_segment_v2", "emu_decode_segment"):
+    for fn in ("emu_decode_segment_v5", "emu_decode_segment_v4", "emu_decode_segment"):
         for kind in range(3):
             n = int(rng.integers(0, 400))
             if kind == 0:
@@ -1048,7 +991,7 @@ def edge_count_bias():
     knob.value = 0
 
 
-@pytest.mark.parametrize("gen", ["", "_v2", "_v4", "_v5"])   # (the retired v3 generation shares v4's per-pair scheme and is not maintained)
+@pytest.mark.parametrize("gen", ["", "_v4", "_v5"])
 @pytest.mark.parametrize("name", ["c420_odd_203x149", "gray_120x88", "c444_96x80", "truncated"])
 def test_decoders_follow_the_reference_on_impossible_edge_counts(emu, edge_count_bias, name, gen):
     """a stream that claims more edge non-zeros than positions remain.  The reference indexes
