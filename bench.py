@@ -155,7 +155,7 @@ def cpu_baseline(jpgs, budget_s=20.0):
 
 def pmc_traffic(kernel, images):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 passes (profiles/pmc_traffic.json: memory-side request
-    counters TCC_EA0_RDREQ x 64 B + TCC_EA0_WRREQ by size, separate --pmc passes, scripts/gpu_r3_final.sh) FOR THE LAUNCH SIZE THAT
+    counters TCC_EA0_RDREQ x 64 B + TCC_EA0_WRREQ by size, separate --pmc passes, scripts/gpu_closing_visit.sh) FOR THE LAUNCH SIZE THAT
     WAS MEASURED: the table is kept per images-per-launch (1024, 256) and a launch of another size gets None -- the decoder's bytes
     per block double between 256 and 1024 images (its model falls out of L2), so scaling one figure linearly to another batch is
     wrong.  A table lookup, not a measurement of this run: the entry names the kernel build it was taken from."""

@@ -357,11 +357,18 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_progressive_decode_kernel(c
 // ... all levels in ONE launch: a scan waits, MCU row by MCU row, for the scans of its file it follows (lep_huffprogdec.h ProgDeps)
 // (128 VGPRs: at 64 the waiting code's spills trip a register-pair alignment check in this compiler's backend; a launch of this
 // kind is small, what it needs is a short chain)
+// A workgroup does not take the scan of its own index: it draws a ticket when it STARTS and takes that scan.  A scan only waits for
+// scans of a lower index (prog_scan_deps), i.e. for tickets drawn before its own -- workgroups that are running or done, whatever
+// order the hardware starts workgroups in.  (Round 3 relied on index-order dispatch, which holds on this chip but is nobody's
+// promise: ADVICE round 3.)
 __global__ __launch_bounds__(64, 4) void lep_huffman_progressive_pipelined_kernel(const lephuff::ProgDecScan* __restrict__ scans, lephuff::HuffDecRow* rows,
-                                                                                 const lephuff::ProgDeps* __restrict__ deps, uint32_t* progress) {
+                                                                                 const lephuff::ProgDeps* __restrict__ deps, uint32_t* progress, uint32_t* ticket) {
     __shared__ lephuff::HuffDecShared sh;
+    uint32_t t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(ticket, 1u);
+    const int k = __builtin_amdgcn_readfirstlane((int)t);
     lephuff::ProgDecWave w;
-    w.run_scan<true>(scans + blockIdx.x, &sh, rows, deps + blockIdx.x, progress, (int)blockIdx.x);
+    w.run_scan<true>(scans + k, &sh, rows, deps + k, progress, k);
 }
 
 // JPEG Huffman scan decode: one wavefront per image (lep_huffdec.h)
@@ -419,7 +426,7 @@ struct lep_gpu {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     int huffprog_pipeline = 1;          // LEP_HUFFPROG_PIPELINE=0: progressive scan decode level by level, whatever the launch size
     int huffprog_pipeline_max = 16384;  // LEP_HUFFPROG_PIPELINE_MAX: scans per launch up to which the levels go out as one pipelined launch (measured to 10240:
-                                        // 1024 4K files, 798 -> 938 MB/s; workgroups start in index order, so a scan's predecessors are always running or done)
+                                        // 1024 4K files, 798 -> 938 MB/s; a workgroup takes the scan of the ticket it draws when it starts, so a scan's predecessors are always running or done)
     int enc5_waves = 2;      // LEP_ENC5_WAVES: wavefronts per segment in the split-phase walks (1 | 2)
     int enc5_parts = 8;      // LEP_ENC5_PARTS: gather / write in this many parts (1..8), a part written while the next is gathered
                              // (MI355X, 1024 x 4K: 1 part 569 ms per launch, 4 parts 481, 8 parts 475)
@@ -1042,18 +1049,18 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu* g, const lep_huffprogdec_
         pipelined = lephuff::prog_scan_deps(reinterpret_cast<const lephuff::ProgDecScan*>(sorted.data()), order.data(), nscan, deps.data());
     }
     const size_t o_deps = ((size_t)nscan * sizeof(lep_huffprogdec_scan) + 255) & ~(size_t)255, o_prog = o_deps + (((size_t)nscan * sizeof(lephuff::ProgDeps) + 255) & ~(size_t)255),
-                 total = o_prog + (size_t)nscan * 4;
+                 total = o_prog + (size_t)nscan * 4 + 4;   // (+ the ticket counter behind the progress words)
     if (int rc = ensure(g, &g->d_huffprogdec, &g->huffprogdec_bytes, total)) return rc;
     HIPCHK(g, hipMemcpyAsync(g->d_huffprogdec, sorted.data(), (size_t)nscan * sizeof(lep_huffprogdec_scan), hipMemcpyHostToDevice, st));
     if (pipelined) {
         HIPCHK(g, hipMemcpyAsync((char*)g->d_huffprogdec + o_deps, deps.data(), (size_t)nscan * sizeof(lephuff::ProgDeps), hipMemcpyHostToDevice, st));
-        HIPCHK(g, hipMemsetAsync((char*)g->d_huffprogdec + o_prog, 0, (size_t)nscan * 4, st));
+        HIPCHK(g, hipMemsetAsync((char*)g->d_huffprogdec + o_prog, 0, (size_t)nscan * 4 + 4, st));
     }
     HIPCHK(g, hipStreamSynchronize(st));
     HIPCHK(g, hipEventRecord(g->ev0, st));
     if (pipelined) {
         hipLaunchKernelGGL(lep_huffman_progressive_pipelined_kernel, dim3(nscan), dim3(64), 0, st, (const lephuff::ProgDecScan*)g->d_huffprogdec, (lephuff::HuffDecRow*)d_rows,
-                           (const lephuff::ProgDeps*)((char*)g->d_huffprogdec + o_deps), (uint32_t*)((char*)g->d_huffprogdec + o_prog));
+                           (const lephuff::ProgDeps*)((char*)g->d_huffprogdec + o_deps), (uint32_t*)((char*)g->d_huffprogdec + o_prog), (uint32_t*)((char*)g->d_huffprogdec + o_prog) + nscan);
         HIPCHK(g, hipGetLastError());
         HIPCHK(g, hipEventRecord(g->ev1, st));
         g->timed = true;

@@ -44,7 +44,9 @@ struct ProgDecScan {
 // finished.  So every scan publishes the number of MCU rows it has completed (a release store after the rows' coefficients),
 // and a scan that follows others waits, MCU row by MCU row, until all of them have passed the row it is about to enter: the
 // file then takes about as long as its longest scan.  Waiting cannot deadlock: a scan only ever waits for scans of a lower
-// index in the launch, workgroups are started in index order, and the lowest unfinished one therefore never waits.
+// index in the launch, and a workgroup takes the scan whose index is the TICKET it draws when it starts running (lep_gpu.hip): every
+// scan of a lower index belongs to a workgroup that is running or done, whatever order the hardware starts workgroups in, and the
+// lowest unfinished one never waits.
 struct ProgDeps { int32_t dep[4]; };   // indices (into the launch) of the scans this one follows, -1 = none
 
 struct ProgDecWave : HuffDecWave {

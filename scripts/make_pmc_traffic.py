@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PMC passes of scripts/gpu_r3_final.sh -> <out>/pmc_summary.json (raw sums per kernel) and <out>/pmc_traffic.json (what
+"""PMC passes of scripts/gpu_closing_visit.sh -> <out>/pmc_summary.json (raw sums per kernel) and <out>/pmc_traffic.json (what
 bench.py's roofline.traffic / bound_by look up; copied to profiles/pmc_traffic.json).  Runs on the GPU box right after the
 passes, so `kernel_source_sha16` is the hash of the sources the measured library was built from (bench.kernel_source_sha)."""
 import collections
@@ -104,7 +104,7 @@ json.dump({
     "by_images_per_launch": {"1024": kernels, "256": kernels_256},
     "source": "rocprofv3 --pmc, five separate passes (SQ wave time; SQ instruction counts; TCC_EA0_RDREQ / WRREQ / HIT / MISS; WRREQ_64B / RDREQ_32B / REQ / READ; "
               "the request counters again at 256 images), --kernel-trace only -- python bench.py --steps 1 --warmup 0 --no-extras --no-end-to-end --no-cpu-baseline "
-              "--mixed-images 0 (scripts/gpu_r3_final.sh, scripts/make_pmc_traffic.py; raw sums: pmc_summary.json beside this file's source in profiles/)",
+              "--mixed-images 0 (scripts/gpu_closing_visit.sh, scripts/make_pmc_traffic.py; raw sums: pmc_summary.json beside this file's source in profiles/)",
     "units": "hbm_bytes = 64 B x (TCC_EA0_RDREQ - RDREQ_32B) + 32 B x RDREQ_32B + 64 B x WRREQ_64B + 32 B x the other write requests, per launch (calibration of the "
              "request size for this access pattern: profiles/r02b_fetch_calibration.txt)",
     "kernel_source_sha16": sha, "images_per_launch": 1024, "blocks_per_image": BLOCKS_4K,

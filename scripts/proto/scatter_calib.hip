@@ -4,7 +4,7 @@
 //   stream   every lane reads consecutive 16-byte words (coalesced 1 KiB per wave instruction)
 //   gather   every lane reads ONE 16-byte word at a random 16-byte-aligned address (the decoder's context-group prefetch)
 //   rmw      the same, then writes the word back changed (the owner lanes' adapt + store)
-// Run under rocprofv3 --pmc (scripts/gpu_r2_visit2.sh); prints accesses and wall time per kernel so that requests per access
+// Run under rocprofv3 --pmc (a --pmc pass of its own); prints accesses and wall time per kernel so that requests per access
 // and requests per second can be read off next to the counters.
 #include <hip/hip_runtime.h>
 #include <cstdio>
