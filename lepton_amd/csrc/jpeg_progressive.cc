@@ -60,58 +60,87 @@ int decode_ac_first(BitReader& br, const HuffTable& ac, int16_t* blk, unsigned* 
     return eob;
 }
 
-// AC refinement: new +-1 coefficients and correction bits of the already non-zero ones
+// ---- AC refinement (T.81 G.1.2.3) the way the GPU scan coders do it (lep_huffprogdec.h): the band as two position masks ----------
+// A refinement scan says two things about a band: where the NEW +-1 coefficients go (a code = "skip z positions that are still zero,
+// then place one"), and one correction bit for every position that is ALREADY non-zero, in the order the walk passes them.  Which
+// positions are zero does not change while a block is decoded -- a position is never visited twice -- so the block is turned into a
+// mask of its zero positions and a mask of its non-zero ones once, a code's target is the (z + 1)-th set bit of the zero mask from the
+// cursor on, and the correction bits of the stretch it passes are read in one go.  On return the band holds the DELTAS (new
+// coefficient, or +-correction bit; the caller scales and adds them), as the reference's block decoders leave it
+// (jpgcoder.cc:5159-5230): same bits consumed, same refusals -- a code that would walk out of the band, a magnitude category other
+// than 1, a missing code.
+struct RefineBand {
+    uint64_t zero = 0, nonzero = 0, negative = 0;   // bit p = position p of the band's block
+    int from, to;
+    RefineBand(const int16_t* blk, int from_, int to_) : from(from_), to(to_) {
+        for (int p = from; p <= to; ++p) {
+            if (blk[p] == 0) zero |= 1ull << p;
+            else { nonzero |= 1ull << p; if (blk[p] < 0) negative |= 1ull << p; }
+        }
+    }
+    static uint64_t at_or_above(int p) { return p >= 64 ? 0ull : ~0ull << p; }
+    static uint64_t below(int p) { return p >= 64 ? ~0ull : (1ull << p) - 1; }
+    // correction bits of the non-zero positions in `m`, lowest position first; a position's delta is its bit with the coefficient's sign
+    void correct(BitReader& br, int16_t* blk, uint64_t m) const {
+        while (m) {
+            uint64_t part = m;
+            int k = __builtin_popcountll(m);
+            if (k > 24) { part = 0; uint64_t r = m; for (int i = 0; i < 24; ++i) { part |= r & (0 - r); r &= r - 1; } k = 24; }
+            const unsigned bits = br.read(k);   // first position = most significant of the k bits
+            int j = 0;
+            for (uint64_t r = part; r; r &= r - 1, ++j) {
+                const int p = __builtin_ctzll(r);
+                const int n = (int)((bits >> (k - 1 - j)) & 1u);
+                blk[p] = (int16_t)(((negative >> p) & 1) ? -n : n);
+            }
+            m &= ~part;
+        }
+    }
+};
+
 int decode_ac_refine(BitReader& br, const HuffTable& ac, int16_t* blk, unsigned* eobrun, int from, int to) {
-    int bpos = from, eob = to;
-    if (*eobrun == 0)
-        while (bpos <= to) {
+    const RefineBand band(blk, from, to);
+    int cursor = from, eob = to;
+    if (*eobrun == 0) {
+        while (cursor <= to) {
             const int hc = next_huffcode(br, ac);
             if (hc < 0) return -1;
-            const int l = (hc >> 4) & 15, r = hc & 15;
-            if (l == 15 || r > 0) {
-                int z = (int8_t)l, v;
-                if (r == 0) v = 0;
-                else if (r == 1) v = br.read(1) == 0 ? -1 : 1;
-                else return -1;
-                for (;;) {
-                    if (blk[bpos] == 0) {
-                        if (z > 0) --z;
-                        else { blk[bpos++] = (int16_t)v; break; }
-                    } else {
-                        const int n = (int)br.read(1);
-                        blk[bpos] = (int16_t)(blk[bpos] > 0 ? n : -n);
-                    }
-                    if (bpos++ >= to) return -1;
-                }
-            } else {
-                eob = bpos;
-                const int n = (int)br.read(l);
-                *eobrun = (unsigned)(n + (1 << l));
+            const int run = (hc >> 4) & 15, cat = hc & 15;
+            if (run != 15 && cat == 0) {   // end of band, and of 2^run + extra - 1 further blocks
+                eob = cursor;
+                *eobrun = br.read(run) + (1u << run);
                 break;
             }
+            if (cat > 1) return -1;
+            const int v = cat == 0 ? 0 : (br.read(1) == 0 ? -1 : 1);   // the sign bit stands in front of the correction bits of this stretch
+            // target: the (run + 1)-th zero position at or after the cursor
+            uint64_t z = band.zero & RefineBand::at_or_above(cursor);
+            if (__builtin_popcountll(z) <= run) return -1;            // the walk would leave the band
+            for (int i = 0; i < run; ++i) z &= z - 1;
+            const int target = __builtin_ctzll(z);
+            band.correct(br, blk, band.nonzero & RefineBand::at_or_above(cursor) & RefineBand::below(target));
+            blk[target] = (int16_t)v;
+            cursor = target + 1;
         }
-    if (*eobrun > 0) {
-        for (; bpos <= to; ++bpos)
-            if (blk[bpos] != 0) {
-                const int n = (int)br.read(1);
-                blk[bpos] = (int16_t)(blk[bpos] > 0 ? n : -n);
-            }
+    }
+    if (*eobrun > 0) {   // inside a run (this block's own end-of-band code included): the rest of the band takes correction bits only
+        band.correct(br, blk, band.nonzero & RefineBand::at_or_above(cursor));
         --*eobrun;
     }
     return eob;
 }
 
 int decode_eobrun_refine(BitReader& br, int16_t* blk, unsigned* eobrun, int from, int to) {
-    for (int bpos = from; bpos <= to; ++bpos)
-        if (blk[bpos] != 0) {
-            const int n = (int)br.read(1);
-            blk[bpos] = (int16_t)(blk[bpos] > 0 ? n : -n);
-        }
+    const RefineBand band(blk, from, to);
+    band.correct(br, blk, band.nonzero);
     --*eobrun;
     return 0;
 }
 
-// blocks covered by an end-of-band run are skipped as a whole (jpgcoder.cc:5462-5500)
+// blocks covered by an end-of-band run are skipped as a whole (jpgcoder.cc:5462-5500).  The arithmetic is the reference's to the
+// letter because damaged streams depend on it: a run that reaches into the padding rows of a non-interleaved component is tested
+// against the row count BEFORE the run is added (so it lands on padding blocks and the scan goes on), and the fuzz harnesses hold
+// exactly that against the reference binary -- a tidier (row, column) form differs on 8 % of the overshooting runs.
 int skip_eobrun(const JpegFile& jf, int cmp, int* dpos, int* rstw, unsigned* eobrun) {
     if (*eobrun == 0) return 0;
     const Component& k = jf.comp[cmp];

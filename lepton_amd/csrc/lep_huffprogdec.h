@@ -54,6 +54,8 @@ struct ProgDecWave : HuffDecWave {
     uint32_t eobrun;
     int peobrun;
     const ProgDeps* deps = nullptr;   // pipelined launches only
+    LV(int16_t, pf);                  // the next block of a refinement scan, requested one block ahead (ac_refine_block)
+    int pf_dpos = -1, pf_cmp = 0;
     uint32_t* progress = nullptr;     // [scan of the launch]: MCU rows completed
     int self = 0;
     uint32_t ready = 0;               // MCU rows every scan this one follows is known to have completed
@@ -191,35 +193,36 @@ struct ProgDecWave : HuffDecWave {
         return rc;
     }
 
-    // the correction bits of the already-non-zero positions in `cm` (a mask of zig-zag positions, consumed in ascending order):
-    // one bit each from the stream; positions whose bit is 1 move one step away from zero.  Lane-parallel except for the read.
-    WDEV void correct(uint64_t cm, uint64_t* changed) {
+    // the correction bits of the already-non-zero positions in `cm` (a mask of zig-zag positions, consumed in ascending order): one bit
+    // each from the stream.  They are only COLLECTED here, in stream order (a block has at most 63 of them); which positions they
+    // belong to is the mask of everything passed, and a position whose bit is 1 moves one step away from zero when the block is done
+    // (apply_corrections) -- one lane-parallel pass per block instead of one per code: the last bit plane of a 4K luma scan is
+    // 130 k blocks of ~6 codes, and the scan is one wavefront's dependent chain.
+    uint64_t cbits = 0, cmask = 0;
+    int ncb = 0;
+    WDEV void correct(uint64_t cm) {
+        cmask |= cm;
+        int k = lepwave::popc64(cm);
 #pragma nounroll
-        while (cm) {
-            // up to 16 positions per read
-            uint64_t part = cm;
-            int k = lepwave::popc64(cm);
-            if (k > 16) {   // keep the 16 lowest set bits
-                uint64_t m = cm;
-                for (int i = 0; i < 16; ++i) m &= m - 1;
-                part = cm & ~m; k = 16;
-            }
-            const uint32_t bits = uni(read((uint32_t)k));   // first position = most significant of the k bits
-            uint64_t ones = 0;
-            LV(int, hit);
-            LANES(l) {
-                int h = 0;
-                if ((part >> l) & 1ull) {
-                    const int j = lepwave::popc64(part & ((1ull << l) - 1));
-                    h = (int)((bits >> (k - 1 - j)) & 1u);
-                    if (h) { const int old = sh->blk[l]; sh->blk[l] = (int16_t)(old + (int16_t)((uint16_t)(int16_t)(old > 0 ? 1 : -1) << sc->sal)); }
-                }
-                L(hit) = h;
-            }
-            ones = lepwave::wave_ballot(hit);
-            *changed |= ones;
-            cm &= ~part;
+        while (k > 0) {
+            const int take = k > 16 ? 16 : k;
+            cbits = (cbits << take) | (uint64_t)uni(read((uint32_t)take));
+            ncb += take; k -= take;
         }
+    }
+    WDEV void apply_corrections(uint64_t* changed) {
+        if (!ncb) return;
+        LV(int, hit);
+        LANES(l) {
+            int h = 0;
+            if ((cmask >> l) & 1ull) {
+                const int j = lepwave::popc64(cmask & ((1ull << l) - 1));
+                h = (int)((cbits >> (ncb - 1 - j)) & 1ull);
+                if (h) { const int old = sh->blk[l]; sh->blk[l] = (int16_t)(old + (int16_t)((uint16_t)(int16_t)(old > 0 ? 1 : -1) << sc->sal)); }
+            }
+            L(hit) = h;
+        }
+        *changed |= lepwave::wave_ballot(hit);
     }
 
     // ---- AC refinement, one block (decode_ac_prg_sa / decode_eobrun_sa) ---------------------------------------------------------------
@@ -229,11 +232,25 @@ struct ProgDecWave : HuffDecWave {
         const int from = sc->from, to = sc->to, sal = sc->sal;
         const int16_t* src = sc->t.blocks[cmp] + (int64_t)dpos * 64;
         LV(int, nzf);
-        LANES(l) { const int v = (l >= from && l <= to) ? (int)src[sh->z2a[l]] : 0; sh->blk[l] = (int16_t)v; L(nzf) = v != 0; }
+        // The block's coefficients as the scans before left them.  A refinement scan is one wavefront and one dependent chain: the
+        // trip to HBM for every block (130 k blocks in a 4K luma scan) stood on it -- the NEXT block of the row is requested while
+        // this one is decoded (the scans this one follows have passed its whole block row: enter_row), and taken from the register
+        // when the walk gets there.
+        const bool have = pf_dpos == dpos && pf_cmp == cmp;
+        LANES(l) {
+            const int v = (l >= from && l <= to) ? (have ? (int)L(pf) : (int)src[sh->z2a[l]]) : 0;
+            sh->blk[l] = (int16_t)v; L(nzf) = v != 0;
+        }
+        pf_dpos = -1;
+        if ((dpos + 1) % sc->t.bch[cmp] != 0) {   // (not across a block row: the next row may not be final yet, or not the next block at all)
+            LANES(l) L(pf) = (l >= from && l <= to) ? src[64 + sh->z2a[l]] : (int16_t)0;
+            pf_dpos = dpos + 1; pf_cmp = cmp;
+        }
         LSYNC();
         const uint64_t band = (to >= 63 ? ~0ull : ((1ull << (to + 1)) - 1)) & ~((1ull << from) - 1);
         const uint64_t nzm = lepwave::wave_ballot(nzf);   // already non-zero positions (zig-zag index = bit index)
         const uint64_t zm = band & ~nzm;                  // zero positions of the band
+        cbits = 0; cmask = 0; ncb = 0;
         uint32_t bpos = (uint32_t)from;                   // scalar: everything it depends on is read through uni()
         uint32_t last_kind = 1;                           // 0: the last code was a ZRL (sixteen zeros)
         uint64_t changed = 0;
@@ -256,7 +273,7 @@ struct ProgDecWave : HuffDecWave {
                     const uint32_t pos = (uint32_t)__builtin_ctzll(m);
                     const uint64_t passed = nzm & ~((1ull << bpos) - 1) & ((1ull << pos) - 1);
                     const int v = r ? (uni(n) ? 1 : -1) : 0;
-                    correct(passed, &changed);
+                    correct(passed);
                     if (v) {
                         const int16_t nv = (int16_t)((uint16_t)(int16_t)v << sal);
                         LANES(ln) if (ln == 0) sh->blk[pos] = nv;
@@ -275,9 +292,10 @@ struct ProgDecWave : HuffDecWave {
             if (!rc && eobrun == 0 && last_kind == 0u) rc = -1;      // the band ends in a ZRL
         }
         if (!rc && eobrun > 0) {
-            if (bpos <= (uint32_t)to) correct(nzm & ~((1ull << bpos) - 1) & band, &changed);   // the rest of the band: correction bits only
+            if (bpos <= (uint32_t)to) correct(nzm & ~((1ull << bpos) - 1) & band);   // the rest of the band: correction bits only
             --eobrun;
         }
+        apply_corrections(&changed);
         flush_block(cmp, dpos, changed);
         peobrun = (int)eobrun;
         return rc;

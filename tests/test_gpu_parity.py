@@ -693,3 +693,16 @@ def test_gpu_progressive_scans_pipelined_or_level_by_level(monkeypatch, pipeline
     assert st2[3:] == [0, 0, 0] and got2[3:] == want_big
     for (code, w), s, g_ in zip(want, st2[:3], got2[:3]):
         assert (s, g_) == (code, w) or (code == 41 and s == 0)   # per-file compress also runs the round-trip check
+
+
+def test_gpu_progressive_pipelined_launch_beyond_what_is_resident(gpu_codec):
+    """the pipelined progressive scan decoder spin-waits on scans of the same launch, so its scans must be taken up in
+    an order in which a scan's predecessors are running or done.  Workgroups now draw a ticket when they start and take that scan.
+    Here: 640 progressive files = 6400+ scans in one launch -- more than the 4096 wavefronts of this kernel the chip holds at once --
+    every file must go through the GPU scan decoder (none gives up and falls back to the host parser) and equal the reference's
+    .lep bytes."""
+    jpg, lep = golden("prog_c420_320x240")
+    n = 640
+    got, st, stats = gpu_codec.compress_batch([jpg] * n)
+    assert st == [0] * n and all(g == lep for g in got)
+    assert stats["gpu_huffman_files"] == n
