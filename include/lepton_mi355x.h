@@ -225,7 +225,7 @@ int lep_gpu_huffman_decode_parallel_device(lep_gpu *g, const lep_huffdec_image *
 int lep_gpu_selftest(lep_gpu *g);
 /* Gives back the device memory the object caches between launches (per-segment models, neighbour rings, the split-phase
  * encoder's scratch: ~140 MB per 4K image of the largest launch so far) -- to the object's own POOL: the workspaces are virtual
- * address ranges into which 64 MB chunks are mapped, a trimmed workspace is unmapped and its chunks wait for the next workspace that
+ * address ranges into which 512 MB chunks are mapped, a trimmed workspace is unmapped and its chunks wait for the next workspace that
  * grows (of whatever kind).  Cheap in both directions (96 GB: 19 ms to unmap, 14 ms to map again) -- what is NOT cheap is taking
  * memory from the driver, which clears it: ~40 ms per GB (hipMalloc of 96 GB: 3 - 4 s); round 3 measured that as "memory serves
  * the kernels slower after a trim".  Waits for the device. */

@@ -452,7 +452,7 @@ struct lep_gpu {
     std::string err;
     const char* last_kernel = "";   // name of the kernel the most recent launch used
     // Device memory the object owns (round 4): every grow-only workspace below is a virtual address range of its own (hipMemAddressReserve)
-    // into which physical chunks of 64 MB (hipMemCreate) are mapped as it grows -- growing maps more chunks behind what is there, nothing
+    // into which physical chunks of 512 MB (hipMemCreate) are mapped as it grows -- growing maps more chunks behind what is there, nothing
     // is freed and taken again.  A workspace that is given back (lep_gpu_trim) is unmapped and its chunks go to the object's POOL, from
     // which the next workspace that grows takes them: memory moves between the encoder's scratch, the decoder's models and the rings
     // without passing through the driver.  Why that matters (MI355X, scripts/proto/vmm_costs.hip, profiles/r05m_*): the driver CLEARS
@@ -463,7 +463,7 @@ struct lep_gpu {
     struct VBuf { char* va = nullptr; size_t reserved = 0, mapped = 0; std::vector<hipMemGenericAllocationHandle_t> chunks; };
     struct Vmm {
         bool on = false;
-        size_t chunk = (size_t)64 << 20;
+        size_t chunk = (size_t)512 << 20;   // (64 MB chunks cost the encoder 2 %: 470 -> 480 ms, more page-table fragments; 512 MB: as one hipMalloc -- profiles/r05q_*)
         hipMemAllocationProp prop;
         hipMemAccessDesc access;
         std::map<void**, VBuf> bufs;   // keyed by the member that holds the workspace's pointer
@@ -527,6 +527,7 @@ static void vmm_init(lep_gpu* g) {
     g->vmm.prop.location.id = g->device;
     size_t gran = 0;
     if (hipMemGetAllocationGranularity(&gran, &g->vmm.prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { (void)hipGetLastError(); return; }
+    if (const char* e = getenv("LEP_VMM_CHUNK_MB")) if (atoi(e) > 0) g->vmm.chunk = (size_t)atoi(e) << 20;
     g->vmm.chunk = ((g->vmm.chunk + gran - 1) / gran) * gran;
     g->vmm.access.location = g->vmm.prop.location;
     g->vmm.access.flags = hipMemAccessFlagsProtReadWrite;
@@ -609,7 +610,12 @@ static int vmm_ensure(lep_gpu* g, void** p, size_t* have, size_t need, bool may_
 }
 static int ensure(lep_gpu* g, void** p, size_t* have, size_t need, bool may_release = true) {
     if (*have >= need) return 0;
-    if (g->vmm.on) return vmm_ensure(g, p, have, need, may_release);
+    // the large workspaces (models, rings, scratch: GBs) are owned address ranges with pooled chunks; descriptors and other small ones
+    // (a chunk would be mostly slack) stay plain allocations
+    if (g->vmm.on && (need >= ((size_t)32 << 20) || g->vmm.bufs.count(p))) {
+        if (*p && !g->vmm.bufs.count(p)) { HIPCHK(g, hipFree(*p)); *p = nullptr; *have = 0; }
+        return vmm_ensure(g, p, have, need, may_release);
+    }
     if (*p) HIPCHK(g, hipFree(*p));
     *p = nullptr; *have = 0;
     size_t want = need + need / 8;
