@@ -324,6 +324,21 @@ static int encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_las
     int32_t status = 0;
     for (int part = 0; part < nparts; ++part) write_wave(&plan, binlist.data(), &seg, 0, 1, out, &slen, &status, arena.data(), part, nparts);
     *len = slen;
+    {   // the stitched writer over the same bin list (K chunks, K and the warm-up varied with the list): the same bytes, the same verdict
+        const int K = 2 << (plan.nbins % 6);
+        const uint32_t warms[4] = {kWarm5, 100, 3000, 1u << 22};
+        std::vector<WChunk5> recs((size_t)K);
+        memset(recs.data(), 0, recs.size() * sizeof(WChunk5));
+        std::vector<uint8_t> again((size_t)cap + 64, 0x5A);
+        uint32_t slen2 = 0;
+        int32_t status2 = 0;
+        for (int k = 0; k < K; ++k) wchunk_range_lane(plan, binlist.data(), &recs[(size_t)k], k, K, warms[(plan.nbins >> 3) & 3]);
+        wchunk_link_lane(plan, binlist.data(), recs.data(), K);
+        for (int k = 0; k < K; ++k) wchunk_code_lane(plan, binlist.data(), seg, again.data(), &recs[(size_t)k], k, K);
+        wchunk_stitch_lane(plan, seg, again.data(), &slen2, &status2, recs.data(), K);
+        if ((status2 == 100) != (status == 100)) return 1006;
+        if (status != 100 && (slen2 != slen || memcmp(again.data(), out, slen))) return 1007;
+    }
     return status == 100 ? LEP_BUFFER_TOO_SMALL : status;
 }
 extern "C" int emu_encode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_last, uint8_t* out, uint32_t cap, uint32_t* len, uint32_t* bins,
