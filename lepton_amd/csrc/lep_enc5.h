@@ -267,28 +267,45 @@ WDEV void fold_thresh_wave(const SegPlan5* plans, uint8_t* arena, uint32_t* thre
     }
 }
 
-// sign chains: one byte per entry; lane = segment, the colour's 48 sign Branches in the lane's slice
+// sign chains: one byte per entry; lane = segment, the colour's 48 sign Branches in the lane's slice.
+// A chain step is LDS read -> probability / update -> LDS write, and half of a segment's signs go through ONE Branch (the interior's),
+// so the round trip to LDS stood on the chain 350,000 times per segment.  The Branch of the NEXT entry is read while this entry is
+// computed, and if it is the Branch just updated the new state is forwarded instead of what the early read saw (the LDS executes a
+// wavefront's accesses in order: an early read can only be stale with respect to the one write behind it).  Straight-line per entry:
+// an entry that is no sign (the padding of a stream) goes through the spare Branch 63 and is written back unchanged.
 WDEV void fold_sign_wave(const SegPlan5* plans, uint8_t* arena, int seg0, int nseg, int ci, FoldShared* sh) {
-    fold_init(sh, kSignSlice);
+    fold_init(sh, kSignSlice > 64 ? kSignSlice : 64);
     LANES(l) {
         const int seg = seg0 + l;
         if (seg < nseg) {
             const SegPlan5& P = plans[seg];
             uint8_t* s = arena + P.arena_off + P.sign_base[ci];
-            FoldLane fl{sh->slice + fold_col(l)};
+            uint16_t* br = sh->slice + fold_col(l);
             const uint32_t n = P.status ? 0u : P.sign_cnt[ci];
             uint32_t* p = reinterpret_cast<uint32_t*>(s);   // the stream starts on 16 bytes and is padded to 16
             U4 nxt = n ? ld4(p) : U4{0, 0, 0, 0};
+            auto slot_of = [](uint32_t e) { return (e & 0x80u) ? (int)(e & 63u) : 63; };
+            int cur_b = n ? slot_of(nxt.x & 255u) : 63;
+            uint32_t cur_w = br[cur_b * 64];
             for (uint32_t i = 0; i < n; i += 16) {
                 U4 g = nxt;
                 if (i + 16 < n) nxt = ld4(p + (i >> 2) + 4);
                 uint32_t w[4] = {g.x, g.y, g.z, g.w};
-                for (int q = 0; q < 16 && i + q < n; ++q) {
+                const uint32_t follow = i + 16 < n ? (nxt.x & 255u) : 0u;   // the entry behind this group's last one
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
                     const uint32_t e = (w[q >> 2] >> (8 * (q & 3))) & 255u;
-                    if (e & 0x80u) {
-                        const uint32_t pr = fl.code((int)(e & 63u), (e >> 6) & 1u);
-                        w[q >> 2] = (w[q >> 2] & ~(255u << (8 * (q & 3)))) | (pr << (8 * (q & 3)));
-                    }
+                    const uint32_t en = q < 15 ? (w[(q + 1) >> 2] >> (8 * ((q + 1) & 3))) & 255u : follow;
+                    const int nb = slot_of(en);
+                    const uint32_t early = br[nb * 64];                     // requested before this entry's update is written
+                    const uint32_t isgn = (i + (uint32_t)q < n) ? (e >> 7) & 1u : 0u;   // (the group's tail behind the stream's end is not the chain's)
+                    const uint32_t pr = prob16(cur_w);
+                    const uint32_t upd = isgn ? upd16(cur_w, (e >> 6) & 1u) : cur_w;
+                    br[cur_b * 64] = (uint16_t)upd;
+                    const uint32_t outb = isgn ? pr : e;
+                    w[q >> 2] = (w[q >> 2] & ~(255u << (8 * (q & 3)))) | (outb << (8 * (q & 3)));
+                    cur_w = nb == cur_b ? upd : early;
+                    cur_b = nb;
                 }
                 st4(p + (i >> 2), U4{w[0], w[1], w[2], w[3]});
             }
