@@ -98,24 +98,33 @@ struct BitReader {
     }
 };
 
+// One Huffman symbol (>= 0) or a negative value for bits that are no code of the table.  What the callers can observe besides
+// the symbol is how far the reader has moved and whether it has met the end of the data (a failed code AT the end is a truncated
+// file, before it a refused one): a code is consumed bit by bit as far as some word of the table still begins with the bits
+// read, the first bit that leaves every word included -- jpgcoder.cc:5407-5425 walks its tree that far.
 inline int next_huffcode(BitReader& br, const HuffTable& t) {
     if (!br.eof) {
         br.top_up();
-        if (br.avail >= 10) {
-            const unsigned e = t.lut[br.peek(10)];
-            if (e) {
-                br.skip((int)(e >> 8));
-                if (br.avail == 0 && br.next_byte == br.size) br.eof = true;   // the bit-by-bit walk sets eof with the read that takes the last bit of the data
-                return (int)(e & 255);
-            }
+        unsigned e = br.avail >= 10 ? t.lut[br.peek(10)] : 0;
+        if (!e && br.avail >= 16) {               // a longer code, away from the end of the data
+            const int k = t.word_at(br.peek(16));
+            if (k >= 0) e = ((unsigned)t.wlen[k] << 8) | t.wsym[k];
+        }
+        if (e) {
+            br.skip((int)(e >> 8));
+            if (br.avail == 0 && br.next_byte == br.size) br.eof = true;   // read() sets eof with the read that takes the last bit of the data
+            return (int)(e & 255);
         }
     }
-    int node = 0;
-    while (node < 256) {
-        node = br.read(1) == 1 ? t.r[node] : t.l[node];
-        if (node == 0) break;
+    unsigned bits = 0;
+    for (int n = 1, k = 0; n <= 16; ++n) {        // k: first word not below the patterns that begin with `bits`
+        bits = (bits << 1) | br.read(1);
+        const unsigned lo = bits << (16 - n), span = 1u << (16 - n);
+        while (k < t.nwords && t.wfirst[k] < lo) ++k;
+        if (k == t.nwords || t.wfirst[k] - lo >= span) break;
+        if (t.wlen[k] == n) return (int)t.wsym[k];
     }
-    return node - 256;
+    return -256;
 }
 
 // MSB-first writer producing un-stuffed bytes; optional hard bound on produced bytes.

@@ -56,11 +56,23 @@ struct HuffTable {
     // with zero-length codes there -- found by the structured differential fuzz as a run-to-run difference
     uint16_t clen[256] = {};
     uint16_t cval[256] = {};
-    uint16_t l[256] = {}, r[256] = {};   // decoding tree, leaf = 256 + symbol
     int max_eobrun = 0;
-    // first-level lookup derived FROM the tree (so that odd tables decode exactly as the walk does): index = the next 10
-    // bits, entry = code length << 8 | symbol, 0 = longer than 10 bits or no such code (the bit-by-bit walk decides)
+    // decode side: the code words a bit stream can actually end on, as disjoint intervals of 16-bit patterns sorted by their
+    // first pattern -- word k covers wfirst[k] .. wfirst[k] + (1 << (16 - wlen[k])) - 1.  For a DHT that follows Annex C these
+    // are its codes; for one that does not (codes that extend other codes, more inner nodes than the reference's 256-entry
+    // tree holds) they are what the reference's tree would let a walk reach (build_huff_table says how)
+    uint16_t wfirst[256] = {};
+    uint8_t wlen[256] = {}, wsym[256] = {};
+    int nwords = 0;
+    // first-level lookup over the same words: index = the next 10 bits, entry = code length << 8 | symbol, 0 = longer than 10
+    // bits or no such code
     uint16_t lut[1024] = {};
+    // the word that begins with these 16 bits, or -1
+    int word_at(unsigned pattern16) const {
+        int lo = 0, hi = nwords;                                  // last word whose first pattern is <= pattern16
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (wfirst[mid] <= pattern16) lo = mid + 1; else hi = mid; }
+        return lo > 0 && pattern16 - wfirst[lo - 1] < (1u << (16 - wlen[lo - 1])) ? lo - 1 : -1;
+    }
 };
 
 struct JpegFile {

@@ -33,49 +33,88 @@ const uint8_t kZigzagToAligned[64] = {
 static inline unsigned be16(unsigned a, unsigned b) { return (a << 8) + b; }
 
 // ------------------------------------------------------------------------------------------------
-// Huffman tables: code assignment in DHT order, then a binary tree of <=256 inner nodes.
+// Huffman tables.  Encode side: code and length per symbol in DHT order (T.81 Annex C; a symbol listed twice keeps its last
+// code).  Decode side: the table's code words as sorted, disjoint intervals of 16-bit patterns (HuffTable::wfirst).
+//
+// A DHT that follows Annex C is prefix-free and its words are its codes.  One that does not is still decoded the way the
+// reference would (jpgcoder.cc:5507-5606 enters the symbols 0..255, in that order, into a binary tree of at most 256 inner
+// nodes, and its walk trusts whatever link it finds).  Stated on code words, symbol by symbol:
+//   * a code that extends a word already entered is dropped (the walk would stop at that word);
+//   * a code that other words extend replaces them (they can no longer be reached);
+//   * every bit of a code but its last that no earlier code shares costs one inner node, numbered 1, 2, ... as they are made;
+//     the node that would be number 256 or more is not an inner node but reads as the symbol (number - 256), the code that
+//     needed it is dropped, and the bits up to that node have become a word of their own.
+// strict (a file being compressed): a dropped code refuses the table; not strict (.lep headers are taken as they were written).
 bool build_huff_table(const uint8_t* clen, size_t clen_avail, const uint8_t* cval, size_t cval_avail,
                       HuffTable* t, bool strict) {
-    memset(t->clen, 0, sizeof t->clen);
-    memset(t->cval, 0, sizeof t->cval);
-    memset(t->l, 0, sizeof t->l);
-    memset(t->r, 0, sizeof t->r);
-    unsigned k = 0, code = 0;
-    for (unsigned bits = 0; bits < 16; ++bits) {
-        unsigned n = bits < clen_avail ? clen[bits] : 0;
-        for (unsigned j = 0; j < n; ++j, ++k, ++code) {
-            unsigned idx = k & 0xff;
-            uint8_t sym = idx < cval_avail ? cval[idx] : 0;
-            t->clen[sym] = (uint16_t)(bits + 1);
+    *t = HuffTable();
+    unsigned listed = 0, code = 0;
+    for (unsigned len = 1; len <= 16; ++len, code <<= 1) {
+        const unsigned n = len - 1 < clen_avail ? clen[len - 1] : 0;
+        for (unsigned j = 0; j < n; ++j, ++listed, ++code) {
+            const unsigned at = listed & 0xff;
+            const uint8_t sym = at < cval_avail ? cval[at] : 0;
+            t->clen[sym] = (uint16_t)len;
             t->cval[sym] = (uint16_t)code;
         }
-        code <<= 1;
     }
-    t->max_eobrun = 0;
-    for (int i = 14; i >= 0; --i)
+    for (int i = 14; i >= 0; --i)                         // longest end-of-band run an AC table of a progressive scan can code
         if (t->clen[(i << 4) & 255] > 0) { t->max_eobrun = (2 << i) - 1; break; }
-    unsigned next_free = 1;
+
+    struct Word { uint16_t first; uint8_t len, sym; };
+    Word words[256];                                      // kept sorted by `first`
+    int nw = 0;
+    uint16_t seen_first[256];                             // codes entered so far: every bit but the last is an inner node
+    uint8_t seen_len[256];
+    int nseen = 0;
+    unsigned next_node = 1;
+    auto put = [&](Word w) {                              // w replaces the words that begin with it
+        const unsigned end = w.first + (1u << (16 - w.len));
+        int a = 0;
+        while (a < nw && words[a].first < w.first) ++a;
+        int b = a;
+        while (b < nw && words[b].first < end) ++b;
+        memmove(words + a + 1, words + b, (size_t)(nw - b) * sizeof(Word));
+        words[a] = w;
+        nw += a + 1 - b;
+    };
     for (unsigned sym = 0; sym < 256; ++sym) {
-        unsigned node = 0;
-        for (int j = (int)t->clen[sym] - 1; j > 0; --j) {
-            if (node > 0xff) { if (strict) return false; continue; }
-            uint16_t* side = ((t->cval[sym] >> j) & 1) ? t->r : t->l;
-            if (side[node] == 0) side[node] = (uint16_t)next_free++;
-            node = side[node];
+        const int len = t->clen[sym];
+        if (!len) continue;
+        const unsigned first = ((unsigned)t->cval[sym] << (16 - len)) & 0xffff;   // (an over-full table counts past its length: the low bits are the code)
+        bool dropped = false;
+        for (int k = 0; k < nw && words[k].first <= first; ++k)
+            if (words[k].len < len && first - words[k].first < (1u << (16 - words[k].len))) dropped = true;
+        int path = len;
+        if (!dropped) {
+            int shared = 0;                               // leading bits that are inner nodes already
+            for (int k = 0; k < nseen; ++k) {
+                const unsigned diff = first ^ seen_first[k];
+                const int same = diff ? __builtin_clz(diff) - 16 : 16;
+                shared = std::max(shared, std::min(same, seen_len[k] - 1));
+            }
+            for (int depth = std::min(shared, len - 1) + 1; depth < len; ++depth) {
+                const unsigned id = next_node++;
+                if (id < 256) continue;
+                put(Word{(uint16_t)(first & (0xffff0000u >> depth)), (uint8_t)depth, (uint8_t)(id - 256)});
+                path = depth;
+                dropped = true;
+                break;
+            }
+            seen_first[nseen] = (uint16_t)first;
+            seen_len[nseen++] = (uint8_t)path;
+            if (!dropped) put(Word{(uint16_t)first, (uint8_t)len, (uint8_t)sym});
         }
-        if (node > 0xff) { if (strict) return false; continue; }
-        if (t->clen[sym] > 0) ((t->cval[sym] & 1) ? t->r : t->l)[node] = (uint16_t)(sym + 256);
+        if (dropped && strict) return false;
     }
-    for (unsigned pat = 0; pat < 1024; ++pat) {
-        unsigned node = 0, depth = 0;
-        uint16_t e = 0;
-        while (depth < 10) {
-            node = ((pat >> (9 - depth)) & 1) ? t->r[node] : t->l[node];
-            ++depth;
-            if (node == 0) break;                                            // no such code
-            if (node >= 256) { e = (uint16_t)((depth << 8) | (node - 256)); break; }
-        }
-        t->lut[pat] = e;
+    t->nwords = nw;
+    for (int k = 0; k < nw; ++k) {
+        t->wfirst[k] = words[k].first;
+        t->wlen[k] = words[k].len;
+        t->wsym[k] = words[k].sym;
+        if (words[k].len <= 10)
+            for (unsigned x = 0; x < (1u << (10 - words[k].len)); ++x)
+                t->lut[(words[k].first >> 6) + x] = (uint16_t)((words[k].len << 8) | words[k].sym);
     }
     t->set = true;
     return true;

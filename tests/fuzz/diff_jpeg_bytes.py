@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Byte-level differential fuzz of the encode direction against the reference binary: damaged JPEGs (bit flips in header and scan,
-insertions, truncation, stray 0xFF) -- either both sides refuse the file with the same exit code or both write the same .lep.
+insertions, truncation, stray 0xFF, Huffman tables with other code counts / symbols) -- either both sides refuse the file with the same exit code or both write the same .lep.
 The reference ends a failing run with syscall(SYS_exit) on a worker thread: the process status stays 0 and the code's NAME is the
 last line on stderr, which is what is compared.  python tests/fuzz/diff_jpeg_bytes.py <seed> <trials>; 800 mutants: no difference."""
 import os, sys, random, subprocess
@@ -21,9 +21,15 @@ same=refused=bad=0
 for trial in range(N):
     name=rnd.choice(names)
     b=bytearray(src(name))
-    kind=rnd.choice(["flip_scan","flip_hdr","trunc","flip_any","insert","ff"])
+    kind=os.environ.get('JPEG_FUZZ_KIND') or rnd.choice(["flip_scan","flip_hdr","trunc","flip_any","insert","ff","dht"])
     if kind=="flip_scan":
         for _ in range(rnd.randint(1,3)): b[rnd.randrange(len(b)//2,len(b))]^=1<<rnd.randrange(8)
+    elif kind=="dht":                  # a Huffman table's code counts or symbols (tables that no longer follow T.81 Annex C)
+        at=[i for i in range(len(b)-20) if b[i]==0xff and b[i+1]==0xc4]
+        i=rnd.choice(at) if at else 0; ln=(b[i+2]<<8)|b[i+3]
+        for _ in range(rnd.randint(1,3)):
+            j=i+5+rnd.randrange(0,16) if rnd.random()<0.6 else i+4+rnd.randrange(0,max(ln-2,1))
+            b[j]=rnd.choice([b[j]^(1<<rnd.randrange(8)),b[j]+1&255,b[j]-1&255,rnd.randrange(256)])
     elif kind=="flip_hdr": b[rnd.randrange(0,min(len(b),700))]^=1<<rnd.randrange(8)
     elif kind=="trunc": b=b[:rnd.randrange(100,len(b))]
     elif kind=="flip_any": b[rnd.randrange(len(b))]=rnd.randrange(256)

@@ -110,7 +110,17 @@ def mutate_lep_structured(rng, lep):
     if k == 3:
         return with_handoffs(lep, thread_byte=rng.choice([0, 1, 8, 9, 16, 17, 255]))
     fixed, p, rest = parts
-    p = mutate(rng, p)
+    dht = [i for i in range(len(p) - 20) if p[i] == 0xff and p[i + 1] == 0xc4]
+    if dht and rng.random() < 0.3:    # a Huffman table of the embedded JPEG header: other code counts, other / repeated symbols
+        p = bytearray(p)
+        i = rng.choice(dht)
+        ln = (p[i + 2] << 8) | p[i + 3]
+        for _ in range(rng.choice([1, 2, 4])):
+            j = i + 5 + rng.randrange(16) if rng.random() < 0.5 else min(len(p) - 1, i + 4 + rng.randrange(max(ln - 2, 1)))
+            p[j] = rng.choice([p[j] ^ (1 << rng.randrange(8)), (p[j] + 1) & 255, (p[j] - 1) & 255, rng.randrange(256)])
+        p = bytes(p)
+    else:
+        p = mutate(rng, p)
     fixed = bytearray(fixed)
     if rng.random() < 0.3:
         fixed[3] = rng.choice([ord("Z"), ord("X"), ord("Y"), rng.randrange(256)])
