@@ -127,6 +127,15 @@ inline int next_huffcode(BitReader& br, const HuffTable& t) {
     return -256;
 }
 
+// the value a magnitude category and its extra bits stand for (T.81 F.2.2.1): the top half of the category's range as read, the
+// bottom half shifted down to the negative numbers.  A category past 16 only comes out of a corrupt DHT: the shift counts are
+// reduced as x86 reduces them, which is what the reference's expression does there.
+inline int extend(int category, int bits) {
+    if (category == 0) return bits;
+    const int half = (int)(1u << ((category - 1) & 31));
+    return bits >= half ? bits : (int)((unsigned)bits + 1u - (1u << (category & 31)));
+}
+
 // MSB-first writer producing un-stuffed bytes; optional hard bound on produced bytes.
 struct BitWriter {
     std::vector<uint8_t> bytes;

@@ -23,41 +23,33 @@ Handoff make_handoff_public(BitReader& br, const JpegFile& jf, int mcu_y, const 
 
 namespace {
 
-inline int devli(int s, int n) {   // s > 16 only on a corrupt DHT; shift counts reduced as x86 does (the reference's DEVLI is the same expression)
-    return s == 0 ? n : (n >= (int)(1u << ((s - 1) & 31)) ? n : (int)((unsigned)n + 1u - (1u << (s & 31))));
-}
 inline unsigned envli(int s, int v) { return (unsigned)((v > 0) ? v : (v - 1) + (1 << s)) & ((1u << s) - 1); }
 inline int blen16(unsigned v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
 inline int fdiv2(int v, int p) { return v < 0 ? -((-v) >> p) : (v >> p); }
 
 // ---- decoding one block of a scan ----------------------------------------------------------------------------------
-// AC first stage: coefficients from..to, or an end-of-band run (returns the eob position, -1 on error)
+// AC first stage, band from..to of one block: the band's coefficients, or the block's turn inside an end-of-band run.  Returns the
+// position behind the band's last coded coefficient (from = nothing coded), -1 for bits that are no code or a run that leaves the band.
 int decode_ac_first(BitReader& br, const HuffTable& ac, int16_t* blk, unsigned* eobrun, int from, int to) {
-    int eob = to + 1;
+    memset(blk + from, 0, (size_t)(to - from + 1) * sizeof blk[0]);
     if (*eobrun > 0) {
-        for (int b = from; b <= to; ++b) blk[b] = 0;
         --*eobrun;
         return from;
     }
-    for (int bpos = from; bpos <= to;) {
-        const int hc = next_huffcode(br, ac);
-        if (hc < 0) return -1;
-        const int l = (hc >> 4) & 15, r = hc & 15;
-        if (l == 15 || r > 0) {
-            int z = l;
-            const int n = (int)br.read(r);
-            if (z + bpos > to) return -1;
-            while (z > 0) { blk[bpos++] = 0; --z; }
-            blk[bpos++] = (int16_t)devli(r, n);
-        } else {
-            eob = bpos;
-            const int n = (int)br.read(l);
-            *eobrun = (unsigned)(n + (1 << l));
-            --*eobrun;
-            break;
+    for (int at = from; at <= to;) {
+        const int sym = next_huffcode(br, ac);
+        if (sym < 0) return -1;
+        const int run = sym >> 4 & 15, category = sym & 15;
+        if (category == 0 && run < 15) {                   // end of band for this block and 2^run - 1 + (run extra bits) blocks after it
+            *eobrun = (unsigned)((1 << run) + (int)br.read(run)) - 1;
+            return at;
         }
+        const int bits = (int)br.read(category);
+        at += run;
+        if (at > to) return -1;
+        blk[at++] = (int16_t)extend(category, bits);
     }
-    return eob;
+    return to + 1;
 }
 
 // ---- AC refinement (T.81 G.1.2.3) the way the GPU scan coders do it (lep_huffprogdec.h): the band as two position masks ----------
@@ -182,7 +174,7 @@ int decode_progressive_scan(JpegFile* jf, BitReader& br, int* lastdc, int* sta_i
                 const int hc = next_huffcode(br, t);
                 int diff = 0;
                 if (hc < 0) sta = -1;
-                else diff = devli(hc & 255, (int)br.read(hc & 255));
+                else diff = extend(hc & 255, (int)br.read(hc & 255));
                 const int16_t v = (int16_t)((int16_t)diff + lastdc[cmp]);
                 lastdc[cmp] = v;
                 dc_of(cmp, dpos) = (int16_t)((uint16_t)v << sal);
@@ -209,7 +201,7 @@ int decode_progressive_scan(JpegFile* jf, BitReader& br, int* lastdc, int* sta_i
                 const int hc = next_huffcode(br, t);
                 int diff = 0;
                 if (hc < 0) sta = -1;
-                else diff = devli(hc & 255, (int)br.read(hc & 255));
+                else diff = extend(hc & 255, (int)br.read(hc & 255));
                 const int16_t v = (int16_t)((int16_t)diff + lastdc[cmp]);
                 lastdc[cmp] = v;
                 dc_of(cmp, dpos) = (int16_t)((uint16_t)v << sal);

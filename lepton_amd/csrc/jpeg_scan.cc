@@ -375,37 +375,28 @@ static Handoff make_handoff(BitReader& br, const JpegFile& jf, int mcu_y, const 
     return h;
 }
 
-static inline int devli(int s, int n) {   // s > 16 only on a corrupt DHT; shift counts reduced as x86 does (the reference's DEVLI is the same expression)
-    return s == 0 ? n : (n >= (int)(1u << ((s - 1) & 31)) ? n : (int)((unsigned)n + 1u - (1u << (s & 31))));
-}
-
-// returns eob (1..64) or -1
+// One block of a sequential scan into blk[0..63] (zigzag order, DC as a difference).  Returns the position behind the last
+// coefficient the scan coded (1..64), -1 for bits that are no code, -2 for a zero run that leaves the block anywhere but at the end
+// of the data (there the reference truncates the block and marks its last coefficient; elsewhere it asserts).
 static int decode_block_seq(BitReader& br, const HuffTable& dc, const HuffTable& ac, int16_t* blk) {
-    int hc = next_huffcode(br, dc);
-    if (hc < 0) return -1;
-    int s = hc & 0xff;
-    int n = (int)br.read(s);
-    blk[0] = (int16_t)devli(s, n);
-    int eob = 64, bpos;
-    bool fixup = false;
-    for (bpos = 1; bpos < 64;) {
-        hc = next_huffcode(br, ac);
-        if (hc > 0) {
-            int z = (hc >> 4) & 15;
-            s = hc & 15;
-            n = (int)br.read(s);
-            if (z + bpos >= 64) { fixup = true; break; }
-            while (z > 0) { blk[bpos++] = 0; --z; }
-            blk[bpos++] = (int16_t)devli(s, n);
-        } else if (hc == 0) { eob = bpos; break; }
-        else return -1;
+    const int dc_category = next_huffcode(br, dc);
+    if (dc_category < 0) return -1;
+    memset(blk, 0, 64 * sizeof blk[0]);
+    blk[0] = (int16_t)extend(dc_category & 0xff, (int)br.read(dc_category & 0xff));
+    for (int at = 1; at < 64;) {
+        const int sym = next_huffcode(br, ac);             // run of zeros << 4 | magnitude category
+        if (sym < 0) return -1;
+        if (sym == 0) return at;                           // end of block
+        const int bits = (int)br.read(sym & 15);
+        at += sym >> 4;
+        if (at >= 64) {
+            if (!br.eof) return -2;
+            blk[63] = 1;
+            return 64;
+        }
+        blk[at++] = (int16_t)extend(sym & 15, bits);
     }
-    if (fixup) {
-        if (!br.eof) return -2;  // "If 0run is longer than the block must be truncated" (assertion in the reference)
-        for (; bpos < eob; ++bpos) blk[bpos] = 0;
-        if (eob) blk[eob - 1] = 1;
-    }
-    return eob;
+    return 64;
 }
 
 // next block position, interleaved scan (recoder.cc:186-241)
