@@ -382,12 +382,11 @@ int lep_decompress(lep_gpu *g, const uint8_t *lepdata, size_t len, lep_bytes *ou
 typedef struct lep_batch_options {
     int32_t host_threads;        /* 0 = the CPUs this process may use (affinity mask capped by the cgroup CPU quota) */
     int32_t verify;              /* compress: on-GPU round-trip verification */
-    size_t chunk_frame_bytes;    /* cap on coefficient-frame bytes per pipeline chunk; 0 = 24 GiB */
+    size_t chunk_frame_bytes;    /* cap on coefficient-frame bytes per pipeline chunk; 0 = 32 GiB (1024 4K frames) */
     int32_t host_huffman;        /* 1 = JPEG Huffman decode / re-encode on the host pool (frames cross PCIe) instead of on the GPU */
-    int32_t chunk_images;        /* images per pipeline chunk; 0 = automatic: at most 1024 images, and for compression with the
-                                    GPU Huffman decoder at most 7168 thread segments (7 coder wavefronts per SIMD; the eighth
-                                    slot decodes the next chunk's scans meanwhile).  A coder kernel takes as long for 100
-                                    segments as for 8192, so chunks must be this big */
+    int32_t chunk_images;        /* images per pipeline chunk; 0 = automatic: at most 1024 images and 8192 thread segments (the decoder
+                                    wavefronts the chip holds at once), chunks of a call balanced.  The decode kernel takes as
+                                    long for 100 segments as for 8192, so chunks must be this big */
     int32_t overlap_launches;    /* compress: consecutive chunks' coder kernels on two streams / two workspace sets (experimental; also
                                     LEP_BATCH_OVERLAP=1) */
 } lep_batch_options;

@@ -516,17 +516,20 @@ int lep_compress_embedded(lep_gpu* g, const uint8_t* blob, size_t len, size_t of
     return compress_parsed(g, j, blob, len, out);
 }
 
-// How lep_compress_batch cuts a batch into pipeline chunks (pure host logic, unit-tested on the CPU).  A chunk's thread
-// segments are one coder wavefront each and the next chunk's Huffman decode needs the eighth wave slot of every SIMD
-// (lep_batch.hip), so an automatic chunk holds at most 7168 segments and 1024 images; a kernel takes as long for a small
-// chunk as for a full one, so the chunks are balanced (k equal chunks, not k - 1 full ones and a remainder), and a batch
-// that fits one launch (<= 1024 images, <= 8192 segments) is not split at all.
+// How the batch calls cut a batch into pipeline chunks (pure host logic, unit-tested on the CPU).  A chunk's thread segments
+// are one decoder wavefront each, and the decode kernel takes as long for 7168 of them as for the 8192 the chip holds at once
+// (rounds 2-3 kept the eighth wave slot of every SIMD for a single-wavefront Huffman kernel beside a one-kernel encoder;
+// neither is what runs beside the coders any more), so an automatic chunk holds at most 8192 segments and 1024 images
+// (LEP_BATCH_CHUNK_SEGMENTS: measurement knob); a kernel takes as long for a small chunk as for a full one, so the chunks are
+// balanced (k equal chunks, not k - 1 full ones and a remainder), and a batch that fits one launch is not split at all.
 int lep_batch_plan(const size_t* file_bytes, const size_t* frame_bytes, int n, const lep_batch_options* o, int* chunk_first, int cap) {
     if (n < 0 || cap < 2) return -1;
-    const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
+    const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)32 << 30);
     size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
     const bool auto_chunks = !(o && o->chunk_images > 0) && !(o && o->host_huffman);
-    size_t chunk_segments = auto_chunks ? 7168 : (size_t)1 << 30;
+    size_t cap_segments = 8192;
+    if (const char* e = getenv("LEP_BATCH_CHUNK_SEGMENTS")) cap_segments = (size_t)std::min(8192, std::max(64, atoi(e)));
+    size_t chunk_segments = auto_chunks ? cap_segments : (size_t)1 << 30;
     // thread segments a file will get, from its size (write_ujpg's rule on the scan size, jpgcoder.cc:3856-3871; the file
     // size over-estimates the scan a little, which only makes a chunk slightly smaller)
     auto segments_guess = [&](int i) -> size_t { const size_t b = file_bytes[i]; return b < 125000 ? 1 : b < 250000 ? 2 : b < 500000 ? 4 : 8; };
@@ -535,9 +538,9 @@ int lep_batch_plan(const size_t* file_bytes, const size_t* frame_bytes, int n, c
         for (int i = 0; i < n; ++i) if (frame_bytes[i]) { ++live; segs += segments_guess(i); }
         if (live <= 1024 && segs <= 8192) chunk_segments = 8192;
         else {
-            const size_t k = std::max({(segs + 7167) / 7168, (live + 1023) / 1024, (size_t)1});
-            chunk_segments = std::min<size_t>(7168, (segs + k - 1) / k + 8);
-            chunk_images = std::min<size_t>(1024, (live + k - 1) / k + 1);
+            const size_t k = std::max({(segs + cap_segments - 1) / cap_segments, (live + 1023) / 1024, (size_t)1});
+            chunk_segments = std::min<size_t>(cap_segments, ((segs + k - 1) / k + 7) & ~(size_t)7);
+            chunk_images = std::min<size_t>(1024, (live + k - 1) / k);
         }
     }
     // The first chunk's upload and scan decode have nothing to hide behind: LEP_BATCH_FIRST_CHUNK_DIV=<d> makes the first chunk of a

@@ -395,10 +395,8 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     if (!g || n < 0) return LEP_GPU_ERROR;
     g_batch_gpu = g;
     const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
-    // With the Huffman decode on the GPU, chunk k+1 is decoded WHILE the arithmetic coder of chunk k runs: a chunk's thread
-    // segments (one coder wavefront each) fill 7 of the 8 wave slots of every SIMD (7 x 4 x 256 = 7168), the eighth holds
-    // the next chunk's Huffman wavefronts (one per image, raised priority, sized to fit: lep_gpu.hip).  The chunking itself
-    // is lep_batch_plan (lep_api.cc).
+    // With the Huffman decode on the GPU, chunk k+1 is decoded (lep_huffdec_par.h, several wavefronts per image, on its own stream)
+    // WHILE the split-phase encoder's kernels of chunk k run.  The chunking itself is lep_batch_plan (lep_api.cc).
     const bool verify = o && o->verify;
     HIPOK(hipSetDevice(lep_gpu_device(g)));
     tune_malloc_for_pool();
@@ -963,7 +961,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     if (!g || n < 0) return LEP_GPU_ERROR;
     g_batch_gpu = g;
     const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
-    const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)24 << 30);
+    const size_t chunk_budget = o && o->chunk_frame_bytes ? o->chunk_frame_bytes : ((size_t)32 << 30);
     const size_t chunk_images = o && o->chunk_images > 0 ? (size_t)o->chunk_images : 1024;
     const bool gpu_huffman = !(o && o->host_huffman);
     HIPOK(hipSetDevice(lep_gpu_device(g)));

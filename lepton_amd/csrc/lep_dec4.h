@@ -67,7 +67,8 @@ struct Dec4Shared {
     uint32_t sign[kSignWords];    // resident Branches
     uint32_t resdc[kResDcWords];
     alignas(16) int32_t t[64];                // IDCT intermediate
-    int32_t icos_x[64], icos_y[64];
+    int32_t icos_x[64], icos_y[64];   // [8..63] as in ImageDev; [0..7] (the DC row / column, which no prior reads) hold DivBy multipliers:
+                                      // icos_x[p] / icos_y[p - 7] for the divisor of edge position p, icos_x[7] and icos_y[7] = the DC quantiser's pair
     int32_t eprior[16];           // Lakhani priors of the 14 edge positions; [14] = bit mask of positions whose prior divides by zero
     int16_t here[64], left[64], above[64], aleft[64];   // aligned order
     alignas(16) int16_t pix[64];
@@ -77,6 +78,9 @@ struct Dec4Shared {
     NSum ns_left, ns_above, ns_here;
     uint32_t inv24[512];          // exact 24-bit reciprocals for the Branch probability (inv24_of)
 };
+// eight wavefronts per SIMD = 32 one-wavefront workgroups per CU share its 160 KB: 5104 bytes fit, 128 more and only 28 workgroups do
+// (measured when the division constants first had fields of their own: 1121 -> 1405 ms per launch)
+static_assert(sizeof(Dec4Shared) <= 160 * 1024 / 32, "Dec4Shared no longer fits 32 times into a CU's LDS");
 
 // kNzBin for 0 <= left <= 49 without a memory access (scalar arithmetic on the GPU)
 WDEV int nzbin_of(int left) {
@@ -114,6 +118,41 @@ WDEV uint32_t mul24_low(uint32_t a, uint32_t b) {
 #else
     return mul24(a, b);
 #endif
+}
+// Truncating division of any int32 by a divisor 2 <= d < 2^31 that stays the same for a row of blocks, as one multiplication:
+// with s = ceil(log2 d) and m = ceil(2^(31+s) / d) (m < 2^32; m * d = 2^(31+s) + e, 0 <= e < d <= 2^s),
+// (u * m) >> (31 + s) = floor(u / d) for every u <= 2^31 -- the error term u * e / (d * 2^(31+s)) stays below 1 / d.
+// The compiler's own expansion of `/` is ~26 vector instructions, four of them quarter-rate multiplies; the block has two.
+// (exhaustive over the divisors the tables can hold, against `/`: tests/emu emu_check_div_by, lep_gpu_selftest)
+struct DivBy {
+    uint32_t mul, shift;          // shift = s - 1 (the other 32 come with the high half of the product)
+    WDEV static uint32_t shift_of(uint32_t d) { return 31u - (uint32_t)__builtin_clz(d - 1); }   // d >= 2
+    WDEV static DivBy of(uint32_t d) {
+        DivBy r;
+        uint32_t s = 1;
+        while (s < 31 && (1u << s) < d) ++s;
+        uint32_t q = 0, rem = 1u << (s - 1);                 // 2^(31+s) = rem * 2^32, rem < d: 32 steps of long division
+        for (int i = 0; i < 32; ++i) {
+            rem <<= 1; q <<= 1;
+            if (rem >= d) { rem -= d; q |= 1u; }
+        }
+        r.mul = q + (rem ? 1u : 0u);
+        r.shift = s - 1;
+        return r;
+    }
+};
+WDEV uint32_t mulhi_u32(uint32_t a, uint32_t b) {
+#if LEP_ON_GPU
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+WDEV int32_t div_by(int32_t n, uint32_t mul, uint32_t shift) {
+    const int32_t sign = n >> 31;
+    const uint32_t u = ((uint32_t)n ^ (uint32_t)sign) - (uint32_t)sign;      // |n|, 2^31 for the most negative one
+    const uint32_t q = mulhi_u32(u, mul) >> shift;
+    return (int32_t)((q ^ (uint32_t)sign) - (uint32_t)sign);
 }
 // Branch::record_obs_and_update (branch.hh:82-100) on the packed word, per lane: straight-line common case (table
 // reciprocal), one divergent branch for the count-overflow case (once per ~250 observations of a Branch)
@@ -309,8 +348,16 @@ struct Dec4Wave {
     WDEV void stage_component(int c) {
         comp = c; ci = c ? 1 : 0;
         LANES(l) {
-            sh->q[l] = img->q[c][l]; sh->icos_x[l] = img->icos_x[c][l]; sh->icos_y[l] = img->icos_y[c][l];
+            sh->q[l] = img->q[c][l];
             sh->thr[l] = img->min_thresh[c][l];
+            if (l >= 8) { sh->icos_x[l] = img->icos_x[c][l]; sh->icos_y[l] = img->icos_y[c][l]; }
+            if (l < 15) {         // a divisor of 1 (a DC quantiser can be) is marked by shift 32; a zero never divides (eprior[14], the host's check)
+                const uint32_t d = l < 7 ? (uint32_t)img->icos_x[c][(l + 1) * 8] : (l < 14 ? (uint32_t)img->icos_y[c][(l - 6) * 8] : (uint32_t)img->q[c][0]);
+                const DivBy m = DivBy::of(d < 2 || d > 0x7fffffffu ? 2u : d);
+                if (l < 7) sh->icos_x[l] = (int32_t)m.mul;
+                else if (l < 14) sh->icos_y[l - 7] = (int32_t)m.mul;
+                else { sh->icos_x[7] = (int32_t)m.mul; sh->icos_y[7] = d == 1 ? 32 : (int32_t)m.shift; }
+            }
         }
         LSYNC();
     }
@@ -948,7 +995,7 @@ struct Dec4Wave {
                                 int32_t term = (i & 1) ? xi + ai : xi - ai;
                                 acc -= (uint32_t)icos[i] * (uint32_t)term;
                             }
-                            prior = (int32_t)acc / icos[0];
+                            prior = div_by((int32_t)acc, (uint32_t)(hz ? S.icos_x[j] : S.icos_y[j]), DivBy::shift_of((uint32_t)icos[0]));
                         } else bad = 1;
                     }
                     S.eprior[l] = prior;
@@ -989,7 +1036,8 @@ struct Dec4Wave {
                 sum0 -= avgmed; sum1 -= avgmed;
                 unc2 = (iabs(sum0) < iabs(sum1) ? sum0 : sum1) >> 3;
             }
-            pred = (avgmed / (int)S.q[0] + 4) >> 3;
+            const uint32_t dc_shift = (uint32_t)S.icos_y[7];
+            pred = ((dc_shift == 32 ? avgmed : div_by(avgmed, (uint32_t)S.icos_x[7], dc_shift)) + 4) >> 3;
             a = imin(bitlen((uint32_t)iabs(unc) & 0xffff), 11);
             b17 = imin(bitlen((uint32_t)iabs(unc2) & 0xffff), 16);
             sctx = unc2 >= 0 ? (unc2 == 0 ? 3 : 2) : 1;

@@ -134,6 +134,15 @@ __global__ void lep_selftest_kernel(uint32_t* mismatches) {
         const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);
         if (lep3::bupd(w, obs) != branch_update(w, obs)) atomicAdd(mismatches, 1u);
     }
+    {   // lep4::div_by against the hardware's expansion of `/`: 65025 divisors (quantiser x ICOS column), numerators at their multiples
+        const int32_t d = (int32_t)((f * 257u + t) * (f & 1 ? 8192u : (t & 1 ? 2260u : 1u)));
+        if (d >= 2) {
+            const lep4::DivBy m = lep4::DivBy::of((uint32_t)d);
+            const int32_t k = (int32_t)(0x7fffffff / d);
+            for (int32_t n : {0, 1, -1, d, d - 1, -d, -d + 1, k * d, k * d - 1, -(k * d), 0x7fffffff, (int32_t)0x80000000, (int32_t)(f * 0x01000193u ^ t * 0x9e3779b9u)})
+                if (lep4::div_by(n, m.mul, m.shift) != n / d) atomicAdd(mismatches, 1u);
+        }
+    }
 }
 
 // v4 decoder: serial part as uniform vector code, multi-bin interior windows, one merged edge round (lep_dec4.h).

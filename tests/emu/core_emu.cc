@@ -163,6 +163,35 @@ extern "C" int emu_check_inv24_update() {
     return 0;
 }
 
+// lep4::div_by against `/`: every divisor the tables can hold (quantiser values 1..65535 as they are and times the eight
+// ICOS column constants), numerators around the multiples of the divisor, the extremes and random ones
+extern "C" int emu_check_div_by() {
+    static const int32_t col0[9] = {1, 8192, 11363, 10703, 9633, 8192, 6436, 4433, 2260};
+    uint64_t rnd = 0x9e3779b97f4a7c15ull;
+    for (int c = 0; c < 9; ++c)
+        for (uint32_t q = 1; q < 65536; ++q) {
+            const int64_t d64 = (int64_t)col0[c] * q;
+            if (d64 < 2 || d64 > 0x7fffffff) continue;
+            const int32_t d = (int32_t)d64;
+            const lep4::DivBy m = lep4::DivBy::of((uint32_t)d);
+            int64_t ns[40];
+            int k = 0;
+            for (int64_t v : {(int64_t)0, (int64_t)1, (int64_t)-1, (int64_t)0x7fffffff, -(int64_t)0x80000000ll, (int64_t)d, (int64_t)d - 1, (int64_t)d + 1}) ns[k++] = v;
+            for (int i = 0; i < 8; ++i) {
+                rnd = rnd * 6364136223846793005ull + 1442695040888963407ull;
+                const int64_t mult = (int64_t)((rnd >> 33) % (uint64_t)(0x7fffffff / d + 1));
+                ns[k++] = mult * d; ns[k++] = mult * d - 1; ns[k++] = -(mult * d); ns[k++] = -(mult * d) + 1;
+            }
+            for (int i = 0; i < k; ++i) {
+                if (ns[i] > 0x7fffffff || ns[i] < -(int64_t)0x80000000ll) continue;
+                const int32_t n = (int32_t)ns[i];
+                const int32_t want = (n == INT32_MIN && d == -1) ? 0 : (int32_t)((int64_t)n / d);
+                if (lep4::div_by(n, m.mul, m.shift) != want) return 1 + c;
+            }
+        }
+    return 0;
+}
+
 // GPU Huffman re-encoder (lep_huff.h) as a 64-lane loop emulation: scan bytes of one thread segment
 #include "../../lepton_amd/csrc/lep_huff.h"
 extern "C" int emu_huffman_encode_segment(const lep_huff_image* img, const lep_huff_segment* seg, uint8_t* out, uint32_t* len, lep_huff_end* end) {

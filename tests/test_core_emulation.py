@@ -244,6 +244,12 @@ def test_inv24_table_update_is_exact(emu):
     assert emu.emu_check_inv24_update() == 0
 
 
+def test_division_by_multiplication_is_exact(emu):
+    """lep_dec4.h divides by a row's constants (the Lakhani divisors, the DC quantiser) with one multiplication: every divisor the tables
+    can hold, numerators at the multiples of the divisor +- 1, the extremes, random ones"""
+    assert emu.emu_check_div_by() == 0
+
+
 @pytest.mark.parametrize("name", golden_cases())
 def test_gpu_huffman_encoder_on_cpu_restores_the_jpeg(emu, name):
     """lep_huff.h (wave-cooperative JPEG Huffman re-encode) as a 64-lane loop emulation: for every eligible fixture the

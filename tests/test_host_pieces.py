@@ -160,12 +160,14 @@ def test_batch_chunk_plan():
 
     big, small = 2_200_000, 60_000                     # 8 thread segments / 1 thread segment
     assert plan([big] * 1024) == [1024]                # fits one launch: nothing to overlap with, not split
-    assert plan([big] * 2688) == [896, 896, 896]       # 7168 segments per chunk: the eighth wave slot decodes the next chunk
-    assert plan([big] * 2048) == [683, 683, 682]       # balanced, not 896 + 896 + 256
+    assert plan([big] * 2688) == [896, 896, 896]       # three launches either way: balanced
+    assert plan([big] * 3072) == [1024, 1024, 1024]    # 8192 segments per chunk: the wavefronts the chip holds at once
+    assert plan([big] * 2048) == [1024, 1024]
+    assert plan([big] * 2100) == [700, 700, 700]       # balanced, not 1024 + 1024 + 52
     sizes = plan([big] * 1025)
     assert len(sizes) == 2 and abs(sizes[0] - sizes[1]) <= 2
-    assert plan([small] * 5000) == [1001, 1001, 1001, 1001, 996]   # images, not segments, bound chunks of small files
-    assert all(s * 8 <= 7168 + 8 for s in plan([big] * 10000))
+    assert plan([small] * 5000) == [1000] * 5           # images, not segments, bound chunks of small files
+    assert all(s * 8 <= 8192 + 8 for s in plan([big] * 10000))
     mixed = plan([big, small] * 3000)
     assert sum(mixed) == 6000 and max(mixed) <= 1024
     # unusable files (frame_bytes 0) ride along in whatever chunk they fall into and do not count
