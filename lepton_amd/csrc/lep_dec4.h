@@ -29,6 +29,26 @@ using namespace lep3;
 #else
 #define LEP_MARK(name) ((void)0)
 #endif
+// -DLEP_DEC4_PAD_VALU=<n> / _SALU / _LDS: n extra independent instructions of that kind in every block (experiment builds,
+// scripts/build_variant.sh): the slope of the launch time over n says which issue port the kernel is short of
+// (profiles/r05w_decoder_issue_port_sensitivity.txt)
+#if LEP_ON_GPU && (defined(LEP_DEC4_PAD_VALU) || defined(LEP_DEC4_PAD_SALU) || defined(LEP_DEC4_PAD_LDS))
+#define LEP_PAD8(x) x x x x x x x x
+WDEV void pad_block(uint32_t seed, const void* lds) {
+    (void)seed; (void)lds;
+#ifdef LEP_DEC4_PAD_VALU
+    { uint32_t o; for (int i = 0; i < LEP_DEC4_PAD_VALU / 8; ++i) __asm__ volatile(LEP_PAD8("v_add_u32 %0, %1, %1\n") : "=v"(o) : "v"(seed)); }
+#endif
+#ifdef LEP_DEC4_PAD_SALU
+    { uint32_t o; const uint32_t u = uni(seed); for (int i = 0; i < LEP_DEC4_PAD_SALU / 8; ++i) __asm__ volatile(LEP_PAD8("s_add_u32 %0, %1, %1\n") : "=s"(o) : "s"(u) : "scc"); }
+#endif
+#ifdef LEP_DEC4_PAD_LDS
+    { uint32_t o; const uint32_t a = (uint32_t)(uintptr_t)lds; for (int i = 0; i < LEP_DEC4_PAD_LDS / 8; ++i) __asm__ volatile(LEP_PAD8("ds_read_b32 %0, %1\n") "s_waitcnt lgkmcnt(0)\n" : "=v"(o) : "v"(a)); }
+#endif
+}
+#else
+WDEV void pad_block(uint32_t, const void*) {}
+#endif
 constexpr int prof_slot(const char* n) {
     // staging prologue nz_prefetch nz_serial nz_update 77_prefetch 77_serial 77_update lakhani edge_prefetch edge_serial
     // edge_update idct_dcpred dc_prefetch dc_serial dc_update publish store
@@ -1045,6 +1065,7 @@ struct Dec4Wave {
         round_dc(pred, a, b17, sctx);
         // ---- neighbour summary (block_context.hh:44-78) -------------------------------------------------------------
         LEP_MARK("publish");
+        pad_block((uint32_t)pred, sh);
         LANES(l) {
             if (l < 16) {
                 const int i = l & 7;
