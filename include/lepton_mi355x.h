@@ -408,6 +408,9 @@ int lep_decompress_batch(lep_gpu *g, const lep_bytes *leps, int n, lep_bytes *ou
 /* the chunking lep_compress_batch will apply: file_bytes[i] / frame_bytes[i] (lep_jpeg_peek_frame_bytes; 0 = not a usable file)
  * -> chunk k holds files [chunk_first[k], chunk_first[k + 1]); returns the number of chunks (cap = entries of chunk_first) */
 int lep_batch_plan(const size_t *file_bytes, const size_t *frame_bytes, int n, const lep_batch_options *opt, int *chunk_first, int cap);
+/* progressive files on the GPU scan decoder: scans of its one-launch form that gave up waiting for a scan in front of them since
+ * the process started (their files went to the host parser; expected 0 -- the wait cannot deadlock, the count is the safety net's) */
+uint64_t lep_jpeg_gpu_scan_wait_timeouts(void);
 void lep_batch_release(void);   /* frees the staging buffers the two calls above keep between invocations (not re-entrant) */
 /* test hook: overwrite the pinned staging buffers kept between batch calls with `value` (stale-staging regression tests) */
 void lep_batch_debug_poison(int value);

@@ -177,6 +177,7 @@ struct ProgScanDecodePlan {
 // pointer-sized integer, t.scan_len, t.rows_off / result_off relative to the file's first record; rows_needed records in all)
 int parse_jpeg_prepare_gpu_progressive(JpegFile* jf, std::vector<ProgScanDecodePlan>* scans, int* rows_needed, bool* eligible);
 int parse_jpeg_finish_gpu_progressive(JpegFile* jf, const std::vector<ProgScanDecodePlan>& scans, const ScanDecodeRow* rows);
+uint64_t prog_wait_timeouts();   // scans that ended with status 4 (gave up waiting) since the process started
 
 bool build_huff_table(const uint8_t* clen, size_t clen_avail, const uint8_t* cval, size_t cval_avail,
                       HuffTable* t, bool strict);

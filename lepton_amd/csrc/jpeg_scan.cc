@@ -12,6 +12,7 @@
 #include "jpeg_bits.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -780,6 +781,9 @@ int parse_jpeg_prepare_gpu_progressive(JpegFile* jf, std::vector<ProgScanDecodeP
     return 0;
 }
 
+static std::atomic<uint64_t> g_prog_wait_timeouts{0};   // scans of the pipelined launch that gave up waiting for a scan in front of them (status 4)
+uint64_t prog_wait_timeouts() { return g_prog_wait_timeouts.load(std::memory_order_relaxed); }
+
 int parse_jpeg_finish_gpu_progressive(JpegFile* jf, const std::vector<ProgScanDecodePlan>& scans, const ScanDecodeRow* rows) {
     const int nrows = std::max(jf->mcuv, jf->comp[0].bcv);
     const int luma_mul = jf->comp[0].bcv / jf->mcuv;
@@ -787,6 +791,7 @@ int parse_jpeg_finish_gpu_progressive(JpegFile* jf, const std::vector<ProgScanDe
     jf->max_bpos = 0; jf->max_sah = 0; jf->max_cmp = 0;
     for (size_t k = 0; k < scans.size(); ++k) {
         const ScanDecodeRow& fin = rows[scans[k].result_off];
+        if ((fin.aux >> 8) == 4) g_prog_wait_timeouts.fetch_add(1, std::memory_order_relaxed);
         if (fin.aux >> 8) return -1;                                       // irregular somewhere in this scan
         if (fin.bitpos != scans[k].t.scan_len * 8u) return -1;
         const int pb = (int8_t)(fin.aux & 255);

@@ -516,6 +516,8 @@ int lep_compress_embedded(lep_gpu* g, const uint8_t* blob, size_t len, size_t of
     return compress_parsed(g, j, blob, len, out);
 }
 
+uint64_t lep_jpeg_gpu_scan_wait_timeouts(void) { return lep::prog_wait_timeouts(); }
+
 // How the batch calls cut a batch into pipeline chunks (pure host logic, unit-tested on the CPU).  A chunk's thread segments
 // are one decoder wavefront each, and the decode kernel takes as long for 7168 of them as for the 8192 the chip holds at once
 // (rounds 2-3 kept the eighth wave slot of every SIMD for a single-wavefront Huffman kernel beside a one-kernel encoder;

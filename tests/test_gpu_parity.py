@@ -706,3 +706,5 @@ def test_gpu_progressive_pipelined_launch_beyond_what_is_resident(gpu_codec):
     got, st, stats = gpu_codec.compress_batch([jpg] * n)
     assert st == [0] * n and all(g == lep for g in got)
     assert stats["gpu_huffman_files"] == n
+    from lepton_amd import abi
+    assert abi.lib().lep_jpeg_gpu_scan_wait_timeouts() == 0
