@@ -206,6 +206,17 @@ WDEV uint32_t bupd_u(uint32_t w, uint32_t obs, const uint32_t* inv24) {
 // ---- bool decoder (boolreader.hh:184-258, 376-416; boolreader.cc:25-34) as uniform vector code ----------------------
 // 64-bit window (vhi:vlo) refilled with one ALIGNED dword at a time, the next dword requested one refill ahead.  Bytes
 // outside [0, len) of the stream are never loaded and read as zero bits (the reference's behaviour past the end).
+// two dwords as one 64-bit value through a vector bit cast: the compiler then sees a register pair, where `(hi << 32) | lo` on
+// scalar registers becomes two moves and an s_or_b64 per bin (LEP_DEC4_PAIR_OR keeps the arithmetic form for A/B builds)
+WDEV uint64_t pair64(uint32_t hi, uint32_t lo) {
+#if LEP_ON_GPU && !defined(LEP_DEC4_PAIR_OR)
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 p = {lo, hi};
+    return __builtin_bit_cast(uint64_t, p);
+#else
+    return ((uint64_t)hi << 32) | lo;
+#endif
+}
 struct BoolDec4 {
     uint32_t vhi, vlo;      // top-aligned window
     int count;              // valid bits - 8
@@ -255,7 +266,7 @@ struct BoolDec4 {
 #endif
         const int shift = __builtin_clz(range) - 24;
         range <<= shift;
-        const uint64_t v = (((uint64_t)vhi << 32) | vlo) << shift;
+        const uint64_t v = pair64(vhi, vlo) << shift;
         vhi = (uint32_t)(v >> 32); vlo = (uint32_t)v;
         count -= shift;
         return bit;
@@ -291,18 +302,26 @@ struct BoolDec4S {
         const uint32_t split = 1 + (((range - 1) * prob) >> 8);
         if (count < 0) refill(b);
         const uint32_t big = split << 24;
-        const uint32_t bit = vhi >= big ? 1u : 0u;
-        vhi = bit ? vhi - big : vhi;
+        uint32_t was = vhi;
+        const uint32_t bit = was >= big ? 1u : 0u;
+        vhi = bit ? was - big : was;
         range = bit ? range - split : split;
 #ifdef LEP_TRACE_GET
         LEP_TRACE_GET(prob, (int)bit);
 #endif
         const int shift = __builtin_clz(range) - 24;
         range <<= shift;
-        const uint64_t v = (((uint64_t)vhi << 32) | vlo) << shift;
+        const uint64_t v = pair64(vhi, vlo) << shift;
         vhi = (uint32_t)(v >> 32); vlo = (uint32_t)v;
         count -= shift;
+#if LEP_ON_GPU && !defined(LEP_DEC4_PAIR_OR)
+        // the decision once more for the caller's branch, from the two registers that still hold it: one s_cmp in front of the
+        // branch instead of a 64-bit mask made of SCC and carried across the normalisation (its shifts and subtractions write SCC)
+        __asm__ volatile("" : "+s"(was));
+        return was >= big ? 1u : 0u;
+#else
         return bit;
+#endif
     }
 };
 
