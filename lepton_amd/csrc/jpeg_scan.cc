@@ -49,22 +49,36 @@ static inline unsigned be16(unsigned a, unsigned b) { return (a << 8) + b; }
 bool build_huff_table(const uint8_t* clen, size_t clen_avail, const uint8_t* cval, size_t cval_avail,
                       HuffTable* t, bool strict) {
     *t = HuffTable();
-    unsigned listed = 0, code = 0;
+    struct Word { uint16_t first; uint8_t len, sym; };
+    Word words[256];                                      // kept sorted by `first`
+    int nw = 0;
+    unsigned listed = 0, code = 0, inner = 0;
+    bool annex_c = true;                                  // every symbol once, no code past its length, at most 255 inner nodes
     for (unsigned len = 1; len <= 16; ++len, code <<= 1) {
         const unsigned n = len - 1 < clen_avail ? clen[len - 1] : 0;
         for (unsigned j = 0; j < n; ++j, ++listed, ++code) {
             const unsigned at = listed & 0xff;
             const uint8_t sym = at < cval_avail ? cval[at] : 0;
+            annex_c = annex_c && listed < 256 && !t->clen[sym] && code < (1u << len);
             t->clen[sym] = (uint16_t)len;
             t->cval[sym] = (uint16_t)code;
+            if (!annex_c) continue;
+            // codes come in rising order: the bits of this one (bar the last) that are not inner nodes yet are those it does not
+            // share with the code before it
+            const unsigned first = code << (16 - len);
+            unsigned shared = 0;
+            if (nw) {
+                const unsigned diff = first ^ words[nw - 1].first;
+                shared = std::min<unsigned>({diff ? (unsigned)__builtin_clz(diff) - 16 : 16u, words[nw - 1].len - 1u, len - 1});
+            }
+            inner += len - 1 - shared;
+            words[nw++] = Word{(uint16_t)first, (uint8_t)len, sym};
         }
     }
     for (int i = 14; i >= 0; --i)                         // longest end-of-band run an AC table of a progressive scan can code
         if (t->clen[(i << 4) & 255] > 0) { t->max_eobrun = (2 << i) - 1; break; }
+    if (!annex_c || inner > 255) nw = 0;                  // the general case below; otherwise the words are the codes as listed
 
-    struct Word { uint16_t first; uint8_t len, sym; };
-    Word words[256];                                      // kept sorted by `first`
-    int nw = 0;
     uint16_t seen_first[256];                             // codes entered so far: every bit but the last is an inner node
     uint8_t seen_len[256];
     int nseen = 0;
@@ -79,7 +93,7 @@ bool build_huff_table(const uint8_t* clen, size_t clen_avail, const uint8_t* cva
         words[a] = w;
         nw += a + 1 - b;
     };
-    for (unsigned sym = 0; sym < 256; ++sym) {
+    for (unsigned sym = 0; sym < 256 && !(annex_c && inner <= 255); ++sym) {
         const int len = t->clen[sym];
         if (!len) continue;
         const unsigned first = ((unsigned)t->cval[sym] << (16 - len)) & 0xffff;   // (an over-full table counts past its length: the low bits are the code)
