@@ -21,6 +21,10 @@ import sys
 import tempfile
 import time
 
+# the library asks for 8 hardware queues when it is loaded (lep_gpu.hip: lep_runtime_defaults) -- too late under N > 1, where torch
+# brings the HIP runtime up for RCCL before the library is: say it here, before anything touches the GPU
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
