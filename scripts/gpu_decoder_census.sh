@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: instructions per block of the decode kernels on made-up frames (scripts/dec_microbench.py)
+# instructions per block of the decode kernels on made-up frames (scripts/dec_microbench.py)
 set -u
 TAG=${1:-r5f}; export TMPDIR=/tmp
 OUT=gpurun_out/$TAG; mkdir -p $OUT

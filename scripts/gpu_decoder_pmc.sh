@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: what bounds the v5 decoder -- instruction counts, wave time, instruction cache, for v4 / v5 one wavefront / v5 groups of four
+# what bounds the v5 decoder -- instruction counts, wave time, instruction cache, for v4 / v5 one wavefront / v5 groups of four
 set -u
 TAG=${1:-r5e}; export TMPDIR=/tmp
 OUT=gpurun_out/$TAG; mkdir -p $OUT

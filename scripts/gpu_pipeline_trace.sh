@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, visit 1: kernel + copy trace of the batch pipeline (2688 x 4K, three chunks) on the shipped build -> timeline table
+# kernel + copy trace of the batch pipeline (2688 x 4K, three chunks) on the shipped build -> timeline table
 set -u
 TAG=${1:-r5a}; export TMPDIR=/tmp
 OUT=gpurun_out/$TAG; mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: workspaces as owned virtual-memory ranges (LEP_VMM=1, the default) against hipMalloc / hipFree (LEP_VMM=0): parity subset, the
+# workspaces as owned virtual-memory ranges (LEP_VMM=1, the default) against hipMalloc / hipFree (LEP_VMM=0): parity subset, the
 # trim experiment, the resident bench
 set -u
 TAG=${1:-r5l}; export TMPDIR=/tmp
