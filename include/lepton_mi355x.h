@@ -219,6 +219,12 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu *g, const lep_huffprogdec_
  * Images with restart intervals are not accepted.  A subsequence that fails to synchronise gives its image a non-zero
  * status, exactly like an irregular scan. */
 int lep_gpu_huffman_decode_parallel_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, int nsub, lep_huffdec_row *d_rows, void *hip_stream);
+/* ... with one LANE per subsequence (lep_huffdec_simt.h): a scan is cut into thousands of subsequences, every lane decodes one with a
+ * bit reader of its own -- a guess from its first bit, settle passes from where the lane in front ended until no end state moves,
+ * a prefix sum, a write pass into the ZERO-FILLED frame.  Same records, same frame, same status semantics as the single-wave
+ * kernel (bit-exact against it on MI355X and in the lane-loop emulation); scans with restart intervals are refused
+ * (LEP_ASSERTION_FAILURE: the single-wave kernel's).  LEP_HUFFDEC_SIMT_BITS forces the subsequence length (tests). */
+int lep_gpu_huffman_decode_simt_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, lep_huffdec_row *d_rows, void *hip_stream);
 /* plain device memory helpers so non-torch callers need no HIP binding */
 /* Device self-test of kernel arithmetic that has no CPU twin (exhaustive: the float-reciprocal Branch probability of the
  * kernels against integer division, src/vp8/model/branch.hh:82-125).  0 = exact everywhere. */

@@ -611,11 +611,15 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             // chunk's encode launch waited ~0.5 s for the scan decode of its own images -- while the parallel form takes 0.31 s and
             // shares the chip with the walks (they wait 60 % of their wave time): compress 1675 -> 2184 MB/s (profiles/r05c_*).
             // LEP_HUFFDEC_PAR=<n> forces n (0 = single wave) for every chunk.
-            const int par = getenv("LEP_HUFFDEC_PAR") ? atoi(getenv("LEP_HUFFDEC_PAR")) : 16;
+            // Round 4, second half: one LANE per subsequence (lep_huffdec_simt.h) -- thousands of subsequences per scan, 64 codes per
+            // instruction -- instead of one wavefront per subsequence; LEP_HUFFDEC_SIMT=0 keeps the wavefront form above.
+            const bool simt = !(getenv("LEP_HUFFDEC_SIMT") && atoi(getenv("LEP_HUFFDEC_SIMT")) == 0) && !getenv("LEP_HUFFDEC_PAR");
+            const int par = simt ? 16 : (getenv("LEP_HUFFDEC_PAR") ? atoi(getenv("LEP_HUFFDEC_PAR")) : 16);
             if (par >= 2) {
                 std::vector<lep_huffdec_image> many, one;
                 for (const lep_huffdec_image& hi : launch) (hi.rsti ? one : many).push_back(hi);
-                if (!many.empty()) { if (int rc = lep_gpu_huffman_decode_parallel_device(g, many.data(), (int)many.size(), par > 64 ? 64 : par, (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
+                if (!many.empty() && simt) { if (int rc = lep_gpu_huffman_decode_simt_device(g, many.data(), (int)many.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
+                else if (!many.empty()) { if (int rc = lep_gpu_huffman_decode_parallel_device(g, many.data(), (int)many.size(), par > 64 ? 64 : par, (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
                 if (!one.empty()) { if (int rc = lep_gpu_huffman_decode_device(g, one.data(), (int)one.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
             } else
             if (int rc = lep_gpu_huffman_decode_device(g, launch.data(), (int)launch.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc;

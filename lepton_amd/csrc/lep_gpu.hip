@@ -25,6 +25,7 @@
 #include "lep_huff.h"
 #include "lep_huffdec.h"
 #include "lep_huffdec_par.h"
+#include "lep_huffdec_simt.h"
 #include "lep_huffprog.h"
 #include "lep_huffprogdec.h"
 
@@ -419,6 +420,32 @@ __global__ void lep_huffman_par_finish_kernel(const lephuff::HuffDecImage* __res
     last->aux = (last->aux & 255) | (img_status[i] << 8);
 }
 
+// One lane per subsequence (lep_huffdec_simt.h): guess / settle / place / write; a wavefront's 64 lanes are 64 consecutive
+// subsequences of one image, whose tables the wavefront keeps in LDS.
+__global__ __launch_bounds__(64) void lep_huffman_simt_settle_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::SimtImage* si, const lephuff::SimtWave* waves,
+                                                                     const lephuff::SimtSub* in, lephuff::SimtSub* out, int settle) {
+    __shared__ lephuff::SimtShared sh;
+    const lephuff::SimtWave w = waves[blockIdx.x];
+    lephuff::simt_guess_or_settle(images + w.image, &sh, si + w.image, in + si[w.image].first, out + si[w.image].first, w.first_sub, settle);
+}
+__global__ __launch_bounds__(64) void lep_huffman_simt_place_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::SimtImage* si, const lephuff::SimtSub* sub,
+                                                                    lephuff::SimtPlace* place, int passes) {
+    const int i = (int)blockIdx.x;
+    lephuff::simt_place(images + i, si + i, sub + si[i].first, place + si[i].first, passes);
+}
+__global__ __launch_bounds__(64) void lep_huffman_simt_write_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::SimtImage* si, const lephuff::SimtWave* waves,
+                                                                    const lephuff::SimtSub* sub, const lephuff::SimtPlace* place, lephuff::HuffDecRow* rows) {
+    __shared__ lephuff::SimtShared sh;
+    const lephuff::SimtWave w = waves[blockIdx.x];
+    lephuff::simt_write(images + w.image, &sh, si + w.image, sub + si[w.image].first, place + si[w.image].first, rows, w.first_sub);
+}
+__global__ void lep_huffman_simt_finish_kernel(const lephuff::HuffDecImage* __restrict__ images, int nimg, lephuff::HuffDecRow* rows, const lephuff::SimtImage* si) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= nimg) return;
+    lephuff::HuffDecRow* last = rows + images[i].rows_off + images[i].mcuv;
+    last->aux = (last->aux & 255) | (si[i].status << 8);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -434,6 +461,7 @@ struct lep_gpu {
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     int huffprog_pipeline = 1;          // LEP_HUFFPROG_PIPELINE=0: progressive scan decode level by level, whatever the launch size
+    int simt_sub_bits = 0;              // LEP_HUFFDEC_SIMT_BITS: bits per subsequence of the lane-per-subsequence scan decoder (0 = from the launch's size)
     int huffprog_pipeline_max = 16384;  // LEP_HUFFPROG_PIPELINE_MAX: scans per launch up to which the levels go out as one pipelined launch (measured to 10240:
                                         // 1024 4K files, 798 -> 938 MB/s; a workgroup takes the scan of the ticket it draws when it starts, so a scan's predecessors are always running or done)
     int enc5_waves = 2;      // LEP_ENC5_WAVES: wavefronts per segment in the split-phase walks (1 | 2)
@@ -941,6 +969,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_ENC5_MIN")) g->enc5_min = atoi(e);
     if (const char* e = getenv("LEP_HUFFPROG_PIPELINE")) g->huffprog_pipeline = atoi(e);
     if (const char* e = getenv("LEP_HUFFPROG_PIPELINE_MAX")) g->huffprog_pipeline_max = atoi(e);
+    if (const char* e = getenv("LEP_HUFFDEC_SIMT_BITS")) g->simt_sub_bits = std::max(0, atoi(e));
     if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
     if (const char* e = getenv("LEP_ENC5_GATHER_WGS")) g->enc5_gather_wgs = atoi(e);
@@ -1173,6 +1202,59 @@ int lep_gpu_huffman_decode_parallel_device(lep_gpu* g, const lep_huffdec_image* 
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
     g->last_kernel = "lep_huffman_par_{sync,stitch,write}_kernel";
+    return 0;
+}
+
+int lep_gpu_huffman_decode_simt_device(lep_gpu* g, const lep_huffdec_image* images, int nimg, lep_huffdec_row* d_rows, void* hip_stream) {
+    if (!g) return LEP_GPU_ERROR;
+    if (nimg <= 0) return 0;
+    uint64_t bits = 0;
+    for (int i = 0; i < nimg; ++i) { if (images[i].rsti) return LEP_ASSERTION_FAILURE; bits += (uint64_t)images[i].scan_len * 8u; }   // restart intervals: the single-wave kernel's
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
+    HIPCHK(g, hipSetDevice(g->device));
+    // subsequences: as many as fill the chip a few times over (lanes = 64 x the wavefronts it holds, twice), but none shorter than a scan
+    // needs to fall into step
+    const uint32_t L = g->simt_sub_bits ? (uint32_t)((g->simt_sub_bits + 31) & ~31) : lephuff::simt_sub_bits(bits, (uint64_t)64 * 8192 * 2);
+    std::vector<lephuff::SimtImage> si((size_t)nimg);
+    std::vector<lephuff::SimtWave> waves;
+    size_t nsub_all = 0;
+    for (int i = 0; i < nimg; ++i) {
+        memset(&si[(size_t)i], 0, sizeof(lephuff::SimtImage));
+        const uint64_t b = (uint64_t)images[i].scan_len * 8u;
+        const uint32_t n = (uint32_t)std::max<uint64_t>(1, (b + L - 1) / L);
+        si[(size_t)i].first = (uint32_t)nsub_all; si[(size_t)i].nsub = n; si[(size_t)i].sub_bits = L;
+        for (uint32_t f = 0; f < n; f += 64) waves.push_back(lephuff::SimtWave{(uint32_t)i, f});
+        nsub_all += n;
+    }
+    if (nsub_all > 0x7fffffffu) return LEP_ASSERTION_FAILURE;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_si = 0, o_wv = up(si.size() * sizeof(lephuff::SimtImage)), o_s0 = o_wv + up(waves.size() * sizeof(lephuff::SimtWave)),
+                 o_s1 = o_s0 + up(nsub_all * sizeof(lephuff::SimtSub)), o_pl = o_s1 + up(nsub_all * sizeof(lephuff::SimtSub)), total = o_pl + up(nsub_all * sizeof(lephuff::SimtPlace));
+    if (int rc = ensure(g, &g->d_huffdec, &g->huffdec_bytes, (size_t)nimg * sizeof(lep_huffdec_image))) return rc;
+    if (int rc = ensure(g, &g->d_huffpar, &g->huffpar_bytes, total)) return rc;
+    char* base = (char*)g->d_huffpar;
+    HIPCHK(g, hipMemcpyAsync(g->d_huffdec, images, (size_t)nimg * sizeof(lep_huffdec_image), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipMemcpyAsync(base + o_si, si.data(), si.size() * sizeof(lephuff::SimtImage), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipMemcpyAsync(base + o_wv, waves.data(), waves.size() * sizeof(lephuff::SimtWave), hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipStreamSynchronize(st));   // the caller's array (and ours) may go away
+    const lephuff::HuffDecImage* di = (const lephuff::HuffDecImage*)g->d_huffdec;
+    lephuff::SimtImage* dsi = (lephuff::SimtImage*)(base + o_si);
+    const lephuff::SimtWave* dwv = (const lephuff::SimtWave*)(base + o_wv);
+    lephuff::SimtSub* buf[2] = {(lephuff::SimtSub*)(base + o_s0), (lephuff::SimtSub*)(base + o_s1)};
+    lephuff::SimtPlace* dpl = (lephuff::SimtPlace*)(base + o_pl);
+    const int nw = (int)waves.size();
+    HIPCHK(g, hipEventRecord(g->ev0, st));
+    hipLaunchKernelGGL(lep_huffman_simt_settle_kernel, dim3(nw), dim3(64), 0, st, di, dsi, dwv, (const lephuff::SimtSub*)buf[1], buf[0], 0);
+    for (int k = 1; k <= lephuff::kSimtSettle; ++k)
+        hipLaunchKernelGGL(lep_huffman_simt_settle_kernel, dim3(nw), dim3(64), 0, st, di, dsi, dwv, (const lephuff::SimtSub*)buf[(k - 1) & 1], buf[k & 1], k);
+    const lephuff::SimtSub* fin = buf[lephuff::kSimtSettle & 1];
+    hipLaunchKernelGGL(lep_huffman_simt_place_kernel, dim3(nimg), dim3(64), 0, st, di, dsi, fin, dpl, lephuff::kSimtSettle);
+    hipLaunchKernelGGL(lep_huffman_simt_write_kernel, dim3(nw), dim3(64), 0, st, di, dsi, dwv, fin, (const lephuff::SimtPlace*)dpl, (lephuff::HuffDecRow*)d_rows);
+    hipLaunchKernelGGL(lep_huffman_simt_finish_kernel, dim3((nimg + 255) / 256), dim3(256), 0, st, di, nimg, (lephuff::HuffDecRow*)d_rows, (const lephuff::SimtImage*)dsi);
+    HIPCHK(g, hipGetLastError());
+    HIPCHK(g, hipEventRecord(g->ev1, st));
+    g->timed = true;
+    g->last_kernel = "lep_huffman_simt_{settle,place,write}_kernel";
     return 0;
 }
 

@@ -286,6 +286,33 @@ extern "C" int emu_huffman_decode_image_parallel(const lep_huffdec_image* img, l
 }
 
 
+// one lane per subsequence (lep_huffdec_simt.h): guess, settle passes, place, write -- every pass one wavefront after the other.
+// settle_moved[k] (k = 0 .. kSimtSettle): whether pass k saw an end state move; nsub_out: subsequences the scan was cut into.
+#include "../../lepton_amd/csrc/lep_huffdec_simt.h"
+extern "C" int emu_huffman_decode_image_simt(const lep_huffdec_image* img, lep_huffdec_row* rows, uint32_t sub_bits, int32_t* settle_moved, uint32_t* nsub_out) {
+    static lephuff::SimtShared sh;
+    lephuff::HuffDecImage im;
+    memcpy(&im, img, sizeof im);
+    im.rows_off = 0;
+    const uint32_t L = (sub_bits + 31u) & ~31u;
+    if (!L) return -1;
+    lephuff::SimtImage si;
+    memset(&si, 0, sizeof si);
+    si.first = 0; si.sub_bits = L;
+    si.nsub = (uint32_t)std::max<uint64_t>(1, ((uint64_t)im.scan_len * 8u + L - 1) / L);
+    std::vector<lephuff::SimtSub> buf[2] = {std::vector<lephuff::SimtSub>(si.nsub), std::vector<lephuff::SimtSub>(si.nsub)};
+    std::vector<lephuff::SimtPlace> place(si.nsub);
+    for (int k = 0; k <= lephuff::kSimtSettle; ++k)
+        for (uint32_t f = 0; f < si.nsub; f += 64) lephuff::simt_guess_or_settle(&im, &sh, &si, buf[(k + 1) & 1].data(), buf[k & 1].data(), f, k);
+    const lephuff::SimtSub* fin = buf[lephuff::kSimtSettle & 1].data();
+    lephuff::simt_place(&im, &si, fin, place.data(), lephuff::kSimtSettle);
+    for (uint32_t f = 0; f < si.nsub; f += 64) lephuff::simt_write(&im, &sh, &si, fin, place.data(), reinterpret_cast<lephuff::HuffDecRow*>(rows), f);
+    rows[im.mcuv].aux = (rows[im.mcuv].aux & 255) | (si.status << 8);
+    if (settle_moved) for (int k = 0; k <= lephuff::kSimtSettle; ++k) settle_moved[k] = si.changed[k];
+    if (nsub_out) *nsub_out = si.nsub;
+    return 0;
+}
+
 // split-phase encoder (lep_enc5.h): count -> plan -> emit -> fold (every chain) -> gather -> write, one segment, every pass
 // stepped as a 64-lane loop emulation; bins_out (optional): the (probability | bit << 8) list the writer consumed
 #include "../../lepton_amd/csrc/lep_enc5.h"

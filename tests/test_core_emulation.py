@@ -493,6 +493,83 @@ def test_parallel_huffman_decoder_equals_the_single_wave_one(emu, name, nsub):
         assert (rows2[r].bitpos, list(rows2[r].last_dc), rows2[r].aux) == (rows1[r].bitpos, list(rows1[r].last_dc), rows1[r].aux), r
 
 
+def _jpeg_for_huffman_tests(name):
+    import io
+    from lepton_amd import corpus
+    if name == "synth_640x360":
+        return corpus.synth_jpeg(640, 360, 71, quality=88)
+    if name == "synth_1920x1080":
+        return corpus.synth_jpeg(1920, 1080, 72, quality=90)
+    if name == "optimized_q30":
+        from PIL import Image
+        import numpy as np
+        rng = np.random.default_rng(31)
+        a = np.asarray(Image.fromarray(rng.integers(0, 256, (30, 40, 3), dtype=np.uint8), "RGB").resize((320, 240), Image.BICUBIC)).astype(np.int16)
+        a = np.clip(a + rng.normal(0, 12, a.shape), 0, 255).astype(np.uint8)
+        buf = io.BytesIO(); Image.fromarray(a, "RGB").save(buf, format="JPEG", quality=30, subsampling="4:2:2", optimize=True)
+        return buf.getvalue()
+    return golden(name)[0]
+
+
+@pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "synth_1920x1080", "optimized_q30"])
+@pytest.mark.parametrize("sub_bits", [1024, 4096, 16384])
+def test_lane_per_subsequence_huffman_decoder_equals_the_single_wave_one(emu, name, sub_bits):
+    """lep_huffdec_simt.h (one lane per subsequence: a guess from the subsequence's first bit, settle passes from where the lane in front
+    ended, prefix sums, write pass) must leave exactly what lep_huffdec.h leaves -- frame, hand-off records, pad bit -- or report a
+    non-zero status (fallback), never a different result.  Subsequences far shorter than the product's 8192 bits are cut on purpose:
+    then lanes do NOT fall into step inside their subsequence and the settle passes have work to do."""
+    from lepton_amd import abi
+
+    jpg = _jpeg_for_huffman_tests(name)
+    one = _huffdec_setup(jpg)
+    if one is None:
+        pytest.skip("not eligible for the GPU Huffman decoder")
+    img1, scan1, planes1, d = one
+    if img1.rsti:
+        pytest.skip("restart intervals: the single-wave kernel keeps these files")
+    rows1 = (abi.HuffDecRow * (img1.mcuv + 1))()
+    assert emu.emu_huffman_decode_image(C.byref(img1), rows1) == 0 and rows1[img1.mcuv].aux >> 8 == 0
+    img2, scan2, planes2, _ = _huffdec_setup(jpg)
+    rows2 = (abi.HuffDecRow * (img2.mcuv + 1))()
+    moved = (C.c_int32 * 8)()
+    nsub = C.c_uint32(0)
+    assert emu.emu_huffman_decode_image_simt(C.byref(img2), rows2, sub_bits, moved, C.byref(nsub)) == 0
+    status = rows2[img2.mcuv].aux >> 8
+    if status:
+        # allowed only where the settle passes ran out: subsequences too short to fall into step in
+        assert sub_bits < 8192 and moved[3], "lane-per-subsequence decode gave up (status %d) with %d bits per subsequence, moved %s" % (status, sub_bits, list(moved)[:4])
+        return
+    assert not moved[3]
+    for c in range(d.ncomp):
+        assert planes2[c].raw == planes1[c].raw
+    for r in range(img1.mcuv + 1):
+        assert (rows2[r].bitpos, list(rows2[r].last_dc), rows2[r].aux) == (rows1[r].bitpos, list(rows1[r].last_dc), rows1[r].aux), r
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_lane_per_subsequence_huffman_decoder_survives_garbage(emu, seed):
+    """random bytes instead of a scan: every pass terminates, nothing is written outside the frame, and the outcome is a status or
+    (if the garbage happens to decode) the same as the single-wave kernel's"""
+    import numpy as np
+    from lepton_amd import abi, corpus
+
+    jpg = corpus.synth_jpeg(96, 64, 78)
+    outs = []
+    for simt in (0, 1):
+        img, scan, planes, d = _huffdec_setup(jpg)
+        n = img.scan_len
+        junk = C.create_string_buffer(bytes(np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)) + bytes(64), n + 72)
+        img.scan = C.addressof(junk)
+        rows = (abi.HuffDecRow * (img.mcuv + 1))()
+        if simt:
+            assert emu.emu_huffman_decode_image_simt(C.byref(img), rows, 1024, None, None) == 0
+        else:
+            assert emu.emu_huffman_decode_image(C.byref(img), rows) == 0
+        outs.append((rows[img.mcuv].aux >> 8, [p.raw for p in planes]))
+    if outs[0][0] == 0 and outs[1][0] == 0:
+        assert outs[0][1] == outs[1][1]
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_parallel_huffman_decoder_survives_garbage(emu, seed):
     """random bytes instead of a scan: every pass terminates, nothing is written outside the frame, and the outcome is a

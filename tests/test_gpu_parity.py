@@ -432,6 +432,84 @@ def test_gpu_parallel_huffman_decode_in_the_compress_pipeline(gpu_codec, monkeyp
     assert got[len(names):] == [gpu_codec.compress(j) for j in jpgs[len(names):]]
 
 
+@pytest.mark.parametrize("bits", ["0", "1024", "4096", "65536"])
+def test_gpu_lane_per_subsequence_huffman_decode_in_the_compress_pipeline(gpu_codec, monkeypatch, bits):
+    """one lane per subsequence decodes the JPEG scan (lep_huffdec_simt.h, the default of the batch compressor; LEP_HUFFDEC_SIMT_BITS
+    forces the subsequence length: 1024 bits leave the settle passes work to do and some scans to the fallback, 65536 make most
+    fixtures a single lane) -- same .lep bytes as the reference's, whichever path a file ends up on"""
+    names = golden_cases()
+    jpgs = [golden(n)[0] for n in names] + [corpus.synth_jpeg(1280, 720, 61), corpus.synth_jpeg(640, 480, 62, quality=97), corpus.synth_jpeg(1920, 1080, 63)]
+    monkeypatch.delenv("LEP_HUFFDEC_PAR", raising=False)
+    monkeypatch.setenv("LEP_HUFFDEC_SIMT", "1")
+    if bits != "0":
+        monkeypatch.setenv("LEP_HUFFDEC_SIMT_BITS", bits)
+    codec = GpuCodec(0)        # the knob is read when the codec object is made
+    try:
+        got, st, stats = codec.compress_batch(jpgs, chunk_images=12)
+        assert st == [0] * len(jpgs)
+        assert got[: len(names)] == [golden(n)[1] for n in names]
+        assert got[len(names):] == [gpu_codec.compress(j) for j in jpgs[len(names):]]
+        assert stats["gpu_huffman_files"] > len(jpgs) // 2
+    finally:
+        codec.close()
+
+
+def test_gpu_lane_per_subsequence_huffman_decode_equals_the_single_wave_kernel(gpu_codec):
+    """the two scan decoders called directly on device-resident scans of 24 different 4:2:0 images: same frames, same hand-off records"""
+    import test_core_emulation as emu_tests
+
+    L = abi.lib()
+    g = gpu_codec.handle
+    jpgs = [corpus.synth_jpeg(640 + 64 * (i % 5), 360 + 40 * (i % 3), 300 + i, quality=70 + i) for i in range(24)]
+
+    def dmalloc(n):
+        p = C.c_void_p()
+        assert L.lep_gpu_malloc(g, n, C.byref(p)) == 0
+        return p
+
+    results = []
+    for simt in (0, 1):
+        frames = [emu_tests._huffdec_setup(jpg) for jpg in jpgs]
+        imgs = (abi.HuffDecImage * len(jpgs))()
+        dev, planes_dev = [], []
+        rows_total = 0
+        for k, (img, scan, planes, d) in enumerate(frames):
+            n = len(scan.raw)
+            dscan = dmalloc(n)
+            assert L.lep_gpu_memcpy_h2d(g, dscan, scan, n) == 0
+            dev.append(dscan)
+            C.memmove(C.byref(imgs[k]), C.byref(img), C.sizeof(abi.HuffDecImage))
+            imgs[k].scan = dscan.value
+            for c in range(d.ncomp):
+                nb = len(planes[c].raw)
+                p = dmalloc(nb)
+                assert L.lep_gpu_memset(g, p, 0, nb) == 0
+                dev.append(p)
+                planes_dev.append((p, nb))
+                imgs[k].blocks[c] = p.value
+            imgs[k].rows_off = rows_total
+            rows_total += img.mcuv + 1
+        nrow_bytes = rows_total * C.sizeof(abi.HuffDecRow)
+        drows = dmalloc(nrow_bytes)
+        assert L.lep_gpu_memset(g, drows, 0, nrow_bytes) == 0
+        fn = L.lep_gpu_huffman_decode_simt_device if simt else L.lep_gpu_huffman_decode_device
+        assert fn(g, imgs, len(jpgs), drows, None) == 0
+        assert L.lep_gpu_sync(g) == 0
+        rows = C.create_string_buffer(nrow_bytes)
+        assert L.lep_gpu_memcpy_d2h(g, rows, drows, nrow_bytes) == 0
+        out = [rows.raw]
+        for p, nb in planes_dev:
+            buf = C.create_string_buffer(nb)
+            assert L.lep_gpu_memcpy_d2h(g, buf, p, nb) == 0
+            out.append(buf.raw)
+        results.append(out)
+        for p in dev + [drows]:
+            L.lep_gpu_free(g, p)
+    assert len(results[0]) == len(results[1])
+    for i, (x, y) in enumerate(zip(results[0], results[1])):
+        assert x == y, "buffer %d differs" % i
+
+
 @pytest.mark.parametrize("waves", ["2", "4", "8"])
 def test_gpu_encoder_builds_agree(waves, monkeypatch):
     """the encoder's three launch forms -- two wavefronts per segment (producer / bool coder, small launches), one wavefront
