@@ -26,6 +26,7 @@
 #include "lep_huffdec.h"
 #include "lep_huffdec_par.h"
 #include "lep_huffdec_simt.h"
+#include "lep_huff_simt.h"
 #include "lep_huffprog.h"
 #include "lep_huffprogdec.h"
 
@@ -341,10 +342,28 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_encode_kernel(const lephuff
     __shared__ lephuff::HuffShared sh;
     const int s = blockIdx.x;
     const lephuff::HuffSegment seg = segs[s];
+    if (seg.pad & 1u) return;                  // the lane-per-unit kernels below own this segment
     lephuff::HuffWave w;
     const uint32_t n = w.run(images + seg.image, seg, &sh, out);
     if (threadIdx.x == 0) out_len[s] = n;
     if (ends) w.export_end(ends + s);
+}
+// ... with one lane per run of MCUs (lep_huff_simt.h): count / place / code / stuff
+template <bool WRITE>
+__global__ __launch_bounds__(64) void lep_huffman_simt_encode_units_kernel(const lephuff::HuffImage* __restrict__ images, const lephuff::HuffSegment* __restrict__ segs,
+                                                                           lephuff::SimtEncSeg* es, const lephuff::SimtEncWave* __restrict__ waves,
+                                                                           uint32_t* unit_bits, uint8_t* scratch) {
+    __shared__ lephuff::SimtEncShared sh;
+    const lephuff::SimtEncWave w = waves[blockIdx.x];
+    lephuff::simt_enc_units<WRITE>(images, segs, es + w.eseg, &sh, unit_bits, scratch, w.first_unit);
+}
+__global__ __launch_bounds__(64) void lep_huffman_simt_encode_place_kernel(const lephuff::HuffSegment* __restrict__ segs, lephuff::SimtEncSeg* es, uint32_t* unit_bits) {
+    lephuff::simt_enc_place(segs, es + blockIdx.x, unit_bits);
+}
+__global__ __launch_bounds__(64) void lep_huffman_simt_encode_stuff_kernel(const lephuff::HuffImage* __restrict__ images, const lephuff::HuffSegment* __restrict__ segs,
+                                                                           const lephuff::SimtEncSeg* __restrict__ es, uint8_t* scratch, uint8_t* out, uint32_t* out_len,
+                                                                           lephuff::HuffEnd* ends) {
+    lephuff::simt_enc_stuff(images, segs, es[blockIdx.x], scratch, out, out_len, ends);
 }
 
 // progressive files: one wavefront per (image, scan) (lep_huffprog.h)
@@ -461,6 +480,8 @@ struct lep_gpu {
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     int huffprog_pipeline = 1;          // LEP_HUFFPROG_PIPELINE=0: progressive scan decode level by level, whatever the launch size
+    int huffenc_simt = 1;               // LEP_HUFFENC_SIMT=0: every segment's scan bytes from the wavefront-per-segment kernel (lep_huff.h)
+    void* d_huffenc = nullptr; size_t huffenc_bytes = 0;   // lep_huff_simt.h: segment / wave descriptors, unit bit counts, bit buffers
     int simt_sub_bits = 0;              // LEP_HUFFDEC_SIMT_BITS: bits per subsequence of the lane-per-subsequence scan decoder (0 = from the launch's size)
     int huffprog_pipeline_max = 16384;  // LEP_HUFFPROG_PIPELINE_MAX: scans per launch up to which the levels go out as one pipelined launch (measured to 10240:
                                         // 1024 4K files, 798 -> 938 MB/s; a workgroup takes the scan of the ticket it draws when it starts, so a scan's predecessors are always running or done)
@@ -970,6 +991,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_HUFFPROG_PIPELINE")) g->huffprog_pipeline = atoi(e);
     if (const char* e = getenv("LEP_HUFFPROG_PIPELINE_MAX")) g->huffprog_pipeline_max = atoi(e);
     if (const char* e = getenv("LEP_HUFFDEC_SIMT_BITS")) g->simt_sub_bits = std::max(0, atoi(e));
+    if (const char* e = getenv("LEP_HUFFENC_SIMT")) g->huffenc_simt = atoi(e) != 0;
     if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
     if (const char* e = getenv("LEP_ENC5_GATHER_WGS")) g->enc5_gather_wgs = atoi(e);
@@ -1005,7 +1027,7 @@ static void release_device_side(lep_gpu* g) {
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     if (g->stream3) (void)hipStreamDestroy(g->stream3);
     for (void** p : {&g->arena[0].d_models, &g->arena[0].d_ns, &g->arena[0].d_meta, &g->arena[1].d_models, &g->arena[1].d_ns, &g->arena[1].d_meta, &g->d_blocks, &g->d_streams, &g->d_lens, &g->d_huff,
-                     &g->d_huffprog[0], &g->d_huffprog[1], &g->d_huffprogdec, &g->d_huffdec, &g->d_huffpar, &g->d_scan, &g->d_scanlen})
+                     &g->d_huffprog[0], &g->d_huffprog[1], &g->d_huffprogdec, &g->d_huffdec, &g->d_huffpar, &g->d_huffenc, &g->d_scan, &g->d_scanlen})
         dev_release(g, p, nullptr);
     vmm_destroy(g);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
@@ -1051,16 +1073,62 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
     HIPCHK(g, hipSetDevice(g->device));
     const size_t o_seg = (nimg * sizeof(lep_huff_image) + 255) & ~(size_t)255, total = o_seg + nseg * sizeof(lep_huff_segment);
     if (int rc = ensure(g, &g->d_huff, &g->huff_bytes, total)) return rc;
+    // which segments the lane-per-unit kernels take (lep_huff_simt.h); the wavefront-per-segment kernel keeps the others
+    static_assert(sizeof(lep_huff_image) == sizeof(lephuff::HuffImage) && sizeof(lep_huff_segment) == sizeof(lephuff::HuffSegment), "C ABI mirrors");
+    std::vector<lep_huff_segment> sv(segs, segs + nseg);
+    std::vector<lephuff::SimtEncSeg> es;
+    std::vector<lephuff::SimtEncWave> waves;
+    size_t nunits = 0, scratch_bytes = 0;
+    if (g->huffenc_simt)
+        for (int i = 0; i < nseg; ++i) {
+            sv[(size_t)i].pad = 0;
+            if (sv[(size_t)i].image < 0 || sv[(size_t)i].image >= nimg) continue;
+            const lephuff::HuffImage& im = reinterpret_cast<const lephuff::HuffImage&>(images[sv[(size_t)i].image]);
+            if (!lephuff::simt_enc_takes(im, reinterpret_cast<const lephuff::HuffSegment&>(sv[(size_t)i]))) continue;
+            lephuff::SimtEncSeg e;
+            memset(&e, 0, sizeof e);
+            const size_t mcus = (size_t)(sv[(size_t)i].mcu_row1 - sv[(size_t)i].mcu_row0) * (size_t)im.mcuh;
+            e.seg = (uint32_t)i; e.first_unit = (uint32_t)nunits; e.nunits = (uint32_t)((mcus + lephuff::kSimtMcus - 1) / lephuff::kSimtMcus);
+            e.buf_off = scratch_bytes; e.buf_bytes = (uint32_t)std::min<size_t>(((size_t)sv[(size_t)i].out_cap + 64 + 15) & ~(size_t)15, 0xfffffff0u);
+            if (nunits + e.nunits > 0x7fffffffu) continue;
+            for (uint32_t f = 0; f < e.nunits; f += 64) waves.push_back(lephuff::SimtEncWave{(uint32_t)es.size(), f});
+            nunits += e.nunits; scratch_bytes += e.buf_bytes;
+            sv[(size_t)i].pad = 1;
+            es.push_back(e);
+        }
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_es = 0, o_wv = up(es.size() * sizeof(lephuff::SimtEncSeg)), o_ub = o_wv + up(waves.size() * sizeof(lephuff::SimtEncWave)),
+                 o_sc = o_ub + up(nunits * 4), simt_total = o_sc + up(scratch_bytes);
+    if (!es.empty()) { if (int rc = ensure(g, &g->d_huffenc, &g->huffenc_bytes, simt_total)) return rc; }
     HIPCHK(g, hipMemcpyAsync(g->d_huff, images, nimg * sizeof(lep_huff_image), hipMemcpyHostToDevice, st));
-    HIPCHK(g, hipMemcpyAsync((char*)g->d_huff + o_seg, segs, nseg * sizeof(lep_huff_segment), hipMemcpyHostToDevice, st));
-    HIPCHK(g, hipStreamSynchronize(st));   // the caller's arrays may go away
+    HIPCHK(g, hipMemcpyAsync((char*)g->d_huff + o_seg, sv.data(), nseg * sizeof(lep_huff_segment), hipMemcpyHostToDevice, st));
+    char* eb = (char*)g->d_huffenc;
+    if (!es.empty()) {
+        HIPCHK(g, hipMemcpyAsync(eb + o_es, es.data(), es.size() * sizeof(lephuff::SimtEncSeg), hipMemcpyHostToDevice, st));
+        HIPCHK(g, hipMemcpyAsync(eb + o_wv, waves.data(), waves.size() * sizeof(lephuff::SimtEncWave), hipMemcpyHostToDevice, st));
+        HIPCHK(g, hipMemsetAsync(eb + o_sc, 0, scratch_bytes, st));
+    }
+    HIPCHK(g, hipStreamSynchronize(st));   // the caller's arrays (and ours) may go away
+    const lephuff::HuffImage* di = (const lephuff::HuffImage*)g->d_huff;
+    const lephuff::HuffSegment* ds = (const lephuff::HuffSegment*)((char*)g->d_huff + o_seg);
     HIPCHK(g, hipEventRecord(g->ev0, st));
-    hipLaunchKernelGGL(lep_huffman_encode_kernel, dim3(nseg), dim3(64), 0, st, (const lephuff::HuffImage*)g->d_huff,
-                       (const lephuff::HuffSegment*)((char*)g->d_huff + o_seg), d_out, d_out_len, (lephuff::HuffEnd*)d_ends);
+    if (!es.empty()) {
+        lephuff::SimtEncSeg* des = (lephuff::SimtEncSeg*)(eb + o_es);
+        const lephuff::SimtEncWave* dwv = (const lephuff::SimtEncWave*)(eb + o_wv);
+        uint32_t* dub = (uint32_t*)(eb + o_ub);
+        uint8_t* dsc = (uint8_t*)(eb + o_sc);
+        hipLaunchKernelGGL((lep_huffman_simt_encode_units_kernel<false>), dim3((unsigned)waves.size()), dim3(64), 0, st, di, ds, des, dwv, dub, dsc);
+        hipLaunchKernelGGL(lep_huffman_simt_encode_place_kernel, dim3((unsigned)es.size()), dim3(64), 0, st, ds, des, dub);
+        hipLaunchKernelGGL((lep_huffman_simt_encode_units_kernel<true>), dim3((unsigned)waves.size()), dim3(64), 0, st, di, ds, des, dwv, dub, dsc);
+        hipLaunchKernelGGL(lep_huffman_simt_encode_stuff_kernel, dim3((unsigned)es.size()), dim3(64), 0, st, di, ds, (const lephuff::SimtEncSeg*)des, dsc, d_out, d_out_len,
+                           (lephuff::HuffEnd*)d_ends);
+    }
+    if ((int)es.size() < nseg)
+        hipLaunchKernelGGL(lep_huffman_encode_kernel, dim3(nseg), dim3(64), 0, st, di, ds, d_out, d_out_len, (lephuff::HuffEnd*)d_ends);
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
-    g->last_kernel = "lep_huffman_encode_kernel";
+    g->last_kernel = es.empty() ? "lep_huffman_encode_kernel" : "lep_huffman_simt_encode_{units,place,stuff}_kernel";
     return 0;
 }
 

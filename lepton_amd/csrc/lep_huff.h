@@ -65,6 +65,13 @@ LEPH_TABLE uint8_t kZ2A[64] = {   // zig-zag index -> aligned index (aligned_blo
     49, 50, 57, 58, 0, 51, 52, 1, 2, 59, 60, 3, 4, 5, 53, 54, 6, 7, 8, 9, 61, 62, 10, 11, 12, 13, 14, 55, 56, 15, 16, 17,
     18, 19, 20, 63, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48};
 
+// the same table where a compile-time index needs it (lep_huff_simt.h unrolls a block's 63 positions)
+constexpr int kZ2A_const(int k) {
+    constexpr uint8_t t[64] = {49, 50, 57, 58, 0, 51, 52, 1, 2, 59, 60, 3, 4, 5, 53, 54, 6, 7, 8, 9, 61, 62, 10, 11, 12, 13, 14, 55, 56, 15, 16, 17,
+                               18, 19, 20, 63, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48};
+    return t[k];
+}
+
 WDEV void lds_or(uint32_t* p, uint32_t v) {
 #if LEP_ON_GPU
     __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

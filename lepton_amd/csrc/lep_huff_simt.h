@@ -1,0 +1,295 @@
+// lep_huff_simt.h -- JPEG Huffman re-encode with one LANE per run of MCUs (round 4).
+//
+// lep_huff.h writes a thread segment with one wavefront: lane = coefficient, the block's bit string assembled with LDS atomics,
+// one block after the other -- 0.2 s for the 7168 segments of a pipeline chunk, in which the 64 lanes of a wavefront spend
+// most of their time on each other's atomics.  Writing a scan has no serial dependency besides WHERE a block's bits go: the DC
+// predictor of a block is the DC of the block before it, which the frame holds, and a block's bit string depends on nothing
+// else.  So here a segment is cut into units of kSimtMcus MCUs, a lane codes one unit with a bit accumulator in its registers,
+// and the positions come from prefix sums:
+//
+//   1  count   lane = unit: the bits its blocks code to (nothing written);
+//   2  place   one wavefront per segment: exclusive prefix sum of the units' bits behind the segment's overhang bits;
+//   3  code    lane = unit: the same walk, its bits OR-ed into the segment's (zero-filled) bit buffer at the unit's position --
+//              MSB first, 32 bits at a time, atomically (a unit's first and last word are shared with its neighbours);
+//   4  stuff   one wavefront per segment: the pad bits where the scan ends, then the bit buffer's whole bytes to the output
+//              with the 00 behind every FF (16 bytes per lane and step, positions from a prefix sum of the FFs), clipped to
+//              the segment's byte bound; the partial byte, its bit count and the last DCs are the segment's end state.
+//
+// Segments of scans with restart intervals, of non-interleaved scans and of images whose scan ends inside its last MCU row keep
+// lep_huff.h's kernel (HuffSegment.pad bit 0 says which kernel owns a segment).  Same bytes, same end states as that kernel
+// (tests/emu, GPU parity tests); recoder.cc:245-412 is what both restate.
+#pragma once
+#include "lep_huff.h"
+
+namespace lephuff {
+
+constexpr int kSimtMcus = 8;            // MCUs per unit
+
+struct SimtEncSeg {         // per segment handled here
+    uint32_t seg;           // index into the caller's segment array
+    uint32_t first_unit;    // its first entry in the unit array
+    uint32_t nunits;
+    uint32_t total_bits;    // pass 2: bits of the segment's stream, overhang bits included
+    uint64_t buf_off;       // its bit buffer (bytes, 16-byte aligned) in the scratch arena
+    uint32_t buf_bytes;     // multiple of 16
+    uint32_t tail;          // pass 3: the stream's last partial byte (its total_bits & 7 bits, top-aligned) -- kept beside the buffer because a
+                            // segment that overruns its byte bound is cut off in the buffer and still owes its true end state
+};
+struct SimtEncWave { uint32_t eseg, first_unit; };   // lane l = unit first_unit + l of SimtEncSeg eseg
+
+struct SimtEncShared {
+    uint32_t code[4][256];
+};
+
+WDEV void simt_or_word(uint32_t* p, uint32_t v) {
+#if LEP_ON_GPU
+    if (v) __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p |= v;
+#endif
+}
+
+// bit sink of one lane: count only, or OR into the segment's bit buffer
+template <bool WRITE>
+struct LaneSink {
+    uint64_t acc;           // MSB first
+    uint32_t fill;          // bits of acc in use (< 32 between calls)
+    uint32_t word;          // WRITE: index of the dword acc's top half goes to;  count: unused
+    uint32_t nwords;        // WRITE: dwords of the buffer (bits beyond are dropped: the segment overran its bound anyway)
+    uint32_t* buf;
+    uint32_t total;
+    WDEV void start(uint32_t bitpos, uint32_t* b, uint32_t nw) { acc = 0; fill = WRITE ? (bitpos & 31u) : 0u; word = bitpos >> 5; buf = b; nwords = nw; total = 0; }
+    WDEV void put(uint32_t bits, uint32_t n) {   // n <= 32, bits right-aligned
+        if (!WRITE) { total += n; return; }
+        if (!n) return;
+        acc |= (uint64_t)bits << (64 - fill - n);
+        fill += n;
+        if (fill >= 32) {
+            if (word < nwords) simt_or_word(buf + word, (uint32_t)(acc >> 32));
+            ++word; acc <<= 32; fill -= 32;
+        }
+    }
+    WDEV void finish() { if (WRITE && fill && word < nwords) simt_or_word(buf + word, (uint32_t)(acc >> 32)); }
+    // the bits behind the last whole byte of everything put so far, top-aligned in a byte (WRITE only; they are this lane's own as long as
+    // it put at least seven bits)
+    WDEV uint32_t tail_byte() const {
+        const uint32_t rem = fill & 7u;
+        return rem ? (((uint32_t)(acc >> (64 - fill)) & ((1u << rem) - 1u)) << (8 - rem)) : 0u;
+    }
+};
+
+// the coefficient at zig-zag position K of a block held as 32 dwords in aligned order
+template <int K>
+WDEV int coef_at(const uint32_t* w) {
+    constexpr int a = kZ2A_const(K);
+    return (int16_t)(w[a >> 1] >> (16 * (a & 1)));
+}
+
+template <bool WRITE>
+struct SimtEncLane {
+    const HuffImage* img;
+    const SimtEncShared* sh;
+    LaneSink<WRITE> sink;
+    int lastdc[4];
+
+    WDEV void put_coef(int table, uint32_t runsize_hi, int t) {   // code of (run << 4 | size) + magnitude bits of t
+        const int at = (t < 0 ? -t : t) & 0xffff;
+        const uint32_t s = (uint32_t)bitlen((uint32_t)at);
+        const uint32_t val = (uint32_t)((t > 0) ? t : (t - 1) + (1 << s)) & ((1u << s) - 1u);
+        const uint32_t e = sh->code[table][(runsize_hi + s) & 255u];
+        sink.put(((e & 0xffffu) << s) | val, (e >> 16) + s);
+    }
+    template <int K>
+    WDEV void ac_step(const uint32_t* w, int act, int& prev) {
+        const int t = coef_at<K>(w);
+        if (t != 0) {
+            const int run = K - prev - 1;
+            if (run >= 16) {
+                const uint32_t zrl = sh->code[act][0xF0];
+                for (int i = run >> 4; i > 0; --i) sink.put(zrl & 0xffffu, zrl >> 16);
+            }
+            put_coef(act, (uint32_t)(run & 15) << 4, t);
+            prev = K;
+        }
+    }
+    template <int K0, int K1>
+    WDEV void ac_range(const uint32_t* w, int act, int& prev) {
+        if constexpr (K0 < K1) { ac_step<K0>(w, act, prev); ac_range<K0 + 1, K1>(w, act, prev); }
+    }
+    // encode_block_seq (recoder.cc:245-314)
+    WDEV void code_block(int cmp, int dpos) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(img->blocks[cmp] + (int64_t)dpos * 64);
+        uint32_t w[32];
+        for (int i = 0; i < 32; ++i) w[i] = src[i];
+        const int dct = img->dc_tbl[cmp], act = 2 + img->ac_tbl[cmp];
+        const int dc = coef_at<0>(w);
+        const int cur = cmp == 0 ? lastdc[0] : (cmp == 1 ? lastdc[1] : (cmp == 2 ? lastdc[2] : lastdc[3]));
+        const int diff = (int16_t)(dc - cur);
+        if (cmp == 0) lastdc[0] = dc; else if (cmp == 1) lastdc[1] = dc; else if (cmp == 2) lastdc[2] = dc; else lastdc[3] = dc;
+        put_coef(dct, 0, diff);
+        int prev = 0;
+        ac_range<1, 64>(w, act, prev);
+        if (prev != 63) { const uint32_t e = sh->code[act][0]; sink.put(e & 0xffffu, e >> 16); }
+    }
+    // the DC of the block in front of MCU `mcu` in scan order, per component (mcu > 0): the predictors a unit starts with
+    WDEV void predictors_before(int mcu) {
+        const int m = mcu - 1, row = m / img->mcuh, mx = m - row * img->mcuh;
+        for (int ci = 0; ci < img->ncomp; ++ci) {
+            const int cmp = img->scan_cmp[ci];
+            const int hs = img->hs[cmp], vs = img->vs[cmp];
+            const int16_t* blk = img->blocks[cmp] + (int64_t)((row * vs + vs - 1) * img->bch[cmp] + mx * hs + hs - 1) * 64;
+            const int dc = blk[kZ2A_const(0)];
+            if (cmp == 0) lastdc[0] = dc; else if (cmp == 1) lastdc[1] = dc; else if (cmp == 2) lastdc[2] = dc; else lastdc[3] = dc;
+        }
+    }
+    // MCUs [m0, m1) of an interleaved scan
+    WDEV void code_mcus(int m0, int m1) {
+        const int mcuh = img->mcuh, ncomp = img->ncomp;
+        int row = m0 / mcuh, mx = m0 - row * mcuh;
+        for (int m = m0; m < m1; ++m) {
+            for (int ci = 0; ci < ncomp; ++ci) {
+                const int cmp = img->scan_cmp[ci];
+                const int hs = img->hs[cmp], vs = img->vs[cmp], bch = img->bch[cmp];
+                for (int v = 0; v < vs; ++v)
+                    for (int h = 0; h < hs; ++h) code_block(cmp, (row * vs + v) * bch + mx * hs + h);
+            }
+            if (++mx == mcuh) { mx = 0; ++row; }
+        }
+    }
+};
+
+WDEV void simt_enc_tables(const HuffImage* img, SimtEncShared* sh) {
+    LANES(l) for (int i = l; i < 1024; i += 64) (&sh->code[0][0])[i] = (&img->code[0][0])[i];
+    LSYNC();
+}
+
+// passes 1 and 3: lanes = units first_unit .. of segment `es`
+template <bool WRITE>
+WDEV void simt_enc_units(const HuffImage* images, const HuffSegment* segs, SimtEncSeg* esp, SimtEncShared* sh, uint32_t* unit_bits, uint8_t* scratch, uint32_t first_unit) {
+    const SimtEncSeg es = *esp;
+    const HuffSegment seg = segs[es.seg];
+    const HuffImage* img = images + seg.image;
+    simt_enc_tables(img, sh);
+    const int mcuh = img->mcuh, m_begin = seg.mcu_row0 * mcuh, m_end = seg.mcu_row1 * mcuh;
+    LANES(l) {
+        const uint32_t u = first_unit + (uint32_t)l;
+        if (u < es.nunits) {
+            const int m0 = m_begin + (int)u * kSimtMcus, m1 = m0 + kSimtMcus < m_end ? m0 + kSimtMcus : m_end;
+            SimtEncLane<WRITE> d;
+            d.img = img; d.sh = sh;
+            for (int c = 0; c < 4; ++c) d.lastdc[c] = seg.last_dc[c];
+            if (u > 0) d.predictors_before(m0);
+            uint32_t* buf = reinterpret_cast<uint32_t*>(scratch + es.buf_off);
+            d.sink.start(WRITE ? unit_bits[es.first_unit + u] : 0u, buf, es.buf_bytes >> 2);
+            if (WRITE && u == 0) {               // the partial byte the segment starts with (ThreadHandoff)
+                const uint32_t pend = (seg.overhang >> 8) & 255u;
+                if (pend) simt_or_word(buf, (seg.overhang & 255u) << 24);   // (as it is: lep_huff.h starts from the byte unmasked too)
+            }
+            d.code_mcus(m0, m1);
+            d.sink.finish();
+            if (!WRITE) unit_bits[es.first_unit + u] = d.sink.total;
+            else if (u + 1 == es.nunits) esp->tail = d.sink.tail_byte();
+        }
+    }
+}
+
+// pass 2: one wavefront per segment
+WDEV void simt_enc_place(const HuffSegment* segs, SimtEncSeg* es, uint32_t* unit_bits) {
+    const uint32_t pend = (segs[es->seg].overhang >> 8) & 255u;
+    uint32_t run = pend;
+    for (uint32_t base = 0; base < es->nunits; base += 64) {
+        LV(int, nb); LV(int, ex);
+        LANES(l) { const uint32_t u = base + (uint32_t)l; L(nb) = u < es->nunits ? (int)unit_bits[es->first_unit + u] : 0; }
+        const int t = lepwave::wave_excl_scan(nb, ex);
+        LANES(l) { const uint32_t u = base + (uint32_t)l; if (u < es->nunits) unit_bits[es->first_unit + u] = run + (uint32_t)L(ex); }
+        run += (uint32_t)t;
+    }
+    LANES(l) if (l == 0) es->total_bits = run;
+}
+
+// pass 4: one wavefront per segment
+WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const SimtEncSeg& es, uint8_t* scratch, uint8_t* arena, uint32_t* out_len, HuffEnd* ends) {
+    const HuffSegment seg = segs[es.seg];
+    const HuffImage* img = images + seg.image;
+    uint32_t* buf = reinterpret_cast<uint32_t*>(scratch + es.buf_off);
+    uint32_t total = es.total_bits;
+    const uint32_t room = es.buf_bytes * 8u;
+    if (total > room) total = room;                       // the segment overran its bound: what is kept is what the bound keeps
+    const bool scan_ends = seg.mcu_row1 * img->mcuh >= img->mcuc;
+    if (scan_ends && (total & 7u)) {                      // abitwriter::pad: the pad-bit pattern, LSB of the pattern first
+        const uint32_t pend = total & 7u, n = 8u - pend;
+        uint32_t v = 0;
+        for (uint32_t j = 0; j < n; ++j) v = (v << 1) | (uint32_t)((img->padbit >> j) & 1);
+        LANES(l) if (l == 0) buf[total >> 5] |= v << (32u - (total & 31u) - n);
+        LSYNC();
+        total += n;
+    }
+    const uint32_t nb = total >> 3, cap = seg.out_cap;
+    uint8_t* out = arena + seg.out_off;
+    uint32_t written = 0;
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        LV(int, nff); LV(int, before);
+        LV(uint32_t, w0); LV(uint32_t, w1); LV(uint32_t, w2); LV(uint32_t, w3);
+        LANES(l) {
+            const uint32_t i = base + 16u * (uint32_t)l;
+            uint32_t a = 0, b = 0, c = 0, d = 0;
+            int n = 0;
+            if (i < nb) {
+                const uint32_t* p = buf + (i >> 2);
+                a = p[0]; b = p[1]; c = p[2]; d = p[3];
+                const uint32_t have = nb - i < 16u ? nb - i : 16u;
+                for (uint32_t k = 0; k < have; ++k) {
+                    const uint32_t word = k < 4 ? a : (k < 8 ? b : (k < 12 ? c : d));
+                    n += ((word >> (24 - 8 * (k & 3))) & 255u) == 0xffu;
+                }
+            }
+            L(w0) = a; L(w1) = b; L(w2) = c; L(w3) = d; L(nff) = n;
+        }
+        const int ffs = lepwave::wave_excl_scan(nff, before);
+        LANES(l) {
+            const uint32_t i = base + 16u * (uint32_t)l;
+            if (i < nb) {
+                const uint32_t have = nb - i < 16u ? nb - i : 16u;
+                uint32_t pos = written + 16u * (uint32_t)l + (uint32_t)L(before);
+                for (uint32_t k = 0; k < have; ++k) {
+                    const uint32_t word = k < 4 ? L(w0) : (k < 8 ? L(w1) : (k < 12 ? L(w2) : L(w3)));
+                    const uint32_t byte = (word >> (24 - 8 * (k & 3))) & 255u;
+                    if (pos < cap) out[pos] = (uint8_t)byte;
+                    ++pos;
+                    if (byte == 0xffu) { if (pos < cap) out[pos] = 0; ++pos; }
+                }
+            }
+        }
+        written += (nb - base < 1024u ? nb - base : 1024u) + (uint32_t)ffs;
+    }
+    const uint32_t rem = scan_ends ? 0u : (es.total_bits & 7u);     // (of the whole stream, whatever the buffer kept of it)
+    LANES(l) if (l == 0) {
+        out_len[es.seg] = written < cap ? written : cap;
+        if (ends) {
+            HuffEnd e;
+            e.attempted = written;
+            e.num_overhang_bits = (uint8_t)rem;
+            e.overhang_byte = (uint8_t)(rem ? es.tail : 0u);
+            for (int c = 0; c < 4; ++c) e.last_dc[c] = seg.last_dc[c];
+            const int m = seg.mcu_row1 * img->mcuh - 1;
+            if (m >= seg.mcu_row0 * img->mcuh) {
+                const int row = m / img->mcuh, mx = m - row * img->mcuh;
+                for (int ci = 0; ci < img->ncomp; ++ci) {
+                    const int cmp = img->scan_cmp[ci];
+                    const int hs = img->hs[cmp], vs = img->vs[cmp];
+                    e.last_dc[cmp & 3] = img->blocks[cmp][(int64_t)((row * vs + vs - 1) * img->bch[cmp] + mx * hs + hs - 1) * 64 + kZ2A_const(0)];
+                }
+            }
+            e.pad = 0;
+            ends[es.seg] = e;
+        }
+    }
+}
+
+// which segments this form takes
+inline bool simt_enc_takes(const HuffImage& img, const HuffSegment& seg) {
+    return img.rsti == 0 && img.interleaved == 1 && img.mcuc == img.mcuh * img.mcuv && seg.mcu_row0 >= 0 && seg.mcu_row1 > seg.mcu_row0 && seg.mcu_row1 <= img.mcuv &&
+           ((seg.overhang >> 8) & 255u) < 8u && img.ncomp >= 2;     // (two blocks per MCU at least: a unit's last byte is its own)
+}
+
+}  // namespace lephuff

@@ -205,6 +205,33 @@ extern "C" int emu_huffman_encode_segment(const lep_huff_image* img, const lep_h
     return 0;
 }
 
+// ... with one lane per run of MCUs (lep_huff_simt.h): count, place, code, stuff for ONE segment; returns 1 when that form does not
+// take the segment (restart intervals, ...), and then writes nothing
+#include "../../lepton_amd/csrc/lep_huff_simt.h"
+extern "C" int emu_huffman_encode_segment_simt(const lep_huff_image* img, const lep_huff_segment* seg, uint8_t* out, uint32_t* len, lep_huff_end* end) {
+    static lephuff::SimtEncShared sh;
+    const lephuff::HuffImage* im = reinterpret_cast<const lephuff::HuffImage*>(img);
+    lephuff::HuffSegment s;
+    memcpy(&s, seg, sizeof s);
+    s.out_off = 0; s.image = 0;
+    if (!lephuff::simt_enc_takes(*im, s)) return 1;
+    lephuff::SimtEncSeg es;
+    memset(&es, 0, sizeof es);
+    const size_t mcus = (size_t)(s.mcu_row1 - s.mcu_row0) * (size_t)im->mcuh;
+    es.seg = 0; es.first_unit = 0; es.nunits = (uint32_t)((mcus + lephuff::kSimtMcus - 1) / lephuff::kSimtMcus);
+    es.buf_off = 0; es.buf_bytes = (uint32_t)(((size_t)s.out_cap + 64 + 15) & ~(size_t)15);
+    std::vector<uint32_t> unit_bits(es.nunits);
+    std::vector<uint32_t> scratch((size_t)es.buf_bytes / 4 + 4, 0u);
+    uint8_t* sc = reinterpret_cast<uint8_t*>(scratch.data());
+    for (uint32_t f = 0; f < es.nunits; f += 64) lephuff::simt_enc_units<false>(im, &s, &es, &sh, unit_bits.data(), sc, f);
+    lephuff::simt_enc_place(&s, &es, unit_bits.data());
+    for (uint32_t f = 0; f < es.nunits; f += 64) lephuff::simt_enc_units<true>(im, &s, &es, &sh, unit_bits.data(), sc, f);
+    uint32_t n = 0;
+    lephuff::simt_enc_stuff(im, &s, es, sc, out, &n, reinterpret_cast<lephuff::HuffEnd*>(end));
+    *len = n;
+    return 0;
+}
+
 // progressive scans (lep_huffprog.h): every scan of one image, one emulated wavefront after the other
 #include "../../lepton_amd/csrc/lep_huffprog.h"
 extern "C" int emu_huffman_progressive_encode(const lep_huffprog_image* img, const lep_huffprog_scan* scans, int nscan, uint8_t* out, uint32_t* corr, uint32_t* out_len) {

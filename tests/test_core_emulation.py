@@ -289,6 +289,53 @@ def test_gpu_huffman_encoder_on_cpu_restores_the_jpeg(emu, name):
     assert got == jpg
 
 
+@pytest.mark.parametrize("name", golden_cases() + ["synth_1280x720", "synth_q100"])
+def test_lane_per_unit_huffman_encoder_equals_the_wave_per_segment_one(emu, name):
+    """lep_huff_simt.h (one lane per run of eight MCUs: count, prefix sums, bits OR-ed into the segment's bit buffer, stuffing pass)
+    must write what lep_huff.h writes -- the segment's bytes, its byte count under a bound, the end state the next hand-off is held
+    against -- or leave the segment to it (restart intervals, non-interleaved scans)"""
+    from lepton_amd import abi, corpus
+    from lepton_amd.codec import LepFile, GpuCodec
+
+    if name.startswith("synth"):
+        jpg = corpus.synth_jpeg(1280, 720, 81, quality=92) if name == "synth_1280x720" else corpus.synth_jpeg(320, 240, 82, quality=100)
+        import oracle_binding as ob
+        img0 = JpegImage(jpg)
+        segs0 = img0.plan()
+        streams, _ = ob.oracle_encode(img0.desc, segs0)
+        lep = img0.write_lep(streams)
+    else:
+        jpg, lep = golden(name)
+    L = abi.lib()
+    f = LepFile(lep)
+    src = JpegImage(jpg)
+    for c in range(f.desc.ncomp):
+        C.memmove(f.desc.blocks[c], src.desc.blocks[c], f.desc.nblocks(c) * 128)
+    img = abi.HuffImage()
+    segs = (abi.HuffSegment * abi.MAX_SEGMENTS)()
+    nseg, ok = C.c_int(0), C.c_int(0)
+    assert L.lep_file_recode_plan(f.handle, C.byref(img), segs, C.byref(nseg), C.byref(ok)) == 0
+    if not ok.value:
+        pytest.skip("not eligible for the GPU Huffman encoder")
+    taken = 0
+    for i in range(nseg.value):
+        for cap in (min(segs[i].out_cap, len(jpg) + 1024), 100):        # the segment's own bound, and one that cuts it short
+            segs[i].out_cap = cap
+            outs = []
+            for fn in (emu.emu_huffman_encode_segment, emu.emu_huffman_encode_segment_simt):
+                buf = C.create_string_buffer(cap + 8)
+                n = C.c_uint32(0)
+                end = abi.HuffEnd()
+                rc = fn(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(end))
+                outs.append((rc, n.value, buf.raw[: n.value], end.overhang_byte, end.num_overhang_bits, list(end.last_dc)))
+            if outs[1][0] == 1:
+                continue
+            taken += 1
+            assert outs[0] == outs[1], (i, cap, outs[0][1], outs[1][1], outs[0][3:], outs[1][3:])
+    if not img.rsti and img.interleaved:
+        assert taken > 0
+
+
 @pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "synth_rst", "optimized_q95", "optimized_q30", "optimized_noise_444"])
 def test_gpu_huffman_decoder_on_cpu_matches_host_parser(emu, name):
     """lep_huffdec.h (wave-per-image JPEG Huffman scan decode) as a 64-lane loop emulation + parse_jpeg_finish_gpu: for

@@ -454,6 +454,30 @@ def test_gpu_lane_per_subsequence_huffman_decode_in_the_compress_pipeline(gpu_co
         codec.close()
 
 
+@pytest.mark.parametrize("simt", ["0", "1"])
+def test_gpu_scan_encoders_in_the_decompress_pipeline(monkeypatch, simt):
+    """the decompressor's JPEG scan bytes from the lane-per-unit kernels (lep_huff_simt.h, the default) and from the
+    wavefront-per-segment kernel (LEP_HUFFENC_SIMT=0): the original files, byte for byte, from both -- fixtures with restart
+    intervals, several thread segments, odd sizes, and three synthetic sizes"""
+    names = golden_cases()
+    jpgs = [golden(n)[0] for n in names] + [corpus.synth_jpeg(1280, 720, 64), corpus.synth_jpeg(1920, 1080, 65, quality=95), corpus.synth_jpeg(203, 149, 66)]
+    leps = [golden(n)[1] for n in names]
+    monkeypatch.setenv("LEP_HUFFENC_SIMT", simt)
+    codec = GpuCodec(0)
+    try:
+        leps += [codec.compress(j) for j in jpgs[len(names):]]
+        back, st, stats = codec.decompress_batch(leps, chunk_images=16)
+        ok = [i for i in range(len(leps)) if st[i] == 0]
+        assert len(ok) >= len(leps) - 8                 # (a few fixtures are files the reference refuses to restore)
+        for i in ok:
+            assert back[i] == jpgs[i], i
+        assert stats["gpu_huffman_files"] > len(leps) // 2
+        name = abi.lib().lep_gpu_last_kernel_name(codec.handle).decode()
+        assert ("simt" in name) == (simt == "1") or "progressive" in name or "decode" in name, name
+    finally:
+        codec.close()
+
+
 def test_gpu_lane_per_subsequence_huffman_decode_equals_the_single_wave_kernel(gpu_codec):
     """the two scan decoders called directly on device-resident scans of 24 different 4:2:0 images: same frames, same hand-off records"""
     import test_core_emulation as emu_tests
