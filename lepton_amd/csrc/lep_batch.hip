@@ -130,7 +130,7 @@ struct Slot {   // one chunk's buffers (double-buffered)
     ScanCheck* d_pcheck = nullptr; size_t pcheck_cap = 0;   // compression with verify: what lep_scan_check_kernel compares
     uint8_t* d_vscan = nullptr; size_t vscan_cap = 0;       // ... and for baseline files: their scans written again from the device frame,
     uint32_t* d_vscanlen = nullptr; ScanCheck* d_vcheck = nullptr; size_t vseg_cap = 0;   // per thread segment
-    hipEvent_t up = nullptr, done = nullptr;
+    hipEvent_t up = nullptr, done = nullptr, decoded = nullptr;
     void release() {
         if (h_frames) (void)hipHostFree(h_frames);
         if (h_streams) (void)hipHostFree(h_streams);
@@ -141,6 +141,7 @@ struct Slot {   // one chunk's buffers (double-buffered)
             if (p) (void)hipFree(p);
         if (up) (void)hipEventDestroy(up);
         if (done) (void)hipEventDestroy(done);
+        if (decoded) (void)hipEventDestroy(decoded);
         *this = Slot();
     }
 };
@@ -232,6 +233,7 @@ int slot_reserve_impl(Slot* s, size_t frames, size_t streams, size_t nseg, size_
     }
     if (!s->up) HIPOK(hipEventCreateWithFlags(&s->up, hipEventDisableTiming));
     if (!s->done) HIPOK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    if (!s->decoded) HIPOK(hipEventCreateWithFlags(&s->decoded, hipEventDisableTiming));
     return 0;
 }
 
@@ -991,9 +993,13 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         });
         st.parse_s += now_s() - t0;
     }
-    hipStream_t s_copy = nullptr, s_compute = nullptr, s_down = nullptr;
+    hipStream_t s_copy = nullptr, s_compute = nullptr, s_down = nullptr, s_scan = nullptr;
     StreamSet stream_set;
-    if (stream_set.make(&s_copy) || stream_set.make(&s_compute) || stream_set.make(&s_down)) return LEP_GPU_ERROR;
+    if (stream_set.make(&s_copy) || stream_set.make(&s_compute) || stream_set.make(&s_down) || stream_set.make(&s_scan)) return LEP_GPU_ERROR;
+    // The scan encoders run behind the decoder on ITS stream.  On a stream of their own (LEP_BATCH_SCAN_STREAM=1) they compete with the
+    // next chunk's decode kernel for wave slots it fills completely, finish when it does, and hold the chunk's download back:
+    // 1530 against 1774 MB/s (profiles/r06j_*).
+    if (!(getenv("LEP_BATCH_SCAN_STREAM") && atoi(getenv("LEP_BATCH_SCAN_STREAM")) == 1)) s_scan = s_compute;
     Slot* slots = g_slots;
     g_alloc_s = 0;
     int rc_all = 0;
@@ -1017,8 +1023,10 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     };
     // streams into the slot's pinned arena (packed back to back), upload, frames zeroed on the device
     std::vector<std::vector<uint32_t>> chunk_lens(2);
+    const double t_pipe0 = now_s();
     auto stage_and_upload = [&](Chunk* c, Slot* s, std::vector<uint32_t>* lens) -> int {
         if (c->live.empty()) return 0;
+        if (getenv("LEP_BATCH_TRACE")) fprintf(stderr, "[batch] stage_and_upload first=%d begins (t=%.3f)\n", c->first, now_s() - t_pipe0);
         c->segs.clear(); c->offs.assign(1, 0); c->seg_first.clear(); lens->clear();
         std::vector<const uint8_t*> src;
         for (size_t k = 0; k < c->live.size(); ++k) {
@@ -1118,10 +1126,19 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         }
         HIPOK(hipMemcpyAsync(s->d_streams, s->h_streams, c->offs.back(), hipMemcpyHostToDevice, s_copy));
         HIPOK(hipMemcpyAsync(s->d_len, lens->data(), lens->size() * 4, hipMemcpyHostToDevice, s_copy));
-        HIPOK(hipMemsetAsync(s->d_frames, 0, c->frame_bytes, s_copy));
+        // The decode kernel stores every coefficient of every block it decodes: only a file whose frame holds blocks that are NOT coded
+        // (a truncated one) needs its frame cleared.  (Clearing the whole chunk was a 25 GB fill kernel that could not start while the
+        // previous chunk's decoder held every wave slot, and this function waited for it.)
+        for (size_t k = 0; k < c->live.size(); ++k) {
+            const lep_image_desc& d = c->host_desc[k];
+            bool whole = true;
+            for (int cc = 0; cc < d.ncomp; ++cc) whole = whole && d.coded_blocks[cc] == d.width_blocks[cc] * d.height_blocks[cc];
+            if (!whole) HIPOK(hipMemsetAsync(s->d_frames + c->frame_off[k], 0, fbytes[c->live[k]], s_copy));
+        }
         HIPOK(hipEventRecord(s->up, s_copy));
         HIPOK(hipStreamSynchronize(s_copy));   // `lens` / pinned arena are reused by the caller
         st.h2d_bytes += (double)c->offs.back();
+        if (getenv("LEP_BATCH_TRACE")) fprintf(stderr, "[batch] stage_and_upload first=%d done (t=%.3f)\n", c->first, now_s() - t_pipe0);
         return 0;
     };
 
@@ -1129,19 +1146,24 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     auto launch_chunk = [&](Chunk* c, Slot* s) -> int {
         const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
         if (!nimg) return 0;
+        static const bool tr = getenv("LEP_BATCH_TRACE") != nullptr;
+        const double tt0 = now_s();
         HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
         int rc = lep_gpu_decode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
         if (rc) return rc;
+        const double tt1 = now_s();
+        if (s_scan != s_compute) { HIPOK(hipEventRecord(s->decoded, s_compute)); HIPOK(hipStreamWaitEvent(s_scan, s->decoded, 0)); }
         if (!c->hseg.empty()) {
-            rc = lep_gpu_huffman_encode_device(g, c->himg.data(), (int)c->himg.size(), c->hseg.data(), (int)c->hseg.size(), s->d_scan, s->d_scanlen, huff_ends(s), s_compute);
+            rc = lep_gpu_huffman_encode_device(g, c->himg.data(), (int)c->himg.size(), c->hseg.data(), (int)c->hseg.size(), s->d_scan, s->d_scanlen, huff_ends(s), s_scan);
             if (rc) return rc;
         }
+        if (tr) fprintf(stderr, "[batch] launch_chunk first=%d: decode launch %.3f s, scan-encode launch %.3f s (t=%.3f)\n", c->first, tt1 - tt0, now_s() - tt1, now_s() - t_pipe0);
         if (!c->pscan.empty()) {
             rc = lep_gpu_huffman_progressive_encode_device(g, c->pimg.data(), (int)c->pimg.size(), c->pscan.data(), (int)c->pscan.size(), s->d_pscan, s->d_corr,
-                                                           s->d_pscanlen, s_compute);
+                                                           s->d_pscanlen, s_scan);
             if (rc) return rc;
         }
-        HIPOK(hipEventRecord(s->done, s_compute));
+        HIPOK(hipEventRecord(s->done, s_scan));
         return 0;
     };
     Joiner writer_guard;

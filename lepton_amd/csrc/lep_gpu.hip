@@ -348,6 +348,11 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_encode_kernel(const lephuff
     if (threadIdx.x == 0) out_len[s] = n;
     if (ends) w.export_end(ends + s);
 }
+// (the bit buffers are cleared by a kernel of our own: hipMemsetAsync of 2.5 GB held the calling thread until everything queued
+// on the stream in front of it had run -- the decode kernel of the chunk, 1.1 s -- measured with LEP_BATCH_TRACE)
+__global__ __launch_bounds__(256) void lep_zero_kernel(uint4* p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = uint4{0u, 0u, 0u, 0u};
+}
 // ... with one lane per run of MCUs (lep_huff_simt.h): count / place / code / stuff
 template <bool WRITE>
 __global__ __launch_bounds__(64) void lep_huffman_simt_encode_units_kernel(const lephuff::HuffImage* __restrict__ images, const lephuff::HuffSegment* __restrict__ segs,
@@ -555,6 +560,10 @@ struct lep_gpu {
     void* d_lens = nullptr; size_t lens_bytes = 0;
     void* d_huff = nullptr; size_t huff_bytes = 0;      // HuffImage[] | HuffSegment[]
     void* d_huffprog[2] = {nullptr, nullptr}; size_t huffprog_bytes[2] = {0, 0};   // ProgImage[] | ProgScan[], one per arena set (two launches on two streams)
+    struct Staging { void* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+    Staging staging[16];                // pinned ring for descriptor uploads (upload()): nothing on a launch path waits for its stream
+    int staging_next = 0;
+    std::vector<void*> staging_retired;
     void* h_huffprog[2] = {nullptr, nullptr}; size_t h_huffprog_bytes[2] = {0, 0};   // pinned staging of the same: the upload does not wait for the stream
     int huffprog_turn = 0;   // the two sets are used in turn: at most two launches are ever in flight (lep_batch.hip queues chunk k+1 before it fetches chunk k)
     void* d_huffprogdec = nullptr; size_t huffprogdec_bytes = 0;   // ProgDecScan[]
@@ -815,6 +824,34 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
     return 0;
 }
 
+// Descriptor bytes to the device, ordered on `st`, WITHOUT waiting for what is queued on it: the bytes are copied into a pinned buffer
+// of the codec's own (the caller's arrays may go away) and go up from there.  A launch function that waited for its stream here --
+// hipMemcpyAsync from pageable memory, then hipStreamSynchronize -- waited for every kernel queued in front of it: in the batch
+// decompressor that was the decode kernel of the chunk being launched (1 s), during which the host could have staged the next chunk
+// (kernel trace of round 4: the decoder idle ~0.1 s per chunk).  A ring slot is reused sixteen uploads later; its event says when its
+// copy has run.
+static int upload(lep_gpu* g, void* dst, const void* src, size_t n, hipStream_t st) {
+    if (!n) return 0;
+    lep_gpu::Staging& sl = g->staging[g->staging_next];
+    g->staging_next = (g->staging_next + 1) % 16;
+    if (sl.used) { HIPCHK(g, hipEventSynchronize(sl.ev)); sl.used = false; }
+    if (!sl.ev) HIPCHK(g, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.cap < n) {
+        // (a buffer that has become too small is kept until the codec is destroyed: hipHostFree waits for the device, i.e. for the
+        // very kernels this function exists not to wait for -- measured: 1.1 s per chunk.  8 MB take the descriptors of a 1024-image launch.)
+        if (sl.host) g->staging_retired.push_back(sl.host);
+        sl.host = nullptr; sl.cap = 0;
+        const size_t want = std::max<size_t>(n + n / 4 + 4096, (size_t)8 << 20);
+        HIPCHK(g, hipHostMalloc(&sl.host, want, hipHostMallocDefault));
+        sl.cap = want;
+    }
+    memcpy(sl.host, src, n);
+    HIPCHK(g, hipMemcpyAsync(dst, sl.host, n, hipMemcpyHostToDevice, st));
+    HIPCHK(g, hipEventRecord(sl.ev, st));
+    sl.used = true;
+    return 0;
+}
+
 template <bool DEC>
 static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_segment* segs, int nseg, uint8_t* d_streams,
                   const uint64_t* stream_offsets, uint32_t* d_stream_len, int32_t* d_status, hipStream_t st) {
@@ -885,10 +922,9 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
                  o_bins = o_ns + ((nseg * sizeof(uint64_t) + 255) & ~(size_t)255), total = o_bins + nseg * sizeof(uint32_t);
     if (int rc = ensure(g, &g->arena[g->cur].d_meta, &g->arena[g->cur].meta_bytes, total)) return rc;
     char* meta = (char*)g->arena[g->cur].d_meta;
-    HIPCHK(g, hipMemcpyAsync(meta + o_img, himg.data(), nimg * sizeof(ImageDev), hipMemcpyHostToDevice, st));
-    HIPCHK(g, hipMemcpyAsync(meta + o_seg, hseg.data(), nseg * sizeof(SegDev), hipMemcpyHostToDevice, st));
-    HIPCHK(g, hipMemcpyAsync(meta + o_ns, hns.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    HIPCHK(g, hipStreamSynchronize(st));   // the host vectors above go out of scope
+    if (int rc = upload(g, meta + o_img, himg.data(), nimg * sizeof(ImageDev), st)) return rc;      // (the host vectors above go out of scope:
+    if (int rc = upload(g, meta + o_seg, hseg.data(), nseg * sizeof(SegDev), st)) return rc;        //  upload() keeps a copy)
+    if (int rc = upload(g, meta + o_ns, hns.data(), nseg * sizeof(uint64_t), st)) return rc;
     g->d_bins = (uint32_t*)(meta + o_bins);
     g->h_bins.assign(nseg, 0);
     g->nstage = 0;
@@ -1034,6 +1070,9 @@ static void release_device_side(lep_gpu* g) {
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     for (void* p : {g->h_huffprog[0], g->h_huffprog[1]}) if (p) (void)hipHostFree(p);
+    for (lep_gpu::Staging& sl : g->staging) { if (sl.host) (void)hipHostFree(sl.host); if (sl.ev) (void)hipEventDestroy(sl.ev); sl = lep_gpu::Staging(); }
+    for (void* p : g->staging_retired) (void)hipHostFree(p);
+    g->staging_retired.clear();
 }
 
 void lep_gpu_destroy(lep_gpu* g) {
@@ -1100,15 +1139,14 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
     const size_t o_es = 0, o_wv = up(es.size() * sizeof(lephuff::SimtEncSeg)), o_ub = o_wv + up(waves.size() * sizeof(lephuff::SimtEncWave)),
                  o_sc = o_ub + up(nunits * 4), simt_total = o_sc + up(scratch_bytes);
     if (!es.empty()) { if (int rc = ensure(g, &g->d_huffenc, &g->huffenc_bytes, simt_total)) return rc; }
-    HIPCHK(g, hipMemcpyAsync(g->d_huff, images, nimg * sizeof(lep_huff_image), hipMemcpyHostToDevice, st));
-    HIPCHK(g, hipMemcpyAsync((char*)g->d_huff + o_seg, sv.data(), nseg * sizeof(lep_huff_segment), hipMemcpyHostToDevice, st));
+    if (int rc = upload(g, g->d_huff, images, nimg * sizeof(lep_huff_image), st)) return rc;           // (the caller's arrays and ours may go away)
+    if (int rc = upload(g, (char*)g->d_huff + o_seg, sv.data(), nseg * sizeof(lep_huff_segment), st)) return rc;
     char* eb = (char*)g->d_huffenc;
     if (!es.empty()) {
-        HIPCHK(g, hipMemcpyAsync(eb + o_es, es.data(), es.size() * sizeof(lephuff::SimtEncSeg), hipMemcpyHostToDevice, st));
-        HIPCHK(g, hipMemcpyAsync(eb + o_wv, waves.data(), waves.size() * sizeof(lephuff::SimtEncWave), hipMemcpyHostToDevice, st));
-        HIPCHK(g, hipMemsetAsync(eb + o_sc, 0, scratch_bytes, st));
+        if (int rc = upload(g, eb + o_es, es.data(), es.size() * sizeof(lephuff::SimtEncSeg), st)) return rc;
+        if (int rc = upload(g, eb + o_wv, waves.data(), waves.size() * sizeof(lephuff::SimtEncWave), st)) return rc;
+        hipLaunchKernelGGL(lep_zero_kernel, dim3(8192), dim3(256), 0, st, (uint4*)(eb + o_sc), scratch_bytes / 16);   // (buf_bytes are multiples of 16)
     }
-    HIPCHK(g, hipStreamSynchronize(st));   // the caller's arrays (and ours) may go away
     const lephuff::HuffImage* di = (const lephuff::HuffImage*)g->d_huff;
     const lephuff::HuffSegment* ds = (const lephuff::HuffSegment*)((char*)g->d_huff + o_seg);
     HIPCHK(g, hipEventRecord(g->ev0, st));
