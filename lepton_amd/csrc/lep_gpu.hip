@@ -460,8 +460,9 @@ __global__ __launch_bounds__(64) void lep_huffman_simt_place_kernel(const lephuf
 __global__ __launch_bounds__(64) void lep_huffman_simt_write_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::SimtImage* si, const lephuff::SimtWave* waves,
                                                                     const lephuff::SimtSub* sub, const lephuff::SimtPlace* place, lephuff::HuffDecRow* rows) {
     __shared__ lephuff::SimtShared sh;
+    __shared__ lephuff::SimtTile tile;
     const lephuff::SimtWave w = waves[blockIdx.x];
-    lephuff::simt_write(images + w.image, &sh, si + w.image, sub + si[w.image].first, place + si[w.image].first, rows, w.first_sub);
+    lephuff::simt_write(images + w.image, &sh, &tile, si + w.image, sub + si[w.image].first, place + si[w.image].first, rows, w.first_sub);
 }
 __global__ void lep_huffman_simt_finish_kernel(const lephuff::HuffDecImage* __restrict__ images, int nimg, lephuff::HuffDecRow* rows, const lephuff::SimtImage* si) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);

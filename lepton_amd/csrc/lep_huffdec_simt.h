@@ -16,8 +16,8 @@
 //              state (induction from lane 0, whose start is the start of the scan), so every E_i and every count is true.  If some
 //              did, the pass is repeated from the new states (kSimtSettle times at most: then the image takes the fallback);
 //   P  place   prefix sums over the image's subsequences: every lane's first block (position in the frame) and DC predictors;
-//   C  write   lane i decodes its region [E_(i-1), E_i) once more, storing the non-zero coefficients into the (zero-filled)
-//              frame and the hand-off record of every MCU row that starts in it; every irregularity a single-wave decode
+//   C  write   lane i decodes its region [E_(i-1), E_i) once more, assembling every block in LDS and storing it whole into the
+//              frame, and the hand-off record of every MCU row that starts in it; every irregularity a single-wave decode
 //              would meet is met here, from true states, and sets the image's status exactly as there.
 //
 // Three passes over the bits, 64 codes per instruction.  The last subsequence is not guessed at: its region runs to the end of
@@ -52,6 +52,11 @@ struct SimtWave { uint32_t image, first_sub; };   // lane l = subsequence first_
 struct SimtShared : HuffDecShared {
     uint8_t ph_cmp[16], ph_v[16], ph_h[16];   // block-within-MCU -> component, row and column inside the MCU
 };
+// pass C only: the block every lane is assembling, dword w of lane l at [w * 64 + l] (a lane's 16-bit writes then fall into a bank of
+// their own).  A block leaves as eight 16-byte stores: written coefficient by coefficient into the frame, every 2-byte store was a
+// read-modify-write of a 32-byte sector in HBM -- 167 GB per 896 4K files, the whole 45 ms of the pass (kernel trace, round 4).
+struct SimtTile { uint32_t w[32 * 64]; };
+typedef uint16_t __attribute__((may_alias)) TileHalf;   // the tile is written in halves and read in dwords: the compiler must know they meet
 
 // bit reader of one lane: 64-bit window, one dword requested ahead
 struct LaneBits {
@@ -116,8 +121,8 @@ struct SimtLane {
             bpos += z + 1;
         }
     }
-    // one block into the frame (dst: its 64 coefficients, zero so far): lep_huffdec.h decode_block; false = irregular
-    WDEV bool store_block(int dct, int act, int16_t* dst, int* diff) {
+    // one block into the lane's tile (zero so far): lep_huffdec.h decode_block; false = irregular
+    WDEV bool store_block(int dct, int act, TileHalf* tile_lane, int* diff) {
         uint32_t n = 0;
         int hc = symbol_and_bits(dct, true, &n);
         if (hc < 0) return false;
@@ -130,7 +135,7 @@ struct SimtLane {
             const uint32_t z = ((uint32_t)hc >> 4) & 15u, s = (uint32_t)hc & 15u;
             if (z + bpos >= 64) return false;
             bpos += z;
-            if (s) dst[sh->z2a[bpos]] = (int16_t)extend(s, n);
+            if (s) { const uint32_t a = sh->z2a[bpos]; tile_lane[(a >> 1) * 128 + (a & 1)] = (uint16_t)extend(s, n); }
             ++bpos;
             last_s = s;
         }
@@ -264,14 +269,17 @@ WDEV void simt_place(const HuffDecImage* img, SimtImage* si, const SimtSub* sub,
 }
 
 // pass C; the image's status collects what the lanes find
-WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtImage* si, const SimtSub* sub, const SimtPlace* place, HuffDecRow* rows_arena, uint32_t first_sub) {
+WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, SimtImage* si, const SimtSub* sub, const SimtPlace* place, HuffDecRow* rows_arena, uint32_t first_sub) {
     if (si->status) return;                                // pass P refused the image: the fallback decodes it
     const int nphase = simt_setup(img, sh);
     const uint32_t scan_bits = img->scan_len * 8u, nsub = si->nsub, total = (uint32_t)img->mcuc * (uint32_t)nphase;
     HuffDecRow* rows = rows_arena + img->rows_off;
+    LANES(l) for (int w = 0; w < 32; ++w) tile->w[w * 64 + l] = 0u;
+    LSYNC();
     LV(int, rc);
     LANES(l) {
         L(rc) = 0;
+        TileHalf* tile_lane = reinterpret_cast<TileHalf*>(tile->w + l);        // halfword h of dword w: tile_lane[w * 128 + h]
         const uint32_t i = first_sub + (uint32_t)l;
         if (i < nsub) {
             const bool last = i + 1 >= nsub;
@@ -304,11 +312,22 @@ WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtImage* si, con
                     const int cmp = sh->ph_cmp[phase], v = sh->ph_v[phase], h = sh->ph_h[phase];
                     int16_t* dst = img->blocks[cmp] + (int64_t)((row * img->vs[cmp] + v) * img->bch[cmp] + mx * img->hs[cmp] + h) * 64;
                     int diff = 0;
-                    if (!d.store_block(img->dc_tbl[cmp], 2 + img->ac_tbl[cmp], dst, &diff)) { bad = 1; break; }
+                    const bool fine = d.store_block(img->dc_tbl[cmp], 2 + img->ac_tbl[cmp], tile_lane, &diff);
                     const int cur = cmp == 0 ? lastdc[0] : (cmp == 1 ? lastdc[1] : (cmp == 2 ? lastdc[2] : lastdc[3]));
                     const int dc = (int16_t)(diff + cur);
                     if (cmp == 0) lastdc[0] = dc; else if (cmp == 1) lastdc[1] = dc; else if (cmp == 2) lastdc[2] = dc; else lastdc[3] = dc;
-                    if (dc) dst[49] = (int16_t)dc;
+                    tile_lane[(49 >> 1) * 128 + (49 & 1)] = (uint16_t)dc;
+                    {   // the block to the frame, the tile cleared for the next one (an irregular block goes out too: the fallback decodes the file again)
+                        typedef uint32_t Quad __attribute__((vector_size(16)));     // (one 16-byte store: gcc and clang both know this form)
+                        Quad* out = reinterpret_cast<Quad*>(dst);
+                        for (int q = 0; q < 8; ++q) {
+                            Quad v;
+                            v[0] = tile->w[(4 * q + 0) * 64 + l]; v[1] = tile->w[(4 * q + 1) * 64 + l]; v[2] = tile->w[(4 * q + 2) * 64 + l]; v[3] = tile->w[(4 * q + 3) * 64 + l];
+                            tile->w[(4 * q + 0) * 64 + l] = 0u; tile->w[(4 * q + 1) * 64 + l] = 0u; tile->w[(4 * q + 2) * 64 + l] = 0u; tile->w[(4 * q + 3) * 64 + l] = 0u;
+                            out[q] = v;
+                        }
+                    }
+                    if (!fine) { bad = 1; break; }
                     if (d.br.bitpos > scan_bits) { bad = 2; break; }           // ran out of data inside a block
                     if (++phase == nphase) { phase = 0; ++mcu; if (++mx == mcuh) { mx = 0; ++row; } }
                 }

@@ -333,7 +333,8 @@ extern "C" int emu_huffman_decode_image_simt(const lep_huffdec_image* img, lep_h
         for (uint32_t f = 0; f < si.nsub; f += 64) lephuff::simt_guess_or_settle(&im, &sh, &si, buf[(k + 1) & 1].data(), buf[k & 1].data(), f, k);
     const lephuff::SimtSub* fin = buf[lephuff::kSimtSettle & 1].data();
     lephuff::simt_place(&im, &si, fin, place.data(), lephuff::kSimtSettle);
-    for (uint32_t f = 0; f < si.nsub; f += 64) lephuff::simt_write(&im, &sh, &si, fin, place.data(), reinterpret_cast<lephuff::HuffDecRow*>(rows), f);
+    static lephuff::SimtTile tile;
+    for (uint32_t f = 0; f < si.nsub; f += 64) lephuff::simt_write(&im, &sh, &tile, &si, fin, place.data(), reinterpret_cast<lephuff::HuffDecRow*>(rows), f);
     rows[im.mcuv].aux = (rows[im.mcuv].aux & 255) | (si.status << 8);
     if (settle_moved) for (int k = 0; k <= lephuff::kSimtSettle; ++k) settle_moved[k] = si.changed[k];
     if (nsub_out) *nsub_out = si.nsub;
