@@ -289,7 +289,7 @@ def test_gpu_huffman_encoder_on_cpu_restores_the_jpeg(emu, name):
     assert got == jpg
 
 
-@pytest.mark.parametrize("name", golden_cases() + ["synth_1280x720", "synth_q100"])
+@pytest.mark.parametrize("name", golden_cases() + ["synth_1280x720", "synth_q100", "optimized_q30", "optimized_q95", "optimized_noise_444"])
 def test_lane_per_unit_huffman_encoder_equals_the_wave_per_segment_one(emu, name):
     """lep_huff_simt.h (one lane per run of eight MCUs: count, prefix sums, bits OR-ed into the segment's bit buffer, stuffing pass)
     must write what lep_huff.h writes -- the segment's bytes, its byte count under a bound, the end state the next hand-off is held
@@ -297,8 +297,8 @@ def test_lane_per_unit_huffman_encoder_equals_the_wave_per_segment_one(emu, name
     from lepton_amd import abi, corpus
     from lepton_amd.codec import LepFile, GpuCodec
 
-    if name.startswith("synth"):
-        jpg = corpus.synth_jpeg(1280, 720, 81, quality=92) if name == "synth_1280x720" else corpus.synth_jpeg(320, 240, 82, quality=100)
+    if name.startswith("synth") or name.startswith("optimized"):
+        jpg = (corpus.synth_jpeg(1280, 720, 81, quality=92) if name == "synth_1280x720" else corpus.synth_jpeg(320, 240, 82, quality=100)) if name.startswith("synth") else _jpeg_for_huffman_tests(name)
         import oracle_binding as ob
         img0 = JpegImage(jpg)
         segs0 = img0.plan()
@@ -547,18 +547,24 @@ def _jpeg_for_huffman_tests(name):
         return corpus.synth_jpeg(640, 360, 71, quality=88)
     if name == "synth_1920x1080":
         return corpus.synth_jpeg(1920, 1080, 72, quality=90)
-    if name == "optimized_q30":
+    if name in ("optimized_q30", "optimized_q95", "optimized_noise_444"):
+        # per-image Huffman tables (libjpeg optimize_coding): long DC codes, rare symbols with 14..16-bit codes
         from PIL import Image
         import numpy as np
         rng = np.random.default_rng(31)
-        a = np.asarray(Image.fromarray(rng.integers(0, 256, (30, 40, 3), dtype=np.uint8), "RGB").resize((320, 240), Image.BICUBIC)).astype(np.int16)
-        a = np.clip(a + rng.normal(0, 12, a.shape), 0, 255).astype(np.uint8)
-        buf = io.BytesIO(); Image.fromarray(a, "RGB").save(buf, format="JPEG", quality=30, subsampling="4:2:2", optimize=True)
+        if name == "optimized_noise_444":
+            a = rng.integers(0, 256, (120, 168, 3), dtype=np.uint8)
+            q, sub = 98, "4:4:4"
+        else:
+            a = np.asarray(Image.fromarray(rng.integers(0, 256, (30, 40, 3), dtype=np.uint8), "RGB").resize((320, 240), Image.BICUBIC)).astype(np.int16)
+            a = np.clip(a + rng.normal(0, 12, a.shape), 0, 255).astype(np.uint8)
+            q, sub = (95, "4:2:0") if name.endswith("95") else (30, "4:2:2")
+        buf = io.BytesIO(); Image.fromarray(a, "RGB").save(buf, format="JPEG", quality=q, subsampling=sub, optimize=True)
         return buf.getvalue()
     return golden(name)[0]
 
 
-@pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "synth_1920x1080", "optimized_q30"])
+@pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "synth_1920x1080", "optimized_q30", "optimized_q95", "optimized_noise_444"])
 @pytest.mark.parametrize("sub_bits", [1024, 4096, 16384])
 def test_lane_per_subsequence_huffman_decoder_equals_the_single_wave_one(emu, name, sub_bits):
     """lep_huffdec_simt.h (one lane per subsequence: a guess from the subsequence's first bit, settle passes from where the lane in front
