@@ -438,7 +438,9 @@ def test_gpu_lane_per_subsequence_huffman_decode_in_the_compress_pipeline(gpu_co
     forces the subsequence length: 1024 bits leave the settle passes work to do and some scans to the fallback, 65536 make most
     fixtures a single lane) -- same .lep bytes as the reference's, whichever path a file ends up on"""
     names = golden_cases()
-    jpgs = [golden(n)[0] for n in names] + [corpus.synth_jpeg(1280, 720, 61), corpus.synth_jpeg(640, 480, 62, quality=97), corpus.synth_jpeg(1920, 1080, 63)]
+    import test_core_emulation as emu_tests
+    jpgs = [golden(n)[0] for n in names] + [corpus.synth_jpeg(1280, 720, 61), corpus.synth_jpeg(640, 480, 62, quality=97), corpus.synth_jpeg(1920, 1080, 63),
+                                             emu_tests._jpeg_for_huffman_tests("optimized_noise_444"), emu_tests._jpeg_for_huffman_tests("optimized_q95")]
     monkeypatch.delenv("LEP_HUFFDEC_PAR", raising=False)
     monkeypatch.setenv("LEP_HUFFDEC_SIMT", "1")
     if bits != "0":
