@@ -10,7 +10,7 @@
 //   1  count   lane = unit: the bits its blocks code to (nothing written);
 //   2  place   one wavefront per segment: exclusive prefix sum of the units' bits behind the segment's overhang bits;
 //   3  code    lane = unit: the same walk, its bits OR-ed into the segment's (zero-filled) bit buffer at the unit's position --
-//              MSB first, 32 bits at a time, atomically (a unit's first and last word are shared with its neighbours);
+//              MSB first, 32 bits at a time (a unit's first and last dword are shared with its neighbours: those two atomically);
 //   4  stuff   one wavefront per segment: the pad bits where the scan ends, then the bit buffer's whole bytes to the output
 //              with the 00 behind every FF (16 bytes per lane and step, positions from a prefix sum of the FFs), clipped to
 //              the segment's byte bound; the partial byte, its bit count and the last DCs are the segment's end state.
@@ -58,14 +58,18 @@ struct LaneSink {
     uint32_t nwords;        // WRITE: dwords of the buffer (bits beyond are dropped: the segment overran its bound anyway)
     uint32_t* buf;
     uint32_t total;
-    WDEV void start(uint32_t bitpos, uint32_t* b, uint32_t nw) { acc = 0; fill = WRITE ? (bitpos & 31u) : 0u; word = bitpos >> 5; buf = b; nwords = nw; total = 0; }
+    uint32_t first;         // WRITE: the dword the lane's first bit falls into -- shared with the unit in front, like its last one
+    WDEV void start(uint32_t bitpos, uint32_t* b, uint32_t nw) { acc = 0; fill = WRITE ? (bitpos & 31u) : 0u; word = first = bitpos >> 5; buf = b; nwords = nw; total = 0; }
     WDEV void put(uint32_t bits, uint32_t n) {   // n <= 32, bits right-aligned
         if (!WRITE) { total += n; return; }
         if (!n) return;
         acc |= (uint64_t)bits << (64 - fill - n);
         fill += n;
         if (fill >= 32) {
-            if (word < nwords) simt_or_word(buf + word, (uint32_t)(acc >> 32));
+            if (word < nwords) {
+                if (word == first) simt_or_word(buf + word, (uint32_t)(acc >> 32));
+                else buf[word] = (uint32_t)(acc >> 32);           // a full dword behind the first is this unit's alone
+            }
             ++word; acc <<= 32; fill -= 32;
         }
     }
