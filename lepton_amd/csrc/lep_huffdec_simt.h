@@ -58,26 +58,50 @@ struct SimtShared : HuffDecShared {
 struct SimtTile { uint32_t w[32 * 64]; };
 typedef uint16_t __attribute__((may_alias)) TileHalf;   // the tile is written in halves and read in dwords: the compiler must know they meet
 
-// bit reader of one lane: 64-bit window, one dword requested ahead
+// bit reader of one lane: 64-bit window, refilled 32 bits at a time from sixteen bytes the lane holds in registers.  (Fetched dword by
+// dword, every 64-byte line of the scan came from HBM again for most of its dwords -- 64 lanes x 32 wavefronts per CU walk 64 x 32
+// different lines, far more than the vector cache holds: 30 GB per pass over 2.3 GB of scan bits, PMC passes of round 4,
+// profiles/r07d_*; sixteen bytes per request are a quarter of the requests.)
 struct LaneBits {
     const uint32_t* words;
     uint32_t nwords;        // dwords that hold scan bytes (the buffer is padded with zeros to 16 bytes behind the scan)
     uint64_t w;
     int navail;
-    uint32_t bitpos, wi, ahead;
-    WDEV uint32_t fetch(uint32_t k) const { return k < nwords ? __builtin_bswap32(words[k]) : 0u; }
+    uint32_t bitpos, wi;    // wi: index of the next dword to enter the window
+    uint32_t q0, q1, q2, q3;   // dwords (wi & ~3) .. + 3 as loaded
+    WDEV void load_quad(uint32_t k) {      // k: multiple of 4; the buffer is 16-byte aligned and zero-padded behind the scan
+        if (k < nwords) {
+#if LEP_ON_GPU
+            typedef uint32_t Quad __attribute__((vector_size(16)));
+            const Quad v = *reinterpret_cast<const Quad*>(words + k);      // one global_load_dwordx4
+            q0 = v[0]; q1 = v[1]; q2 = v[2]; q3 = v[3];
+#else
+            uint32_t v[4];
+            memcpy(v, words + k, 16);
+            q0 = v[0]; q1 = v[1]; q2 = v[2]; q3 = v[3];
+#endif
+        } else { q0 = q1 = q2 = q3 = 0u; }
+    }
+    WDEV uint32_t next_word() {            // dword wi (0 behind the scan's last byte), big-endian, and on to the next
+        const uint32_t k = wi & 3u;
+        if (k == 0) load_quad(wi);
+        const uint32_t raw = k == 0 ? q0 : (k == 1 ? q1 : (k == 2 ? q2 : q3));
+        const uint32_t v = wi < nwords ? __builtin_bswap32(raw) : 0u;
+        ++wi;
+        return v;
+    }
     WDEV void seek(uint32_t bp) {
         wi = bp >> 5;
-        w = ((uint64_t)fetch(wi) << 32) | fetch(wi + 1);
-        wi += 2;
-        ahead = fetch(wi);
+        if (wi & 3u) load_quad(wi & ~3u);
+        const uint32_t hi = next_word(), lo = next_word();
+        w = ((uint64_t)hi << 32) | lo;
         navail = 64; bitpos = bp & ~31u;
         if (bp & 31u) consume(bp & 31u);
     }
     WDEV uint32_t top() const { return (uint32_t)(w >> 32); }
     WDEV void consume(uint32_t n) {   // n <= 31
         w <<= n; navail -= (int)n; bitpos += n;
-        if (navail <= 32) { w |= (uint64_t)ahead << (32 - navail); navail += 32; ++wi; ahead = fetch(wi); }
+        if (navail <= 32) { w |= (uint64_t)next_word() << (32 - navail); navail += 32; }
     }
 };
 
