@@ -142,7 +142,7 @@ typedef struct lep_huff_end {
 } lep_huff_end;
 /* d_ends: nseg records in device memory, or NULL.  Segments of MCU-interleaved scans without restart intervals are written with one
  * lane per run of eight MCUs (lep_huff_simt.h: count, prefix sums, code, stuff), the others with one wavefront per segment (lep_huff.h);
- * same bytes, same end states (LEP_HUFFENC_SIMT=0: the wavefront form for all).  `pad` of a segment is the library's (ignored on entry).
+ * same bytes, same end states (LEP_HUFFENC_SIMT=0: the wavefront form for all).  `pad` of a segment is the library's: pass it as 0 (lep_file_recode_plan does).
  * The call copies its arrays before it returns and does not wait for the stream. */
 int lep_gpu_huffman_encode_device(lep_gpu *g, const lep_huff_image *images, int nimg, const lep_huff_segment *segs, int nseg,
                                   uint8_t *d_out, uint32_t *d_out_len, lep_huff_end *d_ends, void *hip_stream);
