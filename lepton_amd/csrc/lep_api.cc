@@ -2,6 +2,7 @@
 #include "../../include/lepton_mi355x.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -394,8 +395,35 @@ int lep_file_segments(const lep_file* f, lep_segment* segs, lep_bytes* streams, 
     return (int)s.size();
 }
 
+}  // extern "C"
+namespace lep {
+// jpeg_recode.cc: the planned segments' scan bytes and end states from host threads (one per segment); recode_finish takes them like the GPU's
+int recode_segments_on_threads(LepFile* lf, const RecodePlan& plan, std::vector<std::vector<uint8_t>>* seg_bytes, std::vector<lep_huff_end>* ends);
+}
+// A file of several thread segments that the split re-coder takes (recode_prepare: the files the GPU scan encoders take), its segments
+// written on host threads and glued by recode_finish.  false = not such a file, or something in it the split form refuses: the
+// one-thread walk (recode_jpeg) then decides, as it always did.  (8 segments of a 4K file: 5 ms against 40 on the MI355X host.)
+static bool recode_on_threads(lep_file* f, std::vector<uint8_t>* jpg) {
+    // one file at a time: a caller that re-codes many files side by side (the batch calls' host pool) already has its cores busy
+    static std::atomic<int> busy{0};
+    struct Turn { bool mine; Turn() : mine(busy.fetch_add(1) == 0) {} ~Turn() { busy.fetch_sub(1); } } turn;
+    if (!turn.mine) return false;
+    lep::RecodePlan plan;
+    if (lep::recode_prepare(&f->lf, &plan) != 0 || !plan.gpu_ok || plan.segs.size() < 2) return false;
+    std::vector<std::vector<uint8_t>> bytes;
+    std::vector<lep_huff_end> ends;
+    if (lep::recode_segments_on_threads(&f->lf, plan, &bytes, &ends) != 0) return false;
+    std::vector<std::pair<const uint8_t*, size_t>> sb;
+    for (const std::vector<uint8_t>& b : bytes) sb.emplace_back(b.data(), b.size());
+    jpg->clear();
+    if (lep::recode_finish(&f->lf, plan, sb, ends.data(), jpg) != 0) { jpg->clear(); return false; }
+    return true;
+}
+extern "C" {
+
 int lep_file_recode(lep_file* f, lep_bytes* out) {
     std::vector<uint8_t> jpg;
+    if (recode_on_threads(f, &jpg)) return to_bytes(jpg, out);
     int rc = lep::recode_jpeg(&f->lf, &jpg);
     if (rc) return rc;
     return to_bytes(jpg, out);
@@ -414,6 +442,9 @@ int lep_jpeg_check_restores(const lep_jpeg* j, const uint8_t* lepdata, size_t le
     for (int c = 0; c < src.ncomp; ++c) dst.plane[c] = src.plane[c];
     f->frame_ready = true;
     std::vector<uint8_t> jpg;
+    // several thread segments: on host threads first.  Only a match is believed -- anything else is decided by the one-thread walk below.
+    if (recode_on_threads(f, &jpg) && jpg.size() == want_len && (want_len == 0 || memcmp(jpg.data(), want, want_len) == 0)) return 0;
+    jpg.clear();
     if (lep::recode_jpeg(&f->lf, &jpg)) return LEP_ROUNDTRIP_FAILURE;
     return jpg.size() == want_len && (want_len == 0 || memcmp(jpg.data(), want, want_len) == 0) ? 0 : LEP_ROUNDTRIP_FAILURE;
 }
@@ -519,9 +550,9 @@ int lep_compress_embedded(lep_gpu* g, const uint8_t* blob, size_t len, size_t of
 uint64_t lep_jpeg_gpu_scan_wait_timeouts(void) { return lep::prog_wait_timeouts(); }
 
 // How the batch calls cut a batch into pipeline chunks (pure host logic, unit-tested on the CPU).  A chunk's thread segments
-// are one decoder wavefront each, and the decode kernel takes as long for 7168 of them as for the 8192 the chip holds at once
-// (rounds 2-3 kept the eighth wave slot of every SIMD for a single-wavefront Huffman kernel beside a one-kernel encoder;
-// neither is what runs beside the coders any more), so an automatic chunk holds at most 8192 segments and 1024 images
+// are one decoder wavefront each and the chip holds 8192 of them at once (rounds 2-3 kept the eighth wave slot of every SIMD for
+// a single-wavefront Huffman kernel beside a one-kernel encoder; neither is what runs beside the coders any more: the decode kernel's
+// time is proportional to its segments either way, profiles/r05v_*), so an automatic chunk holds at most 8192 segments and 1024 images
 // (LEP_BATCH_CHUNK_SEGMENTS: measurement knob); a kernel takes as long for a small chunk as for a full one, so the chunks are
 // balanced (k equal chunks, not k - 1 full ones and a remainder), and a batch that fits one launch is not split at all.
 int lep_batch_plan(const size_t* file_bytes, const size_t* frame_bytes, int n, const lep_batch_options* o, int* chunk_first, int cap) {
