@@ -61,3 +61,24 @@ def gpu_codec():
     from lepton_amd.codec import GpuCodec
 
     return GpuCodec(0)
+
+
+REF_GOLDEN = os.path.join(GOLDEN, "ref")   # the reference's own images/ + what its binary writes for them (tests/golden/make_golden_ref.py)
+
+
+def ref_manifest():
+    return json.load(open(os.path.join(REF_GOLDEN, "manifest.json")))
+
+
+def ref_cases(progressive=None):
+    """the reference's own images/*.jpg that its binary compresses (exit 0 with -skipverify): names"""
+    return sorted(k for k, v in ref_manifest()["jpegs"].items() if v["encode_exit"] == 0 and (progressive is None or v["progressive"] == progressive))
+
+
+def ref_refused_cases():
+    """[(name, exit code)] of the images the reference refuses (arithmetic.jpg: 42; badzerorun.jpg: an assertion)"""
+    return sorted((k, v["encode_exit"]) for k, v in ref_manifest()["jpegs"].items() if v["encode_exit"] != 0)
+
+
+def ref_golden(name):
+    return (open(os.path.join(REF_GOLDEN, name + ".jpg"), "rb").read(), open(os.path.join(REF_GOLDEN, name + ".lep"), "rb").read())
