@@ -107,7 +107,14 @@ int decode_ac_refine(BitReader& br, const HuffTable& ac, int16_t* blk, unsigned*
             const int v = cat == 0 ? 0 : (br.read(1) == 0 ? -1 : 1);   // the sign bit stands in front of the correction bits of this stretch
             // target: the (run + 1)-th zero position at or after the cursor
             uint64_t z = band.zero & RefineBand::at_or_above(cursor);
-            if (__builtin_popcountll(z) <= run) return -1;            // the walk would leave the band
+            if (__builtin_popcountll(z) <= run) {
+                // the walk would leave the band.  The reference's walk (jpgcoder.cc:5192-5207) only notices at the band's last position:
+                // by then it has read a correction bit for every non-zero position from the cursor on and left the +-bit there.  A
+                // file cut inside a refinement scan is ACCEPTED with exactly this state (eof turns the -1 into "scan done" and the
+                // deltas are added to the frame), so the bits are consumed and the deltas left the same way before refusing.
+                band.correct(br, blk, band.nonzero & RefineBand::at_or_above(cursor));
+                return -1;
+            }
             for (int i = 0; i < run; ++i) z &= z - 1;
             const int target = __builtin_ctzll(z);
             band.correct(br, blk, band.nonzero & RefineBand::at_or_above(cursor) & RefineBand::below(target));

@@ -313,10 +313,25 @@ int recode_segments_on_threads(LepFile* lf, const RecodePlan& plan, std::vector<
         e.pad = 0;
         (*seg_bytes)[s].swap(o.buf);
     };
+    // Nothing may leave this function as an exception: it is called from extern "C" entry points, and a vector of joinable threads
+    // unwound by one would end the process (a thread limit under lepton_served, an allocation failure in a worker).  A segment that
+    // could not be coded is reported and the caller falls back to the one-thread re-coder.
+    std::vector<char> failed(n, 0);
+    auto guarded = [&](size_t s) {
+        try { one(s); } catch (...) { failed[s] = 1; }
+    };
     std::vector<std::thread> pool;
-    for (size_t s = 1; s < n; ++s) pool.emplace_back(one, s);
-    if (n) one(0);
+    pool.reserve(n);
+    size_t started = 1;
+    try {
+        for (; started < n; ++started) pool.emplace_back(guarded, started);
+    } catch (...) {
+        // std::thread's constructor threw (EAGAIN): the segments that have no thread are coded on this one
+    }
+    if (n) guarded(0);
+    for (size_t s = started; s < n; ++s) guarded(s);
     for (std::thread& t : pool) t.join();
+    for (size_t s = 0; s < n; ++s) if (failed[s]) return EX_ASSERTION_FAILURE;
     return 0;
 }
 

@@ -496,9 +496,9 @@ int parse_lep(const uint8_t* d, size_t n, LepFile* lf, const std::vector<uint8_t
         // the reference allocates and zero-fills that much, reads what the file holds into it and interprets it; nothing is left
         // for the sections behind it: "PAD marker not found" unless the header itself is refused first.  The same verdicts from
         // what the file holds plus a short zero tail, without the allocation.
-        const size_t have = left();
-        jf.hdr.assign(have + std::min<size_t>((size_t)hdrs - std::min<size_t>(have, hdrs), 16), 0);   // never longer than the claim
-        read_full(jf.hdr.data(), std::min<size_t>(have, hdrs));
+        const size_t backed = std::min<size_t>(left(), hdrs);   // (more inflated data may follow the claim: it is not the header's)
+        jf.hdr.assign(backed + std::min<size_t>((size_t)hdrs - backed, 16), 0);   // never longer than the claim
+        read_full(jf.hdr.data(), backed);
         memset(jf.qtables, 0, sizeof jf.qtables);
         if (!setup_frame(&jf)) return jf.warn < 0 ? -jf.warn : EX_UNSUPPORTED_JPEG;
         return EX_UNSUPPORTED_JPEG;

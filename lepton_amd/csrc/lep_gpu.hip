@@ -646,6 +646,10 @@ static int vmm_ensure(lep_gpu* g, void** p, size_t* have, size_t need, bool may_
     lep_gpu::VBuf& b = V.bufs[p];
     const size_t want = ((need + V.chunk - 1) / V.chunk) * V.chunk;
     if (want > b.reserved) {   // a longer address range (what the workspace held is not kept: every launch fills it anew)
+        // The old range is unmapped and freed here, and launches do not wait for their streams any more (upload() ring; lep_batch.hip
+        // queues chunk k + 1 while chunk k's kernels run): a kernel still in flight would lose its mapping under its feet.  hipFree
+        // used to synchronise implicitly; this path has to ask.  Rare: growth inside the reservation maps behind.
+        if (b.mapped) (void)hipDeviceSynchronize();
         vmm_unmap(g, b);
         if (b.va) (void)hipMemAddressFree(b.va, b.reserved);
         b.va = nullptr; b.reserved = 0; *p = nullptr; *have = 0;

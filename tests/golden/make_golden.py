@@ -40,6 +40,58 @@ def layout(w, h, comps, seed, **kw):
     return jpeg_writer.write_baseline(w, h, comps, np.random.default_rng(seed), **kw)[0]
 
 
+
+def refine_overrun_cut():
+    """A hand-made grey progressive file cut inside an AC refinement scan, right behind a code that asks for the 7th still-zero position of
+    a band that has five.  The reference's block decoder (jpgcoder.cc:5192-5207) notices the overrun only at the band's
+    last position -- after reading a correction bit for every non-zero position on the way, which runs it into the end of the file -- so
+    the file is ACCEPTED as a truncated one; a decoder that refuses at the code itself never reaches the end of the file and answers
+    UNSUPPORTED_JPEG."""
+    import struct
+
+    dqt, dht = jpeg_writer.annex_k_tables(85)
+    dc, ac = jpeg_writer._codes(*dht[(0, 0)]), jpeg_writer._codes(*dht[(1, 0)])
+    nblk = 4
+    out = bytearray(b"\xff\xd8")
+    out += b"\xff\xdb" + struct.pack(">H", 67) + b"\x00" + dqt[0]
+    out += b"\xff\xc2" + struct.pack(">HBHHB", 11, 8, 8, 8 * nblk, 1) + bytes([1, 0x11, 0])
+    for (cls, tid) in ((0, 0), (1, 0)):
+        bits, vals = dht[(cls, tid)]
+        out += b"\xff\xc4" + struct.pack(">H", 19 + len(vals)) + bytes([cls << 4 | tid]) + bytes(bits) + bytes(vals)
+
+    def sos(ss, se, ah, al):
+        return b"\xff\xda" + struct.pack(">HB", 8, 1) + bytes([1, 0x00, ss, se, ah << 4 | al])
+
+    out += sos(0, 0, 0, 0)                        # DC
+    bw, pred = jpeg_writer._Bits(), 0
+    for b in range(nblk):
+        s, extra = jpeg_writer._magnitude(10 * b - pred)
+        pred = 10 * b
+        bw.put(*dc[s])
+        if s:
+            bw.put(extra, s)
+    bw.flush()
+    out += bw.out
+    out += sos(1, 20, 0, 1)                       # AC band 1..20, point transform 1: positions 1..15 = +-1, 16..20 zero
+    bw = jpeg_writer._Bits()
+    for b in range(nblk):
+        for k in range(1, 16):
+            bw.put(*ac[0x01])
+            bw.put((k + b) & 1, 1)
+        bw.put(*ac[0x00])
+    bw.flush()
+    out += bw.out
+    out += sos(1, 20, 1, 0)                       # its refinement: block 0 regular, block 1 the overrunning code, then nothing
+    bw = jpeg_writer._Bits()
+    bw.put(*ac[0x00])
+    bw.put(0b101100111000101, 15)
+    bw.put(*ac[0x61])
+    bw.put(1, 1)
+    bw.put(0b101, 3)
+    bw.flush()
+    return bytes(out + bw.out)
+
+
 Y, CB, CR = (lambda h, v, i=1: (i, h, v, 0, 0, 0)), (lambda h, v, i=2: (i, h, v, 1, 1, 1)), (lambda h, v, i=3: (i, h, v, 1, 1, 1))
 
 CASES = {
@@ -69,6 +121,7 @@ CASES = {
     "prog_truncated_tail": lambda: corpus.synth_jpeg(320, 240, 131, progressive=True)[:-700],
     "prog_truncated_mid": lambda: (lambda b: b[:len(b) // 2])(corpus.synth_jpeg(320, 240, 132, progressive=True)),
     "prog_truncated_dc": lambda: corpus.synth_jpeg(320, 240, 133, progressive=True)[:1100],
+    "prog_truncated_refine_overrun": refine_overrun_cut,
     "prog_truncated_q97_800x600": lambda: (lambda b: b[:len(b) * 2 // 3])(corpus.synth_jpeg(800, 600, 134, quality=97, progressive=True)),
     # sampling layouts beyond libjpeg's front end (coefficient-domain writer, tests/jpeg_writer.py)
     "lay_440_97x50": lambda: layout(97, 50, [Y(1, 2), CB(1, 1), CR(1, 1)], 201),                         # 4:4:0
