@@ -63,7 +63,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(jpgs, budget_s=20.0):
+def cpu_baseline(jpgs, budget_s=20.0, what="of the bench's 4K JPEGs"):
     """Reference binary (oracle/_ref/lepton, built from the real reference) timed on this host:
     `lepton -singlethread -unjailed -skipverify` encode then decode per file (one core; also the arithmetic-coding
     interval alone, TS_ARITH_STARTED..FINISHED from its stderr, for a like-for-like hot-path number), then the same
@@ -106,7 +106,7 @@ def cpu_baseline(jpgs, budget_s=20.0):
         return None
     out = {
         "value": round(mb / (enc_s + dec_s), 3), "unit": "MB/s", "cores": 1, "kind": "reference",
-        "sample": "%d of the bench's 4K JPEGs (%.1f MB), reference `lepton -singlethread -unjailed -skipverify`, encode then decode, whole process wall clock" % (n, mb),
+        "sample": "%d %s (%.1f MB), reference `lepton -singlethread -unjailed -skipverify`, encode then decode, whole process wall clock" % (n, what, mb),
         "encode_MBps": round(mb / enc_s, 3), "decode_MBps": round(mb / dec_s, 3),
         "hot_path_only_encode_MBps": round(mb / arith_enc, 3) if arith_enc else None,
         "hot_path_only_decode_MBps": round(mb / arith_dec, 3) if arith_dec else None,
@@ -210,6 +210,10 @@ def pipeline_figure(codec, jpgs, label, verify=False, threads=0):
             "value": round(mb / (cs["wall_s"] + ds["wall_s"]), 1), "files_per_s": round(len(jpgs) / (cs["wall_s"] + ds["wall_s"]), 1),
             "unit": "MB/s = JPEG bytes / (compress seconds + decompress seconds), the headline's definition",
             "seconds": {d: {k: round(st[k], 3) for k in ("wall_s", "pipeline_s", "parse_s", "stage_s", "write_s", "alloc_s")} for d, st in (("compress", cs), ("decompress", ds))},
+            # which path the files took (lep_batch_stats): a corpus silently coded by the host Huffman coders, or re-done file by file
+            # because its streams outgrew their reservation, must show in the driver's line
+            "gpu_huffman_files": {"compress": int(cs.get("gpu_huffman_files", 0)), "decompress": int(ds.get("gpu_huffman_files", 0))},
+            "redone_files": int(cs.get("redone_files", 0)),
             "parity": "every file restored bit-exact", "_cs": cs, "_ds": ds}
 
 
@@ -234,9 +238,10 @@ class HipDevice:
         self.L.lep_gpu_sync(self.g)
 
     def pipeline(self, jpgs, label, verify=False):
-        # (no lep_gpu_trim between the phases: giving the cached models and scratch back and taking smaller ones again made the 1080p
-        # figure HALF as fast -- 1485 -> 737 MB/s compress, MI355X -- the device heap hands out memory in smaller pieces after 100+ GB
-        # have come and gone; the library releases its caches by itself when an allocation fails)
+        # (no lep_gpu_trim between the phases by default.  Round 3 saw the 1080p figure halve after a trim and blamed the device heap; round
+        # 4 found the cause -- the driver CLEARS the memory it hands out, 40 ms per GB, so a phase that gives 30 GB back and takes them
+        # again pays seconds -- and the library's workspaces are now pooled address ranges whose chunks a trim keeps (DESIGN.md 4 "What
+        # one phase leaves behind"): with --trim-between-phases the figures are within 1 %.)
         if self.trim:
             self.L.lep_gpu_trim(self.g)
         return pipeline_figure(self.codec, jpgs, label, verify=verify, threads=self.host_threads)
@@ -732,7 +737,7 @@ def main():
         cb = cpu_baseline(uniq)
         if cb:
             try:   # the same file through the reference binary, for the `lepton -benchmark` row
-                rbc = cpu_baseline([reference_benchmark_jpeg()], budget_s=4.0)
+                rbc = cpu_baseline([reference_benchmark_jpeg()], budget_s=4.0, what="x the file `lepton -benchmark` codes (3264x2448 4:2:0, no EOI)")
                 if rbc:
                     cb["reference_benchmark_file"] = {k: rbc[k] for k in ("value", "encode_MBps", "decode_MBps", "sample") if k in rbc}
             except Exception:

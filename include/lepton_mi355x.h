@@ -101,6 +101,12 @@ int lep_gpu_decode_device(lep_gpu *g, const lep_image_desc *images, int nimg, co
  * use different sets; a set may be reused once the launch that used it has finished (stream order does that when the same
  * stream always goes with the same set).  Default 0. */
 int lep_gpu_use_arena(lep_gpu *g, int k);
+/* on = 1: the decode launches that follow will share the chip with a neighbour launch on another stream (both workspace sets in use):
+ * they take the register budget that lets two launches' wavefronts sit on one SIMD.  0 = back to choosing by launch size. */
+int lep_gpu_expect_company(lep_gpu *g, int on);
+/* A caller that passed streams of its own (`hip_stream` arguments) calls this BEFORE destroying them: the object's descriptor-upload
+ * ring holds events recorded on those streams; this waits for the copies and drops the events. */
+int lep_gpu_settle_uploads(lep_gpu *g);
 int lep_gpu_sync(lep_gpu *g);
 double lep_gpu_last_kernel_ms(lep_gpu *g);
 /* The split-phase encoder (lep_enc5.h) is several kernels: stage times of the most recent encode launch that used it, in
@@ -216,13 +222,7 @@ typedef struct lep_huffprogdec_scan {
     uint64_t result_off;
 } lep_huffprogdec_scan;
 int lep_gpu_huffman_progressive_decode_device(lep_gpu *g, const lep_huffprogdec_scan *scans, int nscan, lep_huffdec_row *d_rows, void *hip_stream);
-/* The same result with nsub (2..64) wavefronts per image -- speculative synchronisation pass, stitching walk that proves each
- * region, write pass (lep_huffdec_par.h; bit-exact against the single-wave kernel on MI355X and in the lane-loop emulation).
- * Used by lep_compress_batch for a call's first chunk, whose scan decode nothing hides: 1024 4K images 0.89 s -> ~0.3 s.
- * Images with restart intervals are not accepted.  A subsequence that fails to synchronise gives its image a non-zero
- * status, exactly like an irregular scan. */
-int lep_gpu_huffman_decode_parallel_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, int nsub, lep_huffdec_row *d_rows, void *hip_stream);
-/* ... with one LANE per subsequence (lep_huffdec_simt.h): a scan is cut into thousands of subsequences, every lane decodes one with a
+/* The same result with one LANE per subsequence (lep_huffdec_simt.h; the batch compressor's default): a scan is cut into thousands of subsequences, every lane decodes one with a
  * bit reader of its own -- a guess from its first bit, settle passes from where the lane in front ended until no end state moves,
  * a prefix sum, a write pass into the ZERO-FILLED frame.  Same records, same frame, same status semantics as the single-wave
  * kernel (bit-exact against it on MI355X and in the lane-loop emulation); scans with restart intervals are refused

@@ -131,6 +131,7 @@ struct Slot {   // one chunk's buffers (double-buffered)
     uint8_t* d_vscan = nullptr; size_t vscan_cap = 0;       // ... and for baseline files: their scans written again from the device frame,
     uint32_t* d_vscanlen = nullptr; ScanCheck* d_vcheck = nullptr; size_t vseg_cap = 0;   // per thread segment
     hipEvent_t up = nullptr, done = nullptr, decoded = nullptr;
+    bool done_recorded = false;   // `done` has been recorded in the current batch call
     void release() {
         if (h_frames) (void)hipHostFree(h_frames);
         if (h_streams) (void)hipHostFree(h_streams);
@@ -168,13 +169,18 @@ struct Joiner {   // a background thread that is joined on every way out of the 
 
 struct StreamSet {   // HIP streams of one batch call, destroyed on every way out
     std::vector<hipStream_t> all;
+    lep_gpu* g = nullptr;   // the codec whose launch functions were handed these streams: its upload ring forgets them first
     int make(hipStream_t* s, int priority = 0, bool with_priority = false) {
         const hipError_t e = with_priority ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority) : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
         if (e != hipSuccess) return LEP_GPU_ERROR;
         all.push_back(*s);
         return 0;
     }
-    ~StreamSet() { for (hipStream_t s : all) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } }
+    ~StreamSet() {
+        for (hipStream_t s : all) (void)hipStreamSynchronize(s);
+        if (g) (void)lep_gpu_settle_uploads(g);
+        for (hipStream_t s : all) (void)hipStreamDestroy(s);
+    }
 };
 template <class T, void (*CLOSE)(T*)>
 struct HandleVector {   // parsed files of a batch: whatever is still open when the call returns is closed
@@ -397,7 +403,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     if (!g || n < 0) return LEP_GPU_ERROR;
     g_batch_gpu = g;
     const int threads = o && o->host_threads > 0 ? o->host_threads : effective_cpus();
-    // With the Huffman decode on the GPU, chunk k+1 is decoded (lep_huffdec_par.h, several wavefronts per image, on its own stream)
+    // With the Huffman decode on the GPU, chunk k+1 is decoded (lep_huffdec_simt.h, one lane per piece of the scan, on its own stream)
     // WHILE the split-phase encoder's kernels of chunk k run.  The chunking itself is lep_batch_plan (lep_api.cc).
     const bool verify = o && o->verify;
     HIPOK(hipSetDevice(lep_gpu_device(g)));
@@ -433,6 +439,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
     // (real photographs: segments of equal compressed size differ several-fold in blocks).  Off by default until measured.
     const bool overlap = (o && o->overlap_launches) || (getenv("LEP_BATCH_OVERLAP") && atoi(getenv("LEP_BATCH_OVERLAP")) != 0);
     StreamSet stream_set;
+    stream_set.g = g;
     if (stream_set.make(&s_copy) || stream_set.make(&s_compute) || (overlap && stream_set.make(&s_compute2)) || stream_set.make(&s_down)) return LEP_GPU_ERROR;
     {   // Huffman decode of chunk k+1 beside the coder kernels of chunk k: its workgroups go first whenever a slot is free
         int lo = 0, hi = 0;
@@ -606,22 +613,15 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 launch.push_back(hi); which.push_back(k);
             }
             HIPOK(hipStreamWaitEvent(s_huff, s->up, 0));
-            // Several wavefronts per image (lep_huffdec_par.h) for the scans without restart intervals, for EVERY chunk.  Round 2
-            // kept the single-wave kernel for the chunks behind the first: it was built to sit in the eighth wave slot beside the
-            // previous chunk's one-kernel encoder, which took as long as it did (~0.9 s for 896 4K images).  Beside the split-phase
-            // encoder (0.45 s per chunk) it became the pipeline's critical path -- kernel trace of 2688 x 4K, profiles/r05b_*: every
-            // chunk's encode launch waited ~0.5 s for the scan decode of its own images -- while the parallel form takes 0.31 s and
-            // shares the chip with the walks (they wait 60 % of their wave time): compress 1675 -> 2184 MB/s (profiles/r05c_*).
-            // LEP_HUFFDEC_PAR=<n> forces n (0 = single wave) for every chunk.
-            // Round 4, second half: one LANE per subsequence (lep_huffdec_simt.h) -- thousands of subsequences per scan, 64 codes per
-            // instruction -- instead of one wavefront per subsequence; LEP_HUFFDEC_SIMT=0 keeps the wavefront form above.
-            const bool simt = !(getenv("LEP_HUFFDEC_SIMT") && atoi(getenv("LEP_HUFFDEC_SIMT")) == 0) && !getenv("LEP_HUFFDEC_PAR");
-            const int par = simt ? 16 : (getenv("LEP_HUFFDEC_PAR") ? atoi(getenv("LEP_HUFFDEC_PAR")) : 16);
-            if (par >= 2) {
+            // One LANE per subsequence (lep_huffdec_simt.h: thousands of subsequences per scan, 64 codes per instruction) for the scans
+            // without restart intervals, the single-wave kernel (lep_huffdec.h) for the others; LEP_HUFFDEC_SIMT=0 keeps the single-wave
+            // kernel for every file.  (Round 2-4's form in between -- several WAVEFRONTS per image, 290 ms per 896-file chunk against 43 --
+            // is gone from the product: DESIGN.md 4 "JPEG Huffman kernels" keeps its numbers.)
+            const bool simt = !(getenv("LEP_HUFFDEC_SIMT") && atoi(getenv("LEP_HUFFDEC_SIMT")) == 0);
+            if (simt) {
                 std::vector<lep_huffdec_image> many, one;
                 for (const lep_huffdec_image& hi : launch) (hi.rsti ? one : many).push_back(hi);
-                if (!many.empty() && simt) { if (int rc = lep_gpu_huffman_decode_simt_device(g, many.data(), (int)many.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
-                else if (!many.empty()) { if (int rc = lep_gpu_huffman_decode_parallel_device(g, many.data(), (int)many.size(), par > 64 ? 64 : par, (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
+                if (!many.empty()) { if (int rc = lep_gpu_huffman_decode_simt_device(g, many.data(), (int)many.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
                 if (!one.empty()) { if (int rc = lep_gpu_huffman_decode_device(g, one.data(), (int)one.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
             } else
             if (int rc = lep_gpu_huffman_decode_device(g, launch.data(), (int)launch.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc;
@@ -647,7 +647,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             HIPOK(hipMemcpyAsync(rows.data(), s->d_rows, rows_total * sizeof(lep_huffdec_row), hipMemcpyDeviceToHost, s_huff));
             HIPOK(hipStreamSynchronize(s_huff));
             st.d2h_bytes += (double)(rows_total * sizeof(lep_huffdec_row));
-            if (par >= 2) {
+            if (simt) {
                 // a scan whose subsequences did not synchronise (or that is irregular) gets a second chance with the single-wave
                 // kernel before the host parser is bothered: its frame is wiped first (pass C may have written part of it)
                 std::vector<lep_huffdec_image> again;
@@ -993,9 +993,18 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         });
         st.parse_s += now_s() - t0;
     }
-    hipStream_t s_copy = nullptr, s_compute = nullptr, s_down = nullptr, s_scan = nullptr;
+    hipStream_t s_copy = nullptr, s_compute = nullptr, s_compute_b = nullptr, s_down = nullptr, s_scan = nullptr;
     StreamSet stream_set;
-    if (stream_set.make(&s_copy) || stream_set.make(&s_compute) || stream_set.make(&s_down) || stream_set.make(&s_scan)) return LEP_GPU_ERROR;
+    stream_set.g = g;
+    if (stream_set.make(&s_copy) || stream_set.make(&s_compute) || stream_set.make(&s_compute_b) || stream_set.make(&s_down) || stream_set.make(&s_scan)) return LEP_GPU_ERROR;
+    // Consecutive chunks' decode kernels on TWO streams (and the codec's two workspace sets) where that pays: a launch is over when its
+    // longest thread segment is, and while the long segments of a ragged chunk (1080p files beside 4K ones; a chunk that does not fill the
+    // chip) run on, the wave slots its short ones have left stand empty -- the next chunk's launch, longest segments first, moves into them
+    // instead of waiting behind the whole kernel.  A chunk of equal segments that fills the chip keeps the one-stream order: there is no
+    // tail to fill, and its scan encoders would only have to fight the next decode kernel for slots (the LEP_BATCH_SCAN_STREAM finding
+    // below).  LEP_BATCH_DEC_OVERLAP=0 | 1 forces never / always.
+    int dec_overlap = -1;
+    if (const char* e = getenv("LEP_BATCH_DEC_OVERLAP")) dec_overlap = atoi(e) ? 1 : 0;
     // The scan encoders run behind the decoder on ITS stream.  On a stream of their own (LEP_BATCH_SCAN_STREAM=1) they compete with the
     // next chunk's decode kernel for wave slots it fills completely, finish when it does, and hold the chunk's download back:
     // 1530 against 1774 MB/s (profiles/r06j_*).
@@ -1142,15 +1151,43 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         return 0;
     };
 
-    // decoder + Huffman re-encode kernels of one chunk, stream-ordered behind the previous chunk's
+    // decoder + Huffman re-encode kernels of one chunk: stream-ordered behind the previous chunk's, or beside them on the other stream
+    // when the previous chunk leaves wave slots to fill (see dec_overlap above)
+    hipStream_t s_prev = nullptr;          // the stream the previous chunk's kernels went to
+    Slot* slot_prev = nullptr;
+    bool prev_ragged = false;
+    const hipStream_t s_compute_a = s_compute;
     auto launch_chunk = [&](Chunk* c, Slot* s) -> int {
         const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
         if (!nimg) return 0;
         static const bool tr = getenv("LEP_BATCH_TRACE") != nullptr;
         const double tt0 = now_s();
+        // does THIS chunk leave a tail?  segments whose block counts differ by more than 1.5x, or fewer segments than fill the chip
+        int64_t lo = INT64_MAX, hi = 0;
+        for (int q = 0; q < nseg; ++q) {
+            const lep_image_desc& d = c->dev_desc[(size_t)c->segs[q].image];
+            const int y1 = c->segs[q].is_last ? d.height_blocks[0] : std::min<int>(c->segs[q].luma_y_end, d.height_blocks[0]);
+            const int64_t w = std::max<int64_t>(1, (int64_t)std::max(0, y1 - c->segs[q].luma_y_start) * d.width_blocks[0]);
+            lo = std::min(lo, w); hi = std::max(hi, w);
+        }
+        const bool ragged = hi * 2 > lo * 3 || nseg < 6144;
+        const bool beside = s_prev && (dec_overlap == 1 || (dec_overlap < 0 && prev_ragged));
+        const int set = (int)(s - slots) & 1;
+        hipStream_t s_compute = !s_prev ? s_compute_a : (beside ? (s_prev == s_compute_a ? s_compute_b : s_compute_a) : s_prev);
+        hipStream_t s_scan_here = s_scan == s_compute_a ? s_compute : s_scan;
+        // this slot's buffers and this workspace set were last used by the chunk before the previous one, possibly on the other stream
+        if (s->done_recorded) HIPOK(hipStreamWaitEvent(s_compute, s->done, 0));
         HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
+        if (int rc0 = lep_gpu_use_arena(g, set)) return rc0;
+        (void)lep_gpu_expect_company(g, dec_overlap != 0 && (beside || ragged) && c->count < n);   // (a call of one chunk has no neighbour)
         int rc = lep_gpu_decode_device(g, c->dev_desc.data(), nimg, c->segs.data(), nseg, s->d_streams, c->offs.data(), s->d_len, s->d_status, s_compute);
+        (void)lep_gpu_expect_company(g, 0);
+        (void)lep_gpu_use_arena(g, 0);
         if (rc) return rc;
+        // the scan encoders' descriptors live in ONE device buffer of the codec: the previous chunk's encoders (other stream) read them
+        if (beside && slot_prev && slot_prev->done_recorded) HIPOK(hipStreamWaitEvent(s_scan_here, slot_prev->done, 0));
+        s_prev = s_compute; slot_prev = s; prev_ragged = ragged;
+        hipStream_t s_scan = s_scan_here;
         const double tt1 = now_s();
         if (s_scan != s_compute) { HIPOK(hipEventRecord(s->decoded, s_compute)); HIPOK(hipStreamWaitEvent(s_scan, s->decoded, 0)); }
         if (!c->hseg.empty()) {
@@ -1164,10 +1201,12 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
             if (rc) return rc;
         }
         HIPOK(hipEventRecord(s->done, s_scan));
+        s->done_recorded = true;
         return 0;
     };
     Joiner writer_guard;
     std::thread& writer = writer_guard.t;
+    for (int k = 0; k < 2; ++k) slots[k].done_recorded = false;   // (events of an earlier call: nothing of it is in flight)
     std::unique_ptr<Chunk> cur = cut_chunk(0), nxt;
     int slot_i = 0;
     if (int rc = stage_and_upload(cur.get(), &slots[0], &chunk_lens[0])) rc_all = rc;

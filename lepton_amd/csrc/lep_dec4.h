@@ -325,6 +325,26 @@ struct BoolDec4S {
     }
 };
 
+// Issue priority by kind of phase (s_setprio): a wavefront in a SERIAL round lowers its priority -- to 0 where the round runs on the scalar
+// unit, to 1 where it is uniform vector code -- and goes back to 2 for everything lane-parallel (prefetch, owners' update, priors, IDCT,
+// staging, store).  Why (MI355X, 1024 x 4K, profiles/r09b..e_decoder_priority_*): the eight wavefronts of a SIMD compete for one vector
+// and one scalar issue slot per turn.  A wavefront in a serial round issues one DEPENDENT instruction every second to fourth turn
+// whatever its priority; one in a lane-parallel phase has independent instructions for every turn and ends in the memory requests its
+// next round waits for.  With equal priorities the arbiter served them oldest first; letting the lane-parallel work go first took the
+// launch from 1117 to 980 ms (-12 %).  Swept as a table of levels per kind (prefetch / scalar serial / vector serial / update / other
+// / staging + store), 26 combinations over three visits: scalar serial lowest is worth -8 %, vector serial one level above it another
+// -4 %, the order among the lane-parallel kinds nothing (978..984 ms); raising the serial rounds instead loses (1116 -> 1116..1026 the
+// other way round).  -DLEP_DEC4_PRIO=0 builds the kernel without it.
+#ifndef LEP_DEC4_PRIO
+#define LEP_DEC4_PRIO 1
+#endif
+#if LEP_ON_GPU && LEP_DEC4_PRIO
+#define LEP_PRIO_SERIAL(on_scalar_unit) __builtin_amdgcn_s_setprio((on_scalar_unit) ? 0 : 1)
+#define LEP_PRIO_PARALLEL() __builtin_amdgcn_s_setprio(2)
+#else
+#define LEP_PRIO_SERIAL(on_scalar_unit) ((void)0)
+#define LEP_PRIO_PARALLEL() ((void)0)
+#endif
 // which serial rounds run on the scalar unit: 1 = non-zero count tree, 2 = 7x7 interior, 4 = edges, 8 = DC
 #ifndef LEP_DEC4_SCALAR
 #define LEP_DEC4_SCALAR 2   // measured (1024 x 4K, MI355X, profiles/r02m_*): 0: 1232 ms, 2: 1204, 3: 1212, 11: 1226, 7: 1400, 15: 1440
@@ -587,7 +607,7 @@ struct Dec4Wave {
             }
             L(a0) = adr; L(PK0) = pk;
         }
-        LEP_MARK("nz_serial");
+        LEP_MARK("nz_serial"); LEP_PRIO_SERIAL((LEP_DEC4_SCALAR & 1) != 0);
         int nz;
         {
             Serial<(LEP_DEC4_SCALAR & 1) != 0> sr(*this);
@@ -595,7 +615,7 @@ struct Dec4Wave {
             sr.done();
             LEP_BINS(nbins += 6);
         }
-        LEP_MARK("nz_update");
+        LEP_MARK("nz_update"); LEP_PRIO_PARALLEL();
         LV(int, u0); LV(int, b0);
         LANES(l) {
             int u = 0, b = 0;
@@ -636,7 +656,7 @@ struct Dec4Wave {
         }
         LSYNC();
         // ---- serial (uniform vector) -----------------------------------------------------------------------------
-        LEP_MARK("77_serial");
+        LEP_MARK("77_serial"); LEP_PRIO_SERIAL((LEP_DEC4_SCALAR & 2) != 0);
         int zz, left = left0, cand = 0;
         const int pi_end = zz0 + 16 < 49 ? 16 : 49 - zz0;   // window positions 0 .. pi_end-1
         {
@@ -698,7 +718,7 @@ struct Dec4Wave {
         }
         LSYNC();
         // ---- owners adapt ---------------------------------------------------------------------------------------------------
-        LEP_MARK("77_update");
+        LEP_MARK("77_update"); LEP_PRIO_PARALLEL();
         LV(int, nzw);
         LANES(l) L(nzw) = l < 16 && zz0 + l < zz && S.here[zz0 + l] != 0;
         const uint32_t nzmask = (uint32_t)lepwave::wave_ballot(nzw);
@@ -770,7 +790,7 @@ struct Dec4Wave {
         }
         LSYNC();
         // ---- serial (uniform vector) -----------------------------------------------------------------------------
-        LEP_MARK("edge_serial");
+        LEP_MARK("edge_serial"); LEP_PRIO_SERIAL((LEP_DEC4_SCALAR & 4) != 0);
         int ne[2] = {0, 0}, rc = 0;
         typedef Serial<(LEP_DEC4_SCALAR & 4) != 0> SR;
         SR sr(*this);
@@ -879,7 +899,7 @@ struct Dec4Wave {
         LSYNC();
         if (rc) return rc;
         // ---- owners adapt ---------------------------------------------------------------------------------------------------
-        LEP_MARK("edge_update");
+        LEP_MARK("edge_update"); LEP_PRIO_PARALLEL();
         LV(int, enz);
         LANES(l) L(enz) = l >= 50 && S.here[l] != 0;   // aligned 50..56 horizontal, 57..63 vertical
         const uint64_t em = lepwave::wave_ballot(enz);
@@ -931,7 +951,7 @@ struct Dec4Wave {
             else if (l < 13) rw = S.resdc[a * 12 + (l - 3)];   // residual Branch of bit l-3
             L(a0) = adr; L(PK0) = pk; L(RW) = rw;
         }
-        LEP_MARK("dc_serial");
+        LEP_MARK("dc_serial"); LEP_PRIO_SERIAL((LEP_DEC4_SCALAR & 8) != 0);
         const int sslot = ci * 48 + sctx;
         typedef Serial<(LEP_DEC4_SCALAR & 8) != 0> SR;
         SR sr(*this);
@@ -963,7 +983,7 @@ struct Dec4Wave {
         S.here[49] = (int16_t)dc;
         LSYNC();
         // owners: exponent groups (lanes 0..2), residual Branches (lanes 3..12)
-        LEP_MARK("dc_update");
+        LEP_MARK("dc_update"); LEP_PRIO_PARALLEL();
         LV(uint32_t, VV); LV(int, u0); LV(int, b0);
         LANES(l) L(VV) = v;   // uniform -> per lane (identity on the GPU)
         LANES(l) {
@@ -1101,6 +1121,7 @@ struct Dec4Wave {
     WDEV int run(const ImageDev* image, const SegDev& seg, uint32_t* model_words, NSum* ns, Dec4Shared* shared, const uint8_t* stream,
                  uint32_t len) {
         img = image; model = model_words; sh = shared; nbins = 0;
+        LEP_PRIO_PARALLEL();
         init_tables();
         bc.init_stream(stream, len);
         bool top[3] = {true, true, true};

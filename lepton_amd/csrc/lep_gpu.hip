@@ -20,11 +20,9 @@
 #include "lep_core.h"
 #include "lep_enc3.h"
 #include "lep_dec4.h"
-#include "lep_dec5.h"
 #include "lep_enc5.h"
 #include "lep_huff.h"
 #include "lep_huffdec.h"
-#include "lep_huffdec_par.h"
 #include "lep_huffdec_simt.h"
 #include "lep_huff_simt.h"
 #include "lep_huffprog.h"
@@ -37,7 +35,6 @@ namespace {
 // the encoder uses the dense model layout (kModelBranches words), the decoder the group-aligned one (lep3::kModelWords);
 // segments are spaced by the larger so that one arena serves both
 constexpr size_t kModelStride = lep3::kModelWords > kModelBranches ? lep3::kModelWords : kModelBranches;
-static_assert(lep5d::kModelWords5 <= kModelStride, "the v5 decoder's model fits the arena's spacing");
 
 template <uint32_t WORDS = kModelBranches>
 __device__ void reset_segment_state(uint32_t* model, NSum* ns, int ns_count, int lane) {
@@ -121,17 +118,6 @@ __global__ void lep_selftest_kernel(uint32_t* mismatches) {
     }
     if (lep3::prob_of(f, t) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);
     if (lep5::prob16(f | (t << 8)) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);   // the fold kernels' form (lep_enc5.h)
-    if (lep5d::prob8(f, t) != (f << 8) / (f + t)) atomicAdd(mismatches, 1u);             // the v5 decoder's update pass (lep_dec5.h)
-    if (f == 1 && lep5d::prob8(0, t) != 0) atomicAdd(mismatches, 1u);                    // ... and its saturated state
-    for (uint32_t obs = 0; obs < 2; ++obs) {   // v5's count rule against the packed word's: same counts, same probability afterwards
-        const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);
-        const uint32_t want = branch_update(w, (int)obs);
-        uint32_t f5 = f, t5 = t;
-        lep5d::upd_ft(f5, t5, obs);
-        const uint32_t p5 = f5 ? lep5d::prob8(f5, t5) : 0u;
-        const bool sat = f5 == 0;   // stored form of (1, 255) with probability 0
-        if ((sat ? 1u : f5) != (want & 255) || t5 != ((want >> 8) & 255) || p5 != (want >> 16)) atomicAdd(mismatches, 1u);
-    }
     for (int obs = 0; obs < 2; ++obs) {
         const uint32_t w = f | (t << 8) | (((f << 8) / (f + t)) << 16);
         if (lep3::bupd(w, obs) != branch_update(w, obs)) atomicAdd(mismatches, 1u);
@@ -174,49 +160,6 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
     bins[seg.slot] = w.nbins;
 }
 
-
-// v5 decoder (lep_dec5.h): a workgroup of NW wavefronts = NW segments; the lane-parallel phases serve all of them from 16-lane rows
-// of one wavefront, the owner updates go through a queue in LDS.  WAVES = wavefronts per SIMD the register allocation is held to.
-__device__ void reset_segment_state_v5(uint32_t* model, NSum* ns, int ns_count, int lane) {
-    uint4* m4 = reinterpret_cast<uint4*>(model);
-    const uint32_t pat[3] = {lep5d::kRecInitF, lep5d::kRecInitT, lep5d::kRecInitP};
-    for (uint32_t i = lane; i < lep5d::kThreshOff5 / 4; i += 64) {   // records: the three words repeat (the padding behind them too)
-        const uint32_t b = (4 * i) % 3;
-        m4[i] = make_uint4(pat[b], pat[(b + 1) % 3], pat[(b + 2) % 3], pat[b]);
-    }
-    const uint4 init = make_uint4(kBranchInit, kBranchInit, kBranchInit, kBranchInit);
-    for (uint32_t i = lep5d::kThreshOff5 / 4 + lane; i < lep5d::kModelWords5 / 4; i += 64) m4[i] = init;
-    uint32_t* n32 = reinterpret_cast<uint32_t*>(ns);
-    const uint32_t words = (uint32_t)ns_count * (sizeof(NSum) / 4);
-    for (uint32_t i = lane; i < words; i += 64) n32[i] = 0;
-}
-template <int NW, int WAVES>
-__global__ __launch_bounds__(64 * NW, WAVES) void lep_decode_v5_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
-                                                                uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
-                                                                uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins, int nseg) {
-    __shared__ lep5d::Dec5Shared<NW> sh;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int s = (int)blockIdx.x * NW + wave;
-    lep5d::Dec5Group<NW> g;
-    lep5d::Wave5& W = g.wv[0];
-    W.img = nullptr;
-    g.model0 = models + (size_t)blockIdx.x * NW * kModelStride;
-    g.model_stride = kModelStride;
-    if (s < nseg) {
-        W.seg = segs[s];
-        W.img = images + W.seg.image;
-        W.model = models + (size_t)s * kModelStride;
-        W.ns = ns_area + ns_offsets[s];
-        W.stream = streams + W.seg.stream_off;
-        W.stream_len = stream_len[W.seg.slot];
-        reset_segment_state_v5(W.model, W.ns, W.img->ns_total, lane);
-    }
-    __syncthreads();
-    g.run(&sh);
-    if (lane != 0 || s >= nseg) return;
-    status[W.seg.slot] = W.rc;
-    bins[W.seg.slot] = W.nbins;
-}
 
 // ---- the split-phase encoder (lep_enc5.h) -------------------------------------------------------------------------------------
 // walk: one or two wavefronts per segment (count / emit / gather share the code; NW = 2: lep_enc5.h Walk5); LDS: two transposed
@@ -415,35 +358,6 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_decode_kernel(const lephuff
     w.run(images + blockIdx.x, &sh, rows);
 }
 
-// Several wavefronts per image (lep_huffdec_par.h; experimental, opt-in): sync / stitch / write passes over nsub subsequences
-// of every scan, then one thread per image folds the passes' verdicts into the final row record's status.
-__global__ __launch_bounds__(64, 8) void lep_huffman_par_sync_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffParState* st, int nsub) {
-    __shared__ lephuff::HuffParShared sh;
-    const int img = (int)blockIdx.x / nsub, sub = (int)blockIdx.x % nsub;
-    lephuff::HuffParWave w;
-    w.run_sync(images + img, &sh, st + (size_t)img * nsub, sub, nsub);
-}
-__global__ __launch_bounds__(64, 8) void lep_huffman_par_stitch_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::HuffParState* st, int nsub) {
-    __shared__ lephuff::HuffParShared sh;
-    const int img = (int)blockIdx.x / nsub, sub = (int)blockIdx.x % nsub;
-    lephuff::HuffParWave w;
-    w.run_stitch(images + img, &sh, st + (size_t)img * nsub, sub, nsub);
-}
-__global__ __launch_bounds__(64, 8) void lep_huffman_par_write_kernel(const lephuff::HuffDecImage* __restrict__ images, const lephuff::HuffParState* st, int nsub,
-                                                                     lephuff::HuffDecRow* rows, int* img_status) {
-    __shared__ lephuff::HuffParShared sh;
-    const int img = (int)blockIdx.x / nsub, sub = (int)blockIdx.x % nsub;
-    lephuff::HuffParWave w;
-    const int rc = w.run_write(images + img, &sh, st + (size_t)img * nsub, rows, sub, nsub);
-    if (rc && threadIdx.x == 0) atomicOr(img_status + img, rc);
-}
-__global__ void lep_huffman_par_finish_kernel(const lephuff::HuffDecImage* __restrict__ images, int nimg, lephuff::HuffDecRow* rows, const int* img_status) {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= nimg) return;
-    lephuff::HuffDecRow* last = rows + images[i].rows_off + images[i].mcuv;
-    last->aux = (last->aux & 255) | (img_status[i] << 8);
-}
-
 // One lane per subsequence (lep_huffdec_simt.h): guess / settle / place / write; a wavefront's 64 lanes are 64 consecutive
 // subsequences of one image, whose tables the wavefront keeps in LDS.
 __global__ __launch_bounds__(64) void lep_huffman_simt_settle_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::SimtImage* si, const lephuff::SimtWave* waves,
@@ -506,11 +420,7 @@ struct lep_gpu {
     int enc_pair_max = 1280; // launches of up to this many segments take the two-wave encoder: its 128-thread workgroups are resident 6 per
                              // CU (1536 on the chip), one pass; measured (profiles/r02d_latency_sweep.json, 4K images): 1 .. 128 images
                              // 300-343 ms against 450-496 ms for one wavefront per segment, 256 images 650 against 510.  LEP_ENC_PAIR_MAX
-    int dec5 = 0;            // LEP_DEC5=1: lep_dec5.h (workgroups of segments, shared lane-parallel phases) instead of lep_dec4.h.  Measured
-                             // (MI355X, 1024 x 4K, profiles/r05d_*, r05e_*): 1208 ms per launch against 1118 -- the phases it shares are a
-                             // sixth of the block's instructions, its barriers cost more than that -- so it is not the default
-    int dec5_group = 4;      // LEP_DEC5_GROUP = 1 | 4: segments (= wavefronts) per workgroup of the v5 decoder
-    int dec5_group_min = 16; // LEP_DEC5_GROUP_MIN: launches of fewer segments take one wavefront per workgroup
+    int dec_company = 0;     // lep_gpu_expect_company: decode launches will overlap with their neighbours on another stream
     int dec_waves = 0;       // register-budget build of the decoder: 0 = by batch size (8 waves per SIMD / 64 VGPRs once a launch can
                              // fill them, else 4 / 128 VGPRs, no spills); LEP_DEC_WAVES = 4 | 8 forces one
     std::string err;
@@ -569,7 +479,7 @@ struct lep_gpu {
     int huffprog_turn = 0;   // the two sets are used in turn: at most two launches are ever in flight (lep_batch.hip queues chunk k+1 before it fetches chunk k)
     void* d_huffprogdec = nullptr; size_t huffprogdec_bytes = 0;   // ProgDecScan[]
     void* d_huffdec = nullptr; size_t huffdec_bytes = 0;   // HuffDecImage[]
-    void* d_huffpar = nullptr; size_t huffpar_bytes = 0;   // HuffParState[nimg][nsub] | int status[nimg] (parallel Huffman decode)
+    void* d_huffpar = nullptr; size_t huffpar_bytes = 0;   // the lane-per-subsequence scan decoder's records (SimtImage | SimtWave | SimtSub x 2 | SimtPlace)
     void* d_scan = nullptr; size_t scan_bytes = 0;      // scan bytes of the Huffman encoder (host variant)
     void* d_scanlen = nullptr; size_t scanlen_bytes = 0;
 };
@@ -879,21 +789,6 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
     // carries the caller's index for the results.
     const bool permute = nseg > 8;
     std::vector<int> order(nseg);
-    const int dec_group = DEC ? (g->dec5 ? (g->dec5_group > 1 && nseg >= g->dec5_group_min ? g->dec5_group : 1) : 0) : 0;
-    if (dec_group > 1) {
-        // The v5 decoder takes four consecutive segments of the launch order as one workgroup, whose wavefronts meet at a barrier
-        // after every phase of every block: they should have about as many blocks to go through.  Segments sorted by their block
-        // count (largest first: the long ones start first), groups of four dealt round-robin -- workgroup b lands on XCD b % 8, so
-        // every XCD gets the same mix.
-        std::vector<int64_t> wgt(nseg);
-        for (int s = 0; s < nseg; ++s) {
-            const ImageDev& im = himg[segs[s].image];
-            const int y1 = segs[s].is_last ? im.height[0] : segs[s].luma_y_end;
-            wgt[s] = (int64_t)(y1 - segs[s].luma_y_start) * im.width[0];
-        }
-        for (int s = 0; s < nseg; ++s) order[s] = s;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wgt[a] > wgt[b]; });
-    } else
     if (permute) {
         std::vector<int> q[8];
         int rank = 0;
@@ -907,6 +802,28 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
                 if (at[x] < q[x].size()) order[i++] = q[x][at[x]++];
     } else {
         for (int s = 0; s < nseg; ++s) order[s] = s;
+    }
+    // Longest first.  A launch is over when its longest thread segment is, and the hardware hands workgroups out in launch order as
+    // wave slots come free: with the long segments in front, the short ones of a mixed batch (1080p files beside 4K ones: a quarter of
+    // the blocks) back-fill behind them -- in this launch when it has more segments than the chip holds wavefronts, and in the NEXT
+    // chunk's launch, which the batch decompressor queues on a second stream (lep_batch.hip) -- instead of the other way round.  A
+    // stable sort on the block count's size class (quarter octaves) keeps the XCD interleave above among near-equals, and a corpus whose
+    // segments are within 1.5x of each other (the eight segments of equal-sized files differ by a block row) is launched exactly as before.
+    if (nseg > 8) {
+        std::vector<int> cls(nseg);
+        int64_t lo = INT64_MAX, hi = 0;
+        for (int s = 0; s < nseg; ++s) {
+            const ImageDev& im = himg[segs[s].image];
+            const int y1 = segs[s].is_last ? im.height[0] : std::min(segs[s].luma_y_end, im.height[0]);
+            const int64_t w = std::max<int64_t>(1, (int64_t)std::max(0, y1 - segs[s].luma_y_start) * im.width[0]);
+            lo = std::min(lo, w); hi = std::max(hi, w);
+            int c = 0;
+            for (int64_t v = w; v > 1; v >>= 1) c += 4;                       // 4 * floor(log2 w) ...
+            const int64_t base = (int64_t)1 << (c / 4);
+            c += w * 4 >= base * 7 ? 3 : (w * 2 >= base * 3 ? 2 : (w * 4 >= base * 5 ? 1 : 0));   // ... + the quarter inside the octave
+            cls[s] = c;
+        }
+        if (hi * 2 > lo * 3) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls[a] > cls[b]; });
     }
     for (int i = 0; i < nseg; ++i) {
         const int s = order[i];
@@ -945,21 +862,12 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
         // more resident waves only pay once the batch can fill them (MI355X, 4K corpus: below ~4600 segments the 4-wave
         // build, which does not spill, is faster)
         int waves = g->dec_waves;
-        if (!waves) waves = nseg > 4608 ? 8 : 4;
-#define LEP_LAUNCH_DEC5(NW, W)                                                                                                 \
-    hipLaunchKernelGGL((lep_decode_v5_kernel<NW, W>), dim3((nseg + NW - 1) / NW), dim3(64 * NW), 0, st, (const ImageDev*)(meta + o_img), \
-                       (const SegDev*)(meta + o_seg), (uint32_t*)g->arena[g->cur].d_models, (NSum*)g->arena[g->cur].d_ns, (const uint64_t*)(meta + o_ns), \
-                       d_streams, d_stream_len, d_status, g->d_bins, nseg)
-        if (dec_group == 4) {
-            if (waves >= 8) { g->last_kernel = "lep_decode_v5_kernel<4, 8>"; LEP_LAUNCH_DEC5(4, 8); }
-            else { g->last_kernel = "lep_decode_v5_kernel<4, 4>"; LEP_LAUNCH_DEC5(4, 4); }
-        } else if (dec_group == 1) {
-            if (waves >= 8) { g->last_kernel = "lep_decode_v5_kernel<1, 8>"; LEP_LAUNCH_DEC5(1, 8); }
-            else { g->last_kernel = "lep_decode_v5_kernel<1, 4>"; LEP_LAUNCH_DEC5(1, 4); }
-        } else
+        // (a launch that is to share the chip with the launch before or behind it -- lep_gpu_expect_company, the batch decompressor's
+        // chunks on two streams -- takes the 64-VGPR build whatever its size: four 128-VGPR wavefronts hold a SIMD's whole register file,
+        // and the other launch's wavefronts could not move into the wave slots they leave empty)
+        if (!waves) waves = (nseg > 4608 || (g->dec_company && nseg >= 64)) ? 8 : 4;
         if (waves >= 8) { g->last_kernel = "lep_decode_v4_kernel<8>"; LEP_LAUNCH_DEC4(8); }
         else { g->last_kernel = "lep_decode_v4_kernel<4>"; LEP_LAUNCH_DEC4(4); }
-#undef LEP_LAUNCH_DEC5
 #undef LEP_LAUNCH_DEC4
     } else {
 #define LEP_LAUNCH_ENC3(W)                                                                                                     \
@@ -1022,9 +930,6 @@ static void release_all_at_exit() {
 int lep_gpu_create(int device, lep_gpu** out) {
     lep_gpu* g = new lep_gpu;
     g->device = device;
-    if (const char* e = getenv("LEP_DEC5")) g->dec5 = atoi(e);
-    if (const char* e = getenv("LEP_DEC5_GROUP")) g->dec5_group = atoi(e) == 1 ? 1 : 4;
-    if (const char* e = getenv("LEP_DEC5_GROUP_MIN")) g->dec5_group_min = atoi(e);
     if (const char* e = getenv("LEP_DEC_WAVES")) g->dec_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : 0);
     if (const char* e = getenv("LEP_ENC_WAVES")) g->enc_waves = atoi(e) == 4 ? 4 : (atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 0));
     if (const char* e = getenv("LEP_ENC_PAIR_MAX")) g->enc_pair_max = atoi(e);
@@ -1289,33 +1194,6 @@ int lep_gpu_huffman_decode_device(lep_gpu* g, const lep_huffdec_image* images, i
     return 0;
 }
 
-int lep_gpu_huffman_decode_parallel_device(lep_gpu* g, const lep_huffdec_image* images, int nimg, int nsub, lep_huffdec_row* d_rows, void* hip_stream) {
-    if (!g || nsub < 2 || nsub > lephuff::kHuffParMaxSub) return LEP_ASSERTION_FAILURE;
-    if (nimg <= 0) return 0;
-    for (int i = 0; i < nimg; ++i) if (images[i].rsti) return LEP_ASSERTION_FAILURE;   // restart intervals: the single-wave kernel's
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
-    HIPCHK(g, hipSetDevice(g->device));
-    if (int rc = ensure(g, &g->d_huffdec, &g->huffdec_bytes, (size_t)nimg * sizeof(lep_huffdec_image))) return rc;
-    const size_t o_status = ((size_t)nimg * nsub * sizeof(lephuff::HuffParState) + 255) & ~(size_t)255, total = o_status + (size_t)nimg * sizeof(int);
-    if (int rc = ensure(g, &g->d_huffpar, &g->huffpar_bytes, total)) return rc;
-    HIPCHK(g, hipMemcpyAsync(g->d_huffdec, images, (size_t)nimg * sizeof(lep_huffdec_image), hipMemcpyHostToDevice, st));
-    HIPCHK(g, hipMemsetAsync(g->d_huffpar, 0, total, st));
-    HIPCHK(g, hipStreamSynchronize(st));   // the caller's array may go away
-    lephuff::HuffParState* ps = (lephuff::HuffParState*)g->d_huffpar;
-    int* status = (int*)((char*)g->d_huffpar + o_status);
-    const lephuff::HuffDecImage* di = (const lephuff::HuffDecImage*)g->d_huffdec;
-    HIPCHK(g, hipEventRecord(g->ev0, st));
-    hipLaunchKernelGGL(lep_huffman_par_sync_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, ps, nsub);
-    hipLaunchKernelGGL(lep_huffman_par_stitch_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, ps, nsub);
-    hipLaunchKernelGGL(lep_huffman_par_write_kernel, dim3(nimg * nsub), dim3(64), 0, st, di, (const lephuff::HuffParState*)ps, nsub, (lephuff::HuffDecRow*)d_rows, status);
-    hipLaunchKernelGGL(lep_huffman_par_finish_kernel, dim3((nimg + 255) / 256), dim3(256), 0, st, di, nimg, (lephuff::HuffDecRow*)d_rows, (const int*)status);
-    HIPCHK(g, hipGetLastError());
-    HIPCHK(g, hipEventRecord(g->ev1, st));
-    g->timed = true;
-    g->last_kernel = "lep_huffman_par_{sync,stitch,write}_kernel";
-    return 0;
-}
-
 int lep_gpu_huffman_decode_simt_device(lep_gpu* g, const lep_huffdec_image* images, int nimg, lep_huffdec_row* d_rows, void* hip_stream) {
     if (!g) return LEP_GPU_ERROR;
     if (nimg <= 0) return 0;
@@ -1375,9 +1253,30 @@ int lep_gpu_huffman_decode_simt_device(lep_gpu* g, const lep_huffdec_image* imag
     return 0;
 }
 
+int lep_gpu_expect_company(lep_gpu* g, int on) {
+    if (!g) return LEP_GPU_ERROR;
+    g->dec_company = on ? 1 : 0;
+    return 0;
+}
+
 int lep_gpu_use_arena(lep_gpu* g, int k) {
     if (!g || k < 0 || k > 1) return LEP_ASSERTION_FAILURE;
     g->cur = k;
+    return 0;
+}
+
+// Called by a caller that is about to destroy HIP streams it passed to launch functions of this object (the batch pipelines' per-call
+// streams): the upload ring's events were recorded on those streams, and an event whose stream is gone must not be waited on again --
+// hipEventSynchronize then answers from freed memory (seen on the MI355X as "operation not permitted on an event last recorded in a
+// capturing stream" from a call that never captures anything, one run in a few).  Waits for every slot's copy and forgets the events.
+int lep_gpu_settle_uploads(lep_gpu* g) {
+    if (!g) return LEP_GPU_ERROR;
+    for (lep_gpu::Staging& sl : g->staging) {
+        if (sl.used && sl.ev) (void)hipEventSynchronize(sl.ev);
+        sl.used = false;
+        if (sl.ev) { (void)hipEventDestroy(sl.ev); sl.ev = nullptr; }
+    }
+    (void)hipGetLastError();
     return 0;
 }
 

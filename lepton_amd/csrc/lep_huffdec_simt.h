@@ -1,11 +1,11 @@
 // lep_huffdec_simt.h -- JPEG Huffman scan decode with one LANE per subsequence (round 4).
 //
-// lep_huffdec.h decodes a scan as uniform code of one wavefront, lep_huffdec_par.h cuts it into <= 64 subsequences of one
-// wavefront each: either way 63 of 64 lanes idle through the serial part, a code takes ~750 wave cycles, and the scan decode of a
+// lep_huffdec.h decodes a scan as uniform code of one wavefront (rounds 2-4 also cut it into <= 64 subsequences of one
+// wavefront each, lep_huffdec_par.h, since removed): either way 63 of 64 lanes idle through the serial part, a code takes ~750 wave cycles, and the scan decode of a
 // pipeline chunk (896 4K files, 0.29 s) was what the batch compressor had left besides the coder kernels.  Here the unit of
 // parallelism is the lane: a scan is cut into subsequences of `sub_bits` bits (a few thousand per 4K file), lane l of a
 // wavefront decodes subsequence first_sub + l of its image with a bit reader of its own, and the tables sit in LDS where 64
-// lanes look up 64 different codes with one instruction.  What makes that possible is the same property lep_huffdec_par.h rests
+// lanes look up 64 different codes with one instruction.  What makes that possible is the property the wavefront-per-subsequence form rested
 // on -- Huffman-coded JPEG data self-synchronises (Klein & Wiseman 2003; Weissenberger & Schmidt 2018 for the GPU form):
 //
 //   A  guess   lane i decodes subsequence i from its first bit as if a block started there (speculative: nothing stored, an
@@ -130,7 +130,7 @@ struct SimtLane {
     }
     static WDEV int extend(uint32_t s, uint32_t n) { return s == 0 ? (int)n : (n >= (1u << (s - 1)) ? (int)n : (int)n + 1 - (1 << s)); }
 
-    // one block, nothing stored: lep_huffdec_par.h skip_block in its speculative form
+    // one block, nothing stored (speculative form)
     WDEV void skip_block(int dct, int act, int* diff) {
         uint32_t n = 0;
         int hc = symbol_and_bits(dct, true, &n);

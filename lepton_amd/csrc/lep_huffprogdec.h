@@ -39,7 +39,7 @@ struct ProgDecScan {
 // Pipelining between the scans of one image (one launch for all dependency levels).  A 4K file of libjpeg's default script is
 // ten scans in three levels, and the longest scan of every level is a luma scan (bytes: 276 k first stage, 348 k and 654 k
 // refinement): level by level a file waits for their SUM.  Refinement scans cannot be cut into subsequences the way sequential
-// scans are (lep_huffdec_par.h) -- what a code means depends on which coefficients of ITS block are already non-zero, and a
+// scans are (lep_huffdec_simt.h) -- what a code means depends on which coefficients of ITS block are already non-zero, and a
 // wavefront started in the middle does not know its block -- but a scan only needs the scans it follows to be AHEAD of it, not
 // finished.  So every scan publishes the number of MCU rows it has completed (a release store after the rows' coefficients),
 // and a scan that follows others waits, MCU row by MCU row, until all of them have passed the row it is about to enter: the

@@ -126,53 +126,3 @@ WDEV uint32_t wave_read(const uint32_t* v, int src) {
 WDEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 
 }  // namespace lepwave
-
-// ---- 16-lane rows ("quarters") --------------------------------------------------------------------------------------------
-// The wavefront as four independent rows of 16 lanes (DPP rows): inclusive scans inside every row, a lane's value handed n lanes
-// up inside its row.  Used where one instruction stream serves four thread segments at once (lep_dec5.h).
-namespace lepwave {
-WDEV void row_incl_sum(const int* in, int* out) {
-#if LEP_ON_GPU
-    int v = in[0];
-    v += dpp_or<0x111, 0xf>(0, v);
-    v += dpp_or<0x112, 0xf>(0, v);
-    v += dpp_or<0x114, 0xf>(0, v);
-    v += dpp_or<0x118, 0xf>(0, v);
-    out[0] = v;
-#else
-    for (int r = 0; r < 64; r += 16) { int s = 0; for (int i = 0; i < 16; ++i) { s += in[r + i]; out[r + i] = s; } }
-#endif
-}
-WDEV void row_incl_max(const int* in, int* out) {
-#if LEP_ON_GPU
-    const int lo = (int)0x80000000;
-    int v = in[0], t;
-    t = dpp_or<0x111, 0xf>(lo, v); v = t > v ? t : v;
-    t = dpp_or<0x112, 0xf>(lo, v); v = t > v ? t : v;
-    t = dpp_or<0x114, 0xf>(lo, v); v = t > v ? t : v;
-    t = dpp_or<0x118, 0xf>(lo, v); v = t > v ? t : v;
-    out[0] = v;
-#else
-    for (int r = 0; r < 64; r += 16) { int m = (int)0x80000000; for (int i = 0; i < 16; ++i) { m = in[r + i] > m ? in[r + i] : m; out[r + i] = m; } }
-#endif
-}
-// out[l] = in[l - 8] inside the lane's row of 16, 0 for the lower half of the row
-WDEV void row_shr8(const int* in, int* out) {
-#if LEP_ON_GPU
-    out[0] = dpp_or<0x118, 0xf>(0, in[0]);
-#else
-    int tmp[64];
-    for (int l = 0; l < 64; ++l) tmp[l] = (l & 15) >= 8 ? in[l - 8] : 0;
-    for (int l = 0; l < 64; ++l) out[l] = tmp[l];
-#endif
-}
-// number of set bits of `mask` below the lane
-WDEV int rank_below(uint64_t mask, int lane) {
-#if LEP_ON_GPU
-    (void)lane;
-    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-#else
-    return __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-#endif
-}
-}  // namespace lepwave

@@ -1,9 +1,17 @@
 #!/bin/bash
-# experiment build of the library: scripts/build_variant.sh <name> [-D...]   -> lepton_amd/liblepton_<name>.so (git-ignored; travels to the GPU box)
+# experiment build of the library: scripts/build_variant.sh <name> [-D... | -mllvm ...]   -> lepton_amd/liblepton_<name>.so (git-ignored; travels to
+# the GPU box).  Only the two HIP sources are compiled with the extra flags; the host objects are the product build's (run build() first).
 set -e
 name=$1; shift
 cd "$(dirname "$0")/.."
-C=lepton_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o lepton_amd/liblepton_$name.so $C/lep_gpu.hip $C/lep_batch.hip $C/lep_api.cc $C/jpeg_scan.cc \
-  $C/jpeg_progressive.cc $C/lep_container.cc $C/jpeg_recode.cc $C/lep_serve.cc -lz -ldl -lpthread
+C=lepton_amd/csrc; O=lepton_amd/build/obj; V=lepton_amd/build/variant_$name
+mkdir -p $V
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip "$@" -c $C/lep_gpu.hip -o $V/lep_gpu.o &
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip "$@" -c $C/lep_batch.hip -o $V/lep_batch.o &
+wait
+third=""
+grep -q LEP_HAVE_BROTLI_ENC $O/lep_container.cc.o.flags 2>/dev/null && third="$third $O/brotli/*.o"
+if grep -q LEP_PINNED_ZLIB $O/lep_container.cc.o.flags 2>/dev/null; then third="$third $O/zlib/*.o"; else third="$third -lz"; fi
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o lepton_amd/liblepton_$name.so $V/lep_gpu.o $V/lep_batch.o $O/lep_api.cc.o $O/jpeg_scan.cc.o \
+  $O/jpeg_progressive.cc.o $O/lep_container.cc.o $O/jpeg_recode.cc.o $O/lep_serve.cc.o $third -ldl -lpthread
 echo built lepton_amd/liblepton_$name.so

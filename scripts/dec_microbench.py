@@ -3,7 +3,7 @@
 GPU encoder, decoded under `rocprofv3 --pmc SQ_INSTS_*` -- one decode launch per workload, in the order printed.  The counters of
 launch k divided by the blocks give instructions per block for workload k; differences between workloads give the cost of a block's
 fixed part, of a zero / non-zero interior coefficient, of an edge coefficient, of a 7x7 window round ...
-usage: [LEP_DEC5=..] rocprofv3 --pmc ... -- python scripts/dec_microbench.py [--images 32]"""
+usage: rocprofv3 --pmc ... -- python scripts/dec_microbench.py [--images 32]"""
 import argparse
 import ctypes as C
 import json

@@ -3,7 +3,7 @@
 #
 #   scripts/gpu_ab.sh <tag> [-k "<pytest -k expression>"] [-b resident|batch4k|batch1080p|progressive|latency] [-e "<extra args of the bench>"] -- "<variant>" ...
 #
-# A variant is a string of environment assignments ("" = the product as built): knobs of the library (LEP_DEC5=1,
+# A variant is a string of environment assignments ("" = the product as built): knobs of the library (LEP_DEC_WAVES=4,
 # LEP_ENC5_WCHUNKS=0, LEP_VMM_CHUNK_MB=64, LEP_BATCH_CHUNK_SEGMENTS=7168, GPU_MAX_HW_QUEUES=4, ...) or an experiment build of it
 # (LEP_LIB_PATH=$PWD/lepton_amd/liblepton_<name>.so from scripts/build_variant.sh <name> -D...).  Results: gpurun_out/<tag>/.
 # Round 4's A/B runs in profiles/r05* were taken this way (the decoder forms, the stitched writer, the workspace chunk size, the

@@ -4,15 +4,15 @@ set -u
 TAG=${1:-r5f}; export TMPDIR=/tmp
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 t0=$(date +%s)
-for V in ${VARIANTS:-v4 v5g1 v5g4}; do
-  case $V in v5g4) ENVV="LEP_DEC5=1 LEP_DEC5_GROUP_MIN=1";; v5g1) ENVV="LEP_DEC5=1 LEP_DEC5_GROUP=1";; v4) ENVV="LEP_DEC5=0";; esac
+for V in ${VARIANTS:-v4}; do
+  case $V in v4) ENVV="LEP_DEC_WAVES=8";; *) ENVV="LEP_LIB_PATH=$PWD/lepton_amd/liblepton_$V.so";; esac   # v4 = the product; any other name = an experiment build (scripts/build_variant.sh)
   env $ENVV timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $OUT/pmc_$V -o pmc --output-format csv -- python scripts/dec_microbench.py --images ${IMAGES:-32} > $OUT/micro_$V.json 2> $OUT/micro_$V.err
   echo "$V rc=$? $(( $(date +%s)-t0 )) s"
 done
 python - <<PY
 import csv, glob, collections, json
 res = {}
-for V in "${VARIANTS:-v4 v5g1 v5g4}".split():
+for V in "${VARIANTS:-v4}".split():
     try: meta = json.load(open("$OUT/micro_%s.json" % V))
     except Exception as e: print(V, "no output", e); continue
     rows = collections.defaultdict(dict)

@@ -11,7 +11,7 @@ pass() {  # name, counters... (env in ENVV)
   env $ENVV timeout 300 rocprofv3 --pmc "$@" --kernel-trace -d $OUT/pmc_$name -o pmc --output-format csv -- $B > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err; echo "$name rc=$? $(( $(date +%s)-t0 )) s"
 }
 for V in ${VARIANTS:-v5g4 v5g1 v4}; do
-  case $V in v5g4) ENVV="LEP_DEC5=1";; v5g1) ENVV="LEP_DEC5=1 LEP_DEC5_GROUP=1";; v4) ENVV="LEP_DEC5=0";; esac
+  case $V in v4) ENVV="LEP_DEC_WAVES=8";; *) ENVV="LEP_LIB_PATH=$PWD/lepton_amd/liblepton_$V.so";; esac   # v4 = the product; any other name = an experiment build (scripts/build_variant.sh)
   pass ${V}_in SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES
   pass ${V}_sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS
   pass ${V}_ic SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_IFETCH SQC_DCACHE_REQ SQC_DCACHE_MISSES

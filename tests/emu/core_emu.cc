@@ -94,56 +94,6 @@ extern "C" int emu_decode_segment_v4(const lep_image_desc* d, int y0, int y1, in
     return rc;
 }
 
-// v5 decoder (lep_dec5.h): a workgroup of NW wavefronts decodes NW segments; the lane-parallel phases serve all of them at once.
-// The emulation runs the wavefronts of a phase one after the other between the workgroup barriers.
-#include "../../lepton_amd/csrc/lep_dec5.h"
-template <int NW>
-static int run_group_v5(const lep_image_desc* d, int nseg, const int* y0, const int* y1, const int* is_last, const uint8_t* const* in, const uint32_t* len,
-                        uint32_t* bins, int* rcs) {
-    ImageDev img;
-    int rc = derive_image(*d, &img, false);
-    if (rc) return rc;
-    std::vector<uint32_t> arena((size_t)NW * lep5d::kModelWords5, kBranchInit);   // the segments' models are neighbours, as in a launch
-    struct View { uint32_t* p; void assign(size_t, uint32_t) {} uint32_t& operator[](size_t i) { return p[i]; } uint32_t* data() { return p; } };
-    std::vector<View> models(NW);
-    for (int w = 0; w < NW; ++w) models[w].p = arena.data() + (size_t)w * lep5d::kModelWords5;
-
-    std::vector<std::vector<NSum>> nss(NW);
-    std::vector<PaddedStream> ps;
-    ps.reserve(NW);
-    static lep5d::Dec5Shared<NW> sh;
-    static lep5d::Dec5Group<NW> g;
-    for (int w = 0; w < NW; ++w) {
-        lep5d::Wave5& W = g.wv[w];
-        W.img = nullptr;
-        if (w >= nseg) continue;
-        models[w].assign(lep5d::kModelWords5, kBranchInit);
-        for (uint32_t i = 0; i < lep5d::kGroups; ++i) { models[w][i * 3] = lep5d::kRecInitF; models[w][i * 3 + 1] = lep5d::kRecInitT; models[w][i * 3 + 2] = lep5d::kRecInitP; }
-        nss[w].resize(img.ns_total);
-        memset(nss[w].data(), 0, nss[w].size() * sizeof(NSum));
-        ps.emplace_back(in[w], len[w]);
-        W.img = &img;
-        W.seg.image = 0; W.seg.y0 = y0[w]; W.seg.y1 = y1[w]; W.seg.is_last = is_last[w]; W.seg.stream_off = 0; W.seg.stream_cap = 0; W.seg.slot = (uint32_t)w;
-        W.model = models[w].data(); W.ns = nss[w].data();
-        W.stream = ps.back().p; W.stream_len = len[w];
-    }
-    g.model0 = arena.data(); g.model_stride = lep5d::kModelWords5;
-    g.run(&sh);
-    for (int w = 0; w < nseg; ++w) { if (bins) bins[w] = g.wv[w].nbins; if (rcs) rcs[w] = g.wv[w].rc; }
-    return 0;
-}
-extern "C" int emu_decode_segment_v5(const lep_image_desc* d, int y0, int y1, int is_last, const uint8_t* in, uint32_t len, uint32_t* bins) {
-    int rc = 0;
-    uint32_t nb = 0;
-    const int r = run_group_v5<1>(d, 1, &y0, &y1, &is_last, &in, &len, &nb, &rc);
-    if (bins) *bins = nb;
-    return r ? r : rc;
-}
-// up to four segments of one image as one workgroup; rcs[i] = exit code of segment i
-extern "C" int emu_decode_group_v5(const lep_image_desc* d, int nseg, const int* y0, const int* y1, const int* is_last, const uint8_t* const* in, const uint32_t* len,
-                                   uint32_t* bins, int* rcs) {
-    return run_group_v5<4>(d, nseg, y0, y1, is_last, in, len, bins, rcs);
-}
 
 // exhaustive check of the 24-bit table reciprocal used by lep4::bupd_t / bupd_u against Branch::record_obs_and_update
 extern "C" int emu_check_inv24_update() {
@@ -293,24 +243,6 @@ extern "C" int emu_huffman_progressive_decode_pipelined(const lep_huffprogdec_sc
     return 0;
 }
 
-// several wavefronts per image (lep_huffdec_par.h): the three passes run one wave after the other
-#include "../../lepton_amd/csrc/lep_huffdec_par.h"
-extern "C" int emu_huffman_decode_image_parallel(const lep_huffdec_image* img, lep_huffdec_row* rows, int nsub, uint32_t* sync_blocks) {
-    static lephuff::HuffParShared sh;
-    if (nsub < 1 || nsub > lephuff::kHuffParMaxSub) return -1;
-    lephuff::HuffDecImage im;
-    memcpy(&im, img, sizeof im);
-    im.rows_off = 0;
-    std::vector<lephuff::HuffParState> st((size_t)nsub);
-    memset(st.data(), 0, st.size() * sizeof(lephuff::HuffParState));
-    for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; w.run_sync(&im, &sh, st.data(), s, nsub); }
-    for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; w.run_stitch(&im, &sh, st.data(), s, nsub); }
-    int status = 0;
-    for (int s = 0; s < nsub; ++s) { lephuff::HuffParWave w; status |= w.run_write(&im, &sh, st.data(), reinterpret_cast<lephuff::HuffDecRow*>(rows), s, nsub); }
-    rows[im.mcuv].aux = (rows[im.mcuv].aux & 255) | (status << 8);
-    if (sync_blocks) for (int s = 0; s < nsub; ++s) sync_blocks[s] = st[(size_t)s].nblocks;
-    return 0;
-}
 
 
 // one lane per subsequence (lep_huffdec_simt.h): guess, settle passes, place, write -- every pass one wavefront after the other.

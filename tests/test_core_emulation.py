@@ -31,7 +31,7 @@ def emu_other_forms():
     src = os.path.join(ROOT, "tests", "emu", "core_emu.cc")
     so = os.path.join(ROOT, "tests", "emu", "libcore_emu_forms.so")
     tmp = "%s.%d" % (so, os.getpid())
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DLEP_DEC4_SCALAR=13", "-DLEP_DEC5_SCALAR=13", "-o", tmp, src])
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DLEP_DEC4_SCALAR=13", "-o", tmp, src])
     os.replace(tmp, so)
     return C.CDLL(so)
 
@@ -59,10 +59,10 @@ def test_kernel_source_on_cpu_matches_oracle(emu, name):
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
 
 
-@pytest.mark.parametrize("gen", ["v4", "v5"])
+@pytest.mark.parametrize("gen", ["v4"])
 @pytest.mark.parametrize("name", golden_cases())
 def test_v3_decoder_on_cpu_matches_oracle(emu, name, gen):
-    """lep_dec4.h / lep_dec5.h as 64-lane loop emulations: decoding the oracle's streams returns the coefficient frame and
+    """lep_dec4.h as 64-lane loop emulations: decoding the oracle's streams returns the coefficient frame and
     consumes exactly the oracle's number of bins"""
     jpg, _ = golden(name)
     img = JpegImage(jpg)
@@ -83,7 +83,7 @@ def test_v3_decoder_on_cpu_matches_oracle(emu, name, gen):
         assert C.string_at(d.blocks[c], n) == orig[c][:n]
 
 
-@pytest.mark.parametrize("gen", ["v4", "v5"])
+@pytest.mark.parametrize("gen", ["v4"])
 @pytest.mark.parametrize("shift", [1, 2, 3])
 def test_v3_decoder_unaligned_stream_start(emu, shift, gen):
     """the 64-bit window reads aligned dwords only: a stream that starts 1..3 bytes into a dword (streams packed back to
@@ -173,9 +173,9 @@ def test_v3_encoder_many_bins_per_block(emu, enc_mode):
     assert emu.emu_encode_segment_v3(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, buf, len(buf), C.byref(n), None) == 6
 
 
-@pytest.mark.parametrize("gen", ["v4", "v5"])
+@pytest.mark.parametrize("gen", ["v4"])
 def test_v4_decoder_large_coefficients(emu, gen):
-    """every rare path of lep_dec4.h / lep_dec5.h at once: exponent bins beyond the prefetched groups, residual bits >= 4, threshold
+    """every rare path of lep_dec4.h at once: exponent bins beyond the prefetched groups, residual bits >= 4, threshold
     bins, long interior runs (several windows, all non-zero bins)"""
     import numpy as np
     from lepton_amd import corpus
@@ -221,7 +221,7 @@ def test_v4_decoder_rounds_in_their_other_form(emu_other_forms):
         orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
         for c in range(d.ncomp):
             C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
-        for gen in ("v4", "v5"):
+        for gen in ("v4",):
             for c in range(d.ncomp):
                 C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
             total = 0
@@ -234,7 +234,6 @@ def test_v4_decoder_rounds_in_their_other_form(emu_other_forms):
                 n = d.coded_blocks[c] * 128
                 assert C.string_at(d.blocks[c], n) == orig[c][:n], name
     test_v4_decoder_large_coefficients(emu, "v4")
-    test_v4_decoder_large_coefficients(emu, "v5")
     test_decoders_survive_garbage_streams(emu, 9)
 
 
@@ -429,7 +428,7 @@ def test_decoders_survive_garbage_streams(emu, seed):
     d = img.desc
     segs = img.plan()
     rng = np.random.default_rng(seed)
-    for fn in ("emu_decode_segment_v5", "emu_decode_segment_v4", "emu_decode_segment"):
+    for fn in ("emu_decode_segment_v4", "emu_decode_segment"):
         for kind in range(3):
             n = int(rng.integers(0, 400))
             if kind == 0:
@@ -496,48 +495,6 @@ def _huffdec_setup(jpg):
     L.lep_jpeg_close(h)
     return img, scan, planes, d
 
-
-@pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "optimized_q30"])
-@pytest.mark.parametrize("nsub", [2, 5, 16])
-def test_parallel_huffman_decoder_equals_the_single_wave_one(emu, name, nsub):
-    """lep_huffdec_par.h (several wavefronts per image: speculative sync pass, stitching walk, write pass) must leave
-    exactly what lep_huffdec.h leaves -- frame, hand-off records, pad bit -- or report a non-zero status (fallback), never
-    a different result"""
-    import io
-    from lepton_amd import abi, corpus
-
-    if name == "synth_640x360":
-        jpg = corpus.synth_jpeg(640, 360, 71, quality=88)
-    elif name == "optimized_q30":
-        from PIL import Image
-        import numpy as np
-        rng = np.random.default_rng(31)
-        a = np.asarray(Image.fromarray(rng.integers(0, 256, (30, 40, 3), dtype=np.uint8), "RGB").resize((320, 240), Image.BICUBIC)).astype(np.int16)
-        a = np.clip(a + rng.normal(0, 12, a.shape), 0, 255).astype(np.uint8)
-        buf = io.BytesIO(); Image.fromarray(a, "RGB").save(buf, format="JPEG", quality=30, subsampling="4:2:2", optimize=True)
-        jpg = buf.getvalue()
-    else:
-        jpg, _ = golden(name)
-    one = _huffdec_setup(jpg)
-    if one is None:
-        pytest.skip("not eligible for the GPU Huffman decoder")
-    img1, scan1, planes1, d = one
-    rows1 = (abi.HuffDecRow * (img1.mcuv + 1))()
-    assert emu.emu_huffman_decode_image(C.byref(img1), rows1) == 0 and rows1[img1.mcuv].aux >> 8 == 0
-    img2, scan2, planes2, _ = _huffdec_setup(jpg)
-    rows2 = (abi.HuffDecRow * (img2.mcuv + 1))()
-    assert emu.emu_huffman_decode_image_parallel(C.byref(img2), rows2, nsub, None) == 0
-    status = rows2[img2.mcuv].aux >> 8
-    if img2.rsti:
-        pytest.skip("restart intervals: the single-wave kernel keeps these files")
-    if status:
-        # allowed only when a subsequence is too short to synchronise in (tiny fixtures cut into many pieces)
-        assert img2.scan_len * 8 // nsub < 4096, "parallel decode gave up on a scan with %d bits per subsequence" % (img2.scan_len * 8 // nsub)
-        return
-    for c in range(d.ncomp):
-        assert planes2[c].raw == planes1[c].raw
-    for r in range(img1.mcuv + 1):
-        assert (rows2[r].bitpos, list(rows2[r].last_dc), rows2[r].aux) == (rows1[r].bitpos, list(rows1[r].last_dc), rows1[r].aux), r
 
 
 def _jpeg_for_huffman_tests(name):
@@ -625,32 +582,6 @@ def test_lane_per_subsequence_huffman_decoder_survives_garbage(emu, seed):
         assert outs[0][1] == outs[1][1]
 
 
-@pytest.mark.parametrize("seed", [1, 2])
-def test_parallel_huffman_decoder_survives_garbage(emu, seed):
-    """random bytes instead of a scan: every pass terminates, nothing is written outside the frame, and the outcome is a
-    status or (if the garbage happens to decode) the same as the single-wave kernel's"""
-    import numpy as np
-    from lepton_amd import abi, corpus
-
-    jpg = corpus.synth_jpeg(96, 64, 78)
-    rng = np.random.default_rng(seed)
-    outs = []
-    for par in (0, 4):
-        img, scan, planes, d = _huffdec_setup(jpg)
-        n = img.scan_len
-        junk = C.create_string_buffer(bytes(np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)) + bytes(64), n + 72)
-        img.scan = C.addressof(junk)
-        rows = (abi.HuffDecRow * (img.mcuv + 1))()
-        if par:
-            assert emu.emu_huffman_decode_image_parallel(C.byref(img), rows, par, None) == 0
-        else:
-            assert emu.emu_huffman_decode_image(C.byref(img), rows) == 0
-        outs.append((rows[img.mcuv].aux >> 8, [p.raw for p in planes]))
-    if outs[0][0] == 0 and outs[1][0] == 0:
-        assert outs[0][1] == outs[1][1]
-    del rng
-
-
 def test_current_kernels_on_random_images_match_the_oracle(emu):
     """v3 encoder / v4 decoder kernel sources (lane-loop emulation) on seeded random JPEGs -- sizes from one block up, the
     chroma layouts PIL writes (4:4:4, 4:2:2, 4:2:0; the others are tests/test_sampling_layouts.py's), grey, qualities 5..100, flat to very noisy content,
@@ -696,11 +627,6 @@ def test_current_kernels_on_random_images_match_the_oracle(emu):
         for s, wv in zip(segs, want):
             assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
         got = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
-        for c in range(d.ncomp):
-            C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
-        for s, wv in zip(segs, want):
-            assert emu.emu_decode_segment_v5(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
-        assert got == [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)], trial
         for c in range(d.ncomp):
             C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
         ob.oracle_decode(d, segs, want)
@@ -1112,7 +1038,7 @@ def test_v4_decoder_on_a_first_segment_that_starts_inside_the_image(emu):
         for c in range(d.ncomp):
             C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
         s, wv = segs[0], f.streams[0]
-        for gen in ("v4", "v5"):
+        for gen in ("v4",):
             for c in range(d.ncomp):
                 C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
             assert getattr(emu, "emu_decode_segment_" + gen)(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
@@ -1129,7 +1055,7 @@ def edge_count_bias():
     knob.value = 0
 
 
-@pytest.mark.parametrize("gen", ["", "_v4", "_v5"])
+@pytest.mark.parametrize("gen", ["", "_v4"])
 @pytest.mark.parametrize("name", ["c420_odd_203x149", "gray_120x88", "c444_96x80", "truncated"])
 def test_decoders_follow_the_reference_on_impossible_edge_counts(emu, edge_count_bias, name, gen):
     """a stream that claims more edge non-zeros than positions remain.  The reference indexes
@@ -1166,7 +1092,7 @@ def test_v4_other_forms_on_impossible_edge_counts(emu_other_forms, edge_count_bi
     orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
     for c in range(d.ncomp):
         C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
-    for gen in ("v4", "v5"):
+    for gen in ("v4",):
         for c in range(d.ncomp):
             C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
         for s, w in zip(segs, want):
@@ -1386,72 +1312,3 @@ def test_progressive_scan_dependencies_on_made_up_scripts(emu):
     # the scan that comes first in the FILE stands behind the one that follows it in the LAUNCH: a wait that could never end
     ok, _ = run([(A, [0], 1, 63), (A, [0], 1, 63)], order=[1, 0])
     assert not ok
-
-
-def _decode_group_v5(emu, d, segs, streams):
-    """up to four segments as one workgroup of lep_dec5.h; returns the exit codes"""
-    rcs_all = []
-    for i in range(0, len(segs), 4):
-        grp, ws = segs[i:i + 4], streams[i:i + 4]
-        n = len(grp)
-        y0 = (C.c_int * 4)(*[s.luma_y_start for s in grp])
-        y1 = (C.c_int * 4)(*[s.luma_y_end for s in grp])
-        il = (C.c_int * 4)(*[s.is_last for s in grp])
-        bufs = [C.create_string_buffer(bytes(w), max(1, len(w))) for w in ws]
-        ptrs = (C.c_void_p * 4)(*[C.cast(b, C.c_void_p).value for b in bufs])
-        lens = (C.c_uint32 * 4)(*[len(w) for w in ws])
-        rcs, nbs = (C.c_int * 4)(), (C.c_uint32 * 4)()
-        assert emu.emu_decode_group_v5(C.byref(d), n, y0, y1, il, ptrs, lens, nbs, rcs) == 0
-        rcs_all += [rcs[k] for k in range(n)]
-    return rcs_all
-
-
-@pytest.mark.parametrize("name", golden_cases())
-def test_v5_decoder_workgroup_of_four_segments(emu, name):
-    """lep_dec5.h as a workgroup: four wavefronts = four segments, the lane-parallel phases (priors, Lakhani, IDCT + DC prediction,
-    update pass) serving all of them from 16-lane rows of one wavefront; the emulation runs the wavefronts of a phase one after
-    the other between the barriers.  Frames equal the oracle's; a file of fewer than four segments leaves wavefronts without one."""
-    jpg, _ = golden(name)
-    img = JpegImage(jpg)
-    d = img.desc
-    segs = img.plan()
-    want, _ = ob.oracle_encode(d, segs)
-    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
-    for c in range(d.ncomp):
-        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
-    assert not any(_decode_group_v5(emu, d, segs, want))
-    for c in range(d.ncomp):
-        n = d.coded_blocks[c] * 128
-        assert C.string_at(d.blocks[c], n) == orig[c][:n]
-
-
-def test_v5_decoder_workgroup_with_unequal_and_damaged_segments(emu):
-    """eight segments of a photograph-like image (several-fold different block counts) in two workgroups, then the same with one
-    segment's stream replaced by garbage: the damaged segment ends with an exit code (or decodes garbage), its neighbours in the
-    workgroup still return the oracle's frame rows, and the workgroup's barriers are reached by every wavefront."""
-    import numpy as np
-    from lepton_amd import corpus
-
-    img = JpegImage(corpus.synth_jpeg(1920, 1080, 31, skew=2.0))
-    d = img.desc
-    segs = img.plan()
-    assert len(segs) >= 4
-    want, _ = ob.oracle_encode(d, segs)
-    orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
-    for c in range(d.ncomp):
-        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
-    assert not any(_decode_group_v5(emu, d, segs, want))
-    assert [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == orig
-    rng = np.random.default_rng(3)
-    bad = list(want)
-    bad[1] = bytes(rng.integers(0, 256, 300, dtype=np.uint8))
-    for c in range(d.ncomp):
-        C.memset(d.blocks[c], 0, d.nblocks(c) * 128)
-    rcs = _decode_group_v5(emu, d, segs, bad)
-    assert all(rc == 0 for i, rc in enumerate(rcs) if i != 1) and rcs[1] in (0, 6, 7, 43)
-    w = d.width_blocks[0]
-    for i, s in enumerate(segs):
-        if i == 1:
-            continue
-        a, b = s.luma_y_start * w * 128, (s.luma_y_end if not s.is_last else d.height_blocks[0]) * w * 128
-        assert C.string_at(d.blocks[0], d.nblocks(0) * 128)[a:b] == orig[0][a:b], i
