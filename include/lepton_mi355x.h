@@ -34,7 +34,10 @@ enum {
     LEP_OOM = 37,                      /* a .lep whose header claims sizes beyond the reference's 576 MiB arena (its allocator's exit code) */
     LEP_TOO_MUCH_MEMORY_NEEDED = 38,   /* coefficient frame beyond the reference's default budget of 4,423,680 blocks (566 MB) */
     LEP_ROUNDTRIP_FAILURE = 41, LEP_UNSUPPORTED_JPEG = 42, LEP_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 43,
-    LEP_BUFFER_TOO_SMALL = 100, LEP_GPU_ERROR = 120
+    LEP_BUFFER_TOO_SMALL = 100,
+    LEP_GPU_PATH_DECLINED = 101,       /* lep_file_recode_finish: the scan encoder stopped at the cut of a truncated file before the byte bound was
+                                          reached (or does not take the file): call lep_file_recode, the host re-coder, instead */
+    LEP_GPU_ERROR = 120
 };
 
 #define LEP_MAX_COMPONENTS 3   /* default reference build: ColorChannel::NumBlockTypes == 3 */
@@ -126,6 +129,7 @@ typedef struct lep_huff_image {
     int32_t hs[4], vs[4], bch[4];
     int32_t dc_tbl[4], ac_tbl[4];
     int32_t scan_cmp[4];
+    int32_t trunc_bc[4];                 /* a file cut inside its scan (EEE section): blocks of each component in front of the cut; 0 = whole */
     const int16_t *blocks[4];
     uint32_t code[4][256];               /* [0..1] DC, [2..3] AC tables: code length << 16 | code */
 } lep_huff_image;
@@ -182,10 +186,14 @@ int lep_gpu_huffman_progressive_encode_device(lep_gpu *g, const lep_huffprog_ima
  * 4893-4966, for whole single-scan interleaved sequential files): one wavefront per image decodes the un-stuffed scan into
  * the zero-filled device frame images[i].blocks and writes images[i].mcuv + 1 records (bit position + last DC per MCU row,
  * final record: pad-bit pattern and status) at d_rows + images[i].rows_off.  lep_jpeg_open_gpu fills the struct. */
+#define LEP_HUFFDEC_EARLY_EOF 1          /* lep_huffdec_image.flags */
+#define LEP_HUFFDEC_ROW_TRUNCATED 0x40000000   /* final lep_huffdec_row.aux: the scan stopped in mid-image; .bitpos = blocks decoded (scan order) */
 typedef struct lep_huffdec_image {
     const uint8_t *scan;                 /* device: un-stuffed scan bytes, 16-byte aligned, followed by >= 32 zero bytes */
     uint32_t scan_len;
     int32_t ncomp, mcuh, mcuv, mcuc, rsti;
+    int32_t flags;                       /* LEP_HUFFDEC_EARLY_EOF: the file ends inside its scan (no EOI): the scan may stop in mid-image */
+    int32_t reserved0;
     int32_t hs[4], vs[4], bch[4], dc_tbl[4], ac_tbl[4], scan_cmp[4];
     int16_t *blocks[4];                  /* device: zero-filled coefficient frame */
     uint64_t rows_off;

@@ -53,7 +53,7 @@ class Bytes(C.Structure):
 class HuffImage(C.Structure):
     _fields_ = [("ncomp", C.c_int32), ("mcuh", C.c_int32), ("mcuv", C.c_int32), ("mcuc", C.c_int32), ("rsti", C.c_int32), ("padbit", C.c_int32),
                 ("rst_limit", C.c_uint32), ("interleaved", C.c_int32), ("hs", C.c_int32 * 4), ("vs", C.c_int32 * 4), ("bch", C.c_int32 * 4),
-                ("dc_tbl", C.c_int32 * 4), ("ac_tbl", C.c_int32 * 4), ("scan_cmp", C.c_int32 * 4), ("blocks", C.c_void_p * 4),
+                ("dc_tbl", C.c_int32 * 4), ("ac_tbl", C.c_int32 * 4), ("scan_cmp", C.c_int32 * 4), ("trunc_bc", C.c_int32 * 4), ("blocks", C.c_void_p * 4),
                 ("code", (C.c_uint32 * 256) * 4)]
 
 
@@ -80,7 +80,7 @@ class HuffProgScan(C.Structure):
 
 class HuffDecImage(C.Structure):
     _fields_ = [("scan", C.c_void_p), ("scan_len", C.c_uint32), ("ncomp", C.c_int32), ("mcuh", C.c_int32), ("mcuv", C.c_int32), ("mcuc", C.c_int32),
-                ("rsti", C.c_int32), ("hs", C.c_int32 * 4), ("vs", C.c_int32 * 4), ("bch", C.c_int32 * 4), ("dc_tbl", C.c_int32 * 4),
+                ("rsti", C.c_int32), ("flags", C.c_int32), ("reserved0", C.c_int32), ("hs", C.c_int32 * 4), ("vs", C.c_int32 * 4), ("bch", C.c_int32 * 4), ("dc_tbl", C.c_int32 * 4),
                 ("ac_tbl", C.c_int32 * 4), ("scan_cmp", C.c_int32 * 4), ("blocks", C.c_void_p * 4), ("rows_off", C.c_uint64),
                 ("lut", (C.c_uint16 * 512) * 4), ("maxcode", (C.c_int32 * 8) * 4), ("valoff", (C.c_int32 * 8) * 4), ("longsym", (C.c_uint8 * 256) * 4)]
 

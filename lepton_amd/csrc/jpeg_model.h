@@ -20,6 +20,7 @@ enum ExitCode : int {
     EX_OS_ERROR = 33, EX_HEADER_TOO_LARGE = 34, EX_BLOCK_OFFSET_OOM = 37,
     EX_TOO_MUCH_MEMORY_NEEDED = 38, EX_ROUNDTRIP_FAILURE = 41, EX_UNSUPPORTED_JPEG = 42, EX_UNSUPPORTED_JPEG_WITH_ZERO_IDCT_0 = 43,
     EX_INVALID_RESET_MARKER_FOUND = 40, EX_UNSUPPORTED_4_COLORS_B = 4,
+    EX_GPU_PATH_DECLINED = 101,   // ours: a GPU scan coder left a file to the host coder (recode_finish on a truncated file): not an error of the file
     EX_GPU_ERROR = 120,   // ours: HIP runtime failure (no reference equivalent)
 };
 
@@ -140,10 +141,13 @@ int parse_jpeg(const uint8_t* data, size_t size, bool allow_progressive, JpegFil
 
 // GPU Huffman scan decode (lep_huffdec.h): host-side halves.  ScanDecodePlan / ScanDecodeRow are laid out exactly like
 // lephuff::HuffDecImage / HuffDecRow and the C ABI's lep_huffdec_image / lep_huffdec_row.
+constexpr int32_t kScanEarlyEof = 1;               // ScanDecodePlan::flags (== LEP_HUFFDEC_EARLY_EOF)
+constexpr int32_t kScanRowTruncated = 0x40000000;  // final ScanDecodeRow::aux (== LEP_HUFFDEC_ROW_TRUNCATED)
 struct ScanDecodePlan {
     const uint8_t* scan;
     uint32_t scan_len;
     int32_t ncomp, mcuh, mcuv, mcuc, rsti;
+    int32_t flags, reserved0;              /* flags: kScanEarlyEof */
     int32_t hs[4], vs[4], bch[4], dc_tbl[4], ac_tbl[4], scan_cmp[4];
     int16_t* blocks[4];
     uint64_t rows_off;

@@ -166,8 +166,14 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
     // components or a plain single-component scan.  Everything else takes the host path (recode_jpeg).
     plan->gpu_ok = false;
     plan->segs.clear();
-    bool ok = !jf.early_eof && jf.ncomp >= 1 && jf.ncomp <= 3 && jf.cs_cmpc == jf.ncomp && jf.mcuh > 0 && jf.mcuv > 0 &&
-              jf.trunc_bcv[0] >= jf.comp[0].bcv && !lf->segs.empty();
+    // A file that was cut inside its scan (early_eof): its blocks behind the cut are ones the reference's decoder never wrote, and what its
+    // re-coder reads there (RowCoder::mcu_row above) only shows in damaged files -- in a file the reference compressed, the byte bound of
+    // the last thread cuts the output in front of them.  The lane-per-unit scan encoder (lep_huff_simt.h) stops at the first such block
+    // and says so; the caller takes its bytes when the bound was reached by then and the host re-coder otherwise.  Only that kernel knows
+    // the cut: interleaved scans of two or three components without restart intervals.
+    const bool cut = jf.early_eof;
+    bool ok = jf.ncomp >= 1 && jf.ncomp <= 3 && jf.cs_cmpc == jf.ncomp && jf.mcuh > 0 && jf.mcuv > 0 &&
+              (cut ? (jf.ncomp >= 2 && jf.rsti == 0) : jf.trunc_bcv[0] >= jf.comp[0].bcv) && !lf->segs.empty();
     for (const Handoff& th : lf->segs) if (th.num_overhang_bits == 0xff || th.num_overhang_bits > 7) ok = false;
     for (size_t q = 1; q < lf->segs.size(); ++q) if (lf->version > 1 && !lf->segs[q].segment_size) ok = false;   // a worker bound of nothing: host path
     if ((size_t)std::min(lf->nthreads, 8) != lf->segs.size()) ok = false;   // several logical threads folded onto one worker (a damaged thread hint): cumulative bounds, host path
@@ -187,6 +193,7 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
     im.ncomp = jf.ncomp; im.mcuh = jf.mcuh; im.mcuv = jf.mcuv; im.mcuc = jf.mcuc; im.rsti = jf.rsti; im.padbit = jf.padbit;
     im.rst_limit = (jf.rst_cnt.empty() || !lf->rst_cnt_set) ? 0xffffffffu : jf.rst_cnt[0];
     im.interleaved = jf.ncomp > 1 ? 1 : 0;
+    for (int c = 0; c < 4; ++c) im.trunc_bc[c] = (cut && c < jf.ncomp) ? std::max(1, jf.trunc_bc[c]) : 0;
     for (int c = 0; c < jf.ncomp; ++c) {
         im.hs[c] = jf.comp[c].hs; im.vs[c] = jf.comp[c].vs; im.bch[c] = jf.comp[c].bch;
         im.dc_tbl[c] = jf.comp[c].dc_tbl; im.ac_tbl[c] = jf.comp[c].ac_tbl;
@@ -252,6 +259,14 @@ int recode_finish(LepFile* lf, const RecodePlan& plan, const std::vector<std::pa
     // the host path).  `ends` is what lep_huffman_encode_kernel hands back (one logical thread per physical thread here:
     // recode_prepare sends everything else to the host re-coder).  The byte count -- a segment that restores its part of the
     // file exactly writes exactly segment_size bytes -- stays as the check for callers without end states.
+    // a truncated file's segments (recode_prepare): what the scan encoder said about the cut.  Bytes that stop at the cut are the file's
+    // only if the thread's byte bound was reached by then (then nothing behind the cut can show) and only in the last thread; anything
+    // else is the host re-coder's, which knows what the reference reads behind a cut: EX_GPU_PATH_DECLINED tells the caller so
+    if (ends)
+        for (size_t q = 0; q < seg_bytes.size() && q < plan.segs.size(); ++q) {
+            if (ends[q].pad & 2) return EX_GPU_PATH_DECLINED;
+            if ((ends[q].pad & 1) && (q + 1 != seg_bytes.size() || ends[q].attempted < plan.segs[q].out_cap)) return EX_GPU_PATH_DECLINED;
+        }
     if (seg_bytes.size() == lf->segs.size())
         for (size_t q = 0; q + 1 < seg_bytes.size(); ++q) {
             const Handoff& nx = lf->segs[q + 1];

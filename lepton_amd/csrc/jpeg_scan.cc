@@ -449,6 +449,18 @@ int next_mcuposn(const JpegFile& jf, int cmp, int* dpos, int* rstw) {
 static int min_vertical_multiple(const JpegFile& jf, int c) {   // uncompressed_components.cc:26-35
     return jf.comp[c].bcv / jf.mcuv;
 }
+// a file that ended inside its scan: how much of every component was decoded (uncompressed_components.hh:166-185), from max_dpos
+static void note_truncation(JpegFile* jf) {
+    for (int c = 0; c < jf->ncomp; ++c) {
+        const Component& k = jf->comp[c];
+        int tbc = jf->max_dpos[c] + 1;
+        int lines = std::min(tbc / k.bch + (tbc % k.bch ? 1 : 0), k.bcv);
+        int ratio = std::max(min_vertical_multiple(*jf, c), 1);
+        while (lines % ratio != 0 && lines + 1 <= k.bcv) ++lines;
+        jf->trunc_bcv[c] = lines;
+        jf->trunc_bc[c] = tbc;
+    }
+}
 
 int decode_progressive_scan(JpegFile* jf, BitReader& br, int* lastdc, int* sta_io, int* cmp_io, int* dpos_io,
                             int* mcu_io, int* csc_io, int* sub_io, int* rstw_io, unsigned* eobrun_io, int* peobrun_io,
@@ -557,17 +569,7 @@ static int decode_scans(JpegFile* jf, bool allow_progressive) {
             if (sta == 2) { ++jf->scan_count; break; }
         }
     }
-    if (jf->early_eof) {   // uncompressed_components.hh:166-185
-        for (int c = 0; c < jf->ncomp; ++c) {
-            const Component& k = jf->comp[c];
-            int tbc = jf->max_dpos[c] + 1;
-            int lines = std::min(tbc / k.bch + (tbc % k.bch ? 1 : 0), k.bcv);
-            int ratio = std::max(min_vertical_multiple(*jf, c), 1);
-            while (lines % ratio != 0 && lines + 1 <= k.bcv) ++lines;
-            jf->trunc_bcv[c] = lines;
-            jf->trunc_bc[c] = tbc;
-        }
-    }
+    if (jf->early_eof) note_truncation(jf);
     jf->rows.push_back(make_handoff(br, *jf, (uint16_t)(mcu / jf->mcuh), lastdc, luma_mul));
     for (size_t i = 1; i < jf->rows.size(); ++i)
         if (jf->rows[i].luma_y_start < jf->rows[i - 1].luma_y_end) jf->rows[i].luma_y_start = jf->rows[i - 1].luma_y_end;
@@ -623,7 +625,9 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
     if (rc) return rc;
     if (!setup_frame(jf)) return jf->warn < 0 ? -jf->warn : EX_UNSUPPORTED_JPEG;
     if (jf->ncomp > 3) return EX_UNSUPPORTED_4_COLORS;
-    if (jf->early_eof || jf->jpegtype != 1) return 0;
+    if (jf->jpegtype != 1) return 0;
+    // (a file that ends inside its scan -- no EOI -- is eligible: the kernels decode up to the block that reads the data's last bit and
+    // say how far they came; anything odd in that last block is left to the host parser, which knows the reference's rules there)
     const uint8_t* h = jf->hdr.data();
     const size_t hdrs = jf->hdr.size();
     size_t hpos = 0;
@@ -642,6 +646,8 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
     memset(plan, 0, sizeof *plan);
     plan->scan_len = (uint32_t)jf->scan.size();
     plan->ncomp = jf->ncomp; plan->mcuh = jf->mcuh; plan->mcuv = jf->mcuv; plan->mcuc = jf->mcuc; plan->rsti = jf->rsti;
+    plan->flags = jf->early_eof ? kScanEarlyEof : 0;
+    if (jf->early_eof && jf->rsti) return 0;   // (restart intervals in a cut file: the single-wave kernel has no notion of the cut)
     for (int i = 0; i < jf->ncomp; ++i) {
         const Component& k = jf->comp[i];
         if (k.dc_tbl > 1 || k.ac_tbl > 1 || !jf->htab[0][k.dc_tbl].set || !jf->htab[1][k.ac_tbl].set) return 0;
@@ -665,15 +671,24 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
 // record that makes no sense) is returned as -1: the caller re-parses the file on the host.
 int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows) {
     const int mcuv = jf->mcuv;
-    const int status = rows[mcuv].aux >> 8;
+    const int status = (rows[mcuv].aux >> 8) & 0x3fffff;
     if (status) return -1;
+    const bool truncated = (rows[mcuv].aux & kScanRowTruncated) != 0;
+    if (truncated && !jf->early_eof) return -1;
     const uint32_t total_bits = (uint32_t)jf->scan.size() * 8u;
     const int luma_mul = jf->comp[0].bcv / jf->mcuv;
+    // blocks of an MCU in scan order; a truncated scan: how many MCU rows were entered, and where the walk stood when the data ended
+    int nphase = 0;
+    for (int ci = 0; ci < jf->cs_cmpc; ++ci) nphase += jf->comp[jf->cs_cmp[ci]].hs * jf->comp[jf->cs_cmp[ci]].vs;
+    if (nphase < 1 || jf->mcuh < 1) return -1;
+    const uint32_t done = truncated ? rows[mcuv].bitpos : (uint32_t)jf->mcuc * (uint32_t)nphase;   // blocks decoded
+    if (truncated && (done == 0 || done >= (uint32_t)jf->mcuc * (uint32_t)nphase)) return -1;
+    const uint32_t mcu_last = (done - 1) / (uint32_t)nphase;                    // MCU of the last decoded block
+    const uint32_t mcu_after = done / (uint32_t)nphase;                         // where next_mcupos left `mcu`
+    const int rows_entered = truncated ? (int)(mcu_last / (uint32_t)jf->mcuh) + 1 : mcuv;
     jf->rows.clear();
     const auto& offs = jf->scan_to_file;
-    for (int r = 0; r <= mcuv; ++r) {
-        const uint32_t bp = rows[r].bitpos;
-        if (bp > total_bits) return -1;
+    auto handoff_at = [&](uint32_t bp, const int16_t* last_dc, int mcu_y) {
         const uint32_t p = (bp >> 3) + 1;   // BitReader::getpos: 1 + index of the byte holding the next unread bit
         auto it = std::lower_bound(offs.begin(), offs.end(), std::pair<uint32_t, uint32_t>(p, p));
         if (it != offs.begin()) --it;
@@ -681,25 +696,59 @@ int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows) {
         if (it != offs.end()) mapped = it->second + (p - it->first);
         Handoff hnd;
         hnd.segment_size = mapped;
-        for (int i = 0; i < 4; ++i) hnd.last_dc[i] = rows[r].last_dc[i];
-        hnd.luma_y_start = (uint16_t)(luma_mul * r);
-        hnd.luma_y_end = (uint16_t)(luma_mul * (r + 1));
+        for (int i = 0; i < 4; ++i) hnd.last_dc[i] = last_dc[i];
+        hnd.luma_y_start = (uint16_t)(luma_mul * mcu_y);
+        hnd.luma_y_end = (uint16_t)(luma_mul * (mcu_y + 1));
         const int rem = (int)(bp & 7u);
         hnd.num_overhang_bits = (uint8_t)rem;
         hnd.overhang_byte = rem ? (uint8_t)(jf->scan[bp >> 3] & (uint8_t)(((1 << rem) - 1) << (8 - rem))) : 0;
         jf->rows.push_back(hnd);
+    };
+    for (int r = 0; r < rows_entered; ++r) {
+        if (rows[r].bitpos > total_bits) return -1;
+        handoff_at(rows[r].bitpos, rows[r].last_dc, r);
+    }
+    if (truncated) {
+        // the reader stands at the end of the data (every bit read: getpos = size + 1, nothing overhanging); the record is the one
+        // decode_scans appends behind its loop, for the MCU row the walk had reached
+        handoff_at(total_bits, rows[mcuv].last_dc, (int)(mcu_after / (uint32_t)jf->mcuh));
+    } else {
+        if (rows[mcuv].bitpos > total_bits) return -1;
+        handoff_at(rows[mcuv].bitpos, rows[mcuv].last_dc, mcuv);
     }
     for (size_t i = 1; i < jf->rows.size(); ++i)
         if (jf->rows[i].luma_y_start < jf->rows[i - 1].luma_y_end) jf->rows[i].luma_y_start = jf->rows[i - 1].luma_y_end;
     // entropy-coded bytes left over behind the last MCU and its padding ("unneeded data found after coded image data",
     // jpgcoder.cc:3290): the host parser refuses the file as the reference does
-    if (rows[mcuv].bitpos != total_bits) return -1;
+    if (!truncated && rows[mcuv].bitpos != total_bits) return -1;
     jf->padbit = (int8_t)(rows[mcuv].aux & 255);
     jf->scan_count = 1;
     jf->max_bpos = std::max(jf->max_bpos, jf->cs_to);
     jf->max_sah = std::max(jf->max_sah, std::max(jf->cs_sal, jf->cs_sah));
     for (int i = 0; i < jf->cs_cmpc; ++i) jf->max_cmp = std::max(jf->max_cmp, jf->cs_cmp[i]);
     for (int c = 0; c < jf->ncomp; ++c) jf->max_dpos[c] = jf->comp[c].bc - 1;
+    if (truncated) {
+        // max_dpos: the largest block position of every component among the decoded blocks (decode_scans notes it at the start of every
+        // block): all of the MCU rows in front of the last one entered, and of that row what its MCUs up to the last block hold
+        const int row = (int)(mcu_last / (uint32_t)jf->mcuh);
+        for (int c = 0; c < jf->ncomp; ++c) jf->max_dpos[c] = row > 0 ? row * jf->comp[c].vs * jf->comp[c].bch - 1 : 0;
+        const uint32_t first = (uint32_t)row * (uint32_t)jf->mcuh * (uint32_t)nphase;
+        for (uint32_t b = first; b < done; ++b) {
+            const int mx = (int)((b / (uint32_t)nphase) % (uint32_t)jf->mcuh);
+            int ph = (int)(b % (uint32_t)nphase);
+            for (int ci = 0; ci < jf->cs_cmpc; ++ci) {
+                const int c = jf->cs_cmp[ci];
+                const Component& k = jf->comp[c];
+                if (ph < k.hs * k.vs) {
+                    const int dpos = (row * k.vs + ph / k.hs) * k.bch + mx * k.hs + ph % k.hs;
+                    jf->max_dpos[c] = std::max(jf->max_dpos[c], dpos);
+                    break;
+                }
+                ph -= k.hs * k.vs;
+            }
+        }
+    }
+    if (jf->early_eof) note_truncation(jf);
     jf->progressive_needed = false;
     return 0;
 }

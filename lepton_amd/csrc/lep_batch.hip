@@ -1258,13 +1258,23 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
             }
             // the scan bytes of the GPU-coded files come down in one copy of the arena range they lie in (same reasoning as the
             // compressor's streams: 8195 copies per chunk took 370 ms), unless that range is mostly slack
+            // does the GPU's answer for file k stand?  A segment that filled its reserved slot may have been cut short; a truncated file's
+            // segments are the file's bytes only if the encoder stopped at the cut in the LAST thread with that thread's byte bound reached
+            // (lep_huff_simt.h code_mcus, recode_finish) -- otherwise the host re-coder takes the file
+            auto gpu_answer_stands = [&](int k) {
+                const int h0 = c->hfirst[k], h1 = h0 + (c->seg_first[k + 1] - c->seg_first[k]);
+                for (int q = h0; q < h1; ++q) {
+                    if (slens[q] >= c->hslot[q] && c->hslot[q] < c->hbound[q]) return false;
+                    if (sends[q].pad & 2) return false;
+                    if ((sends[q].pad & 1) && (q + 1 != h1 || sends[q].attempted < c->hbound[q])) return false;
+                }
+                return true;
+            };
             size_t scan_lo = ~(size_t)0, scan_hi = 0, scan_live = 0;
             for (int k = 0; k < nimg; ++k) {
                 if (c->pfirst[k] >= 0 || c->hfirst[k] < 0) continue;
                 const int h0 = c->hfirst[k], h1 = h0 + (c->seg_first[k + 1] - c->seg_first[k]);
-                bool ok = true;
-                for (int q = h0; q < h1; ++q) if (slens[q] >= c->hslot[q] && c->hslot[q] < c->hbound[q]) ok = false;
-                if (!ok) continue;
+                if (!gpu_answer_stands(k)) continue;
                 for (int q = h0; q < h1; ++q) if (slens[q]) {
                     scan_lo = std::min<size_t>(scan_lo, c->hseg[q].out_off); scan_hi = std::max<size_t>(scan_hi, (size_t)c->hseg[q].out_off + slens[q]);
                     scan_live += slens[q];
@@ -1280,8 +1290,9 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
                 bool on_gpu = c->hfirst[k] >= 0;
                 if (on_gpu) {   // a segment that filled its reserved slot may have been cut short: let the host redo that file
                     const int h0 = c->hfirst[k], h1 = h0 + (c->seg_first[k + 1] - c->seg_first[k]);
-                    for (int q = h0; q < h1; ++q) if (slens[q] >= c->hslot[q] && c->hslot[q] < c->hbound[q]) on_gpu = false;
+                    on_gpu = gpu_answer_stands(k);
                     if (!on_gpu) {
+                        st.gpu_huffman_files -= 1;
                         c->hfirst[k] = -1;
                         if (int rc = host_frames_reserve(s, c->frame_bytes)) { rc_all = rc; break; }
                         lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);

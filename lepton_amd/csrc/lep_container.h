@@ -63,6 +63,7 @@ struct RecodeImage {
     int32_t hs[4], vs[4], bch[4];
     int32_t dc_tbl[4], ac_tbl[4];
     int32_t scan_cmp[4];
+    int32_t trunc_bc[4];
     const int16_t* blocks[4];
     uint32_t code[4][256];
 };

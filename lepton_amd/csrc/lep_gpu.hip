@@ -285,7 +285,14 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_encode_kernel(const lephuff
     __shared__ lephuff::HuffShared sh;
     const int s = blockIdx.x;
     const lephuff::HuffSegment seg = segs[s];
-    if (seg.pad & 1u) return;                  // the lane-per-unit kernels below own this segment
+    if (seg.pad & lephuff::kHuffSegSimt) return;   // the lane-per-unit kernels below own this segment
+    if (seg.pad & lephuff::kHuffSegRefuse) {       // a truncated file's segment nobody on the GPU takes: said so, the host re-coder's
+        if (threadIdx.x == 0) {
+            out_len[s] = 0;
+            if (ends) { lephuff::HuffEnd e; memset(&e, 0, sizeof e); e.pad = lephuff::kHuffEndRefused; ends[s] = e; }
+        }
+        return;
+    }
     lephuff::HuffWave w;
     const uint32_t n = w.run(images + seg.image, seg, &sh, out);
     if (threadIdx.x == 0) out_len[s] = n;
@@ -382,7 +389,7 @@ __global__ void lep_huffman_simt_finish_kernel(const lephuff::HuffDecImage* __re
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= nimg) return;
     lephuff::HuffDecRow* last = rows + images[i].rows_off + images[i].mcuv;
-    last->aux = (last->aux & 255) | (si[i].status << 8);
+    last->aux = (last->aux & (255 | lephuff::kHuffDecRowTruncated)) | ((si[i].status & 0x3fffff) << 8);
 }
 
 }  // namespace
@@ -1028,9 +1035,14 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
     std::vector<lephuff::SimtEncSeg> es;
     std::vector<lephuff::SimtEncWave> waves;
     size_t nunits = 0, scratch_bytes = 0;
+    for (int i = 0; i < nseg; ++i) {   // (a truncated file's segments are the lane-per-unit kernels' or nobody's: the wavefront kernel knows no cut)
+        sv[(size_t)i].pad = 0;
+        if (sv[(size_t)i].image < 0 || sv[(size_t)i].image >= nimg) continue;
+        const lep_huff_image& im = images[sv[(size_t)i].image];
+        if (im.trunc_bc[0] | im.trunc_bc[1] | im.trunc_bc[2] | im.trunc_bc[3]) sv[(size_t)i].pad = lephuff::kHuffSegRefuse;
+    }
     if (g->huffenc_simt)
         for (int i = 0; i < nseg; ++i) {
-            sv[(size_t)i].pad = 0;
             if (sv[(size_t)i].image < 0 || sv[(size_t)i].image >= nimg) continue;
             const lephuff::HuffImage& im = reinterpret_cast<const lephuff::HuffImage&>(images[sv[(size_t)i].image]);
             if (!lephuff::simt_enc_takes(im, reinterpret_cast<const lephuff::HuffSegment&>(sv[(size_t)i]))) continue;
@@ -1042,7 +1054,7 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
             if (nunits + e.nunits > 0x7fffffffu) continue;
             for (uint32_t f = 0; f < e.nunits; f += 64) waves.push_back(lephuff::SimtEncWave{(uint32_t)es.size(), f});
             nunits += e.nunits; scratch_bytes += e.buf_bytes;
-            sv[(size_t)i].pad = 1;
+            sv[(size_t)i].pad = lephuff::kHuffSegSimt;
             es.push_back(e);
         }
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };

@@ -30,6 +30,7 @@ struct HuffImage {          // one image, device-visible
     int32_t hs[4], vs[4], bch[4];
     int32_t dc_tbl[4], ac_tbl[4];
     int32_t scan_cmp[4];    // component order inside the MCU
+    int32_t trunc_bc[4];    // a file cut inside its scan: blocks of each component in front of the cut (JpegFile::trunc_bc); 0 = whole
     const int16_t* blocks[4];
     uint32_t code[4][256];  // [0..1] DC tables, [2..3] AC tables: length << 16 | code
 };
@@ -47,8 +48,11 @@ struct HuffEnd {             // state a segment's writer ends in: what the next 
     uint32_t attempted;     // bytes the segment tried to write (not clipped to out_cap)
     uint8_t overhang_byte, num_overhang_bits;
     int16_t last_dc[4];
-    uint16_t pad;
+    uint16_t pad;           // kHuffEndCut: the segment stopped at the cut of a truncated file (its bytes are those in front of the cut);
+                            // kHuffEndRefused: a truncated file's segment this kernel does not take -- the host re-coder's
 };
+constexpr uint16_t kHuffEndCut = 1, kHuffEndRefused = 2;
+constexpr uint32_t kHuffSegSimt = 1, kHuffSegRefuse = 2;   // HuffSegment::pad: which kernel owns the segment
 
 struct HuffShared {
     uint32_t code[4][256];

@@ -34,7 +34,11 @@ struct SimtEncSeg {         // per segment handled here
     uint32_t buf_bytes;     // multiple of 16
     uint32_t tail;          // pass 3: the stream's last partial byte (its total_bits & 7 bits, top-aligned) -- kept beside the buffer because a
                             // segment that overruns its byte bound is cut off in the buffer and still owes its true end state
+    uint32_t cut;           // pass 2: a unit met the cut of a truncated file: the stream ends in front of it
+    uint32_t reserved;
 };
+constexpr uint32_t kUnitMetCut = 0x80000000u;   // pass 1, in a unit's bit count
+constexpr uint32_t kUnitDead = 0xffffffffu;     // pass 2, in place of a unit's position: it lies behind the cut
 struct SimtEncWave { uint32_t eseg, first_unit; };   // lane l = unit first_unit + l of SimtEncSeg eseg
 
 struct SimtEncShared {
@@ -146,19 +150,28 @@ struct SimtEncLane {
             if (cmp == 0) lastdc[0] = dc; else if (cmp == 1) lastdc[1] = dc; else if (cmp == 2) lastdc[2] = dc; else lastdc[3] = dc;
         }
     }
-    // MCUs [m0, m1) of an interleaved scan
-    WDEV void code_mcus(int m0, int m1) {
+    // MCUs [m0, m1) of an interleaved scan; true = stopped in front of the first block behind the cut of a truncated file.
+    // Such a block -- at or behind its component's trunc_bc and not the first of its block row (RowCoder::mcu_row, jpeg_recode.cc;
+    // decode_row, lepton_codec.cc:7-47) -- is one the reference's decoder never wrote: its re-coder reads what an earlier row left in
+    // its two-row ring there.  In a file the reference itself compressed the byte bound cuts the output in front of it; the stream
+    // ends here, and the host decides whether that is so (lep_file_recode_finish).
+    WDEV bool code_mcus(int m0, int m1) {
         const int mcuh = img->mcuh, ncomp = img->ncomp;
         int row = m0 / mcuh, mx = m0 - row * mcuh;
         for (int m = m0; m < m1; ++m) {
             for (int ci = 0; ci < ncomp; ++ci) {
                 const int cmp = img->scan_cmp[ci];
-                const int hs = img->hs[cmp], vs = img->vs[cmp], bch = img->bch[cmp];
+                const int hs = img->hs[cmp], vs = img->vs[cmp], bch = img->bch[cmp], cutat = img->trunc_bc[cmp];
                 for (int v = 0; v < vs; ++v)
-                    for (int h = 0; h < hs; ++h) code_block(cmp, (row * vs + v) * bch + mx * hs + h);
+                    for (int h = 0; h < hs; ++h) {
+                        const int dpos = (row * vs + v) * bch + mx * hs + h;
+                        if (cutat > 0 && dpos >= cutat && dpos % bch != 0) return true;
+                        code_block(cmp, dpos);
+                    }
             }
             if (++mx == mcuh) { mx = 0; ++row; }
         }
+        return false;
     }
 };
 
@@ -184,15 +197,18 @@ WDEV void simt_enc_units(const HuffImage* images, const HuffSegment* segs, SimtE
             for (int c = 0; c < 4; ++c) d.lastdc[c] = seg.last_dc[c];
             if (u > 0) d.predictors_before(m0);
             uint32_t* buf = reinterpret_cast<uint32_t*>(scratch + es.buf_off);
-            d.sink.start(WRITE ? unit_bits[es.first_unit + u] : 0u, buf, es.buf_bytes >> 2);
+            const uint32_t at = WRITE ? unit_bits[es.first_unit + u] : 0u;
             if (WRITE && u == 0) {               // the partial byte the segment starts with (ThreadHandoff)
                 const uint32_t pend = (seg.overhang >> 8) & 255u;
                 if (pend) simt_or_word(buf, (seg.overhang & 255u) << 24);   // (as it is: lep_huff.h starts from the byte unmasked too)
             }
-            d.code_mcus(m0, m1);
-            d.sink.finish();
-            if (!WRITE) unit_bits[es.first_unit + u] = d.sink.total;
-            else if (u + 1 == es.nunits) esp->tail = d.sink.tail_byte();
+            if (!(WRITE && at == kUnitDead)) {   // (a unit behind the cut of a truncated file writes nothing)
+                d.sink.start(at, buf, es.buf_bytes >> 2);
+                const bool met_cut = d.code_mcus(m0, m1);
+                d.sink.finish();
+                if (!WRITE) unit_bits[es.first_unit + u] = d.sink.total | (met_cut ? kUnitMetCut : 0u);
+                else if (u + 1 == es.nunits || met_cut) esp->tail = d.sink.tail_byte();
+            }
         }
     }
 }
@@ -201,14 +217,24 @@ WDEV void simt_enc_units(const HuffImage* images, const HuffSegment* segs, SimtE
 WDEV void simt_enc_place(const HuffSegment* segs, SimtEncSeg* es, uint32_t* unit_bits) {
     const uint32_t pend = (segs[es->seg].overhang >> 8) & 255u;
     uint32_t run = pend;
+    bool cut = false;                                      // a unit in front has met the cut of a truncated file: the rest is dead
     for (uint32_t base = 0; base < es->nunits; base += 64) {
-        LV(int, nb); LV(int, ex);
-        LANES(l) { const uint32_t u = base + (uint32_t)l; L(nb) = u < es->nunits ? (int)unit_bits[es->first_unit + u] : 0; }
+        LV(int, nb); LV(int, ex); LV(int, met);
+        LANES(l) {
+            const uint32_t u = base + (uint32_t)l;
+            const uint32_t v = u < es->nunits ? unit_bits[es->first_unit + u] : 0u;
+            L(met) = (v & kUnitMetCut) != 0;
+            L(nb) = (int)(v & ~kUnitMetCut);
+        }
+        const uint64_t metmask = lepwave::wave_ballot(met);
+        const int first_met = cut ? -1 : (metmask ? (int)__builtin_ctzll(metmask) : 64);   // lanes behind it are dead
+        LANES(l) if (l > first_met) L(nb) = 0;
         const int t = lepwave::wave_excl_scan(nb, ex);
-        LANES(l) { const uint32_t u = base + (uint32_t)l; if (u < es->nunits) unit_bits[es->first_unit + u] = run + (uint32_t)L(ex); }
+        LANES(l) { const uint32_t u = base + (uint32_t)l; if (u < es->nunits) unit_bits[es->first_unit + u] = l > first_met ? kUnitDead : run + (uint32_t)L(ex); }
         run += (uint32_t)t;
+        if (first_met < 64) cut = true;
     }
-    LANES(l) if (l == 0) es->total_bits = run;
+    LANES(l) if (l == 0) { es->total_bits = run; es->cut = cut ? 1u : 0u; }
 }
 
 // pass 4: one wavefront per segment
@@ -219,7 +245,7 @@ WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const
     uint32_t total = es.total_bits;
     const uint32_t room = es.buf_bytes * 8u;
     if (total > room) total = room;                       // the segment overran its bound: what is kept is what the bound keeps
-    const bool scan_ends = seg.mcu_row1 * img->mcuh >= img->mcuc;
+    const bool scan_ends = seg.mcu_row1 * img->mcuh >= img->mcuc && !es.cut;   // (a stream that stops at a cut has no end to pad)
     if (scan_ends && (total & 7u)) {                      // abitwriter::pad: the pad-bit pattern, LSB of the pattern first
         const uint32_t pend = total & 7u, n = 8u - pend;
         uint32_t v = 0;
@@ -284,7 +310,7 @@ WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const
                     e.last_dc[cmp & 3] = img->blocks[cmp][(int64_t)((row * vs + vs - 1) * img->bch[cmp] + mx * hs + hs - 1) * 64 + kZ2A_const(0)];
                 }
             }
-            e.pad = 0;
+            e.pad = es.cut ? kHuffEndCut : (uint16_t)0;
             ends[es.seg] = e;
         }
     }

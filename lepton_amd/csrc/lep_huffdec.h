@@ -25,10 +25,14 @@ using lep3::ucond;
 using lep3::uni;
 using lep3::vec;
 
+constexpr int32_t kHuffDecEarlyEof = 1;              // HuffDecImage::flags
+constexpr int32_t kHuffDecRowTruncated = 0x40000000; // final HuffDecRow::aux: the data ran out in mid-image; bitpos = blocks decoded
 struct HuffDecImage {       // one image, device-visible
     const uint8_t* scan;    // un-stuffed entropy-coded bytes (RSTn removed), 16-byte aligned, followed by >= 16 zero bytes
     uint32_t scan_len;
     int32_t ncomp, mcuh, mcuv, mcuc, rsti;
+    int32_t flags;          // kHuffDecEarlyEof: the file ends inside its scan
+    int32_t reserved0;
     int32_t hs[4], vs[4], bch[4], dc_tbl[4], ac_tbl[4], scan_cmp[4];
     int16_t* blocks[4];     // zero-filled frame (device)
     uint64_t rows_off;      // this image's first record in the row arena (mcuv + 1 records)

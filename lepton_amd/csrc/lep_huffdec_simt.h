@@ -297,6 +297,11 @@ WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, Si
     if (si->status) return;                                // pass P refused the image: the fallback decodes it
     const int nphase = simt_setup(img, sh);
     const uint32_t scan_bits = img->scan_len * 8u, nsub = si->nsub, total = (uint32_t)img->mcuc * (uint32_t)nphase;
+    // A file that ends inside its scan (no EOI; kHuffDecEarlyEof): the reference decodes block after block until the read that takes
+    // the data's last bit (bits behind it read as zeros: the buffer's padding), keeps the block that read it and stops
+    // (jpgcoder.cc:3034-3069 with bitops.hh:262-300; jpeg_scan.cc decode_scans).  The lane whose region holds that block stops there
+    // and leaves the final record {blocks decoded, last DC, kHuffDecRowTruncated}; regions behind it have nothing to decode.
+    const bool cut = (img->flags & kHuffDecEarlyEof) != 0;
     HuffDecRow* rows = rows_arena + img->rows_off;
     LANES(l) for (int w = 0; w < 32; ++w) tile->w[w * 64 + l] = 0u;
     LSYNC();
@@ -314,12 +319,15 @@ WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, Si
             if (i > 0) { bp = sub[i - 1].end_bitpos; phase = (int)sub[i - 1].end_phase; }
             int bad = 0;
             uint32_t mine = 0;
-            if (before > total) bad = 3;
+            bool stopped = false;                          // this lane met the end of a cut file's data
+            const bool behind_the_end = cut && i > 0 && bp >= scan_bits;
+            if (behind_the_end) {}
+            else if (before > total) bad = 3;
             else {
                 mine = last ? total - before : sub[i].nblocks;
                 if (before + mine > total || bp > scan_bits || phase >= nphase || (uint32_t)phase != before % (uint32_t)nphase) bad = 3;
             }
-            if (!bad) {
+            if (!bad && !behind_the_end) {
                 SimtLane d;
                 d.img = img; d.sh = sh;
                 d.br.words = reinterpret_cast<const uint32_t*>(img->scan); d.br.nwords = (img->scan_len + 3) >> 2;
@@ -351,12 +359,19 @@ WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, Si
                             out[q] = v;
                         }
                     }
-                    if (!fine) { bad = 1; break; }
-                    if (d.br.bitpos > scan_bits) { bad = 2; break; }           // ran out of data inside a block
+                    if (!fine) { bad = 1; break; }             // (also in the block that meets the end: the reference's rules there are the host's)
+                    if (d.br.bitpos > scan_bits && !cut) { bad = 2; break; }   // ran out of data inside a block
                     if (++phase == nphase) { phase = 0; ++mcu; if (++mx == mcuh) { mx = 0; ++row; } }
+                    if (cut && d.br.bitpos >= scan_bits && before + k + 1 < total) {   // the data's last bit has been read, blocks are still missing
+                        rows[img->mcuv].bitpos = before + k + 1;
+                        for (int c = 0; c < 4; ++c) rows[img->mcuv].last_dc[c] = (int16_t)lastdc[c];
+                        rows[img->mcuv].aux = 255 | kHuffDecRowTruncated;
+                        stopped = true;
+                        break;
+                    }
                 }
-                if (!bad && !last && (d.br.bitpos != sub[i].end_bitpos || (uint32_t)phase != sub[i].end_phase)) bad = 3;   // must stand where the next region starts
-                if (!bad && last) {
+                if (!bad && !stopped && !last && (d.br.bitpos != sub[i].end_bitpos || (uint32_t)phase != sub[i].end_phase)) bad = 3;   // must stand where the next region starts
+                if (!bad && !stopped && last) {
                     if (phase != 0 || mcu != img->mcuc) bad = 3;
                     else {
                         const int padbit = (int8_t)d.unpad(255);

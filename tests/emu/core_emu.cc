@@ -267,7 +267,7 @@ extern "C" int emu_huffman_decode_image_simt(const lep_huffdec_image* img, lep_h
     lephuff::simt_place(&im, &si, fin, place.data(), lephuff::kSimtSettle);
     static lephuff::SimtTile tile;
     for (uint32_t f = 0; f < si.nsub; f += 64) lephuff::simt_write(&im, &sh, &tile, &si, fin, place.data(), reinterpret_cast<lephuff::HuffDecRow*>(rows), f);
-    rows[im.mcuv].aux = (rows[im.mcuv].aux & 255) | (si.status << 8);
+    rows[im.mcuv].aux = (rows[im.mcuv].aux & (255 | lephuff::kHuffDecRowTruncated)) | ((si.status & 0x3fffff) << 8);   // (lep_huffman_simt_finish_kernel)
     if (settle_moved) for (int k = 0; k <= lephuff::kSimtSettle; ++k) settle_moved[k] = si.changed[k];
     if (nsub_out) *nsub_out = si.nsub;
     return 0;

@@ -316,6 +316,8 @@ def test_lane_per_unit_huffman_encoder_equals_the_wave_per_segment_one(emu, name
     assert L.lep_file_recode_plan(f.handle, C.byref(img), segs, C.byref(nseg), C.byref(ok)) == 0
     if not ok.value:
         pytest.skip("not eligible for the GPU Huffman encoder")
+    if any(img.trunc_bc[c] for c in range(4)):
+        pytest.skip("a file cut inside its scan: only the lane-per-unit kernels know the cut (test_..._restores_files_cut_inside_their_scan)")
     taken = 0
     for i in range(nseg.value):
         for cap in (min(segs[i].out_cap, len(jpg) + 1024), 100):        # the segment's own bound, and one that cuts it short
@@ -379,7 +381,10 @@ def test_gpu_huffman_decoder_on_cpu_matches_host_parser(emu, name):
     assert rc == 0
     if not ok.value:
         L.lep_jpeg_close(h)
-        pytest.skip("not eligible for the GPU Huffman decoder (grey, truncated, multi-scan, ...): host parser only")
+        pytest.skip("not eligible for the GPU Huffman decoder (grey, multi-scan, ...): host parser only")
+    if img.flags & 1:
+        L.lep_jpeg_close(h)
+        pytest.skip("a file cut inside its scan: the single-wave kernel reports it irregular, the lane-per-subsequence kernels decode it")
     p, n = C.c_void_p(), C.c_size_t(0)
     L.lep_jpeg_scan_bytes(h, C.byref(p), C.byref(n))
     scan = C.create_string_buffer(C.string_at(p, n.value) + b"\0" * 64, n.value + 64)   # zero padded copy ("device" arena)
@@ -537,6 +542,8 @@ def test_lane_per_subsequence_huffman_decoder_equals_the_single_wave_one(emu, na
     img1, scan1, planes1, d = one
     if img1.rsti:
         pytest.skip("restart intervals: the single-wave kernel keeps these files")
+    if img1.flags & 1:
+        pytest.skip("a file cut inside its scan: only the lane-per-subsequence kernels know the cut (test_..._on_files_cut_inside_their_scan)")
     rows1 = (abi.HuffDecRow * (img1.mcuv + 1))()
     assert emu.emu_huffman_decode_image(C.byref(img1), rows1) == 0 and rows1[img1.mcuv].aux >> 8 == 0
     img2, scan2, planes2, _ = _huffdec_setup(jpg)
@@ -937,7 +944,8 @@ def test_gpu_progressive_scan_decoder_on_random_files(emu):
 
 
 def _emulated_gpu_scan_encode(emu, f):
-    """plan -> lep_huff.h as a lane loop per segment -> finish; None when the file is not eligible for the GPU scan encoder"""
+    """plan -> lep_huff.h (lep_huff_simt.h for a file cut inside its scan) as a lane loop per segment -> finish; None when the file is not
+    eligible for the GPU scan encoder or the encoder leaves it to the host re-coder"""
     from lepton_amd import abi
     L = abi.lib()
     img = abi.HuffImage()
@@ -955,11 +963,19 @@ def _emulated_gpu_scan_encode(emu, f):
         buf = C.create_string_buffer(cap + 8)
         keep.append(buf)
         n = C.c_uint32(0)
-        assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) == 0
+        if any(img.trunc_bc[c] for c in range(4)):
+            # a file cut inside its scan: the lane-per-unit kernels' or nobody's (lep_gpu_huffman_encode_device) -- and the host re-coder's
+            # whenever the cut is met before the byte bound (LEP_GPU_PATH_DECLINED, what the batch decompressor acts on)
+            if emu.emu_huffman_encode_segment_simt(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) != 0:
+                return None
+        else:
+            assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) == 0
         outs[i].data = C.cast(buf, C.c_void_p).value
         outs[i].len = outs[i].cap = n.value
     out = abi.Bytes()
     rc = L.lep_file_recode_finish(f.handle, outs, ends, nseg.value, C.byref(out))
+    if rc == 101:
+        return None
     assert rc == 0, rc
     got = out.tobytes()
     L.lep_free(out.data)
@@ -1312,3 +1328,134 @@ def test_progressive_scan_dependencies_on_made_up_scripts(emu):
     # the scan that comes first in the FILE stands behind the one that follows it in the LAUNCH: a wait that could never end
     ok, _ = run([(A, [0], 1, 63), (A, [0], 1, 63)], order=[1, 0])
     assert not ok
+
+
+def _cut_jpegs():
+    """files that end inside their scan (no EOI): [(name, bytes)] -- the truncated goldens, the reference's own truncated photographs, the
+    file `lepton -benchmark` codes, and a 4:2:0 file cut at many places (in the first MCU row, at a row boundary, in the last bytes)"""
+    import bench
+    from conftest import ref_golden
+    out = [(n, golden(n)[0]) for n in ("truncated", "truncated_short")]
+    out += [(n, ref_golden(n)[0]) for n in ("truncatedzerorun", "singlerowtrunc")]
+    out.append(("reference_benchmark_file", bench.reference_benchmark_jpeg()))
+    whole = golden("c420_odd_203x149")[0]
+    sos = whole.find(b"\xff\xda")
+    for cut in (sos + 30, sos + 200, len(whole) // 2, len(whole) * 3 // 4, len(whole) - 40, len(whole) - 3, len(whole) - 2):
+        out.append(("c420_odd_cut_at_%d" % cut, whole[:cut]))
+    big = golden("q30_256x256_4seg")[0]      # several thread segments
+    out += [("q97_4seg_cut_at_%d" % c, big[:c]) for c in (len(big) // 3, len(big) - 1000)]
+    return out
+
+
+@pytest.mark.parametrize("bits", [1024, 8192])
+@pytest.mark.parametrize("name", [n for n, _ in _cut_jpegs()])
+def test_lane_per_subsequence_huffman_decoder_on_files_cut_inside_their_scan(emu, name, bits):
+    """A file without EOI ends inside its scan: the reference decodes up to the block that reads the data's last bit (zeros behind it) and
+    codes what it has (uncompressed_components.hh:166-185).  lep_huffdec_simt.h + parse_jpeg_finish_gpu must leave exactly the host
+    parser's frame, hand-offs and truncation bounds -- the .lep written from them is the host parser's (== the reference's for the
+    fixtures) -- or report a status and leave the file to the host parser; never a different result."""
+    from lepton_amd import abi
+
+    jpg = dict(_cut_jpegs())[name]
+    L = abi.lib()
+    try:
+        host = JpegImage(jpg)
+    except Exception:
+        pytest.skip("the host parser refuses this cut")
+    h = C.c_void_p()
+    img = abi.HuffDecImage()
+    ok = C.c_int(0)
+    assert L.lep_jpeg_open_gpu(jpg, len(jpg), C.byref(h), C.byref(img), C.byref(ok)) == 0
+    if not ok.value:
+        L.lep_jpeg_close(h)
+        pytest.skip("not eligible for the GPU scan decoder (restart intervals, grey with padding, ...)")
+    assert img.flags & 1, "the fixture is not a cut file"
+    p, n = C.c_void_p(), C.c_size_t(0)
+    L.lep_jpeg_scan_bytes(h, C.byref(p), C.byref(n))
+    scan = C.create_string_buffer(C.string_at(p, n.value) + b"\0" * 64, n.value + 64)
+    img.scan = C.addressof(scan)
+    d = host.desc
+    planes = []
+    for c in range(d.ncomp):
+        b = C.create_string_buffer(d.nblocks(c) * 128)
+        planes.append(b)
+        img.blocks[c] = C.cast(b, C.c_void_p).value
+    rows = (abi.HuffDecRow * (img.mcuv + 1))()
+    assert emu.emu_huffman_decode_image_simt(C.byref(img), rows, bits, None, None) == 0
+    if (rows[img.mcuv].aux >> 8) & 0x3fffff:
+        L.lep_jpeg_close(h)
+        pytest.skip("the kernel left the file to the host parser (status %d)" % ((rows[img.mcuv].aux >> 8) & 0x3fffff))
+    assert L.lep_jpeg_finish_gpu(h, rows) == 0
+    gd = abi.ImageDesc()
+    assert L.lep_jpeg_describe(h, C.byref(gd)) == 0
+    for c in range(d.ncomp):
+        assert gd.coded_blocks[c] == d.coded_blocks[c] and gd.coded_height[c] == d.coded_height[c], (c, gd.coded_blocks[c], d.coded_blocks[c])
+        nb = d.coded_blocks[c] * 128
+        assert planes[c].raw[:nb] == C.string_at(d.blocks[c], nb), "component %d" % c
+    segs = host.plan()
+    streams, _ = ob.oracle_encode(d, segs)
+    want = host.write_lep(streams)
+    arr = (abi.Bytes * len(streams))()
+    keep = []
+    for i, s in enumerate(streams):
+        b = C.create_string_buffer(bytes(s), max(1, len(s)))
+        keep.append(b)
+        arr[i].data = C.cast(b, C.c_void_p).value
+        arr[i].len = arr[i].cap = len(s)
+    out = abi.Bytes()
+    assert L.lep_jpeg_write_lep(h, 0, arr, len(streams), C.byref(out)) == 0
+    got = out.tobytes()
+    L.lep_free(out.data)
+    L.lep_jpeg_close(h)
+    assert got == want
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _cut_jpegs()])
+def test_lane_per_unit_huffman_encoder_restores_files_cut_inside_their_scan(emu, name):
+    """The decompress direction of a truncated file on the GPU scan encoder: lep_huff_simt.h stops in front of the first block behind the
+    cut and says so (HuffEnd.pad); lep_file_recode_finish takes its bytes when the last thread's byte bound was reached by then -- the file
+    comes back byte for byte -- and answers LEP_GPU_PATH_DECLINED otherwise (a shorter scan than the bound: damaged files), which sends the
+    caller to the host re-coder.  The .lep is the oracle's for the cut file (== the reference's for the fixtures)."""
+    from lepton_amd import abi
+    from lepton_amd.codec import LepFile
+
+    jpg = dict(_cut_jpegs())[name]
+    L = abi.lib()
+    try:
+        src = JpegImage(jpg)
+    except Exception:
+        pytest.skip("the host parser refuses this cut")
+    segs0 = src.plan()
+    streams, _ = ob.oracle_encode(src.desc, segs0)
+    lep = src.write_lep(streams)
+    f = LepFile(lep)
+    ob.oracle_decode(f.desc, f.segments, f.streams)
+    assert f.recode() == jpg                      # the host re-coder (threads) restores it: the baseline of this test
+    img = abi.HuffImage()
+    segs = (abi.HuffSegment * abi.MAX_SEGMENTS)()
+    nseg, ok = C.c_int(0), C.c_int(0)
+    assert L.lep_file_recode_plan(f.handle, C.byref(img), segs, C.byref(nseg), C.byref(ok)) == 0
+    if not ok.value:
+        pytest.skip("not eligible for the GPU Huffman encoder (grey, restart intervals, ...)")
+    assert any(img.trunc_bc[c] for c in range(3)), "the plan does not know the file is cut"
+    n = nseg.value
+    bufs, arr, ends = [], (abi.Bytes * n)(), (abi.HuffEnd * n)()
+    for i in range(n):
+        cap = min(segs[i].out_cap, len(jpg) + 1024)
+        segs[i].out_cap = cap
+        buf = C.create_string_buffer(cap + 8)
+        ln = C.c_uint32(0)
+        rc = emu.emu_huffman_encode_segment_simt(C.byref(img), C.byref(segs[i]), buf, C.byref(ln), C.byref(ends[i]))
+        assert rc == 0, "the lane-per-unit kernel must take every segment of a cut file the plan lets through"
+        bufs.append(buf)
+        arr[i].data = C.cast(buf, C.c_void_p).value
+        arr[i].len = arr[i].cap = ln.value
+    out = abi.Bytes()
+    rc = L.lep_file_recode_finish(f.handle, arr, ends, n, C.byref(out))
+    if rc == 101:
+        assert ends[n - 1].pad & 1 and ends[n - 1].attempted < segs[n - 1].out_cap
+        pytest.skip("the cut was met before the byte bound (LEP_GPU_PATH_DECLINED): the host re-coder's")
+    assert rc == 0
+    got = out.tobytes()
+    L.lep_free(out.data)
+    assert got == jpg

@@ -209,3 +209,28 @@ def test_gpu_refuses_what_the_reference_refuses(gpu_codec, name, code):
     with pytest.raises(LeptonError) as e:
         gpu_codec.compress(jpg)
     assert e.value.code == (code if code > 0 else 1)
+
+
+@pytest.mark.gpu
+def test_gpu_scan_kernels_take_files_cut_inside_their_scan(gpu_codec):
+    """the file `lepton -benchmark` codes (src/lepton/benchmark.cc:116-119: no EOI, the scan ends in mid-image) and the truncated fixtures
+    through the batch pipeline: the GPU scan decoder / encoder take them (lep_batch_stats.gpu_huffman_files), the .lep is the per-file
+    path's (== the reference's for the fixtures), the file comes back byte for byte"""
+    import bench
+    from conftest import golden
+
+    rb = bench.reference_benchmark_jpeg()
+    cut = [rb, golden("truncated")[0], golden("truncated_short")[0], ref_golden("iphone")[0][:1500000], ref_golden("androidcrop")[0][:60000]]
+    whole = [golden("c420_160x120")[0]]
+    jpgs = cut + whole + cut[:1] * 3
+    leps, status, cs = gpu_codec.compress_batch(jpgs, verify=False)
+    assert status == [0] * len(jpgs)
+    assert cs["gpu_huffman_files"] >= len(jpgs) - 2, cs      # (a cut whose last block is irregular may be the host parser's)
+    assert leps[1] == golden("truncated")[1] and leps[2] == golden("truncated_short")[1] and leps[5] == golden("c420_160x120")[1]
+    assert leps[0] == gpu_codec.compress(rb) and leps[6] == leps[0]
+    back, status, ds = gpu_codec.decompress_batch(leps)
+    assert status == [0] * len(jpgs) and back == jpgs
+    assert ds["gpu_huffman_files"] >= len(jpgs) - 2, ds
+    # and with the host Huffman coders: the same bytes
+    leps_h, status, _ = gpu_codec.compress_batch(jpgs, verify=False, host_huffman=True)
+    assert status == [0] * len(jpgs) and leps_h == leps
