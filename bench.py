@@ -246,7 +246,7 @@ class HipDevice:
             self.L.lep_gpu_trim(self.g)
         return pipeline_figure(self.codec, jpgs, label, verify=verify, threads=self.host_threads)
 
-    def resident(self, uniq, images, steps, warmup, barrier, check_parity=True, with_latency=False):
+    def resident(self, uniq, images, steps, warmup, barrier, check_parity=True, with_latency=False, latency_sizes=(1, 8, 64), latency_repeats=3, whole_file=True):
         """`images` 4K frames (the `uniq` distinct ones replicated device-to-device) and their streams resident in HBM;
         `warmup` + `steps` encode + decode launches; returns counters, kernel times (HIP events on the launch stream) and the
         parity verdict (every segment's exit code, decode(encode(x)) == x, streams == oracle for every distinct image)."""
@@ -262,12 +262,12 @@ class HipDevice:
         nimg = len(order)
         allocs = []
         try:
-            return self._resident(L, g, codec, uniq, imgs, plans, order, nuniq, jpeg_bytes, nimg, allocs, steps, warmup, barrier, check_parity, with_latency)
+            return self._resident(L, g, codec, uniq, imgs, plans, order, nuniq, jpeg_bytes, nimg, allocs, steps, warmup, barrier, check_parity, with_latency, latency_sizes, latency_repeats, whole_file)
         finally:
             for a in allocs:   # the resident frames are no longer needed (or could not all be had); what follows wants the memory
                 L.lep_gpu_free(g, a)
 
-    def _resident(self, L, g, codec, uniq, imgs, plans, order, nuniq, jpeg_bytes, nimg, allocs, steps, warmup, barrier, check_parity, with_latency):
+    def _resident(self, L, g, codec, uniq, imgs, plans, order, nuniq, jpeg_bytes, nimg, allocs, steps, warmup, barrier, check_parity, with_latency, latency_sizes=(1, 8, 64), latency_repeats=3, whole_file=True):
         from lepton_amd import abi
 
         def dmalloc(n):
@@ -391,12 +391,12 @@ class HipDevice:
         latency = None
         if with_latency:
             latency = {"unit": "ms, device-resident frames, launch + kernel + sync (best of 3)", "encode": {}, "decode": {}}
-            for nb in (1, 8, 64):
+            for nb in latency_sizes:
                 if nb > nimg:
                     break
                 ns = sum(len(plans[order[k]]) for k in range(nb))
                 best_e = best_d = 1e9
-                for _ in range(3):
+                for _ in range(latency_repeats):
                     t0 = time.perf_counter()
                     assert L.lep_gpu_encode_device(g, descs, nb, segs, ns, d_streams, offs, d_len, d_status, None) == 0
                     L.lep_gpu_sync(g)
@@ -407,9 +407,10 @@ class HipDevice:
                     best_e = min(best_e, t1 - t0); best_d = min(best_d, t2 - t1)
                 latency["encode"]["%d_image%s" % (nb, "" if nb == 1 else "s")] = round(best_e * 1e3, 1)
                 latency["decode"]["%d_image%s" % (nb, "" if nb == 1 else "s")] = round(best_d * 1e3, 1)
-            t0 = time.perf_counter(); one = codec.compress(uniq[0]); t1 = time.perf_counter(); assert codec.decompress(one) == uniq[0]; t2 = time.perf_counter()
-            latency["whole_file_host_to_host"] = {"compress_ms": round((t1 - t0) * 1e3, 1), "decompress_ms": round((t2 - t1) * 1e3, 1),
-                                                  "note": "lep_compress / lep_decompress of one 4K JPEG: host Huffman + PCIe + kernels + container"}
+            if whole_file:
+                t0 = time.perf_counter(); one = codec.compress(uniq[0]); t1 = time.perf_counter(); assert codec.decompress(one) == uniq[0]; t2 = time.perf_counter()
+                latency["whole_file_host_to_host"] = {"compress_ms": round((t1 - t0) * 1e3, 1), "decompress_ms": round((t2 - t1) * 1e3, 1),
+                                                      "note": "lep_compress / lep_decompress of one 4K JPEG: host Huffman + PCIe + kernels + container"}
         return {"jpeg_bytes": jpeg_bytes, "images": nimg, "segments": nseg, "blocks": nblocks, "stream_bytes": stream_bytes,
                 "elapsed": elapsed, "enc_ms": enc_ms, "dec_ms": dec_ms, "names": names, "parity": parity,
                 "bins_per_image": bins_per_image, "latency": latency,

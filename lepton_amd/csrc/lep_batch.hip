@@ -652,7 +652,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 // kernel before the host parser is bothered: its frame is wiped first (pass C may have written part of it)
                 std::vector<lep_huffdec_image> again;
                 for (const lep_huffdec_image& hi : launch) {
-                    if (hi.rsti || (rows[hi.rows_off + (size_t)hi.mcuv].aux >> 8) == 0) continue;
+                    if (hi.rsti || ((rows[hi.rows_off + (size_t)hi.mcuv].aux >> 8) & 0x3fffff) == 0) continue;   // (bit 30: LEP_HUFFDEC_ROW_TRUNCATED, not a status)
                     for (int cc = 0; cc < hi.ncomp; ++cc)
                         HIPOK(hipMemsetAsync(hi.blocks[cc], 0, (size_t)hi.bch[cc] * hi.vs[cc] * hi.mcuv * 128, s_huff));
                     again.push_back(hi);
@@ -1156,6 +1156,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     hipStream_t s_prev = nullptr;          // the stream the previous chunk's kernels went to
     Slot* slot_prev = nullptr;
     bool prev_ragged = false;
+    int set_prev = 0;
     const hipStream_t s_compute_a = s_compute;
     auto launch_chunk = [&](Chunk* c, Slot* s) -> int {
         const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
@@ -1172,11 +1173,16 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         }
         const bool ragged = hi * 2 > lo * 3 || nseg < 6144;
         const bool beside = s_prev && (dec_overlap == 1 || (dec_overlap < 0 && prev_ragged));
-        const int set = (int)(s - slots) & 1;
+        // the second workspace set (its own 3 MB of model per segment) only where two launches are in flight; launches in stream order
+        // share one
+        const int set = !s_prev ? 0 : (beside ? set_prev ^ 1 : set_prev);
+        set_prev = set;
         hipStream_t s_compute = !s_prev ? s_compute_a : (beside ? (s_prev == s_compute_a ? s_compute_b : s_compute_a) : s_prev);
         hipStream_t s_scan_here = s_scan == s_compute_a ? s_compute : s_scan;
-        // this slot's buffers and this workspace set were last used by the chunk before the previous one, possibly on the other stream
+        // this slot's buffers were last used by the chunk before the previous one, possibly on the other stream -- and a workspace set by
+        // either of the two chunks in front
         if (s->done_recorded) HIPOK(hipStreamWaitEvent(s_compute, s->done, 0));
+        if (slot_prev && slot_prev->done_recorded && !beside && s_compute != s_prev) HIPOK(hipStreamWaitEvent(s_compute, slot_prev->done, 0));
         HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
         if (int rc0 = lep_gpu_use_arena(g, set)) return rc0;
         (void)lep_gpu_expect_company(g, dec_overlap != 0 && (beside || ragged) && c->count < n);   // (a call of one chunk has no neighbour)

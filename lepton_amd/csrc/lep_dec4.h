@@ -350,7 +350,10 @@ struct BoolDec4S {
 #define LEP_DEC4_SCALAR 2   // measured (1024 x 4K, MI355X, profiles/r02m_*): 0: 1232 ms, 2: 1204, 3: 1212, 11: 1226, 7: 1400, 15: 1440
 #endif
 
-struct Dec4Wave {
+// SCMASK: which serial rounds run on the scalar unit (LEP_DEC4_SCALAR above for the throughput kernel; the launches of a few segments,
+// where a wavefront has its SIMD to itself and the dependent-instruction latency is all that counts, take their own: lep_gpu.hip)
+template <int SCMASK>
+struct Dec4WaveT {
     const ImageDev* img;
     uint32_t* model;
     Dec4Shared* sh;
@@ -426,9 +429,9 @@ struct Dec4Wave {
     // done().  Values a round passes in (packed probabilities read from a lane, Branch words) go through U().
     template <bool SC>
     struct Serial {
-        Dec4Wave& w;
+        Dec4WaveT& w;
         BoolDec4S s;
-        WDEV explicit Serial(Dec4Wave& w_) : w(w_) { if (SC) s.load(w.bc); }
+        WDEV explicit Serial(Dec4WaveT& w_) : w(w_) { if (SC) s.load(w.bc); }
         WDEV void done() { if (SC) s.store(w.bc); }
         static WDEV uint32_t U(uint32_t x) { return SC ? uni(x) : vec(x); }
         static WDEV bool is(bool c) { return SC ? c : ucond(c); }
@@ -607,10 +610,10 @@ struct Dec4Wave {
             }
             L(a0) = adr; L(PK0) = pk;
         }
-        LEP_MARK("nz_serial"); LEP_PRIO_SERIAL((LEP_DEC4_SCALAR & 1) != 0);
+        LEP_MARK("nz_serial"); LEP_PRIO_SERIAL((SCMASK & 1) != 0);
         int nz;
         {
-            Serial<(LEP_DEC4_SCALAR & 1) != 0> sr(*this);
+            Serial<(SCMASK & 1) != 0> sr(*this);
             nz = sr.template tree<6>(PK0, 0);
             sr.done();
             LEP_BINS(nbins += 6);
@@ -656,7 +659,7 @@ struct Dec4Wave {
         }
         LSYNC();
         // ---- serial (uniform vector) -----------------------------------------------------------------------------
-        LEP_MARK("77_serial"); LEP_PRIO_SERIAL((LEP_DEC4_SCALAR & 2) != 0);
+        LEP_MARK("77_serial"); LEP_PRIO_SERIAL((SCMASK & 2) != 0);
         int zz, left = left0, cand = 0;
         const int pi_end = zz0 + 16 < 49 ? 16 : 49 - zz0;   // window positions 0 .. pi_end-1
         {
@@ -664,7 +667,7 @@ struct Dec4Wave {
             // induction variable of the inner loop (position and candidate are folded into it), so that iteration is the bin
             // itself + one lane read + add / compare / branch.  Runs while position < pi_end && left > 0 && cand < CANDS
             // (true on entry: the caller checks zz < 49 && left > 0).
-            typedef Serial<(LEP_DEC4_SCALAR & 2) != 0> SR;
+            typedef Serial<(SCMASK & 2) != 0> SR;
             SR sr(*this);
             uint32_t sgw = SR::U(S.sign[ci * 48]);
             int pi = 0;
@@ -790,9 +793,9 @@ struct Dec4Wave {
         }
         LSYNC();
         // ---- serial (uniform vector) -----------------------------------------------------------------------------
-        LEP_MARK("edge_serial"); LEP_PRIO_SERIAL((LEP_DEC4_SCALAR & 4) != 0);
+        LEP_MARK("edge_serial"); LEP_PRIO_SERIAL((SCMASK & 4) != 0);
         int ne[2] = {0, 0}, rc = 0;
-        typedef Serial<(LEP_DEC4_SCALAR & 4) != 0> SR;
+        typedef Serial<(SCMASK & 4) != 0> SR;
         SR sr(*this);
 #pragma nounroll
         for (int e = 0; e < 2 && !rc; ++e) {
@@ -951,9 +954,9 @@ struct Dec4Wave {
             else if (l < 13) rw = S.resdc[a * 12 + (l - 3)];   // residual Branch of bit l-3
             L(a0) = adr; L(PK0) = pk; L(RW) = rw;
         }
-        LEP_MARK("dc_serial"); LEP_PRIO_SERIAL((LEP_DEC4_SCALAR & 8) != 0);
+        LEP_MARK("dc_serial"); LEP_PRIO_SERIAL((SCMASK & 8) != 0);
         const int sslot = ci * 48 + sctx;
-        typedef Serial<(LEP_DEC4_SCALAR & 8) != 0> SR;
+        typedef Serial<(SCMASK & 8) != 0> SR;
         SR sr(*this);
         int len = sr.template unary_from<0>(SR::U(lepwave::wave_read(PK0, 0)));
         if (len == 4) {
@@ -1177,5 +1180,6 @@ struct Dec4Wave {
         return 0;
     }
 };
+typedef Dec4WaveT<LEP_DEC4_SCALAR> Dec4Wave;
 
 }  // namespace lep4

@@ -135,7 +135,7 @@ __global__ void lep_selftest_kernel(uint32_t* mismatches) {
 
 // v4 decoder: serial part as uniform vector code, multi-bin interior windows, one merged edge round (lep_dec4.h).
 // WAVES = waves per SIMD the register allocation is held to.
-template <int WAVES>
+template <int WAVES, int SCMASK = LEP_DEC4_SCALAR>
 __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev* __restrict__ images, const SegDev* __restrict__ segs,
                                                            uint32_t* models, NSum* ns_area, const uint64_t* ns_offsets,
                                                            uint8_t* streams, uint32_t* stream_len, int32_t* status, uint32_t* bins) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64, WAVES) void lep_decode_v4_kernel(const ImageDev
     NSum* ns = ns_area + ns_offsets[s];
     reset_segment_state<lep3::kModelWords>(model, ns, img->ns_total, lane);
     __syncthreads();
-    lep4::Dec4Wave w;
+    lep4::Dec4WaveT<SCMASK> w;
 #ifdef LEP_PROF
     w.prof_begin(&g_prof4[s & 8191][0]);
 #endif
@@ -1369,10 +1369,14 @@ int lep_gpu_release_memory(lep_gpu* g) {
 }
 int lep_gpu_malloc(lep_gpu* g, size_t bytes, void** dptr) {
     HIPCHK(g, hipSetDevice(g->device));
-    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) {   // (no room: the caches first, pool included)
+    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) {   // (no room: the caches first, pool included, then the batch calls' staging)
         (void)hipGetLastError();
         if (int rc = lep_gpu_release_memory(g)) return rc;
-        HIPCHK(g, hipMalloc(dptr, bytes ? bytes : 16));
+        if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) {
+            (void)hipGetLastError();
+            lep_batch_release();
+            HIPCHK(g, hipMalloc(dptr, bytes ? bytes : 16));
+        }
     }
     return 0;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU visit: an optional parity subset, then the same measurement under several variants, back to back on one box.
 #
-#   scripts/gpu_ab.sh <tag> [-k "<pytest -k expression>"] [-b resident|batch4k|batch1080p|progressive|latency] [-e "<extra args of the bench>"] -- "<variant>" ...
+#   scripts/gpu_ab.sh <tag> [-k "<pytest -k expression>"] [-b resident|batch4k|batch1080p|progressive|latency|latency-decode] [-e "<extra args of the bench>"] -- "<variant>" ...
 #
 # A variant is a string of environment assignments ("" = the product as built): knobs of the library (LEP_DEC_WAVES=4,
 # LEP_ENC5_WCHUNKS=0, LEP_VMM_CHUNK_MB=64, LEP_BATCH_CHUNK_SEGMENTS=7168, GPU_MAX_HW_QUEUES=4, ...) or an experiment build of it
@@ -28,6 +28,7 @@ case $BENCH in
   batch1080p)  CMD="python scripts/bench_batch.py --images 1024 --unique 32 --width 1920 --height 1080 $EXTRA";;
   progressive) CMD="python scripts/bench_batch.py --images 256 --unique 8 --width 3840 --height 2160 --progressive $EXTRA";;
   latency)     CMD="python scripts/latency_writer_ab.py $EXTRA";;
+  latency-decode) CMD="python scripts/latency_decode_ab.py $EXTRA";;
   *) echo "unknown bench $BENCH"; exit 2;;
 esac
 i=0
