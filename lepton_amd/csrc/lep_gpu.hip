@@ -830,7 +830,9 @@ static int launch(lep_gpu* g, const lep_image_desc* images, int nimg, const lep_
             c += w * 4 >= base * 7 ? 3 : (w * 2 >= base * 3 ? 2 : (w * 4 >= base * 5 ? 1 : 0));   // ... + the quarter inside the octave
             cls[s] = c;
         }
-        if (hi * 2 > lo * 3) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls[a] > cls[b]; });
+        if (hi * 2 > lo * 3) {
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls[a] > cls[b]; });
+        }
     }
     for (int i = 0; i < nseg; ++i) {
         const int s = order[i];
