@@ -187,6 +187,10 @@ int lep_gpu_huffman_progressive_encode_device(lep_gpu *g, const lep_huffprog_ima
  * the zero-filled device frame images[i].blocks and writes images[i].mcuv + 1 records (bit position + last DC per MCU row,
  * final record: pad-bit pattern and status) at d_rows + images[i].rows_off.  lep_jpeg_open_gpu fills the struct. */
 #define LEP_HUFFDEC_EARLY_EOF 1          /* lep_huffdec_image.flags */
+#define LEP_HUFFDEC_RST_TABLE 2          /* ... a scan with restart intervals whose markers all stand where they should: their positions (uint32
+                                            offsets into the un-stuffed scan, (mcuc - 1) / rsti of them) follow the scan bytes at
+                                            scan + LEP_HUFFDEC_SCAN_ROOM(scan_len); every interval is then decoded by a lane of its own */
+#define LEP_HUFFDEC_SCAN_ROOM(scan_len) ((((size_t)(scan_len)) + 64 + 15) & ~(size_t)15)   /* scan bytes + zero padding, 16-byte multiple */
 #define LEP_HUFFDEC_ROW_TRUNCATED 0x40000000   /* final lep_huffdec_row.aux: the scan stopped in mid-image; .bitpos = blocks decoded (scan order) */
 typedef struct lep_huffdec_image {
     const uint8_t *scan;                 /* device: un-stuffed scan bytes, 16-byte aligned, followed by >= 32 zero bytes */
@@ -294,6 +298,9 @@ int lep_jpeg_finish_gpu_progressive(lep_jpeg *j, const lep_huffprogdec_scan *sca
 int lep_jpeg_plan_progressive_check(lep_jpeg *j, size_t jpeg_len, lep_huffprog_image *image, lep_huffprog_scan *scans,
                                     uint32_t *file_first, uint32_t *file_len, int cap, int *nscan, int *eligible);
 int lep_jpeg_scan_bytes(const lep_jpeg *j, const uint8_t **data, size_t *len);
+/* The restart markers of a file lep_jpeg_open_gpu flagged LEP_HUFFDEC_RST_TABLE: the offset in the un-stuffed scan bytes at which
+ * each stood.  The caller puts them, as uint32, at scan + LEP_HUFFDEC_SCAN_ROOM(scan_len) on the device. */
+int lep_jpeg_scan_restarts(const lep_jpeg *j, const uint32_t **pos, size_t *count);
 int lep_jpeg_finish_gpu(lep_jpeg *j, const lep_huffdec_row *rows);
 void lep_jpeg_close(lep_jpeg *j);
 int lep_jpeg_describe(const lep_jpeg *j, lep_image_desc *desc);          /* host pointers into j */

@@ -85,6 +85,7 @@ struct JpegFile {
     std::vector<uint32_t> scan_start;   // offset in `scan` where the entropy-coded bytes behind each SOS begin
     std::vector<std::pair<uint32_t, uint32_t>> scan_file_range;   // the same scans in the FILE: [first entropy-coded byte, the marker that ends them)
     std::vector<uint32_t> rst_cnt;  // RST markers seen per scan
+    std::vector<uint32_t> rst_pos;  // first scan: offset (in `scan`, the un-stuffed bytes) at which each of its restart markers stood
     std::vector<uint8_t> rst_err;   // wrongly placed RST markers at scan end, per scan
     bool early_eof = false;
     int padbit = -1;
@@ -142,6 +143,7 @@ int parse_jpeg(const uint8_t* data, size_t size, bool allow_progressive, JpegFil
 // GPU Huffman scan decode (lep_huffdec.h): host-side halves.  ScanDecodePlan / ScanDecodeRow are laid out exactly like
 // lephuff::HuffDecImage / HuffDecRow and the C ABI's lep_huffdec_image / lep_huffdec_row.
 constexpr int32_t kScanEarlyEof = 1;               // ScanDecodePlan::flags (== LEP_HUFFDEC_EARLY_EOF)
+constexpr int32_t kScanRstTable = 2;               // ... (== LEP_HUFFDEC_RST_TABLE): the restart positions follow the scan bytes (lep_jpeg_scan_restarts)
 constexpr int32_t kScanRowTruncated = 0x40000000;  // final ScanDecodeRow::aux (== LEP_HUFFDEC_ROW_TRUNCATED)
 struct ScanDecodePlan {
     const uint8_t* scan;

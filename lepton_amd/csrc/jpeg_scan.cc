@@ -327,6 +327,7 @@ static int split_file(const uint8_t* d, size_t n, JpegFile* jf) {
                 if (!rd1(&tmp)) { jf->early_eof = true; have_hdr = true; break; }
                 if (tmp == 0x00) { crst = 0; jf->scan.push_back(0xFF); }
                 else if (tmp == 0xD0 + (cpos & 7)) {
+                    if (scnc == 0) jf->rst_pos.push_back((uint32_t)jf->scan.size());
                     ++cpos; ++crst;
                     if (jf->rst_cnt.size() <= (size_t)scnc) jf->rst_cnt.resize(scnc + 1, 0);
                     ++jf->rst_cnt[scnc];
@@ -648,6 +649,15 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
     plan->ncomp = jf->ncomp; plan->mcuh = jf->mcuh; plan->mcuv = jf->mcuv; plan->mcuc = jf->mcuc; plan->rsti = jf->rsti;
     plan->flags = jf->early_eof ? kScanEarlyEof : 0;
     if (jf->early_eof && jf->rsti) return 0;   // (restart intervals in a cut file: the single-wave kernel has no notion of the cut)
+    // restart intervals: when the scan holds exactly the markers its length asks for -- one behind every rsti MCUs but the last run --
+    // their positions travel with the scan bytes and every interval is decoded by a lane of its own (lep_huffdec_simt.h); otherwise the
+    // single-wave kernel walks the scan as the reference does
+    if (jf->rsti > 0 && jf->mcuc > 0) {
+        const size_t want = (size_t)((jf->mcuc - 1) / jf->rsti);
+        bool ok = jf->rst_pos.size() == want && (jf->rst_cnt.empty() ? want == 0 : jf->rst_cnt[0] == want) && (jf->rst_err.empty() || jf->rst_err[0] == 0);
+        for (size_t q = 0; ok && q < want; ++q) ok = jf->rst_pos[q] <= jf->scan.size() && (q == 0 || jf->rst_pos[q] >= jf->rst_pos[q - 1]);
+        if (ok && want > 0) plan->flags |= kScanRstTable;
+    }
     for (int i = 0; i < jf->ncomp; ++i) {
         const Component& k = jf->comp[i];
         if (k.dc_tbl > 1 || k.ac_tbl > 1 || !jf->htab[0][k.dc_tbl].set || !jf->htab[1][k.ac_tbl].set) return 0;

@@ -180,6 +180,10 @@ int lep_jpeg_scan_bytes(const lep_jpeg* j, const uint8_t** data, size_t* len) {
     *data = j->jf.scan.data(); *len = j->jf.scan.size();
     return 0;
 }
+int lep_jpeg_scan_restarts(const lep_jpeg* j, const uint32_t** pos, size_t* count) {
+    *pos = j->jf.rst_pos.data(); *count = j->jf.rst_pos.size();
+    return 0;
+}
 int lep_jpeg_finish_gpu(lep_jpeg* j, const lep_huffdec_row* rows) {
     return lep::parse_jpeg_finish_gpu(&j->jf, reinterpret_cast<const lep::ScanDecodeRow*>(rows)) ? LEP_UNSUPPORTED_JPEG : 0;
 }

@@ -532,7 +532,8 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
         size_t scan_total = 0, rows_total = 0;
         int ngpu = 0;
         for (int k = 0; k < nl; ++k) if (on_gpu[k]) {
-            scan_off[k] = scan_total; scan_total += ((size_t)himg[k].scan_len + 64 + 15) & ~(size_t)15;
+            scan_off[k] = scan_total; scan_total += LEP_HUFFDEC_SCAN_ROOM(himg[k].scan_len);
+            if (himg[k].flags & LEP_HUFFDEC_RST_TABLE) scan_total += ((size_t)((himg[k].mcuc - 1) / himg[k].rsti) * 4 + 15) & ~(size_t)15;   // the restart positions behind the scan bytes
             row_off[k] = rows_total; rows_total += (size_t)himg[k].mcuv + 1;
             ++ngpu;
         }
@@ -580,7 +581,12 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                     return;
                 }
                 memcpy(s->h_scan + scan_off[k], p, len);
-                memset(s->h_scan + scan_off[k] + len, 0, (((size_t)himg[k].scan_len + 64 + 15) & ~(size_t)15) - len);
+                memset(s->h_scan + scan_off[k] + len, 0, LEP_HUFFDEC_SCAN_ROOM(himg[k].scan_len) - len);
+                if (himg[k].flags & LEP_HUFFDEC_RST_TABLE) {
+                    const uint32_t* rp = nullptr; size_t rn = 0;
+                    lep_jpeg_scan_restarts(parsed[c->live[k]], &rp, &rn);
+                    memcpy(s->h_scan + scan_off[k] + LEP_HUFFDEC_SCAN_ROOM(himg[k].scan_len), rp, rn * 4);
+                }
                 if (vraw_len[k]) memcpy(s->h_scan + vraw_off[k], jpgs[c->live[k]].data + vraw_first[k], vraw_len[k]);
             });
         }
@@ -620,7 +626,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             const bool simt = !(getenv("LEP_HUFFDEC_SIMT") && atoi(getenv("LEP_HUFFDEC_SIMT")) == 0);
             if (simt) {
                 std::vector<lep_huffdec_image> many, one;
-                for (const lep_huffdec_image& hi : launch) (hi.rsti ? one : many).push_back(hi);
+                for (const lep_huffdec_image& hi : launch) ((hi.rsti && !(hi.flags & LEP_HUFFDEC_RST_TABLE)) ? one : many).push_back(hi);
                 if (!many.empty()) { if (int rc = lep_gpu_huffman_decode_simt_device(g, many.data(), (int)many.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
                 if (!one.empty()) { if (int rc = lep_gpu_huffman_decode_device(g, one.data(), (int)one.size(), (lep_huffdec_row*)s->d_rows, s_huff)) return rc; }
             } else
@@ -652,7 +658,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
                 // kernel before the host parser is bothered: its frame is wiped first (pass C may have written part of it)
                 std::vector<lep_huffdec_image> again;
                 for (const lep_huffdec_image& hi : launch) {
-                    if (hi.rsti || ((rows[hi.rows_off + (size_t)hi.mcuv].aux >> 8) & 0x3fffff) == 0) continue;   // (bit 30: LEP_HUFFDEC_ROW_TRUNCATED, not a status)
+                    if ((hi.rsti && !(hi.flags & LEP_HUFFDEC_RST_TABLE)) || ((rows[hi.rows_off + (size_t)hi.mcuv].aux >> 8) & 0x3fffff) == 0) continue;   // (bit 30: LEP_HUFFDEC_ROW_TRUNCATED, not a status)
                     for (int cc = 0; cc < hi.ncomp; ++cc)
                         HIPOK(hipMemsetAsync(hi.blocks[cc], 0, (size_t)hi.bch[cc] * hi.vs[cc] * hi.mcuv * 128, s_huff));
                     again.push_back(hi);

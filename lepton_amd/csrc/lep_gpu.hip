@@ -389,7 +389,13 @@ __global__ void lep_huffman_simt_finish_kernel(const lephuff::HuffDecImage* __re
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= nimg) return;
     lephuff::HuffDecRow* last = rows + images[i].rows_off + images[i].mcuv;
-    last->aux = (last->aux & (255 | lephuff::kHuffDecRowTruncated)) | ((si[i].status & 0x3fffff) << 8);
+    int status = si[i].status & 0x3fffff;
+    if (images[i].flags & lephuff::kHuffDecRstTable) {      // restart intervals: the pad byte is what all intervals agreed on
+        const int pad = lephuff::simt_intervals_pad(si + i, &status);
+        last->aux = pad | (status << 8);
+        return;
+    }
+    last->aux = (last->aux & (255 | lephuff::kHuffDecRowTruncated)) | (status << 8);
 }
 
 }  // namespace
@@ -1212,7 +1218,8 @@ int lep_gpu_huffman_decode_simt_device(lep_gpu* g, const lep_huffdec_image* imag
     if (!g) return LEP_GPU_ERROR;
     if (nimg <= 0) return 0;
     uint64_t bits = 0;
-    for (int i = 0; i < nimg; ++i) { if (images[i].rsti) return LEP_ASSERTION_FAILURE; bits += (uint64_t)images[i].scan_len * 8u; }   // restart intervals: the single-wave kernel's
+    // (restart intervals: only with the markers' positions behind the scan bytes -- LEP_HUFFDEC_RST_TABLE; the others are the single-wave kernel's)
+    for (int i = 0; i < nimg; ++i) { if (images[i].rsti && !(images[i].flags & LEP_HUFFDEC_RST_TABLE)) return LEP_ASSERTION_FAILURE; bits += (uint64_t)images[i].scan_len * 8u; }
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
     HIPCHK(g, hipSetDevice(g->device));
     // subsequences: as many as fill the chip a few times over (lanes = 64 x the wavefronts it holds, twice), but none shorter than a scan
@@ -1230,7 +1237,12 @@ int lep_gpu_huffman_decode_simt_device(lep_gpu* g, const lep_huffdec_image* imag
         for (int ci = 0; ci < images[i].ncomp && ci < 4; ++ci) { const int cmp = images[i].scan_cmp[ci] & 3; nblocks += (uint64_t)images[i].hs[cmp] * images[i].vs[cmp]; }
         nblocks *= (uint64_t)std::max(images[i].mcuc, 1);
         const uint32_t Li = g->simt_sub_bits ? L : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(L, (64 * b / std::max<uint64_t>(nblocks, 1) + 31) & ~(uint64_t)31), 1u << 24);
-        const uint32_t n = (uint32_t)std::max<uint64_t>(1, (b + Li - 1) / Li);
+        uint32_t n = (uint32_t)std::max<uint64_t>(1, (b + Li - 1) / Li);
+        if (images[i].flags & LEP_HUFFDEC_RST_TABLE) {        // lane = restart interval; the pad patterns' and / or / count start from 0xff / 0 / 0
+            if (images[i].rsti <= 0 || images[i].mcuc <= 0) return LEP_ASSERTION_FAILURE;
+            n = (uint32_t)((images[i].mcuc - 1) / images[i].rsti) + 1u;
+            si[(size_t)i].changed[0] = 0xff;
+        }
         si[(size_t)i].first = (uint32_t)nsub_all; si[(size_t)i].nsub = n; si[(size_t)i].sub_bits = Li;
         for (uint32_t f = 0; f < n; f += 64) waves.push_back(lephuff::SimtWave{(uint32_t)i, f});
         nsub_all += n;

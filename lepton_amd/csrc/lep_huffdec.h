@@ -26,6 +26,8 @@ using lep3::uni;
 using lep3::vec;
 
 constexpr int32_t kHuffDecEarlyEof = 1;              // HuffDecImage::flags
+constexpr int32_t kHuffDecRstTable = 2;              // ... the restart positions follow the scan bytes at scan + huffdec_scan_room(scan_len)
+WDEV uint32_t huffdec_scan_room(uint32_t scan_len) { return (scan_len + 64u + 15u) & ~15u; }
 constexpr int32_t kHuffDecRowTruncated = 0x40000000; // final HuffDecRow::aux: the data ran out in mid-image; bitpos = blocks decoded
 struct HuffDecImage {       // one image, device-visible
     const uint8_t* scan;    // un-stuffed entropy-coded bytes (RSTn removed), 16-byte aligned, followed by >= 16 zero bytes

@@ -208,6 +208,7 @@ WDEV int simt_setup(const HuffDecImage* img, SimtShared* sh) {
 
 // passes A (settle = 0) and S (settle = 1..): `in` is read (S), `out` written
 WDEV void simt_guess_or_settle(const HuffDecImage* img, SimtShared* sh, SimtImage* si, const SimtSub* in, SimtSub* out, uint32_t first_sub, int settle) {
+    if (img->flags & kHuffDecRstTable) return;             // restart intervals: every piece's start is known (simt_write_intervals)
     if (settle > 0 && !si->changed[settle - 1]) {          // the pass before this one moved nothing: its states are the answer
         LANES(l) { const uint32_t i = first_sub + (uint32_t)l; if (i < si->nsub) out[i] = in[i]; }
         return;
@@ -258,6 +259,7 @@ WDEV void simt_guess_or_settle(const HuffDecImage* img, SimtShared* sh, SimtImag
 
 // pass P: one wavefront per image
 WDEV void simt_place(const HuffDecImage* img, SimtImage* si, const SimtSub* sub, SimtPlace* place, int passes) {
+    if (img->flags & kHuffDecRstTable) return;
     int nphase = 0;
     for (int ci = 0; ci < img->ncomp; ++ci) nphase += img->hs[img->scan_cmp[ci]] * img->vs[img->scan_cmp[ci]];
     const uint32_t nsub = si->nsub, total = (uint32_t)img->mcuc * (uint32_t)nphase;
@@ -292,9 +294,120 @@ WDEV void simt_place(const HuffDecImage* img, SimtImage* si, const SimtSub* sub,
     if (bad) { LANES(l) if (l == 0) si->status |= bad; }
 }
 
+// Scans with RESTART INTERVALS whose markers all stand where they should (kHuffDecRstTable): a restart marker is a piece boundary that
+// needs no guessing -- the bit stream is byte-aligned behind it, the DC predictors start from zero, and the MCU it starts with follows
+// from its number (decode_jpeg resets all three at every marker: jpgcoder.cc:2895-2910, 3230-3260).  The host splitter, which sees
+// every marker, sends their positions in the un-stuffed scan along behind the scan bytes; lane = interval: `sub` index i covers MCUs
+// [i * rsti, (i + 1) * rsti), starts at byte rst[i - 1] and must end -- last MCU, then the pad bits to the byte boundary -- exactly at
+// byte rst[i].  The pad-bit patterns of all intervals must agree (the reference notes the first one and takes offence at any other:
+// decode_scans); they are collected in si->changed[0..2] (and / or / count), which a restart-table image does not otherwise use.
+// Anything else -- a code that is none, an interval that ends elsewhere, differing pad bits -- sets the image's status: the
+// single-wave kernel and then the host parser decode the file the reference's way.
+WDEV void simt_write_intervals(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, SimtImage* si, HuffDecRow* rows_arena, uint32_t first_sub) {
+    const int nphase = simt_setup(img, sh);
+    const uint32_t nsub = si->nsub;                         // intervals
+    const uint32_t* rst = reinterpret_cast<const uint32_t*>(img->scan + huffdec_scan_room(img->scan_len));
+    HuffDecRow* rows = rows_arena + img->rows_off;
+    LANES(l) for (int w = 0; w < 32; ++w) tile->w[w * 64 + l] = 0u;
+    LSYNC();
+    LV(int, rc); LV(int, padv);
+    LANES(l) {
+        L(rc) = 0; L(padv) = -1;
+        TileHalf* tile_lane = reinterpret_cast<TileHalf*>(tile->w + l);
+        const uint32_t i = first_sub + (uint32_t)l;
+        if (i < nsub) {
+            const uint32_t first_byte = i ? rst[i - 1] : 0u, end_byte = i + 1 < nsub ? rst[i] : img->scan_len;
+            int bad = 0;
+            if (first_byte > end_byte || end_byte > img->scan_len) bad = 3;
+            if (!bad) {
+                SimtLane d;
+                d.img = img; d.sh = sh;
+                d.br.words = reinterpret_cast<const uint32_t*>(img->scan); d.br.nwords = (img->scan_len + 3) >> 2;
+                d.br.seek(first_byte * 8u);
+                const uint32_t end_bits = end_byte * 8u;
+                const int mcuh = img->mcuh;
+                int mcu = (int)(i * (uint32_t)img->rsti);
+                const int mcu_end = mcu + img->rsti < img->mcuc ? mcu + img->rsti : img->mcuc;
+                int row = mcu / mcuh, mx = mcu - row * mcuh;
+                int lastdc[4] = {0, 0, 0, 0};
+                for (; mcu < mcu_end && !bad; ++mcu) {
+                    for (int phase = 0; phase < nphase; ++phase) {
+                        if (phase == 0 && mx == 0) {       // hand-off record of the MCU row that starts here
+                            rows[row].bitpos = d.br.bitpos;
+                            for (int c = 0; c < 4; ++c) rows[row].last_dc[c] = (int16_t)lastdc[c];
+                            rows[row].aux = 0;
+                        }
+                        const int cmp = sh->ph_cmp[phase], v = sh->ph_v[phase], h = sh->ph_h[phase];
+                        int16_t* dst = img->blocks[cmp] + (int64_t)((row * img->vs[cmp] + v) * img->bch[cmp] + mx * img->hs[cmp] + h) * 64;
+                        int diff = 0;
+                        const bool fine = d.store_block(img->dc_tbl[cmp], 2 + img->ac_tbl[cmp], tile_lane, &diff);
+                        const int cur = cmp == 0 ? lastdc[0] : (cmp == 1 ? lastdc[1] : (cmp == 2 ? lastdc[2] : lastdc[3]));
+                        const int dc = (int16_t)(diff + cur);
+                        if (cmp == 0) lastdc[0] = dc; else if (cmp == 1) lastdc[1] = dc; else if (cmp == 2) lastdc[2] = dc; else lastdc[3] = dc;
+                        tile_lane[(49 >> 1) * 128 + (49 & 1)] = (uint16_t)dc;
+                        {
+                            typedef uint32_t Quad __attribute__((vector_size(16)));
+                            Quad* out = reinterpret_cast<Quad*>(dst);
+                            for (int q = 0; q < 8; ++q) {
+                                Quad v4;
+                                v4[0] = tile->w[(4 * q + 0) * 64 + l]; v4[1] = tile->w[(4 * q + 1) * 64 + l]; v4[2] = tile->w[(4 * q + 2) * 64 + l]; v4[3] = tile->w[(4 * q + 3) * 64 + l];
+                                tile->w[(4 * q + 0) * 64 + l] = 0u; tile->w[(4 * q + 1) * 64 + l] = 0u; tile->w[(4 * q + 2) * 64 + l] = 0u; tile->w[(4 * q + 3) * 64 + l] = 0u;
+                                out[q] = v4;
+                            }
+                        }
+                        if (!fine) { bad = 1; break; }
+                        if (d.br.bitpos > end_bits) { bad = 2; break; }       // ran into the next interval (or out of data) inside a block
+                    }
+                    if (++mx == mcuh) { mx = 0; ++row; }
+                }
+                if (!bad) {
+                    if (d.br.bitpos & 7u) L(padv) = d.unpad(255) & 255;      // (an interval that ends on a byte boundary says nothing about the pad bits)
+                    if (d.br.bitpos != end_bits) bad = 3;                      // bytes left over in front of the marker, or the pad bits ran past it
+                    else if (i + 1 == nsub) {                                  // the scan's end: the final record (its pad byte is filled in by the finish pass)
+                        rows[img->mcuv].bitpos = d.br.bitpos;
+                        for (int c = 0; c < 4; ++c) rows[img->mcuv].last_dc[c] = (int16_t)lastdc[c];
+                        rows[img->mcuv].aux = 255;
+                    }
+                }
+            }
+            L(rc) = bad;
+        }
+    }
+    // the intervals' pad patterns: all that were seen must be one and the same
+    LANES(l) {
+        if (L(padv) >= 0) {
+#if LEP_ON_GPU
+            atomicAnd(&si->changed[0], L(padv)); atomicOr(&si->changed[1], L(padv)); atomicAdd(&si->changed[2], 1);
+#else
+            si->changed[0] &= L(padv); si->changed[1] |= L(padv); si->changed[2] += 1;
+#endif
+        }
+    }
+    LV(int, any);
+    int all = 0;
+    for (int b = 1; b <= 2; b <<= 1) {
+        LANES(l) L(any) = (L(rc) & b) != 0;
+        if (lepwave::wave_ballot(any)) all |= b;
+    }
+    if (all) {
+#if LEP_ON_GPU
+        if (lep_lane_now() == 0) atomicOr(&si->status, all);
+#else
+        si->status |= all;
+#endif
+    }
+}
+// what the finish pass makes of a restart-table image's pad patterns: the status bit for patterns that differ, the pad byte of the final record
+WDEV int simt_intervals_pad(const SimtImage* si, int* status_bits) {
+    if (si->changed[2] == 0) return 255;                                    // never determined
+    if (si->changed[0] != si->changed[1]) { *status_bits |= 1; return 255; }
+    return si->changed[1] & 255;
+}
+
 // pass C; the image's status collects what the lanes find
 WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, SimtImage* si, const SimtSub* sub, const SimtPlace* place, HuffDecRow* rows_arena, uint32_t first_sub) {
     if (si->status) return;                                // pass P refused the image: the fallback decodes it
+    if (img->flags & kHuffDecRstTable) { simt_write_intervals(img, sh, tile, si, rows_arena, first_sub); return; }
     const int nphase = simt_setup(img, sh);
     const uint32_t scan_bits = img->scan_len * 8u, nsub = si->nsub, total = (uint32_t)img->mcuc * (uint32_t)nphase;
     // A file that ends inside its scan (no EOI; kHuffDecEarlyEof): the reference decodes block after block until the read that takes

@@ -259,6 +259,11 @@ extern "C" int emu_huffman_decode_image_simt(const lep_huffdec_image* img, lep_h
     memset(&si, 0, sizeof si);
     si.first = 0; si.sub_bits = L;
     si.nsub = (uint32_t)std::max<uint64_t>(1, ((uint64_t)im.scan_len * 8u + L - 1) / L);
+    if (im.flags & lephuff::kHuffDecRstTable) {   // lane = restart interval (lep_gpu_huffman_decode_simt_device)
+        if (im.rsti <= 0 || im.mcuc <= 0) return -1;
+        si.nsub = (uint32_t)((im.mcuc - 1) / im.rsti) + 1u;
+        si.changed[0] = 0xff;
+    }
     std::vector<lephuff::SimtSub> buf[2] = {std::vector<lephuff::SimtSub>(si.nsub), std::vector<lephuff::SimtSub>(si.nsub)};
     std::vector<lephuff::SimtPlace> place(si.nsub);
     for (int k = 0; k <= lephuff::kSimtSettle; ++k)
@@ -267,7 +272,12 @@ extern "C" int emu_huffman_decode_image_simt(const lep_huffdec_image* img, lep_h
     lephuff::simt_place(&im, &si, fin, place.data(), lephuff::kSimtSettle);
     static lephuff::SimtTile tile;
     for (uint32_t f = 0; f < si.nsub; f += 64) lephuff::simt_write(&im, &sh, &tile, &si, fin, place.data(), reinterpret_cast<lephuff::HuffDecRow*>(rows), f);
-    rows[im.mcuv].aux = (rows[im.mcuv].aux & (255 | lephuff::kHuffDecRowTruncated)) | ((si.status & 0x3fffff) << 8);   // (lep_huffman_simt_finish_kernel)
+    if (im.flags & lephuff::kHuffDecRstTable) {   // (lep_huffman_simt_finish_kernel)
+        int status = si.status & 0x3fffff;
+        const int pad = lephuff::simt_intervals_pad(&si, &status);
+        rows[im.mcuv].aux = pad | (status << 8);
+    } else
+    rows[im.mcuv].aux = (rows[im.mcuv].aux & (255 | lephuff::kHuffDecRowTruncated)) | ((si.status & 0x3fffff) << 8);
     if (settle_moved) for (int k = 0; k <= lephuff::kSimtSettle; ++k) settle_moved[k] = si.changed[k];
     if (nsub_out) *nsub_out = si.nsub;
     return 0;

@@ -1459,3 +1459,113 @@ def test_lane_per_unit_huffman_encoder_restores_files_cut_inside_their_scan(emu,
     got = out.tobytes()
     L.lep_free(out.data)
     assert got == jpg
+
+
+def _restart_interval_jpegs():
+    """[(name, bytes)]: fixtures with restart intervals (interleaved colour scans: the ones the lane-per-interval form takes), the
+    reference's own narrowrst.jpg, PIL files with intervals of one MCU / a few MCUs / one MCU row / several rows, and damaged ones"""
+    import io
+    import numpy as np
+    from PIL import Image
+    from conftest import ref_golden
+    out = [(n, golden(n)[0]) for n in ("rst_c420_176x112", "lay_mixed_rst_104x72", "lay_ids_pad0_64x64", "lay_440_640x480_2seg")]
+    out.append(("narrowrst", ref_golden("narrowrst")[0]))
+    rng = np.random.default_rng(77)
+    base = np.asarray(Image.fromarray(rng.integers(0, 256, (40, 60, 3), dtype=np.uint8), "RGB").resize((480, 320), Image.BICUBIC)).astype(np.int16)
+    img = Image.fromarray(np.clip(base + rng.normal(0, 10, base.shape), 0, 255).astype(np.uint8), "RGB")
+    for tag, kw in (("rst_1mcu", dict(restart_marker_blocks=1)), ("rst_7mcu", dict(restart_marker_blocks=7)), ("rst_row", dict(restart_marker_rows=1)),
+                    ("rst_3rows_444", dict(restart_marker_rows=3, subsampling="4:4:4")), ("rst_422_optimized", dict(restart_marker_blocks=11, subsampling="4:2:2", optimize=True))):
+        buf = io.BytesIO()
+        img.save(buf, format="JPEG", quality=88, **{"subsampling": "4:2:0", **kw})
+        out.append((tag, buf.getvalue()))
+    whole = dict(out)["rst_7mcu"]
+    sos = whole.find(b"\xff\xda")
+    marks = [i for i in range(sos, len(whole) - 1) if whole[i] == 0xFF and 0xD0 <= whole[i + 1] <= 0xD7]
+    dropped = whole[: marks[3]] + whole[marks[3] + 2:]                      # a marker missing: fewer markers than the scan's length asks for
+    moved = bytearray(whole); i = marks[5]; moved[i - 3: i + 2] = bytes([moved[i], moved[i + 1]]) + bytes(moved[i - 3: i]); moved = bytes(moved)   # a marker three bytes early
+    out += [("rst_marker_dropped", dropped), ("rst_marker_moved", moved)]
+    return out
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _restart_interval_jpegs()])
+def test_lane_per_restart_interval_huffman_decoder(emu, name):
+    """Scans with restart intervals on lep_huffdec_simt.h: the markers' positions travel behind the scan bytes (LEP_HUFFDEC_RST_TABLE) and
+    every interval is decoded by a lane of its own -- frame, hand-off records and pad bits must be the host parser's (the .lep written from
+    them == the host parser's == the reference's for the fixtures), or the kernel reports a status and the file goes the single-wave
+    kernel's / host parser's way; a file whose markers are not where its restart interval says is not flagged at all"""
+    from lepton_amd import abi
+    from lepton_amd.codec import LeptonError
+
+    jpg = dict(_restart_interval_jpegs())[name]
+    L = abi.lib()
+    try:
+        host = JpegImage(jpg)
+    except LeptonError:
+        host = None                                  # the reference refuses the damaged file: so must every path of ours
+    h = C.c_void_p()
+    img = abi.HuffDecImage()
+    ok = C.c_int(0)
+    rc = L.lep_jpeg_open_gpu(jpg, len(jpg), C.byref(h), C.byref(img), C.byref(ok))
+    if rc:
+        assert host is None
+        return
+    if not ok.value:
+        L.lep_jpeg_close(h)
+        pytest.skip("not eligible for the GPU scan decoder")
+    assert img.rsti > 0
+    damaged = name in ("rst_marker_dropped", "rst_marker_moved")
+    if name == "rst_marker_dropped":
+        assert not (img.flags & 2), "a scan with a marker missing must not be flagged LEP_HUFFDEC_RST_TABLE"
+    if not (img.flags & 2):
+        L.lep_jpeg_close(h)
+        pytest.skip("markers not where the restart interval says: the single-wave kernel's")
+    p, n = C.c_void_p(), C.c_size_t(0)
+    L.lep_jpeg_scan_bytes(h, C.byref(p), C.byref(n))
+    rp, rn = C.POINTER(C.c_uint32)(), C.c_size_t(0)
+    L.lep_jpeg_scan_restarts(h, C.byref(rp), C.byref(rn))
+    assert rn.value == (img.mcuc - 1) // img.rsti
+    room = (n.value + 64 + 15) & ~15
+    table = bytes(C.cast(rp, C.POINTER(C.c_uint8 * (4 * rn.value))).contents) if rn.value else b""
+    scan = C.create_string_buffer(C.string_at(p, n.value) + b"\0" * (room - n.value) + table + b"\0" * 64, room + len(table) + 64)
+    assert C.addressof(scan) % 8 == 0
+    img.scan = C.addressof(scan)
+    d = host.desc if host else None
+    gd = abi.ImageDesc()
+    planes = []
+    ncomp = img.ncomp
+    for c in range(ncomp):
+        b = C.create_string_buffer(img.bch[c] * img.vs[c] * img.mcuv * 128)
+        planes.append(b)
+        img.blocks[c] = C.cast(b, C.c_void_p).value
+    rows = (abi.HuffDecRow * (img.mcuv + 1))()
+    assert emu.emu_huffman_decode_image_simt(C.byref(img), rows, 8192, None, None) == 0
+    status = (rows[img.mcuv].aux >> 8) & 0x3fffff
+    if damaged or host is None:
+        assert status != 0 or L.lep_jpeg_finish_gpu(h, rows) != 0 or host is not None, "a damaged scan slipped through"
+    if status:
+        L.lep_jpeg_close(h)
+        assert damaged or host is None, "kernel reported an irregular scan on a clean fixture (status %d)" % status
+        return
+    if L.lep_jpeg_finish_gpu(h, rows) != 0:
+        L.lep_jpeg_close(h)
+        assert damaged or host is None
+        return
+    assert host is not None
+    for c in range(d.ncomp):
+        assert planes[c].raw[: d.nblocks(c) * 128] == C.string_at(d.blocks[c], d.nblocks(c) * 128), "component %d" % c
+    segs = host.plan()
+    streams, _ = ob.oracle_encode(d, segs)
+    want = host.write_lep(streams)
+    arr = (abi.Bytes * len(streams))()
+    keep = []
+    for i, s in enumerate(streams):
+        b = C.create_string_buffer(bytes(s), max(1, len(s)))
+        keep.append(b)
+        arr[i].data = C.cast(b, C.c_void_p).value
+        arr[i].len = arr[i].cap = len(s)
+    out = abi.Bytes()
+    assert L.lep_jpeg_write_lep(h, 0, arr, len(streams), C.byref(out)) == 0
+    got = out.tobytes()
+    L.lep_free(out.data)
+    L.lep_jpeg_close(h)
+    assert got == want

@@ -234,3 +234,39 @@ def test_gpu_scan_kernels_take_files_cut_inside_their_scan(gpu_codec):
     # and with the host Huffman coders: the same bytes
     leps_h, status, _ = gpu_codec.compress_batch(jpgs, verify=False, host_huffman=True)
     assert status == [0] * len(jpgs) and leps_h == leps
+
+
+@pytest.mark.gpu
+def test_gpu_lane_per_restart_interval_scan_decode_in_the_compress_pipeline(gpu_codec, monkeypatch):
+    """files with restart intervals through lep_compress_batch: the lane-per-interval form of lep_huffdec_simt.h takes the scans whose
+    markers stand where they should (the positions travel behind the scan bytes), the single-wave kernel and the host parser the others
+    -- the .lep is the per-file path's whichever way a file went, == the reference's for the fixtures; a second codec object with the
+    lane-per-piece kernels switched off gives the same bytes"""
+    import test_core_emulation as emu_tests
+    from conftest import golden
+    from lepton_amd.codec import GpuCodec
+
+    cases = emu_tests._restart_interval_jpegs()
+    jpgs = [j for _, j in cases] + [ref_golden("trailingrst")[0], ref_golden("trailingrst2")[0], golden("rst_rows_gray_64x96")[0]]
+    want = []
+    for j in jpgs:
+        try:
+            want.append(gpu_codec.compress(j))
+        except LeptonError as e:
+            want.append(e.code)
+    got, status, stats = gpu_codec.compress_batch(jpgs, verify=False)
+    for g, s, w in zip(got, status, want):
+        assert (g if s == 0 else s) == w
+    names = [n for n, _ in cases]
+    for n in ("rst_c420_176x112", "lay_mixed_rst_104x72", "lay_ids_pad0_64x64", "lay_440_640x480_2seg"):
+        assert got[names.index(n)] == golden(n)[1], n
+    assert stats["gpu_huffman_files"] >= 9, stats
+    monkeypatch.setenv("LEP_HUFFDEC_SIMT", "0")
+    other = GpuCodec(0)
+    try:
+        got2, status2, _ = other.compress_batch(jpgs, verify=False)
+        assert status2 == status and got2 == got
+    finally:
+        other.close()
+    back, st, _ = gpu_codec.decompress_batch([g for g in got if g is not None])
+    assert st == [0] * len(back) and back == [j for j, g in zip(jpgs, got) if g is not None]
