@@ -1002,7 +1002,11 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     hipStream_t s_copy = nullptr, s_compute = nullptr, s_compute_b = nullptr, s_down = nullptr, s_scan = nullptr;
     StreamSet stream_set;
     stream_set.g = g;
-    if (stream_set.make(&s_copy) || stream_set.make(&s_compute) || stream_set.make(&s_compute_b) || stream_set.make(&s_down) || stream_set.make(&s_scan)) return LEP_GPU_ERROR;
+    if (stream_set.make(&s_copy) || stream_set.make(&s_compute) || stream_set.make(&s_down) || stream_set.make(&s_scan)) return LEP_GPU_ERROR;
+    // (No fifth stream: the runtime deals its 8 hardware queues out to streams in turn, the codec holds three streams of its own, and
+    // the stream that then SHARES a queue with the compute stream has its work -- the next chunk's upload, say -- run behind the decode
+    // kernel: measured, 0.77 s of a 1.9 s call (LEP_BATCH_TRACE).  The scan stream is free unless LEP_BATCH_SCAN_STREAM=1 asks for it.)
+    s_compute_b = s_scan;
     // Consecutive chunks' decode kernels on TWO streams (and the codec's two workspace sets) where that pays: a launch is over when its
     // longest thread segment is, and while the long segments of a ragged chunk (1080p files beside 4K ones; a chunk that does not fill the
     // chip) run on, the wave slots its short ones have left stand empty -- the next chunk's launch, longest segments first, moves into them
@@ -1015,6 +1019,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     // next chunk's decode kernel for wave slots it fills completely, finish when it does, and hold the chunk's download back:
     // 1530 against 1774 MB/s (profiles/r06j_*).
     if (!(getenv("LEP_BATCH_SCAN_STREAM") && atoi(getenv("LEP_BATCH_SCAN_STREAM")) == 1)) s_scan = s_compute;
+    else { s_compute_b = nullptr; dec_overlap = 0; }   // (the second compute stream IS the scan stream)
     Slot* slots = g_slots;
     g_alloc_s = 0;
     int rc_all = 0;
@@ -1058,8 +1063,10 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         }
         c->seg_first.push_back((int)c->segs.size());
         if (int rc = slot_reserve(s, c->frame_bytes, c->offs.back() + 256, c->segs.size(), c->live.size(), false, c->offs.back() + 256)) return rc;
+        if (getenv("LEP_BATCH_TRACE")) fprintf(stderr, "[batch]   %s (t=%.3f)\n", "slot reserved", now_s() - t_pipe0);
         const double t0 = now_s();
         parallel_for((int)c->segs.size(), threads, [&](int q) { if ((*lens)[q]) memcpy(s->h_streams + c->offs[q], src[q], (*lens)[q]); });
+        if (getenv("LEP_BATCH_TRACE")) fprintf(stderr, "[batch]   %s (t=%.3f)\n", "streams staged", now_s() - t_pipe0);
         st.stage_s += now_s() - t0;
         // geometry of every frame (the frames themselves are decoded into device memory)
         c->host_desc.resize(c->live.size());
@@ -1139,6 +1146,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
             for (size_t k = 0; k < c->live.size(); ++k)
                 if (c->hfirst[k] < 0 && c->pfirst[k] < 0) lep_file_describe_into(files[c->live[k]], s->h_frames + c->frame_off[k], fbytes[c->live[k]], &c->host_desc[k]);
         }
+        if (getenv("LEP_BATCH_TRACE")) fprintf(stderr, "[batch]   %s (t=%.3f)\n", "plans made", now_s() - t_pipe0);
         HIPOK(hipMemcpyAsync(s->d_streams, s->h_streams, c->offs.back(), hipMemcpyHostToDevice, s_copy));
         HIPOK(hipMemcpyAsync(s->d_len, lens->data(), lens->size() * 4, hipMemcpyHostToDevice, s_copy));
         // The decode kernel stores every coefficient of every block it decodes: only a file whose frame holds blocks that are NOT coded
@@ -1150,6 +1158,7 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
             for (int cc = 0; cc < d.ncomp; ++cc) whole = whole && d.coded_blocks[cc] == d.width_blocks[cc] * d.height_blocks[cc];
             if (!whole) HIPOK(hipMemsetAsync(s->d_frames + c->frame_off[k], 0, fbytes[c->live[k]], s_copy));
         }
+        if (getenv("LEP_BATCH_TRACE")) fprintf(stderr, "[batch]   %s (t=%.3f)\n", "copies queued", now_s() - t_pipe0);
         HIPOK(hipEventRecord(s->up, s_copy));
         HIPOK(hipStreamSynchronize(s_copy));   // `lens` / pinned arena are reused by the caller
         st.h2d_bytes += (double)c->offs.back();
@@ -1223,17 +1232,41 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     int slot_i = 0;
     if (int rc = stage_and_upload(cur.get(), &slots[0], &chunk_lens[0])) rc_all = rc;
     const double t_pipe = now_s();
+    // A host-to-device copy does not run beside a decode kernel on this platform (kernel + copy traces of rounds 4 and 5: the copies sit in
+    // the gaps between the kernels; LEP_BATCH_TRACE: the upload of chunk k + 1 returns when chunk k's kernel ends).  For chunks of equal
+    // segments that costs nothing -- the next kernel could not start earlier anyway.  But the SECOND chunk of a ragged call is what should
+    // move into the wave slots the first one's short segments leave: so when the first chunk is ragged, the second is staged and uploaded
+    // BEFORE the first is launched, and both launches go out back to back (the second beside the first: launch_chunk).
+    bool second_is_staged = false;
+    if (!rc_all && cur && cur->count > 0 && dec_overlap != 0 && cur->first + cur->count < n) {
+        int64_t lo = INT64_MAX, hi = 0;
+        for (const lep_segment& sg : cur->segs) {
+            const lep_image_desc& d = cur->dev_desc[(size_t)sg.image];
+            const int y1 = sg.is_last ? d.height_blocks[0] : std::min<int>(sg.luma_y_end, d.height_blocks[0]);
+            const int64_t w = std::max<int64_t>(1, (int64_t)std::max(0, y1 - sg.luma_y_start) * d.width_blocks[0]);
+            lo = std::min(lo, w); hi = std::max(hi, w);
+        }
+        if (dec_overlap == 1 || hi * 2 > lo * 3 || cur->segs.size() < 6144) {
+            nxt = cut_chunk(cur->first + cur->count);
+            if (int rc = stage_and_upload(nxt.get(), &slots[1], &chunk_lens[1])) rc_all = rc;
+            second_is_staged = true;
+        }
+    }
     if (!rc_all && cur && cur->count > 0) rc_all = launch_chunk(cur.get(), &slots[0]);
+    if (!rc_all && second_is_staged && nxt && nxt->count > 0) rc_all = launch_chunk(nxt.get(), &slots[1]);
     while (!rc_all && cur && cur->count > 0) {
         Slot* s = &slots[slot_i];
         Chunk* c = cur.get();
         const int nseg = (int)c->segs.size(), nimg = (int)c->live.size();
         // stage the next chunk and queue its kernels behind this chunk's before fetching this chunk's results
         if (writer.joinable()) writer.join();
-        nxt = c->first + c->count < n ? cut_chunk(c->first + c->count) : nullptr;
-        if (nxt) {
-            if (int rc = stage_and_upload(nxt.get(), &slots[slot_i ^ 1], &chunk_lens[slot_i ^ 1])) { rc_all = rc; break; }
-            if (nxt->count > 0) { if (int rc = launch_chunk(nxt.get(), &slots[slot_i ^ 1])) { rc_all = rc; break; } }
+        if (second_is_staged) second_is_staged = false;   // (the call's second chunk: staged and launched above)
+        else {
+            nxt = c->first + c->count < n ? cut_chunk(c->first + c->count) : nullptr;
+            if (nxt) {
+                if (int rc = stage_and_upload(nxt.get(), &slots[slot_i ^ 1], &chunk_lens[slot_i ^ 1])) { rc_all = rc; break; }
+                if (nxt->count > 0) { if (int rc = launch_chunk(nxt.get(), &slots[slot_i ^ 1])) { rc_all = rc; break; } }
+            }
         }
         std::vector<int32_t> sts(nseg);
         std::vector<uint32_t> slens(c->hseg.size()), plens(c->pscan.size());

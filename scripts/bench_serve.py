@@ -73,6 +73,14 @@ def main():
         leps = [request(name, j, timeout=600) for j in uniq]           # also warms kernels
         assert all(l[:2] == b"\xcf\x84" for l in leps)
         assert [request(name, l, timeout=600) for l in leps[:2]] == uniq[:2]
+        # one client, one request at a time: what a lone caller waits (the reference's forked child answers a 4K file in ~280 / ~60 ms)
+        lat = {}
+        for label, payloads in (("compress", uniq), ("decompress", leps)):
+            ts = []
+            for i in range(12):
+                t0 = time.perf_counter(); request(name, payloads[i % len(payloads)], timeout=600); ts.append((time.perf_counter() - t0) * 1e3)
+            ts.sort()
+            lat[label] = {"p50_ms": round(ts[len(ts) // 2], 1), "min_ms": round(ts[0], 1), "max_ms": round(ts[-1], 1)}
         fan(name, uniq, min(args.requests, 1024), args.clients, args.procs)   # staging buffers of the batch pipeline
         mb = sum(len(uniq[i % len(uniq)]) for i in range(args.requests)) / 1e6
         tc, rc = fan(name, uniq, args.requests, args.clients, args.procs)
@@ -90,6 +98,7 @@ def main():
             args.requests, args.width, args.height, len(uniq), args.clients, "without verification" if args.skipverify else "with on-GPU round-trip verification"),
         "jpeg_MB": round(mb, 1), "compress_MBps": round(mb / tc, 1), "compress_requests_per_s": round(args.requests / tc, 1),
         "decompress_MBps": round(mb / td, 1), "decompress_requests_per_s": round(args.requests / td, 1),
+        "one_client_latency": lat,
         "answers": "every answer checked against the first (md5)", "server_log": err.strip().splitlines()[-1] if err.strip() else ""}))
 
 
