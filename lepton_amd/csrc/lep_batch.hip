@@ -1236,21 +1236,14 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
     // the gaps between the kernels; LEP_BATCH_TRACE: the upload of chunk k + 1 returns when chunk k's kernel ends).  For chunks of equal
     // segments that costs nothing -- the next kernel could not start earlier anyway.  But the SECOND chunk of a ragged call is what should
     // move into the wave slots the first one's short segments leave: so when the first chunk is ragged, the second is staged and uploaded
-    // BEFORE the first is launched, and both launches go out back to back (the second beside the first: launch_chunk).
+    // BEFORE the first is launched, and both launches go out back to back (the second beside the first: launch_chunk).  Behind a chunk
+    // of equal segments the second launch waits in stream order as before, and only saves its upload's place in the gap (~30 ms).
     bool second_is_staged = false;
     if (!rc_all && cur && cur->count > 0 && dec_overlap != 0 && cur->first + cur->count < n) {
-        int64_t lo = INT64_MAX, hi = 0;
-        for (const lep_segment& sg : cur->segs) {
-            const lep_image_desc& d = cur->dev_desc[(size_t)sg.image];
-            const int y1 = sg.is_last ? d.height_blocks[0] : std::min<int>(sg.luma_y_end, d.height_blocks[0]);
-            const int64_t w = std::max<int64_t>(1, (int64_t)std::max(0, y1 - sg.luma_y_start) * d.width_blocks[0]);
-            lo = std::min(lo, w); hi = std::max(hi, w);
-        }
-        if (dec_overlap == 1 || hi * 2 > lo * 3 || cur->segs.size() < 6144) {
-            nxt = cut_chunk(cur->first + cur->count);
-            if (int rc = stage_and_upload(nxt.get(), &slots[1], &chunk_lens[1])) rc_all = rc;
-            second_is_staged = true;
-        }
+        // (whether the second launch then goes BESIDE the first is launch_chunk's decision: only behind a ragged chunk)
+        nxt = cut_chunk(cur->first + cur->count);
+        if (int rc = stage_and_upload(nxt.get(), &slots[1], &chunk_lens[1])) rc_all = rc;
+        second_is_staged = true;
     }
     if (!rc_all && cur && cur->count > 0) rc_all = launch_chunk(cur.get(), &slots[0]);
     if (!rc_all && second_is_staged && nxt && nxt->count > 0) rc_all = launch_chunk(nxt.get(), &slots[1]);
