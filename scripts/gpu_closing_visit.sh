@@ -2,7 +2,7 @@
 # round 3 closing visit: the whole GPU suite, the default bench line (with extras) under the kernel trace, then the PMC passes
 # over the shipped kernels (separate --pmc runs, kernel trace only) -> profiles-ready files under gpurun_out/<tag>/
 set -u
-TAG=${1:-r3final}; export TMPDIR=/tmp
+TAG=${1:-r10z}; export TMPDIR=/tmp
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 t0=$(date +%s)
 if [ "${SKIP_TESTS:-0}" != 1 ]; then
@@ -31,6 +31,9 @@ if [ "${SKIP_BENCH:-0}" != 1 ]; then
   timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o b --output-format csv -- python bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err; echo "rocprof rc=$? ($(( $(date +%s)-t0 )) s)"
   for f in $(find $OUT/prof -name "*kernel_stats.csv"); do cp $f $OUT/rocprofv3_kernel_stats.csv; done
   rm -rf $OUT/prof
+fi
+if [ "${SERVE:-0}" = 1 ]; then   # the daemon: what one caller waits, then a small concurrent load (every answer checked)
+  timeout 600 python scripts/bench_serve.py --requests 256 --clients 64 --procs 4 --unique 8 > $OUT/serve_4k.json 2> $OUT/serve_4k.err; echo "serve rc=$? ($(( $(date +%s)-t0 )) s)"; head -c 1200 $OUT/serve_4k.json; echo
 fi
 if [ "${SKIP_PMC:-0}" = 1 ] || [ "${PMC_FIRST:-0}" = 1 ]; then echo "total $(( $(date +%s)-t0 )) s"; exit 0; fi
 pmc_passes
