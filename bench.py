@@ -237,6 +237,16 @@ class HipDevice:
     def sync(self):
         self.L.lep_gpu_sync(self.g)
 
+    def footprint(self):
+        """what this rank holds on the host side once its phases have run: the batch pipeline's pinned staging and device arenas
+        (lep_batch_footprint), the host pool it runs its file splitting / container writing on"""
+        import ctypes
+
+        pinned, device = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self.L.lep_batch_footprint(ctypes.byref(pinned), ctypes.byref(device))
+        return {"pinned_MB": round(pinned.value / 1e6, 1), "staging_device_MB": round(device.value / 1e6, 1),
+                "host_threads": self.host_threads or usable_cpus()}
+
     def pipeline(self, jpgs, label, verify=False):
         # (no lep_gpu_trim between the phases by default.  Round 3 saw the 1080p figure halve after a trim and blamed the device heap; round
         # 4 found the cause -- the driver CLEARS the memory it hands out, 40 ms per GB, so a phase that gives 30 GB back and takes them
@@ -533,6 +543,7 @@ def main():
     rank, local_rank, world = shard.dist_env()
     stub = os.environ.get("LEP_BENCH_DEVICE") == "stub"   # tests/bench_stub.py: the CPU suite's stand-in for the device layer
     dist = None
+    numa_note = "not pinned (one rank)"
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -552,7 +563,8 @@ def main():
         dev = bench_stub.StubDevice(local_rank)
     else:
         if world > 1:
-            log("[rank %d] %s" % (rank, pin_to_gpu_numa_node(local_rank)))
+            numa_note = pin_to_gpu_numa_node(local_rank)
+            log("[rank %d] %s" % (rank, numa_note))
         dev = HipDevice(local_rank, host_threads=max(1, usable_cpus() // world) if world > 1 else 0, trim=args.trim_between_phases)
 
     def barrier():
@@ -616,6 +628,17 @@ def main():
     local.update(e2e_local)
     local.update(mixed_local)
     agg = shard.aggregate(local, backend_device=("cuda:%d" % local_rank) if (dist and not stub) else None)
+    # per rank, for reading a multi-GPU run without a second visit: the host side of each rank (threads, CPUs, pinned staging, NUMA
+    # placement) next to what it took of the wall clock -- the same counters the sums / maxima above were made of
+    mine_rec = dict(dev.footprint(), rank=rank, local_rank=local_rank, cpus_allowed=len(os.sched_getaffinity(0)), numa=numa_note,
+                    resident_s=round(res["elapsed"], 4), enc_ms=round(res["enc_ms"] / max(1, args.steps), 3), dec_ms=round(res["dec_ms"] / max(1, args.steps), 3),
+                    e2e_compress_s=round(e2e_local["e2e_c_s_max"], 4), e2e_decompress_s=round(e2e_local["e2e_d_s_max"], 4),
+                    mixed_files=int(mixed_local["mixed_files"]), mixed_MB=round(mixed_local["mixed_bytes"] / 1e6, 2),
+                    mixed_compress_s=round(mixed_local["mixed_c_s_max"], 4), mixed_decompress_s=round(mixed_local["mixed_d_s_max"], 4))
+    per_rank = [mine_rec]
+    if dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_rec)
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -660,6 +683,7 @@ def main():
                      "encode_stages_ms": dict(zip(("count_plan", "emit", "fold", "gather", "write"), res["encode_stages_ms"])) if res.get("encode_stages_ms") else None, "bound_by": pmc_bound(names.get(dominant, "")),
                      "note": "frac = algorithmic bytes (128 B per block + stream bytes) / kernel time / 8 TB/s; traffic = HBM bytes from the memory-side request counters of the committed PMC passes (profiles/pmc_traffic.json) for THIS launch size (null for a size that was not measured: never scaled) -- `traffic_source.stale` says whether those passes were taken from the kernel sources measured here; bound_by = what those passes say limits the kernel (DESIGN.md 4)"},
     }
+    out["per_rank"] = per_rank
     if bins_per_image:
         bins_launch = bins_per_image * args.images
         out["bins_per_s"] = {"encode": round(bins_launch / enc_kernel_s / 1e6, 1), "decode": round(bins_launch / dec_kernel_s / 1e6, 1), "unit": "Mbins/s (per GPU, image 0's bin count x images)"}

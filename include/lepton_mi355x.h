@@ -436,6 +436,8 @@ int lep_batch_plan(const size_t *file_bytes, const size_t *frame_bytes, int n, c
  * the process started (their files went to the host parser; expected 0 -- the wait cannot deadlock, the count is the safety net's) */
 uint64_t lep_jpeg_gpu_scan_wait_timeouts(void);
 void lep_batch_release(void);   /* frees the staging buffers the two calls above keep between invocations (not re-entrant) */
+/* what the batch calls keep between invocations: pinned host bytes / device bytes of the large staging arenas (either pointer may be NULL) */
+void lep_batch_footprint(size_t *pinned_bytes, size_t *device_bytes);
 /* test hook: overwrite the pinned staging buffers kept between batch calls with `value` (stale-staging regression tests) */
 void lep_batch_debug_poison(int value);
 

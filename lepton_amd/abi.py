@@ -209,6 +209,8 @@ def lib():
         L.lep_gpu_huffman_encode_device.argtypes = [vp, P(HuffImage), C.c_int, P(HuffSegment), C.c_int, vp, vp, vp, vp]
         L.lep_batch_release.argtypes = []
         L.lep_batch_release.restype = None
+        L.lep_batch_footprint.argtypes = [P(C.c_size_t), P(C.c_size_t)]
+        L.lep_batch_footprint.restype = None
         L.lep_file_recode_plan_progressive.argtypes = [vp, P(HuffProgImage), P(HuffProgScan), C.c_int, P(C.c_int), P(C.c_int)]
         L.lep_file_recode_finish_progressive.argtypes = [vp, P(Bytes), C.c_int, P(Bytes)]
         L.lep_gpu_huffman_progressive_encode_device.argtypes = [vp, P(HuffProgImage), C.c_int, P(HuffProgScan), C.c_int, vp, vp, vp, vp]
@@ -240,7 +242,7 @@ EXPORTS = [
     "lep_gpu_free", "lep_gpu_memcpy_h2d", "lep_gpu_memcpy_d2h", "lep_gpu_memcpy_d2d", "lep_gpu_memset", "lep_jpeg_open", "lep_jpeg_close",
     "lep_jpeg_describe", "lep_jpeg_plan", "lep_jpeg_write_lep", "lep_file_open", "lep_file_close", "lep_file_describe",
     "lep_file_segments", "lep_file_jpeg_size", "lep_file_recode", "lep_compress", "lep_decompress", "lep_free",
-    "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_file_recode_plan", "lep_file_recode_finish", "lep_gpu_huffman_encode_device", "lep_jpeg_open_gpu", "lep_jpeg_scan_bytes", "lep_jpeg_scan_restarts", "lep_jpeg_finish_gpu", "lep_gpu_huffman_decode_device", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
+    "lep_version", "lep_jpeg_open_into", "lep_jpeg_peek_frame_bytes", "lep_file_describe_into", "lep_file_frame_bytes", "lep_jpeg_is_progressive", "lep_compress_batch", "lep_decompress_batch", "lep_batch_release", "lep_batch_footprint", "lep_file_recode_plan", "lep_file_recode_finish", "lep_gpu_huffman_encode_device", "lep_jpeg_open_gpu", "lep_jpeg_scan_bytes", "lep_jpeg_scan_restarts", "lep_jpeg_finish_gpu", "lep_gpu_huffman_decode_device", "lep_handoffs_serialize", "lep_handoffs_parse", "lep_mux", "lep_demux",
     "lep_serve_start", "lep_serve_get_stats", "lep_serve_stop", "lep_zlib0_wrap", "lep_jpeg_open_slice", "lep_compress_slice", "lep_jpeg_open_embedded", "lep_compress_embedded", "lep_gpu_use_arena", "lep_gpu_expect_company", "lep_gpu_settle_uploads", "lep_batch_plan", "lep_jpeg_set_encode_options", "lep_gpu_huffman_decode_simt_device",
     "lep_jpeg_check_restores", "lep_jpeg_gpu_scan_wait_timeouts", "lep_batch_debug_poison", "lep_jpeg_plan_handoffs", "lep_file_consumed", "lep_chained_file_follows", "lep_file_open_next",
     "lep_file_recode_plan_progressive", "lep_file_recode_finish_progressive", "lep_gpu_huffman_progressive_encode_device",

@@ -387,6 +387,19 @@ extern "C" {
 // frees the pinned / device staging buffers the batch calls keep between invocations
 void lep_batch_release(void) { for (Slot& s : g_slots) s.release(); }
 
+// what the batch calls keep between invocations: bytes of pinned host memory, and of device memory in the large arenas
+// (frames, scratch frames, stream / scan arenas, row records; the per-segment tables are KBs and not counted)
+void lep_batch_footprint(size_t* pinned_bytes, size_t* device_bytes) {
+    size_t pinned = 0, device = 0;
+    for (const Slot& s : g_slots) {
+        pinned += (s.h_frames ? s.hframes_cap : 0) + (s.h_streams ? s.hstreams_cap : 0) + (s.h_scan ? s.scan_cap : 0) + (s.h_pscan ? s.hpscan_cap : 0);
+        device += (s.d_frames ? s.frames_cap : 0) + (s.d_scratch ? s.frames_cap : 0) + (s.d_streams ? s.streams_cap : 0) + (s.d_scan ? s.scan_cap : 0)
+                  + (s.d_rows ? s.rows_cap : 0) + (s.d_pscan ? s.pscan_cap : 0) + (s.d_corr ? s.corr_cap * 4 : 0) + (s.d_vscan ? s.vscan_cap : 0);
+    }
+    if (pinned_bytes) *pinned_bytes = pinned;
+    if (device_bytes) *device_bytes = device;
+}
+
 // test hook: fills every pinned staging buffer the batch calls keep between invocations with `value`, so that a test can
 // show that nothing stale from an earlier batch (the padding between frames, the tails of streams) reaches a result
 void lep_batch_debug_poison(int value) {

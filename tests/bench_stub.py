@@ -22,6 +22,9 @@ class StubDevice:
     def sync(self):
         pass
 
+    def footprint(self):
+        return {"pinned_MB": 0.0, "staging_device_MB": 0.0, "host_threads": 1}
+
     def resident(self, uniq, images, steps, warmup, barrier, check_parity=True, with_latency=False):
         nb = sum(len(uniq[i % len(uniq)]) for i in range(images))
         barrier()

@@ -46,6 +46,10 @@ def test_gpus_2_starts_two_ranks_and_shards_the_mixed_corpus(tmp_path):
     assert out["mixed"]["scaling"] == "strong" and out["mixed"]["n_gpus"] == 2
     assert abs(out["mixed"]["jpeg_MB"] * 1e6 - sum(b)) < 1e5
     assert out["end_to_end"]["n_gpus"] == 2
+    # every rank's host side is in the line: threads, CPUs, pinned staging, its share of the mixed corpus and of the wall clock
+    pr = out["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all({"host_threads", "pinned_MB", "cpus_allowed", "numa", "resident_s", "mixed_compress_s"} <= set(r) for r in pr)
+    assert sum(r["mixed_files"] for r in pr) == 12 and max(r["mixed_compress_s"] for r in pr) > 0
     # one definition of MB/s in the whole line
     for fig in (out["mixed"], out["end_to_end"]):
         assert abs(1 / fig["value"] - (1 / fig["compress_MBps"] + 1 / fig["decompress_MBps"])) / (1 / fig["value"]) < 0.08   # (figures are rounded to 0.1 MB/s)
@@ -54,6 +58,7 @@ def test_gpus_2_starts_two_ranks_and_shards_the_mixed_corpus(tmp_path):
 def test_one_rank_runs_the_same_corpus_alone(tmp_path):
     out, notes = run_bench(tmp_path, [])
     assert out["n_gpus"] == 1 and out["mixed"]["files"] == 12 and out["mixed"]["n_gpus"] == 1
+    assert len(out["per_rank"]) == 1 and out["per_rank"][0]["mixed_files"] == 12
     assert [n["rank"] for n in notes if n["what"] == "resident"] == [0]
 
 
@@ -78,7 +83,7 @@ def test_gpus_8_codes_the_ten_thousand_file_corpus_once(tmp_path):
     eight ranks, every rank generates ONLY its own share of the 10,000 distinct files (seeds 20000..29999, dealt by size class -- no
     rank needs the others' bytes to know its share), the line says n_gpus 8, mixed.files 10000, and that one point is not a curve."""
     out, notes = run_bench(tmp_path, ["--gpus", "8", "--mixed-images", "10000", "--mixed-distinct", "10000", "--mixed-shapes", "32x24,64x48", "--no-end-to-end"])
-    assert out["n_gpus"] == 8
+    assert out["n_gpus"] == 8 and [r["rank"] for r in out["per_rank"]] == list(range(8))
     mixed = [n for n in notes if n["what"] == "pipeline" and n["label"].startswith("mixed")]
     assert sorted(n["rank"] for n in mixed) == list(range(8))
     assert sum(n["files"] for n in mixed) == 10000 == out["mixed"]["files"] and out["mixed"]["distinct"] == 10000
