@@ -150,8 +150,9 @@ typedef struct lep_huff_end {
     int16_t last_dc[4];
     uint16_t pad;
 } lep_huff_end;
-/* d_ends: nseg records in device memory, or NULL.  Segments of MCU-interleaved scans without restart intervals are written with one
- * lane per run of eight MCUs (lep_huff_simt.h: count, prefix sums, code, stuff), the others with one wavefront per segment (lep_huff.h);
+/* d_ends: nseg records in device memory, or NULL.  Segments of MCU-interleaved scans (with or without restart intervals) are written with one
+ * lane per run of at most eight MCUs (lep_huff_simt.h: count, prefix sums, code, stuff; a run ends where its restart interval does and
+ * carries the pad bits and the marker), the others with one wavefront per segment (lep_huff.h);
  * same bytes, same end states (LEP_HUFFENC_SIMT=0: the wavefront form for all).  `pad` of a segment is the library's: pass it as 0 (lep_file_recode_plan does).
  * The call copies its arrays before it returns and does not wait for the stream. */
 int lep_gpu_huffman_encode_device(lep_gpu *g, const lep_huff_image *images, int nimg, const lep_huff_segment *segs, int nseg,
@@ -237,8 +238,9 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu *g, const lep_huffprogdec_
 /* The same result with one LANE per subsequence (lep_huffdec_simt.h; the batch compressor's default): a scan is cut into thousands of subsequences, every lane decodes one with a
  * bit reader of its own -- a guess from its first bit, settle passes from where the lane in front ended until no end state moves,
  * a prefix sum, a write pass into the ZERO-FILLED frame.  Same records, same frame, same status semantics as the single-wave
- * kernel (bit-exact against it on MI355X and in the lane-loop emulation); scans with restart intervals are refused
- * (LEP_ASSERTION_FAILURE: the single-wave kernel's).  LEP_HUFFDEC_SIMT_BITS forces the subsequence length (tests). */
+ * kernel (bit-exact against it on MI355X and in the lane-loop emulation); scans with restart intervals are taken when the image
+ * carries LEP_HUFFDEC_RST_TABLE (lane = restart interval) and refused otherwise (LEP_ASSERTION_FAILURE: the single-wave kernel's).
+ * LEP_HUFFDEC_SIMT_BITS forces the subsequence length (tests). */
 int lep_gpu_huffman_decode_simt_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, lep_huffdec_row *d_rows, void *hip_stream);
 /* plain device memory helpers so non-torch callers need no HIP binding */
 /* Device self-test of kernel arithmetic that has no CPU twin (exhaustive: the float-reciprocal Branch probability of the

@@ -312,8 +312,9 @@ __global__ __launch_bounds__(64) void lep_huffman_simt_encode_units_kernel(const
     const lephuff::SimtEncWave w = waves[blockIdx.x];
     lephuff::simt_enc_units<WRITE>(images, segs, es + w.eseg, &sh, unit_bits, scratch, w.first_unit);
 }
-__global__ __launch_bounds__(64) void lep_huffman_simt_encode_place_kernel(const lephuff::HuffSegment* __restrict__ segs, lephuff::SimtEncSeg* es, uint32_t* unit_bits) {
-    lephuff::simt_enc_place(segs, es + blockIdx.x, unit_bits);
+__global__ __launch_bounds__(64) void lep_huffman_simt_encode_place_kernel(const lephuff::HuffImage* __restrict__ images, const lephuff::HuffSegment* __restrict__ segs,
+                                                                           lephuff::SimtEncSeg* es, uint32_t* unit_bits, uint32_t* unit_plain) {
+    lephuff::simt_enc_place(images, segs, es + blockIdx.x, unit_bits, unit_plain);
 }
 __global__ __launch_bounds__(64) void lep_huffman_simt_encode_stuff_kernel(const lephuff::HuffImage* __restrict__ images, const lephuff::HuffSegment* __restrict__ segs,
                                                                            const lephuff::SimtEncSeg* __restrict__ es, uint8_t* scratch, uint8_t* out, uint32_t* out_len,
@@ -1056,18 +1057,21 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
             if (!lephuff::simt_enc_takes(im, reinterpret_cast<const lephuff::HuffSegment&>(sv[(size_t)i]))) continue;
             lephuff::SimtEncSeg e;
             memset(&e, 0, sizeof e);
-            const size_t mcus = (size_t)(sv[(size_t)i].mcu_row1 - sv[(size_t)i].mcu_row0) * (size_t)im.mcuh;
-            e.seg = (uint32_t)i; e.first_unit = (uint32_t)nunits; e.nunits = (uint32_t)((mcus + lephuff::kSimtMcus - 1) / lephuff::kSimtMcus);
+            if ((int64_t)sv[(size_t)i].mcu_row1 * im.mcuh > 0x7fffffff) continue;
+            lephuff::SimtUnitMap map;
+            map.set(sv[(size_t)i].mcu_row0 * im.mcuh, sv[(size_t)i].mcu_row1 * im.mcuh, im.rsti);
+            e.seg = (uint32_t)i; e.first_unit = (uint32_t)nunits; e.nunits = map.count();
             e.buf_off = scratch_bytes; e.buf_bytes = (uint32_t)std::min<size_t>(((size_t)sv[(size_t)i].out_cap + 64 + 15) & ~(size_t)15, 0xfffffff0u);
+            e.map_bytes = im.rsti > 0 ? ((e.buf_bytes >> 3) + 15u) & ~15u : 0u;   // restart intervals: which bytes of the bit buffer are markers
             if (nunits + e.nunits > 0x7fffffffu) continue;
             for (uint32_t f = 0; f < e.nunits; f += 64) waves.push_back(lephuff::SimtEncWave{(uint32_t)es.size(), f});
-            nunits += e.nunits; scratch_bytes += e.buf_bytes;
+            nunits += e.nunits; scratch_bytes += (size_t)e.buf_bytes + e.map_bytes;
             sv[(size_t)i].pad = lephuff::kHuffSegSimt;
             es.push_back(e);
         }
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_es = 0, o_wv = up(es.size() * sizeof(lephuff::SimtEncSeg)), o_ub = o_wv + up(waves.size() * sizeof(lephuff::SimtEncWave)),
-                 o_sc = o_ub + up(nunits * 4), simt_total = o_sc + up(scratch_bytes);
+                 o_sc = o_ub + up(nunits * 8), simt_total = o_sc + up(scratch_bytes);   // (units: bit counts / positions, and the plain prefix sum of scans with restart intervals)
     if (!es.empty()) { if (int rc = ensure(g, &g->d_huffenc, &g->huffenc_bytes, simt_total)) return rc; }
     if (int rc = upload(g, g->d_huff, images, nimg * sizeof(lep_huff_image), st)) return rc;           // (the caller's arrays and ours may go away)
     if (int rc = upload(g, (char*)g->d_huff + o_seg, sv.data(), nseg * sizeof(lep_huff_segment), st)) return rc;
@@ -1086,7 +1090,7 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
         uint32_t* dub = (uint32_t*)(eb + o_ub);
         uint8_t* dsc = (uint8_t*)(eb + o_sc);
         hipLaunchKernelGGL((lep_huffman_simt_encode_units_kernel<false>), dim3((unsigned)waves.size()), dim3(64), 0, st, di, ds, des, dwv, dub, dsc);
-        hipLaunchKernelGGL(lep_huffman_simt_encode_place_kernel, dim3((unsigned)es.size()), dim3(64), 0, st, ds, des, dub);
+        hipLaunchKernelGGL(lep_huffman_simt_encode_place_kernel, dim3((unsigned)es.size()), dim3(64), 0, st, di, ds, des, dub, dub + nunits);
         hipLaunchKernelGGL((lep_huffman_simt_encode_units_kernel<true>), dim3((unsigned)waves.size()), dim3(64), 0, st, di, ds, des, dwv, dub, dsc);
         hipLaunchKernelGGL(lep_huffman_simt_encode_stuff_kernel, dim3((unsigned)es.size()), dim3(64), 0, st, di, ds, (const lephuff::SimtEncSeg*)des, dsc, d_out, d_out_len,
                            (lephuff::HuffEnd*)d_ends);

@@ -15,8 +15,12 @@
 //              with the 00 behind every FF (16 bytes per lane and step, positions from a prefix sum of the FFs), clipped to
 //              the segment's byte bound; the partial byte, its bit count and the last DCs are the segment's end state.
 //
-// Segments of scans with restart intervals, of non-interleaved scans and of images whose scan ends inside its last MCU row keep
-// lep_huff.h's kernel (HuffSegment.pad bit 0 says which kernel owns a segment).  Same bytes, same end states as that kernel
+// Restart intervals (round 5): a unit never straddles an interval's end (SimtUnitMap); the unit an interval ends with appends the pad
+// bits and the two marker bytes to its own bits, a unit an interval starts with begins from zero predictors; pass 2 adds those bits
+// to the prefix sum (an interval starts on a byte, so its pad is its own bit count's), and a bit per buffer byte tells pass 4 which
+// FFs are markers and take no 00 (recoder.cc:364-400).
+// Segments of non-interleaved scans and of images whose scan ends inside its last MCU row keep lep_huff.h's kernel (HuffSegment.pad
+// bit 0 says which kernel owns a segment).  Same bytes, same end states as that kernel
 // (tests/emu, GPU parity tests); recoder.cc:245-412 is what both restate.
 #pragma once
 #include "lep_huff.h"
@@ -35,11 +39,56 @@ struct SimtEncSeg {         // per segment handled here
     uint32_t tail;          // pass 3: the stream's last partial byte (its total_bits & 7 bits, top-aligned) -- kept beside the buffer because a
                             // segment that overruns its byte bound is cut off in the buffer and still owes its true end state
     uint32_t cut;           // pass 2: a unit met the cut of a truncated file: the stream ends in front of it
-    uint32_t reserved;
+    uint32_t map_bytes;     // restart intervals: bytes of the marker map behind the bit buffer (bit q = byte q of the buffer is a marker's FF); else 0
 };
 constexpr uint32_t kUnitMetCut = 0x80000000u;   // pass 1, in a unit's bit count
 constexpr uint32_t kUnitDead = 0xffffffffu;     // pass 2, in place of a unit's position: it lies behind the cut
 struct SimtEncWave { uint32_t eseg, first_unit; };   // lane l = unit first_unit + l of SimtEncSeg eseg
+
+// Which MCUs a unit codes.  Without restart intervals: runs of kSimtMcus from the segment's first MCU.  With them a unit ends where its
+// interval does: the head (the segment's first MCU up to the first interval end in it) in runs of kSimtMcus, then every interval in
+// runs of kSimtMcus -- the last run of each as short as it comes out.
+#if LEP_ON_GPU
+#define LEPH_BOTH __host__ __device__ __forceinline__    // the launch code sizes its arrays with the same functions
+#else
+#define LEPH_BOTH inline
+#endif
+struct SimtUnitMap {
+    int m_begin, m_end, rsti, first_end, head_units, per_interval;
+    LEPH_BOTH void set(int mb, int me, int r) {
+        m_begin = mb; m_end = me; rsti = r > 0 ? r : 0;
+        first_end = me;
+        if (rsti) {
+            const int b = ((mb + rsti - 1) / rsti) * rsti;      // (mb itself when the segment starts where an interval does)
+            if (b < me) first_end = b;
+        }
+        head_units = (first_end - mb + kSimtMcus - 1) / kSimtMcus;
+        per_interval = rsti ? (rsti + kSimtMcus - 1) / kSimtMcus : 1;
+    }
+    LEPH_BOTH uint32_t count() const {
+        const int rest = m_end - first_end;
+        if (rest <= 0) return (uint32_t)head_units;
+        return (uint32_t)head_units + (uint32_t)(rest / rsti) * (uint32_t)per_interval + (uint32_t)((rest % rsti + kSimtMcus - 1) / kSimtMcus);
+    }
+    // unit u: its MCUs [m0, m1), and the unit its interval (or the head) starts with
+    LEPH_BOTH void span(uint32_t u, int* m0, int* m1, uint32_t* interval_first) const {
+        int from, to;
+        if (u < (uint32_t)head_units) { from = m_begin + (int)u * kSimtMcus; to = first_end; *interval_first = 0; }
+        else {
+            const uint32_t v = u - (uint32_t)head_units, iv = v / (uint32_t)per_interval, k = v - iv * (uint32_t)per_interval;
+            const int base = first_end + (int)iv * rsti;
+            from = base + (int)k * kSimtMcus;
+            to = base + rsti < m_end ? base + rsti : m_end;
+            *interval_first = (uint32_t)head_units + iv * (uint32_t)per_interval;
+        }
+        *m0 = from;
+        *m1 = from + kSimtMcus < to ? from + kSimtMcus : to;
+    }
+};
+// MCU m1 is where a restart interval ends inside the scan (next_mcupos, jpgcoder.cc: the end of the scan comes first)
+WDEV bool simt_interval_ends_at(const HuffImage* img, int m1) { return img->rsti > 0 && m1 % img->rsti == 0 && m1 < img->mcuc; }
+// ... and whether its marker is written (a truncated file counts the markers it had: rst_limit)
+WDEV bool simt_marker_written(const HuffImage* img, int m1) { return (uint32_t)(m1 / img->rsti) - 1u < img->rst_limit; }
 
 struct SimtEncShared {
     uint32_t code[4][256];
@@ -78,6 +127,7 @@ struct LaneSink {
         }
     }
     WDEV void finish() { if (WRITE && fill && word < nwords) simt_or_word(buf + word, (uint32_t)(acc >> 32)); }
+    WDEV uint32_t bitpos() const { return word * 32u + fill; }   // WRITE: where the next bit goes
     // the bits behind the last whole byte of everything put so far, top-aligned in a byte (WRITE only; they are this lane's own as long as
     // it put at least seven bits)
     WDEV uint32_t tail_byte() const {
@@ -187,15 +237,21 @@ WDEV void simt_enc_units(const HuffImage* images, const HuffSegment* segs, SimtE
     const HuffSegment seg = segs[es.seg];
     const HuffImage* img = images + seg.image;
     simt_enc_tables(img, sh);
-    const int mcuh = img->mcuh, m_begin = seg.mcu_row0 * mcuh, m_end = seg.mcu_row1 * mcuh;
+    SimtUnitMap map;
+    map.set(seg.mcu_row0 * img->mcuh, seg.mcu_row1 * img->mcuh, img->rsti);
     LANES(l) {
         const uint32_t u = first_unit + (uint32_t)l;
         if (u < es.nunits) {
-            const int m0 = m_begin + (int)u * kSimtMcus, m1 = m0 + kSimtMcus < m_end ? m0 + kSimtMcus : m_end;
+            int m0, m1;
+            uint32_t interval_first;
+            map.span(u, &m0, &m1, &interval_first);
             SimtEncLane<WRITE> d;
             d.img = img; d.sh = sh;
             for (int c = 0; c < 4; ++c) d.lastdc[c] = seg.last_dc[c];
-            if (u > 0) d.predictors_before(m0);
+            if (u > 0) {
+                if (img->rsti > 0 && m0 % img->rsti == 0) d.lastdc[0] = d.lastdc[1] = d.lastdc[2] = d.lastdc[3] = 0;   // behind a restart marker
+                else d.predictors_before(m0);
+            }
             uint32_t* buf = reinterpret_cast<uint32_t*>(scratch + es.buf_off);
             const uint32_t at = WRITE ? unit_bits[es.first_unit + u] : 0u;
             if (WRITE && u == 0) {               // the partial byte the segment starts with (ThreadHandoff)
@@ -205,6 +261,17 @@ WDEV void simt_enc_units(const HuffImage* images, const HuffSegment* segs, SimtE
             if (!(WRITE && at == kUnitDead)) {   // (a unit behind the cut of a truncated file writes nothing)
                 d.sink.start(at, buf, es.buf_bytes >> 2);
                 const bool met_cut = d.code_mcus(m0, m1);
+                if (WRITE && simt_interval_ends_at(img, m1)) {   // the interval ends with this unit: abitwriter::pad, then the marker
+                    const uint32_t n = (0u - d.sink.bitpos()) & 7u;
+                    uint32_t v = 0;
+                    for (uint32_t j = 0; j < n; ++j) v = (v << 1) | (uint32_t)((img->padbit >> j) & 1);
+                    d.sink.put(v, n);
+                    if (simt_marker_written(img, m1)) {
+                        const uint32_t q = d.sink.bitpos() >> 3;                     // the buffer byte the marker's FF becomes
+                        if (q < es.buf_bytes && es.map_bytes) simt_or_word(reinterpret_cast<uint32_t*>(scratch + es.buf_off + es.buf_bytes) + (q >> 5), 1u << (q & 31u));
+                        d.sink.put(0xff00u | 0xd0u | (((uint32_t)(m1 / img->rsti) - 1u) & 7u), 16);
+                    }
+                }
                 d.sink.finish();
                 if (!WRITE) unit_bits[es.first_unit + u] = d.sink.total | (met_cut ? kUnitMetCut : 0u);
                 else if (u + 1 == es.nunits || met_cut) esp->tail = d.sink.tail_byte();
@@ -213,8 +280,53 @@ WDEV void simt_enc_units(const HuffImage* images, const HuffSegment* segs, SimtE
     }
 }
 
-// pass 2: one wavefront per segment
-WDEV void simt_enc_place(const HuffSegment* segs, SimtEncSeg* es, uint32_t* unit_bits) {
+// pass 2 with restart intervals: the units' positions are the prefix sum of their bits (`unit_plain`, kept) plus, behind every interval
+// that ends in front of them, its pad bits -- an interval starts on a byte, so they are minus its own bit count modulo eight -- and
+// the sixteen of its marker
+WDEV void simt_enc_place_intervals(const HuffImage* img, const HuffSegment& seg, SimtEncSeg* es, uint32_t* unit_bits, uint32_t* unit_plain) {
+    SimtUnitMap map;
+    map.set(seg.mcu_row0 * img->mcuh, seg.mcu_row1 * img->mcuh, img->rsti);
+    const uint32_t nunits = es->nunits, fu = es->first_unit;
+    uint32_t run = (seg.overhang >> 8) & 255u;
+    for (uint32_t base = 0; base < nunits; base += 64) {
+        LV(int, nb); LV(int, ex);
+        LANES(l) { const uint32_t u = base + (uint32_t)l; L(nb) = u < nunits ? (int)(unit_bits[fu + u] & ~kUnitMetCut) : 0; }
+        const int t = lepwave::wave_excl_scan(nb, ex);
+        LANES(l) { const uint32_t u = base + (uint32_t)l; if (u < nunits) unit_plain[fu + u] = run + (uint32_t)L(ex); }
+        run += (uint32_t)t;
+    }
+    const uint32_t plain_total = run;
+    LSYNC();
+    uint32_t extra = 0;
+    for (uint32_t base = 0; base < nunits; base += 64) {
+        LV(int, xb); LV(int, ex); LV(uint32_t, plain);
+        LANES(l) {
+            const uint32_t u = base + (uint32_t)l;
+            int x = 0;
+            uint32_t p = 0;
+            if (u < nunits) {
+                p = unit_plain[fu + u];
+                int m0, m1;
+                uint32_t f;
+                map.span(u, &m0, &m1, &f);
+                if (simt_interval_ends_at(img, m1)) {
+                    const uint32_t next = u + 1 < nunits ? unit_plain[fu + u + 1] : plain_total;
+                    const uint32_t start = f ? unit_plain[fu + f] : 0u;      // (the segment's first interval holds the overhang bits too)
+                    x = (int)((0u - (next - start)) & 7u) + (simt_marker_written(img, m1) ? 16 : 0);
+                }
+            }
+            L(xb) = x; L(plain) = p;
+        }
+        const int t = lepwave::wave_excl_scan(xb, ex);
+        LANES(l) { const uint32_t u = base + (uint32_t)l; if (u < nunits) unit_bits[fu + u] = L(plain) + extra + (uint32_t)L(ex); }
+        extra += (uint32_t)t;
+    }
+    LANES(l) if (l == 0) { es->total_bits = plain_total + extra; es->cut = 0u; }
+}
+
+// pass 2: one wavefront per segment (`unit_plain`: a second array of the units' size, used for scans with restart intervals)
+WDEV void simt_enc_place(const HuffImage* images, const HuffSegment* segs, SimtEncSeg* es, uint32_t* unit_bits, uint32_t* unit_plain) {
+    if (images[segs[es->seg].image].rsti > 0) { simt_enc_place_intervals(images + segs[es->seg].image, segs[es->seg], es, unit_bits, unit_plain); return; }
     const uint32_t pend = (segs[es->seg].overhang >> 8) & 255u;
     uint32_t run = pend;
     bool cut = false;                                      // a unit in front has met the cut of a truncated file: the rest is dead
@@ -256,24 +368,26 @@ WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const
     }
     const uint32_t nb = total >> 3, cap = seg.out_cap;
     uint8_t* out = arena + seg.out_off;
+    const uint32_t* marker_map = es.map_bytes ? reinterpret_cast<const uint32_t*>(scratch + es.buf_off + es.buf_bytes) : nullptr;
     uint32_t written = 0;
     for (uint32_t base = 0; base < nb; base += 1024) {
         LV(int, nff); LV(int, before);
-        LV(uint32_t, w0); LV(uint32_t, w1); LV(uint32_t, w2); LV(uint32_t, w3);
+        LV(uint32_t, w0); LV(uint32_t, w1); LV(uint32_t, w2); LV(uint32_t, w3); LV(uint32_t, mk);
         LANES(l) {
             const uint32_t i = base + 16u * (uint32_t)l;
-            uint32_t a = 0, b = 0, c = 0, d = 0;
+            uint32_t a = 0, b = 0, c = 0, d = 0, markers = 0;
             int n = 0;
             if (i < nb) {
                 const uint32_t* p = buf + (i >> 2);
                 a = p[0]; b = p[1]; c = p[2]; d = p[3];
+                if (marker_map) markers = (marker_map[i >> 5] >> (i & 16u)) & 0xffffu;   // bit k: byte i + k is a restart marker's FF
                 const uint32_t have = nb - i < 16u ? nb - i : 16u;
                 for (uint32_t k = 0; k < have; ++k) {
                     const uint32_t word = k < 4 ? a : (k < 8 ? b : (k < 12 ? c : d));
-                    n += ((word >> (24 - 8 * (k & 3))) & 255u) == 0xffu;
+                    n += (((word >> (24 - 8 * (k & 3))) & 255u) == 0xffu) & (~markers >> k & 1u);
                 }
             }
-            L(w0) = a; L(w1) = b; L(w2) = c; L(w3) = d; L(nff) = n;
+            L(w0) = a; L(w1) = b; L(w2) = c; L(w3) = d; L(nff) = n; L(mk) = markers;
         }
         const int ffs = lepwave::wave_excl_scan(nff, before);
         LANES(l) {
@@ -286,7 +400,7 @@ WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const
                     const uint32_t byte = (word >> (24 - 8 * (k & 3))) & 255u;
                     if (pos < cap) out[pos] = (uint8_t)byte;
                     ++pos;
-                    if (byte == 0xffu) { if (pos < cap) out[pos] = 0; ++pos; }
+                    if (byte == 0xffu && !(L(mk) >> k & 1u)) { if (pos < cap) out[pos] = 0; ++pos; }
                 }
             }
         }
@@ -300,9 +414,13 @@ WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const
             e.attempted = written;
             e.num_overhang_bits = (uint8_t)rem;
             e.overhang_byte = (uint8_t)(rem ? es.tail : 0u);
-            for (int c = 0; c < 4; ++c) e.last_dc[c] = seg.last_dc[c];
-            const int m = seg.mcu_row1 * img->mcuh - 1;
-            if (m >= seg.mcu_row0 * img->mcuh) {
+            // (lep_huff.h's writer zeroes all four predictors at every restart marker position, the unused fourth too)
+            const int m_begin = seg.mcu_row0 * img->mcuh, m_end = seg.mcu_row1 * img->mcuh;
+            const int last_end = img->rsti > 0 ? ((m_end < img->mcuc ? m_end : img->mcuc - 1) / img->rsti) * img->rsti : 0;   // the last interval end in (m_begin, m_end]
+            const bool reset_inside = img->rsti > 0 && last_end > m_begin;
+            for (int c = 0; c < 4; ++c) e.last_dc[c] = reset_inside ? (int16_t)0 : seg.last_dc[c];
+            const int m = m_end - 1;
+            if (m >= m_begin && !(reset_inside && last_end == m_end)) {
                 const int row = m / img->mcuh, mx = m - row * img->mcuh;
                 for (int ci = 0; ci < img->ncomp; ++ci) {
                     const int cmp = img->scan_cmp[ci];
@@ -318,7 +436,7 @@ WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const
 
 // which segments this form takes
 inline bool simt_enc_takes(const HuffImage& img, const HuffSegment& seg) {
-    return img.rsti == 0 && img.interleaved == 1 && img.mcuc == img.mcuh * img.mcuv && seg.mcu_row0 >= 0 && seg.mcu_row1 > seg.mcu_row0 && seg.mcu_row1 <= img.mcuv &&
+    return (img.rsti == 0 || (img.rsti > 0 && !(img.trunc_bc[0] | img.trunc_bc[1] | img.trunc_bc[2] | img.trunc_bc[3]))) && img.interleaved == 1 && img.mcuc == img.mcuh * img.mcuv && seg.mcu_row0 >= 0 && seg.mcu_row1 > seg.mcu_row0 && seg.mcu_row1 <= img.mcuv &&
            ((seg.overhang >> 8) & 255u) < 8u && img.ncomp >= 2;     // (two blocks per MCU at least: a unit's last byte is its own)
 }
 

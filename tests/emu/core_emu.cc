@@ -167,14 +167,16 @@ extern "C" int emu_huffman_encode_segment_simt(const lep_huff_image* img, const 
     if (!lephuff::simt_enc_takes(*im, s)) return 1;
     lephuff::SimtEncSeg es;
     memset(&es, 0, sizeof es);
-    const size_t mcus = (size_t)(s.mcu_row1 - s.mcu_row0) * (size_t)im->mcuh;
-    es.seg = 0; es.first_unit = 0; es.nunits = (uint32_t)((mcus + lephuff::kSimtMcus - 1) / lephuff::kSimtMcus);
+    lephuff::SimtUnitMap map;
+    map.set(s.mcu_row0 * im->mcuh, s.mcu_row1 * im->mcuh, im->rsti);
+    es.seg = 0; es.first_unit = 0; es.nunits = map.count();
     es.buf_off = 0; es.buf_bytes = (uint32_t)(((size_t)s.out_cap + 64 + 15) & ~(size_t)15);
-    std::vector<uint32_t> unit_bits(es.nunits);
-    std::vector<uint32_t> scratch((size_t)es.buf_bytes / 4 + 4, 0u);
+    es.map_bytes = im->rsti > 0 ? ((es.buf_bytes >> 3) + 15u) & ~15u : 0u;
+    std::vector<uint32_t> unit_bits(es.nunits), unit_plain(es.nunits);
+    std::vector<uint32_t> scratch(((size_t)es.buf_bytes + es.map_bytes) / 4 + 4, 0u);
     uint8_t* sc = reinterpret_cast<uint8_t*>(scratch.data());
     for (uint32_t f = 0; f < es.nunits; f += 64) lephuff::simt_enc_units<false>(im, &s, &es, &sh, unit_bits.data(), sc, f);
-    lephuff::simt_enc_place(&s, &es, unit_bits.data());
+    lephuff::simt_enc_place(im, &s, &es, unit_bits.data(), unit_plain.data());
     for (uint32_t f = 0; f < es.nunits; f += 64) lephuff::simt_enc_units<true>(im, &s, &es, &sh, unit_bits.data(), sc, f);
     uint32_t n = 0;
     lephuff::simt_enc_stuff(im, &s, es, sc, out, &n, reinterpret_cast<lephuff::HuffEnd*>(end));

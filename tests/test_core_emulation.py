@@ -333,8 +333,8 @@ def test_lane_per_unit_huffman_encoder_equals_the_wave_per_segment_one(emu, name
                 continue
             taken += 1
             assert outs[0] == outs[1], (i, cap, outs[0][1], outs[1][1], outs[0][3:], outs[1][3:])
-    if not img.rsti and img.interleaved:
-        assert taken > 0
+    if img.interleaved and img.ncomp >= 2:
+        assert taken > 0          # (restart intervals too, since round 5)
 
 
 @pytest.mark.parametrize("name", golden_cases() + ["synth_640x360", "synth_rst", "optimized_q95", "optimized_q30", "optimized_noise_444"])
@@ -963,12 +963,12 @@ def _emulated_gpu_scan_encode(emu, f):
         buf = C.create_string_buffer(cap + 8)
         keep.append(buf)
         n = C.c_uint32(0)
-        if any(img.trunc_bc[c] for c in range(4)):
-            # a file cut inside its scan: the lane-per-unit kernels' or nobody's (lep_gpu_huffman_encode_device) -- and the host re-coder's
-            # whenever the cut is met before the byte bound (LEP_GPU_PATH_DECLINED, what the batch decompressor acts on)
-            if emu.emu_huffman_encode_segment_simt(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) != 0:
+        # lep_gpu_huffman_encode_device's routing: the lane-per-unit kernels take what they can (restart intervals included), the
+        # wavefront-per-segment kernel the rest -- except a file cut inside its scan, which is the lane-per-unit kernels' or nobody's, and
+        # the host re-coder's whenever the cut is met before the byte bound (LEP_GPU_PATH_DECLINED, what the batch decompressor acts on)
+        if emu.emu_huffman_encode_segment_simt(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) != 0:
+            if any(img.trunc_bc[c] for c in range(4)):
                 return None
-        else:
             assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) == 0
         outs[i].data = C.cast(buf, C.c_void_p).value
         outs[i].len = outs[i].cap = n.value
@@ -1485,6 +1485,88 @@ def _restart_interval_jpegs():
     moved = bytearray(whole); i = marks[5]; moved[i - 3: i + 2] = bytes([moved[i], moved[i + 1]]) + bytes(moved[i - 3: i]); moved = bytes(moved)   # a marker three bytes early
     out += [("rst_marker_dropped", dropped), ("rst_marker_moved", moved)]
     return out
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _restart_interval_jpegs()])
+def test_lane_per_unit_huffman_encoder_on_restart_intervals(emu, name):
+    """Scans with restart intervals on lep_huff_simt.h: a unit ends where its interval does and carries the pad bits and the marker, the
+    prefix sum counts them, the stuffing pass leaves the markers' FFs alone (recoder.cc:364-400).  For every segment -- under its own
+    byte bound and under one that cuts it short, started on an MCU row inside an interval as the hand-offs have it -- the bytes, the
+    byte count and the end state are the wavefront-per-segment kernel's, and the file glued from them is the JPEG (a damaged file the
+    reference codes with -skipverify restores to what the reference restores: the host re-coder's bytes)"""
+    import oracle_binding as ob
+    from lepton_amd import abi
+    from lepton_amd.codec import LepFile, LeptonError
+
+    jpg = dict(_restart_interval_jpegs())[name]
+    try:
+        src = JpegImage(jpg)
+    except LeptonError:
+        pytest.skip("the reference refuses this file")
+    for nthreads in (1, 8):
+        plan = src.plan(nthreads)
+        streams, _ = ob.oracle_encode(src.desc, plan)
+        f = LepFile(src.write_lep(streams, nthreads))
+        for c in range(f.desc.ncomp):
+            C.memmove(f.desc.blocks[c], src.desc.blocks[c], f.desc.nblocks(c) * 128)
+        L = abi.lib()
+        img = abi.HuffImage()
+        segs = (abi.HuffSegment * abi.MAX_SEGMENTS)()
+        nseg, ok = C.c_int(0), C.c_int(0)
+        assert L.lep_file_recode_plan(f.handle, C.byref(img), segs, C.byref(nseg), C.byref(ok)) == 0
+        if not ok.value:
+            pytest.skip("not eligible for the GPU scan encoder (narrowrst.jpg: markers the file withheld)")
+        assert img.rsti > 0
+        for i in range(nseg.value):
+            own = min(segs[i].out_cap, len(jpg) + 1024)
+            for cap in (own, 100, 37):
+                segs[i].out_cap = cap
+                outs = []
+                for fn in (emu.emu_huffman_encode_segment, emu.emu_huffman_encode_segment_simt):
+                    buf = C.create_string_buffer(cap + 8)
+                    n = C.c_uint32(0)
+                    end = abi.HuffEnd()
+                    assert fn(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(end)) == 0
+                    # (`attempted` under a bound that cuts the segment short: the lane-per-unit form counts what its bit buffer kept, enough to say "more than the bound")
+                    outs.append((n.value, buf.raw[: n.value], end.attempted if cap == own else end.attempted > cap, end.overhang_byte, end.num_overhang_bits, list(end.last_dc), end.pad))
+                assert outs[0] == outs[1], (nthreads, i, cap, outs[0][0], outs[1][0], outs[0][2:], outs[1][2:])
+            segs[i].out_cap = own
+        got = _emulated_gpu_scan_encode(emu, f)
+        assert got is not None and got == f.recode()
+        if "marker" not in name:
+            assert got == jpg
+        if nthreads == 1:
+            # the same segment cut at MCU rows of our choosing: the second piece starts from the end state of the first (what a hand-off
+            # records), inside a restart interval wherever the intervals are not whole rows
+            whole = segs[0]
+            rows = whole.mcu_row1 - whole.mcu_row0
+            for cut_row in sorted({1, rows // 3, rows // 2, rows - 1} - {0, rows}):
+                state = None
+                pieces = []
+                for r0, r1 in ((whole.mcu_row0, whole.mcu_row0 + cut_row), (whole.mcu_row0 + cut_row, whole.mcu_row1)):
+                    seg = abi.HuffSegment()
+                    C.memmove(C.byref(seg), C.byref(whole), C.sizeof(seg))
+                    seg.mcu_row0, seg.mcu_row1, seg.out_cap = r0, r1, len(jpg) + 1024
+                    if state is not None:
+                        seg.overhang = state.overhang_byte | state.num_overhang_bits << 8
+                        for c in range(4):
+                            seg.last_dc[c] = state.last_dc[c]
+                    outs = []
+                    for fn in (emu.emu_huffman_encode_segment, emu.emu_huffman_encode_segment_simt):
+                        buf = C.create_string_buffer(seg.out_cap + 8)
+                        n = C.c_uint32(0)
+                        end = abi.HuffEnd()
+                        assert fn(C.byref(img), C.byref(seg), buf, C.byref(n), C.byref(end)) == 0
+                        outs.append((n.value, buf.raw[: n.value], end.attempted, end.overhang_byte, end.num_overhang_bits, list(end.last_dc), end.pad))
+                    assert outs[0] == outs[1], (cut_row, r0, r1, outs[0][0], outs[1][0], outs[0][2:], outs[1][2:])
+                    state = end
+                    pieces.append(outs[1][1])
+                buf = C.create_string_buffer(len(jpg) + 1032)
+                n = C.c_uint32(0)
+                end = abi.HuffEnd()
+                whole.out_cap = len(jpg) + 1024
+                assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(whole), buf, C.byref(n), C.byref(end)) == 0
+                assert b"".join(pieces) == buf.raw[: n.value], cut_row
 
 
 @pytest.mark.parametrize("name", [n for n, _ in _restart_interval_jpegs()])

@@ -270,6 +270,46 @@ def test_gpu_lane_per_restart_interval_scan_decode_in_the_compress_pipeline(gpu_
 
 
 @pytest.mark.gpu
+def test_gpu_lane_per_unit_scan_encoder_writes_restart_intervals(gpu_codec, monkeypatch):
+    """files with restart intervals through lep_decompress_batch: since round 5 the lane-per-unit kernels (lep_huff_simt.h) write their scans
+    too -- a unit ends where its interval does and carries pad bits and marker, the stuffing pass leaves the markers' FFs alone.  The JPEG
+    bytes are the originals, == the wavefront-per-segment kernel's (LEP_HUFFENC_SIMT=0, a second codec object) == the host re-coder's;
+    intervals of one MCU, of a few, of whole rows, intervals longer than a thread segment, 1080p files of several segments"""
+    import io
+    import numpy as np
+    from PIL import Image
+    import test_core_emulation as emu_tests
+    from lepton_amd.codec import GpuCodec
+
+    cases = [(n, j) for n, j in emu_tests._restart_interval_jpegs() if "marker" not in n and n != "narrowrst"]
+    rng = np.random.default_rng(78)
+    base = np.asarray(Image.fromarray(rng.integers(0, 256, (135, 240, 3), dtype=np.uint8), "RGB").resize((1920, 1080), Image.BICUBIC)).astype(np.int16)
+    big = Image.fromarray(np.clip(base + rng.normal(0, 12, base.shape), 0, 255).astype(np.uint8), "RGB")
+    for tag, kw in (("big_rst_5mcu", dict(restart_marker_blocks=5)), ("big_rst_row", dict(restart_marker_rows=1)), ("big_rst_1000mcu", dict(restart_marker_blocks=1000)),
+                    ("big_rst_13mcu_444", dict(restart_marker_blocks=13, subsampling="4:4:4"))):
+        buf = io.BytesIO()
+        big.save(buf, format="JPEG", quality=90, **{"subsampling": "4:2:0", **kw})
+        cases.append((tag, buf.getvalue()))
+    jpgs = [j for _, j in cases]
+    leps, status, _ = gpu_codec.compress_batch(jpgs)
+    assert status == [0] * len(jpgs)
+    back, st, stats = gpu_codec.decompress_batch(leps)
+    assert st == [0] * len(jpgs)
+    for (n, j), b in zip(cases, back):
+        assert b == j, n
+    assert stats["gpu_huffman_files"] == len(jpgs), stats
+    host, st_h, _ = gpu_codec.decompress_batch(leps, host_huffman=True)
+    assert st_h == st and host == back
+    monkeypatch.setenv("LEP_HUFFENC_SIMT", "0")
+    other = GpuCodec(0)
+    try:
+        back2, st2, stats2 = other.decompress_batch(leps)
+        assert st2 == st and back2 == back and stats2["gpu_huffman_files"] == len(jpgs)
+    finally:
+        other.close()
+
+
+@pytest.mark.gpu
 def test_gpu_lane_per_restart_interval_kernel_equals_the_single_wave_kernel(gpu_codec):
     """lep_gpu_huffman_decode_simt_device on device-resident scans with the restart positions behind the scan bytes, against
     lep_gpu_huffman_decode_device (which walks the scan as the reference does): same frames, same hand-off records, same pad byte"""
