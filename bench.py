@@ -752,7 +752,8 @@ def main():
             log("[rank 0] extra %s: %s" % (key, str({k: v for k, v in extras[key].items() if k not in ("workload", "unit", "parity", "jpeg_MB", "lep_MB")})[:600]))
         try:   # the reference's own benchmark input (src/lepton/benchmark.cc:116-119), so that numbers line up with `lepton -benchmark`
             rb = reference_benchmark_jpeg()
-            fig = dev.pipeline([rb] * 512, "512 copies of the file `lepton -benchmark` codes (bigger_hdr + 76 x bigger_rep, 2,589,088 B, 3264x2448 4:2:0)")
+            # (1024 files like every other figure of this line: 8192 thread segments, one full pipeline chunk -- until round 5 this one ran 512)
+            fig = dev.pipeline([rb] * 1024, "1024 copies of the file `lepton -benchmark` codes (bigger_hdr + 76 x bigger_rep, 2,589,088 B, 3264x2448 4:2:0, cut inside its scan: no EOI)")
             fig.pop("_cs"); fig.pop("_ds")
             extras["reference_benchmark_file"] = fig
         except Exception as e:

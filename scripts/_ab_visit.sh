@@ -1,6 +1,8 @@
 set -u
 export TMPDIR=/tmp
-V=""
-for v in ww3 ww4; do V="$V LEP_LIB_PATH=$PWD/lepton_amd/liblepton_$v.so"; done
-bash scripts/gpu_ab.sh r5x -k "4k_roundtrip" -b resident -- "" $V
-LEP_LIB_PATH=$PWD/lepton_amd/liblepton_ww3.so timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider -k "4k_roundtrip or streams_equal" 2>&1 | tail -2
+mkdir -p gpurun_out/r11d
+t0=$(date +%s)
+for k in 8mcu none; do
+  timeout 300 python scripts/bench_restart_corpora.py --only $k --simt 1,0 --verbose --repeats 3 2>&1 | grep -v "^W2026" | tee -a gpurun_out/r11d/restart_verbose.txt
+done
+echo "total $(( $(date +%s)-t0 )) s"
