@@ -52,7 +52,7 @@ def spawn_ranks(n):
 
 
 def kernel_source_sha():
-    """identity of the kernel sources a PMC pass was taken from / this run was built from: sha256 over lepton_amd/csrc/*.h, *.hip"""
+    """identity of the kernel sources a PMC pass was taken from / this run was built from: sha256 over lepton_amd/csrc/*.h, *.hip and their compile flags"""
     import hashlib
 
     h = hashlib.sha256()
@@ -60,6 +60,10 @@ def kernel_source_sha():
     for f in sorted(os.listdir(d)):
         if f.endswith((".h", ".hip")):
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    # ... and the flags the kernels are compiled with (the objects' .flags records, written by build(): a compiler mode is part of the kernel)
+    for f in ("lep_gpu.hip", "lep_batch.hip"):
+        p = os.path.join(ROOT, "lepton_amd", "build", "obj", f + ".o.flags")
+        h.update(open(p, "rb").read() if os.path.exists(p) else b"")
     return h.hexdigest()[:16]
 
 

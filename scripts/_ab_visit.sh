@@ -1,8 +1,9 @@
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r11d
 t0=$(date +%s)
-for k in 8mcu none; do
-  timeout 300 python scripts/bench_restart_corpora.py --only $k --simt 1,0 --verbose --repeats 3 2>&1 | grep -v "^W2026" | tee -a gpurun_out/r11d/restart_verbose.txt
-done
+V=""
+for v in lat6 lat14 lat10; do V="$V LEP_LIB_PATH=$PWD/lepton_amd/liblepton_$v.so"; done
+bash scripts/gpu_ab.sh r11e -b latency-decode -- "" $V
+cat gpurun_out/r11e/latency-decode_*.json
+bash scripts/gpu_ab.sh r11f -b resident -- "" "LEP_LIB_PATH=$PWD/lepton_amd/liblepton_pairor.so"
 echo "total $(( $(date +%s)-t0 )) s"

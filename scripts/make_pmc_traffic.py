@@ -43,6 +43,9 @@ def kernel_source_sha():   # bench.kernel_source_sha: sha256 over lepton_amd/csr
     for f in sorted(os.listdir(d)):
         if f.endswith((".h", ".hip")):
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("lep_gpu.hip", "lep_batch.hip"):   # (and the compile flags build() recorded for them)
+        p = os.path.join(ROOT, "lepton_amd", "build", "obj", f + ".o.flags")
+        h.update(open(p, "rb").read() if os.path.exists(p) else b"")
     return h.hexdigest()[:16]
 
 
