@@ -6,8 +6,9 @@ name=$1; shift
 cd "$(dirname "$0")/.."
 C=lepton_amd/csrc; O=lepton_amd/build/obj; V=lepton_amd/build/variant_$name
 mkdir -p $V
-# (lep_gpu.hip's product flags: __graft_entry__.py; LEP_NO_SU=1 builds it in the compiler's default structurizer mode)
-SU="-mllvm -structurizecfg-skip-uniform-regions=1"; [ -n "${LEP_NO_SU:-}" ] && SU=""
+# (LEP_SU=1: lep_gpu.hip with -mllvm -structurizecfg-skip-uniform-regions=1 -- measured -1.2 % on the decoder, and the lane-per-unit scan
+#  encoder's restart-interval output comes out wrong under it: __graft_entry__.py, profiles/r12d_*; experiments only)
+SU=""; [ -n "${LEP_SU:-}" ] && SU="-mllvm -structurizecfg-skip-uniform-regions=1"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip $SU "$@" -c $C/lep_gpu.hip -o $V/lep_gpu.o &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip "$@" -c $C/lep_batch.hip -o $V/lep_batch.o &
 wait

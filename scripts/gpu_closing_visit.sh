@@ -35,6 +35,9 @@ fi
 if [ "${SERVE:-0}" = 1 ]; then   # the daemon: what one caller waits, then a small concurrent load (every answer checked)
   timeout 600 python scripts/bench_serve.py --requests 256 --clients 64 --procs 4 --unique 8 > $OUT/serve_4k.json 2> $OUT/serve_4k.err; echo "serve rc=$? ($(( $(date +%s)-t0 )) s)"; head -c 1200 $OUT/serve_4k.json; echo
 fi
+if [ "${RESTART:-0}" = 1 ]; then   # files with restart intervals through the batch pipeline, scan kernels A/B
+  timeout 600 python scripts/bench_restart_corpora.py > $OUT/restart_interval_corpora_ab.txt 2> $OUT/restart_interval_corpora.err; echo "restart corpora rc=$? ($(( $(date +%s)-t0 )) s)"; cat $OUT/restart_interval_corpora_ab.txt
+fi
 if [ "${SKIP_PMC:-0}" = 1 ] || [ "${PMC_FIRST:-0}" = 1 ]; then echo "total $(( $(date +%s)-t0 )) s"; exit 0; fi
 pmc_passes
 echo "total $(( $(date +%s)-t0 )) s"

@@ -1535,6 +1535,21 @@ def test_lane_per_unit_huffman_encoder_on_restart_intervals(emu, name):
         assert got is not None and got == f.recode()
         if "marker" not in name:
             assert got == jpg
+        # a file that withheld markers (rst_cnt: only the first `rst_limit` markers of the scan are written, the pad bits and the predictor
+        # reset stay): both kernels honour the limit the same way
+        for limit in (0, 3):
+            keep_limit = img.rst_limit
+            img.rst_limit = limit
+            for i in range(nseg.value):
+                outs = []
+                for fn in (emu.emu_huffman_encode_segment, emu.emu_huffman_encode_segment_simt):
+                    buf = C.create_string_buffer(segs[i].out_cap + 8)
+                    n = C.c_uint32(0)
+                    end = abi.HuffEnd()
+                    assert fn(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(end)) == 0
+                    outs.append((n.value, buf.raw[: n.value], end.attempted, end.overhang_byte, end.num_overhang_bits, list(end.last_dc)))
+                assert outs[0] == outs[1], (limit, i, outs[0][0], outs[1][0])
+            img.rst_limit = keep_limit
         if nthreads == 1:
             # the same segment cut at MCU rows of our choosing: the second piece starts from the end state of the first (what a hand-off
             # records), inside a restart interval wherever the intervals are not whole rows
