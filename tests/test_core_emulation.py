@@ -1584,6 +1584,66 @@ def test_lane_per_unit_huffman_encoder_on_restart_intervals(emu, name):
                 assert b"".join(pieces) == buf.raw[: n.value], cut_row
 
 
+@pytest.mark.parametrize("sub,size", [("4:2:0", (200, 136)), ("4:2:2", (328, 88)), ("4:4:4", (136, 120)), ("4:2:0", (1040, 48))])
+def test_lane_per_unit_huffman_encoder_restart_interval_sweep(emu, sub, size):
+    """restart intervals of 1 .. 1000 MCUs (shorter than a unit, a unit, a unit and a bit, several units, a row and a bit, longer than the
+    scan) x segment cuts at every third MCU row: the lane-per-unit kernels against the wavefront kernel, piece by piece with the end state
+    of one piece handed to the next, and the pieces together against the whole"""
+    import io
+    import numpy as np
+    from PIL import Image
+    import oracle_binding as ob
+    from lepton_amd import abi
+    from lepton_amd.codec import LepFile
+
+    rng = np.random.default_rng(size[0] * 7 + size[1])
+    base = np.asarray(Image.fromarray(rng.integers(0, 256, (size[1] // 8, size[0] // 8, 3), dtype=np.uint8), "RGB").resize(size, Image.BICUBIC)).astype(np.int16)
+    pic = Image.fromarray(np.clip(base + rng.normal(0, 14, base.shape), 0, 255).astype(np.uint8), "RGB")
+    L = abi.lib()
+    for rsti in (1, 2, 3, 7, 8, 9, 16, 17, 63, 64, 65, 1000):
+        buf = io.BytesIO()
+        pic.save(buf, format="JPEG", quality=int(rng.integers(60, 97)), subsampling=sub, restart_marker_blocks=rsti)
+        jpg = buf.getvalue()
+        src = JpegImage(jpg)
+        streams, _ = ob.oracle_encode(src.desc, src.plan(1))
+        f = LepFile(src.write_lep(streams, 1))
+        for c in range(f.desc.ncomp):
+            C.memmove(f.desc.blocks[c], src.desc.blocks[c], f.desc.nblocks(c) * 128)
+        img = abi.HuffImage()
+        segs = (abi.HuffSegment * abi.MAX_SEGMENTS)()
+        nseg, ok = C.c_int(0), C.c_int(0)
+        assert L.lep_file_recode_plan(f.handle, C.byref(img), segs, C.byref(nseg), C.byref(ok)) == 0 and ok.value and nseg.value == 1
+        assert img.rsti == rsti
+        whole = segs[0]
+        whole.out_cap = len(jpg) + 1024
+        wbuf = C.create_string_buffer(whole.out_cap + 8)
+        wn = C.c_uint32(0)
+        wend = abi.HuffEnd()
+        assert emu.emu_huffman_encode_segment(C.byref(img), C.byref(whole), wbuf, C.byref(wn), C.byref(wend)) == 0
+        cuts = list(range(whole.mcu_row0, whole.mcu_row1, 3)) + [whole.mcu_row1]
+        state, pieces = None, []
+        for r0, r1 in zip(cuts, cuts[1:]):
+            seg = abi.HuffSegment()
+            C.memmove(C.byref(seg), C.byref(whole), C.sizeof(seg))
+            seg.mcu_row0, seg.mcu_row1 = r0, r1
+            if state is not None:
+                seg.overhang = state.overhang_byte | state.num_overhang_bits << 8
+                for c in range(4):
+                    seg.last_dc[c] = state.last_dc[c]
+            outs = []
+            for fn in (emu.emu_huffman_encode_segment, emu.emu_huffman_encode_segment_simt):
+                b = C.create_string_buffer(seg.out_cap + 8)
+                n = C.c_uint32(0)
+                end = abi.HuffEnd()
+                assert fn(C.byref(img), C.byref(seg), b, C.byref(n), C.byref(end)) == 0
+                outs.append((n.value, b.raw[: n.value], end.attempted, end.overhang_byte, end.num_overhang_bits, list(end.last_dc), end.pad))
+            assert outs[0] == outs[1], (rsti, r0, r1, outs[0][0], outs[1][0], outs[0][2:], outs[1][2:])
+            state = end
+            pieces.append(outs[1][1])
+        assert b"".join(pieces) == wbuf.raw[: wn.value], rsti
+        assert _emulated_gpu_scan_encode(emu, f) == jpg, rsti
+
+
 @pytest.mark.parametrize("name", [n for n, _ in _restart_interval_jpegs()])
 def test_lane_per_restart_interval_huffman_decoder(emu, name):
     """Scans with restart intervals on lep_huffdec_simt.h: the markers' positions travel behind the scan bytes (LEP_HUFFDEC_RST_TABLE) and
