@@ -445,27 +445,27 @@ def usable_cpus():
 
 def pin_to_gpu_numa_node(local_rank):
     """one rank per GPU: keep the rank's host threads (file splitting, container writing) on the CPUs of the NUMA node its GPU hangs off,
-    where the kernel exposes that (/sys/bus/pci/devices/<bdf>/numa_node); returns a note for the log"""
+    where the kernel exposes that (/sys/bus/pci/devices/<bdf>/numa_node); returns (a note for the log, the node or -1 when not pinned)"""
     try:
         import torch
 
         bdf = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None
         if not bdf:
-            return "no PCI id for device %d" % local_rank
+            return "no PCI id for device %d" % local_rank, -1
         node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf.lower()).read())
         if node < 0:
-            return "device %s: no NUMA node reported" % bdf
+            return "device %s: no NUMA node reported" % bdf, -1
         cpus = set()
         for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
             a, _, b = part.partition("-")
             cpus.update(range(int(a), int(b or a) + 1))
         mine = cpus & os.sched_getaffinity(0)
         if not mine:
-            return "device %s on node %d: none of its CPUs allowed here" % (bdf, node)
+            return "device %s on node %d: none of its CPUs allowed here" % (bdf, node), -1
         os.sched_setaffinity(0, mine)
-        return "device %s on NUMA node %d: pinned to %d CPUs" % (bdf, node, len(mine))
+        return "device %s on NUMA node %d: pinned to %d CPUs" % (bdf, node, len(mine)), node
     except Exception as e:
-        return "not pinned (%s)" % repr(e)[:80]
+        return "not pinned (%s)" % repr(e)[:80], -1
 
 
 def mixed_plan(n, distinct, small=(1920, 1080), big=(3840, 2160), seed0=20000):
@@ -547,7 +547,7 @@ def main():
     rank, local_rank, world = shard.dist_env()
     stub = os.environ.get("LEP_BENCH_DEVICE") == "stub"   # tests/bench_stub.py: the CPU suite's stand-in for the device layer
     dist = None
-    numa_note = "not pinned (one rank)"
+    numa_node = -1   # the NUMA node this rank's host threads were pinned to (-1: not pinned -- one rank, or the box does not say)
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -567,7 +567,7 @@ def main():
         dev = bench_stub.StubDevice(local_rank)
     else:
         if world > 1:
-            numa_note = pin_to_gpu_numa_node(local_rank)
+            numa_note, numa_node = pin_to_gpu_numa_node(local_rank)
             log("[rank %d] %s" % (rank, numa_note))
         dev = HipDevice(local_rank, host_threads=max(1, usable_cpus() // world) if world > 1 else 0, trim=args.trim_between_phases)
 
@@ -634,15 +634,24 @@ def main():
     agg = shard.aggregate(local, backend_device=("cuda:%d" % local_rank) if (dist and not stub) else None)
     # per rank, for reading a multi-GPU run without a second visit: the host side of each rank (threads, CPUs, pinned staging, NUMA
     # placement) next to what it took of the wall clock -- the same counters the sums / maxima above were made of
-    mine_rec = dict(dev.footprint(), rank=rank, local_rank=local_rank, cpus_allowed=len(os.sched_getaffinity(0)), numa=numa_note,
+    mine_rec = dict(dev.footprint(), local_rank=local_rank, cpus_allowed=len(os.sched_getaffinity(0)), numa_node=numa_node,
                     resident_s=round(res["elapsed"], 4), enc_ms=round(res["enc_ms"] / max(1, args.steps), 3), dec_ms=round(res["dec_ms"] / max(1, args.steps), 3),
                     e2e_compress_s=round(e2e_local["e2e_c_s_max"], 4), e2e_decompress_s=round(e2e_local["e2e_d_s_max"], 4),
                     mixed_files=int(mixed_local["mixed_files"]), mixed_MB=round(mixed_local["mixed_bytes"] / 1e6, 2),
                     mixed_compress_s=round(mixed_local["mixed_c_s_max"], 4), mixed_decompress_s=round(mixed_local["mixed_d_s_max"], 4))
-    per_rank = [mine_rec]
+    # (numbers only, and gathered with the one collective the counters above already went through -- a [world x fields] matrix, every
+    # rank its own row, summed -- so the multi-GPU line depends on nothing a one-GPU box could not exercise)
+    per_rank = [dict(mine_rec, rank=rank)]
     if dist:
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine_rec)
+        import torch
+
+        keys = sorted(mine_rec)
+        m = torch.zeros((world, len(keys)), dtype=torch.float64, device=("cuda:%d" % local_rank) if not stub else "cpu")
+        m[rank] = torch.tensor([float(mine_rec[k]) for k in keys], dtype=torch.float64)
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+        rows = m.cpu().tolist()
+        ints = {"local_rank", "cpus_allowed", "numa_node", "host_threads", "mixed_files"}
+        per_rank = [dict({k: (int(round(v)) if k in ints else round(v, 4)) for k, v in zip(keys, row)}, rank=r) for r, row in enumerate(rows)]
     if rank != 0:
         if dist:
             dist.destroy_process_group()

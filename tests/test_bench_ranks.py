@@ -48,7 +48,7 @@ def test_gpus_2_starts_two_ranks_and_shards_the_mixed_corpus(tmp_path):
     assert out["end_to_end"]["n_gpus"] == 2
     # every rank's host side is in the line: threads, CPUs, pinned staging, its share of the mixed corpus and of the wall clock
     pr = out["per_rank"]
-    assert [r["rank"] for r in pr] == [0, 1] and all({"host_threads", "pinned_MB", "cpus_allowed", "numa", "resident_s", "mixed_compress_s"} <= set(r) for r in pr)
+    assert [r["rank"] for r in pr] == [0, 1] and all({"host_threads", "pinned_MB", "cpus_allowed", "numa_node", "resident_s", "mixed_compress_s"} <= set(r) for r in pr)
     assert sum(r["mixed_files"] for r in pr) == 12 and max(r["mixed_compress_s"] for r in pr) > 0
     # one definition of MB/s in the whole line
     for fig in (out["mixed"], out["end_to_end"]):
