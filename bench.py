@@ -422,9 +422,13 @@ class HipDevice:
                 latency["encode"]["%d_image%s" % (nb, "" if nb == 1 else "s")] = round(best_e * 1e3, 1)
                 latency["decode"]["%d_image%s" % (nb, "" if nb == 1 else "s")] = round(best_d * 1e3, 1)
             if whole_file:
-                t0 = time.perf_counter(); one = codec.compress(uniq[0]); t1 = time.perf_counter(); assert codec.decompress(one) == uniq[0]; t2 = time.perf_counter()
-                latency["whole_file_host_to_host"] = {"compress_ms": round((t1 - t0) * 1e3, 1), "decompress_ms": round((t2 - t1) * 1e3, 1),
-                                                      "note": "lep_compress / lep_decompress of one 4K JPEG: host Huffman + PCIe + kernels + container"}
+                best_c = best_x = 1e9   # (best of 3 like the launches above: the first call of its kind in the process pays for its buffers)
+                for _ in range(3):
+                    t0 = time.perf_counter(); one = codec.compress(uniq[0]); t1 = time.perf_counter(); back = codec.decompress(one); t2 = time.perf_counter()
+                    assert back == uniq[0]
+                    best_c = min(best_c, t1 - t0); best_x = min(best_x, t2 - t1)
+                latency["whole_file_host_to_host"] = {"compress_ms": round(best_c * 1e3, 1), "decompress_ms": round(best_x * 1e3, 1),
+                                                      "note": "lep_compress / lep_decompress of one 4K JPEG, best of 3: host Huffman + PCIe + kernels + container (+ the host-side check that the .lep restores the file)"}
         return {"jpeg_bytes": jpeg_bytes, "images": nimg, "segments": nseg, "blocks": nblocks, "stream_bytes": stream_bytes,
                 "elapsed": elapsed, "enc_ms": enc_ms, "dec_ms": dec_ms, "names": names, "parity": parity,
                 "bins_per_image": bins_per_image, "latency": latency,
