@@ -39,7 +39,14 @@ def decode_setup(L, jpg):
         return None
     p, n = C.c_void_p(), C.c_size_t(0)
     L.lep_jpeg_scan_bytes(h, C.byref(p), C.byref(n))
-    scan = C.create_string_buffer(C.string_at(p, n.value) + bytes(64), n.value + 64)
+    if img.flags & 2:   # LEP_HUFFDEC_RST_TABLE: the markers' positions behind the scan bytes, at LEP_HUFFDEC_SCAN_ROOM(scan_len)
+        rp, rn = C.POINTER(C.c_uint32)(), C.c_size_t(0)
+        L.lep_jpeg_scan_restarts(h, C.byref(rp), C.byref(rn))
+        room = (n.value + 64 + 15) & ~15
+        table = bytes(C.cast(rp, C.POINTER(C.c_uint8 * (4 * rn.value))).contents) if rn.value else b""
+        scan = C.create_string_buffer(C.string_at(p, n.value) + bytes(room - n.value) + table + bytes(64), room + len(table) + 64)
+    else:
+        scan = C.create_string_buffer(C.string_at(p, n.value) + bytes(64), n.value + 64)
     img.scan = C.addressof(scan)
     d = JpegImage(jpg).desc
     planes = [C.create_string_buffer(d.nblocks(c) * 128) for c in range(d.ncomp)]
@@ -55,7 +62,7 @@ def main():
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "emu", "core_emu.cc")])
     emu = C.CDLL(so)
     L = abi.lib()
-    dec_ran = dec_gave_up = enc_ran = enc_segments = skipped = bad = 0
+    dec_ran = dec_gave_up = enc_ran = enc_segments = skipped = bad = rst_ran = 0
     for k in range(cases):
         rng = np.random.default_rng(seed0 * 100003 + k)
         comps = LAYOUTS[rng.integers(len(LAYOUTS))]
@@ -63,7 +70,7 @@ def main():
         if rng.random() < 0.25:
             w, h = int(rng.integers(1, 40)), int(rng.integers(1, 40))
         kw = dict(quality=int(rng.choice([1, 10, 40, 75, 90, 98, 100])), density=float(rng.choice([0.01, 0.05, 0.25, 0.6, 1.0, 4.0])),
-                  amp=float(rng.choice([0.5, 4, 40, 200, 900])), restart_interval=int(rng.choice([0, 0, 0, 0, 3])))
+                  amp=float(rng.choice([0.5, 4, 40, 200, 900])), restart_interval=int(rng.choice([0, 0, 0, 1, 2, 3, 5, 8, 9, 17, 100])))
         try:
             jpg = jw.write_baseline(w, h, comps, rng, **kw)[0]
             src = JpegImage(jpg)
@@ -96,6 +103,27 @@ def main():
                     if not same:
                         bad += 1
                         print("DECODE MISMATCH", seed0, k, w, h, comps, kw, sub_bits, flush=True)
+        # ---- decode direction, restart intervals: lane = interval (the markers' positions behind the scan bytes) against the single-wave
+        #      decoder, which walks the scan as the reference does
+        if one is not None and one[0].rsti and (one[0].flags & 2):
+            img1, scan1, planes1, d = one
+            rows1 = (abi.HuffDecRow * (img1.mcuv + 1))()
+            img1.flags &= ~2   # (the single-wave kernel reads no table)
+            emu.emu_huffman_decode_image(C.byref(img1), rows1)
+            if rows1[img1.mcuv].aux >> 8 == 0:
+                img2, scan2, planes2, _ = decode_setup(L, jpg)
+                rows2 = (abi.HuffDecRow * (img2.mcuv + 1))()
+                emu.emu_huffman_decode_image_simt(C.byref(img2), rows2, 8192, None, None)
+                rst_ran += 1
+                if (rows2[img2.mcuv].aux >> 8) & 0x3fffff:
+                    bad += 1
+                    print("RST DECODE GAVE UP", seed0, k, w, h, comps, kw, flush=True)
+                else:
+                    same = all(planes2[c].raw == planes1[c].raw for c in range(d.ncomp)) and all(
+                        (rows2[r].bitpos, list(rows2[r].last_dc), rows2[r].aux & 0xff) == (rows1[r].bitpos, list(rows1[r].last_dc), rows1[r].aux & 0xff) for r in range(img1.mcuv + 1))
+                    if not same:
+                        bad += 1
+                        print("RST DECODE MISMATCH", seed0, k, w, h, comps, kw, flush=True)
         # ---- encode direction
         try:
             segs0 = src.plan()
@@ -128,7 +156,7 @@ def main():
                 if outs[0] != outs[1]:
                     bad += 1
                     print("ENCODE MISMATCH", seed0, k, w, h, comps, kw, "segment", i, "cap", cap, outs[0][1], outs[1][1], outs[0][3:], outs[1][3:], flush=True)
-    print(f"seed {seed0}: decodes {dec_ran} (gave up where allowed {dec_gave_up}), files encoded {enc_ran} ({enc_segments} segment runs), not a file {skipped}, bad {bad}")
+    print(f"seed {seed0}: decodes {dec_ran} (gave up where allowed {dec_gave_up}), restart-interval decodes {rst_ran}, files encoded {enc_ran} ({enc_segments} segment runs), not a file {skipped}, bad {bad}")
 
 
 if __name__ == "__main__":
