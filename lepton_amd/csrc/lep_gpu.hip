@@ -26,6 +26,7 @@
 #include "lep_huffdec_simt.h"
 #include "lep_huff_simt.h"
 #include "lep_huffprog.h"
+#include "lep_huffprog_simt.h"
 #include "lep_huffprogdec.h"
 
 using namespace lepdev;
@@ -328,9 +329,42 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_progressive_encode_kernel(c
                                                                                uint32_t* corr, uint32_t* out_len) {
     __shared__ lephuff::ProgShared sh;
     const lephuff::ProgScan* sc = scans + blockIdx.x;
+    if (sc->pad & lephuff::kProgScanSimt) return;   // the lane-per-unit kernels below own this scan
     lephuff::ProgWave w;
     const uint32_t n = w.run_scan(images + sc->image, sc, &sh, out, corr);
     if (threadIdx.x == 0) out_len[blockIdx.x] = n;
+}
+// ... with one lane per run of blocks (lep_huffprog_simt.h): count / place / code / stuff
+template <bool WRITE>
+__global__ __launch_bounds__(64) void lep_huffprog_simt_units_kernel(const lephuff::ProgImage* __restrict__ images, const lephuff::ProgScan* __restrict__ scans,
+                                                                     const lephuff::ProgSimtScan* __restrict__ ps, const lephuff::ProgSimtWave* __restrict__ waves,
+                                                                     uint32_t* unit_words, size_t units, uint8_t* scratch) {
+    __shared__ lephuff::ProgSimtShared sh;
+    const lephuff::ProgSimtWave w = waves[blockIdx.x];
+    lephuff::ProgSimtUnits U;
+    U.set(unit_words, units);
+    lephuff::prog_simt_units<WRITE>(images, scans, ps + w.pscan, &sh, U, scratch, w.first_unit);
+}
+__global__ __launch_bounds__(64) void lep_huffprog_simt_place_kernel(const lephuff::ProgScan* __restrict__ scans, lephuff::ProgSimtScan* ps, uint32_t* unit_words, size_t units) {
+    lephuff::ProgSimtUnits U;
+    U.set(unit_words, units);
+    lephuff::prog_simt_place(scans, ps + blockIdx.x, U);
+}
+// the bit buffers are cleared as far as the scans reach (pass 2 knows; the buffers are sized by what a scan MAY need, ten times that)
+__global__ __launch_bounds__(256) void lep_huffprog_simt_zero_kernel(const lephuff::ProgSimtScan* __restrict__ ps, uint8_t* scratch, uint32_t chunk16) {
+    const lephuff::ProgSimtScan s = ps[blockIdx.x];
+    const uint32_t need16 = (uint32_t)std::min<uint64_t>(((uint64_t)s.total_bits + 7) / 8 / 16 + 2, s.buf_bytes / 16);
+    uint4* p = reinterpret_cast<uint4*>(scratch + s.buf_off);
+    const uint32_t i0 = blockIdx.y * chunk16, i1 = i0 + chunk16 < need16 ? i0 + chunk16 : need16;
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+__global__ void lep_huffprog_simt_assign_kernel(const lephuff::ProgSimtRegion* __restrict__ regions, int nregion, lephuff::ProgSimtScan* ps) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < nregion) lephuff::prog_simt_assign(regions[i], ps);
+}
+__global__ __launch_bounds__(64) void lep_huffprog_simt_stuff_kernel(const lephuff::ProgImage* __restrict__ images, const lephuff::ProgScan* __restrict__ scans,
+                                                                     const lephuff::ProgSimtScan* __restrict__ ps, uint8_t* scratch, uint8_t* out, uint32_t* out_len) {
+    lephuff::prog_simt_stuff(images, scans, ps[blockIdx.x], scratch, out, out_len);
 }
 
 // progressive files, encode direction: one wavefront per (image, scan) of one dependency level (lep_huffprogdec.h)
@@ -414,6 +448,8 @@ struct lep_gpu {
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     int huffprog_pipeline = 1;          // LEP_HUFFPROG_PIPELINE=0: progressive scan decode level by level, whatever the launch size
+    int huffprog_simt = 1;              // LEP_HUFFPROG_SIMT=0: every progressive scan's bytes from the wavefront-per-scan kernel (lep_huffprog.h)
+    void* d_huffprogsimt[2] = {nullptr, nullptr}; size_t huffprogsimt_bytes[2] = {0, 0};   // lep_huffprog_simt.h: descriptors, unit arrays, bit buffers (one per arena set)
     int huffenc_simt = 1;               // LEP_HUFFENC_SIMT=0: every segment's scan bytes from the wavefront-per-segment kernel (lep_huff.h)
     void* d_huffenc = nullptr; size_t huffenc_bytes = 0;   // lep_huff_simt.h: segment / wave descriptors, unit bit counts, bit buffers
     int simt_sub_bits = 0;              // LEP_HUFFDEC_SIMT_BITS: bits per subsequence of the lane-per-subsequence scan decoder (0 = from the launch's size)
@@ -954,6 +990,7 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_HUFFPROG_PIPELINE_MAX")) g->huffprog_pipeline_max = atoi(e);
     if (const char* e = getenv("LEP_HUFFDEC_SIMT_BITS")) g->simt_sub_bits = std::max(0, atoi(e));
     if (const char* e = getenv("LEP_HUFFENC_SIMT")) g->huffenc_simt = atoi(e) != 0;
+    if (const char* e = getenv("LEP_HUFFPROG_SIMT")) g->huffprog_simt = atoi(e) != 0;
     if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
     if (const char* e = getenv("LEP_ENC5_GATHER_WGS")) g->enc5_gather_wgs = atoi(e);
@@ -989,7 +1026,7 @@ static void release_device_side(lep_gpu* g) {
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     if (g->stream3) (void)hipStreamDestroy(g->stream3);
     for (void** p : {&g->arena[0].d_models, &g->arena[0].d_ns, &g->arena[0].d_meta, &g->arena[1].d_models, &g->arena[1].d_ns, &g->arena[1].d_meta, &g->d_blocks, &g->d_streams, &g->d_lens, &g->d_huff,
-                     &g->d_huffprog[0], &g->d_huffprog[1], &g->d_huffprogdec, &g->d_huffdec, &g->d_huffpar, &g->d_huffenc, &g->d_scan, &g->d_scanlen})
+                     &g->d_huffprog[0], &g->d_huffprog[1], &g->d_huffprogsimt[0], &g->d_huffprogsimt[1], &g->d_huffprogdec, &g->d_huffdec, &g->d_huffpar, &g->d_huffenc, &g->d_scan, &g->d_scanlen})
         dev_release(g, p, nullptr);
     vmm_destroy(g);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
@@ -1187,14 +1224,85 @@ int lep_gpu_huffman_progressive_encode_device(lep_gpu* g, const lep_huffprog_ima
     char* const h_desc = (char*)g->h_huffprog[turn];
     memcpy(h_desc, images, nimg * sizeof(lep_huffprog_image));
     memcpy(h_desc + o_scan, scans, nscan * sizeof(lep_huffprog_scan));
+    // which scans the lane-per-unit kernels take (lep_huffprog_simt.h); the wavefront-per-scan kernel keeps the others
+    lephuff::ProgScan* hs = reinterpret_cast<lephuff::ProgScan*>(h_desc + o_scan);
+    std::vector<lephuff::ProgSimtScan> ps;
+    std::vector<lephuff::ProgSimtWave> waves;
+    std::vector<lephuff::ProgSimtRegion> regions;
+    size_t nunits = 0, scratch_bytes = 0;
+    for (int i = 0; i < nscan; ++i) hs[i].pad = 0;
+    if (g->huffprog_simt) {
+        // scans grouped by image (a region of bit buffers per image): the caller lists them file by file, but nothing here relies on it
+        std::vector<int> order((size_t)nscan);
+        for (int i = 0; i < nscan; ++i) order[(size_t)i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hs[a].image < hs[b].image; });
+        for (size_t a = 0; a < order.size();) {
+            size_t b = a;
+            while (b < order.size() && hs[order[b]].image == hs[order[a]].image) ++b;
+            const int im = hs[order[a]].image;
+            lephuff::ProgSimtRegion r{(uint32_t)ps.size(), 0u, scratch_bytes, 0};
+            uint64_t sum_cap = 0, max_cap = 0;
+            for (size_t k = a; k < b && im >= 0 && im < nimg; ++k) {
+                const int i = order[k];
+                uint32_t nb = 0, nu = 0;
+                if (!lephuff::prog_simt_takes(reinterpret_cast<const lephuff::ProgImage&>(images[im]), hs[i], &nb, &nu)) continue;
+                if (nunits + nu > 0x7fffffffu) continue;
+                lephuff::ProgSimtScan e;
+                memset(&e, 0, sizeof e);
+                e.scan = (uint32_t)i; e.first_unit = (uint32_t)nunits; e.nunits = nu; e.nblocks = nb;
+                for (uint32_t f = 0; f < nu; f += 64) waves.push_back(lephuff::ProgSimtWave{(uint32_t)ps.size(), f});
+                nunits += nu;
+                sum_cap += (uint64_t)hs[i].out_cap + 96; max_cap = std::max<uint64_t>(max_cap, hs[i].out_cap);
+                hs[i].pad = lephuff::kProgScanSimt;
+                ps.push_back(e);
+                ++r.nps;
+            }
+            if (r.nps) {
+                // the file's scans together are shorter than the file: out_cap of its longest-capped scan is the file's size where any AC
+                // scan is among them (progressive_plan); a file this does not hold for overflows its region and goes to the host re-coder
+                r.bytes = (std::min<uint64_t>(sum_cap, max_cap + 96ull * r.nps + 4096) + 15) & ~(uint64_t)15;
+                scratch_bytes += r.bytes;
+                regions.push_back(r);
+            }
+            a = b;
+        }
+    }
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_ps = 0, o_wv = up(ps.size() * sizeof(lephuff::ProgSimtScan)), o_rg = o_wv + up(waves.size() * sizeof(lephuff::ProgSimtWave)),
+                 o_un = o_rg + up(regions.size() * sizeof(lephuff::ProgSimtRegion)), o_sc = o_un + up(nunits * 4 * lephuff::kProgSimtUnitWords),
+                 simt_total = o_sc + up(scratch_bytes);
+    if (!ps.empty()) { if (int rc = ensure(g, &g->d_huffprogsimt[turn], &g->huffprogsimt_bytes[turn], simt_total)) return rc; }
     HIPCHK(g, hipMemcpyAsync(d_desc, h_desc, total, hipMemcpyHostToDevice, st));
+    char* eb = (char*)g->d_huffprogsimt[turn];
+    if (!ps.empty()) {
+        if (int rc = upload(g, eb + o_ps, ps.data(), ps.size() * sizeof(lephuff::ProgSimtScan), st)) return rc;
+        if (int rc = upload(g, eb + o_wv, waves.data(), waves.size() * sizeof(lephuff::ProgSimtWave), st)) return rc;
+        if (int rc = upload(g, eb + o_rg, regions.data(), regions.size() * sizeof(lephuff::ProgSimtRegion), st)) return rc;
+    }
+    const lephuff::ProgImage* di = (const lephuff::ProgImage*)d_desc;
+    const lephuff::ProgScan* ds = (const lephuff::ProgScan*)(d_desc + o_scan);
     HIPCHK(g, hipEventRecord(g->ev0, st));
-    hipLaunchKernelGGL(lep_huffman_progressive_encode_kernel, dim3(nscan), dim3(64), 0, st, (const lephuff::ProgImage*)d_desc,
-                       (const lephuff::ProgScan*)(d_desc + o_scan), d_out, d_corr, d_out_len);
+    if (!ps.empty()) {
+        lephuff::ProgSimtScan* dps = (lephuff::ProgSimtScan*)(eb + o_ps);
+        const lephuff::ProgSimtWave* dwv = (const lephuff::ProgSimtWave*)(eb + o_wv);
+        uint32_t* dun = (uint32_t*)(eb + o_un);
+        uint8_t* dsc = (uint8_t*)(eb + o_sc);
+        uint32_t longest = 0;
+        for (const lephuff::ProgSimtRegion& r : regions) longest = (uint32_t)std::max<uint64_t>(longest, r.bytes);
+        const uint32_t chunk16 = 4096;   // 64 KB of a bit buffer per workgroup of the clearing kernel
+        hipLaunchKernelGGL((lep_huffprog_simt_units_kernel<false>), dim3((unsigned)waves.size()), dim3(64), 0, st, di, ds, (const lephuff::ProgSimtScan*)dps, dwv, dun, nunits, dsc);
+        hipLaunchKernelGGL(lep_huffprog_simt_place_kernel, dim3((unsigned)ps.size()), dim3(64), 0, st, ds, dps, dun, nunits);
+        hipLaunchKernelGGL(lep_huffprog_simt_assign_kernel, dim3((unsigned)(regions.size() + 63) / 64), dim3(64), 0, st, (const lephuff::ProgSimtRegion*)(eb + o_rg), (int)regions.size(), dps);
+        hipLaunchKernelGGL(lep_huffprog_simt_zero_kernel, dim3((unsigned)ps.size(), (longest / 16 + chunk16 - 1) / chunk16 + 1), dim3(256), 0, st, (const lephuff::ProgSimtScan*)dps, dsc, chunk16);
+        hipLaunchKernelGGL((lep_huffprog_simt_units_kernel<true>), dim3((unsigned)waves.size()), dim3(64), 0, st, di, ds, (const lephuff::ProgSimtScan*)dps, dwv, dun, nunits, dsc);
+        hipLaunchKernelGGL(lep_huffprog_simt_stuff_kernel, dim3((unsigned)ps.size()), dim3(64), 0, st, di, ds, (const lephuff::ProgSimtScan*)dps, dsc, d_out, d_out_len);
+    }
+    if ((int)ps.size() < nscan)
+        hipLaunchKernelGGL(lep_huffman_progressive_encode_kernel, dim3(nscan), dim3(64), 0, st, di, ds, d_out, d_corr, d_out_len);
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
-    g->last_kernel = "lep_huffman_progressive_encode_kernel";
+    g->last_kernel = ps.empty() ? "lep_huffman_progressive_encode_kernel" : "lep_huffprog_simt_{units,place,stuff}_kernel";
     return 0;
 }
 

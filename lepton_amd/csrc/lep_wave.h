@@ -114,6 +114,28 @@ WDEV int wave_max(const int* in) {
 #endif
 }
 
+// inclusive prefix maximum (lane l: the largest of lanes 0 .. l)
+WDEV void wave_prefix_max(const int* in, int* out) {
+#if LEP_ON_GPU
+    out[0] = wave_incl_max(in[0]);
+#else
+    int m = in[0];
+    for (int i = 0; i < 64; ++i) { m = in[i] > m ? in[i] : m; out[i] = m; }
+#endif
+}
+// inclusive suffix minimum (lane l: the smallest of lanes l .. 63): the lanes reversed (one ds_bpermute each way), the prefix
+// maximum of the negated values in between
+WDEV void wave_suffix_min(const int* in, int* out) {
+#if LEP_ON_GPU
+    const int rev = (63 - (int)(threadIdx.x & 63)) * 4;
+    const int r = __builtin_amdgcn_ds_bpermute(rev, -in[0]);
+    out[0] = -__builtin_amdgcn_ds_bpermute(rev, wave_incl_max(r));
+#else
+    int m = in[63];
+    for (int i = 63; i >= 0; --i) { m = in[i] < m ? in[i] : m; out[i] = m; }
+#endif
+}
+
 // value of lane `src` (wave-uniform src)
 WDEV uint32_t wave_read(const uint32_t* v, int src) {
 #if LEP_ON_GPU

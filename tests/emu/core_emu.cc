@@ -195,6 +195,53 @@ extern "C" int emu_huffman_progressive_encode(const lep_huffprog_image* img, con
     return 0;
 }
 
+// ... with one lane per run of blocks (lep_huffprog_simt.h): count, place, assign, code, stuff, every pass one emulated wavefront
+// after the other.  taken[i]: 1 when that form took scan i (the others are written by the wavefront form above, as on the GPU).
+// region_bytes: > 0 stands in for the launch code's region size (tests: a region that does not suffice)
+#include "../../lepton_amd/csrc/lep_huffprog_simt.h"
+extern "C" int emu_huffman_progressive_encode_simt(const lep_huffprog_image* img, const lep_huffprog_scan* scans, int nscan, uint8_t* out, uint32_t* corr, uint32_t* out_len,
+                                                   int32_t* taken, uint64_t region_bytes) {
+    static lephuff::ProgSimtShared sh;
+    static lephuff::ProgShared shw;
+    const lephuff::ProgImage* im = reinterpret_cast<const lephuff::ProgImage*>(img);
+    std::vector<lephuff::ProgScan> sv((size_t)nscan);
+    memcpy(sv.data(), scans, sizeof(lephuff::ProgScan) * (size_t)nscan);
+    std::vector<lephuff::ProgSimtScan> ps;
+    size_t nunits = 0;
+    uint64_t sum_cap = 0, max_cap = 0;
+    for (int i = 0; i < nscan; ++i) {
+        sv[(size_t)i].pad = 0; sv[(size_t)i].image = 0; taken[i] = 0;
+        uint32_t nb = 0, nu = 0;
+        if (!lephuff::prog_simt_takes(*im, sv[(size_t)i], &nb, &nu)) continue;
+        lephuff::ProgSimtScan e;
+        memset(&e, 0, sizeof e);
+        e.scan = (uint32_t)i; e.first_unit = (uint32_t)nunits; e.nunits = nu; e.nblocks = nb;
+        nunits += nu;
+        sum_cap += (uint64_t)sv[(size_t)i].out_cap + 96; max_cap = std::max<uint64_t>(max_cap, sv[(size_t)i].out_cap);
+        sv[(size_t)i].pad = lephuff::kProgScanSimt; taken[i] = 1;
+        ps.push_back(e);
+    }
+    lephuff::ProgSimtRegion r{0u, (uint32_t)ps.size(), 0, 0};
+    r.bytes = region_bytes ? region_bytes : (std::min<uint64_t>(sum_cap, max_cap + 96ull * r.nps + 4096) + 15) & ~(uint64_t)15;
+    std::vector<uint32_t> words(nunits * lephuff::kProgSimtUnitWords + 1, 0xdeadbeefu);
+    std::vector<uint32_t> scratch((size_t)r.bytes / 4 + 8, 0xa5a5a5a5u);   // (garbage: the clearing pass has to do its work)
+    uint8_t* scb = reinterpret_cast<uint8_t*>(scratch.data());
+    lephuff::ProgSimtUnits U;
+    U.set(words.data(), nunits);
+    for (auto& e : ps) for (uint32_t f = 0; f < e.nunits; f += 64) lephuff::prog_simt_units<false>(im, sv.data(), &e, &sh, U, scb, f);
+    for (auto& e : ps) lephuff::prog_simt_place(sv.data(), &e, U);
+    if (!ps.empty()) lephuff::prog_simt_assign(r, ps.data());
+    for (auto& e : ps) {   // (lep_huffprog_simt_zero_kernel)
+        const uint64_t need16 = std::min<uint64_t>(((uint64_t)e.total_bits + 7) / 8 / 16 + 2, e.buf_bytes / 16);
+        memset(scb + e.buf_off, 0, (size_t)need16 * 16);
+    }
+    for (auto& e : ps) for (uint32_t f = 0; f < e.nunits; f += 64) lephuff::prog_simt_units<true>(im, sv.data(), &e, &sh, U, scb, f);
+    for (auto& e : ps) lephuff::prog_simt_stuff(im, sv.data(), e, scb, out, out_len);
+    for (int i = 0; i < nscan; ++i)
+        if (!taken[i]) { lephuff::ProgWave w; out_len[i] = w.run_scan(im, &sv[(size_t)i], &shw, out, corr); }
+    return 0;
+}
+
 // GPU Huffman scan decoder (lep_huffdec.h) as a 64-lane loop emulation: one image
 #include "../../lepton_amd/csrc/lep_huffdec.h"
 extern "C" int emu_huffman_decode_image(const lep_huffdec_image* img, lep_huffdec_row* rows) {

@@ -642,9 +642,10 @@ def test_current_kernels_on_random_images_match_the_oracle(emu):
     assert done >= 18
 
 
-def _progressive_scans_on_the_emulation(emu, jpg, lep):
+def _progressive_scans_on_the_emulation(emu, jpg, lep, simt=False, taken_out=None):
     """the frame of `jpg` through lep_huffprog.h's scan coders (lane-loop emulation), glued by the host; None if the file is
-    not eligible for the GPU coder"""
+    not eligible for the GPU coder.  simt: through lep_huffprog_simt.h's lane-per-unit passes (and every scan held against the
+    wavefront form's bytes)"""
     from lepton_amd import abi
     from lepton_amd.codec import LepFile
 
@@ -673,6 +674,19 @@ def _progressive_scans_on_the_emulation(emu, jpg, lep):
     emu.emu_huffman_progressive_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     assert emu.emu_huffman_progressive_encode(C.byref(img), scans, n, out, corr, lens) == 0
     assert all(l < 0x80000000 for l in lens), "a scan outgrew its slot"
+    if simt:
+        out2 = C.create_string_buffer(out_total + 64)
+        lens2 = (C.c_uint32 * n)()
+        taken = (C.c_int32 * n)()
+        emu.emu_huffman_progressive_encode_simt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        assert emu.emu_huffman_progressive_encode_simt(C.byref(img), scans, n, out2, corr, lens2, taken, 0) == 0
+        for i in range(n):
+            assert lens2[i] == lens[i], (i, lens2[i], lens[i], scans[i].from_, scans[i].to, scans[i].sah, scans[i].sal)
+            a, b = scans[i].out_off, scans[i].out_off + lens[i]
+            assert out2.raw[a:b] == out.raw[a:b], (i, scans[i].from_, scans[i].to, scans[i].sah, scans[i].sal)
+        if taken_out is not None:
+            taken_out.extend(taken)
+        out, lens = out2, lens2
     sb = (abi.Bytes * n)()
     for i in range(n):
         sb[i].data = C.addressof(out) + scans[i].out_off
@@ -761,6 +775,153 @@ def test_gpu_progressive_scan_encoder_on_cpu_restores_the_jpeg(emu, name):
     assert got == jpg
 
 
+@pytest.mark.parametrize("name", [n for n in golden_cases() if n.startswith("prog_") and "truncated" not in n])
+def test_lane_per_unit_progressive_scan_encoder_restores_the_jpeg(emu, name):
+    """lep_huffprog_simt.h (count / place / assign / code / stuff, one lane per 32 blocks) as a lane-loop emulation: every scan
+    byte-equal to the wavefront-per-scan form's, the glued file == the original; files with restart intervals stay with the
+    wavefront form"""
+    jpg, lep = golden(name)
+    taken = []
+    got, f = _progressive_scans_on_the_emulation(emu, jpg, lep, simt=True, taken_out=taken)
+    assert got is not None and got == jpg
+    assert all(taken) != ("rst" in name), taken
+
+
+def _prog_plan_for(jpg, lep):
+    """(file, image, scans, n) of an eligible progressive file: the descriptors lep_file_recode_plan_progressive fills"""
+    from lepton_amd import abi
+    from lepton_amd.codec import LepFile
+
+    L = abi.lib()
+    f = LepFile(lep)
+    img = abi.HuffProgImage()
+    scans = (abi.HuffProgScan * 64)()
+    nscan, ok = C.c_int(0), C.c_int(0)
+    assert L.lep_file_recode_plan_progressive(f.handle, C.byref(img), scans, 64, C.byref(nscan), C.byref(ok)) == 0
+    assert ok.value
+    return f, img, scans, nscan.value
+
+
+def _both_scan_writers(emu, img, scans, n, region=0):
+    """every scan of the plan through the wavefront form and the lane-per-unit form: [(bytes, bytes)]"""
+    out_total = corr_total = 0
+    for i in range(n):
+        scans[i].image = 0
+        scans[i].out_off = out_total
+        out_total += (scans[i].out_cap + 15) & ~15
+        scans[i].corr_off = corr_total
+        corr_total += scans[i].corr_cap
+    corr = (C.c_uint32 * (corr_total + 8))()
+    outs, lens = [], []
+    for form in (0, 1):
+        out = C.create_string_buffer(out_total + 64)
+        ln = (C.c_uint32 * n)()
+        if form == 0:
+            emu.emu_huffman_progressive_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            assert emu.emu_huffman_progressive_encode(C.byref(img), scans, n, out, corr, ln) == 0
+        else:
+            taken = (C.c_int32 * n)()
+            emu.emu_huffman_progressive_encode_simt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+            assert emu.emu_huffman_progressive_encode_simt(C.byref(img), scans, n, out, corr, ln, taken, region) == 0
+            assert all(taken)
+        outs.append(out)
+        lens.append(list(ln))
+    return [(lens[0][i], outs[0].raw[scans[i].out_off: scans[i].out_off + (lens[0][i] & 0x7fffffff)],
+             lens[1][i], outs[1].raw[scans[i].out_off: scans[i].out_off + (lens[1][i] & 0x7fffffff)]) for i in range(n)]
+
+
+def test_lane_per_unit_progressive_scan_encoder_on_drawn_frames(emu):
+    """the two forms on frames drawn as coefficients (not every one a frame a decoder could have produced -- the writers do not
+    care): densities from empty to full, long stretches of blocks with nothing in a band (end-of-band runs across many units),
+    tables whose longest run is 1 / 3 / 7 / 31 blocks (the run arithmetic modulo that), one block wide and one block high
+    components"""
+    import numpy as np
+    from lepton_amd import corpus
+
+    rng = np.random.default_rng(77)
+    cases = 0
+    for trial, (w, h, sub) in enumerate([(160, 120, "4:2:0"), (203, 149, "4:4:4"), (8, 600, "4:2:0"), (700, 8, "4:2:2"), (333, 241, "4:2:0"), (96, 64, "4:2:2")]):
+        jpg = corpus.synth_jpeg(w, h, 600 + trial, progressive=True, subsampling=sub, quality=[90, 60, 95, 30, 75, 85][trial])
+        img0 = JpegImage(jpg)
+        streams, _ = ob.oracle_encode(img0.desc, img0.plan())
+        f, img, scans, n = _prog_plan_for(jpg, img0.write_lep(streams))
+        for variant in range(5):
+            for c in range(f.desc.ncomp):
+                nb = f.desc.nblocks(c)
+                arr = np.zeros((nb, 64), dtype=np.int16)
+                dens = [0.0, 0.02, 0.15, 0.6, 1.0][variant]
+                mask = rng.random((nb, 64)) < dens
+                vals = rng.integers(-40, 41, (nb, 64)).astype(np.int16)
+                if variant == 3:
+                    vals = rng.integers(-2000, 2001, (nb, 64)).astype(np.int16)
+                arr[mask] = vals[mask]
+                if variant in (1, 2):   # whole stretches of blocks with nothing in them, and blocks that only hold old coefficients
+                    for _ in range(4):
+                        a = int(rng.integers(0, nb)); b = min(nb, a + int(rng.integers(1, max(2, nb // 2))))
+                        arr[a:b] = 0 if rng.random() < 0.5 else (arr[a:b] & ~1) * 2
+                C.memmove(f.desc.blocks[c], arr.ctypes.data, nb * 128)
+            for mx in (0, 1, 3, 7, 31):
+                keep = [scans[i].max_eobrun for i in range(n)]
+                if mx:
+                    for i in range(n):
+                        if scans[i].to != 0:
+                            scans[i].max_eobrun = min(mx, keep[i])
+                res = _both_scan_writers(emu, img, scans, n)
+                outgrown = any(l0 & 0x80000000 for l0, _, _, _ in res) or sum(l0 for l0, _, _, _ in res) > len(jpg)
+                for i, (l0, b0, l1, b1) in enumerate(res):
+                    if l0 & 0x80000000:     # (a drawn frame may code to more than the file the plan was made for: both forms say so)
+                        assert l1 & 0x80000000, (trial, variant, mx, i)
+                        continue
+                    if outgrown and (l1 & 0x80000000):   # (... and the scans behind it found the file's region used up)
+                        continue
+                    assert l0 == l1 and b0 == b1, (trial, variant, mx, i, scans[i].from_, scans[i].to, scans[i].sah, scans[i].sal, l0, l1)
+                    cases += 1
+                for i in range(n):
+                    scans[i].max_eobrun = keep[i]
+    assert cases > 500
+
+
+def test_lane_per_unit_progressive_scan_encoder_on_runs_past_32767_blocks(emu):
+    """a 2048 x 2048 frame whose bands are empty for tens of thousands of blocks in a row: an end-of-band run is written when it
+    reaches 32767 blocks and the next begins (encode_eobrun, jpgcoder.cc:5337-5368); the lane-per-unit form finds those
+    places by arithmetic"""
+    import numpy as np
+    from lepton_amd import corpus
+
+    jpg = corpus.synth_jpeg(2048, 2048, 610, progressive=True, subsampling="4:4:4", quality=20)
+    img0 = JpegImage(jpg)
+    streams, _ = ob.oracle_encode(img0.desc, img0.plan())
+    f, img, scans, n = _prog_plan_for(jpg, img0.write_lep(streams))
+    assert any(scans[i].max_eobrun == 32767 for i in range(n))
+    rng = np.random.default_rng(3)
+    for c in range(f.desc.ncomp):
+        nb = f.desc.nblocks(c)
+        arr = np.zeros((nb, 64), dtype=np.int16)
+        for at in ([5, 40000, 40001, 65000] if c == 0 else ([32767 + 3] if c == 1 else [])):
+            arr[at] = rng.integers(-9, 10, 64)
+        C.memmove(f.desc.blocks[c], arr.ctypes.data, nb * 128)
+    for i, (l0, b0, l1, b1) in enumerate(_both_scan_writers(emu, img, scans, n)):
+        assert l0 == l1 and b0 == b1, (i, l0, l1)
+
+
+def test_lane_per_unit_progressive_scan_encoder_says_when_its_region_is_too_small(emu):
+    """the bit buffers of a file's scans share a region sized by the file; when it does not suffice the scans left without one
+    answer "outgrew" (bit 31) and the rest are still right"""
+    from lepton_amd import corpus
+
+    jpg = corpus.synth_jpeg(320, 240, 611, progressive=True)
+    img0 = JpegImage(jpg)
+    streams, _ = ob.oracle_encode(img0.desc, img0.plan())
+    f, img, scans, n = _prog_plan_for(jpg, img0.write_lep(streams))
+    src = JpegImage(jpg)
+    for c in range(f.desc.ncomp):
+        C.memmove(f.desc.blocks[c], src.desc.blocks[c], f.desc.nblocks(c) * 128)
+    res = _both_scan_writers(emu, img, scans, n, region=len(jpg) // 2)
+    assert any(l1 & 0x80000000 for _, _, l1, _ in res) and any(not (l1 & 0x80000000) for _, _, l1, _ in res)
+    for l0, b0, l1, b1 in res:
+        assert (l1 & 0x80000000) or (l0 == l1 and b0 == b1)
+
+
 def test_gpu_progressive_scan_encoder_on_random_files(emu):
     """PIL-written progressive files over sizes, samplings, qualities and restart intervals (long end-of-band runs in smooth
     images, 4:4:4 / 4:2:2 / 4:2:0 / grey, non-multiple-of-MCU sizes): emulated GPU scans == the input JPEG"""
@@ -792,7 +953,7 @@ def test_gpu_progressive_scan_encoder_on_random_files(emu):
         img = JpegImage(jpg)
         streams, _ = ob.oracle_encode(img.desc, img.plan())
         lep = img.write_lep(streams)
-        got, _ = _progressive_scans_on_the_emulation(emu, jpg, lep)
+        got, _ = _progressive_scans_on_the_emulation(emu, jpg, lep, simt=True)
         assert got is not None and got == jpg, (trial, w, h, mode, kw)
         done += 1
     assert done == 14

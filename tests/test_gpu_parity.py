@@ -593,6 +593,39 @@ def test_gpu_progressive_scans_are_recoded_on_the_gpu(gpu_codec):
     assert st3 == [0, 0, 0] and back3 == big
 
 
+@pytest.mark.parametrize("simt", ["0", "1"])
+def test_gpu_progressive_scan_writers_in_the_decompress_pipeline(monkeypatch, simt):
+    """the decompressor's progressive scan bytes from the lane-per-unit kernels (lep_huffprog_simt.h, the default: count / place /
+    assign / code / stuff) and from the wavefront-per-scan kernel (LEP_HUFFPROG_SIMT=0): the original files, byte for byte, from
+    both -- the progressive fixtures (one with restart intervals, which stays with the wavefront kernel), the reference's own
+    progressive images, and synthetic files up to 4K in three sampling layouts"""
+    from conftest import ref_cases, ref_golden
+
+    names = [n for n in golden_cases() if n.startswith("prog_") and "truncated" not in n]
+    jpgs = [golden(n)[0] for n in names]
+    leps = [golden(n)[1] for n in names]
+    for n in ref_cases(progressive=True):
+        j, l = ref_golden(n)
+        jpgs.append(j); leps.append(l)
+    big = [corpus.synth_jpeg(3840, 2160, 191, progressive=True), corpus.synth_jpeg(640, 480, 192, progressive=True, subsampling="4:4:4", quality=97),
+           corpus.synth_jpeg(800, 600, 193, progressive=True, quality=35), corpus.synth_jpeg(333, 241, 194, progressive=True, subsampling="4:2:2"),
+           corpus.synth_jpeg(2048, 2048, 195, progressive=True, quality=10)]
+    monkeypatch.setenv("LEP_HUFFPROG_SIMT", simt)
+    codec = GpuCodec(0)        # the knob is read when the codec object is made
+    try:
+        leps += [codec.compress(j) for j in big]
+        jpgs += big
+        back, st, stats = codec.decompress_batch(leps, chunk_images=64)
+        assert st == [0] * len(leps), st
+        for i in range(len(leps)):
+            assert back[i] == jpgs[i], i
+        assert stats["gpu_huffman_files"] >= len(leps) - 3, stats   # (two of the reference's images are not whole progressive frames: the host re-coder's)
+        name = abi.lib().lep_gpu_last_kernel_name(codec.handle).decode()
+        assert ("huffprog_simt" in name) == (simt == "1"), name
+    finally:
+        codec.close()
+
+
 def test_gpu_progressive_scans_are_decoded_on_the_gpu(gpu_codec):
     """encode direction of progressive files: lep_huffprogdec.h (one wavefront per scan, dependency levels) + the arithmetic
     coder; the .lep files equal the reference's byte for byte, truncated progressive files still take the host parser, and
