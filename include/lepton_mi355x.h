@@ -178,7 +178,8 @@ typedef struct lep_huffprog_scan {
     uint64_t out_off;
     uint32_t out_cap;
     uint32_t corr_off, corr_cap;         /* dwords */
-    uint32_t pad;
+    uint32_t file_bound;                 /* bytes ALL scans of this scan's image produce together at most (they are parts of one file: its
+                                          * size); 0 = unknown, the sum of their out_cap.  Sizes the bit buffers of the lane-per-unit kernels. */
     uint32_t code[2][256];               /* DC scans: DC tables 0 / 1; AC scans: [0] = the component's AC table; length << 16 | code */
 } lep_huffprog_scan;
 int lep_gpu_huffman_progressive_encode_device(lep_gpu *g, const lep_huffprog_image *images, int nimg, const lep_huffprog_scan *scans,

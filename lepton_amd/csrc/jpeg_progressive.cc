@@ -598,6 +598,7 @@ int progressive_plan(JpegFile* jfp, size_t jpeg_size, bool rst_cnt_set, ProgPlan
         const size_t geo = blocks * (dc ? 8 : 432) + nmark * 2 + units / 4 + 64;
         sc.out_cap = (uint32_t)std::min<size_t>(std::min<size_t>(jpeg_size + 16, geo), 0xfffffff0u);
         sc.corr_cap = (!dc && sc.sah != 0) ? (uint32_t)std::min<size_t>(blocks * 2 + 8, 0x7fffffffu) : 0u;
+        sc.file_bound = (uint32_t)std::min<size_t>(jpeg_size + 16, 0xfffffff0u);   // what ALL scans of the file come to at most: they are parts of it
         plan->scans.push_back(sc);
         if (plan->scans.size() > 256) return 0;
     }

@@ -105,7 +105,7 @@ struct ProgScan {
     uint32_t out_cap;
     uint32_t corr_off;
     uint32_t corr_cap;
-    uint32_t pad;
+    uint32_t file_bound;                  // bytes all scans of the file produce together at most (0 = unknown)
     uint32_t code[2][256];
 };
 struct ProgPlan {

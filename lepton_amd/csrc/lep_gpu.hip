@@ -28,6 +28,7 @@
 #include "lep_huffprog.h"
 #include "lep_huffprog_simt.h"
 #include "lep_huffprogdec.h"
+#include "lep_huffprogdec_win.h"
 
 using namespace lepdev;
 
@@ -373,6 +374,28 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_progressive_decode_kernel(c
     lephuff::ProgDecWave w;
     w.run_scan<false>(scans + blockIdx.x, &sh, rows);
 }
+// the same two launches with the window of speculative codes (lep_huffprogdec_win.h) for the scans it takes (ProgDecScan.pad)
+__global__ __launch_bounds__(64, 2) void lep_huffprogdec_win_kernel(const lephuff::ProgDecScan* __restrict__ scans, lephuff::HuffDecRow* rows) {
+    __shared__ lephuff::ProgWinShared ws;
+    __shared__ lephuff::HuffDecShared sh;
+    const lephuff::ProgDecScan* sc = scans + blockIdx.x;
+    if (sc->pad & lephuff::kProgDecWin) { lephuff::ProgWinWave w; w.run_scan_win<false>(sc, &ws, rows); }
+    else { lephuff::ProgDecWave w; w.run_scan<false>(sc, &sh, rows); }
+}
+__global__ __launch_bounds__(64, 2) void lep_huffprogdec_win_pipelined_kernel(const lephuff::ProgDecScan* __restrict__ scans, lephuff::HuffDecRow* rows,
+                                                                            const lephuff::ProgDeps* __restrict__ deps, uint32_t* progress, uint32_t* ticket) {
+    __shared__ lephuff::ProgWinShared ws;
+    __shared__ lephuff::HuffDecShared sh;
+    uint32_t t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(ticket, 1u);
+    const int k = __builtin_amdgcn_readfirstlane((int)t);
+    const lephuff::ProgDecScan* sc = scans + k;
+    // (the scans of a file run side by side, two or three wavefronts to a SIMD, and each is one chain bound by its own instruction
+    // issue: the long ones -- luma AC scans, the file's critical path -- are served first)
+    if (sc->to != 0) { if (sc->cmp[0] == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); }
+    if (sc->pad & lephuff::kProgDecWin) { lephuff::ProgWinWave w; w.run_scan_win<true>(sc, &ws, rows, deps + k, progress, k); }
+    else { lephuff::ProgDecWave w; w.run_scan<true>(sc, &sh, rows, deps + k, progress, k); }
+}
 // ... all levels in ONE launch: a scan waits, MCU row by MCU row, for the scans of its file it follows (lep_huffprogdec.h ProgDeps)
 // (128 VGPRs: at 64 the waiting code's spills trip a register-pair alignment check in this compiler's backend; a launch of this
 // kind is small, what it needs is a short chain)
@@ -448,6 +471,8 @@ struct lep_gpu {
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // the split-phase encoder folds its long chains beside its many short ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     int huffprog_pipeline = 1;          // LEP_HUFFPROG_PIPELINE=0: progressive scan decode level by level, whatever the launch size
+    int huffprog_split = 0;             // LEP_HUFFPROG_SPLIT=1: level-by-level launches split by kind of scan (measurement aid)
+    int huffprogdec_win = 1;            // LEP_HUFFPROGDEC_WIN=0: progressive scans decoded by lep_huffprogdec.h's uniform vector code only
     int huffprog_simt = 1;              // LEP_HUFFPROG_SIMT=0: every progressive scan's bytes from the wavefront-per-scan kernel (lep_huffprog.h)
     void* d_huffprogsimt[2] = {nullptr, nullptr}; size_t huffprogsimt_bytes[2] = {0, 0};   // lep_huffprog_simt.h: descriptors, unit arrays, bit buffers (one per arena set)
     int huffenc_simt = 1;               // LEP_HUFFENC_SIMT=0: every segment's scan bytes from the wavefront-per-segment kernel (lep_huff.h)
@@ -991,6 +1016,8 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_HUFFDEC_SIMT_BITS")) g->simt_sub_bits = std::max(0, atoi(e));
     if (const char* e = getenv("LEP_HUFFENC_SIMT")) g->huffenc_simt = atoi(e) != 0;
     if (const char* e = getenv("LEP_HUFFPROG_SIMT")) g->huffprog_simt = atoi(e) != 0;
+    if (const char* e = getenv("LEP_HUFFPROGDEC_WIN")) g->huffprogdec_win = atoi(e) != 0;
+    if (const char* e = getenv("LEP_HUFFPROG_SPLIT")) g->huffprog_split = atoi(e) != 0;
     if (const char* e = getenv("LEP_ENC5_WAVES")) g->enc5_waves = atoi(e) == 1 ? 1 : 2;
     if (const char* e = getenv("LEP_ENC5_FOLD_APART")) g->enc5_fold_apart = atoi(e);
     if (const char* e = getenv("LEP_ENC5_GATHER_WGS")) g->enc5_gather_wgs = atoi(e);
@@ -1155,11 +1182,22 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu* g, const lep_huffprogdec_
     sorted.reserve((size_t)nscan);
     std::vector<int> first((size_t)maxlevel + 2, 0), order;
     order.reserve((size_t)nscan);
+    // (LEP_HUFFPROG_SPLIT=1, a measurement aid: inside a level the scans of one KIND -- DC / AC, first stage / refinement, component, band --
+    // stand together and get a launch of their own, so that a kernel trace shows what each kind of scan takes)
+    auto kind = [](const lep_huffprogdec_scan& s) { return (s.to == 0 ? 0 : 1) * 100000 + (s.sah ? 1 : 0) * 10000 + (s.cmpc > 1 ? 9 : s.cmp[0]) * 1000 + s.from * 10 + (s.to > 9 ? 9 : s.to); };
+    std::vector<int> cut;   // launch boundaries inside `sorted`
     for (int lv = 0; lv <= maxlevel; ++lv) {
         first[(size_t)lv] = (int)sorted.size();
-        for (int i = 0; i < nscan; ++i) if (scans[i].level == lv) { sorted.push_back(scans[i]); order.push_back(i); }
+        std::vector<int> idx;
+        for (int i = 0; i < nscan; ++i) if (scans[i].level == lv) idx.push_back(i);
+        if (g->huffprog_split) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return kind(scans[a]) < kind(scans[b]); });
+        for (size_t q = 0; q < idx.size(); ++q) {
+            if (q == 0 || (g->huffprog_split && kind(scans[idx[q]]) != kind(scans[idx[q - 1]]))) cut.push_back((int)sorted.size());
+            sorted.push_back(scans[idx[q]]); order.push_back(idx[q]);
+        }
     }
     first[(size_t)maxlevel + 1] = (int)sorted.size();
+    cut.push_back((int)sorted.size());
     // Small launches wait for the chain of a file's dependent scans, not for throughput: all levels go out as ONE launch in which
     // a scan follows the scans in front of it MCU row by MCU row.  (Beyond what is resident at once the levels are launched one
     // after the other as before: the chip is full either way.)
@@ -1172,6 +1210,13 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu* g, const lep_huffprogdec_
     const size_t o_deps = ((size_t)nscan * sizeof(lep_huffprogdec_scan) + 255) & ~(size_t)255, o_prog = o_deps + (((size_t)nscan * sizeof(lephuff::ProgDeps) + 255) & ~(size_t)255),
                  total = o_prog + (size_t)nscan * 4 + 4;   // (+ the ticket counter behind the progress words)
     if (int rc = ensure(g, &g->d_huffprogdec, &g->huffprogdec_bytes, total)) return rc;
+    // which scans the window of speculative codes decodes (lep_huffprogdec_win.h); lep_huffprogdec.h's uniform vector code keeps the others
+    bool any_win = false;
+    for (lep_huffprogdec_scan& sc : sorted) {
+        const bool w = g->huffprogdec_win && lephuff::prog_win_takes(reinterpret_cast<const lephuff::ProgDecScan&>(sc));
+        sc.pad = w ? lephuff::kProgDecWin : 0;
+        any_win = any_win || w;
+    }
     HIPCHK(g, hipMemcpyAsync(g->d_huffprogdec, sorted.data(), (size_t)nscan * sizeof(lep_huffprogdec_scan), hipMemcpyHostToDevice, st));
     if (pipelined) {
         HIPCHK(g, hipMemcpyAsync((char*)g->d_huffprogdec + o_deps, deps.data(), (size_t)nscan * sizeof(lephuff::ProgDeps), hipMemcpyHostToDevice, st));
@@ -1180,24 +1225,25 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu* g, const lep_huffprogdec_
     HIPCHK(g, hipStreamSynchronize(st));
     HIPCHK(g, hipEventRecord(g->ev0, st));
     if (pipelined) {
-        hipLaunchKernelGGL(lep_huffman_progressive_pipelined_kernel, dim3(nscan), dim3(64), 0, st, (const lephuff::ProgDecScan*)g->d_huffprogdec, (lephuff::HuffDecRow*)d_rows,
+        hipLaunchKernelGGL(any_win ? lep_huffprogdec_win_pipelined_kernel : lep_huffman_progressive_pipelined_kernel, dim3(nscan), dim3(64), 0, st,
+                           (const lephuff::ProgDecScan*)g->d_huffprogdec, (lephuff::HuffDecRow*)d_rows,
                            (const lephuff::ProgDeps*)((char*)g->d_huffprogdec + o_deps), (uint32_t*)((char*)g->d_huffprogdec + o_prog), (uint32_t*)((char*)g->d_huffprogdec + o_prog) + nscan);
         HIPCHK(g, hipGetLastError());
         HIPCHK(g, hipEventRecord(g->ev1, st));
         g->timed = true;
-        g->last_kernel = "lep_huffman_progressive_pipelined_kernel";
+        g->last_kernel = any_win ? "lep_huffprogdec_win_pipelined_kernel" : "lep_huffman_progressive_pipelined_kernel";
         return 0;
     }
-    for (int lv = 0; lv <= maxlevel; ++lv) {
-        const int n = first[(size_t)lv + 1] - first[(size_t)lv];
+    for (size_t c = 0; c + 1 < cut.size(); ++c) {   // one launch per level (LEP_HUFFPROG_SPLIT: per level and kind of scan)
+        const int n = cut[c + 1] - cut[c];
         if (n <= 0) continue;
-        hipLaunchKernelGGL(lep_huffman_progressive_decode_kernel, dim3(n), dim3(64), 0, st,
-                           (const lephuff::ProgDecScan*)g->d_huffprogdec + first[(size_t)lv], (lephuff::HuffDecRow*)d_rows);
+        hipLaunchKernelGGL(any_win ? lep_huffprogdec_win_kernel : lep_huffman_progressive_decode_kernel, dim3(n), dim3(64), 0, st,
+                           (const lephuff::ProgDecScan*)g->d_huffprogdec + cut[c], (lephuff::HuffDecRow*)d_rows);
     }
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));
     g->timed = true;
-    g->last_kernel = "lep_huffman_progressive_decode_kernel";
+    g->last_kernel = any_win ? "lep_huffprogdec_win_kernel" : "lep_huffman_progressive_decode_kernel";
     return 0;
 }
 
@@ -1230,7 +1276,8 @@ int lep_gpu_huffman_progressive_encode_device(lep_gpu* g, const lep_huffprog_ima
     std::vector<lephuff::ProgSimtWave> waves;
     std::vector<lephuff::ProgSimtRegion> regions;
     size_t nunits = 0, scratch_bytes = 0;
-    for (int i = 0; i < nscan; ++i) hs[i].pad = 0;
+    std::vector<uint32_t> file_bound((size_t)nscan);
+    for (int i = 0; i < nscan; ++i) { file_bound[(size_t)i] = hs[i].pad; hs[i].pad = 0; }   // (the caller's field; on the device it says which kernel owns the scan)
     if (g->huffprog_simt) {
         // scans grouped by image (a region of bit buffers per image): the caller lists them file by file, but nothing here relies on it
         std::vector<int> order((size_t)nscan);
@@ -1241,7 +1288,7 @@ int lep_gpu_huffman_progressive_encode_device(lep_gpu* g, const lep_huffprog_ima
             while (b < order.size() && hs[order[b]].image == hs[order[a]].image) ++b;
             const int im = hs[order[a]].image;
             lephuff::ProgSimtRegion r{(uint32_t)ps.size(), 0u, scratch_bytes, 0};
-            uint64_t sum_cap = 0, max_cap = 0;
+            uint64_t sum_cap = 0, bound = 0;
             for (size_t k = a; k < b && im >= 0 && im < nimg; ++k) {
                 const int i = order[k];
                 uint32_t nb = 0, nu = 0;
@@ -1252,15 +1299,15 @@ int lep_gpu_huffman_progressive_encode_device(lep_gpu* g, const lep_huffprog_ima
                 e.scan = (uint32_t)i; e.first_unit = (uint32_t)nunits; e.nunits = nu; e.nblocks = nb;
                 for (uint32_t f = 0; f < nu; f += 64) waves.push_back(lephuff::ProgSimtWave{(uint32_t)ps.size(), f});
                 nunits += nu;
-                sum_cap += (uint64_t)hs[i].out_cap + 96; max_cap = std::max<uint64_t>(max_cap, hs[i].out_cap);
+                sum_cap += (uint64_t)hs[i].out_cap + 96; bound = std::max<uint64_t>(bound, file_bound[(size_t)i]);
                 hs[i].pad = lephuff::kProgScanSimt;
                 ps.push_back(e);
                 ++r.nps;
             }
             if (r.nps) {
-                // the file's scans together are shorter than the file: out_cap of its longest-capped scan is the file's size where any AC
-                // scan is among them (progressive_plan); a file this does not hold for overflows its region and goes to the host re-coder
-                r.bytes = (std::min<uint64_t>(sum_cap, max_cap + 96ull * r.nps + 4096) + 15) & ~(uint64_t)15;
+                // the file's scans together are shorter than the file (lep_huffprog_scan.file_bound, where the caller said); a region
+                // that turns out too small leaves scans without a buffer, and the host re-coder takes the file
+                r.bytes = ((bound ? std::min<uint64_t>(sum_cap, bound + 96ull * r.nps + 4096) : sum_cap) + 15) & ~(uint64_t)15;
                 scratch_bytes += r.bytes;
                 regions.push_back(r);
             }

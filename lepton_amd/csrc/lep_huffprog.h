@@ -39,7 +39,8 @@ struct ProgScan {
     uint32_t out_cap;
     uint32_t corr_off;          // this scan's scratch area for held-back correction bits (dwords into the scratch arena)
     uint32_t corr_cap;          // dwords
-    uint32_t pad;
+    uint32_t pad;               // caller: bytes all scans of the image produce together at most (lep_huffprog_scan.file_bound); on the device:
+                                // which kernel owns the scan (lep_huffprog_simt.h kProgScanSimt)
     uint32_t code[2][256];      // length << 16 | code
 };
 

@@ -145,6 +145,60 @@ WDEV uint32_t wave_read(const uint32_t* v, int src) {
 #endif
 }
 
+// lane `dst` (wave-uniform) of v takes `value` (wave-uniform).  (A compare and a select: this compiler has no builtin for
+// v_writelane_b32, and on gfx9 the instruction may name one scalar register only -- lane and value would have to share it or go through m0.)
+WDEV void wave_write(uint32_t* v, int dst, uint32_t value) {
+#if LEP_ON_GPU
+    v[0] = (int)(threadIdx.x & 63) == dst ? value : v[0];
+#else
+    v[dst] = value;
+#endif
+}
+
+// lanes whose bit is set in the wave-uniform mask m take `value` (wave-uniform); the others keep what they have.  One v_cndmask_b32
+// with the mask as its scalar-pair operand: written in C (`(m >> lane) & 1 ? value : v`) the compiler shifts the mask by the lane
+// number in every lane -- six vector instructions where the hardware takes the mask as it is.
+WDEV void wave_select(uint32_t* v, uint64_t m, uint32_t value) {
+#if LEP_ON_GPU
+    uint32_t x = v[0];
+    __asm__ volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(value), "s"(m));
+    v[0] = x;
+#else
+    for (int i = 0; i < 64; ++i) if ((m >> i) & 1ull) v[i] = value;
+#endif
+}
+// ... and per-lane values: lanes in m take their own w, the others keep v
+WDEV void wave_select_v(uint32_t* v, uint64_t m, const uint32_t* w) {
+#if LEP_ON_GPU
+    uint32_t x = v[0];
+    __asm__ volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(w[0]), "s"(m));
+    v[0] = x;
+#else
+    for (int i = 0; i < 64; ++i) if ((m >> i) & 1ull) v[i] = w[i];
+#endif
+}
+
 WDEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
+
+// Global memory through pointers whose address space the compiler cannot see (they come out of descriptors in memory): a plain
+// dereference is a FLAT instruction, which counts against the LDS wait counter as well -- every wait for an LDS read then also
+// waits for whatever was requested from HBM and is still in flight.  gld / gst name the address space (lep_enc5.h has the same pair).
+#if LEP_ON_GPU
+template <class T> WDEV T gld(const T* p) { return *(const __attribute__((address_space(1))) T*)(uintptr_t)p; }
+template <class T> WDEV void gst(T* p, const T& v) { *(__attribute__((address_space(1))) T*)(uintptr_t)p = v; }
+#else
+template <class T> WDEV T gld(const T* p) { return *p; }
+template <class T> WDEV void gst(T* p, const T& v) { *p = v; }
+#endif
+
+// set bits of a wave-uniform mask below lane l (inside LANES(l)): v_mbcnt_lo / _hi
+WDEV int mbcnt(uint64_t m, int l) {
+#if LEP_ON_GPU
+    (void)l;
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#else
+    return __builtin_popcountll(m & ((1ull << l) - 1));
+#endif
+}
 
 }  // namespace lepwave

@@ -208,8 +208,9 @@ extern "C" int emu_huffman_progressive_encode_simt(const lep_huffprog_image* img
     memcpy(sv.data(), scans, sizeof(lephuff::ProgScan) * (size_t)nscan);
     std::vector<lephuff::ProgSimtScan> ps;
     size_t nunits = 0;
-    uint64_t sum_cap = 0, max_cap = 0;
+    uint64_t sum_cap = 0, bound = 0;
     for (int i = 0; i < nscan; ++i) {
+        bound = std::max<uint64_t>(bound, sv[(size_t)i].pad);   // (lep_huffprog_scan.file_bound)
         sv[(size_t)i].pad = 0; sv[(size_t)i].image = 0; taken[i] = 0;
         uint32_t nb = 0, nu = 0;
         if (!lephuff::prog_simt_takes(*im, sv[(size_t)i], &nb, &nu)) continue;
@@ -217,12 +218,12 @@ extern "C" int emu_huffman_progressive_encode_simt(const lep_huffprog_image* img
         memset(&e, 0, sizeof e);
         e.scan = (uint32_t)i; e.first_unit = (uint32_t)nunits; e.nunits = nu; e.nblocks = nb;
         nunits += nu;
-        sum_cap += (uint64_t)sv[(size_t)i].out_cap + 96; max_cap = std::max<uint64_t>(max_cap, sv[(size_t)i].out_cap);
+        sum_cap += (uint64_t)sv[(size_t)i].out_cap + 96;
         sv[(size_t)i].pad = lephuff::kProgScanSimt; taken[i] = 1;
         ps.push_back(e);
     }
     lephuff::ProgSimtRegion r{0u, (uint32_t)ps.size(), 0, 0};
-    r.bytes = region_bytes ? region_bytes : (std::min<uint64_t>(sum_cap, max_cap + 96ull * r.nps + 4096) + 15) & ~(uint64_t)15;
+    r.bytes = region_bytes ? region_bytes : ((bound ? std::min<uint64_t>(sum_cap, bound + 96ull * r.nps + 4096) : sum_cap) + 15) & ~(uint64_t)15;
     std::vector<uint32_t> words(nunits * lephuff::kProgSimtUnitWords + 1, 0xdeadbeefu);
     std::vector<uint32_t> scratch((size_t)r.bytes / 4 + 8, 0xa5a5a5a5u);   // (garbage: the clearing pass has to do its work)
     uint8_t* scb = reinterpret_cast<uint8_t*>(scratch.data());
@@ -293,6 +294,40 @@ extern "C" int emu_huffman_progressive_decode_pipelined(const lep_huffprogdec_sc
 }
 
 
+
+// ... with the window of speculative codes (lep_huffprogdec_win.h) for the scans that form takes: level by level (pipelined = 0) or
+// in the one launch's order with its waiting / publishing code (pipelined = 1).  taken: how many scans the window form decoded.
+#include "../../lepton_amd/csrc/lep_huffprogdec_win.h"
+extern "C" int emu_huffman_progressive_decode_win(const lep_huffprogdec_scan* scans, int nscan, lep_huffdec_row* rows, int pipelined, int32_t* taken) {
+    static lephuff::HuffDecShared sh;
+    static lephuff::ProgWinShared ws;
+    std::vector<lephuff::ProgDecScan> sorted;
+    std::vector<int> order;
+    for (int lv = 0; lv < 64; ++lv)
+        for (int i = 0; i < nscan; ++i)
+            if (scans[i].level == lv) { sorted.push_back(*reinterpret_cast<const lephuff::ProgDecScan*>(scans + i)); order.push_back(i); }
+    if ((int)sorted.size() != nscan) return -1;
+    std::vector<lephuff::ProgDeps> deps((size_t)nscan);
+    if (pipelined && !lephuff::prog_scan_deps(sorted.data(), order.data(), nscan, deps.data())) return -2;
+    std::vector<uint32_t> progress((size_t)nscan, 0u);
+    *taken = 0;
+    for (int k = 0; k < nscan; ++k) {
+        const bool win = lephuff::prog_win_takes(sorted[(size_t)k]);
+        *taken += win;
+        lephuff::HuffDecRow* r = reinterpret_cast<lephuff::HuffDecRow*>(rows);
+        if (win) {
+            lephuff::ProgWinWave w;
+            if (pipelined) w.run_scan_win<true>(&sorted[(size_t)k], &ws, r, &deps[(size_t)k], progress.data(), k);
+            else w.run_scan_win<false>(&sorted[(size_t)k], &ws, r);
+        } else {
+            lephuff::ProgDecWave w;
+            if (pipelined) w.run_scan<true>(&sorted[(size_t)k], &sh, r, &deps[(size_t)k], progress.data(), k);
+            else w.run_scan<false>(&sorted[(size_t)k], &sh, r);
+        }
+        if (pipelined && progress[(size_t)k] != 0x7fffffffu) return -4;
+    }
+    return 0;
+}
 
 // one lane per subsequence (lep_huffdec_simt.h): guess, settle passes, place, write -- every pass one wavefront after the other.
 // settle_moved[k] (k = 0 .. kSimtSettle): whether pass k saw an end state move; nsub_out: subsequences the scan was cut into.

@@ -959,10 +959,11 @@ def test_gpu_progressive_scan_encoder_on_random_files(emu):
     assert done == 14
 
 
-def _progressive_decode_on_the_emulation(emu, jpg, pipelined=False, deps_out=None):
+def _progressive_decode_on_the_emulation(emu, jpg, pipelined=False, deps_out=None, win=False, rows_out=None):
     """progressive scans of `jpg` through lep_huffprogdec.h (lane-loop emulation), level by level or as the one pipelined launch
     small batches take.  Returns (handle, frame planes, status): status None = not eligible, -1 = the kernels found it irregular,
-    0 = decoded and finished"""
+    0 = decoded and finished.  win: through lep_huffprogdec_win.h (the window of speculative codes) where that form takes the scan;
+    rows_out: receives every record the kernels wrote (bit positions, last DCs, pad bits | status)"""
     from lepton_amd import abi
 
     L = abi.lib()
@@ -992,7 +993,13 @@ def _progressive_decode_on_the_emulation(emu, jpg, pipelined=False, deps_out=Non
         for c in range(d.ncomp):
             scans[i].t.blocks[c] = C.addressof(planes[c])
     rows = (abi.HuffDecRow * (need.value + 4))()
-    if pipelined:
+    if win:
+        taken = C.c_int32(0)
+        emu.emu_huffman_progressive_decode_win.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        assert emu.emu_huffman_progressive_decode_win(scans, nscan.value, rows, 1 if pipelined else 0, C.byref(taken)) == 0
+        if deps_out is not None:
+            deps_out.append(taken.value)
+    elif pipelined:
         deps = (C.c_int32 * (4 * nscan.value))()
         emu.emu_huffman_progressive_decode_pipelined.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         assert emu.emu_huffman_progressive_decode_pipelined(scans, nscan.value, rows, deps) == 0
@@ -1002,6 +1009,8 @@ def _progressive_decode_on_the_emulation(emu, jpg, pipelined=False, deps_out=Non
     else:
         emu.emu_huffman_progressive_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         assert emu.emu_huffman_progressive_decode(scans, nscan.value, rows) == 0
+    if rows_out is not None:
+        rows_out.extend((r.bitpos, tuple(r.last_dc), r.aux) for r in rows)
     rc = L.lep_jpeg_finish_gpu_progressive(h, scans, nscan.value, rows)
     return h, planes, (0 if rc == 0 else -1)
 
@@ -1071,6 +1080,79 @@ def test_gpu_progressive_scan_decoder_on_cpu_equals_the_host_parser(emu, name, p
     abi.lib().lep_jpeg_close(h)
 
 
+@pytest.mark.parametrize("pipelined", [False, True], ids=["level_by_level", "one_pipelined_launch"])
+@pytest.mark.parametrize("name", [n for n in golden_cases() if n.startswith("prog_") and "truncated" not in n])
+def test_window_progressive_scan_decoder_on_cpu_equals_the_host_parser(emu, name, pipelined):
+    """lep_huffprogdec_win.h (every lane decodes the code that would start at its bit, the chain hops between them on the scalar
+    unit; correction bits fetched by their lanes) as a lane-loop emulation: the frame and the .lep header equal the host
+    parser's, the records equal lep_huffprogdec.h's; the fixture with restart intervals stays with that form"""
+    from lepton_amd import abi
+
+    jpg, _ = golden(name)
+    taken, rows_w, rows_o = [], [], []
+    h, planes, st = _progressive_decode_on_the_emulation(emu, jpg, pipelined=pipelined, win=True, deps_out=taken, rows_out=rows_w)
+    assert st == 0, "eligible fixture was refused or found irregular"
+    assert (taken[0] > 0) != ("rst" in name)
+    _same_as_the_host_parser(jpg, h, planes)
+    abi.lib().lep_jpeg_close(h)
+    h2, planes2, st2 = _progressive_decode_on_the_emulation(emu, jpg, pipelined=pipelined, rows_out=rows_o)
+    abi.lib().lep_jpeg_close(h2)
+    assert st2 == 0 and rows_w == rows_o
+
+
+def _mutated_progressive(rnd, seeds):
+    j = bytearray(rnd.choice(seeds))
+    sos = j.find(b"\xff\xda")
+    k = rnd.choice(["flip", "byte", "del", "ins", "hdr", "flip", "byte"])
+    pos = rnd.randrange(sos, len(j) - 2) if k != "hdr" else rnd.randrange(2, sos)
+    if k == "flip":
+        j[pos] ^= 1 << rnd.randrange(8)
+    elif k == "byte":
+        j[pos] = rnd.randrange(256)
+    elif k == "del":
+        del j[pos:pos + rnd.choice([1, 2, 5])]
+    elif k == "ins":
+        j[pos:pos] = bytes(rnd.randrange(256) for _ in range(rnd.choice([1, 2])))
+    else:
+        j[pos] ^= 1 << rnd.randrange(8)
+    return bytes(j), k
+
+
+def test_window_progressive_scan_decoder_on_damaged_files(emu):
+    """progressive files damaged inside their scans (bit flips, overwritten / deleted / inserted bytes) and in their headers:
+    the window form refuses exactly the files the uniform-code form refuses, and where both decode, frame and records are the
+    same -- so the host parser is asked for the same files as before"""
+    import random
+    from lepton_amd import abi
+
+    rnd = random.Random(61)
+    seeds = [golden(n)[0] for n in golden_cases() if n.startswith("prog_") and "trunc" not in n and "rst" not in n and len(golden(n)[0]) < 30000]
+    both = refused = 0
+    for trial in range(220):
+        j, kind = _mutated_progressive(rnd, seeds)
+        res = []
+        for win in (False, True):
+            rows = []
+            try:
+                h, planes, st = _progressive_decode_on_the_emulation(emu, j, pipelined=bool(trial & 1), win=win, rows_out=rows)
+            except AssertionError:
+                res.append(None)      # not openable / not a progressive file any more: neither form is asked
+                continue
+            if st is not None:
+                abi.lib().lep_jpeg_close(h)
+            res.append((st, [p.raw for p in planes] if st == 0 else None, [r[2] >> 8 for r in rows] if st is not None else None, rows if st == 0 else None))
+        if res[0] is None or res[1] is None:
+            assert res[0] is None and res[1] is None, (trial, kind)
+            continue
+        assert res[0][0] == res[1][0], (trial, kind, res[0][0], res[1][0])
+        if res[0][0] == 0:
+            assert res[0][1] == res[1][1] and res[0][3] == res[1][3], (trial, kind)
+            both += 1
+        elif res[0][0] == -1:
+            refused += 1
+    assert both >= 20 and refused >= 60, (both, refused)
+
+
 def test_gpu_progressive_scan_decoder_on_random_files(emu):
     import io
     import random
@@ -1096,10 +1178,11 @@ def test_gpu_progressive_scan_decoder_on_random_files(emu):
         buf = io.BytesIO()
         Image.fromarray(a, "RGB").convert(mode).save(buf, **kw)
         jpg = buf.getvalue()
-        hdl, planes, st = _progressive_decode_on_the_emulation(emu, jpg, pipelined=trial % 2 == 1)   # level by level / one pipelined launch, in turn
-        assert st == 0, (trial, w, h_, mode, kw, st)
-        _same_as_the_host_parser(jpg, hdl, planes)
-        abi.lib().lep_jpeg_close(hdl)
+        for win in (False, True):    # lep_huffprogdec.h, then lep_huffprogdec_win.h (files with restart intervals: the former both times)
+            hdl, planes, st = _progressive_decode_on_the_emulation(emu, jpg, pipelined=trial % 2 == 1, win=win)   # level by level / one pipelined launch, in turn
+            assert st == 0, (trial, w, h_, mode, kw, st, win)
+            _same_as_the_host_parser(jpg, hdl, planes)
+            abi.lib().lep_jpeg_close(hdl)
         done += 1
     assert done == 16
 

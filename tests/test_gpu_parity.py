@@ -795,17 +795,25 @@ def test_gpu_split_phase_encoder_without_room_for_its_scratch(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("win", ["1", "0"], ids=["window_of_codes", "uniform_vector_code"])
 @pytest.mark.parametrize("pipelined", ["1", "0"], ids=["one_pipelined_launch", "level_by_level"])
-def test_gpu_progressive_scans_pipelined_or_level_by_level(monkeypatch, pipelined):
-    """lep_huffprogdec.h both ways on the MI355X: all dependency levels of the progressive files of a batch as ONE launch in which
+def test_gpu_progressive_scans_pipelined_or_level_by_level(monkeypatch, pipelined, win):
+    """the progressive scan decoders both ways on the MI355X: all dependency levels of the progressive files of a batch as ONE launch in which
     a scan follows the scans of its file MCU row by MCU row (small launches), or a launch per level (LEP_HUFFPROG_PIPELINE=0 /
     large launches): the same .lep bytes as the reference, damaged files included (a scan that gives up still tells the scans
-    waiting for it that it is done)"""
+    waiting for it that it is done).  win: lep_huffprogdec_win.h (the default: every lane decodes the code at its bit, the chain
+    hops between them) or lep_huffprogdec.h alone (LEP_HUFFPROGDEC_WIN=0)"""
     monkeypatch.setenv("LEP_HUFFPROG_PIPELINE", pipelined)
+    monkeypatch.setenv("LEP_HUFFPROGDEC_WIN", win)
+    from conftest import ref_cases, ref_golden
+
     codec = GpuCodec(0)
     names = [n for n in golden_cases() if n.startswith("prog_")]
     jpgs = [golden(n)[0] for n in names]
     leps = [golden(n)[1] for n in names]
+    for n in ref_cases(progressive=True):        # the reference's own progressive images and what its binary writes for them
+        j, l = ref_golden(n)
+        jpgs.append(j); leps.append(l); names.append(n)
     big = [corpus.synth_jpeg(1920, 1080, 94, progressive=True), corpus.synth_jpeg(640, 480, 95, progressive=True, subsampling="4:4:4", quality=97),
            corpus.synth_jpeg(333, 241, 97, progressive=True, subsampling="4:2:2")]
     want_big = [codec.compress(j) for j in big]
@@ -826,6 +834,7 @@ def test_gpu_progressive_scans_pipelined_or_level_by_level(monkeypatch, pipeline
     assert st2[3:] == [0, 0, 0] and got2[3:] == want_big
     for (code, w), s, g_ in zip(want, st2[:3], got2[:3]):
         assert (s, g_) == (code, w) or (code == 41 and s == 0)   # per-file compress also runs the round-trip check
+    codec.close()
 
 
 def test_gpu_progressive_pipelined_launch_beyond_what_is_resident(gpu_codec):
