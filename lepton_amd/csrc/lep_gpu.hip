@@ -432,9 +432,9 @@ __global__ __launch_bounds__(64) void lep_huffman_simt_settle_kernel(const lephu
     lephuff::simt_guess_or_settle(images + w.image, &sh, si + w.image, in + si[w.image].first, out + si[w.image].first, w.first_sub, settle);
 }
 __global__ __launch_bounds__(64) void lep_huffman_simt_place_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::SimtImage* si, const lephuff::SimtSub* sub,
-                                                                    lephuff::SimtPlace* place, int passes) {
+                                                                    lephuff::SimtPlace* place, int passes, lephuff::HuffDecRow* rows) {
     const int i = (int)blockIdx.x;
-    lephuff::simt_place(images + i, si + i, sub + si[i].first, place + si[i].first, passes);
+    lephuff::simt_place(images + i, si + i, sub + si[i].first, place + si[i].first, passes, rows);
 }
 __global__ __launch_bounds__(64) void lep_huffman_simt_write_kernel(const lephuff::HuffDecImage* __restrict__ images, lephuff::SimtImage* si, const lephuff::SimtWave* waves,
                                                                     const lephuff::SimtSub* sub, const lephuff::SimtPlace* place, lephuff::HuffDecRow* rows) {
@@ -448,6 +448,7 @@ __global__ void lep_huffman_simt_finish_kernel(const lephuff::HuffDecImage* __re
     if (i >= nimg) return;
     lephuff::HuffDecRow* last = rows + images[i].rows_off + images[i].mcuv;
     int status = si[i].status & 0x3fffff;
+    if (last->aux == lephuff::kHuffDecRowUnwritten) { status |= 2; last->aux = 255; }   // no lane of the write pass got to the final record: irregular
     if (images[i].flags & lephuff::kHuffDecRstTable) {      // restart intervals: the pad byte is what all intervals agreed on
         const int pad = lephuff::simt_intervals_pad(si + i, &status);
         last->aux = pad | (status << 8);
@@ -1428,7 +1429,7 @@ int lep_gpu_huffman_decode_simt_device(lep_gpu* g, const lep_huffdec_image* imag
     for (int k = 1; k <= lephuff::kSimtSettle; ++k)
         hipLaunchKernelGGL(lep_huffman_simt_settle_kernel, dim3(nw), dim3(64), 0, st, di, dsi, dwv, (const lephuff::SimtSub*)buf[(k - 1) & 1], buf[k & 1], k);
     const lephuff::SimtSub* fin = buf[lephuff::kSimtSettle & 1];
-    hipLaunchKernelGGL(lep_huffman_simt_place_kernel, dim3(nimg), dim3(64), 0, st, di, dsi, fin, dpl, lephuff::kSimtSettle);
+    hipLaunchKernelGGL(lep_huffman_simt_place_kernel, dim3(nimg), dim3(64), 0, st, di, dsi, fin, dpl, lephuff::kSimtSettle, (lephuff::HuffDecRow*)d_rows);
     hipLaunchKernelGGL(lep_huffman_simt_write_kernel, dim3(nw), dim3(64), 0, st, di, dsi, dwv, fin, (const lephuff::SimtPlace*)dpl, (lephuff::HuffDecRow*)d_rows);
     hipLaunchKernelGGL(lep_huffman_simt_finish_kernel, dim3((nimg + 255) / 256), dim3(256), 0, st, di, nimg, (lephuff::HuffDecRow*)d_rows, (const lephuff::SimtImage*)dsi);
     HIPCHK(g, hipGetLastError());

@@ -29,6 +29,7 @@ constexpr int32_t kHuffDecEarlyEof = 1;              // HuffDecImage::flags
 constexpr int32_t kHuffDecRstTable = 2;              // ... the restart positions follow the scan bytes at scan + huffdec_scan_room(scan_len)
 WDEV uint32_t huffdec_scan_room(uint32_t scan_len) { return (scan_len + 64u + 15u) & ~15u; }
 constexpr int32_t kHuffDecRowTruncated = 0x40000000; // final HuffDecRow::aux: the data ran out in mid-image; bitpos = blocks decoded
+constexpr int32_t kHuffDecRowUnwritten = (int32_t)0x80000000;   // ... set in front of the lane-per-piece write pass: no lane has written the record
 struct HuffDecImage {       // one image, device-visible
     const uint8_t* scan;    // un-stuffed entropy-coded bytes (RSTn removed), 16-byte aligned, followed by >= 16 zero bytes
     uint32_t scan_len;

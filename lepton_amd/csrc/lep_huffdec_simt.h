@@ -258,7 +258,10 @@ WDEV void simt_guess_or_settle(const HuffDecImage* img, SimtShared* sh, SimtImag
 }
 
 // pass P: one wavefront per image
-WDEV void simt_place(const HuffDecImage* img, SimtImage* si, const SimtSub* sub, SimtPlace* place, int passes) {
+// (... and, before the write pass runs, marks the image's final record as not written: the record array is reused from call to call,
+// and a write pass in which no lane gets to it must not leave an older image's record standing there with status 0 -- ADVICE round 5)
+WDEV void simt_place(const HuffDecImage* img, SimtImage* si, const SimtSub* sub, SimtPlace* place, int passes, HuffDecRow* rows_arena = nullptr) {
+    if (rows_arena) { LANES(l) if (l == 0) { HuffDecRow* fin = rows_arena + img->rows_off + img->mcuv; fin->bitpos = 0; fin->aux = kHuffDecRowUnwritten; } }
     if (img->flags & kHuffDecRstTable) return;
     int nphase = 0;
     for (int ci = 0; ci < img->ncomp; ++ci) nphase += img->hs[img->scan_cmp[ci]] * img->vs[img->scan_cmp[ci]];
@@ -434,7 +437,9 @@ WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, Si
             uint32_t mine = 0;
             bool stopped = false;                          // this lane met the end of a cut file's data
             const bool behind_the_end = cut && i > 0 && bp >= scan_bits;
-            if (behind_the_end) {}
+            // (the LAST lane behind the end with every block counted: a lane in front decoded the image's last block out of the data's
+            // last bits and nobody has written the final record -- the single-wave kernel's case, it knows what the reference does there)
+            if (behind_the_end) { if (last && before >= total) bad = 2; }
             else if (before > total) bad = 3;
             else {
                 mine = last ? total - before : sub[i].nblocks;

@@ -353,10 +353,11 @@ extern "C" int emu_huffman_decode_image_simt(const lep_huffdec_image* img, lep_h
     for (int k = 0; k <= lephuff::kSimtSettle; ++k)
         for (uint32_t f = 0; f < si.nsub; f += 64) lephuff::simt_guess_or_settle(&im, &sh, &si, buf[(k + 1) & 1].data(), buf[k & 1].data(), f, k);
     const lephuff::SimtSub* fin = buf[lephuff::kSimtSettle & 1].data();
-    lephuff::simt_place(&im, &si, fin, place.data(), lephuff::kSimtSettle);
+    lephuff::simt_place(&im, &si, fin, place.data(), lephuff::kSimtSettle, reinterpret_cast<lephuff::HuffDecRow*>(rows));
     static lephuff::SimtTile tile;
     for (uint32_t f = 0; f < si.nsub; f += 64) lephuff::simt_write(&im, &sh, &tile, &si, fin, place.data(), reinterpret_cast<lephuff::HuffDecRow*>(rows), f);
-    if (im.flags & lephuff::kHuffDecRstTable) {   // (lep_huffman_simt_finish_kernel)
+    if (rows[im.mcuv].aux == lephuff::kHuffDecRowUnwritten) { si.status |= 2; rows[im.mcuv].aux = 255; }   // (lep_huffman_simt_finish_kernel)
+    if (im.flags & lephuff::kHuffDecRstTable) {
         int status = si.status & 0x3fffff;
         const int pad = lephuff::simt_intervals_pad(&si, &status);
         rows[im.mcuv].aux = pad | (status << 8);
