@@ -77,6 +77,7 @@ int lep_gpu_create(int device, lep_gpu **out);
 void lep_gpu_destroy(lep_gpu *g);
 const char *lep_gpu_last_error(lep_gpu *g);
 int lep_gpu_device(lep_gpu *g);   /* the HIP device this object was created on */
+int lep_gpu_pci_bus_id(lep_gpu *g, char *out, int cap);   /* its PCI address ("0000:c1:00.0", cap >= 16): which physical GPU a rank drives */
 
 /* Encode nseg segments of nimg images.  Host variant: blocks[] are host pointers, copied to HBM,
  * coded, streams copied back into out[i] (out[i].data with capacity out[i].cap; len is set).

@@ -52,7 +52,11 @@ static int to_bytes(const std::vector<uint8_t>& v, lep_bytes* out) {
 
 extern "C" {
 
-const char* lep_version(void) { return "lepton-mi355x 0.1 (format v1, gfx950)"; }
+#ifndef LEP_SRC_SHA16
+#define LEP_SRC_SHA16 "unknown"
+#endif
+// (build() compiles the hash of every source file into this string: a loaded library can be held against the files beside it)
+const char* lep_version(void) { return "lepton-mi355x 0.1 (format v1, gfx950, src " LEP_SRC_SHA16 ")"; }
 void lep_free(void* p) { free(p); }
 
 int lep_jpeg_open(const uint8_t* jpg, size_t len, int allow_progressive, lep_jpeg** out) {

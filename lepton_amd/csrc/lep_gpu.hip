@@ -1474,6 +1474,12 @@ int lep_gpu_sync(lep_gpu* g) {
 
 const char* lep_gpu_last_kernel_name(lep_gpu* g) { return g ? g->last_kernel : ""; }
 int lep_gpu_device(lep_gpu* g) { return g ? g->device : -1; }
+// "0000:c1:00.0" of the device the object was created on (hipDeviceGetPCIBusId): which physical GPU a rank of a multi-GPU run drives
+int lep_gpu_pci_bus_id(lep_gpu* g, char* out, int cap) {
+    if (!g || !out || cap < 16) return LEP_ASSERTION_FAILURE;
+    HIPCHK(g, hipDeviceGetPCIBusId(out, cap, g->device));
+    return 0;
+}
 
 double lep_gpu_last_kernel_ms(lep_gpu* g) {
     if (!g->timed) return -1.0;

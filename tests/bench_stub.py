@@ -12,6 +12,7 @@ class StubDevice:
 
     def __init__(self, local_rank):
         self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = local_rank
         self.log = os.environ.get("LEP_BENCH_STUB_LOG")
 
     def _note(self, what, **kw):
@@ -24,6 +25,10 @@ class StubDevice:
 
     def footprint(self):
         return {"pinned_MB": 0.0, "staging_device_MB": 0.0, "host_threads": 1}
+
+    def identity(self):
+        # (a made-up PCI address per rank: the plumbing that carries it is what the CPU suite exercises)
+        return {"pci_domain": 0, "pci_bus": 0x10 + self.local_rank, "pci_device": 0, "pci_function": 0, "xgmi_hive_hi": 0, "xgmi_hive_lo": 0x1234}
 
     def resident(self, uniq, images, steps, warmup, barrier, check_parity=True, with_latency=False):
         nb = sum(len(uniq[i % len(uniq)]) for i in range(images))

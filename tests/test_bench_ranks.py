@@ -84,6 +84,10 @@ def test_gpus_8_codes_the_ten_thousand_file_corpus_once(tmp_path):
     rank needs the others' bytes to know its share), the line says n_gpus 8, mixed.files 10000, and that one point is not a curve."""
     out, notes = run_bench(tmp_path, ["--gpus", "8", "--mixed-images", "10000", "--mixed-distinct", "10000", "--mixed-shapes", "32x24,64x48", "--no-end-to-end"])
     assert out["n_gpus"] == 8 and [r["rank"] for r in out["per_rank"]] == list(range(8))
+    # the first SCALE run must be able to show N ranks on N devices: every rank's PCI address and xGMI hive, the world size each rank
+    # saw and the backend are in the line (VERDICT round 5 next #10)
+    assert out["distributed"]["world_size"] == 8 and out["distributed"]["distinct_devices"] == 8 and out["distributed"]["backend"] == "gloo"
+    assert all(r["world_size_seen"] == 8 and r["backend_is_rccl"] == 0 and r["pci_bus"] == 0x10 + r["local_rank"] and r["xgmi_hive_lo"] == 0x1234 for r in out["per_rank"])
     mixed = [n for n in notes if n["what"] == "pipeline" and n["label"].startswith("mixed")]
     assert sorted(n["rank"] for n in mixed) == list(range(8))
     assert sum(n["files"] for n in mixed) == 10000 == out["mixed"]["files"] and out["mixed"]["distinct"] == 10000

@@ -201,3 +201,21 @@ def test_encode_thread_options_match_the_reference_flags(tmp_path):
         segs = img.plan(max_threads=0)
         streams, _ = ob.oracle_encode(img.desc, segs)
         assert len(segs) == want[4] and img.write_lep(streams, max_threads=0) == want
+
+
+def test_the_library_says_which_sources_it_was_built_from(monkeypatch):
+    """build() compiles a hash of every source file into lep_version(); the loaded library is held against
+    the files on the box, and a library built from other sources -- a stale .so that travelled with a snapshot -- fails build(),
+    hence smoke() and bench.py"""
+    import __graft_entry__ as ge
+    from lepton_amd import abi
+
+    ok, said = ge.library_matches_sources()
+    assert ok and ("src " + ge.source_sha16()) in said and abi.lib().lep_version().decode() == said
+    monkeypatch.setattr(ge, "source_sha16", lambda: "0123456789abcdef")     # as if a source file had changed under the library
+    assert ge.library_matches_sources()[0] is False
+    monkeypatch.setattr(ge, "_compile_library", lambda record: None)          # (and the build had not noticed)
+    monkeypatch.setattr(ge, "_build_locked", lambda record: None)
+    import pytest
+    with pytest.raises(RuntimeError, match="not built from the sources"):
+        ge.build()
