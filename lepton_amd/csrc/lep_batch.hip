@@ -1209,8 +1209,10 @@ int lep_decompress_batch(lep_gpu* g, const lep_bytes* leps, int n, lep_bytes* ou
         hipStream_t s_scan_here = s_scan == s_compute_a ? s_compute : s_scan;
         // this slot's buffers were last used by the chunk before the previous one, possibly on the other stream -- and a workspace set by
         // either of the two chunks in front
+        // (At most ONE earlier chunk is in flight when this runs: the caller has fetched -- waited for the download of -- every chunk but
+        // the one in front before it launches this one.  A launch that is not `beside` goes onto the previous launch's stream, so stream
+        // order is its dependency; ADVICE round 5: the extra wait that stood here could never fire.)
         if (s->done_recorded) HIPOK(hipStreamWaitEvent(s_compute, s->done, 0));
-        if (slot_prev && slot_prev->done_recorded && !beside && s_compute != s_prev) HIPOK(hipStreamWaitEvent(s_compute, slot_prev->done, 0));
         HIPOK(hipStreamWaitEvent(s_compute, s->up, 0));
         if (int rc0 = lep_gpu_use_arena(g, set)) return rc0;
         (void)lep_gpu_expect_company(g, dec_overlap != 0 && (beside || ragged) && c->count < n);   // (a call of one chunk has no neighbour)

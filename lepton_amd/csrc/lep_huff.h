@@ -48,7 +48,8 @@ struct HuffEnd {             // state a segment's writer ends in: what the next 
     uint32_t attempted;     // bytes the segment tried to write (not clipped to out_cap)
     uint8_t overhang_byte, num_overhang_bits;
     int16_t last_dc[4];
-    uint16_t pad;           // kHuffEndCut: the segment stopped at the cut of a truncated file (its bytes are those in front of the cut);
+    uint16_t pad;           // kHuffEndCut: the segment stopped at the cut of a truncated file (its bytes are those in front of the cut; overhang_byte /
+                            // num_overhang_bits of such an end state are undefined);
                             // kHuffEndRefused: a truncated file's segment this kernel does not take -- the host re-coder's
 };
 constexpr uint16_t kHuffEndCut = 1, kHuffEndRefused = 2;

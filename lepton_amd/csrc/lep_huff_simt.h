@@ -274,6 +274,10 @@ WDEV void simt_enc_units(const HuffImage* images, const HuffSegment* segs, SimtE
                 }
                 d.sink.finish();
                 if (!WRITE) unit_bits[es.first_unit + u] = d.sink.total | (met_cut ? kUnitMetCut : 0u);
+                // (a unit that meets the cut at its first block and puts no bit leaves a tail made of its own accumulator only -- the bits of
+                // the partial byte that belong to the unit in front are not in it.  A kHuffEndCut end state's overhang is therefore NOT
+                // defined; nobody compares it: a cut end state is only taken for the last thread with its byte bound reached, lep_huff.h
+                // kHuffEndCut.  ADVICE round 5.)
                 else if (u + 1 == es.nunits || met_cut) esp->tail = d.sink.tail_byte();
             }
         }
