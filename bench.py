@@ -297,7 +297,7 @@ class HipDevice:
     def pipeline(self, jpgs, label, verify=False):
         # (no lep_gpu_trim between the phases by default.  Round 3 saw the 1080p figure halve after a trim and blamed the device heap; round
         # 4 found the cause -- the driver CLEARS the memory it hands out, 40 ms per GB, so a phase that gives 30 GB back and takes them
-        # again pays seconds -- and the library's workspaces are now pooled address ranges whose chunks a trim keeps (DESIGN.md 4 "What
+        # again pays seconds -- and the library's workspaces are now pooled address ranges whose chunks a trim keeps (LAB_NOTES.md 4 "What
         # one phase leaves behind"): with --trim-between-phases the figures are within 1 %.)
         if self.trim:
             self.L.lep_gpu_trim(self.g)
@@ -744,7 +744,7 @@ def main():
                      "encode_kernel_ms": round(enc_kernel_s * 1e3, 3), "decode_kernel_ms": round(dec_kernel_s * 1e3, 3),
                      "kernels": names, "per_kernel": per_kernel,
                      "encode_stages_ms": dict(zip(("count_plan", "emit", "fold", "gather", "write"), res["encode_stages_ms"])) if res.get("encode_stages_ms") else None, "bound_by": pmc_bound(names.get(dominant, "")),
-                     "note": "frac = algorithmic bytes (128 B per block + stream bytes) / kernel time / 8 TB/s; traffic = HBM bytes from the memory-side request counters of the committed PMC passes (profiles/pmc_traffic.json) for THIS launch size (null for a size that was not measured: never scaled) -- `traffic_source.stale` says whether those passes were taken from the kernel sources measured here; bound_by = what those passes say limits the kernel (DESIGN.md 4)"},
+                     "note": "frac = algorithmic bytes (128 B per block + stream bytes) / kernel time / 8 TB/s; traffic = HBM bytes from the memory-side request counters of the committed PMC passes (profiles/pmc_traffic.json) for THIS launch size (null for a size that was not measured: never scaled) -- `traffic_source.stale` says whether those passes were taken from the kernel sources measured here; bound_by = what those passes say limits the kernel (DESIGN.md 4, LAB_NOTES.md 4)"},
     }
     out["distributed"] = {"world_size": world, "backend": (dist.get_backend() if dist else None), "launcher": "torch.distributed.run / spawn_ranks" if dist else "single process",
                           "distinct_devices": len({(r.get("pci_domain"), r.get("pci_bus"), r.get("pci_device"), r.get("pci_function")) for r in per_rank}),

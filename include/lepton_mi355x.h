@@ -77,6 +77,7 @@ int lep_gpu_create(int device, lep_gpu **out);
 void lep_gpu_destroy(lep_gpu *g);
 const char *lep_gpu_last_error(lep_gpu *g);
 int lep_gpu_device(lep_gpu *g);   /* the HIP device this object was created on */
+size_t lep_gpu_debug_huffenc(lep_gpu *g, void *out, size_t cap);   /* diagnosis: the lane-per-unit scan encoder's work area after its last launch */
 int lep_gpu_pci_bus_id(lep_gpu *g, char *out, int cap);   /* its PCI address ("0000:c1:00.0", cap >= 16): which physical GPU a rank drives */
 
 /* Encode nseg segments of nimg images.  Host variant: blocks[] are host pointers, copied to HBM,
@@ -112,12 +113,12 @@ int lep_gpu_expect_company(lep_gpu *g, int on);
  * ring holds events recorded on those streams; this waits for the copies and drops the events. */
 int lep_gpu_settle_uploads(lep_gpu *g);
 int lep_gpu_sync(lep_gpu *g);
-double lep_gpu_last_kernel_ms(lep_gpu *g);
+double lep_gpu_last_kernel_ms(lep_gpu *g);          /* HIP-event duration of the most recent encode / decode / scan launch (ms; -1: none timed) */
 /* The split-phase encoder (lep_enc5.h) is several kernels: stage times of the most recent encode launch that used it, in
  * order count + plan, emit, fold, gather, write (HIP events on the launch stream); returns how many were written (0: the
  * launch was a single-kernel one). */
 int lep_gpu_last_stage_ms(lep_gpu *g, double *ms, int cap);
-const char *lep_gpu_last_kernel_name(lep_gpu *g);   /* which kernel generation / register-budget variant that launch used */   /* HIP-event duration of the most recent encode/decode kernel */
+const char *lep_gpu_last_kernel_name(lep_gpu *g);   /* which kernel generation / register-budget variant that launch used */
 /* JPEG Huffman re-encode of decoded coefficient frames on the GPU (replaces recode_one_mcu_row / encode_block_seq,
  * src/lepton/recoder.cc:316-412, 245-314, for whole, untruncated sequential scans): one wavefront per thread segment writes
  * that segment's scan bytes (FF00-stuffed, RST markers included) to d_out + segs[i].out_off, at most segs[i].out_cap of
@@ -160,8 +161,9 @@ int lep_gpu_huffman_encode_device(lep_gpu *g, const lep_huff_image *images, int 
                                   uint8_t *d_out, uint32_t *d_out_len, lep_huff_end *d_ends, void *hip_stream);
 /* The same for PROGRESSIVE files (BASELINE.json configs[4]; replaces the scan loop of recode_jpeg, src/lepton/jpgcoder.cc:3309-3716,
  * with encode_dc_prg_*, encode_ac_prg_fs / _sa, encode_eobrun, encode_crbits :4991-5400): every scan of a progressive file is a
- * function of the finished frame alone, so one wavefront per (image, scan) writes that scan's bytes (FF00-stuffed, restart
- * markers included) to d_out + scans[i].out_off; d_out_len[i] = byte count, bit 31 set = the scan outgrew its slot or its
+ * function of the finished frame alone, so its bytes (FF00-stuffed, restart markers included) are written to d_out +
+ * scans[i].out_off by one LANE per 32 blocks (lep_huffprog_simt.h: count / place / assign / code / stuff; files with restart
+ * intervals: one wavefront per scan, lep_huffprog.h); d_out_len[i] = byte count, bit 31 set = the scan outgrew its slot or its
  * scratch (let the host re-coder do that file).  d_corr: scratch for correction bits held back behind end-of-band runs
  * (scans[i].corr_off / corr_cap dwords).  lep_file_recode_plan_progressive fills both structs. */
 typedef struct lep_huffprog_image {
@@ -216,7 +218,8 @@ typedef struct lep_huffdec_row {
 int lep_gpu_huffman_decode_device(lep_gpu *g, const lep_huffdec_image *images, int nimg, lep_huffdec_row *d_rows, void *hip_stream);
 /* The same for PROGRESSIVE files (replaces the progressive branches of decode_jpeg's scan loop, src/lepton/jpgcoder.cc:2975-3260,
  * with decode_dc_prg_*, decode_ac_prg_fs / _sa, decode_eobrun_sa, skip_eobrun :4968-5335, :5462-5500): one wavefront per
- * (image, scan).  A refinement scan must see what the earlier scans of its band wrote, so every descriptor carries a
+ * (image, scan) whose 64 lanes decode the codes that would start at the next 64 bits while the scalar unit hops from code to
+ * code (lep_huffprogdec_win.h; scans with restart intervals: uniform vector code, lep_huffprogdec.h).  A refinement scan must see what the earlier scans of its band wrote, so every descriptor carries a
  * dependency `level`.  Up to 16384 scans go out as ONE launch, ordered by level, in which a scan waits -- MCU row by MCU row,
  * on a progress word the scans in front of it publish -- for the scans of its file (same frame pointers) whose component and
  * band meet its own: a file then takes as long as its longest scan instead of the sum over its levels.  Larger calls (or

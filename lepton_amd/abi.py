@@ -236,7 +236,7 @@ def lib():
 
 
 EXPORTS = [
-    "lep_gpu_create", "lep_gpu_destroy", "lep_gpu_last_error", "lep_gpu_device", "lep_gpu_pci_bus_id", "lep_gpu_encode_host", "lep_gpu_decode_host",
+    "lep_gpu_create", "lep_gpu_destroy", "lep_gpu_last_error", "lep_gpu_device", "lep_gpu_pci_bus_id", "lep_gpu_debug_huffenc", "lep_gpu_encode_host", "lep_gpu_decode_host",
     "lep_gpu_encode_device", "lep_gpu_decode_device", "lep_gpu_sync", "lep_gpu_last_kernel_ms", "lep_gpu_last_kernel_name", "lep_gpu_selftest", "lep_gpu_trim", "lep_gpu_release_memory",
     "lep_gpu_debug_prof", "lep_gpu_malloc",
     "lep_gpu_free", "lep_gpu_memcpy_h2d", "lep_gpu_memcpy_d2h", "lep_gpu_memcpy_d2d", "lep_gpu_memset", "lep_jpeg_open", "lep_jpeg_close",

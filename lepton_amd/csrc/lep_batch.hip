@@ -635,7 +635,7 @@ int lep_compress_batch(lep_gpu* g, const lep_bytes* jpgs, int n, lep_bytes* outs
             // One LANE per subsequence (lep_huffdec_simt.h: thousands of subsequences per scan, 64 codes per instruction) for the scans
             // without restart intervals, the single-wave kernel (lep_huffdec.h) for the others; LEP_HUFFDEC_SIMT=0 keeps the single-wave
             // kernel for every file.  (Round 2-4's form in between -- several WAVEFRONTS per image, 290 ms per 896-file chunk against 43 --
-            // is gone from the product: DESIGN.md 4 "JPEG Huffman kernels" keeps its numbers.)
+            // is gone from the product: LAB_NOTES.md 4 "JPEG Huffman kernels" keeps its numbers.)
             const bool simt = !(getenv("LEP_HUFFDEC_SIMT") && atoi(getenv("LEP_HUFFDEC_SIMT")) == 0);
             if (simt) {
                 std::vector<lep_huffdec_image> many, one;

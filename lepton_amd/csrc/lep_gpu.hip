@@ -1516,6 +1516,16 @@ int lep_gpu_selftest(lep_gpu* g) {
     return h == 0 ? 0 : LEP_ASSERTION_FAILURE;
 }
 
+// diagnosis: the lane-per-unit scan encoder's work area as the last lep_gpu_huffman_encode_device left it (segment / wave descriptors,
+// unit positions, plain prefix sums, bit buffers + marker maps; the layout is that function's), copied to `out`; returns the bytes copied.
+// scripts/diag_scan_encode_isolate.py compares two builds of the library pass by pass with it.
+size_t lep_gpu_debug_huffenc(lep_gpu* g, void* out, size_t cap) {
+    if (!g || !g->d_huffenc) return 0;
+    if (hipSetDevice(g->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
+    const size_t n = std::min(cap, g->huffenc_bytes);
+    return hipMemcpy(out, g->d_huffenc, n, hipMemcpyDeviceToHost) == hipSuccess ? n : 0;
+}
+
 // profiling builds (-DLEP_PROF) only: per-phase shader-clock totals folded over the segments of the last decoder launch
 int lep_gpu_debug_prof(lep_gpu* g, uint64_t* out /* [64][32] */) {
 #ifdef LEP_PROF

@@ -249,7 +249,15 @@ WDEV void simt_enc_units(const HuffImage* images, const HuffSegment* segs, SimtE
             d.img = img; d.sh = sh;
             for (int c = 0; c < 4; ++c) d.lastdc[c] = seg.last_dc[c];
             if (u > 0) {
-                if (img->rsti > 0 && m0 % img->rsti == 0) d.lastdc[0] = d.lastdc[1] = d.lastdc[2] = d.lastdc[3] = 0;   // behind a restart marker
+                // behind a restart marker: zero predictors.  ONE lane-dependent condition on purpose -- as `img->rsti > 0 && m0 % img->rsti
+                // == 0` (a wave-uniform test in front of the lane's own, merged into one branch by the optimiser) this was the branch that
+                // `-mllvm -structurizecfg-skip-uniform-regions` took for the whole wavefront in the COUNT instantiation of this function:
+                // the first unit of every restart interval counted its DC differences against the frame's predictors, the code pass
+                // wrote them against zero, and everything behind was displaced (round 5's "miscompile"; isolated in round 6 with
+                // scripts/diag_scan_encode_isolate.py, profiles/r6k_*).  The default compiler mode never had the problem; the source no
+                // longer offers the pattern.
+                const int every = img->rsti > 0 ? img->rsti : 0x7fffffff;
+                if (m0 % every == 0) d.lastdc[0] = d.lastdc[1] = d.lastdc[2] = d.lastdc[3] = 0;
                 else d.predictors_before(m0);
             }
             uint32_t* buf = reinterpret_cast<uint32_t*>(scratch + es.buf_off);

@@ -186,7 +186,7 @@ def test_gpu_decoder_register_budget_forms(env, kernel, monkeypatch):
     """the two builds of the decode kernel a launch can take -- 4 wavefronts per SIMD (128 VGPRs, no spills: launches that cannot fill the
     chip) and 8 (64 VGPRs) -- forced here for launches of any size (files of 1, 2, 4 and 8 segments): restore the reference-written
     goldens byte for byte, return the oracle's frame from the oracle's streams, and refuse a garbage stream in one segment without
-    disturbing its neighbours.  (Round 4's second decoder generation, lep_dec5.h, was measured slower and is gone: DESIGN.md 4.)"""
+    disturbing its neighbours.  (Round 4's second decoder generation, lep_dec5.h, was measured slower and is gone: LAB_NOTES.md 4.)"""
     import numpy as np
     import oracle_binding as ob
 
