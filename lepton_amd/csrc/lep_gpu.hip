@@ -485,6 +485,8 @@ struct lep_gpu {
     int enc5_parts = 8;      // LEP_ENC5_PARTS: gather / write in this many parts (1..8), a part written while the next is gathered
                              // (MI355X, 1024 x 4K: 1 part 569 ms per launch, 4 parts 481, 8 parts 475)
     hipEvent_t ev_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    long enc5_wlanes = 131072;  // LEP_ENC5_WLANES: chunk lanes a launch of the stitched writer may have (segments x chunks per segment)
+    int enc5_wmaxseg = 4096;    // LEP_ENC5_WMAXSEG: launches of more segments keep the lane-per-segment writer beside gather
     int enc5_wchunks = 64;   // LEP_ENC5_WCHUNKS: the stitched writer for launches that leave lanes free: up to this many chunks per segment (power of
                              // two; 0 = always the lane-per-segment writer beside gather)
     int enc5_gather_wgs = 0; // LEP_ENC5_GATHER_WGS: resident gather workgroups per CU held to this (through the LDS a launch asks for)
@@ -776,11 +778,13 @@ static int launch_enc5(lep_gpu* g, const ImageDev* d_img, const SegDev* d_seg, c
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join, 0));
         HIPCHK(g, hipStreamWaitEvent(st, g->ev_join3, 0));
         HIPCHK(g, hipEventRecord(g->ev_stage[3], st));
-        // A launch that leaves most of the chip's lanes free takes the stitched writer: K chunks per segment, chosen so that the
-        // launch has at most 4096 chunk lanes (K = 64 for one image, 32 for 8, 2 for 256; from 512 images on the lane-per-segment writer
-        // beside gather is the faster one: measured, profiles/r05k_*); its four small kernels run behind the whole gather.
+        // A launch that leaves the chip's lanes free takes the stitched writer: K chunks per segment (a power of two up to 64), as many as
+        // keep the launch under enc5_wlanes chunk lanes.  Round 4 capped the lanes at 4096 (K = 2 at 256 images: two chains of 1.15 M bins
+        // per segment, 118 ms of writer on 64 wavefronts); round 6 measured the cap away (profiles/r6o_*: 256 images 253 -> 148 ms per
+        // launch with K = 32, 128 images 159 -> 107, 512 images -- which had kept the lane-per-segment writer -- 308 -> 260).  From 4097
+        // segments on the lane-per-segment writer beside gather stays: there the walks fill the chip and hide it.
         int K = 0;
-        if (g->enc5_wchunks >= 2) { K = 1; while (K * 2 <= g->enc5_wchunks && (long)nseg * K * 2 < 8192) K *= 2; }
+        if (g->enc5_wchunks >= 2 && nseg <= g->enc5_wmaxseg) { K = 1; while (K * 2 <= g->enc5_wchunks && (long)nseg * K * 2 <= g->enc5_wlanes) K *= 2; }
         if (K >= 2 && ensure(g, &E.d_wchunks, &E.wchunks_bytes, (size_t)nseg * K * sizeof(lep5::WChunk5) + 256, false)) { (void)hipGetLastError(); g->err.clear(); K = 0; }
         if (K >= 2) {
             for (int part = 0; part < nparts; ++part) walk(lep5::kGather, (uint8_t*)E.d_entries, (uint16_t*)E.d_binlist, part);
@@ -1024,6 +1028,8 @@ int lep_gpu_create(int device, lep_gpu** out) {
     if (const char* e = getenv("LEP_ENC5_GATHER_WGS")) g->enc5_gather_wgs = atoi(e);
     if (const char* e = getenv("LEP_ENC5_PARTS")) g->enc5_parts = atoi(e);
     if (const char* e = getenv("LEP_ENC5_WCHUNKS")) g->enc5_wchunks = atoi(e);
+    if (const char* e = getenv("LEP_ENC5_WLANES")) g->enc5_wlanes = atol(e);
+    if (const char* e = getenv("LEP_ENC5_WMAXSEG")) g->enc5_wmaxseg = atoi(e);
     if (const char* e = getenv("LEP_ENC5_SCRATCH_MAX")) g->enc5_scratch_max = (size_t)strtoull(e, nullptr, 10);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= device) { delete g; return LEP_GPU_ERROR; }

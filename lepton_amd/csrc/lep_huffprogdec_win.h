@@ -37,7 +37,6 @@ constexpr uint32_t kWinRing = 1024;     // dwords of scan data in LDS
 constexpr uint32_t kWinChunk = 256;     // dwords per refill (64 lanes x 16 bytes)
 constexpr uint32_t kWinAhead = 300;     // dwords the ring stays in front of the window
 constexpr uint32_t kWinNoMark = 0x7fffffffu;
-constexpr uint32_t kWinFast = 0x8000u;  // in a lane's answer: a code the chain's short path takes (see stage)
 
 struct ProgWinShared {
     uint32_t ring[kWinRing];            // dword d of the scan (big-endian value) at ring[d & 1023]
@@ -50,6 +49,7 @@ struct ProgWinShared {
 
 struct WinScan {                        // the scan's constants, in registers
     int from, to, sal, sah, max_eobrun, want_rows, tbl0;
+    uint32_t plus, minus;               // +-1 << sal as the 16 bits a coefficient is stored as
     int cmp, bch, nch, ncv, vs;         // one-component scans: the component's geometry
     int16_t* blocks;                    // ... and its frame
     const uint8_t* scan;
@@ -97,13 +97,11 @@ struct ProgWinWave : ProgDecWave {
         request(ring_hi);
         LSYNC();
     }
-    // a lane's answer: symbol | length << 8 | the 16 bits behind the code << 16, and kWinFast where the chain's short path takes the
-    // code: in a refinement scan a new +-1 or a ZRL, in a first-stage AC scan a coefficient (DC scans: never)
-    int fast_kind = 0;                  // 0 DC, 1 AC first stage, 2 AC refinement
+    // a lane's answer: symbol | length << 8 | the 16 bits behind the code << 16
+    int fast_kind = 0;                  // 0 DC, 1 AC first stage, 2 AC refinement (what stage() puts into the short path's words)
     WDEV uint32_t pack(uint32_t e, uint32_t w) const {
-        const uint32_t len = e >> 8, sym = e & 255u, s = sym & 15u;
-        const bool fast = len != 0u && (fast_kind == 2 ? (s == 1u || sym == 0xF0u) : (fast_kind == 1 && s != 0u));
-        return (e & 0x1fffu) | (fast ? kWinFast : 0u) | (len ? ((w << len) >> 16) << 16 : 0u);
+        const uint32_t len = e >> 8;
+        return (e & 0x1fffu) | (len ? ((w << len) >> 16) << 16 : 0u);
     }
     // lane l looks at the code that would start at bit base + off + l; off becomes 0
     WDEV void stage() {
@@ -115,7 +113,22 @@ struct ProgWinWave : ProgDecWave {
             const uint32_t w = (uint32_t)((((uint64_t)w0 << 32) | w1) >> (32u - sft));
             L(win) = w;
             if (two_tables) { L(pre) = pack(ws->lut[0][w >> 23], w); L(pre1) = pack(ws->lut[1][w >> 23], w); }
-            else L(pre) = pack(ws->lut[2][w >> 23], w);
+            else {
+                const uint32_t e = ws->lut[2][w >> 23];
+                L(pre) = pack(e, w);
+                // what the chain's short path reads (`pre1` is free in AC scans): run | bits consumed << 8 | value placed << 16 for the codes it
+                // takes -- refinement: a new +-1 (1 << sal) or a ZRL (value 0), first stage: a coefficient -- and a run of 255, which no
+                // position can answer, for everything else
+                const uint32_t len = e >> 8, sym = e & 255u, s = sym & 15u;
+                uint32_t f = 0xffu;
+                if (fast_kind == 2) {
+                    if (len != 0u && (s == 1u || sym == 0xF0u)) f = (sym >> 4) | (len + s) << 8 | (s ? ((w << len) >> 31 ? k.plus : k.minus) : 0u) << 16;
+                } else if (len != 0u && s != 0u) {
+                    const uint32_t n = (w << len) >> (32u - s);
+                    f = (sym >> 4) | (len + s) << 8 | ((uint32_t)(uint16_t)((uint16_t)devli(s, n) << k.sal)) << 16;
+                }
+                L(pre1) = f;
+            }
         }
     }
     // a code of 9..16 bits at lane `off`: lane k tests length 9 + k (lep_huffdec.h symbol_long); -1 = not a code
@@ -165,32 +178,24 @@ struct ProgWinWave : ProgDecWave {
         const int sal = k.sal;
         if (eobrun > 0) { --eobrun; return 0; }   // inside a run: the band of this block is zero (the frame starts zeroed)
         uint32_t bpos = from, last_s = 1;
-        uint64_t changed = 0;
         int rc = 0;
         bool run_read = false;
         LV(uint32_t, nv);
         LANES(l) L(nv) = 0;
 #pragma nounroll
         while (bpos <= to) {
-            // the common codes without leaving the scalar unit: a coefficient behind a run of up to fifteen zeros
-            bool more = false;
-#pragma nounroll
-            for (;;) {
-                if (off >= 64u) stage();
-                const uint32_t e = lepwave::wave_read(pre, (int)off);
-                const uint32_t len = (e >> 8) & 31u, r = (e >> 4) & 15u, s = e & 15u;
-                const uint32_t at = bpos + r;
-                if (!(e & kWinFast) || at > to) break;
-                const uint32_t n = (e >> 16) >> (16u - s);
-                const uint32_t v = (uint32_t)(uint16_t)((uint16_t)devli(s, n) << sal);
-                LANES(l) if ((uint32_t)l == at) L(nv) = v;
-                changed |= 1ull << at;
+            // the common codes without leaving the scalar unit: a coefficient behind a run of up to fifteen zeros (the lane's word
+            // holds run, bits and value; a run of 255 -- everything else -- lands behind the band)
+            if (off >= 64u) stage();
+            const uint32_t f = lepwave::wave_read(pre1, (int)off);
+            const uint32_t at = bpos + (f & 255u);
+            if (at <= to) {
+                LANES(l) if ((uint32_t)l == at) L(nv) = f >> 16;
                 bpos = at + 1u;
-                off += len + s;
-                last_s = s;
-                if (bpos > to) { more = true; break; }
+                off += (f >> 8) & 63u;
+                last_s = 1;
+                continue;
             }
-            if (more) break;
             uint32_t len, sym, f16;
             if (!code_at(2, &len, &sym, &f16)) { rc = -1; break; }
             const uint32_t r = sym >> 4, s = sym & 15u;
@@ -200,7 +205,6 @@ struct ProgWinWave : ProgDecWave {
                 if (s > 0u) {
                     const uint32_t n = f16 >> (16u - s);
                     lepwave::wave_write(nv, (int)bpos, (uint32_t)(uint16_t)((uint16_t)devli(s, n) << sal));
-                    changed |= 1ull << bpos;
                 }
                 ++bpos;
                 off += len + s;
@@ -221,9 +225,12 @@ struct ProgWinWave : ProgDecWave {
             if (!rc && last_s == 0u) rc = -1;         // the band ends in a coded zero
             peobrun = 0;
         }
-        if (changed) {
+        // (a value whose 16 bits come out zero is not stored: the frame starts zeroed)
+        LV(int, chg);
+        LANES(l) L(chg) = L(nv) != 0;
+        if (lepwave::wave_ballot(chg)) {
             int16_t* dst = k.blocks + (int64_t)dpos * 64;
-            LANES(l) if ((changed >> l) & 1ull) lepwave::gst(dst + L(zz), (int16_t)L(nv));
+            LANES(l) if (L(chg)) lepwave::gst(dst + L(zz), (int16_t)L(nv));
         }
         return rc;
     }
@@ -275,79 +282,73 @@ struct ProgWinWave : ProgDecWave {
             L(nv) = 0;
         }
         lepwave::wave_select(zrank, ~zm, 0xffffu);
-        uint32_t bpos = (uint32_t)from, zr = 0, nzr = 0, last_kind = 1;
-        uint64_t passed = 0;             // positions in front of bpos
+        // The chain's state.  acc = (bit position) - (non-zero positions in front of the next position): a code's correction bits start at
+        // acc + its own bits, which is also the next acc -- one addition per code for both; the window offset follows from it.  p: the
+        // position the last code took (from - 1: none yet); ahead: the lanes behind it.  zr: zero positions in front of the next one.
+        uint32_t acc = base + off, zr = 0, last = 0x10000u;
+        int p = from - 1;
+        uint64_t ahead = ~0ull;
         int rc = 0;
-        const uint32_t plus = (uint32_t)(uint16_t)((uint16_t)1 << sal), minus = (uint32_t)(uint16_t)((uint16_t)(int16_t)-1 << sal);
         if (eobrun == 0) {
 #pragma nounroll
-            while (bpos <= (uint32_t)to) {
-                // the common codes without leaving the scalar unit: a new +-1 behind r zeros, or sixteen zeros (ZRL; kWinFast in the
-                // lane's answer).  The (r + 1)-th zero position at or after bpos takes it; the non-zero positions in front of it
-                // take correction bits, which the chain only steps over: they stand behind this code, in the order of their ranks.
-                bool more = false;
-#pragma nounroll
-                for (;;) {
-                    if (off >= 64u) stage();
-                    const uint32_t e = lepwave::wave_read(pre, (int)off);
-                    const uint32_t T = zr + ((e >> 4) & 15u);
-                    LV(int, hit);
-                    LANES(l) L(hit) = L(zrank) == T;
-                    const uint64_t m = lepwave::wave_ballot(hit);
-                    if (!(e & kWinFast) || !m) break;
-                    const uint32_t s = e & 1u, consumed = ((e >> 8) & 31u) + s;
-                    const int p = __builtin_ctzll(m);
+            for (;;) {
+                // the common codes without leaving the scalar unit: a new +-1 behind r zeros, or sixteen zeros (ZRL).  The (r + 1)-th zero
+                // position behind p takes it: one compare of the lanes' zero ranks; the non-zero positions in between take correction
+                // bits, which the chain only steps over (their count: the difference of two lanes' ranks) -- every lane still AHEAD takes
+                // this code's mark for them, the lanes behind the NEXT code's start will be overwritten by that code's.
+                if (off >= 64u) stage();
+                const uint32_t f = lepwave::wave_read(pre1, (int)off);
+                const uint32_t T = zr + (f & 255u);
+                LV(int, hit);
+                LANES(l) L(hit) = L(zrank) == T;
+                const uint64_t m = lepwave::wave_ballot(hit);
+                if (m) {
+                    p = __builtin_ctzll(m);
                     const uint32_t nz2 = lepwave::wave_read(nzrank, p);
-                    const uint32_t mark = base + off + consumed - nzr;
-                    const uint32_t val = s ? ((e >> 31) ? plus : minus) : 0u;
-                    const uint64_t upto = m | (m - 1);                          // positions up to and including p
-                    const uint64_t between = upto & ~passed;
-                    lepwave::wave_select(cmark, between, mark);
-                    lepwave::wave_select(nv, m, val);
-                    passed = upto;
-                    off += consumed + (nz2 - nzr);
-                    nzr = nz2; zr = T + 1u; bpos = (uint32_t)p + 1u; last_kind = s;
-                    if (bpos > (uint32_t)to) { more = true; break; }
+                    const uint32_t mark = acc + ((f >> 8) & 63u);
+                    lepwave::wave_select(cmark, ahead, mark);
+                    lepwave::wave_select(nv, m, f >> 16);
+                    ahead = ~(m | (m - 1));
+                    off = mark + nz2 - base;
+                    acc = mark; zr = T + 1u; last = f;
+                    if (p >= to) break;
+                    continue;
                 }
-                if (more) break;
+                // anything else: a code of more than nine bits, an end of band, or something a canonical encoder does not write
                 uint32_t len, sym, f16;
                 if (!code_at(2, &len, &sym, &f16)) { rc = -1; break; }
                 const uint32_t r = sym >> 4, s = sym & 15u;
                 if (r == 15u || s > 0u) {
                     if (s > 1u) { rc = -1; break; }
-                    const uint32_t T = zr + r;
-                    LV(int, hit);
-                    LANES(l) L(hit) = L(zrank) == T;
-                    const uint64_t m = lepwave::wave_ballot(hit);
-                    if (!m) { rc = -1; break; }                                  // the walk would leave the band
-                    const int p = __builtin_ctzll(m);
+                    const uint32_t T2 = zr + r;
+                    LANES(l) L(hit) = L(zrank) == T2;
+                    const uint64_t m2 = lepwave::wave_ballot(hit);
+                    if (!m2) { rc = -1; break; }                                 // the walk would leave the band
+                    p = __builtin_ctzll(m2);
                     const uint32_t nz2 = lepwave::wave_read(nzrank, p);
-                    const uint32_t consumed = len + s;
-                    const uint32_t mark = base + off + consumed - nzr;
-                    const uint32_t val = s ? ((f16 >> 15) ? plus : minus) : 0u;
-                    const uint64_t upto = m | (m - 1);
-                    const uint64_t between = upto & ~passed;
-                    lepwave::wave_select(cmark, between, mark);
-                    lepwave::wave_select(nv, m, val);
-                    passed = upto;
-                    off += consumed + (nz2 - nzr);
-                    nzr = nz2; zr = T + 1u; bpos = (uint32_t)p + 1u; last_kind = s;
+                    const uint32_t mark = acc + len + s;
+                    const uint32_t val = s ? ((f16 >> 15) ? k.plus : k.minus) : 0u;
+                    lepwave::wave_select(cmark, ahead, mark);
+                    lepwave::wave_select(nv, m2, val);
+                    ahead = ~(m2 | (m2 - 1));
+                    off = mark + nz2 - base;
+                    acc = mark; zr = T2 + 1u; last = val << 16;
+                    if (p >= to) break;
                 } else {
                     const uint32_t extra = r ? f16 >> (16u - r) : 0u;
-                    off += len + r;
-                    if (last_kind == 0u) { rc = -1; break; }                     // ZRL in front of the end of band: not canonical
+                    off += len + r; acc += len + r;
+                    if ((last >> 16) == 0u) { rc = -1; break; }                  // ZRL in front of the end of band: not canonical
                     eobrun = extra + (1u << r);
-                    if (bpos == (uint32_t)from && peobrun > 0 && peobrun < k.max_eobrun - 1) { rc = -1; break; }   // jpgcoder.cc:3229-3236
+                    if (p == from - 1 && peobrun > 0 && peobrun < k.max_eobrun - 1) { rc = -1; break; }   // jpgcoder.cc:3229-3236
                     break;
                 }
             }
-            if (!rc && eobrun == 0 && last_kind == 0u) rc = -1;                  // the band ends in a ZRL
+            if (!rc && eobrun == 0 && (last >> 16) == 0u) rc = -1;               // the band ends in a ZRL
         }
         if (!rc && eobrun > 0) {
-            if (bpos <= (uint32_t)to) {                                          // the rest of the band: correction bits only
-                const uint32_t tailmark = base + off - nzr;
-                lepwave::wave_select(cmark, ~passed, tailmark);
-                off += nztotal - nzr;
+            if (p < to) {                                                        // the rest of the band: correction bits only
+                lepwave::wave_select(cmark, ahead, acc);
+                off += nztotal - (base + off - acc);
             }
             --eobrun;
         }
@@ -418,6 +419,7 @@ struct ProgWinWave : ProgDecWave {
             const int c = scan->cmp[0];
             k.from = scan->from; k.to = scan->to; k.sal = scan->sal; k.sah = scan->sah; k.max_eobrun = scan->max_eobrun;
             k.want_rows = scan->want_rows; k.tbl0 = scan->tbl[0] & 1;
+            k.plus = (uint32_t)(uint16_t)((uint16_t)1 << scan->sal); k.minus = (uint32_t)(uint16_t)((uint16_t)(int16_t)-1 << scan->sal);
             k.cmp = c; k.bch = img->bch[c]; k.nch = scan->nch[c]; k.ncv = scan->ncv[c]; k.vs = img->vs[c];
             k.blocks = img->blocks[c];
             k.scan = img->scan; k.scan_len = img->scan_len; k.limit = img->scan_len * 8u;
@@ -544,10 +546,13 @@ struct ProgWinWave : ProgDecWave {
                 } else {
                     const int rc = k.sah == 0 ? ac_first_win(dpos) : ac_refine_win(dpos, col + 1 < k.nch);
                     if (rc < 0) { sta = -1; break; }
-                    if (k.sah == 0 && eobrun) {          // a run: its blocks are passed as a whole (skip_eobrun's own arithmetic)
-                        sta = skip_run(k.cmp, &dpos, &rstw);
-                        row = dpos / k.bch; col = dpos - row * k.bch;
-                        if (row >= k.ncv || col >= k.nch) stray = true;
+                    if (k.sah == 0 && eobrun) {          // a run: its blocks are passed as a whole
+                        if (!stray && col + (int)eobrun < k.nch) { col += (int)eobrun; dpos += (int)eobrun; eobrun = 0; }   // (inside the block row: skip_run comes to the same)
+                        else {                           // skip_eobrun's own arithmetic (jpgcoder.cc:5462-5500), divisions and all
+                            sta = skip_run(k.cmp, &dpos, &rstw);
+                            row = dpos / k.bch; col = dpos - row * k.bch;
+                            if (row >= k.ncv || col >= k.nch) stray = true;
+                        }
                     }
                 }
                 if (sta == 0) {

@@ -160,9 +160,7 @@ WDEV void wave_write(uint32_t* v, int dst, uint32_t value) {
 // number in every lane -- six vector instructions where the hardware takes the mask as it is.
 WDEV void wave_select(uint32_t* v, uint64_t m, uint32_t value) {
 #if LEP_ON_GPU
-    uint32_t x = v[0];
-    __asm__ volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(value), "s"(m));
-    v[0] = x;
+    __asm__("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[0]) : "v"(value), "s"(m));
 #else
     for (int i = 0; i < 64; ++i) if ((m >> i) & 1ull) v[i] = value;
 #endif
@@ -170,9 +168,7 @@ WDEV void wave_select(uint32_t* v, uint64_t m, uint32_t value) {
 // ... and per-lane values: lanes in m take their own w, the others keep v
 WDEV void wave_select_v(uint32_t* v, uint64_t m, const uint32_t* w) {
 #if LEP_ON_GPU
-    uint32_t x = v[0];
-    __asm__ volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(w[0]), "s"(m));
-    v[0] = x;
+    __asm__("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[0]) : "v"(w[0]), "s"(m));
 #else
     for (int i = 0; i < 64; ++i) if ((m >> i) & 1ull) v[i] = w[i];
 #endif

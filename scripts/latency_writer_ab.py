@@ -57,8 +57,11 @@ def main():
     # the encoder's forms for small launches: the default choice (round 4: the split-phase encoder with the stitched writer from 64
     # segments on, the two-wavefront single-kernel encoder below), the lane-per-segment writer instead of the stitched one, and the
     # split-phase encoder for launches of any size
-    for name, extra in (("default", {}), ("LEP_ENC5_WCHUNKS=0", {"LEP_ENC5_WCHUNKS": "0"}), ("LEP_ENC5_MIN=1", {"LEP_ENC5_MIN": "1"}),
-                        ("LEP_ENC5_MIN=1 LEP_ENC5_WCHUNKS=0", {"LEP_ENC5_MIN": "1", "LEP_ENC5_WCHUNKS": "0"})):
+    forms = (("default", {}), ("LEP_ENC5_WCHUNKS=0", {"LEP_ENC5_WCHUNKS": "0"}), ("LEP_ENC5_MIN=1", {"LEP_ENC5_MIN": "1"}),
+             ("LEP_ENC5_MIN=1 LEP_ENC5_WCHUNKS=0", {"LEP_ENC5_MIN": "1", "LEP_ENC5_WCHUNKS": "0"}))
+    if len(sys.argv) > 1:      # the forms named on the command line instead: "LEP_ENC5_WLANES=65536" "LEP_ENC5_WLANES=262144 LEP_ENC5_WCHUNKS=128" ...
+        forms = tuple((a or "default", dict(kv.split("=") for kv in a.split())) for a in sys.argv[1:])
+    for name, extra in forms:
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=env, timeout=400)
         try:
