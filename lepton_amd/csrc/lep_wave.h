@@ -37,6 +37,14 @@ static inline int lep_lane_id(int i) { __asm__ volatile("" : "+r"(i)); return i;
 #define WDEV inline
 #endif
 
+// LANES0(l): a lane-parallel region that does not use the lane NUMBER (only L() variables): on the GPU no lane index is made --
+// LANES' opaque one is a v_mov every time, which a chain that runs on one wavefront's issue slots pays for
+#if LEP_ON_GPU
+#define LANES0(l) for (int l = 0, lep_once_ = 1; lep_once_; lep_once_ = 0)
+#else
+#define LANES0(l) LANES(l)
+#endif
+
 #define LV(T, name) T name[LEP_NL]
 #define L(name) name[LEP_LI(l)]
 

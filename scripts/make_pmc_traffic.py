@@ -45,7 +45,7 @@ def kernel_source_sha():   # bench.kernel_source_sha: sha256 over lepton_amd/csr
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     for f in ("lep_gpu.hip", "lep_batch.hip"):   # (and the compile flags build() recorded for them)
         p = os.path.join(ROOT, "lepton_amd", "build", "obj", f + ".o.flags")
-        h.update(open(p, "rb").read() if os.path.exists(p) else b"")
+        h.update(open(p, "rb").read().split(b" |src:")[0] if os.path.exists(p) else b"")   # (the flags, not the input hash build() keeps beside them)
     return h.hexdigest()[:16]
 
 
