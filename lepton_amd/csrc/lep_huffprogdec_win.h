@@ -69,7 +69,6 @@ struct ProgWinWave : ProgDecWave {
     LV(uint32_t, pre1);                 // ... DC table 1
     LV(uint32_t, wpf0); LV(uint32_t, wpf1); LV(uint32_t, wpf2); LV(uint32_t, wpf3);
     LV(uint32_t, zz);                   // the lane's zig-zag position in aligned order
-    LV(int, lanei);                     // the lane's number, kept in a register (LANES0 regions compare against it)
 
     WDEV uint32_t pos() const { return base + off; }
 
@@ -191,7 +190,7 @@ struct ProgWinWave : ProgDecWave {
             const uint32_t f = lepwave::wave_read(pre1, (int)off);
             const uint32_t at = bpos + (f & 255u);
             if (at <= to) {
-                LANES0(l) if ((uint32_t)L(lanei) == at) L(nv) = f >> 16;
+                LANES(l) if ((uint32_t)l == at) L(nv) = f >> 16;
                 bpos = at + 1u;
                 off += (f >> 8) & 63u;
                 last_s = 1;
@@ -264,9 +263,9 @@ struct ProgWinWave : ProgDecWave {
         const int from = k.from, to = k.to, sal = k.sal;
         const uint64_t band = (to >= 63 ? ~0ull : ((1ull << (to + 1)) - 1)) & ~((1ull << from) - 1);
         LV(int, cur); LV(int, nzf);
-        LANES0(l) L(cur) = (int)L(pf);
+        LANES(l) L(cur) = (int)L(pf);
         lepwave::wave_select((uint32_t*)cur, ~band, 0u);
-        LANES0(l) L(nzf) = L(cur) != 0;
+        LANES(l) L(nzf) = L(cur) != 0;
         flush_store();
 #ifndef LEP_WIN_NOLOAD
         request_block(next_in_row ? dpos + 1 : dpos);   // (no next block in this row: the same one again, for nobody)
@@ -285,28 +284,31 @@ struct ProgWinWave : ProgDecWave {
         lepwave::wave_select(zrank, ~zm, 0xffffu);
         // The chain's state.  acc = (bit position) - (non-zero positions in front of the next position): a code's correction bits start at
         // acc + its own bits, which is also the next acc -- one addition per code for both; the window offset follows from it.  p: the
-        // position the last code took (from - 1: none yet).  zr: zero positions in front of the next one.
+        // position the last code took (from - 1: none yet); ahead: the lanes behind it.  zr: zero positions in front of the next one.
         uint32_t acc = base + off, zr = 0, last = 0x10000u;
         int p = from - 1;
+        uint64_t ahead = ~0ull;
         int rc = 0;
         if (eobrun == 0) {
 #pragma nounroll
             for (;;) {
                 // the common codes without leaving the scalar unit: a new +-1 behind r zeros, or sixteen zeros (ZRL).  The (r + 1)-th zero
                 // position behind p takes it: one compare of the lanes' zero ranks; the non-zero positions in between take correction
-                // bits, which the chain only steps over (their count: the difference of two lanes' ranks) -- every lane behind the LAST
-                // code's position takes this code's mark for them; the lanes behind this code's own position will be overwritten by the next.
+                // bits, which the chain only steps over (their count: the difference of two lanes' ranks) -- every lane still AHEAD takes
+                // this code's mark for them, the lanes behind the NEXT code's start will be overwritten by that code's.
                 if (off >= 64u) stage();
                 const uint32_t f = lepwave::wave_read(pre1, (int)off);
                 const uint32_t T = zr + (f & 255u);
                 LV(int, hit);
-                LANES0(l) L(hit) = L(zrank) == T;
+                LANES(l) L(hit) = L(zrank) == T;
                 const uint64_t m = lepwave::wave_ballot(hit);
                 if (m) {
-                    const uint32_t mark = acc + ((f >> 8) & 63u), val = f >> 16;
-                    LANES0(l) { if (L(lanei) > p) L(cmark) = mark; if (L(hit)) L(nv) = val; }
                     p = __builtin_ctzll(m);
                     const uint32_t nz2 = lepwave::wave_read(nzrank, p);
+                    const uint32_t mark = acc + ((f >> 8) & 63u);
+                    lepwave::wave_select(cmark, ahead, mark);
+                    lepwave::wave_select(nv, m, f >> 16);
+                    ahead = ~(m | (m - 1));
                     off = mark + nz2 - base;
                     acc = mark; zr = T + 1u; last = f;
                     if (p >= to) break;
@@ -319,14 +321,16 @@ struct ProgWinWave : ProgDecWave {
                 if (r == 15u || s > 0u) {
                     if (s > 1u) { rc = -1; break; }
                     const uint32_t T2 = zr + r;
-                    LANES0(l) L(hit) = L(zrank) == T2;
+                    LANES(l) L(hit) = L(zrank) == T2;
                     const uint64_t m2 = lepwave::wave_ballot(hit);
                     if (!m2) { rc = -1; break; }                                 // the walk would leave the band
-                    const uint32_t mark = acc + len + s;
-                    const uint32_t val = s ? ((f16 >> 15) ? k.plus : k.minus) : 0u;
-                    LANES0(l) { if (L(lanei) > p) L(cmark) = mark; if (L(hit)) L(nv) = val; }
                     p = __builtin_ctzll(m2);
                     const uint32_t nz2 = lepwave::wave_read(nzrank, p);
+                    const uint32_t mark = acc + len + s;
+                    const uint32_t val = s ? ((f16 >> 15) ? k.plus : k.minus) : 0u;
+                    lepwave::wave_select(cmark, ahead, mark);
+                    lepwave::wave_select(nv, m2, val);
+                    ahead = ~(m2 | (m2 - 1));
                     off = mark + nz2 - base;
                     acc = mark; zr = T2 + 1u; last = val << 16;
                     if (p >= to) break;
@@ -343,7 +347,7 @@ struct ProgWinWave : ProgDecWave {
         }
         if (!rc && eobrun > 0) {
             if (p < to) {                                                        // the rest of the band: correction bits only
-                LANES0(l) if (L(lanei) > p) L(cmark) = acc;
+                lepwave::wave_select(cmark, ahead, acc);
                 off += nztotal - (base + off - acc);
             }
             --eobrun;
@@ -360,7 +364,7 @@ struct ProgWinWave : ProgDecWave {
         }
         // what changed (new coefficients are not zero, corrected ones neither) is stored a block later
         LV(int, chg);
-        LANES0(l) { L(chg) = L(nv) != 0; L(held) = L(nv); }
+        LANES(l) { L(chg) = L(nv) != 0; L(held) = L(nv); }
         held_mask = lepwave::wave_ballot(chg);
         held_dpos = dpos;
         peobrun = (int)eobrun;
@@ -426,7 +430,6 @@ struct ProgWinWave : ProgDecWave {
             for (int i = l; i < 3 * 256; i += 64) (&ws->longsym[0][0])[i] = (&img->longsym[0][0])[i];
             ws->z2a[l] = kZ2A[l];
             L(zz) = kZ2A[l];
-            L(lanei) = l;
         }
         LSYNC();
         base = 0; off = 0; ring_hi = 0;
