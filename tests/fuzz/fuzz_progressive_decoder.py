@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Mutation fuzz of the GPU progressive scan decoder (lep_huffprogdec.h, lane-loop emulation) against the host parser: a damaged
+"""Mutation fuzz of the GPU progressive scan decoders (lep_huffprogdec_win.h and lep_huffprogdec.h, lane-loop emulations) against each other and the host parser: a damaged
 progressive file is either flagged irregular (-> host parser) or decoded to exactly what the host parser decodes and finished to
 the same .lep header.  A tool, run by hand:  python tests/fuzz/fuzz_progressive_decoder.py <seed> <trials>"""
 import sys, random, ctypes as C
@@ -24,10 +24,17 @@ for trial in range(N):
     else: j[pos]^=1<<rnd.randrange(8)
     j=bytes(j)
     try:
-        h,planes,st=t._progressive_decode_on_the_emulation(emu,j,pipelined=bool(trial&1))   # level by level / one pipelined launch, in turn
+        rows_w=[]
+        h,planes,st=t._progressive_decode_on_the_emulation(emu,j,pipelined=bool(trial&1),win=True,rows_out=rows_w)   # lep_huffprogdec_win.h; level by level / one pipelined launch, in turn
     except AssertionError as e:
         inel+=1; continue   # open_gpu failed / sequential
     if st is None: inel+=1; continue
+    # the uniform-code form (lep_huffprogdec.h) on the same bytes: same verdict, same frame, same records
+    rows_o=[]
+    h2,planes2,st2=t._progressive_decode_on_the_emulation(emu,j,pipelined=bool(trial&1),rows_out=rows_o)
+    if st2 is not None: abi.lib().lep_jpeg_close(h2)
+    if st2!=st or (st==0 and ([p.raw for p in planes]!=[p.raw for p in planes2] or rows_w!=rows_o)):
+        bad+=1; print('FORMS DIFFER',trial,k,st,st2); open('/tmp/pdw_%d.jpg'%trial,'wb').write(j)
     if st==-1: irr+=1; abi.lib().lep_jpeg_close(h); continue
     # accepted by the GPU path: the host parser must accept too and agree
     try:
