@@ -1187,14 +1187,13 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu* g, const lep_huffprogdec_
     for (int i = 0; i < nscan; ++i) { if (scans[i].level < 0 || scans[i].level > 63) return LEP_ASSERTION_FAILURE; maxlevel = std::max(maxlevel, (int)scans[i].level); }
     std::vector<lep_huffprogdec_scan> sorted;
     sorted.reserve((size_t)nscan);
-    std::vector<int> first((size_t)maxlevel + 2, 0), order;
+    std::vector<int> order;
     order.reserve((size_t)nscan);
     // (LEP_HUFFPROG_SPLIT=1, a measurement aid: inside a level the scans of one KIND -- DC / AC, first stage / refinement, component, band --
     // stand together and get a launch of their own, so that a kernel trace shows what each kind of scan takes)
     auto kind = [](const lep_huffprogdec_scan& s) { return (s.to == 0 ? 0 : 1) * 100000 + (s.sah ? 1 : 0) * 10000 + (s.cmpc > 1 ? 9 : s.cmp[0]) * 1000 + s.from * 10 + (s.to > 9 ? 9 : s.to); };
     std::vector<int> cut;   // launch boundaries inside `sorted`
     for (int lv = 0; lv <= maxlevel; ++lv) {
-        first[(size_t)lv] = (int)sorted.size();
         std::vector<int> idx;
         for (int i = 0; i < nscan; ++i) if (scans[i].level == lv) idx.push_back(i);
         if (g->huffprog_split) std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return kind(scans[a]) < kind(scans[b]); });
@@ -1203,7 +1202,6 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu* g, const lep_huffprogdec_
             sorted.push_back(scans[idx[q]]); order.push_back(idx[q]);
         }
     }
-    first[(size_t)maxlevel + 1] = (int)sorted.size();
     cut.push_back((int)sorted.size());
     // Small launches wait for the chain of a file's dependent scans, not for throughput: all levels go out as ONE launch in which
     // a scan follows the scans in front of it MCU row by MCU row.  (Beyond what is resident at once the levels are launched one

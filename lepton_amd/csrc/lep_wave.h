@@ -37,14 +37,6 @@ static inline int lep_lane_id(int i) { __asm__ volatile("" : "+r"(i)); return i;
 #define WDEV inline
 #endif
 
-// LANES0(l): a lane-parallel region that does not use the lane NUMBER (only L() variables): on the GPU no lane index is made --
-// LANES' opaque one is a v_mov every time, which a chain that runs on one wavefront's issue slots pays for
-#if LEP_ON_GPU
-#define LANES0(l) for (int l = 0, lep_once_ = 1; lep_once_; lep_once_ = 0)
-#else
-#define LANES0(l) LANES(l)
-#endif
-
 #define LV(T, name) T name[LEP_NL]
 #define L(name) name[LEP_LI(l)]
 
@@ -173,15 +165,6 @@ WDEV void wave_select(uint32_t* v, uint64_t m, uint32_t value) {
     for (int i = 0; i < 64; ++i) if ((m >> i) & 1ull) v[i] = value;
 #endif
 }
-// ... and per-lane values: lanes in m take their own w, the others keep v
-WDEV void wave_select_v(uint32_t* v, uint64_t m, const uint32_t* w) {
-#if LEP_ON_GPU
-    __asm__("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[0]) : "v"(w[0]), "s"(m));
-#else
-    for (int i = 0; i < 64; ++i) if ((m >> i) & 1ull) v[i] = w[i];
-#endif
-}
-
 WDEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 
 // Global memory through pointers whose address space the compiler cannot see (they come out of descriptors in memory): a plain
