@@ -127,7 +127,8 @@ typedef struct lep_huff_image {
     int32_t ncomp, mcuh, mcuv, mcuc;
     int32_t rsti, padbit;
     uint32_t rst_limit;
-    int32_t interleaved;
+    int32_t interleaved;                 /* 1: MCUs of hs x vs blocks per component.  A one-component file (never interleaved: MCU = one block, the scan steps over the
+                                          * frame's padding blocks) is planned as mcuh x mcuv = its nch x ncv blocks, hs = vs = 1, block rows bch apart, segments in block rows */
     int32_t hs[4], vs[4], bch[4];
     int32_t dc_tbl[4], ac_tbl[4];
     int32_t scan_cmp[4];
@@ -152,7 +153,7 @@ typedef struct lep_huff_end {
     int16_t last_dc[4];
     uint16_t pad;
 } lep_huff_end;
-/* d_ends: nseg records in device memory, or NULL.  Segments of MCU-interleaved scans (with or without restart intervals) are written with one
+/* d_ends: nseg records in device memory, or NULL.  Segments (of MCU-interleaved scans and of one-component files, with or without restart intervals) are written with one
  * lane per run of at most eight MCUs (lep_huff_simt.h: count, prefix sums, code, stuff; a run ends where its restart interval does and
  * carries the pad bits and the marker), the others with one wavefront per segment (lep_huff.h);
  * same bytes, same end states (LEP_HUFFENC_SIMT=0: the wavefront form for all).  `pad` of a segment is the library's: pass it as 0 (lep_file_recode_plan does).

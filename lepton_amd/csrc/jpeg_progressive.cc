@@ -533,7 +533,10 @@ int progressive_plan(JpegFile* jfp, size_t jpeg_size, bool rst_cnt_set, ProgPlan
     plan->gpu_ok = false;
     plan->scans.clear(); plan->scan_hdr_end.clear(); plan->markers.clear();
     // eligibility: whole progressive frames of up to three components; everything else keeps the host coder
-    bool ok = jf.jpegtype == 2 && !jf.early_eof && jf.ncomp >= 1 && jf.ncomp <= 3 && jf.mcuh > 0 && jf.mcuv > 0;
+    // (... and SEQUENTIAL frames coded in several scans: the same walk, every scan a descriptor with from 0 / to 63 that the sequential scan
+    // encoders write -- lep_huffprog.h sequential_scan_segment)
+    const bool sequential = jf.jpegtype == 1;
+    bool ok = (jf.jpegtype == 2 || sequential) && !jf.early_eof && jf.ncomp >= 1 && jf.ncomp <= 3 && jf.mcuh > 0 && jf.mcuv > 0;
     for (int c = 0; c < jf.ncomp; ++c) ok = ok && jf.trunc_bcv[c] >= jf.comp[c].bcv && jf.comp[c].nch > 0 && jf.comp[c].ncv > 0;
     if (!ok) return 0;
     ProgImage& im = plan->image;
@@ -564,19 +567,34 @@ int progressive_plan(JpegFile* jfp, size_t jpeg_size, bool rst_cnt_set, ProgPlan
         ProgScan sc;
         memset(&sc, 0, sizeof sc);
         sc.cmpc = jf.cs_cmpc; sc.from = jf.cs_from; sc.to = jf.cs_to; sc.sah = jf.cs_sah; sc.sal = jf.cs_sal;
+        if (sequential) { sc.from = 0; sc.to = 63; sc.sah = 0; sc.sal = 0; }   // (a sequential scan codes whole blocks whatever its SOS says: encode_block_seq)
         if (sc.cmpc < 1 || sc.cmpc > jf.ncomp || sc.sal < 0 || sc.sal > 13 || sc.from < 0 || sc.to > 63 || sc.from > sc.to) return 0;
         const bool dc = sc.to == 0;
-        if (!dc && (sc.cmpc != 1 || sc.from < 1)) return 0;
+        if (!sequential && sc.from == 0 && sc.to == 63) return 0;             // (a progressive scan of the whole band: nothing writes that)
+        if (!sequential && !dc && (sc.cmpc != 1 || sc.from < 1)) return 0;
         if (dc && sc.from != 0) return 0;
         size_t blocks = 0, units;
         for (int i = 0; i < sc.cmpc; ++i) {
             const int c = jf.cs_cmp[i];
             if (c < 0 || c >= jf.ncomp) return 0;
+            for (int j = 0; j < i; ++j) if (sequential && sc.cmp[j] == c) return 0;
             sc.cmp[i] = c;
         }
         if (sc.cmpc == 1) { const Component& k = jf.comp[sc.cmp[0]]; blocks = units = (size_t)k.nch * k.ncv; }
         else { units = (size_t)jf.mcuc; for (int i = 0; i < sc.cmpc; ++i) blocks += (size_t)jf.comp[sc.cmp[i]].mbs * jf.mcuc; }
-        if (dc) {
+        if (sequential) {
+            // one DC and one AC table for all components of the scan (code[0], code[1]); scans of several components have the frame's MCUs
+            const Component& k0 = jf.comp[sc.cmp[0]];
+            if (k0.dc_tbl < 0 || k0.dc_tbl > 1 || k0.ac_tbl < 0 || k0.ac_tbl > 1 || !jf.htab[0][k0.dc_tbl].set || !jf.htab[1][k0.ac_tbl].set) return 0;
+            for (int i = 0; i < sc.cmpc; ++i) {
+                const Component& k = jf.comp[sc.cmp[i]];
+                if (k.dc_tbl != k0.dc_tbl || k.ac_tbl != k0.ac_tbl || k.bch != jf.mcuh * k.hs || k.bcv != jf.mcuv * k.vs || k.nch > k.bch || k.ncv > k.bcv) return 0;
+            }
+            for (int i = 0; i < 256; ++i) {
+                sc.code[0][i] = ((uint32_t)jf.htab[0][k0.dc_tbl].clen[i] << 16) | jf.htab[0][k0.dc_tbl].cval[i];
+                sc.code[1][i] = ((uint32_t)jf.htab[1][k0.ac_tbl].clen[i] << 16) | jf.htab[1][k0.ac_tbl].cval[i];
+            }
+        } else if (dc) {
             for (int i = 0; i < sc.cmpc; ++i) {
                 const int t = jf.comp[sc.cmp[i]].dc_tbl;
                 if (t < 0 || t > 1 || (sc.sah == 0 && !jf.htab[0][t].set)) return 0;
@@ -595,7 +613,7 @@ int progressive_plan(JpegFile* jfp, size_t jpeg_size, bool rst_cnt_set, ProgPlan
         const size_t scan_index = plan->scans.size();
         if (rst_cnt_set && nmark > 0 && !(jf.rst_cnt.size() > scan_index && nmark <= jf.rst_cnt[scan_index])) return 0;   // markers withheld: host
         plan->markers.push_back((uint32_t)nmark);
-        const size_t geo = blocks * (dc ? 8 : 432) + nmark * 2 + units / 4 + 64;
+        const size_t geo = blocks * ((dc && !sequential) ? 8 : 432) + nmark * 2 + units / 4 + 64;
         sc.out_cap = (uint32_t)std::min<size_t>(std::min<size_t>(jpeg_size + 16, geo), 0xfffffff0u);
         sc.corr_cap = (!dc && sc.sah != 0) ? (uint32_t)std::min<size_t>(blocks * 2 + 8, 0x7fffffffu) : 0u;
         sc.file_bound = (uint32_t)std::min<size_t>(jpeg_size + 16, 0xfffffff0u);   // what ALL scans of the file come to at most: they are parts of it

@@ -178,9 +178,17 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
     for (size_t q = 1; q < lf->segs.size(); ++q) if (lf->version > 1 && !lf->segs[q].segment_size) ok = false;   // a worker bound of nothing: host path
     if ((size_t)std::min(lf->nthreads, 8) != lf->segs.size()) ok = false;   // several logical threads folded onto one worker (a damaged thread hint): cumulative bounds, host path
     if (ok && lf->version > 1 && (uint64_t)plan->head.size() + lf->segs[0].segment_size > 0xffffffffull) ok = false;   // the first thread's bound wraps (recode_jpeg): host path
-    if (ok && jf.ncomp == 1) {
+    // One component: never interleaved -- the scan codes the nch x ncv blocks the picture covers and steps over the blocks that pad the
+    // frame to whole MCUs (recode_one_mcu_row with next_mcuposn, recoder.cc:316-412); an MCU row of the hand-offs is bcv / mcuv block
+    // rows.  The kernels get that as a frame of nch x ncv MCUs of one block, block rows bch apart, and segments in block rows.  With
+    // sampling factors or padding blocks the re-coder counts restart intervals in MCUs of hs x vs blocks where the scan counted blocks
+    // (the reference cannot restore such files: tests/test_sampling_layouts.py): those stay with the host re-coder, which is held to that.
+    const bool planar = jf.ncomp == 1;
+    bool plain = false;
+    if (ok && planar) {
         const Component& k = jf.comp[jf.cs_cmp[0]];
-        ok = k.hs == 1 && k.vs == 1 && k.bch == k.nch && k.bcv == k.ncv && k.bc == jf.mcuc;
+        plain = k.hs == 1 && k.vs == 1 && k.bch == k.nch && k.bcv == k.ncv && k.bc == jf.mcuc;
+        if (!plain) ok = jf.rsti == 0 && jf.cs_cmp[0] == 0 && k.nch >= 1 && k.ncv >= 1 && k.nch <= k.bch && k.ncv <= k.bcv && k.bcv % jf.mcuv == 0 && (jf.mcuv - 1) * (k.bcv / jf.mcuv) < k.ncv;
     }
     for (int c = 0; ok && c < jf.ncomp; ++c) {
         const Component& k = jf.comp[c];
@@ -192,10 +200,11 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
     memset(&im, 0, sizeof im);
     im.ncomp = jf.ncomp; im.mcuh = jf.mcuh; im.mcuv = jf.mcuv; im.mcuc = jf.mcuc; im.rsti = jf.rsti; im.padbit = jf.padbit;
     im.rst_limit = (jf.rst_cnt.empty() || !lf->rst_cnt_set) ? 0xffffffffu : jf.rst_cnt[0];
-    im.interleaved = jf.ncomp > 1 ? 1 : 0;
+    im.interleaved = 1;
+    if (planar) { im.mcuh = jf.comp[0].nch; im.mcuv = jf.comp[0].ncv; im.mcuc = im.mcuh * im.mcuv; }
     for (int c = 0; c < 4; ++c) im.trunc_bc[c] = (cut && c < jf.ncomp) ? std::max(1, jf.trunc_bc[c]) : 0;
     for (int c = 0; c < jf.ncomp; ++c) {
-        im.hs[c] = jf.comp[c].hs; im.vs[c] = jf.comp[c].vs; im.bch[c] = jf.comp[c].bch;
+        im.hs[c] = planar ? 1 : jf.comp[c].hs; im.vs[c] = planar ? 1 : jf.comp[c].vs; im.bch[c] = jf.comp[c].bch;
         im.dc_tbl[c] = jf.comp[c].dc_tbl; im.ac_tbl[c] = jf.comp[c].ac_tbl;
         im.scan_cmp[c] = jf.cs_cmp[c];
     }
@@ -221,6 +230,7 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
         }
         if (r1 <= r0) { r0 = r1 = 0; }
         g.mcu_row0 = r0; g.mcu_row1 = r1;
+        if (planar) { g.mcu_row0 = std::min(r0 * luma_mul, im.mcuv); g.mcu_row1 = std::min(r1 * luma_mul, im.mcuv); }   // block rows
         g.overhang = (uint32_t)th.overhang_byte | ((uint32_t)th.num_overhang_bits << 8);
         memcpy(g.last_dc, th.last_dc, sizeof g.last_dc);
         const size_t room = plan->scan_bound - plan->head.size();
@@ -231,8 +241,9 @@ int recode_prepare(LepFile* lf, RecodePlan* plan) {
         // the batch pipeline: never reserve more than the file may hold, nor more than the segment's blocks can possibly
         // code to -- 64 coefficients x (16-bit code + 11 magnitude bits) = 216 bytes, every one of them 0xFF and stuffed,
         // plus a restart marker per MCU at worst
-        const size_t seg_blocks = (size_t)(r1 - r0) * (size_t)jf.mcuh * std::max<size_t>(1, blocks_per_mcu);
-        const size_t geo = seg_blocks * 432 + (size_t)(r1 - r0) * (size_t)jf.mcuh * 2 + 64;
+        const size_t seg_mcus = planar ? (size_t)(g.mcu_row1 - g.mcu_row0) * (size_t)im.mcuh : (size_t)(r1 - r0) * (size_t)jf.mcuh;
+        const size_t seg_blocks = seg_mcus * std::max<size_t>(1, blocks_per_mcu);
+        const size_t geo = seg_blocks * 432 + seg_mcus * 2 + 64;
         cap = std::min(std::min(cap, room), geo);
         if (s > 0) total_cap += cap;   // segment 0 is only bounded by the file; the caller gives it what the others leave
         g.out_cap = (uint32_t)std::min<size_t>(cap, 0xffffffffu);

@@ -649,6 +649,21 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
     plan->ncomp = jf->ncomp; plan->mcuh = jf->mcuh; plan->mcuv = jf->mcuv; plan->mcuc = jf->mcuc; plan->rsti = jf->rsti;
     plan->flags = jf->early_eof ? kScanEarlyEof : 0;
     if (jf->early_eof && jf->rsti) return 0;   // (restart intervals in a cut file: the single-wave kernel has no notion of the cut)
+    // One component: the scan is not interleaved whatever the sampling factors say -- its MCU is one block and it walks the nch x ncv
+    // blocks the picture covers, stepping over the blocks that pad the frame to whole MCUs (next_mcuposn; jpgcoder.cc:3135-3175 with
+    // :3855-3890).  To the kernels that is a frame of nch x ncv MCUs of one block whose block rows lie bch blocks apart: they leave one
+    // row record per BLOCK row, of which parse_jpeg_finish_gpu takes every (bcv / mcuv)-th.  The plain case (factors 1x1) is the same plan
+    // as ever.  Cut files and restart intervals of the other cases stay with the host parser (a restart interval counts blocks in the
+    // scan and MCUs of hs x vs blocks in the re-coder: the reference cannot restore such a file, tests/test_sampling_layouts.py).
+    const bool planar = jf->ncomp == 1;
+    if (planar) {
+        const Component& k = jf->comp[jf->cs_cmp[0]];
+        const bool plain = k.hs == 1 && k.vs == 1 && k.bch == k.nch && k.bcv == k.ncv && k.bc == jf->mcuc;
+        if (!plain) {
+            if (jf->early_eof || jf->rsti || jf->cs_cmp[0] != 0 || k.nch < 1 || k.ncv < 1 || k.nch > k.bch || k.ncv > k.bcv || jf->mcuv < 1 || k.bcv % jf->mcuv) return 0;
+            plan->mcuh = k.nch; plan->mcuv = k.ncv; plan->mcuc = k.nch * k.ncv;
+        }
+    }
     // restart intervals: when the scan holds exactly the markers its length asks for -- one behind every rsti MCUs but the last run --
     // their positions travel with the scan bytes and every interval is decoded by a lane of its own (lep_huffdec_simt.h); otherwise the
     // single-wave kernel walks the scan as the reference does
@@ -662,8 +677,7 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
         const Component& k = jf->comp[i];
         if (k.dc_tbl > 1 || k.ac_tbl > 1 || !jf->htab[0][k.dc_tbl].set || !jf->htab[1][k.ac_tbl].set) return 0;
         if (k.bch != jf->mcuh * k.hs || k.bcv != jf->mcuv * k.vs || k.hs < 1 || k.vs < 1) return 0;
-        if (jf->ncomp == 1 && (k.hs != 1 || k.vs != 1 || k.bch != k.nch || k.bcv != k.ncv || k.bc != jf->mcuc)) return 0;   // grey: one block per MCU, no padding blocks
-        plan->hs[i] = k.hs; plan->vs[i] = k.vs; plan->bch[i] = k.bch; plan->dc_tbl[i] = k.dc_tbl; plan->ac_tbl[i] = k.ac_tbl;
+        plan->hs[i] = planar ? 1 : k.hs; plan->vs[i] = planar ? 1 : k.vs; plan->bch[i] = k.bch; plan->dc_tbl[i] = k.dc_tbl; plan->ac_tbl[i] = k.ac_tbl;
         plan->scan_cmp[i] = jf->cs_cmp[i];
     }
     for (int cls = 0; cls < 2; ++cls)
@@ -679,14 +693,29 @@ int parse_jpeg_prepare_gpu(const uint8_t* data, size_t size, JpegFile* jf, ScanD
 // parse_jpeg_finish_gpu: what decode_scans leaves behind besides the coefficients -- hand-off records from the bit
 // positions the kernel recorded per MCU row, the pad-bit pattern, the scan bookkeeping.  A non-zero kernel status (or a
 // record that makes no sense) is returned as -1: the caller re-parses the file on the host.
-int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows) {
+int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* all_rows) {
+    // (one component: the kernels' frame is nch x ncv MCUs of one block, parse_jpeg_prepare_gpu -- a record per block row, of which
+    // every luma_mul-th starts an MCU row of the file's; the final record stands behind the ncv-th)
     const int mcuv = jf->mcuv;
+    const int luma_mul = jf->comp[0].bcv / jf->mcuv;
+    const bool planar = jf->ncomp == 1;
+    const int step = planar ? std::max(luma_mul, 1) : 1;
+    const int nrec = planar ? jf->comp[0].ncv : mcuv;
+    std::vector<ScanDecodeRow> picked;
+    const ScanDecodeRow* rows = all_rows;
+    if (planar && (step != 1 || nrec != mcuv)) {
+        if ((mcuv - 1) * step >= nrec) return -1;
+        picked.resize((size_t)mcuv + 1);
+        for (int r = 0; r < mcuv; ++r) picked[(size_t)r] = all_rows[r * step];
+        picked[(size_t)mcuv] = all_rows[nrec];
+        rows = picked.data();
+        if (all_rows[nrec].aux & kScanRowTruncated) return -1;   // (cut files of this kind never get here)
+    }
     const int status = (rows[mcuv].aux >> 8) & 0x3fffff;
     if (status) return -1;
     const bool truncated = (rows[mcuv].aux & kScanRowTruncated) != 0;
     if (truncated && !jf->early_eof) return -1;
     const uint32_t total_bits = (uint32_t)jf->scan.size() * 8u;
-    const int luma_mul = jf->comp[0].bcv / jf->mcuv;
     // blocks of an MCU in scan order; a truncated scan: how many MCU rows were entered, and where the walk stood when the data ended
     int nphase = 0;
     for (int ci = 0; ci < jf->cs_cmpc; ++ci) nphase += jf->comp[jf->cs_cmp[ci]].hs * jf->comp[jf->cs_cmp[ci]].vs;
@@ -737,6 +766,7 @@ int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows) {
     jf->max_sah = std::max(jf->max_sah, std::max(jf->cs_sal, jf->cs_sah));
     for (int i = 0; i < jf->cs_cmpc; ++i) jf->max_cmp = std::max(jf->max_cmp, jf->cs_cmp[i]);
     for (int c = 0; c < jf->ncomp; ++c) jf->max_dpos[c] = jf->comp[c].bc - 1;
+    if (planar) jf->max_dpos[0] = (jf->comp[0].ncv - 1) * jf->comp[0].bch + jf->comp[0].nch - 1;   // the last block the scan codes: padding blocks are stepped over
     if (truncated) {
         // max_dpos: the largest block position of every component among the decoded blocks (decode_scans notes it at the start of every
         // block): all of the MCU rows in front of the last one entered, and of that row what its MCUs up to the last block hold
@@ -768,9 +798,144 @@ int parse_jpeg_finish_gpu(JpegFile* jf, const ScanDecodeRow* rows) {
 // sequential kernel.  Eligible here: whole progressive frames whose FIRST scan is the one DC first-stage scan of all
 // components (what libjpeg writes), every other scan a DC refinement or a single-component AC scan, canonical tables, one
 // restart interval for the whole file.  Everything else -- and anything the kernels then find irregular -- is the host's.
+// SEQUENTIAL frames coded in several scans -- luma alone, then Cb + Cr together; a scan per component (`jpegtran -scans`, some scanners).
+// To the reference they are format 'X' like progressive files (cs_cmpc != cmpc: jpgcoder.cc:3009-3014) but their scans are decoded by the
+// sequential block loop (:3034-3175), each scan leaving hand-off records of its own.  Here: every scan one descriptor with from 0 / to 63
+// (lep_huffprogdec.h sequential_scan_image), t = the frame with all four tables, a record per MCU row of the SCAN's geometry -- the frame's
+// MCU rows for a scan of several components, the component's ncv block rows for a scan of one.  Eligible: whole files, two or three
+// components each coded by exactly one scan, tables 0 / 1, canonical codes.
+static int prepare_gpu_sequential_scans(JpegFile* jf, std::vector<ProgScanDecodePlan>* scans, int* rows_needed, bool* eligible) {
+    if (jf->early_eof || jf->ncomp < 2 || jf->ncomp > 3 || jf->scan.empty() || jf->start_byte || jf->mcuh < 1 || jf->mcuv < 1) return 0;
+    const uint8_t* h = jf->hdr.data();
+    const size_t hdrs = jf->hdr.size();
+    size_t hpos = 0;
+    unsigned coded = 0;
+    uint64_t next_row = 0;
+    while (3 + (uint64_t)hpos < hdrs) {
+        const uint8_t type = h[hpos + 1];
+        const unsigned len = 2 + be16(h[hpos + 2], h[hpos + 3]);
+        if ((uint64_t)hpos + len > hdrs) return 0;
+        if (type == 0xC4 || type == 0xDA || type == 0xDD)
+            if (!parse_segment(jf, type, len, len, h + hpos, true)) return 0;
+        hpos += len;
+        if (type != 0xDA) continue;
+        const size_t k = scans->size();
+        if (k >= jf->scan_start.size() || k >= 4) return 0;
+        ProgScanDecodePlan sc;
+        memset(&sc, 0, sizeof sc);
+        sc.cmpc = jf->cs_cmpc; sc.from = 0; sc.to = 63;
+        if (jf->cs_from != 0 || jf->cs_to != 63 || jf->cs_sah != 0 || jf->cs_sal != 0 || sc.cmpc < 1 || sc.cmpc > jf->ncomp) return 0;
+        ScanDecodePlan& t = sc.t;
+        t.scan = (const uint8_t*)(uintptr_t)jf->scan_start[k];
+        const size_t end = k + 1 < jf->scan_start.size() ? jf->scan_start[k + 1] : jf->scan.size();
+        if (end <= jf->scan_start[k]) return 0;
+        t.scan_len = (uint32_t)(end - jf->scan_start[k]);
+        t.ncomp = jf->ncomp; t.mcuh = jf->mcuh; t.mcuv = jf->mcuv; t.mcuc = jf->mcuc; t.rsti = jf->rsti;
+        for (int c = 0; c < jf->ncomp; ++c) {
+            const Component& q = jf->comp[c];
+            if (q.hs < 1 || q.vs < 1 || q.nch < 1 || q.ncv < 1 || q.nch > q.bch || q.ncv > q.bcv || q.bch != jf->mcuh * q.hs || q.bcv != jf->mcuv * q.vs) return 0;
+            t.hs[c] = q.hs; t.vs[c] = q.vs; t.bch[c] = q.bch; t.dc_tbl[c] = q.dc_tbl; t.ac_tbl[c] = q.ac_tbl;
+            sc.bcv[c] = q.bcv; sc.nch[c] = q.nch; sc.ncv[c] = q.ncv; sc.mbs[c] = q.mbs;
+        }
+        for (int i = 0; i < sc.cmpc; ++i) {
+            const int c = jf->cs_cmp[i];
+            if (c < 0 || c >= jf->ncomp || (coded >> c & 1u)) return 0;            // (a component coded twice: the host parser's)
+            coded |= 1u << c;
+            sc.cmp[i] = c; t.scan_cmp[i] = c;
+            const Component& q = jf->comp[c];
+            if (q.dc_tbl < 0 || q.dc_tbl > 1 || q.ac_tbl < 0 || q.ac_tbl > 1 || !jf->htab[0][q.dc_tbl].set || !jf->htab[1][q.ac_tbl].set) return 0;
+            if (!fill_decode_tables(jf->htab[0][q.dc_tbl], t.lut[q.dc_tbl], t.maxcode[q.dc_tbl], t.valoff[q.dc_tbl], t.longsym[q.dc_tbl])) return 0;
+            if (!fill_decode_tables(jf->htab[1][q.ac_tbl], t.lut[2 + q.ac_tbl], t.maxcode[2 + q.ac_tbl], t.valoff[2 + q.ac_tbl], t.longsym[2 + q.ac_tbl])) return 0;
+        }
+        const int scan_rows = sc.cmpc > 1 ? jf->mcuv : jf->comp[sc.cmp[0]].ncv;
+        sc.level = 0; sc.want_rows = 1;
+        t.rows_off = next_row;
+        sc.result_off = next_row + (uint64_t)scan_rows;
+        next_row += (uint64_t)scan_rows + 1;
+        scans->push_back(sc);
+    }
+    if (scans->size() < 2 || scans->size() != jf->scan_start.size() || coded != (1u << jf->ncomp) - 1u || next_row > 0x7fffffffu) { scans->clear(); return 0; }
+    *rows_needed = (int)next_row;
+    *eligible = true;
+    return 0;
+}
+
+// what decode_scans leaves behind for such a file (jpeg_scan.cc decode_scans, the two jpegtype == 1 loops): a hand-off record in front of
+// the first block of every scan, and from then on in front of the first block of every MCU row -- in a scan of several components; in a
+// scan of one component only if it is component 0 (`cmp == 0 && mcu % mcuh == 0 && dpos % (hmul * vmul) == 0`, mcu = dpos / (hmul *
+// vmul) with LUMA's factors) -- and the record behind the last scan, whose MCU row is the one the last scan's walk left `mcu` at.
+static int finish_gpu_sequential_scans(JpegFile* jf, const std::vector<ProgScanDecodePlan>& scans, const ScanDecodeRow* rows) {
+    const int luma_mul = jf->comp[0].bcv / jf->mcuv, hmul = jf->comp[0].bch / jf->mcuh;
+    if (luma_mul < 1 || hmul < 1) return -1;
+    int padbit = -1;
+    jf->max_bpos = 0; jf->max_sah = 0; jf->max_cmp = 0;
+    for (const ProgScanDecodePlan& sc : scans) {
+        const ScanDecodeRow& fin = rows[sc.result_off];
+        if (fin.aux == (int32_t)0x80000000 || ((fin.aux >> 8) & 0x3fffff) || (fin.aux & kScanRowTruncated)) return -1;   // not written / irregular / ran out of data
+        if (fin.bitpos != sc.t.scan_len * 8u) return -1;                       // bytes left over behind the scan's last MCU
+        const int pb = (int8_t)(fin.aux & 255);
+        if (pb != -1) { if (padbit == -1) padbit = pb; else if (padbit != pb) return -1; }   // "inconsistent use of padbits"
+        jf->max_bpos = 63;
+        for (int i = 0; i < sc.cmpc; ++i) jf->max_cmp = std::max(jf->max_cmp, sc.cmp[i]);
+    }
+    jf->rows.clear();
+    const auto& offs = jf->scan_to_file;
+    auto record = [&](uint32_t bit_in_all, const int16_t* last_dc, int mcu_y) {
+        const uint32_t p = (bit_in_all >> 3) + 1;   // BitReader::getpos
+        auto it = std::lower_bound(offs.begin(), offs.end(), std::pair<uint32_t, uint32_t>(p, p));
+        if (it != offs.begin()) --it;
+        uint32_t mapped = 0;
+        if (it != offs.end()) mapped = it->second + (p - it->first);
+        Handoff hnd;
+        hnd.segment_size = mapped;
+        for (int i = 0; i < 4; ++i) hnd.last_dc[i] = last_dc[i];
+        hnd.luma_y_start = (uint16_t)(luma_mul * mcu_y);
+        hnd.luma_y_end = (uint16_t)(luma_mul * (mcu_y + 1));
+        const int rem = (int)(bit_in_all & 7u);
+        hnd.num_overhang_bits = (uint8_t)rem;
+        hnd.overhang_byte = rem ? (uint8_t)(jf->scan[bit_in_all >> 3] & (uint8_t)(((1 << rem) - 1) << (8 - rem))) : 0;
+        jf->rows.push_back(hnd);
+    };
+    int last_mcu = 0;
+    for (size_t k = 0; k < scans.size(); ++k) {
+        const ProgScanDecodePlan& sc = scans[k];
+        const uint32_t base = jf->scan_start[k] * 8u;
+        const ScanDecodeRow* r = rows + sc.t.rows_off;
+        if (sc.cmpc > 1) {
+            for (int y = 0; y < jf->mcuv; ++y) { if (r[y].bitpos > sc.t.scan_len * 8u) return -1; record(base + r[y].bitpos, r[y].last_dc, y); }
+            last_mcu = jf->mcuc;
+        } else {
+            const Component& q = jf->comp[sc.cmp[0]];
+            if (sc.cmp[0] == 0) {
+                for (int y = 0; y < jf->mcuv; ++y) {
+                    if (y * luma_mul >= q.ncv) return -1;
+                    const ScanDecodeRow& e = r[y * luma_mul];
+                    if (e.bitpos > sc.t.scan_len * 8u) return -1;
+                    record(base + e.bitpos, e.last_dc, y);
+                }
+            } else {
+                record(base + r[0].bitpos, r[0].last_dc, 0);
+            }
+            last_mcu = q.bc / (hmul * luma_mul);
+        }
+    }
+    const ScanDecodeRow& fin = rows[scans.back().result_off];
+    record((uint32_t)jf->scan.size() * 8u, fin.last_dc, last_mcu / jf->mcuh);
+    for (size_t i = 1; i < jf->rows.size(); ++i)
+        if (jf->rows[i].luma_y_start < jf->rows[i - 1].luma_y_end) jf->rows[i].luma_y_start = jf->rows[i - 1].luma_y_end;
+    jf->padbit = (int8_t)padbit;
+    jf->scan_count = (int)scans.size();
+    for (int c = 0; c < jf->ncomp; ++c) jf->max_dpos[c] = jf->comp[c].bc - 1;
+    for (const ProgScanDecodePlan& sc : scans)
+        if (sc.cmpc == 1) { const Component& q = jf->comp[sc.cmp[0]]; jf->max_dpos[sc.cmp[0]] = (q.ncv - 1) * q.bch + q.nch - 1; }
+    jf->progressive_needed = true;
+    return 0;
+}
+
 int parse_jpeg_prepare_gpu_progressive(JpegFile* jf, std::vector<ProgScanDecodePlan>* scans, int* rows_needed, bool* eligible) {
     *eligible = false;
     scans->clear();
+    if (jf->jpegtype == 1) return prepare_gpu_sequential_scans(jf, scans, rows_needed, eligible);
     if (jf->early_eof || jf->jpegtype != 2 || jf->ncomp < 1 || jf->ncomp > 3 || jf->scan.empty() || jf->start_byte) return 0;
     const uint8_t* h = jf->hdr.data();
     const size_t hdrs = jf->hdr.size();
@@ -858,6 +1023,7 @@ static std::atomic<uint64_t> g_prog_wait_timeouts{0};   // scans of the pipeline
 uint64_t prog_wait_timeouts() { return g_prog_wait_timeouts.load(std::memory_order_relaxed); }
 
 int parse_jpeg_finish_gpu_progressive(JpegFile* jf, const std::vector<ProgScanDecodePlan>& scans, const ScanDecodeRow* rows) {
+    if (!scans.empty() && scans[0].from == 0 && scans[0].to == 63) return finish_gpu_sequential_scans(jf, scans, rows);
     const int nrows = std::max(jf->mcuv, jf->comp[0].bcv);
     const int luma_mul = jf->comp[0].bcv / jf->mcuv;
     int padbit = -1;

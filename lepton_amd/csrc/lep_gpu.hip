@@ -330,10 +330,19 @@ __global__ __launch_bounds__(64, 8) void lep_huffman_progressive_encode_kernel(c
                                                                                uint32_t* corr, uint32_t* out_len) {
     __shared__ lephuff::ProgShared sh;
     const lephuff::ProgScan* sc = scans + blockIdx.x;
-    if (sc->pad & lephuff::kProgScanSimt) return;   // the lane-per-unit kernels below own this scan
+    if (sc->pad & (lephuff::kProgScanSimt | lephuff::kProgScanSeq)) return;   // the lane-per-unit kernels below / the sequential scan encoders own this scan
     lephuff::ProgWave w;
     const uint32_t n = w.run_scan(images + sc->image, sc, &sh, out, corr);
     if (threadIdx.x == 0) out_len[blockIdx.x] = n;
+}
+// scans of sequential frames, written by the sequential scan encoders as segments of their own: their byte counts to the scans' places, with
+// the progressive writers' mark (bit 31) on a scan that outgrew its slot
+__global__ void lep_huffprog_seq_lens_kernel(const uint32_t* __restrict__ which, const uint32_t* __restrict__ cap, const uint32_t* __restrict__ lens,
+                                             const lephuff::HuffEnd* __restrict__ ends, int n, uint32_t* out_len) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const bool over = ends[i].attempted > cap[i] || (ends[i].pad & (lephuff::kHuffEndCut | lephuff::kHuffEndRefused)) != 0;
+    out_len[which[i]] = lens[i] | (over ? 0x80000000u : 0u);
 }
 // ... with one lane per run of blocks (lep_huffprog_simt.h): count / place / code / stuff
 template <bool WRITE>
@@ -475,6 +484,7 @@ struct lep_gpu {
     int huffprog_split = 0;             // LEP_HUFFPROG_SPLIT=1: level-by-level launches split by kind of scan (measurement aid)
     int huffprogdec_win = 1;            // LEP_HUFFPROGDEC_WIN=0: progressive scans decoded by lep_huffprogdec.h's uniform vector code only
     int huffprog_simt = 1;              // LEP_HUFFPROG_SIMT=0: every progressive scan's bytes from the wavefront-per-scan kernel (lep_huffprog.h)
+    void* d_huffseq[2] = {nullptr, nullptr}; size_t huffseq_bytes[2] = {0, 0};             // scans of sequential frames in a progressive launch: which / caps / byte counts / end states
     void* d_huffprogsimt[2] = {nullptr, nullptr}; size_t huffprogsimt_bytes[2] = {0, 0};   // lep_huffprog_simt.h: descriptors, unit arrays, bit buffers (one per arena set)
     int huffenc_simt = 1;               // LEP_HUFFENC_SIMT=0: every segment's scan bytes from the wavefront-per-segment kernel (lep_huff.h)
     void* d_huffenc = nullptr; size_t huffenc_bytes = 0;   // lep_huff_simt.h: segment / wave descriptors, unit bit counts, bit buffers
@@ -1060,7 +1070,7 @@ static void release_device_side(lep_gpu* g) {
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     if (g->stream3) (void)hipStreamDestroy(g->stream3);
     for (void** p : {&g->arena[0].d_models, &g->arena[0].d_ns, &g->arena[0].d_meta, &g->arena[1].d_models, &g->arena[1].d_ns, &g->arena[1].d_meta, &g->d_blocks, &g->d_streams, &g->d_lens, &g->d_huff,
-                     &g->d_huffprog[0], &g->d_huffprog[1], &g->d_huffprogsimt[0], &g->d_huffprogsimt[1], &g->d_huffprogdec, &g->d_huffdec, &g->d_huffpar, &g->d_huffenc, &g->d_scan, &g->d_scanlen})
+                     &g->d_huffprog[0], &g->d_huffprog[1], &g->d_huffprogsimt[0], &g->d_huffprogsimt[1], &g->d_huffseq[0], &g->d_huffseq[1], &g->d_huffprogdec, &g->d_huffdec, &g->d_huffpar, &g->d_huffenc, &g->d_scan, &g->d_scanlen})
         dev_release(g, p, nullptr);
     vmm_destroy(g);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
@@ -1182,6 +1192,30 @@ int lep_gpu_huffman_progressive_decode_device(lep_gpu* g, const lep_huffprogdec_
     if (nscan <= 0) return 0;
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
     HIPCHK(g, hipSetDevice(g->device));
+    // scans of SEQUENTIAL frames coded in several scans (lep_huffprogdec.h sequential_scan_image): no scan depends on another, each is an image
+    // of its own to the sequential kernels -- one lane per subsequence, or the single-wave kernel where there are restart intervals
+    std::vector<lep_huffprogdec_scan> progressive_only;
+    {
+        std::vector<lep_huffdec_image> many, one;
+        const bool simt = !(getenv("LEP_HUFFDEC_SIMT") && atoi(getenv("LEP_HUFFDEC_SIMT")) == 0);
+        for (int i = 0; i < nscan; ++i) {
+            const lephuff::ProgDecScan& sc = reinterpret_cast<const lephuff::ProgDecScan&>(scans[i]);
+            if (!lephuff::progdec_is_sequential(sc)) continue;
+            if (sc.cmpc < 1 || sc.cmpc > 4) return LEP_ASSERTION_FAILURE;
+            const lephuff::HuffDecImage im = lephuff::sequential_scan_image(sc);
+            lep_huffdec_image out;
+            static_assert(sizeof out == sizeof im, "C ABI mirrors");
+            memcpy(&out, &im, sizeof out);
+            ((simt && lephuff::sequential_scan_for_lanes(im)) ? many : one).push_back(out);
+        }
+        if (!many.empty() || !one.empty()) {
+            if (!many.empty()) { if (int rc = lep_gpu_huffman_decode_simt_device(g, many.data(), (int)many.size(), d_rows, st)) return rc; }
+            if (!one.empty()) { if (int rc = lep_gpu_huffman_decode_device(g, one.data(), (int)one.size(), d_rows, st)) return rc; }
+            for (int i = 0; i < nscan; ++i) if (!lephuff::progdec_is_sequential(reinterpret_cast<const lephuff::ProgDecScan&>(scans[i]))) progressive_only.push_back(scans[i]);
+            if (progressive_only.empty()) return 0;
+            scans = progressive_only.data(); nscan = (int)progressive_only.size();
+        }
+    }
     // scans ordered by dependency level (stable): one launch per level, stream order is the dependency
     int maxlevel = 0;
     for (int i = 0; i < nscan; ++i) { if (scans[i].level < 0 || scans[i].level > 63) return LEP_ASSERTION_FAILURE; maxlevel = std::max(maxlevel, (int)scans[i].level); }
@@ -1283,6 +1317,34 @@ int lep_gpu_huffman_progressive_encode_device(lep_gpu* g, const lep_huffprog_ima
     size_t nunits = 0, scratch_bytes = 0;
     std::vector<uint32_t> file_bound((size_t)nscan);
     for (int i = 0; i < nscan; ++i) { file_bound[(size_t)i] = hs[i].pad; hs[i].pad = 0; }   // (the caller's field; on the device it says which kernel owns the scan)
+    // scans of SEQUENTIAL frames coded in several scans (lep_huffprog.h sequential_scan_segment): the sequential scan encoders write them,
+    // each scan an image with one segment; their byte counts are moved to the scans' places behind that launch
+    std::vector<lep_huff_image> seq_img;
+    std::vector<lep_huff_segment> seq_seg;
+    std::vector<uint32_t> seq_which, seq_cap;
+    for (int i = 0; i < nscan; ++i) {
+        if (!lephuff::prog_is_sequential(hs[i])) continue;
+        if (hs[i].image < 0 || hs[i].image >= nimg || hs[i].cmpc < 1 || hs[i].cmpc > 4) return LEP_ASSERTION_FAILURE;
+        lephuff::HuffImage hi;
+        lephuff::HuffSegment sg;
+        lephuff::sequential_scan_segment(reinterpret_cast<const lephuff::ProgImage&>(images[hs[i].image]), hs[i], (int32_t)seq_img.size(), &hi, &sg);
+        lep_huff_image ci; lep_huff_segment cs;
+        memcpy(&ci, &hi, sizeof ci); memcpy(&cs, &sg, sizeof cs);
+        seq_img.push_back(ci); seq_seg.push_back(cs);
+        seq_which.push_back((uint32_t)i); seq_cap.push_back(hs[i].out_cap);
+        hs[i].pad = lephuff::kProgScanSeq;
+    }
+    if (!seq_seg.empty()) {
+        const size_t n = seq_seg.size(), o_cap = n * 4, o_len = o_cap + n * 4, o_end = (o_len + n * 4 + 15) & ~(size_t)15, bytes = o_end + n * sizeof(lep_huff_end);
+        if (int rc = ensure(g, &g->d_huffseq[turn], &g->huffseq_bytes[turn], bytes)) return rc;
+        char* b = (char*)g->d_huffseq[turn];
+        if (int rc = upload(g, b, seq_which.data(), n * 4, st)) return rc;
+        if (int rc = upload(g, b + o_cap, seq_cap.data(), n * 4, st)) return rc;
+        if (int rc = lep_gpu_huffman_encode_device(g, seq_img.data(), (int)n, seq_seg.data(), (int)n, d_out, (uint32_t*)(b + o_len), (lep_huff_end*)(b + o_end), st)) return rc;
+        hipLaunchKernelGGL(lep_huffprog_seq_lens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)b, (const uint32_t*)(b + o_cap), (const uint32_t*)(b + o_len),
+                           (const lephuff::HuffEnd*)(b + o_end), (int)n, d_out_len);
+        if ((int)n == nscan) { HIPCHK(g, hipGetLastError()); return 0; }
+    }
     if (g->huffprog_simt) {
         // scans grouped by image (a region of bit buffers per image): the caller lists them file by file, but nothing here relies on it
         std::vector<int> order((size_t)nscan);
@@ -1349,7 +1411,7 @@ int lep_gpu_huffman_progressive_encode_device(lep_gpu* g, const lep_huffprog_ima
         hipLaunchKernelGGL((lep_huffprog_simt_units_kernel<true>), dim3((unsigned)waves.size()), dim3(64), 0, st, di, ds, (const lephuff::ProgSimtScan*)dps, dwv, dun, nunits, dsc);
         hipLaunchKernelGGL(lep_huffprog_simt_stuff_kernel, dim3((unsigned)ps.size()), dim3(64), 0, st, di, ds, (const lephuff::ProgSimtScan*)dps, dsc, d_out, d_out_len);
     }
-    if ((int)ps.size() < nscan)
+    if (ps.size() + seq_seg.size() < (size_t)nscan)
         hipLaunchKernelGGL(lep_huffman_progressive_encode_kernel, dim3(nscan), dim3(64), 0, st, di, ds, d_out, d_corr, d_out_len);
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipEventRecord(g->ev1, st));

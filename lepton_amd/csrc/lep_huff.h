@@ -26,7 +26,8 @@ struct HuffImage {          // one image, device-visible
     int32_t ncomp, mcuh, mcuv, mcuc;
     int32_t rsti, padbit;
     uint32_t rst_limit;     // RST markers allowed in the scan (0xffffffff = no limit)
-    int32_t interleaved;    // 1: MCU-interleaved scan of all components; 0: one component, hs = vs = 1, no padding blocks
+    int32_t interleaved;    // 1: a scan of MCUs of hs x vs blocks per component (a one-component file: mcuh x mcuv = its nch x ncv blocks, hs = vs = 1,
+                            // block rows bch apart -- recode_prepare); 0: one component, block `mcu` of a frame without padding blocks (older callers)
     int32_t hs[4], vs[4], bch[4];
     int32_t dc_tbl[4], ac_tbl[4];
     int32_t scan_cmp[4];    // component order inside the MCU

@@ -19,8 +19,9 @@
 // bits and the two marker bytes to its own bits, a unit an interval starts with begins from zero predictors; pass 2 adds those bits
 // to the prefix sum (an interval starts on a byte, so its pad is its own bit count's), and a bit per buffer byte tells pass 4 which
 // FFs are markers and take no 00 (recoder.cc:364-400).
-// Segments of non-interleaved scans and of images whose scan ends inside its last MCU row keep lep_huff.h's kernel (HuffSegment.pad
-// bit 0 says which kernel owns a segment).  Same bytes, same end states as that kernel
+// One-component files (never interleaved, whatever their sampling factors) come as frames of nch x ncv MCUs of one block with block rows
+// bch apart (recode_prepare, jpeg_recode.cc) and are coded like any other; images whose scan ends inside its last MCU row keep
+// lep_huff.h's kernel (HuffSegment.pad bit 0 says which kernel owns a segment).  Same bytes, same end states as that kernel
 // (tests/emu, GPU parity tests); recoder.cc:245-412 is what both restate.
 #pragma once
 #include "lep_huff.h"
@@ -41,6 +42,7 @@ struct SimtEncSeg {         // per segment handled here
     uint32_t cut;           // pass 2: a unit met the cut of a truncated file: the stream ends in front of it
     uint32_t map_bytes;     // restart intervals: bytes of the marker map behind the bit buffer (bit q = byte q of the buffer is a marker's FF); else 0
 };
+constexpr uint32_t kTailNotOwn = 0x100u;        // pass 3, in SimtEncSeg::tail: the last unit's accumulator does not hold all of the partial byte
 constexpr uint32_t kUnitMetCut = 0x80000000u;   // pass 1, in a unit's bit count
 constexpr uint32_t kUnitDead = 0xffffffffu;     // pass 2, in place of a unit's position: it lies behind the cut
 struct SimtEncWave { uint32_t eseg, first_unit; };   // lane l = unit first_unit + l of SimtEncSeg eseg
@@ -286,7 +288,13 @@ WDEV void simt_enc_units(const HuffImage* images, const HuffSegment* segs, SimtE
                 // the partial byte that belong to the unit in front are not in it.  A kHuffEndCut end state's overhang is therefore NOT
                 // defined; nobody compares it: a cut end state is only taken for the last thread with its byte bound reached, lep_huff.h
                 // kHuffEndCut.  ADVICE round 5.)
-                else if (u + 1 == es.nunits || met_cut) esp->tail = d.sink.tail_byte();
+                else if (u + 1 == es.nunits || met_cut) {
+                    // ... and of a stream's last partial byte the bits in FRONT of this unit's first are not in its accumulator either:
+                    // a last unit that put fewer bits than the byte holds (one block of a one-component scan can code to two) says so,
+                    // and the stuffing pass takes the byte from the bit buffer instead
+                    const uint32_t put = d.sink.bitpos() - at;
+                    esp->tail = d.sink.tail_byte() | (put < (d.sink.bitpos() & 7u) ? kTailNotOwn : 0u);
+                }
             }
         }
     }
@@ -426,6 +434,11 @@ WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const
             e.attempted = written;
             e.num_overhang_bits = (uint8_t)rem;
             e.overhang_byte = (uint8_t)(rem ? es.tail : 0u);
+            bool tail_lost = false;
+            if (rem && (es.tail & kTailNotOwn)) {        // the partial byte as the buffer holds it -- if the buffer kept the stream's end
+                if (es.total_bits <= room) e.overhang_byte = (uint8_t)((buf[es.total_bits >> 5] >> (24u - (es.total_bits & 24u))) & (0xff00u >> rem) & 0xffu);
+                else tail_lost = true;
+            }
             // (lep_huff.h's writer zeroes all four predictors at every restart marker position, the unused fourth too)
             const int m_begin = seg.mcu_row0 * img->mcuh, m_end = seg.mcu_row1 * img->mcuh;
             const int last_end = img->rsti > 0 ? ((m_end < img->mcuc ? m_end : img->mcuc - 1) / img->rsti) * img->rsti : 0;   // the last interval end in (m_begin, m_end]
@@ -440,7 +453,7 @@ WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const
                     e.last_dc[cmp & 3] = img->blocks[cmp][(int64_t)((row * vs + vs - 1) * img->bch[cmp] + mx * hs + hs - 1) * 64 + kZ2A_const(0)];
                 }
             }
-            e.pad = es.cut ? kHuffEndCut : (uint16_t)0;
+            e.pad = es.cut ? kHuffEndCut : (tail_lost ? kHuffEndRefused : (uint16_t)0);
             ends[es.seg] = e;
         }
     }
@@ -449,7 +462,7 @@ WDEV void simt_enc_stuff(const HuffImage* images, const HuffSegment* segs, const
 // which segments this form takes
 inline bool simt_enc_takes(const HuffImage& img, const HuffSegment& seg) {
     return (img.rsti == 0 || (img.rsti > 0 && !(img.trunc_bc[0] | img.trunc_bc[1] | img.trunc_bc[2] | img.trunc_bc[3]))) && img.interleaved == 1 && img.mcuc == img.mcuh * img.mcuv && seg.mcu_row0 >= 0 && seg.mcu_row1 > seg.mcu_row0 && seg.mcu_row1 <= img.mcuv &&
-           ((seg.overhang >> 8) & 255u) < 8u && img.ncomp >= 2;     // (two blocks per MCU at least: a unit's last byte is its own)
+           ((seg.overhang >> 8) & 255u) < 8u;
 }
 
 }  // namespace lephuff

@@ -44,6 +44,33 @@ struct ProgScan {
     uint32_t code[2][256];      // length << 16 | code
 };
 
+// SEQUENTIAL frames coded in several scans (the reference's recode_jpeg codes them with encode_block_seq under the general scan walk,
+// jpgcoder.cc:3461-3486, 3560-3580; format flag 'X' like progressive files): a scan with from 0 / to 63 -- which no progressive scan has --
+// whose components all use ONE DC table (code[0]) and ONE AC table (code[1]).  They are written by the sequential scan encoders
+// (lep_huff_simt.h, lep_huff.h) as an image of their own with one segment: the scan's components only, and for a scan of one component
+// (never interleaved: MCU = one block, the frame's padding blocks stepped over) that component's nch x ncv blocks as MCUs, as
+// recode_prepare plans a one-component file.
+constexpr uint32_t kProgScanSeq = 2;        // ProgScan::pad on the device: the sequential scan encoders own the scan
+inline bool prog_is_sequential(const ProgScan& s) { return s.from == 0 && s.to == 63; }
+inline void sequential_scan_segment(const ProgImage& im, const ProgScan& sc, int32_t image_index, HuffImage* hi, HuffSegment* hs) {
+    memset(hi, 0, sizeof *hi);
+    memset(hs, 0, sizeof *hs);
+    hi->ncomp = sc.cmpc; hi->mcuh = im.mcuh; hi->mcuv = im.mcuv; hi->mcuc = im.mcuc; hi->rsti = im.rsti; hi->padbit = im.padbit;
+    hi->rst_limit = 0xffffffffu;
+    hi->interleaved = 1;
+    for (int c = 0; c < 4; ++c) { hi->hs[c] = im.hs[c]; hi->vs[c] = im.vs[c]; hi->bch[c] = im.bch[c]; hi->blocks[c] = im.blocks[c]; }
+    for (int i = 0; i < 4; ++i) hi->scan_cmp[i] = i < sc.cmpc ? (sc.cmp[i] & 3) : 0;
+    if (sc.cmpc == 1) {
+        const int c = sc.cmp[0] & 3;
+        hi->mcuh = im.nch[c]; hi->mcuv = im.ncv[c]; hi->mcuc = im.nch[c] * im.ncv[c];
+        hi->hs[c] = 1; hi->vs[c] = 1;
+    }
+    memcpy(hi->code[0], sc.code[0], sizeof hi->code[0]);
+    memcpy(hi->code[2], sc.code[1], sizeof hi->code[2]);
+    hs->image = image_index; hs->mcu_row0 = 0; hs->mcu_row1 = hi->mcuv;
+    hs->out_off = sc.out_off; hs->out_cap = sc.out_cap;
+}
+
 struct ProgShared {
     HuffShared h;
     int32_t vals[64];

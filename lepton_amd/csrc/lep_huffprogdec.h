@@ -36,6 +36,44 @@ struct ProgDecScan {
     uint64_t result_off;    // this scan's final record {bit position, last DC, pad bits | status << 8} in the rows arena
 };
 
+// SEQUENTIAL frames coded in several scans (luma alone, then Cb + Cr together, ...; the reference decodes them with its sequential block
+// loop under the general scan walk, jpgcoder.cc:3034-3175, and keeps the file's format flag 'X'): their scans come through the same
+// descriptors -- from 0, to 63, which no progressive scan has -- with t holding the FRAME (all components, lut[0..1] DC tables 0 / 1,
+// lut[2..3] AC tables 0 / 1, dc_tbl / ac_tbl per component) and are decoded by the sequential kernels (lep_huffdec_simt.h, lep_huffdec.h)
+// from the image sequential_scan_image makes of them: the scan's components only, and for a scan of ONE component -- never interleaved:
+// MCU = one block, the frame's padding blocks stepped over -- that component's nch x ncv blocks as MCUs (as parse_jpeg_prepare_gpu plans a
+// one-component file).  rows_off: a record per MCU row of THAT geometry and the final one, which is result_off.
+inline bool progdec_is_sequential(const ProgDecScan& s) { return s.from == 0 && s.to == 63; }
+inline HuffDecImage sequential_scan_image(const ProgDecScan& s) {
+    HuffDecImage im = s.t;
+    im.ncomp = s.cmpc;
+    for (int i = 0; i < 4; ++i) im.scan_cmp[i] = i < s.cmpc ? (s.cmp[i] & 3) : 0;
+    if (s.cmpc == 1) {
+        const int c = s.cmp[0] & 3;
+        im.mcuh = s.nch[c]; im.mcuv = s.ncv[c]; im.mcuc = s.nch[c] * s.ncv[c];
+        im.hs[c] = 1; im.vs[c] = 1;
+    }
+    im.flags = 0;
+    return im;
+}
+
+// Whether the lane-per-subsequence decoder (lep_huffdec_simt.h) is the one to send such a scan to.  Its lanes fall into step with the BLOCK
+// boundaries by decoding, and with the position inside the MCU only because a block decoded with another component's tables soon stops
+// making sense: when every block of the MCU uses the same two tables (Cb + Cr together, as most encoders write them) nothing in the bits
+// says which is which, the true position travels one lane per settle pass, and the scan would end up with the single-wave kernel after
+// three wasted passes.  Restart intervals come without the table of marker positions here.
+inline bool sequential_scan_for_lanes(const HuffDecImage& im) {
+    if (im.rsti) return false;
+    int nphase = 0;
+    bool same = true;
+    for (int ci = 0; ci < im.ncomp && ci < 4; ++ci) {
+        const int c = im.scan_cmp[ci] & 3, c0 = im.scan_cmp[0] & 3;
+        nphase += im.hs[c] * im.vs[c];
+        same = same && im.dc_tbl[c] == im.dc_tbl[c0] && im.ac_tbl[c] == im.ac_tbl[c0];
+    }
+    return nphase == 1 || !same;
+}
+
 // Pipelining between the scans of one image (one launch for all dependency levels).  A 4K file of libjpeg's default script is
 // ten scans in three levels, and the longest scan of every level is a luma scan (bytes: 276 k first stage, 348 k and 654 k
 // refinement): level by level a file waits for their SUM.  Refinement scans cannot be cut into subsequences the way sequential

@@ -186,9 +186,28 @@ extern "C" int emu_huffman_encode_segment_simt(const lep_huff_image* img, const 
 
 // progressive scans (lep_huffprog.h): every scan of one image, one emulated wavefront after the other
 #include "../../lepton_amd/csrc/lep_huffprog.h"
+// (a scan of a SEQUENTIAL frame coded in several scans goes where the launch code sends it: to the sequential scan encoders, as an image with
+// one segment -- lep_huffprog.h sequential_scan_segment, lep_gpu.hip lep_gpu_huffman_progressive_encode_device)
+static uint32_t emu_sequential_scan(const lephuff::ProgImage* im, const lephuff::ProgScan& sc, uint8_t* out, bool lanes) {
+    lephuff::HuffImage hi;
+    lephuff::HuffSegment sg;
+    lephuff::sequential_scan_segment(*im, sc, 0, &hi, &sg);
+    uint32_t n = 0;
+    lep_huff_end end;
+    memset(&end, 0, sizeof end);
+    int rc = 1;
+    if (lanes) rc = emu_huffman_encode_segment_simt(reinterpret_cast<const lep_huff_image*>(&hi), reinterpret_cast<const lep_huff_segment*>(&sg), out + sc.out_off, &n, &end);
+    if (rc == 1) emu_huffman_encode_segment(reinterpret_cast<const lep_huff_image*>(&hi), reinterpret_cast<const lep_huff_segment*>(&sg), out + sc.out_off, &n, &end);
+    const bool over = end.attempted > sc.out_cap || (end.pad & (lephuff::kHuffEndCut | lephuff::kHuffEndRefused)) != 0;
+    return n | (over ? 0x80000000u : 0u);
+}
 extern "C" int emu_huffman_progressive_encode(const lep_huffprog_image* img, const lep_huffprog_scan* scans, int nscan, uint8_t* out, uint32_t* corr, uint32_t* out_len) {
     static lephuff::ProgShared sh;
     for (int i = 0; i < nscan; ++i) {
+        if (lephuff::prog_is_sequential(*reinterpret_cast<const lephuff::ProgScan*>(scans + i))) {
+            out_len[i] = emu_sequential_scan(reinterpret_cast<const lephuff::ProgImage*>(img), *reinterpret_cast<const lephuff::ProgScan*>(scans + i), out, false);
+            continue;
+        }
         lephuff::ProgWave w;
         out_len[i] = w.run_scan(reinterpret_cast<const lephuff::ProgImage*>(img), reinterpret_cast<const lephuff::ProgScan*>(scans + i), &sh, out, corr);
     }
@@ -212,6 +231,7 @@ extern "C" int emu_huffman_progressive_encode_simt(const lep_huffprog_image* img
     for (int i = 0; i < nscan; ++i) {
         bound = std::max<uint64_t>(bound, sv[(size_t)i].pad);   // (lep_huffprog_scan.file_bound)
         sv[(size_t)i].pad = 0; sv[(size_t)i].image = 0; taken[i] = 0;
+        if (lephuff::prog_is_sequential(sv[(size_t)i])) { out_len[i] = emu_sequential_scan(im, sv[(size_t)i], out, true); taken[i] = 1; continue; }
         uint32_t nb = 0, nu = 0;
         if (!lephuff::prog_simt_takes(*im, sv[(size_t)i], &nb, &nu)) continue;
         lephuff::ProgSimtScan e;
@@ -257,10 +277,16 @@ extern "C" int emu_huffman_decode_image(const lep_huffdec_image* img, lep_huffde
 
 // progressive scan decoder (lep_huffprogdec.h): the scans of one image, level by level, one emulated wavefront after the other
 #include "../../lepton_amd/csrc/lep_huffprogdec.h"
+// (a scan of a SEQUENTIAL frame coded in several scans goes where the launch code sends it: to the sequential scan decoders, as an image of
+// its own -- lep_huffprogdec.h sequential_scan_image, lep_gpu.hip lep_gpu_huffman_progressive_decode_device; defined at the end of the file)
+static void emu_sequential_scan_decode(const lephuff::ProgDecScan& sc, lephuff::HuffDecRow* rows, bool lanes);
 extern "C" int emu_huffman_progressive_decode(const lep_huffprogdec_scan* scans, int nscan, lep_huffdec_row* rows) {
     static lephuff::HuffDecShared sh;
     for (int lv = 0; lv < 64; ++lv)
         for (int i = 0; i < nscan; ++i)
+            if (scans[i].level == lv && lephuff::progdec_is_sequential(*reinterpret_cast<const lephuff::ProgDecScan*>(scans + i)))
+                emu_sequential_scan_decode(*reinterpret_cast<const lephuff::ProgDecScan*>(scans + i), reinterpret_cast<lephuff::HuffDecRow*>(rows), false);
+            else
             if (scans[i].level == lv) { lephuff::ProgDecWave w; w.run_scan(reinterpret_cast<const lephuff::ProgDecScan*>(scans + i), &sh, reinterpret_cast<lephuff::HuffDecRow*>(rows)); }
     return 0;
 }
@@ -286,6 +312,7 @@ extern "C" int emu_huffman_progressive_decode_pipelined(const lep_huffprogdec_sc
             if (j >= k) return -3;                                  // a scan may only follow scans in front of it in the launch
             deps_out[order[(size_t)k] * 4 + d] = j < 0 ? -1 : order[(size_t)j];
         }
+        if (lephuff::progdec_is_sequential(sorted[(size_t)k])) { emu_sequential_scan_decode(sorted[(size_t)k], reinterpret_cast<lephuff::HuffDecRow*>(rows), false); progress[(size_t)k] = 0x7fffffffu; continue; }
         lephuff::ProgDecWave w;
         w.run_scan<true>(&sorted[(size_t)k], &sh, reinterpret_cast<lephuff::HuffDecRow*>(rows), &deps[(size_t)k], progress.data(), k);
         if (progress[(size_t)k] != 0x7fffffffu) return -4;          // every scan says when it is done, whatever happened to it
@@ -312,9 +339,10 @@ extern "C" int emu_huffman_progressive_decode_win(const lep_huffprogdec_scan* sc
     std::vector<uint32_t> progress((size_t)nscan, 0u);
     *taken = 0;
     for (int k = 0; k < nscan; ++k) {
+        lephuff::HuffDecRow* r = reinterpret_cast<lephuff::HuffDecRow*>(rows);
+        if (lephuff::progdec_is_sequential(sorted[(size_t)k])) { emu_sequential_scan_decode(sorted[(size_t)k], r, true); progress[(size_t)k] = 0x7fffffffu; continue; }
         const bool win = lephuff::prog_win_takes(sorted[(size_t)k]);
         *taken += win;
-        lephuff::HuffDecRow* r = reinterpret_cast<lephuff::HuffDecRow*>(rows);
         if (win) {
             lephuff::ProgWinWave w;
             if (pipelined) w.run_scan_win<true>(&sorted[(size_t)k], &ws, r, &deps[(size_t)k], progress.data(), k);
@@ -611,4 +639,20 @@ extern "C" int emu_prog_scan_deps(const lep_huffprogdec_scan* scans, const int* 
     const bool ok = lephuff::prog_scan_deps(reinterpret_cast<const lephuff::ProgDecScan*>(scans), order, n, deps.data());
     for (int i = 0; i < n; ++i) for (int d = 0; d < 4; ++d) deps_out[4 * i + d] = deps[(size_t)i].dep[d];
     return ok ? 1 : 0;
+}
+
+static void emu_sequential_scan_decode(const lephuff::ProgDecScan& sc, lephuff::HuffDecRow* rows, bool lanes) {
+    const lephuff::HuffDecImage im = lephuff::sequential_scan_image(sc);
+    lep_huffdec_row* at = reinterpret_cast<lep_huffdec_row*>(rows + im.rows_off);
+    if (lanes && lephuff::sequential_scan_for_lanes(im)) {
+        int32_t moved[lephuff::kSimtSettle + 1];
+        uint32_t nsub = 0;
+        // (subsequences as the launch code cuts them: 8192 bits, or 64 of the scan's average block if that is more)
+        uint64_t nblocks = 0;
+        for (int ci = 0; ci < im.ncomp && ci < 4; ++ci) { const int cmp = im.scan_cmp[ci] & 3; nblocks += (uint64_t)im.hs[cmp] * im.vs[cmp]; }
+        nblocks *= (uint64_t)std::max(im.mcuc, 1);
+        const uint64_t b = (uint64_t)im.scan_len * 8u;
+        const uint32_t sub_bits = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(8192, (64 * b / std::max<uint64_t>(nblocks, 1) + 31) & ~(uint64_t)31), 1u << 24);
+        emu_huffman_decode_image_simt(reinterpret_cast<const lep_huffdec_image*>(&im), at, sub_bits, moved, &nsub);
+    } else emu_huffman_decode_image(reinterpret_cast<const lep_huffdec_image*>(&im), at);
 }

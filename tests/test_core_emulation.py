@@ -1040,6 +1040,58 @@ def _same_as_the_host_parser(jpg, h, planes):
     assert got == host.write_lep(fake), "container (hand-offs / pad bit / restart counts) differs from the host parser's"
 
 
+SEQUENTIAL_SCAN_SCRIPTS = {            # (components: id, h, v, quantisation table, DC table, AC table; scans: component indices)
+    "y_cbcr_420": ([(1, 2, 2, 0, 0, 0), (2, 1, 1, 1, 1, 1), (3, 1, 1, 1, 1, 1)], [[0], [1, 2]]),
+    "y_cb_cr_444": ([(1, 1, 1, 0, 0, 0), (2, 1, 1, 1, 1, 1), (3, 1, 1, 1, 1, 1)], [[0], [1], [2]]),
+    "ycb_cr_422": ([(1, 2, 1, 0, 0, 0), (2, 1, 1, 1, 1, 1), (3, 1, 1, 1, 1, 1)], [[0, 1], [2]]),
+    "cbcr_y_420": ([(1, 2, 2, 0, 0, 0), (2, 1, 1, 1, 1, 1), (3, 1, 1, 1, 1, 1)], [[1, 2], [0]]),
+    "cr_cb_y_440": ([(1, 1, 2, 0, 0, 0), (2, 1, 1, 1, 1, 1), (3, 1, 1, 1, 1, 1)], [[2], [1], [0]]),
+    "y_cbcr_mixed": ([(1, 2, 2, 0, 0, 0), (2, 2, 1, 1, 1, 1), (3, 1, 2, 1, 1, 1)], [[0], [1, 2]]),
+    "two_y_c": ([(1, 2, 1, 0, 0, 0), (2, 1, 1, 1, 1, 1)], [[0], [1]]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SEQUENTIAL_SCAN_SCRIPTS))
+def test_sequential_frames_in_several_scans_on_the_scan_kernels(emu, name):
+    """SEQUENTIAL frames coded in several scans (luma alone, then Cb + Cr together; a scan per component; any order): format 'X' like
+    progressive files, decoded and written by the reference with its sequential block loop under the general scan walk.  Their scans
+    come through the progressive descriptors (from 0 / to 63) and go to the SEQUENTIAL kernels, each scan an image of its own
+    (VERDICT round 5 next #6): the scan decoders -- single wave, one lane per subsequence -- must leave the host parser's frame and a
+    container that is the host parser's byte for byte (a hand-off record per MCU row of every scan of several components or of
+    component 0, one per other scan); the scan encoders -- single wave, one lane per unit -- must write every scan as the host re-coder
+    does.  Widths and heights with and without padding blocks, restart intervals (which count BLOCKS in a one-component scan)."""
+    import jpeg_writer as jw
+    import numpy as np
+    import zlib
+    from lepton_amd import abi
+
+    L = abi.lib()
+    comps, scans = SEQUENTIAL_SCAN_SCRIPTS[name]
+    shared_tables = all(len({comps[c][4] for c in sc}) == 1 and len({comps[c][5] for c in sc}) == 1 for sc in scans)
+    for w, h, ri, dens in [(97, 50, 0, 0.3), (96, 64, 5, 0.3), (640, 480, 0, 0.6), (333, 250, 7, 0.2), (8, 8, 0, 0.5), (17, 9, 1, 0.5), (1300, 40, 0, 0.02)]:
+        jpg, _ = jw.write_sequential_scans(w, h, comps, np.random.default_rng(zlib.crc32(("%s %d %d" % (name, w, h)).encode())), scans, restart_interval=ri, density=dens)
+        host = JpegImage(jpg)
+        lep = host.write_lep(ob.oracle_encode(host.desc, host.plan())[0])
+        assert lep[3:4] == b"X"
+        for kw in (dict(), dict(pipelined=True), dict(win=True), dict(win=True, pipelined=True)):
+            hnd, planes, status = _progressive_decode_on_the_emulation(emu, jpg, **kw)
+            assert status == 0, (name, w, h, ri, kw, status)
+            _same_as_the_host_parser(jpg, hnd, planes)
+            L.lep_jpeg_close(hnd)
+        for simt in (False, True):
+            got, f = _progressive_scans_on_the_emulation(emu, jpg, lep, simt=simt)
+            if not shared_tables:
+                assert got is None, "a scan whose components use different tables is the host re-coder's"
+                continue
+            assert got is not None, (name, w, h, ri, "not planned for the GPU scan encoders")
+            assert got == jpg, (name, w, h, ri, simt)
+        if shared_tables:
+            res = _progressive_check_on_the_emulation(emu, jpg)
+            assert res is not None
+            for length, got, want in res:
+                assert length == len(want) and got == want
+
+
 def test_progressive_scans_follow_the_right_scans(emu):
     """lep_huffprogdec.h prog_scan_deps: in the one pipelined launch a scan waits for exactly the scans of its file whose
     coefficients it reads or overwrites -- same component, bands that meet, earlier in the file -- minus those another of them

@@ -162,10 +162,158 @@ def test_layout_through_the_kernel_sources(emu, name):
             assert emu.emu_decode_segment_v4(C.byref(d), s.luma_y_start, s.luma_y_end, s.is_last, wv, len(wv), None) == 0
         assert [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)] == orig, (name, w, h)
         kind, planes = gpu_scan_decode(emu, jpg)
-        assert kind in ("ok", "host")
-        if len(LAYOUTS[name]) > 1:
-            assert kind == "ok", "an interleaved sequential scan must be eligible for the GPU decoder"
-            assert planes == orig, (name, w, h)
+        assert kind == "ok", "a single sequential scan of all components must be eligible for the GPU decoder"
+        assert planes == orig, (name, w, h)
+
+
+@pytest.mark.parametrize("name", ["gray22", "gray21", "gray12", "gray11"])
+def test_one_component_scans_on_the_gpu_scan_decoders(emu, name):
+    """A file of ONE component is never interleaved, whatever its sampling factors: the scan walks the nch x ncv blocks of the picture and
+    steps over the blocks that pad the frame to whole MCUs (next_mcuposn, jpgcoder.cc).  The kernels see it as nch x ncv MCUs of one block
+    with block rows bch apart (parse_jpeg_prepare_gpu) and parse_jpeg_finish_gpu picks the hand-off of every MCU row out of the records per
+    block row: single-wave and lane-per-subsequence kernels in the emulation must leave the host parser's frame,
+    and the container written from the GPU-side parse must be the host's, byte for byte -- widths and heights with and without padding
+    blocks, one block row, one block."""
+    L = abi.lib()
+    comps = LAYOUTS.get(name) or {"gray12": [Y(1, 2)], "gray11": [Y(1, 1)]}[name]
+    sizes = [(97, 50), (33, 70), (8, 8), (9, 9), (16, 16), (17, 33), (200, 333), (1, 1), (640, 40), (24, 481)]
+    for w, h in sizes:
+        jpg, _ = jw.write_baseline(w, h, comps, np.random.default_rng(zlib.crc32(("one %s %d %d" % (name, w, h)).encode())), density=0.5)
+        host = JpegImage(jpg)
+        d = host.desc
+        orig = [C.string_at(d.blocks[c], d.nblocks(c) * 128) for c in range(d.ncomp)]
+        want = host.write_lep(ob.oracle_encode(d, host.plan())[0])
+        for kernel in ("wave", "lanes"):
+            hnd, img, ok = C.c_void_p(), abi.HuffDecImage(), C.c_int(0)
+            assert L.lep_jpeg_open_gpu(jpg, len(jpg), C.byref(hnd), C.byref(img), C.byref(ok)) == 0
+            assert ok.value, "%s %dx%d: not planned for the GPU scan decoder" % (name, w, h)
+            k = JpegImage(jpg)
+            assert img.ncomp == 1 and img.hs[0] == 1 and img.vs[0] == 1 and img.mcuc == img.mcuh * img.mcuv
+            p, n = C.c_void_p(), C.c_size_t(0)
+            L.lep_jpeg_scan_bytes(hnd, C.byref(p), C.byref(n))
+            scan = C.create_string_buffer(C.string_at(p, n.value) + bytes(80), n.value + 80)
+            img.scan = C.addressof(scan)
+            plane = C.create_string_buffer(d.nblocks(0) * 128)
+            img.blocks[0] = C.cast(plane, C.c_void_p).value
+            rows = (abi.HuffDecRow * (img.mcuv + 1))()
+            if kernel == "wave":
+                assert emu.emu_huffman_decode_image(C.byref(img), rows) == 0
+            else:
+                moved, nsub = (C.c_int32 * 8)(), C.c_uint32(0)
+                assert emu.emu_huffman_decode_image_simt(C.byref(img), rows, 256, moved, C.byref(nsub)) == 0
+            assert rows[img.mcuv].aux >> 8 == 0, (name, w, h, kernel)
+            assert plane.raw == orig[0], (name, w, h, kernel)
+            assert L.lep_jpeg_finish_gpu(hnd, rows) == 0
+            streams = ob.oracle_encode(d, host.plan())[0]
+            arr = (abi.Bytes * len(streams))()
+            keep = []
+            for i, st in enumerate(streams):
+                b = C.create_string_buffer(bytes(st), max(1, len(st)))
+                keep.append(b)
+                arr[i].data = C.cast(b, C.c_void_p).value
+                arr[i].len = arr[i].cap = len(st)
+            out = abi.Bytes()
+            assert L.lep_jpeg_write_lep(hnd, 0, arr, len(streams), C.byref(out)) == 0
+            got = out.tobytes()
+            L.lep_free(out.data)
+            L.lep_jpeg_close(hnd)
+            assert got == want, (name, w, h, kernel)
+            del k
+
+
+@pytest.mark.parametrize("name", ["gray22", "gray21", "gray12", "gray11"])
+def test_one_component_scans_on_the_gpu_scan_encoders(emu, name):
+    """... and the way back: recode_prepare plans a one-component file as nch x ncv MCUs of one block with its thread segments in block
+    rows; the wavefront kernel (lep_huff.h) and the lane-per-unit kernels (lep_huff_simt.h -- a unit of a one-component scan can be ONE
+    block of two or three bits, so a segment's last partial byte may hold bits of the unit in front: kTailNotOwn) must both write the
+    file's scan bytes segment by segment, with the end states the next hand-off recorded; several thread segments, widths and heights
+    with and without padding blocks, plain grey with restart intervals."""
+    L = abi.lib()
+    comps = LAYOUTS.get(name) or {"gray12": [Y(1, 2)], "gray11": [Y(1, 1)]}[name]
+    cases = [(97, 50, 0, 0.5, 40), (9, 9, 0, 0.5, 40), (1, 1, 0, 0.5, 40), (24, 481, 0, 0.02, 2), (1203, 897, 0, 1.0, 200), (3001, 2999, 0, 0.01, 1), (8, 30000, 0, 1.0, 200), (3000, 24, 0, 1.0, 200), (1500, 1100, 0, 0.3, 60)]
+    if name == "gray11":
+        cases += [(1203, 897, 7, 1.0, 200), (1203, 897, 1, 0.3, 100), (640, 480, 80, 1.0, 200), (97, 50, 3, 0.5, 40)]
+    several = 0
+    for w, h, ri, dens, amp in cases:
+        jpg, _ = jw.write_baseline(w, h, comps, np.random.default_rng(zlib.crc32(("back %s %d %d" % (name, w, h)).encode())), density=dens, amp=amp, restart_interval=ri)
+        _, lep = oracle_compress(jpg)
+        f = LepFile(lep)
+        src = JpegImage(jpg)
+        C.memmove(f.desc.blocks[0], src.desc.blocks[0], f.desc.nblocks(0) * 128)
+        assert f.recode() == jpg
+        img = abi.HuffImage()
+        segs = (abi.HuffSegment * abi.MAX_SEGMENTS)()
+        nseg, ok = C.c_int(0), C.c_int(0)
+        assert L.lep_file_recode_plan(f.handle, C.byref(img), segs, C.byref(nseg), C.byref(ok)) == 0
+        assert ok.value, "%s %dx%d: not planned for the GPU scan encoder" % (name, w, h)
+        assert img.interleaved == 1 and img.hs[0] == 1 and img.vs[0] == 1 and img.mcuc == img.mcuh * img.mcuv
+        several += nseg.value > 1
+        for fn in (emu.emu_huffman_encode_segment, emu.emu_huffman_encode_segment_simt):
+            outs = (abi.Bytes * nseg.value)()
+            ends = (abi.HuffEnd * nseg.value)()
+            keep = []
+            for i in range(nseg.value):
+                cap = min(segs[i].out_cap, len(jpg) + 1024)
+                segs[i].out_cap = cap
+                buf = C.create_string_buffer(cap + 8)
+                keep.append(buf)
+                n = C.c_uint32(0)
+                assert fn(C.byref(img), C.byref(segs[i]), buf, C.byref(n), C.byref(ends[i])) == 0, (name, w, h, i, "the kernel left the segment to the other one")
+                outs[i].data = C.cast(buf, C.c_void_p).value
+                outs[i].len = outs[i].cap = n.value
+            out = abi.Bytes()
+            assert L.lep_file_recode_finish(f.handle, outs, ends, nseg.value, C.byref(out)) == 0, (name, w, h, fn)
+            got = out.tobytes()
+            L.lep_free(out.data)
+            assert got == jpg, (name, w, h, fn)
+    assert several >= 3
+
+
+def test_lane_per_unit_encoder_when_the_last_unit_is_one_tiny_block(emu):
+    """A segment of a one-component scan whose MCU count is 1 modulo 8 ends in a unit of ONE block -- two to six bits in a sparse file,
+    fewer than the stream's last partial byte may hold: every (first row, last row, partial byte carried in) of a nine-block-wide frame,
+    lane-per-unit kernels against the wavefront kernel: bytes, byte count, end state."""
+    L = abi.lib()
+    tiny = seen = 0
+    for seed, dens in [(1, 0.0), (2, 0.01), (3, 0.05)]:
+        # (the chroma tables: a block of zeros with an unchanged DC codes to FOUR bits; every twentieth block moves the DC, a few have one AC coefficient)
+        rng0 = np.random.default_rng(seed)
+        blocks = np.zeros((12, 9, 64), dtype=np.int32)
+        blocks[:, :, 0] = np.cumsum(rng0.integers(-2, 3, (12, 9)) * (rng0.random((12, 9)) < 0.05), axis=None).reshape(12, 9)
+        blocks[:, :, 1] = rng0.integers(-1, 2, (12, 9)) * (rng0.random((12, 9)) < dens)
+        blocks[:, 7, 63] = 1       # ... and the block in front of a row's last ends in a ONE (its last coefficient's value bit, no end-of-block code)
+        jpg, _ = jw.write_baseline(70, 96, [(1, 1, 1, 0, 1, 1)], rng0, blocks=[blocks])
+        _, lep = oracle_compress(jpg)
+        f = LepFile(lep)
+        src = JpegImage(jpg)
+        C.memmove(f.desc.blocks[0], src.desc.blocks[0], f.desc.nblocks(0) * 128)
+        img = abi.HuffImage()
+        segs = (abi.HuffSegment * abi.MAX_SEGMENTS)()
+        nseg, ok = C.c_int(0), C.c_int(0)
+        assert L.lep_file_recode_plan(f.handle, C.byref(img), segs, C.byref(nseg), C.byref(ok)) == 0 and ok.value
+        assert img.mcuh == 9 and img.mcuv == 12
+        rng = np.random.default_rng(seed)
+        for r0 in range(12):
+            for r1 in range(r0 + 1, 13):
+                for _ in range(3):
+                    sg = abi.HuffSegment()
+                    C.memmove(C.byref(sg), C.byref(segs[0]), C.sizeof(sg))
+                    nb = int(rng.integers(0, 8))
+                    sg.mcu_row0, sg.mcu_row1, sg.out_cap = r0, r1, 4096
+                    sg.overhang = (int(rng.integers(0, 256)) & (0xff00 >> nb) & 0xff) | (nb << 8)
+                    for c in range(4):
+                        sg.last_dc[c] = int(rng.integers(-3, 4))
+                    outs = []
+                    for fn in (emu.emu_huffman_encode_segment, emu.emu_huffman_encode_segment_simt):
+                        buf = C.create_string_buffer(4096 + 8)
+                        n = C.c_uint32(0)
+                        end = abi.HuffEnd()
+                        assert fn(C.byref(img), C.byref(sg), buf, C.byref(n), C.byref(end)) == 0
+                        outs.append((n.value, buf.raw[: n.value], end.attempted, end.overhang_byte, end.num_overhang_bits, list(end.last_dc), end.pad))
+                    assert outs[0] == outs[1], (seed, r0, r1, nb, outs[0][2:], outs[1][2:])
+                    seen += 1
+                    tiny += r1 < 12 and outs[0][4] >= 5
+    assert seen > 600 and tiny > 20
 
 
 QUIRKS = ["trailing_zrl", "rst_fill", "mixed_pad", "dup_symbol", "rst_order", "scan_tail"]
