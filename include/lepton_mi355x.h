@@ -189,7 +189,8 @@ typedef struct lep_huffprog_scan {
 int lep_gpu_huffman_progressive_encode_device(lep_gpu *g, const lep_huffprog_image *images, int nimg, const lep_huffprog_scan *scans,
                                               int nscan, uint8_t *d_out, uint32_t *d_corr, uint32_t *d_out_len, void *hip_stream);
 /* JPEG Huffman scan decode on the GPU (replaces decode_jpeg / decode_block_seq, src/lepton/jpgcoder.cc:2799-3302,
- * 4893-4966, for whole single-scan interleaved sequential files): one wavefront per image decodes the un-stuffed scan into
+ * 4893-4966, for single-scan sequential files -- an interleaved scan of all components, or a one-component file, which is planned as
+ * mcuh x mcuv = its nch x ncv blocks with hs = vs = 1 and block rows bch apart): one wavefront per image decodes the un-stuffed scan into
  * the zero-filled device frame images[i].blocks and writes images[i].mcuv + 1 records (bit position + last DC per MCU row,
  * final record: pad-bit pattern and status) at d_rows + images[i].rows_off.  lep_jpeg_open_gpu fills the struct. */
 #define LEP_HUFFDEC_EARLY_EOF 1          /* lep_huffdec_image.flags */
@@ -293,7 +294,9 @@ int lep_jpeg_open_slice(const uint8_t *jpg, size_t len, size_t start_byte, lep_j
  * into a larger blob; the .lep ('PGE' section + ordinary garbage) restores the whole blob */
 int lep_jpeg_open_embedded(const uint8_t *blob, size_t len, size_t offset, lep_jpeg **out);
 int lep_compress_embedded(lep_gpu *g, const uint8_t *blob, size_t len, size_t offset, lep_bytes *out);
-/* progressive files: after lep_jpeg_open_gpu answered *eligible = 0.  Fills up to `cap` scan descriptors (t.scan = byte offset of
+/* progressive files, and sequential frames coded in several scans (their scans: from 0 / to 63, t = the frame with all four tables,
+ * a record per MCU row of the scan's own geometry; lep_gpu_huffman_progressive_decode_device hands them to the sequential scan decoders):
+ * after lep_jpeg_open_gpu answered *eligible = 0.  Fills up to `cap` scan descriptors (t.scan = byte offset of
  * the scan inside lep_jpeg_scan_bytes, t.rows_off / result_off relative to the file's first record -- the caller adds its arena
  * offsets and sets t.blocks); *rows_needed = records the file needs in the row arena.  _finish turns the kernels' records into
  * the hand-offs and bookkeeping of the .lep header (non-zero: irregular, use the host parser). */
@@ -361,7 +364,9 @@ int lep_file_recode_plan(lep_file *f, lep_huff_image *image, lep_huff_segment *s
 int lep_file_recode_finish(lep_file *f, const lep_bytes *seg_bytes, const lep_huff_end *ends, int nseg, lep_bytes *out);
 /* progressive files: _plan fills the image and up to `cap` scan descriptors (out_cap / corr_cap = what each scan may need;
  * image index, out_off, corr_off and blocks[] are the caller's to set); *gpu_ok = 0: the file keeps the host re-coder
- * (truncated, sequential multi-scan, withheld restart markers ...).  _finish glues header pieces, scans and trailer. */
+ * (truncated, withheld restart markers ...).  SEQUENTIAL frames coded in several scans are planned here too: their scans have
+ * from 0 / to 63 (no progressive scan has), code[0] / code[1] = the one DC / AC table all their components use, and
+ * lep_gpu_huffman_progressive_encode_device hands them to the sequential scan encoders.  _finish glues header pieces, scans and trailer. */
 /* Compression with verification, baseline files: the plan that writes the parsed file's scan again on the GPU from its coefficient frame
  * (lep_gpu_huffman_encode_device; images[].blocks and the segments' out_off are the caller's to set) and, per thread segment, the
  * bytes of the file it must reproduce -- the Huffman half of the reference's round-trip check (src/lepton/validation.cc:97-218),
