@@ -206,6 +206,25 @@ WDEV int simt_setup(const HuffDecImage* img, SimtShared* sh) {
     return nphase;
 }
 
+// An image whose blocks ALL use the same DC and the same AC table (Cb + Cr coded together in a scan of their own; files written with one
+// pair of tables for every component): the lanes fall into step with the block boundaries like any others, but WHICH block of the MCU a
+// lane stands on is not in the bits -- a block decodes the same whatever component it is taken for -- so a guessed position inside the
+// MCU never corrects itself, and the true one would travel one lane per settle pass.  For such an image (2 .. 4 blocks per MCU) the
+// passes do without it: a lane counts its blocks from SLOT 0 of an MCU it does not know and sums the DC differences per slot
+// (SimtSub::dcsum by slot, not by component); pass P learns every lane's true slot from the prefix sum of the block counts and only then
+// turns slot sums into component sums; pass C starts from that slot.  Returns the blocks per MCU of such an image, else 0.
+WDEV int simt_blind_phases(const HuffDecImage* img) {
+    int nphase = 0;
+    bool same = true;
+    const int c0 = img->scan_cmp[0];
+    for (int ci = 0; ci < img->ncomp; ++ci) {
+        const int cmp = img->scan_cmp[ci];
+        nphase += img->hs[cmp] * img->vs[cmp];
+        same = same && img->dc_tbl[cmp] == img->dc_tbl[c0] && img->ac_tbl[cmp] == img->ac_tbl[c0];
+    }
+    return (same && nphase >= 2 && nphase <= 4 && !(img->flags & kHuffDecRstTable)) ? nphase : 0;
+}
+
 // passes A (settle = 0) and S (settle = 1..): `in` is read (S), `out` written
 WDEV void simt_guess_or_settle(const HuffDecImage* img, SimtShared* sh, SimtImage* si, const SimtSub* in, SimtSub* out, uint32_t first_sub, int settle) {
     if (img->flags & kHuffDecRstTable) return;             // restart intervals: every piece's start is known (simt_write_intervals)
@@ -214,6 +233,7 @@ WDEV void simt_guess_or_settle(const HuffDecImage* img, SimtShared* sh, SimtImag
         return;
     }
     const int nphase = simt_setup(img, sh);
+    const bool blind = simt_blind_phases(img) != 0;
     const uint32_t scan_bits = img->scan_len * 8u, L = si->sub_bits, nsub = si->nsub;
     LV(int, moved);
     LANES(l) {
@@ -228,7 +248,7 @@ WDEV void simt_guess_or_settle(const HuffDecImage* img, SimtShared* sh, SimtImag
                 uint32_t bp = i * L;
                 int phase = 0;
                 bool ok = true;
-                if (settle > 0) { bp = in[i - 1].end_bitpos; phase = (int)in[i - 1].end_phase; ok = bp <= scan_bits && phase < nphase; }
+                if (settle > 0) { bp = in[i - 1].end_bitpos; phase = blind ? 0 : (int)in[i - 1].end_phase; ok = bp <= scan_bits && phase < nphase; }
                 const uint32_t stop = (i + 1) * L < scan_bits ? (i + 1) * L : scan_bits;
                 if (ok) {
                     SimtLane d;
@@ -239,8 +259,9 @@ WDEV void simt_guess_or_settle(const HuffDecImage* img, SimtShared* sh, SimtImag
                     uint32_t count = 0;
                     while (d.br.bitpos < stop) {
                         int diff = 0;
-                        const int cmp = sh->ph_cmp[phase];
-                        d.skip_block(img->dc_tbl[cmp], 2 + img->ac_tbl[cmp], &diff);
+                        const int at = sh->ph_cmp[phase];
+                        d.skip_block(img->dc_tbl[at], 2 + img->ac_tbl[at], &diff);
+                        const int cmp = blind ? phase : at;            // (blind: the sums go by slot, counted from the lane's first block)
                         if (cmp == 0) sum[0] = (int16_t)(sum[0] + diff); else if (cmp == 1) sum[1] = (int16_t)(sum[1] + diff);
                         else if (cmp == 2) sum[2] = (int16_t)(sum[2] + diff); else sum[3] = (int16_t)(sum[3] + diff);
                         ++count;
@@ -269,6 +290,14 @@ WDEV void simt_place(const HuffDecImage* img, SimtImage* si, const SimtSub* sub,
     int bad = si->changed[passes] ? 3 : 0;                 // the last settle pass still moved an end state: not synchronised
     uint32_t run = 0;
     int dc[4] = {0, 0, 0, 0};
+    // (blind images, simt_blind_phases: component of every slot of the MCU)
+    const int blind = simt_blind_phases(img);
+    int slot_cmp[4] = {0, 0, 0, 0};
+    if (blind) {
+        int p = 0;
+        for (int ci = 0; ci < img->ncomp; ++ci)
+            for (int k = img->hs[img->scan_cmp[ci]] * img->vs[img->scan_cmp[ci]]; k > 0; --k) { if (p < 4) slot_cmp[p] = img->scan_cmp[ci] & 3; ++p; }
+    }
     for (uint32_t base = 0; base < nsub; base += 64) {
         LV(int, nb); LV(int, ex);
         LV(int, d0); LV(int, d1); LV(int, d2); LV(int, d3);
@@ -280,6 +309,19 @@ WDEV void simt_place(const HuffDecImage* img, SimtImage* si, const SimtSub* sub,
             L(d0) = in ? sub[i].dcsum[0] : 0; L(d1) = in ? sub[i].dcsum[1] : 0; L(d2) = in ? sub[i].dcsum[2] : 0; L(d3) = in ? sub[i].dcsum[3] : 0;
         }
         const int tn = lepwave::wave_excl_scan(nb, ex);
+        if (blind) {                                       // slot sums -> component sums, now that the lane's first slot is known
+            LANES(l) {
+                const uint32_t first = (run + (uint32_t)L(ex)) % (uint32_t)blind;
+                int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                for (int r = 0; r < blind; ++r) {
+                    const int v = r == 0 ? L(d0) : (r == 1 ? L(d1) : (r == 2 ? L(d2) : L(d3)));
+                    const uint32_t slot = (first + (uint32_t)r) % (uint32_t)blind;
+                    const int cmp = slot == 0 ? slot_cmp[0] : (slot == 1 ? slot_cmp[1] : (slot == 2 ? slot_cmp[2] : slot_cmp[3]));
+                    if (cmp == 0) c0 += v; else if (cmp == 1) c1 += v; else if (cmp == 2) c2 += v; else c3 += v;
+                }
+                L(d0) = (int16_t)c0; L(d1) = (int16_t)c1; L(d2) = (int16_t)c2; L(d3) = (int16_t)c3;
+            }
+        }
         const int t0 = lepwave::wave_excl_scan(d0, e0), t1 = lepwave::wave_excl_scan(d1, e1), t2 = lepwave::wave_excl_scan(d2, e2), t3 = lepwave::wave_excl_scan(d3, e3);
         LANES(l) {
             const uint32_t i = base + (uint32_t)l;
@@ -412,6 +454,7 @@ WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, Si
     if (si->status) return;                                // pass P refused the image: the fallback decodes it
     if (img->flags & kHuffDecRstTable) { simt_write_intervals(img, sh, tile, si, rows_arena, first_sub); return; }
     const int nphase = simt_setup(img, sh);
+    const bool blind = simt_blind_phases(img) != 0;
     const uint32_t scan_bits = img->scan_len * 8u, nsub = si->nsub, total = (uint32_t)img->mcuc * (uint32_t)nphase;
     // A file that ends inside its scan (no EOI; kHuffDecEarlyEof): the reference decodes block after block until the read that takes
     // the data's last bit (bits behind it read as zeros: the buffer's padding), keeps the block that read it and stops
@@ -432,7 +475,7 @@ WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, Si
             int lastdc[4] = {place[i].dc[0], place[i].dc[1], place[i].dc[2], place[i].dc[3]};
             uint32_t bp = 0;
             int phase = 0;
-            if (i > 0) { bp = sub[i - 1].end_bitpos; phase = (int)sub[i - 1].end_phase; }
+            if (i > 0) { bp = sub[i - 1].end_bitpos; phase = blind ? (int)(before % (uint32_t)nphase) : (int)sub[i - 1].end_phase; }
             int bad = 0;
             uint32_t mine = 0;
             bool stopped = false;                          // this lane met the end of a cut file's data
@@ -488,7 +531,7 @@ WDEV void simt_write(const HuffDecImage* img, SimtShared* sh, SimtTile* tile, Si
                         break;
                     }
                 }
-                if (!bad && !stopped && !last && (d.br.bitpos != sub[i].end_bitpos || (uint32_t)phase != sub[i].end_phase)) bad = 3;   // must stand where the next region starts
+                if (!bad && !stopped && !last && (d.br.bitpos != sub[i].end_bitpos || (!blind && (uint32_t)phase != sub[i].end_phase))) bad = 3;   // must stand where the next region starts
                 if (!bad && !stopped && last) {
                     if (phase != 0 || mcu != img->mcuc) bad = 3;
                     else {

@@ -57,22 +57,9 @@ inline HuffDecImage sequential_scan_image(const ProgDecScan& s) {
     return im;
 }
 
-// Whether the lane-per-subsequence decoder (lep_huffdec_simt.h) is the one to send such a scan to.  Its lanes fall into step with the BLOCK
-// boundaries by decoding, and with the position inside the MCU only because a block decoded with another component's tables soon stops
-// making sense: when every block of the MCU uses the same two tables (Cb + Cr together, as most encoders write them) nothing in the bits
-// says which is which, the true position travels one lane per settle pass, and the scan would end up with the single-wave kernel after
-// three wasted passes.  Restart intervals come without the table of marker positions here.
-inline bool sequential_scan_for_lanes(const HuffDecImage& im) {
-    if (im.rsti) return false;
-    int nphase = 0;
-    bool same = true;
-    for (int ci = 0; ci < im.ncomp && ci < 4; ++ci) {
-        const int c = im.scan_cmp[ci] & 3, c0 = im.scan_cmp[0] & 3;
-        nphase += im.hs[c] * im.vs[c];
-        same = same && im.dc_tbl[c] == im.dc_tbl[c0] && im.ac_tbl[c] == im.ac_tbl[c0];
-    }
-    return nphase == 1 || !same;
-}
+// Whether the lane-per-subsequence decoder (lep_huffdec_simt.h) is the one to send such a scan to: restart intervals come without the
+// table of marker positions here, and those go to the single-wave kernel.
+inline bool sequential_scan_for_lanes(const HuffDecImage& im) { return im.rsti == 0; }
 
 // Pipelining between the scans of one image (one launch for all dependency levels).  A 4K file of libjpeg's default script is
 // ten scans in three levels, and the longest scan of every level is a luma scan (bytes: 276 k first stage, 348 k and 654 k

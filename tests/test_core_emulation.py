@@ -477,6 +477,48 @@ def test_gpu_huffman_decoder_survives_garbage_scans(emu, seed):
     L.lep_jpeg_close(h)
 
 
+@pytest.mark.parametrize("layout", ["444_one_pair", "two_one_pair", "y21_c_one_pair", "420_one_pair", "444_chroma_pair"])
+def test_lane_per_subsequence_decoder_on_images_whose_blocks_share_their_tables(emu, layout):
+    """When every block of the MCU is coded with the same DC and the same AC table, nothing in the bits tells a lane WHICH block of the MCU
+    it stands on (lep_huffdec_simt.h simt_blind_phases): until round 6 such an image never settled -- the true position travels one lane per
+    pass -- and went to the single-wave kernel after three wasted passes.  With 2 .. 4 blocks per MCU the lanes now sum DC differences per
+    SLOT and pass P turns them into component sums once the prefix sum of block counts says where each lane stands: frame, records and
+    status as the single-wave kernel leaves them, with subsequences far shorter than the product's so that every lane starts in mid-MCU."""
+    import jpeg_writer as jw
+    import numpy as np
+    from lepton_amd import abi
+
+    comps = {"444_one_pair": [(1, 1, 1, 0, 0, 0), (2, 1, 1, 0, 0, 0), (3, 1, 1, 0, 0, 0)],
+             "two_one_pair": [(1, 1, 1, 0, 1, 1), (2, 1, 1, 0, 1, 1)],
+             "y21_c_one_pair": [(1, 2, 1, 0, 0, 0), (2, 1, 1, 0, 0, 0)],
+             "420_one_pair": [(1, 2, 2, 0, 0, 0), (2, 1, 1, 0, 0, 0), (3, 1, 1, 0, 0, 0)],          # six blocks per MCU: not taken, must still answer (or hand over)
+             "444_chroma_pair": [(1, 1, 1, 0, 0, 0), (2, 1, 1, 1, 1, 1), (3, 1, 1, 1, 1, 1)]}[layout]  # (the ordinary case: the tables tell the slots apart)
+    settled = 0
+    for w, h, dens, sub_bits in [(640, 480, 0.5, 4096), (333, 250, 0.1, 1024), (97, 50, 0.3, 512), (1300, 40, 0.1, 2048), (640, 480, 0.5, 32768)]:
+        jpg, _ = jw.write_baseline(w, h, comps, np.random.default_rng(w * 7 + h), density=dens)
+        one = _huffdec_setup(jpg)
+        assert one is not None
+        img, scan, planes, d = one
+        rows1 = (abi.HuffDecRow * (img.mcuv + 1))()
+        assert emu.emu_huffman_decode_image(C.byref(img), rows1) == 0 and rows1[img.mcuv].aux >> 8 == 0
+        want = [p.raw for p in planes]
+        for p in planes:
+            C.memset(p, 0, len(p))
+        rows2 = (abi.HuffDecRow * (img.mcuv + 1))()
+        moved, nsub = (C.c_int32 * 8)(), C.c_uint32(0)
+        assert emu.emu_huffman_decode_image_simt(C.byref(img), rows2, sub_bits, moved, C.byref(nsub)) == 0
+        status = (rows2[img.mcuv].aux >> 8) & 0x3fffff
+        if layout in ("420_one_pair", "444_chroma_pair") and status:
+            continue                                                   # (the fallback's: a second chance with the single-wave kernel; subsequences this short need not settle)
+        assert status == 0, (layout, w, h, sub_bits, status, list(moved)[:4], nsub.value)
+        settled += 1
+        assert [p.raw for p in planes] == want, (layout, w, h, sub_bits)
+        assert [(r.bitpos, tuple(r.last_dc), r.aux) for r in rows2] == [(r.bitpos, tuple(r.last_dc), r.aux) for r in rows1], (layout, w, h, sub_bits)
+        if nsub.value > 4 and layout.endswith("one_pair") and layout != "420_one_pair":   # (nothing travels lane by lane any more)
+            assert not moved[2], (layout, w, h, "still moving in the second settle pass", list(moved)[:4])
+    assert settled >= (5 if layout.endswith("one_pair") and layout != "420_one_pair" else 0)
+
+
 def _huffdec_setup(jpg):
     """lep_jpeg_open_gpu + a zero padded copy of the scan + zeroed planes for the Huffman decode kernels' emulation"""
     from lepton_amd import abi

@@ -101,3 +101,28 @@ def test_gpu_sequential_frames_in_several_scans_take_the_scan_kernels_both_ways(
         assert ds["gpu_huffman_files"] >= sum(shared), (ds, sum(shared), len(jpgs))
     finally:
         codec.close()
+
+
+def test_gpu_files_whose_blocks_share_their_tables():
+    """every block of the MCU coded with the same DC and the same AC table (lep_huffdec_simt.h simt_blind_phases): the lanes of the scan
+    decoder cannot tell from the bits which block of the MCU they stand on; 2 .. 4 blocks per MCU are settled through per-slot DC sums,
+    six (4:2:0) still end with the single-wave kernel -- the same .lep as the per-file path either way, and the file back"""
+    import jpeg_writer as jw
+
+    layouts = {"444_one_pair": [(1, 1, 1, 0, 0, 0), (2, 1, 1, 0, 0, 0), (3, 1, 1, 0, 0, 0)], "two_one_pair": [(1, 1, 1, 0, 1, 1), (2, 1, 1, 0, 1, 1)],
+               "y21_c_one_pair": [(1, 2, 1, 0, 0, 0), (2, 1, 1, 0, 0, 0)], "420_one_pair": [(1, 2, 2, 0, 0, 0), (2, 1, 1, 0, 0, 0), (3, 1, 1, 0, 0, 0)]}
+    jpgs = []
+    for name, comps in sorted(layouts.items()):
+        for w, h, dens in [(1920, 1080, 0.5), (640, 480, 0.2), (97, 50, 0.3), (3000, 2000, 0.05)]:
+            jpgs.append(jw.write_baseline(w, h, comps, np.random.default_rng(zlib.crc32(("%s %d" % (name, w)).encode())), density=dens)[0])
+    codec = GpuCodec(0)
+    try:
+        want = [codec.compress(j) for j in jpgs]
+        got, st, cs = codec.compress_batch(jpgs, chunk_images=8)
+        assert st == [0] * len(jpgs) and got == want
+        assert cs["gpu_huffman_files"] == len(jpgs), cs
+        back, st2, ds = codec.decompress_batch(got, chunk_images=8)
+        assert st2 == [0] * len(jpgs) and back == jpgs
+        assert ds["gpu_huffman_files"] == len(jpgs), ds
+    finally:
+        codec.close()
