@@ -283,9 +283,17 @@ struct BoolDec4 {
 struct BoolDec4S {
     uint32_t vhi, vlo;
     int count;
-    uint32_t range;
+    uint32_t range;         // the range in the TOP byte (range << 24): split << 24 is what the window's high word is compared with, so the
+                            // product is taken where it is needed -- ((range - 1) << 24) x (prob << 24) >> 32 = (range - 1) * prob << 16, whose top byte
+                            // is ((range - 1) * prob) >> 8 -- and the normalisation shift is the count of leading zeros as it comes (round 6:
+                            // two scalar instructions fewer per bin than range / split / split << 24 / clz - 24)
+#ifdef LEP_DEC4_RANGE_LOW   // (the form until round 6, kept for the A/B: profiles/r6z2_decoder_scalar_bin_ab.txt)
     WDEV void load(const BoolDec4& b) { vhi = uni(b.vhi); vlo = uni(b.vlo); count = (int)uni((uint32_t)b.count); range = uni(b.range); }
     WDEV void store(BoolDec4& b) const { b.vhi = vec(vhi); b.vlo = vec(vlo); b.count = (int)vec((uint32_t)count); b.range = vec(range); }
+#else
+    WDEV void load(const BoolDec4& b) { vhi = uni(b.vhi); vlo = uni(b.vlo); count = (int)uni((uint32_t)b.count); range = uni(b.range) << 24; }
+    WDEV void store(BoolDec4& b) const { b.vhi = vec(vhi); b.vlo = vec(vlo); b.count = (int)vec((uint32_t)count); b.range = vec(range >> 24); }
+#endif
     WDEV void refill(BoolDec4& b) {
         const uint32_t lo = b.wi * 4;
         uint32_t w = __builtin_bswap32(uni(b.raw));
@@ -298,18 +306,28 @@ struct BoolDec4S {
         ++b.wi;
         b.raw = b.fetch(b.wi);
     }
-    WDEV uint32_t get(BoolDec4& b, uint32_t prob) {
-        const uint32_t split = 1 + (((range - 1) * prob) >> 8);
+    // prob in the low byte of `pk` (the bytes above it are the caller's next probabilities and fall off the shift)
+    WDEV uint32_t get(BoolDec4& b, uint32_t pk) {
         if (count < 0) refill(b);
+#ifdef LEP_DEC4_RANGE_LOW
+        const uint32_t split = 1 + (((range - 1) * (pk & 255u)) >> 8);
         const uint32_t big = split << 24;
         uint32_t was = vhi;
         const uint32_t bit = was >= big ? 1u : 0u;
         vhi = bit ? was - big : was;
         range = bit ? range - split : split;
-#ifdef LEP_TRACE_GET
-        LEP_TRACE_GET(prob, (int)bit);
-#endif
         const int shift = __builtin_clz(range) - 24;
+#else
+        const uint32_t big = ((uint32_t)(((uint64_t)(range - 0x01000000u) * (uint64_t)(pk << 24)) >> 32) & 0xff000000u) + 0x01000000u;   // split << 24
+        uint32_t was = vhi;
+        const uint32_t bit = was >= big ? 1u : 0u;
+        vhi = bit ? was - big : was;
+        range = bit ? range - big : big;
+        const int shift = __builtin_clz(range);
+#endif
+#ifdef LEP_TRACE_GET
+        LEP_TRACE_GET(pk & 255u, (int)bit);
+#endif
         range <<= shift;
         const uint64_t v = pair64(vhi, vlo) << shift;
         vhi = (uint32_t)(v >> 32); vlo = (uint32_t)v;
