@@ -487,7 +487,7 @@ struct lep_gpu {
     void* d_huffseq[2] = {nullptr, nullptr}; size_t huffseq_bytes[2] = {0, 0};             // scans of sequential frames in a progressive launch: which / caps / byte counts / end states
     void* d_huffprogsimt[2] = {nullptr, nullptr}; size_t huffprogsimt_bytes[2] = {0, 0};   // lep_huffprog_simt.h: descriptors, unit arrays, bit buffers (one per arena set)
     int huffenc_simt = 1;               // LEP_HUFFENC_SIMT=0: every segment's scan bytes from the wavefront-per-segment kernel (lep_huff.h)
-    void* d_huffenc = nullptr; size_t huffenc_bytes = 0;   // lep_huff_simt.h: segment / wave descriptors, unit bit counts, bit buffers
+    void* d_huffenc[2] = {nullptr, nullptr}; size_t huffenc_bytes[2] = {0, 0};   // lep_huff_simt.h: segment / wave descriptors, unit bit counts, bit buffers (one per arena set, like d_huff)
     int simt_sub_bits = 0;              // LEP_HUFFDEC_SIMT_BITS: bits per subsequence of the lane-per-subsequence scan decoder (0 = from the launch's size)
     int huffprog_pipeline_max = 16384;  // LEP_HUFFPROG_PIPELINE_MAX: scans per launch up to which the levels go out as one pipelined launch (measured to 10240:
                                         // 1024 4K files, 798 -> 938 MB/s; a workgroup takes the scan of the ticket it draws when it starts, so a scan's predecessors are always running or done)
@@ -557,7 +557,11 @@ struct lep_gpu {
     void* d_blocks = nullptr; size_t blocks_bytes = 0;
     void* d_streams = nullptr; size_t streams_bytes = 0;
     void* d_lens = nullptr; size_t lens_bytes = 0;
-    void* d_huff = nullptr; size_t huff_bytes = 0;      // HuffImage[] | HuffSegment[]
+    // HuffImage[] | HuffSegment[], one per arena set: the batch compressor's round-trip check writes the scans of chunk k and of chunk k + 1 on two
+    // streams (lep_gpu_use_arena picks the set), and a short chunk k + 1 reaches its scan encoder before a long chunk k does -- with one buffer its
+    // descriptors replaced the ones chunk k's kernels were still to read (a memory fault in tests/test_gpu_parity.py::*overlapped_launches, once,
+    // round 6: the scans of sequential frames in several scans come through here a second time per chunk)
+    void* d_huff[2] = {nullptr, nullptr}; size_t huff_bytes[2] = {0, 0};
     void* d_huffprog[2] = {nullptr, nullptr}; size_t huffprog_bytes[2] = {0, 0};   // ProgImage[] | ProgScan[], one per arena set (two launches on two streams)
     struct Staging { void* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
     Staging staging[16];                // pinned ring for descriptor uploads (upload()): nothing on a launch path waits for its stream
@@ -1069,8 +1073,8 @@ static void release_device_side(lep_gpu* g) {
     if (g->ev_join3) (void)hipEventDestroy(g->ev_join3);
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     if (g->stream3) (void)hipStreamDestroy(g->stream3);
-    for (void** p : {&g->arena[0].d_models, &g->arena[0].d_ns, &g->arena[0].d_meta, &g->arena[1].d_models, &g->arena[1].d_ns, &g->arena[1].d_meta, &g->d_blocks, &g->d_streams, &g->d_lens, &g->d_huff,
-                     &g->d_huffprog[0], &g->d_huffprog[1], &g->d_huffprogsimt[0], &g->d_huffprogsimt[1], &g->d_huffseq[0], &g->d_huffseq[1], &g->d_huffprogdec, &g->d_huffdec, &g->d_huffpar, &g->d_huffenc, &g->d_scan, &g->d_scanlen})
+    for (void** p : {&g->arena[0].d_models, &g->arena[0].d_ns, &g->arena[0].d_meta, &g->arena[1].d_models, &g->arena[1].d_ns, &g->arena[1].d_meta, &g->d_blocks, &g->d_streams, &g->d_lens, &g->d_huff[0], &g->d_huff[1],
+                     &g->d_huffprog[0], &g->d_huffprog[1], &g->d_huffprogsimt[0], &g->d_huffprogsimt[1], &g->d_huffseq[0], &g->d_huffseq[1], &g->d_huffprogdec, &g->d_huffdec, &g->d_huffpar, &g->d_huffenc[0], &g->d_huffenc[1], &g->d_scan, &g->d_scanlen})
         dev_release(g, p, nullptr);
     vmm_destroy(g);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
@@ -1118,7 +1122,8 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g->stream;
     HIPCHK(g, hipSetDevice(g->device));
     const size_t o_seg = (nimg * sizeof(lep_huff_image) + 255) & ~(size_t)255, total = o_seg + nseg * sizeof(lep_huff_segment);
-    if (int rc = ensure(g, &g->d_huff, &g->huff_bytes, total)) return rc;
+    const int set = g->cur & 1;                            // (the arena set the caller chose: two launches on two streams never share descriptors or scratch)
+    if (int rc = ensure(g, &g->d_huff[set], &g->huff_bytes[set], total)) return rc;
     // which segments the lane-per-unit kernels take (lep_huff_simt.h); the wavefront-per-segment kernel keeps the others
     static_assert(sizeof(lep_huff_image) == sizeof(lephuff::HuffImage) && sizeof(lep_huff_segment) == sizeof(lephuff::HuffSegment), "C ABI mirrors");
     std::vector<lep_huff_segment> sv(segs, segs + nseg);
@@ -1153,17 +1158,17 @@ int lep_gpu_huffman_encode_device(lep_gpu* g, const lep_huff_image* images, int 
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_es = 0, o_wv = up(es.size() * sizeof(lephuff::SimtEncSeg)), o_ub = o_wv + up(waves.size() * sizeof(lephuff::SimtEncWave)),
                  o_sc = o_ub + up(nunits * 8), simt_total = o_sc + up(scratch_bytes);   // (units: bit counts / positions, and the plain prefix sum of scans with restart intervals)
-    if (!es.empty()) { if (int rc = ensure(g, &g->d_huffenc, &g->huffenc_bytes, simt_total)) return rc; }
-    if (int rc = upload(g, g->d_huff, images, nimg * sizeof(lep_huff_image), st)) return rc;           // (the caller's arrays and ours may go away)
-    if (int rc = upload(g, (char*)g->d_huff + o_seg, sv.data(), nseg * sizeof(lep_huff_segment), st)) return rc;
-    char* eb = (char*)g->d_huffenc;
+    if (!es.empty()) { if (int rc = ensure(g, &g->d_huffenc[set], &g->huffenc_bytes[set], simt_total)) return rc; }
+    if (int rc = upload(g, g->d_huff[set], images, nimg * sizeof(lep_huff_image), st)) return rc;           // (the caller's arrays and ours may go away)
+    if (int rc = upload(g, (char*)g->d_huff[set] + o_seg, sv.data(), nseg * sizeof(lep_huff_segment), st)) return rc;
+    char* eb = (char*)g->d_huffenc[set];
     if (!es.empty()) {
         if (int rc = upload(g, eb + o_es, es.data(), es.size() * sizeof(lephuff::SimtEncSeg), st)) return rc;
         if (int rc = upload(g, eb + o_wv, waves.data(), waves.size() * sizeof(lephuff::SimtEncWave), st)) return rc;
         hipLaunchKernelGGL(lep_zero_kernel, dim3(8192), dim3(256), 0, st, (uint4*)(eb + o_sc), scratch_bytes / 16);   // (buf_bytes are multiples of 16)
     }
-    const lephuff::HuffImage* di = (const lephuff::HuffImage*)g->d_huff;
-    const lephuff::HuffSegment* ds = (const lephuff::HuffSegment*)((char*)g->d_huff + o_seg);
+    const lephuff::HuffImage* di = (const lephuff::HuffImage*)g->d_huff[set];
+    const lephuff::HuffSegment* ds = (const lephuff::HuffSegment*)((char*)g->d_huff[set] + o_seg);
     HIPCHK(g, hipEventRecord(g->ev0, st));
     if (!es.empty()) {
         lephuff::SimtEncSeg* des = (lephuff::SimtEncSeg*)(eb + o_es);
@@ -1586,10 +1591,10 @@ int lep_gpu_selftest(lep_gpu* g) {
 // unit positions, plain prefix sums, bit buffers + marker maps; the layout is that function's), copied to `out`; returns the bytes copied.
 // scripts/diag_scan_encode_isolate.py compares two builds of the library pass by pass with it.
 size_t lep_gpu_debug_huffenc(lep_gpu* g, void* out, size_t cap) {
-    if (!g || !g->d_huffenc) return 0;
+    if (!g || !g->d_huffenc[g->cur & 1]) return 0;
     if (hipSetDevice(g->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return 0;
-    const size_t n = std::min(cap, g->huffenc_bytes);
-    return hipMemcpy(out, g->d_huffenc, n, hipMemcpyDeviceToHost) == hipSuccess ? n : 0;
+    const size_t n = std::min(cap, g->huffenc_bytes[g->cur & 1]);
+    return hipMemcpy(out, g->d_huffenc[g->cur & 1], n, hipMemcpyDeviceToHost) == hipSuccess ? n : 0;
 }
 
 // profiling builds (-DLEP_PROF) only: per-phase shader-clock totals folded over the segments of the last decoder launch

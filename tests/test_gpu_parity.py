@@ -286,6 +286,26 @@ def test_gpu_batch_pipeline_with_overlapped_launches(gpu_codec, monkeypatch):
         assert status == [0] * len(jpgs) and got == leps
 
 
+def test_gpu_overlapped_chunks_of_unequal_length_with_verification(gpu_codec, monkeypatch):
+    """LEP_BATCH_OVERLAP=1 + verify with chunks of very unequal lengths: a short chunk reaches its scan encoder (the Huffman half of the
+    round-trip check) on the second stream BEFORE the long chunk in front of it does on the first.  Until the end of round 6 the scan
+    encoder's descriptors and scratch were one buffer for both streams: the short chunk's replaced the ones the long chunk's kernels were
+    still to read -- a memory fault (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION), seen once in the closing visit and then every time under
+    scripts/stress_overlap_verify.py.  They are per workspace set now (lep_gpu.hip d_huff / d_huffenc)."""
+    monkeypatch.setenv("LEP_BATCH_OVERLAP", "1")
+    names = golden_cases()
+    big = [corpus.synth_jpeg(3840, 2160, 900 + i) for i in range(2)]
+    want_big = [gpu_codec.compress(j) for j in big]
+    jpgs, leps = [], []
+    for _ in range(2):
+        jpgs += big; leps += want_big
+        jpgs += [golden(n)[0] for n in names]; leps += [golden(n)[1] for n in names]
+    for chunk_bytes in (300000, 40000, 2500000):
+        got, status, _ = gpu_codec.compress_batch(jpgs, chunk_bytes=chunk_bytes, verify=True)
+        assert status == [0] * len(jpgs), (chunk_bytes, [s for s in status if s][:8])
+        assert got == leps, chunk_bytes
+
+
 def test_gpu_batch_pipeline_verifies_on_the_gpu(gpu_codec):
     """verify=1: every file is decoded again on the GPU and compared with its input frame before its .lep is released"""
     jpgs = [corpus.synth_jpeg(640, 480, 51), corpus.synth_jpeg(320, 200, 52, quality=75), golden("c420_odd_203x149")[0]]
