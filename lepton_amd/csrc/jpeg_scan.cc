@@ -865,8 +865,13 @@ static int prepare_gpu_sequential_scans(JpegFile* jf, std::vector<ProgScanDecode
 // scan of one component only if it is component 0 (`cmp == 0 && mcu % mcuh == 0 && dpos % (hmul * vmul) == 0`, mcu = dpos / (hmul *
 // vmul) with LUMA's factors) -- and the record behind the last scan, whose MCU row is the one the last scan's walk left `mcu` at.
 static int finish_gpu_sequential_scans(JpegFile* jf, const std::vector<ProgScanDecodePlan>& scans, const ScanDecodeRow* rows) {
+    if (jf->mcuv < 1 || jf->mcuh < 1 || scans.size() > jf->scan_start.size()) return -1;
     const int luma_mul = jf->comp[0].bcv / jf->mcuv, hmul = jf->comp[0].bch / jf->mcuh;
     if (luma_mul < 1 || hmul < 1) return -1;
+    for (const ProgScanDecodePlan& sc : scans) {           // (descriptors come back through the public entry: hold them to what prepare made)
+        if (sc.cmpc < 1 || sc.cmpc > jf->ncomp) return -1;
+        for (int i = 0; i < sc.cmpc; ++i) if (sc.cmp[i] < 0 || sc.cmp[i] >= jf->ncomp) return -1;
+    }
     int padbit = -1;
     jf->max_bpos = 0; jf->max_sah = 0; jf->max_cmp = 0;
     for (const ProgScanDecodePlan& sc : scans) {
