@@ -10,7 +10,7 @@ from conftest import golden, golden_cases, ref_cases, ref_golden
 from lepton_amd import corpus
 from lepton_amd.codec import GpuCodec
 pairs = [golden(n) for n in golden_cases()]
-pairs += [ref_golden(n) for n in ref_cases()]
+pairs += [ref_golden(n) for n in ref_cases() if n != "roundtripfail"]   # (the image the reference itself cannot restore: ROUNDTRIP_FAILURE under verify, by design)
 c = GpuCodec(0)
 big = [corpus.synth_jpeg(3840, 2160, 950 + i) for i in range(2)] + [corpus.synth_jpeg(1920, 1080, 960, progressive=True), corpus.synth_jpeg(2048, 1536, 961, subsampling="4:4:4")]
 pairs += [(j, c.compress(j)) for j in big]
