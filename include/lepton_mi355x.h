@@ -179,6 +179,8 @@ typedef struct lep_huffprog_scan {
     int32_t from, to, sah, sal;          /* spectral band, successive approximation high / low */
     int32_t max_eobrun;
     int32_t tbl[4];                      /* DC scans: table slot (0 / 1) of each scan component */
+    int32_t rsti;                        /* this scan's restart interval (a DRI segment may stand in front of any scan: phone cameras write one per scan);
+                                          * -1 = the image's (lep_huffprog_image.rsti).  Sits where the struct had four bytes of padding. */
     uint64_t out_off;
     uint32_t out_cap;
     uint32_t corr_off, corr_cap;         /* dwords */

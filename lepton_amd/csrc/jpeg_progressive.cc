@@ -562,10 +562,10 @@ int progressive_plan(JpegFile* jfp, size_t jpeg_size, bool rst_cnt_set, ProgPlan
         }
         if (type != 0xDA) break;
         plan->scan_hdr_end.push_back(hpos);
-        if (rsti_seen >= 0 && rsti_seen != jf.rsti) return 0;   // a restart interval that changes between scans: host
         rsti_seen = jf.rsti;
         ProgScan sc;
         memset(&sc, 0, sizeof sc);
+        sc.rsti = jf.rsti;                                     // (a DRI in front of any scan: phone cameras set one per scan -- the reference's androidprogressive.jpg, iphoneprogressive2.jpg)
         sc.cmpc = jf.cs_cmpc; sc.from = jf.cs_from; sc.to = jf.cs_to; sc.sah = jf.cs_sah; sc.sal = jf.cs_sal;
         if (sequential) { sc.from = 0; sc.to = 63; sc.sah = 0; sc.sal = 0; }   // (a sequential scan codes whole blocks whatever its SOS says: encode_block_seq)
         if (sc.cmpc < 1 || sc.cmpc > jf.ncomp || sc.sal < 0 || sc.sal > 13 || sc.from < 0 || sc.to > 63 || sc.from > sc.to) return 0;

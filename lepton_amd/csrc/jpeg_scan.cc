@@ -957,8 +957,7 @@ int parse_jpeg_prepare_gpu_progressive(JpegFile* jf, std::vector<ProgScanDecodeP
         if (type != 0xDA) continue;
         const size_t k = scans->size();
         if (k >= jf->scan_start.size() || k >= 256) return 0;
-        if (rsti_seen >= 0 && rsti_seen != jf->rsti) return 0;
-        rsti_seen = jf->rsti;
+        rsti_seen = jf->rsti;                                  // (it may change from scan to scan: every descriptor carries its own, t.rsti)
         ProgScanDecodePlan sc;
         memset(&sc, 0, sizeof sc);
         sc.cmpc = jf->cs_cmpc; sc.from = jf->cs_from; sc.to = jf->cs_to; sc.sah = jf->cs_sah; sc.sal = jf->cs_sal;

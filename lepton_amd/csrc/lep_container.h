@@ -101,6 +101,7 @@ struct ProgScan {
     int32_t from, to, sah, sal;
     int32_t max_eobrun;
     int32_t tbl[4];
+    int32_t rsti;                         // this scan's restart interval (-1: the image's)
     uint64_t out_off;
     uint32_t out_cap;
     uint32_t corr_off;

@@ -35,6 +35,7 @@ struct ProgScan {
     int32_t from, to, sah, sal; // spectral band, successive approximation
     int32_t max_eobrun;         // longest end-of-band run the scan's AC table can code
     int32_t tbl[4];             // per scan component: which of code[0..1] it uses (DC scans); AC scans use code[0]
+    int32_t rsti;               // this scan's restart interval (DRI may change from scan to scan); < 0: the image's
     uint64_t out_off;           // into the output arena
     uint32_t out_cap;
     uint32_t corr_off;          // this scan's scratch area for held-back correction bits (dwords into the scratch arena)
@@ -50,12 +51,19 @@ struct ProgScan {
 // (lep_huff_simt.h, lep_huff.h) as an image of their own with one segment: the scan's components only, and for a scan of one component
 // (never interleaved: MCU = one block, the frame's padding blocks stepped over) that component's nch x ncv blocks as MCUs, as
 // recode_prepare plans a one-component file.
+#if LEP_ON_GPU
+__host__ __device__ __forceinline__
+#else
+inline
+#endif
+int prog_scan_rsti(const ProgImage& im, const ProgScan& sc) { return sc.rsti >= 0 ? sc.rsti : im.rsti; }   // (DRI may stand in front of any scan)
+
 constexpr uint32_t kProgScanSeq = 2;        // ProgScan::pad on the device: the sequential scan encoders own the scan
 inline bool prog_is_sequential(const ProgScan& s) { return s.from == 0 && s.to == 63; }
 inline void sequential_scan_segment(const ProgImage& im, const ProgScan& sc, int32_t image_index, HuffImage* hi, HuffSegment* hs) {
     memset(hi, 0, sizeof *hi);
     memset(hs, 0, sizeof *hs);
-    hi->ncomp = sc.cmpc; hi->mcuh = im.mcuh; hi->mcuv = im.mcuv; hi->mcuc = im.mcuc; hi->rsti = im.rsti; hi->padbit = im.padbit;
+    hi->ncomp = sc.cmpc; hi->mcuh = im.mcuh; hi->mcuv = im.mcuv; hi->mcuc = im.mcuc; hi->rsti = prog_scan_rsti(im, sc); hi->padbit = im.padbit;
     hi->rst_limit = 0xffffffffu;
     hi->interleaved = 1;
     for (int c = 0; c < 4; ++c) { hi->hs[c] = im.hs[c]; hi->vs[c] = im.vs[c]; hi->bch[c] = im.bch[c]; hi->blocks[c] = im.blocks[c]; }
@@ -414,7 +422,7 @@ struct ProgWave : HuffWave {
         }
         LSYNC();
         const uint32_t units = total_units(), P = blocks_per_unit();
-        const uint32_t rsti = (uint32_t)pim->rsti;
+        const uint32_t rsti = (uint32_t)prog_scan_rsti(*pim, *scan);
         const bool dc = scan->to == 0;
         uint32_t unit = 0, cum_rst = 0;
         while (unit < units) {

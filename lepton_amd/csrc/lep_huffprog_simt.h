@@ -466,7 +466,7 @@ WDEV void prog_simt_stuff(const ProgImage* images, const ProgScan* scans, const 
 
 // which scans this form takes, and how many units it cuts one into
 inline bool prog_simt_takes(const ProgImage& im, const ProgScan& sc, uint32_t* nblocks, uint32_t* nunits) {
-    if (im.rsti != 0 || prog_is_sequential(sc)) return false;
+    if (prog_scan_rsti(im, sc) != 0 || prog_is_sequential(sc)) return false;
     const bool dc = sc.to == 0;
     if (sc.cmpc < 1 || sc.cmpc > 4 || (!dc && (sc.cmpc != 1 || sc.max_eobrun < 1))) return false;
     uint64_t n, per;

@@ -268,11 +268,12 @@ def _put_block(bw, blk, pred, dc, ac):
     return int(blk[0])
 
 
-def write_sequential_scans(width, height, comps, rng, scans, restart_interval=0, quality=85, density=0.25, amp=40.0):
+def write_sequential_scans(width, height, comps, rng, scans, restart_interval=0, quality=85, density=0.25, amp=40.0, restart_intervals=None):
     """A sequential (SOF0) frame coded in SEVERAL scans, e.g. scans=[[0], [1, 2]]: luma alone, then the chroma components
     interleaved -- what `jpegtran -scans` writes for non-progressive multi-scan files.  A one-component scan is
     non-interleaved (T.81 A.2.2: only the blocks covering the image are coded, MCU = one block, the restart interval counts
-    blocks); the frame geometry is the interleaved one.  Returns (jpeg bytes, per-component block arrays)."""
+    blocks); the frame geometry is the interleaved one.  restart_intervals: one interval per scan, each with a DRI segment of its own in
+    front of its SOS (0 = none for that scan) -- what phone cameras do in progressive files.  Returns (jpeg bytes, per-component block arrays)."""
     dqt, dht = annex_k_tables(quality)
     hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
     mcux, mcuy = -(-width // (8 * hmax)), -(-height // (8 * vmax))
@@ -287,9 +288,12 @@ def write_sequential_scans(width, height, comps, rng, scans, restart_interval=0,
     for key in sorted({(0, c[4]) for c in comps} | {(1, c[5]) for c in comps}):
         bits, vals = dht[key]
         out += b"\xff\xc4" + struct.pack(">H", 19 + len(vals)) + bytes([(key[0] << 4) | key[1]]) + bytes(bits) + bytes(vals)
-    if restart_interval:
+    if restart_interval and restart_intervals is None:
         out += b"\xff\xdd" + struct.pack(">HH", 4, restart_interval)
-    for scan in scans:
+    for si, scan in enumerate(scans):
+        if restart_intervals is not None:
+            restart_interval = restart_intervals[si]
+            out += b"\xff\xdd" + struct.pack(">HH", 4, restart_interval)
         out += b"\xff\xda" + struct.pack(">HB", 6 + 2 * len(scan), len(scan))
         for ci in scan:
             out += bytes([comps[ci][0], (comps[ci][4] << 4) | comps[ci][5]])

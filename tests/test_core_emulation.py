@@ -1134,6 +1134,42 @@ def test_sequential_frames_in_several_scans_on_the_scan_kernels(emu, name):
                 assert length == len(want) and got == want
 
 
+def test_restart_interval_that_changes_from_scan_to_scan(emu):
+    """A DRI segment may stand in front of ANY scan: the progressive files of phone cameras (the reference's images/androidprogressive.jpg,
+    iphoneprogressive2.jpg) set one per scan -- 258 / 516, 768 / 1524 MCUs or blocks, a row of the scan's own units.  Until the end of round 6
+    both scan plans sent such files to the host; every descriptor carries its own interval now (lep_huffprogdec_scan.t.rsti,
+    lep_huffprog_scan.rsti).  The two reference images and sequential frames in several scans with an interval per scan (0 among them), both
+    directions, every form of the kernels."""
+    import jpeg_writer as jw
+    import numpy as np
+    import zlib
+    from conftest import ref_golden, REF_GOLDEN
+    from lepton_amd import abi
+
+    L = abi.lib()
+    files = []
+    if os.path.exists(os.path.join(REF_GOLDEN, "androidprogressive.jpg")):
+        files += [("ref:" + n,) + ref_golden(n) for n in ("androidprogressive", "iphoneprogressive2")]
+    for name, intervals in [("y_cbcr_420", [12, 5]), ("y_cb_cr_444", [0, 7, 3]), ("cbcr_y_420", [4, 0]), ("two_y_c", [1, 40])]:
+        comps, scans = SEQUENTIAL_SCAN_SCRIPTS[name]
+        for w, h in [(97, 50), (333, 250)]:
+            jpg, _ = jw.write_sequential_scans(w, h, comps, np.random.default_rng(zlib.crc32(("dri %s %d" % (name, w)).encode())), scans, restart_intervals=intervals, density=0.3)
+            host = JpegImage(jpg)
+            files.append(("%s %dx%d %s" % (name, w, h, intervals), jpg, host.write_lep(ob.oracle_encode(host.desc, host.plan())[0])))
+    assert len(files) >= 8
+    for name, jpg, lep in files:
+        for kw in (dict(), dict(pipelined=True), dict(win=True, pipelined=True)):
+            hnd, planes, status = _progressive_decode_on_the_emulation(emu, jpg, **kw)
+            assert status == 0, (name, kw, status)
+            _same_as_the_host_parser(jpg, hnd, planes)
+            L.lep_jpeg_close(hnd)
+        for simt in (False, True):
+            got, f = _progressive_scans_on_the_emulation(emu, jpg, lep, simt=simt)
+            assert got is not None and got == jpg, (name, simt)
+        res = _progressive_check_on_the_emulation(emu, jpg)
+        assert res is not None and all(length == len(want) and got == want for length, got, want in res), name
+
+
 def test_progressive_scans_follow_the_right_scans(emu):
     """lep_huffprogdec.h prog_scan_deps: in the one pipelined launch a scan waits for exactly the scans of its file whose
     coefficients it reads or overwrites -- same component, bands that meet, earlier in the file -- minus those another of them

@@ -126,3 +126,36 @@ def test_gpu_files_whose_blocks_share_their_tables():
         assert ds["gpu_huffman_files"] == len(jpgs), ds
     finally:
         codec.close()
+
+
+def test_gpu_restart_interval_that_changes_from_scan_to_scan():
+    """a DRI segment in front of every scan: the progressive files of phone cameras (the reference's androidprogressive.jpg and
+    iphoneprogressive2.jpg: 258 / 516 and 768 / 1524) and sequential frames in several scans with an interval per scan -- host-only until
+    the end of round 6, when every scan descriptor got its own interval.  Same .lep as the reference wrote for its two images, files back,
+    scan kernels in both directions, with and without the round-trip check."""
+    import jpeg_writer as jw
+    from test_core_emulation import SEQUENTIAL_SCAN_SCRIPTS
+
+    jpgs, known = [], {}
+    for n in ("androidprogressive", "iphoneprogressive2"):
+        j, l = ref_golden(n)
+        known[len(jpgs)] = l
+        jpgs.append(j)
+    for name, intervals in [("y_cbcr_420", [12, 5]), ("y_cb_cr_444", [0, 7, 3]), ("cbcr_y_420", [4, 0]), ("two_y_c", [1, 40])]:
+        comps, scans = SEQUENTIAL_SCAN_SCRIPTS[name]
+        for w, h in [(97, 50), (333, 250), (1920, 1080)]:
+            jpgs.append(jw.write_sequential_scans(w, h, comps, np.random.default_rng(zlib.crc32(("dri %s %d" % (name, w)).encode())), scans, restart_intervals=intervals, density=0.3)[0])
+    codec = GpuCodec(0)
+    try:
+        want = [codec.compress(j) for j in jpgs]
+        for i, l in known.items():
+            assert want[i] == l, i
+        for verify in (False, True):
+            got, st, cs = codec.compress_batch(jpgs, chunk_images=8, verify=verify)
+            assert st == [0] * len(jpgs) and got == want, verify
+            assert cs["gpu_huffman_files"] == len(jpgs), cs
+        back, st2, ds = codec.decompress_batch(want, chunk_images=8)
+        assert st2 == [0] * len(jpgs) and back == jpgs
+        assert ds["gpu_huffman_files"] == len(jpgs), ds
+    finally:
+        codec.close()
