@@ -186,7 +186,9 @@ typedef struct lep_huffprog_scan {
     uint32_t corr_off, corr_cap;         /* dwords */
     uint32_t file_bound;                 /* bytes ALL scans of this scan's image produce together at most (they are parts of one file: its
                                           * size); 0 = unknown, the sum of their out_cap.  Sizes the bit buffers of the lane-per-unit kernels. */
-    uint32_t code[2][256];               /* DC scans: DC tables 0 / 1; AC scans: [0] = the component's AC table; length << 16 | code */
+    uint32_t code[4][256];               /* length << 16 | code.  DC scans: [0..1] = DC tables 0 / 1; AC scans: [0] = the component's AC table; scans of
+                                          * sequential frames (from 0 / to 63): [0..1] = DC tables 0 / 1, [2..3] = AC tables 0 / 1, tbl[i] = DC table | AC table << 8
+                                          * of scan component i */
 } lep_huffprog_scan;
 int lep_gpu_huffman_progressive_encode_device(lep_gpu *g, const lep_huffprog_image *images, int nimg, const lep_huffprog_scan *scans,
                                               int nscan, uint8_t *d_out, uint32_t *d_corr, uint32_t *d_out_len, void *hip_stream);
@@ -367,7 +369,7 @@ int lep_file_recode_finish(lep_file *f, const lep_bytes *seg_bytes, const lep_hu
 /* progressive files: _plan fills the image and up to `cap` scan descriptors (out_cap / corr_cap = what each scan may need;
  * image index, out_off, corr_off and blocks[] are the caller's to set); *gpu_ok = 0: the file keeps the host re-coder
  * (truncated, withheld restart markers ...).  SEQUENTIAL frames coded in several scans are planned here too: their scans have
- * from 0 / to 63 (no progressive scan has), code[0] / code[1] = the one DC / AC table all their components use, and
+ * from 0 / to 63 (no progressive scan has), all four tables in code[] and the components' choice of them in tbl[], and
  * lep_gpu_huffman_progressive_encode_device hands them to the sequential scan encoders.  _finish glues header pieces, scans and trailer. */
 /* Compression with verification, baseline files: the plan that writes the parsed file's scan again on the GPU from its coefficient frame
  * (lep_gpu_huffman_encode_device; images[].blocks and the segments' out_off are the caller's to set) and, per thread segment, the

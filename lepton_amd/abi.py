@@ -75,7 +75,7 @@ class HuffProgImage(C.Structure):
 class HuffProgScan(C.Structure):
     _fields_ = [("image", C.c_int32), ("cmpc", C.c_int32), ("cmp", C.c_int32 * 4), ("from_", C.c_int32), ("to", C.c_int32), ("sah", C.c_int32),
                 ("sal", C.c_int32), ("max_eobrun", C.c_int32), ("tbl", C.c_int32 * 4), ("rsti", C.c_int32), ("out_off", C.c_uint64), ("out_cap", C.c_uint32),
-                ("corr_off", C.c_uint32), ("corr_cap", C.c_uint32), ("file_bound", C.c_uint32), ("code", (C.c_uint32 * 256) * 2)]
+                ("corr_off", C.c_uint32), ("corr_cap", C.c_uint32), ("file_bound", C.c_uint32), ("code", (C.c_uint32 * 256) * 4)]
 
 
 class HuffDecImage(C.Structure):

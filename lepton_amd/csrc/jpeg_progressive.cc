@@ -583,17 +583,18 @@ int progressive_plan(JpegFile* jfp, size_t jpeg_size, bool rst_cnt_set, ProgPlan
         if (sc.cmpc == 1) { const Component& k = jf.comp[sc.cmp[0]]; blocks = units = (size_t)k.nch * k.ncv; }
         else { units = (size_t)jf.mcuc; for (int i = 0; i < sc.cmpc; ++i) blocks += (size_t)jf.comp[sc.cmp[i]].mbs * jf.mcuc; }
         if (sequential) {
-            // one DC and one AC table for all components of the scan (code[0], code[1]); scans of several components have the frame's MCUs
-            const Component& k0 = jf.comp[sc.cmp[0]];
-            if (k0.dc_tbl < 0 || k0.dc_tbl > 1 || k0.ac_tbl < 0 || k0.ac_tbl > 1 || !jf.htab[0][k0.dc_tbl].set || !jf.htab[1][k0.ac_tbl].set) return 0;
+            // code[0..1] = DC tables 0 / 1, code[2..3] = AC tables 0 / 1 as they stand at this scan; scans of several components have the frame's MCUs
             for (int i = 0; i < sc.cmpc; ++i) {
                 const Component& k = jf.comp[sc.cmp[i]];
-                if (k.dc_tbl != k0.dc_tbl || k.ac_tbl != k0.ac_tbl || k.bch != jf.mcuh * k.hs || k.bcv != jf.mcuv * k.vs || k.nch > k.bch || k.ncv > k.bcv) return 0;
+                if (k.dc_tbl < 0 || k.dc_tbl > 1 || k.ac_tbl < 0 || k.ac_tbl > 1 || !jf.htab[0][k.dc_tbl].set || !jf.htab[1][k.ac_tbl].set) return 0;
+                if (k.bch != jf.mcuh * k.hs || k.bcv != jf.mcuv * k.vs || k.nch > k.bch || k.ncv > k.bcv) return 0;
+                sc.tbl[i] = k.dc_tbl | (k.ac_tbl << 8);
             }
-            for (int i = 0; i < 256; ++i) {
-                sc.code[0][i] = ((uint32_t)jf.htab[0][k0.dc_tbl].clen[i] << 16) | jf.htab[0][k0.dc_tbl].cval[i];
-                sc.code[1][i] = ((uint32_t)jf.htab[1][k0.ac_tbl].clen[i] << 16) | jf.htab[1][k0.ac_tbl].cval[i];
-            }
+            for (int t = 0; t < 2; ++t)
+                for (int i = 0; i < 256; ++i) {
+                    sc.code[t][i] = jf.htab[0][t].set ? ((uint32_t)jf.htab[0][t].clen[i] << 16) | jf.htab[0][t].cval[i] : 0u;
+                    sc.code[2 + t][i] = jf.htab[1][t].set ? ((uint32_t)jf.htab[1][t].clen[i] << 16) | jf.htab[1][t].cval[i] : 0u;
+                }
         } else if (dc) {
             for (int i = 0; i < sc.cmpc; ++i) {
                 const int t = jf.comp[sc.cmp[i]].dc_tbl;

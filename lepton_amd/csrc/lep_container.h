@@ -107,7 +107,7 @@ struct ProgScan {
     uint32_t corr_off;
     uint32_t corr_cap;
     uint32_t file_bound;                  // bytes all scans of the file produce together at most (0 = unknown)
-    uint32_t code[2][256];
+    uint32_t code[4][256];                // (scans of sequential frames use all four: DC tables 0 / 1, AC tables 0 / 1)
 };
 struct ProgPlan {
     bool gpu_ok = false;

@@ -42,12 +42,12 @@ struct ProgScan {
     uint32_t corr_cap;          // dwords
     uint32_t pad;               // caller: bytes all scans of the image produce together at most (lep_huffprog_scan.file_bound); on the device:
                                 // which kernel owns the scan (lep_huffprog_simt.h kProgScanSimt)
-    uint32_t code[2][256];      // length << 16 | code
+    uint32_t code[4][256];      // length << 16 | code; [2..3]: scans of sequential frames only (their AC tables 0 / 1)
 };
 
 // SEQUENTIAL frames coded in several scans (the reference's recode_jpeg codes them with encode_block_seq under the general scan walk,
 // jpgcoder.cc:3461-3486, 3560-3580; format flag 'X' like progressive files): a scan with from 0 / to 63 -- which no progressive scan has --
-// whose components all use ONE DC table (code[0]) and ONE AC table (code[1]).  They are written by the sequential scan encoders
+// with code[0..1] = DC tables 0 / 1, code[2..3] = AC tables 0 / 1 and tbl[i] = DC table | AC table << 8 of scan component i.  They are written by the sequential scan encoders
 // (lep_huff_simt.h, lep_huff.h) as an image of their own with one segment: the scan's components only, and for a scan of one component
 // (never interleaved: MCU = one block, the frame's padding blocks stepped over) that component's nch x ncv blocks as MCUs, as
 // recode_prepare plans a one-component file.
@@ -73,8 +73,8 @@ inline void sequential_scan_segment(const ProgImage& im, const ProgScan& sc, int
         hi->mcuh = im.nch[c]; hi->mcuv = im.ncv[c]; hi->mcuc = im.nch[c] * im.ncv[c];
         hi->hs[c] = 1; hi->vs[c] = 1;
     }
-    memcpy(hi->code[0], sc.code[0], sizeof hi->code[0]);
-    memcpy(hi->code[2], sc.code[1], sizeof hi->code[2]);
+    memcpy(hi->code, sc.code, sizeof hi->code);
+    for (int i = 0; i < sc.cmpc && i < 4; ++i) { const int c = sc.cmp[i] & 3; hi->dc_tbl[c] = sc.tbl[i] & 1; hi->ac_tbl[c] = (sc.tbl[i] >> 8) & 1; }
     hs->image = image_index; hs->mcu_row0 = 0; hs->mcu_row1 = hi->mcuv;
     hs->out_off = sc.out_off; hs->out_cap = sc.out_cap;
 }

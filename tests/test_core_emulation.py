@@ -1109,7 +1109,6 @@ def test_sequential_frames_in_several_scans_on_the_scan_kernels(emu, name):
 
     L = abi.lib()
     comps, scans = SEQUENTIAL_SCAN_SCRIPTS[name]
-    shared_tables = all(len({comps[c][4] for c in sc}) == 1 and len({comps[c][5] for c in sc}) == 1 for sc in scans)
     for w, h, ri, dens in [(97, 50, 0, 0.3), (96, 64, 5, 0.3), (640, 480, 0, 0.6), (333, 250, 7, 0.2), (8, 8, 0, 0.5), (17, 9, 1, 0.5), (1300, 40, 0, 0.02)]:
         jpg, _ = jw.write_sequential_scans(w, h, comps, np.random.default_rng(zlib.crc32(("%s %d %d" % (name, w, h)).encode())), scans, restart_interval=ri, density=dens)
         host = JpegImage(jpg)
@@ -1122,16 +1121,12 @@ def test_sequential_frames_in_several_scans_on_the_scan_kernels(emu, name):
             L.lep_jpeg_close(hnd)
         for simt in (False, True):
             got, f = _progressive_scans_on_the_emulation(emu, jpg, lep, simt=simt)
-            if not shared_tables:
-                assert got is None, "a scan whose components use different tables is the host re-coder's"
-                continue
-            assert got is not None, (name, w, h, ri, "not planned for the GPU scan encoders")
+            assert got is not None, (name, w, h, ri, "not planned for the GPU scan encoders")    # (a scan whose components use different tables too: "ycb_cr_422")
             assert got == jpg, (name, w, h, ri, simt)
-        if shared_tables:
-            res = _progressive_check_on_the_emulation(emu, jpg)
-            assert res is not None
-            for length, got, want in res:
-                assert length == len(want) and got == want
+        res = _progressive_check_on_the_emulation(emu, jpg)
+        assert res is not None
+        for length, got, want in res:
+            assert length == len(want) and got == want
 
 
 def test_restart_interval_that_changes_from_scan_to_scan(emu):
